@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- tree log-likelihoods+gradients/sec on BASELINE.json's headline config.
+
+Workload (config 3): DS1.fasta (27 taxa, 934 site patterns), the 100 topologies of
+DS1.100_topologies.nwk replicated R times per GPU with per-tree seeded branch lengths,
+GTR + weibull+4 (4 rate categories), FP64, log-likelihood + branch-length gradient.
+A "step" is one pass of the hot path over the resident batch: per-tree model set-up +
+eigendecomposition, transition matrices, post-order partials, pre-order partials + edge
+derivatives, per-tree reductions.  Inputs (parent-id vectors, branch lengths, parameter
+rows, compressed alignment) are resident in HBM before the timed region.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); every rank owns
+R x 100 trees (weak scaling); each step ends with an all-gather of the per-tree results
+and an all-reduce of the summed log-likelihood, the only exchange the path has.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_tree(n: int, P: int, C: int, gradient: bool) -> float:
+    """B_plv = C*P*S*8; LL: (3(n-1)+1) B_plv; LL+grad: (13n-12) B_plv."""
+    b_plv = C * P * 4 * 8
+    return ((13 * n - 12) if gradient else (3 * (n - 1) + 1)) * b_plv
+
+
+def cpu_baseline(w, seconds: float):
+    """The CPU oracle driven like the reference Engine (one instance per thread, dynamic
+    queue over trees) on a bounded sample of the same workload."""
+    from oracle import oracle
+
+    threads = os.cpu_count() or 1
+    eng = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, threads)
+    probe = min(w.tree_count, max(2 * threads, 8))
+    run = eng.gradients if w.want_gradient else eng.log_likelihoods
+    run(w.parent_ids[:probe], w.branch_lengths[:probe], w.params[:probe], rescaling=w.rescaling)  # warm-up
+    t0 = time.perf_counter()
+    run(w.parent_ids[:probe], w.branch_lengths[:probe], w.params[:probe], rescaling=w.rescaling)
+    rate = probe / (time.perf_counter() - t0)
+    count = int(min(w.tree_count, max(probe, rate * seconds)))
+    t0 = time.perf_counter()
+    run(w.parent_ids[:count], w.branch_lengths[:count], w.params[:count], rescaling=w.rescaling)
+    dt = time.perf_counter() - t0
+    return {"value": count / dt, "unit": "trees/s", "cores": threads, "kind": "port",
+            "sample": f"{count} trees of the same workload, {dt:.1f} s, oracle/bito_oracle.c with {threads} threads "
+                      "(FP64 restatement of the BEAGLE CPU path; the reference binary cannot be built here)"}
+
+
+def measured_traffic(kernel: str, trees_per_launch: int):
+    """HBM bytes per launch of the traversal kernel from the committed rocprofv3 PMC pass
+    (profiles/*_traffic.json), if one matches this launch shape."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            for row in json.load(fh):
+                if row["kernel"] == kernel and row["trees_per_launch"] == trees_per_launch:
+                    return row["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--replicas", type=int, default=16, help="x100 DS1 topologies per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 HBM arena, 2 LDS")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+
+    import torch
+
+    import bito_amd
+    from bito_amd import workloads
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # every rank builds the same replicated workload and takes its own block of trees
+    full = workloads.ds1_gtr_weibull4(args.replicas * world)
+    w = full.shard(rank, world)
+    T = w.tree_count
+    n, P = w.patterns.shape
+    C = 4
+    N = 2 * n - 1
+
+    eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights,
+                          device_id=local_rank)
+    eng.set_kernel(args.kernel)
+    eng.upload(w.parent_ids, w.branch_lengths, w.params)
+
+    ll_dev = torch.empty(T, dtype=torch.float64, device="cuda")
+    grad_dev = torch.empty(T, N, dtype=torch.float64, device="cuda")
+    if world > 1:
+        ll_all = torch.empty(world * T, dtype=torch.float64, device="cuda")
+        grad_all = torch.empty(world * T, N, dtype=torch.float64, device="cuda")
+        ll_sum = torch.zeros(1, dtype=torch.float64, device="cuda")
+
+    def step():
+        eng.run(w.want_gradient, w.rescaling)
+        if world > 1:
+            eng.download_to(ll_dev.data_ptr(), grad_dev.data_ptr())  # device -> device, then RCCL
+            dist.all_gather_into_tensor(ll_all, ll_dev)
+            dist.all_gather_into_tensor(grad_all, grad_dev)
+            ll_sum.copy_(ll_dev.sum().reshape(1))
+            dist.all_reduce(ll_sum)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = eng.kernel_elapsed()
+    eng.kernel_timing(False)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # sanity: results of the timed batch are finite
+    ll_host, grad_host = eng.download(True)
+    if not (np.all(np.isfinite(ll_host)) and np.all(np.isfinite(grad_host))):
+        raise SystemExit("non-finite results in the timed batch")
+
+    if rank == 0:
+        total_trees = world * T
+        value = total_trees * args.steps / elapsed
+        trees_per_launch = T * args.steps / max(launches, 1)
+        avg_kernel_s = kernel_ms * 1e-3 / max(launches, 1)
+        alg_bytes = algorithmic_bytes_per_tree(n, P, C, w.want_gradient) * trees_per_launch
+        achieved = alg_bytes / avg_kernel_s / 1e9
+        kernel = eng.kernel_name()
+        out = {
+            "metric": "tree log-likelihoods+gradients/sec (DS1 GTR+Gamma4)",
+            "value": value,
+            "unit": "trees/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config 3: DS1.fasta (27 taxa, 934 patterns) x 100 topologies x "
+                            f"{args.replicas} replicas per GPU, GTR+weibull4 (4 categories), seeded Exp(0.1) branch "
+                            "lengths, log-likelihood + branch-length gradient",
+                "trees_per_gpu": T,
+                "trees_total": total_trees,
+                "kernel": kernel,
+                "multi_gpu": "trees sharded by rank; all-gather of per-tree results + all-reduce of the summed "
+                             "log-likelihood per step" if world > 1 else "single GPU, no collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(kernel, int(trees_per_launch)),
+                "kernel": kernel,
+                "avg_kernel_ms": avg_kernel_s * 1e3,
+                "trees_per_launch": trees_per_launch,
+                "algorithmic_bytes_per_tree": algorithmic_bytes_per_tree(n, P, C, w.want_gradient),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(full.subset(min(full.tree_count, 4000)), args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

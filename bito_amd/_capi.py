@@ -1,0 +1,83 @@
+"""ctypes binding of the C ABI in include/bito_amd.h (libbito_amd.so).
+
+There is no CPU fallback: if the HIP library is missing, or no MI355X is
+visible when an engine is created, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbito_amd.so")
+
+OK = 0
+ERR_BAD_MODEL, ERR_BAD_PARAMS, ERR_BAD_TREE, ERR_BAD_ARG, ERR_DEVICE, ERR_STATE = -1, -2, -3, -4, -5, -6
+
+GRAD_SUBSTITUTION_MODEL = 1
+GRAD_SITE_MODEL = 2
+GRAD_CLOCK_MODEL = 4
+GRAD_STICKBREAKING = 8
+
+KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS = 0, 1, 2
+
+# Every symbol include/bito_amd.h declares (tests check that the library exports them all).
+SYMBOLS = [
+    "bito_amd_engine_create", "bito_amd_engine_destroy", "bito_amd_engine_last_error",
+    "bito_amd_engine_param_count", "bito_amd_engine_category_count", "bito_amd_engine_block_count",
+    "bito_amd_engine_block", "bito_amd_engine_log_likelihoods", "bito_amd_engine_gradients",
+    "bito_amd_engine_upload", "bito_amd_engine_update", "bito_amd_engine_run", "bito_amd_engine_sync",
+    "bito_amd_engine_download", "bito_amd_engine_set_kernel", "bito_amd_engine_time_runs",
+    "bito_amd_engine_kernel_timing", "bito_amd_engine_kernel_elapsed", "bito_amd_engine_kernel_name",
+    "bito_amd_version",
+]
+
+
+class EngineSpec(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("use_tip_states", C.c_int32), ("arena_bytes", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C bito_amd/csrc). bito_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    L.bito_amd_version.restype = C.c_char_p
+    L.bito_amd_engine_create.restype = C.c_int
+    L.bito_amd_engine_create.argtypes = [C.POINTER(EngineSpec), C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32,
+                                         C.c_int32, ip, dp, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.bito_amd_engine_destroy.restype = None
+    L.bito_amd_engine_destroy.argtypes = [vp]
+    L.bito_amd_engine_last_error.restype = C.c_char_p
+    L.bito_amd_engine_last_error.argtypes = [vp]
+    for name in ("param_count", "category_count", "block_count"):
+        fn = getattr(L, f"bito_amd_engine_{name}")
+        fn.restype = C.c_int32
+        fn.argtypes = [vp]
+    L.bito_amd_engine_block.argtypes = [vp, C.c_int32, C.c_char_p, C.c_size_t, ip, ip]
+    L.bito_amd_engine_log_likelihoods.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, ip, dp, dp, dp, C.c_int32, dp]
+    L.bito_amd_engine_gradients.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, ip, dp, dp, dp, C.c_int32,
+                                            C.c_int32, C.c_double, dp, dp, dp, dp, dp]
+    L.bito_amd_engine_upload.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, ip, dp, dp, dp]
+    L.bito_amd_engine_update.argtypes = [vp, dp, dp]
+    L.bito_amd_engine_run.argtypes = [vp, C.c_int32, C.c_int32]
+    L.bito_amd_engine_sync.argtypes = [vp]
+    # destinations may be host or device addresses: pass raw integers
+    L.bito_amd_engine_download.argtypes = [vp, vp, vp]
+    L.bito_amd_engine_set_kernel.argtypes = [vp, C.c_int32]
+    L.bito_amd_engine_time_runs.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, ip]
+    L.bito_amd_engine_kernel_timing.argtypes = [vp, C.c_int32]
+    L.bito_amd_engine_kernel_elapsed.argtypes = [vp, dp, ip]
+    L.bito_amd_engine_kernel_name.restype = C.c_char_p
+    L.bito_amd_engine_kernel_name.argtypes = [vp]
+    _lib = L
+    return L

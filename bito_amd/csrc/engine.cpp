@@ -1,0 +1,590 @@
+// engine.cpp -- host side of the C ABI declared in include/bito_amd.h.
+//
+// The engine owns one GPU, the compressed alignment in HBM, and one resident
+// batch of trees.  It mirrors what Engine + FatBeagleParallelize do in the
+// reference (src/engine.cpp:10-110, src/fat_beagle.hpp:151-184) but hands the
+// whole tree collection to the device at once instead of farming trees to
+// threads: the per-tree work (model set-up, transition matrices, traversal) is
+// done by kernels, the host only validates inputs and moves buffers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bito_amd.h"
+#include "kernels.hpp"
+#include "model.hpp"
+
+using namespace bito_amd;
+
+namespace {
+
+struct Block {
+  std::string name;
+  int32_t start, len;
+};
+
+template <typename T>
+struct DeviceBuffer {
+  T* ptr = nullptr;
+  size_t capacity = 0;  // elements
+  hipError_t Reserve(size_t count) {
+    if (count <= capacity) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    capacity = 0;
+    hipError_t rc = hipMalloc(reinterpret_cast<void**>(&ptr), count * sizeof(T));
+    if (rc == hipSuccess) capacity = count;
+    return rc;
+  }
+  void Free() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    capacity = 0;
+  }
+};
+
+}  // namespace
+
+struct bito_amd_engine {
+  ModelSpec spec{};
+  std::vector<Block> blocks;
+  int device = 0;
+  int n = 0, P = 0, Ppad = 0;
+  uint64_t arena_limit = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int kernel_choice = BITO_AMD_KERNEL_AUTO;
+  std::string kernel_name = "none";
+
+  // alignment
+  DeviceBuffer<uint8_t> tip_states;
+  DeviceBuffer<double> weights;
+  // resident batch
+  bool resident = false;
+  BatchDims dims{};
+  bool has_rates = false;
+  DeviceBuffer<int32_t> parent_ids, children;
+  DeviceBuffer<double> branch_in, rates, params, branch, mats, arena, part_ll, part_grad, out_ll,
+      out_grad;
+  DeviceBuffer<TreeModel> model;
+  // host mirrors for the composed gradients
+  std::vector<double> h_params;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+
+  ~bito_amd_engine() {
+    (void)hipSetDevice(device);
+    for (auto ev : ev_pool) (void)hipEventDestroy(ev);
+    tip_states.Free(); weights.Free(); parent_ids.Free(); children.Free(); branch_in.Free();
+    rates.Free(); params.Free(); branch.Free(); mats.Free(); arena.Free(); part_ll.Free();
+    part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free();
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+int Fail(bito_amd_engine* e, int code, const std::string& msg) {
+  if (e) e->err = msg;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                              \
+  do {                                                                                \
+    hipError_t rc_ = (call);                                                          \
+    if (rc_ != hipSuccess)                                                            \
+      return Fail(e, BITO_AMD_ERR_DEVICE,                                             \
+                  std::string(#call) + " failed: " + hipGetErrorString(rc_));         \
+  } while (0)
+
+// PhyloModel::OfSpecification + BlockSpecification layout
+// (reference src/phylo_model.cpp:6-24, src/block_specification.cpp:14-53).
+int ParseSpec(const char* sub, const char* site, const char* clock, ModelSpec* m,
+              std::vector<Block>* blocks, std::string* err) {
+  std::memset(m, 0, sizeof(*m));
+  const std::string s(sub ? sub : ""), si(site ? site : ""), cl(clock ? clock : "");
+  if (s == "JC69") m->substitution = kJC69;
+  else if (s == "HKY") m->substitution = kHKY;
+  else if (s == "GTR") m->substitution = kGTR;
+  else { *err = "Substitution model not known: " + s; return BITO_AMD_ERR_BAD_MODEL; }
+  if (si == "constant") {
+    m->weibull = 0;
+    m->category_count = 1;
+  } else if (si.rfind("weibull", 0) == 0) {
+    m->weibull = 1;
+    m->category_count = 4;
+    const auto plus = si.find('+');
+    if (plus != std::string::npos) m->category_count = std::atoi(si.c_str() + plus + 1);
+    if (m->category_count < 1 || m->category_count > 8) {
+      *err = "Site model '" + si + "': the GPU engine supports 1..8 rate categories.";
+      return BITO_AMD_ERR_BAD_MODEL;
+    }
+  } else { *err = "Site model not known: " + si; return BITO_AMD_ERR_BAD_MODEL; }
+  if (cl == "none") m->strict_clock = 0;
+  else if (cl == "strict") m->strict_clock = 1;
+  else { *err = "Clock model not known: " + cl; return BITO_AMD_ERR_BAD_MODEL; }
+  int at = 0;
+  m->freq_start = m->rates_start = m->shape_start = m->clock_start = -1;
+  blocks->clear();
+  if (m->substitution != kJC69) {
+    m->freq_start = at;
+    at += 4;
+    m->rates_start = at;
+    m->rates_len = (m->substitution == kGTR) ? 6 : 1;
+    at += m->rates_len;
+    blocks->push_back({"substitution_model_frequencies", m->freq_start, 4});
+    blocks->push_back({"substitution_model_rates", m->rates_start, m->rates_len});
+    blocks->push_back({"entire_substitution", m->freq_start, 4 + m->rates_len});
+  }
+  if (m->weibull) {
+    m->shape_start = at++;
+    blocks->push_back({"Weibull_shape", m->shape_start, 1});
+    blocks->push_back({"entire_site", m->shape_start, 1});
+  }
+  if (m->strict_clock) {
+    m->clock_start = at++;
+    blocks->push_back({"clock_rate", m->clock_start, 1});
+    blocks->push_back({"entire_clock", m->clock_start, 1});
+  }
+  m->param_count = at;
+  blocks->push_back({"entire", 0, at});
+  return BITO_AMD_OK;
+}
+
+// GTRModel/HKYModel::SetParameters checks (reference src/substitution_model.cpp:33-47,120-139).
+int ValidateParams(bito_amd_engine* e, int tree_count, const double* params) {
+  const ModelSpec& m = e->spec;
+  if (m.substitution == kJC69) return BITO_AMD_OK;
+  const char* name = m.substitution == kGTR ? "GTR" : "HKY";
+  for (int t = 0; t < tree_count; t++) {
+    const double* row = params + (size_t)t * m.param_count;
+    const double* f = row + m.freq_start;
+    if (std::fabs(f[0] + f[1] + f[2] + f[3] - 1.) >= 0.001) {
+      char buf[256];
+      std::snprintf(buf, sizeof(buf),
+                    "%s frequencies do not sum to 1 +/- 0.001! frequency vector: (%g,%g,%g,%g) [tree %d]",
+                    name, f[0], f[1], f[2], f[3], t);
+      return Fail(e, BITO_AMD_ERR_BAD_PARAMS, buf);
+    }
+    if (m.substitution == kGTR) {
+      const double* r = row + m.rates_start;
+      double sum = 0;
+      for (int i = 0; i < 6; i++) sum += r[i];
+      if (std::fabs(sum - 1.) >= 0.001) {
+        char buf[256];
+        std::snprintf(buf, sizeof(buf),
+                      "GTR rates do not sum to 1 +/- 0.001! rate vector: (%g,%g,%g,%g,%g,%g) [tree %d]",
+                      r[0], r[1], r[2], r[3], r[4], r[5], t);
+        return Fail(e, BITO_AMD_ERR_BAD_PARAMS, buf);
+      }
+    }
+  }
+  return BITO_AMD_OK;
+}
+
+// The parent-id vector must describe a bito topology: leaves 0..n-1, internal ids
+// in post-order (every parent id larger than its children), bifurcating except for
+// the trifurcating root of an unrooted tree (reference src/node.cpp:383-402,511-551;
+// src/unrooted_tree.cpp:46-52).
+int ValidateTrees(bito_amd_engine* e, int tree_count, int rooted, int node_count,
+                  const int32_t* parent_ids) {
+  const int n = e->n, M = node_count;
+  if (M != (rooted ? 2 * n - 1 : 2 * n - 2)) {
+    char buf[200];
+    std::snprintf(buf, sizeof(buf), "node_count %d does not match %d taxa for a%s tree (expected %d)",
+                  M, n, rooted ? " rooted" : "n unrooted", rooted ? 2 * n - 1 : 2 * n - 2);
+    return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
+  }
+  if (M < 3) return Fail(e, BITO_AMD_ERR_BAD_TREE, "tree too small");
+  std::vector<int> count(M);
+  for (int t = 0; t < tree_count; t++) {
+    const int32_t* par = parent_ids + (size_t)t * (M - 1);
+    std::fill(count.begin(), count.end(), 0);
+    for (int child = 0; child < M - 1; child++) {
+      const int p = par[child];
+      if (p < n || p >= M || p <= child) {
+        char buf[200];
+        std::snprintf(buf, sizeof(buf), "tree %d: parent id %d of node %d is not a valid internal id",
+                      t, p, child);
+        return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
+      }
+      count[p]++;
+    }
+    for (int i = n; i < M; i++) {
+      const int want = (!rooted && i == M - 1) ? 3 : 2;
+      if (count[i] != want) {
+        char buf[200];
+        std::snprintf(buf, sizeof(buf), "tree %d: node %d has %d children, expected %d", t, i,
+                      count[i], want);
+        return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
+      }
+    }
+  }
+  return BITO_AMD_OK;
+}
+
+DeviceBatch MakeBatch(bito_amd_engine* e) {
+  DeviceBatch b{};
+  b.parent_ids = e->parent_ids.ptr;
+  b.branch_in = e->branch_in.ptr;
+  b.rates = e->has_rates ? e->rates.ptr : nullptr;
+  b.params = e->params.ptr;
+  b.tip_states = e->tip_states.ptr;
+  b.weights = e->weights.ptr;
+  b.children = e->children.ptr;
+  b.branch = e->branch.ptr;
+  b.model = e->model.ptr;
+  b.mats = e->mats.ptr;
+  b.arena = e->arena.ptr;
+  b.part_ll = e->part_ll.ptr;
+  b.part_grad = e->part_grad.ptr;
+  b.out_ll = e->out_ll.ptr;
+  b.out_grad = e->out_grad.ptr;
+  return b;
+}
+
+hipEvent_t NextEvent(bito_amd_engine* e) {
+  if (e->ev_used == e->ev_pool.size()) {
+    hipEvent_t ev;
+    (void)hipEventCreate(&ev);
+    e->ev_pool.push_back(ev);
+  }
+  return e->ev_pool[e->ev_used++];
+}
+
+int RunResident(bito_amd_engine* e, int want_gradient, int rescaling) {
+  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const BatchDims& d = e->dims;
+  const int T = d.tree_count;
+  const int tiles = HbmTiles(d.pattern_count);
+  // scratch sized for this run
+  const size_t per_tree = HbmArenaBytesPerTree(d);
+  size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
+  // grid.y limit
+  chunk = std::min<size_t>(chunk, 65535);
+  HIP_TRY(e, e->arena.Reserve(chunk * per_tree / sizeof(double)));
+  HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
+  if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
+  const DeviceBatch b = MakeBatch(e);
+  LaunchSetup(d, e->spec, b, want_gradient, e->stream);
+  LaunchMatrices(d, b, want_gradient, e->stream);
+  for (int t0 = 0; t0 < T; t0 += (int)chunk) {
+    const int ct = std::min<int>((int)chunk, T - t0);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e->timing) {
+      ev0 = NextEvent(e);
+      ev1 = NextEvent(e);
+      HIP_TRY(e, hipEventRecord(ev0, e->stream));
+    }
+    LaunchWalkHbm(d, b, t0, ct, want_gradient, rescaling, e->stream);
+    if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
+  }
+  e->kernel_name = WalkHbmKernelName(d.category_count, want_gradient, rescaling);
+  LaunchReduce(d, b, tiles, want_gradient, e->stream);
+  HIP_TRY(e, hipGetLastError());
+  return BITO_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bito_amd_version(void) {
+  static std::string v;
+  if (v.empty()) {
+    v = "bito_amd 0.1 (gfx950)";
+    int count = 0;
+    if (hipGetDeviceCount(&count) == hipSuccess && count > 0) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, 0) == hipSuccess) {
+        char buf[256];
+        std::snprintf(buf, sizeof(buf), "bito_amd 0.1 %s %dCU %.0fGB", prop.gcnArchName,
+                      prop.multiProcessorCount, prop.totalGlobalMem / 1e9);
+        v = buf;
+      }
+    }
+  }
+  return v.c_str();
+}
+
+int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substitution,
+                           const char* site, const char* clock, int32_t taxon_count,
+                           int32_t pattern_count, const int32_t* patterns, const double* weights,
+                           bito_amd_engine** out, char* err, size_t err_len) {
+  auto report = [&](int code, const std::string& msg) {
+    if (err && err_len) std::snprintf(err, err_len, "%s", msg.c_str());
+    return code;
+  };
+  if (!out) return report(BITO_AMD_ERR_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  auto e = new bito_amd_engine();
+  std::string msg;
+  int rc = ParseSpec(substitution, site, clock, &e->spec, &e->blocks, &msg);
+  if (rc) { delete e; return report(rc, msg); }
+  if (taxon_count < 2 || pattern_count < 1 || !patterns || !weights) {
+    delete e;
+    return report(BITO_AMD_ERR_BAD_ARG, "need at least 2 taxa, 1 site pattern and non-NULL arrays");
+  }
+  e->device = spec ? spec->device_id : 0;
+  int count = 0;
+  hipError_t hrc = hipGetDeviceCount(&count);
+  if (hrc != hipSuccess || count <= 0) {
+    delete e;
+    return report(BITO_AMD_ERR_DEVICE, "no HIP device available: the bito_amd engine needs an MI355X (gfx950); there is no CPU fallback");
+  }
+  if (e->device < 0 || e->device >= count) {
+    delete e;
+    return report(BITO_AMD_ERR_DEVICE, "device_id out of range");
+  }
+  auto dev_fail = [&](const char* what, hipError_t c) {
+    std::string m = std::string(what) + " failed: " + hipGetErrorString(c);
+    delete e;
+    return report(BITO_AMD_ERR_DEVICE, m);
+  };
+  if ((hrc = hipSetDevice(e->device)) != hipSuccess) return dev_fail("hipSetDevice", hrc);
+  if ((hrc = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
+    return dev_fail("hipStreamCreate", hrc);
+  e->n = taxon_count;
+  e->P = pattern_count;
+  e->Ppad = (pattern_count + kHbmBlock - 1) / kHbmBlock * kHbmBlock;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  e->arena_limit = (spec && spec->arena_bytes) ? spec->arena_bytes : std::max<size_t>(free_b / 4, (size_t)1 << 28);
+  // Compact tip states, gap for every symbol >= 4 and for the padding columns
+  // (SitePattern symbol table, reference src/site_pattern.cpp:16-46).
+  std::vector<uint8_t> tips((size_t)e->n * e->Ppad, 4);
+  for (int t = 0; t < e->n; t++)
+    for (int p = 0; p < e->P; p++) {
+      const int32_t s = patterns[(size_t)t * e->P + p];
+      if (s < 0) { delete e; return report(BITO_AMD_ERR_BAD_ARG, "negative pattern symbol"); }
+      tips[(size_t)t * e->Ppad + p] = (uint8_t)(s >= 4 ? 4 : s);
+    }
+  std::vector<double> w(e->Ppad, 0.0);
+  std::copy(weights, weights + e->P, w.begin());
+  if ((hrc = e->tip_states.Reserve(tips.size())) != hipSuccess) return dev_fail("hipMalloc", hrc);
+  if ((hrc = e->weights.Reserve(w.size())) != hipSuccess) return dev_fail("hipMalloc", hrc);
+  if ((hrc = hipMemcpy(e->tip_states.ptr, tips.data(), tips.size(), hipMemcpyHostToDevice)) != hipSuccess)
+    return dev_fail("hipMemcpy", hrc);
+  if ((hrc = hipMemcpy(e->weights.ptr, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
+    return dev_fail("hipMemcpy", hrc);
+  *out = e;
+  return BITO_AMD_OK;
+}
+
+void bito_amd_engine_destroy(bito_amd_engine* e) { delete e; }
+
+const char* bito_amd_engine_last_error(const bito_amd_engine* e) { return e ? e->err.c_str() : ""; }
+
+int32_t bito_amd_engine_param_count(const bito_amd_engine* e) { return e->spec.param_count; }
+int32_t bito_amd_engine_category_count(const bito_amd_engine* e) { return e->spec.category_count; }
+int32_t bito_amd_engine_block_count(const bito_amd_engine* e) { return (int32_t)e->blocks.size(); }
+
+int bito_amd_engine_block(const bito_amd_engine* e, int32_t idx, char* name, size_t name_len,
+                          int32_t* start, int32_t* len) {
+  if (idx < 0 || idx >= (int32_t)e->blocks.size()) return BITO_AMD_ERR_BAD_ARG;
+  const Block& b = e->blocks[idx];
+  if (name && name_len) std::snprintf(name, name_len, "%s", b.name.c_str());
+  if (start) *start = b.start;
+  if (len) *len = b.len;
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t rooted,
+                           int32_t node_count, const int32_t* parent_ids,
+                           const double* branch_lengths, const double* rates, const double* params) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  e->resident = false;
+  if (tree_count < 1 || !parent_ids || !branch_lengths)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "need at least one tree and non-NULL parent_ids / branch_lengths");
+  if (e->spec.param_count > 0 && !params)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "params is NULL but the model has parameters");
+  int rc = ValidateTrees(e, tree_count, rooted, node_count, parent_ids);
+  if (rc) return rc;
+  if (params && (rc = ValidateParams(e, tree_count, params))) return rc;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const int n = e->n, N = 2 * n - 1, M = node_count, C = e->spec.category_count;
+  const size_t T = tree_count;
+  const int pc = std::max(e->spec.param_count, 1);
+  HIP_TRY(e, e->parent_ids.Reserve(T * (M - 1)));
+  HIP_TRY(e, e->branch_in.Reserve(T * M));
+  HIP_TRY(e, e->params.Reserve(T * pc));
+  HIP_TRY(e, e->children.Reserve(T * (n - 1) * 2));
+  HIP_TRY(e, e->branch.Reserve(T * N));
+  HIP_TRY(e, e->model.Reserve(T));
+  HIP_TRY(e, e->mats.Reserve(T * (N - 1) * C * kMatStride));
+  HIP_TRY(e, e->out_ll.Reserve(T));
+  HIP_TRY(e, e->out_grad.Reserve(T * N));
+  HIP_TRY(e, hipMemcpyAsync(e->parent_ids.ptr, parent_ids, T * (M - 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * M * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  if (e->spec.param_count > 0)
+    HIP_TRY(e, hipMemcpyAsync(e->params.ptr, params, T * e->spec.param_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  e->has_rates = rooted && rates != nullptr;
+  if (e->has_rates) {
+    HIP_TRY(e, e->rates.Reserve(T * (M - 1)));
+    HIP_TRY(e, hipMemcpyAsync(e->rates.ptr, rates, T * (M - 1) * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->dims.taxon_count = n;
+  e->dims.node_count = N;
+  e->dims.in_node_count = M;
+  e->dims.rooted = rooted;
+  e->dims.pattern_count = e->P;
+  e->dims.pattern_stride = e->Ppad;
+  e->dims.category_count = C;
+  e->dims.tree_count = tree_count;
+  e->resident = true;
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_update(bito_amd_engine* e, const double* branch_lengths, const double* params) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t T = e->dims.tree_count;
+  if (params && e->spec.param_count > 0) {
+    int rc = ValidateParams(e, (int)T, params);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->params.ptr, params, T * e->spec.param_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  }
+  if (branch_lengths)
+    HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * e->dims.in_node_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_run(bito_amd_engine* e, int32_t want_gradient, int32_t rescaling) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  return RunResident(e, want_gradient != 0, rescaling != 0);
+}
+
+int bito_amd_engine_sync(bito_amd_engine* e) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_download(bito_amd_engine* e, double* out_ll, double* out_grad) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t T = e->dims.tree_count;
+  if (out_ll)
+    HIP_TRY(e, hipMemcpyAsync(out_ll, e->out_ll.ptr, T * sizeof(double), hipMemcpyDefault, e->stream));
+  if (out_grad)
+    HIP_TRY(e, hipMemcpyAsync(out_grad, e->out_grad.ptr, T * e->dims.node_count * sizeof(double), hipMemcpyDefault, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_log_likelihoods(bito_amd_engine* e, int32_t tree_count, int32_t rooted,
+                                    int32_t node_count, const int32_t* parent_ids,
+                                    const double* branch_lengths, const double* rates,
+                                    const double* params, int32_t rescaling, double* out) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  int rc = bito_amd_engine_upload(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params);
+  if (rc) return rc;
+  if ((rc = RunResident(e, 0, rescaling != 0))) return rc;
+  return bito_amd_engine_download(e, out, nullptr);
+}
+
+int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t rooted,
+                              int32_t node_count, const int32_t* parent_ids,
+                              const double* branch_lengths, const double* rates,
+                              const double* params, int32_t rescaling, int32_t flags,
+                              double fd_delta, double* out_ll, double* out_branch,
+                              double* out_site, double* out_subst, double* out_clock) {
+  if (!e || !out_ll || !out_branch) return BITO_AMD_ERR_BAD_ARG;
+  (void)flags; (void)fd_delta; (void)out_site; (void)out_subst;
+  int rc = bito_amd_engine_upload(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params);
+  if (rc) return rc;
+  if ((rc = RunResident(e, 1, rescaling != 0))) return rc;
+  if ((rc = bito_amd_engine_download(e, out_ll, out_branch))) return rc;
+  if (rooted && (flags & BITO_AMD_GRAD_CLOCK_MODEL) && out_clock) {
+    // ClockGradient, strict clock (reference src/fat_beagle.cpp:379-399): sum of
+    // branch gradient times the tree's own (time) branch length.
+    const int N = 2 * e->n - 1;
+    for (int t = 0; t < tree_count; t++) {
+      double s = 0;
+      for (int i = 0; i < N - 1; i++) s += out_branch[(size_t)t * N + i] * branch_lengths[(size_t)t * node_count + i];
+      out_clock[t] = s;
+    }
+  }
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_set_kernel(bito_amd_engine* e, int32_t kernel) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  e->kernel_choice = kernel;
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_kernel_timing(bito_amd_engine* e, int32_t enable) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  e->timing = enable != 0;
+  e->ev_used = 0;
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_kernel_elapsed(bito_amd_engine* e, double* kernel_ms, int32_t* kernel_launches) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  double k = 0;
+  int launches = 0;
+  for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+    float kms = 0;
+    HIP_TRY(e, hipEventElapsedTime(&kms, e->ev_pool[i], e->ev_pool[i + 1]));
+    k += kms;
+    launches++;
+  }
+  e->ev_used = 0;
+  if (kernel_ms) *kernel_ms = k;
+  if (kernel_launches) *kernel_launches = launches;
+  return BITO_AMD_OK;
+}
+
+const char* bito_amd_engine_kernel_name(const bito_amd_engine* e) { return e ? e->kernel_name.c_str() : ""; }
+
+int bito_amd_engine_time_runs(bito_amd_engine* e, int32_t want_gradient, int32_t rescaling,
+                              int32_t steps, double* total_ms, double* kernel_ms,
+                              int32_t* kernel_launches) {
+  if (!e || steps < 1) return BITO_AMD_ERR_BAD_ARG;
+  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident");
+  HIP_TRY(e, hipSetDevice(e->device));
+  e->timing = true;
+  e->ev_used = 0;
+  hipEvent_t t0 = NextEvent(e), t1 = NextEvent(e);
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  HIP_TRY(e, hipEventRecord(t0, e->stream));
+  int rc = BITO_AMD_OK;
+  for (int s = 0; s < steps && !rc; s++) rc = RunResident(e, want_gradient != 0, rescaling != 0);
+  e->timing = false;
+  if (rc) return rc;
+  HIP_TRY(e, hipEventRecord(t1, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  float ms = 0;
+  HIP_TRY(e, hipEventElapsedTime(&ms, t0, t1));
+  if (total_ms) *total_ms = ms;
+  double k = 0;
+  int launches = 0;
+  for (size_t i = 2; i + 1 < e->ev_used; i += 2) {
+    float kms = 0;
+    HIP_TRY(e, hipEventElapsedTime(&kms, e->ev_pool[i], e->ev_pool[i + 1]));
+    k += kms;
+    launches++;
+  }
+  if (kernel_ms) *kernel_ms = k;
+  if (kernel_launches) *kernel_launches = launches;
+  return BITO_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,478 @@
+// kernels.hip -- gfx950 kernels of the per-tree likelihood path.
+//
+// Pipeline for one resident batch of T trees (all on one HIP stream):
+//   setup_trees_kernel     parent-id vector -> children lists (+ detrifurcation),
+//                          effective branch lengths, per-tree Q / eigensystem /
+//                          category rates            (reference fat_beagle.cpp:42-45,
+//                          unrooted_tree.cpp:27-37, tree.cpp:82-88, substitution_model.cpp,
+//                          site_model.cpp)
+//   transition_matrices_kernel  P(t r_c) and dP/dt for every branch and category
+//                          (beagleUpdateTransitionMatrices, fat_beagle.cpp:315-325;
+//                          differential matrices :101-111)
+//   walk_hbm_kernel        post-order partials + root log-likelihood
+//                          (beagleUpdatePartials / CalculateRootLogLikelihoods,
+//                          fat_beagle.cpp:54-68) and, for gradients, the pre-order
+//                          partials and edge derivatives (:138-160) fused in one walk
+//   reduce_tiles_kernel    fixed-order sum of the per-tile partial results
+//
+// FP64 throughout.  No atomics anywhere: every sum has a fixed order, so results
+// are bit-reproducible run to run.
+#include "kernels.hpp"
+
+namespace bito_amd {
+
+// --------------------------------------------------------------------------
+// Set-up: one thread per tree.
+
+__global__ void __launch_bounds__(64)
+setup_trees_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.tree_count) return;
+  const int n = d.taxon_count, N = d.node_count, M = d.in_node_count, NI = n - 1;
+  int32_t* ch = b.children + (size_t)t * NI * 2;
+  for (int k = 0; k < NI * 2; k++) ch[k] = -1;
+  const int32_t* parent = b.parent_ids + (size_t)t * (M - 1);
+  int third = -1;
+  // Children in ascending id order, as Node::OfParentIdVector builds them
+  // (reference src/node.cpp:511-551).
+  for (int child = 0; child < M - 1; child++) {
+    const int k = parent[child] - n;
+    if (ch[k * 2] < 0) {
+      ch[k * 2] = child;
+    } else if (ch[k * 2 + 1] < 0) {
+      ch[k * 2 + 1] = child;
+    } else {
+      third = child;
+    }
+  }
+  double* bl = b.branch + (size_t)t * N;
+  const double* bl_in = b.branch_in + (size_t)t * M;
+  for (int i = 0; i < M; i++) bl[i] = bl_in[i];
+  if (!d.rooted) {
+    // UnrootedTree::Detrifurcate (reference src/unrooted_tree.cpp:27-37): children 1 and
+    // 2 of the trifurcation are joined under a node that re-uses the old root id
+    // with branch length 0; the new root (id+1) joins child 0 with it.
+    // Tree::SlideRootPosition (src/tree.cpp:82-88) is then the identity apart from
+    // pinning that branch to 0.
+    const int r = M - 1;
+    const int a = ch[(r - n) * 2], bb = ch[(r - n) * 2 + 1];
+    ch[(r - n) * 2] = bb;
+    ch[(r - n) * 2 + 1] = third;
+    bl[r] = 0.0;
+    ch[(r + 1 - n) * 2] = a;
+    ch[(r + 1 - n) * 2 + 1] = r;
+    bl[r + 1] = 0.0;
+  } else if (b.rates != nullptr) {
+    // FatBeagle::LogLikelihood(RootedTree) (reference src/fat_beagle.cpp:86-90).
+    const double* rates = b.rates + (size_t)t * (M - 1);
+    for (int i = 0; i < N - 1; i++) bl[i] *= rates[i];
+  }
+  SetupTreeModel(spec, b.params + (size_t)t * spec.param_count, &b.model[t]);
+}
+
+void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int,
+                 hipStream_t stream) {
+  const int blocks = (d.tree_count + 63) / 64;
+  hipLaunchKernelGGL(setup_trees_kernel, dim3(blocks), dim3(64), 0, stream, d, spec, b);
+}
+
+// --------------------------------------------------------------------------
+// Transition matrices: one thread per (tree, branch, category).
+
+__global__ void __launch_bounds__(256)
+transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient) {
+  const int C = d.category_count, NB = d.node_count - 1;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)d.tree_count * NB * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const size_t tb = idx / C;
+  const int br = (int)(tb % NB);
+  const int t = (int)(tb / NB);
+  const TreeModel* __restrict__ m = b.model + t;
+  const double rate = m->cat_rate[c];
+  const double time = b.branch[(size_t)t * d.node_count + br] * rate;
+  double e[4], de[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    e[k] = exp(m->lambda[k] * time);
+    de[k] = m->lambda[k] * rate * e[k];
+  }
+  double* out = b.mats + idx * kMatStride;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double s = 0, ds = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const double vv = m->V[i * 4 + k] * m->Vinv[k * 4 + j];
+        s += vv * e[k];
+        ds += vv * de[k];
+      }
+      out[kMatP + i * 4 + j] = s;
+      out[kMatPT + j * 4 + i] = s;
+      if (want_gradient) {
+        out[kMatDP + i * 4 + j] = ds;
+        out[kMatDPT + j * 4 + i] = ds;
+      }
+    }
+    out[kMatPT + 16 + i] = 1.0;   // gap: the all-ones column BEAGLE appends
+    out[kMatDPT + 16 + i] = 0.0;  // Q 1 = 0
+  }
+}
+
+void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, hipStream_t stream) {
+  const size_t total = (size_t)d.tree_count * (d.node_count - 1) * d.category_count;
+  const int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(transition_matrices_kernel, dim3(blocks), dim3(256), 0, stream, d, b,
+                     want_gradient);
+}
+
+// --------------------------------------------------------------------------
+// Traversal with the PLV arena in HBM.
+//
+// One thread owns one site pattern and walks the whole tree for it; patterns are
+// independent end to end, so there is no inter-thread dependency until the final
+// sums.  Arena cell (node, category, state) of a tree is a row of Ppad doubles:
+// a wave reads/writes 64 consecutive doubles (512 B) per access.  Transition
+// matrices and the child lists are wave-uniform and come through scalar loads.
+//
+// Gradient pass.  With u = pre-order partial at the top of a node's two child
+// branches, a_k = P_k x_k the child messages and d_k = dP_k x_k:
+//     site likelihood  L = sum_c w_c sum_i u_i a0_i a1_i           (any node)
+//     dL/dt_0            = sum_c w_c sum_i u_i a1_i d0_i   (Q and P commute)
+//     pre(child 0)       = P_0^T (u . a1)
+// so one step per internal node, in descending id order (parents first), yields
+// both child-edge derivatives and both child pre-order partials.  The child's
+// pre-order partial overwrites its post-order partial in place -- it is dead
+// once both siblings are done -- so the arena holds n-1 PLVs per tree instead
+// of the 3n-2 buffers of the reference's BEAGLE instance (fat_beagle.cpp:218-246).
+
+__device__ __forceinline__ double WaveSum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ void MatVec(const double* __restrict__ M, const double x[4], double out[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    out[i] = M[i * 4 + 0] * x[0] + M[i * 4 + 1] * x[1] + M[i * 4 + 2] * x[2] + M[i * 4 + 3] * x[3];
+}
+
+__device__ __forceinline__ void MatVecT(const double* __restrict__ M, const double x[4], double out[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    out[j] = M[0 * 4 + j] * x[0] + M[1 * 4 + j] * x[1] + M[2 * 4 + j] * x[2] + M[3 * 4 + j] * x[3];
+}
+
+// Read-only inputs are separate __restrict__ kernel arguments so that the
+// wave-uniform ones (child lists, matrices, model) are fetched with scalar loads.
+template <int C, bool GRAD, bool RESCALE>
+__global__ void __launch_bounds__(kHbmBlock)
+walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
+                const double* __restrict__ all_mats, const TreeModel* __restrict__ models,
+                const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
+                double* __restrict__ arena_base, double* __restrict__ part_ll,
+                double* __restrict__ part_grad) {
+  extern __shared__ double lds[];  // [waves][N] gradient rows, then [waves] log-likelihoods
+  constexpr int kWaves = kHbmBlock / 64;
+  const int n = d.taxon_count, N = d.node_count, NI = n - 1, Ppad = d.pattern_stride;
+  const int tree = tree0 + blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = blockIdx.x * kHbmBlock + tid;
+  const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
+  const double* __restrict__ mats = all_mats + (size_t)tree * (N - 1) * C * kMatStride;
+  const TreeModel* __restrict__ tm = models + tree;
+  const uint8_t* __restrict__ tips = tip_states + p;
+  double* __restrict__ arena = arena_base + (size_t)blockIdx.y * NI * C * 4 * Ppad + p;
+  const double weight = weights[p];
+
+  if (GRAD) {
+    for (int k = tid; k < kWaves * N; k += kHbmBlock) lds[k] = 0.0;
+    __syncthreads();
+  }
+
+  // ---- post-order: dest = (P0 x0) . (P1 x1) per category -------------------
+  double log_scale = 0.0, site = 0.0;
+  for (int node = n; node < N; ++node) {
+    const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
+    const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
+    const int s0 = c0 < n ? tips[(size_t)c0 * Ppad] : 0;
+    const int s1 = c1 < n ? tips[(size_t)c1 * Ppad] : 0;
+    double dd[C][4];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      double A[4], B[4];
+      const double* m0 = mats + (size_t)(c0 * C + c) * kMatStride;
+      const double* m1 = mats + (size_t)(c1 * C + c) * kMatStride;
+      if (c0 < n) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) A[i] = m0[kMatPT + s0 * 4 + i];
+      } else {
+        double x[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad];
+        MatVec(m0 + kMatP, x, A);
+      }
+      if (c1 < n) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) B[i] = m1[kMatPT + s1 * 4 + i];
+      } else {
+        double x[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad];
+        MatVec(m1 + kMatP, x, B);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) dd[c][i] = A[i] * B[i];
+    }
+    if (RESCALE) {
+      // BEAGLE manual scaling: per pattern, max over categories and states.
+      double mx = 0.0;
+#pragma unroll
+      for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) mx = fmax(mx, dd[c][i]);
+      if (mx == 0.0) mx = 1.0;
+      const double inv = 1.0 / mx;
+#pragma unroll
+      for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) dd[c][i] *= inv;
+      log_scale += log(mx);
+    }
+    if (node == N - 1) {
+#pragma unroll
+      for (int c = 0; c < C; c++)
+        site += tm->cat_weight[c] * (tm->pi[0] * dd[c][0] + tm->pi[1] * dd[c][1] +
+                                     tm->pi[2] * dd[c][2] + tm->pi[3] * dd[c][3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) arena[((size_t)((node - n) * C + c) * 4 + i) * Ppad] = dd[c][i];
+    }
+  }
+  const double ll = weight * (log(site) + log_scale);
+
+  // ---- pre-order + edge derivatives ---------------------------------------
+  if (GRAD) {
+    double* my_row = lds + wave * N;
+    for (int node = N - 1; node >= n; --node) {
+      const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
+      const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
+      const bool tip0 = c0 < n, tip1 = c1 < n;
+      const int s0 = tip0 ? tips[(size_t)c0 * Ppad] : 0;
+      const int s1 = tip1 ? tips[(size_t)c1 * Ppad] : 0;
+      double num0 = 0.0, num1 = 0.0, den = 0.0;
+      // One category of the step: accumulates the three site sums and returns the
+      // two child pre-order partials (only meaningful for internal children).
+      auto category_step = [&](int c, double q0[4], double q1[4]) {
+        double U[4], A0[4], D0[4], A1[4], D1[4];
+        if (node == N - 1) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) U[i] = tm->pi[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) U[i] = arena[((size_t)((node - n) * C + c) * 4 + i) * Ppad];
+        }
+        const double* m0 = mats + (size_t)(c0 * C + c) * kMatStride;
+        const double* m1 = mats + (size_t)(c1 * C + c) * kMatStride;
+        if (tip0) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            A0[i] = m0[kMatPT + s0 * 4 + i];
+            D0[i] = m0[kMatDPT + s0 * 4 + i];
+          }
+        } else {
+          double x[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad];
+          MatVec(m0 + kMatP, x, A0);
+          MatVec(m0 + kMatDP, x, D0);
+        }
+        if (tip1) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            A1[i] = m1[kMatPT + s1 * 4 + i];
+            D1[i] = m1[kMatDPT + s1 * 4 + i];
+          }
+        } else {
+          double x[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad];
+          MatVec(m1 + kMatP, x, A1);
+          MatVec(m1 + kMatDP, x, D1);
+        }
+        double UA0[4], UA1[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          UA0[i] = U[i] * A0[i];
+          UA1[i] = U[i] * A1[i];
+        }
+        const double wc = tm->cat_weight[c];
+        den += wc * (UA1[0] * A0[0] + UA1[1] * A0[1] + UA1[2] * A0[2] + UA1[3] * A0[3]);
+        num0 += wc * (UA1[0] * D0[0] + UA1[1] * D0[1] + UA1[2] * D0[2] + UA1[3] * D0[3]);
+        num1 += wc * (UA0[0] * D1[0] + UA0[1] * D1[1] + UA0[2] * D1[2] + UA0[3] * D1[3]);
+        if (!tip0) MatVecT(m0 + kMatP, UA1, q0);
+        if (!tip1) MatVecT(m1 + kMatP, UA0, q1);
+      };
+      if constexpr (RESCALE) {
+        // Pre-order partials are rescaled per pattern over all categories like the
+        // post-order ones (BEAGLE scaleWrite on the pre-order ops, fat_beagle.cpp:362-363);
+        // the factor cancels in num/den, so it is not accumulated.
+        double pre0[C][4], pre1[C][4];
+#pragma unroll
+        for (int c = 0; c < C; c++) category_step(c, pre0[c], pre1[c]);
+        if (!tip0) {
+          double mx = 0.0;
+#pragma unroll
+          for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) mx = fmax(mx, pre0[c][i]);
+          const double inv = 1.0 / (mx == 0.0 ? 1.0 : mx);
+#pragma unroll
+          for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad] = pre0[c][i] * inv;
+        }
+        if (!tip1) {
+          double mx = 0.0;
+#pragma unroll
+          for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) mx = fmax(mx, pre1[c][i]);
+          const double inv = 1.0 / (mx == 0.0 ? 1.0 : mx);
+#pragma unroll
+          for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad] = pre1[c][i] * inv;
+        }
+      } else {
+        // In place, one category at a time: cell (child, c) is read (as the child's
+        // post-order partial) before it is overwritten with its pre-order partial.
+#pragma unroll 1
+        for (int c = 0; c < C; c++) {
+          double q0[4], q1[4];
+          category_step(c, q0, q1);
+          if (!tip0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad] = q0[i];
+          }
+          if (!tip1) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad] = q1[i];
+          }
+        }
+      }
+      const double scale = weight / den;
+      const double g0 = WaveSum(num0 * scale);
+      const double g1 = WaveSum(num1 * scale);
+      if (lane == 0) {
+        my_row[c0] = g0;
+        my_row[c1] = g1;
+      }
+    }
+  }
+
+  // ---- block-level sums, fixed order --------------------------------------
+  const double wll = WaveSum(ll);
+  double* ll_slots = lds + kWaves * N;
+  if (lane == 0) ll_slots[wave] = wll;
+  __syncthreads();
+  const int tiles = gridDim.x;
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < kWaves; w++) s += ll_slots[w];
+    part_ll[(size_t)tree * tiles + blockIdx.x] = s;
+  }
+  if (GRAD) {
+    double* out = part_grad + ((size_t)tree * tiles + blockIdx.x) * N;
+    for (int e = tid; e < N; e += kHbmBlock) {
+      double s = 0.0;
+      for (int w = 0; w < kWaves; w++) s += lds[w * N + e];
+      out[e] = s;
+    }
+  }
+}
+
+size_t HbmArenaBytesPerTree(const BatchDims& d) {
+  return (size_t)(d.taxon_count - 1) * d.category_count * 4 * d.pattern_stride * sizeof(double);
+}
+
+template <int C>
+static void LaunchWalkHbmC(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk,
+                           int want_gradient, int rescaling, hipStream_t stream) {
+  const dim3 grid(HbmTiles(d.pattern_count), chunk), block(kHbmBlock);
+  const size_t lds = ((size_t)(kHbmBlock / 64) * d.node_count + kHbmBlock / 64) * sizeof(double);
+  if (want_gradient) {
+    if (rescaling)
+      hipLaunchKernelGGL((walk_hbm_kernel<C, true, true>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model,
+                         b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+    else
+      hipLaunchKernelGGL((walk_hbm_kernel<C, true, false>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model,
+                         b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+  } else {
+    if (rescaling)
+      hipLaunchKernelGGL((walk_hbm_kernel<C, false, true>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model,
+                         b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+    else
+      hipLaunchKernelGGL((walk_hbm_kernel<C, false, false>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model,
+                         b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+  }
+}
+
+void LaunchWalkHbm(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk, int want_gradient,
+                   int rescaling, hipStream_t stream) {
+  switch (d.category_count) {
+    case 1: LaunchWalkHbmC<1>(d, b, tree0, chunk, want_gradient, rescaling, stream); break;
+    case 2: LaunchWalkHbmC<2>(d, b, tree0, chunk, want_gradient, rescaling, stream); break;
+    case 3: LaunchWalkHbmC<3>(d, b, tree0, chunk, want_gradient, rescaling, stream); break;
+    case 4: LaunchWalkHbmC<4>(d, b, tree0, chunk, want_gradient, rescaling, stream); break;
+    case 5: LaunchWalkHbmC<5>(d, b, tree0, chunk, want_gradient, rescaling, stream); break;
+    case 6: LaunchWalkHbmC<6>(d, b, tree0, chunk, want_gradient, rescaling, stream); break;
+    case 7: LaunchWalkHbmC<7>(d, b, tree0, chunk, want_gradient, rescaling, stream); break;
+    case 8: LaunchWalkHbmC<8>(d, b, tree0, chunk, want_gradient, rescaling, stream); break;
+    default: break;  // rejected at engine creation
+  }
+}
+
+const char* WalkHbmKernelName(int, int, int) { return "walk_hbm_kernel"; }
+
+// --------------------------------------------------------------------------
+// Final per-tree sums over pattern tiles, fixed order.
+
+__global__ void __launch_bounds__(256)
+reduce_tiles_kernel(BatchDims d, DeviceBatch b, int tiles, int want_gradient) {
+  const int N = d.node_count;
+  const int per_tree = want_gradient ? N + 1 : 1;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)d.tree_count * per_tree) return;
+  const int t = (int)(idx / per_tree), e = (int)(idx % per_tree);
+  if (e == per_tree - 1) {
+    double s = 0.0;
+    for (int k = 0; k < tiles; k++) s += b.part_ll[(size_t)t * tiles + k];
+    b.out_ll[t] = s;
+    return;
+  }
+  double s = 0.0;
+  for (int k = 0; k < tiles; k++) s += b.part_grad[((size_t)t * tiles + k) * N + e];
+  // Root has no branch; for unrooted trees the node that re-uses the old root id
+  // is the fixed node whose gradient is pinned to 0 (reference fat_beagle.cpp:148,553).
+  if (e == N - 1 || (!d.rooted && e == N - 2)) s = 0.0;
+  b.out_grad[(size_t)t * N + e] = s;
+}
+
+void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
+                  hipStream_t stream) {
+  const size_t total = (size_t)d.tree_count * (want_gradient ? d.node_count + 1 : 1);
+  const int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(reduce_tiles_kernel, dim3(blocks), dim3(256), 0, stream, d, b, tiles,
+                     want_gradient);
+}
+
+}  // namespace bito_amd

@@ -1,0 +1,69 @@
+// kernels.hpp -- launch interface between the host engine and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "model.hpp"
+
+namespace bito_amd {
+
+// Per (tree, branch, category) matrix record, 72 doubles:
+//   [ 0,16) P      row-major          P[i][j]   = V exp(lambda t r_c) V^-1
+//   [16,32) dP     row-major          dP = r_c Q P  (first derivative wrt t)
+//   [32,52) PT5    [state 0..4][i]    column lookup for tip children; row 4 (gap) = 1
+//   [52,72) dPT5   [state 0..4][i]    same for dP; row 4 (gap) = 0 (rows of Q sum to 0)
+constexpr int kMatStride = 72;
+constexpr int kMatP = 0, kMatDP = 16, kMatPT = 32, kMatDPT = 52;
+
+struct BatchDims {
+  int32_t taxon_count;    // n
+  int32_t node_count;     // N = 2n-1 (after detrifurcation)
+  int32_t in_node_count;  // M = 2n-2 (unrooted input) or 2n-1 (rooted)
+  int32_t rooted;
+  int32_t pattern_count;  // P
+  int32_t pattern_stride; // Ppad (multiple of 64)
+  int32_t category_count; // C
+  int32_t tree_count;     // T
+};
+
+struct DeviceBatch {
+  // inputs, resident in HBM (wire format of the reference)
+  const int32_t* parent_ids;  // [T][M-1]
+  const double* branch_in;    // [T][M]
+  const double* rates;        // [T][M-1] or nullptr
+  const double* params;       // [T][param_count]
+  // alignment
+  const uint8_t* tip_states;  // [n][Ppad], 4 = gap (padding = gap)
+  const double* weights;      // [Ppad], padding = 0
+  // produced by the set-up kernels
+  int32_t* children;          // [T][n-1][2]  children of internal node n+k
+  double* branch;             // [T][N]       effective branch lengths
+  TreeModel* model;           // [T]
+  double* mats;               // [T][N-1][C][kMatStride]
+  // traversal scratch + outputs
+  double* arena;              // [chunk][n-1][C][4][Ppad]
+  double* part_ll;            // [T][tiles]
+  double* part_grad;          // [T][tiles][N]
+  double* out_ll;             // [T]
+  double* out_grad;           // [T][N]
+};
+
+void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int want_gradient,
+                 hipStream_t stream);
+void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, hipStream_t stream);
+
+// HBM-arena traversal: one thread per site pattern walks the whole tree.
+constexpr int kHbmBlock = 256;
+inline int HbmTiles(int pattern_count) { return (pattern_count + kHbmBlock - 1) / kHbmBlock; }
+size_t HbmArenaBytesPerTree(const BatchDims& d);
+void LaunchWalkHbm(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk_trees,
+                   int want_gradient, int rescaling, hipStream_t stream);
+const char* WalkHbmKernelName(int category_count, int want_gradient, int rescaling);
+
+void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
+                  hipStream_t stream);
+
+}  // namespace bito_amd

@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference ``Engine`` on top of the C ABI.
+
+``Engine.log_likelihoods`` / ``Engine.gradients`` take a whole tree collection in
+wire format (parent-id vectors + branch lengths + one parameter row per tree) and
+return what ``Engine::LogLikelihoods`` / ``Engine::Gradients`` return in the
+reference (src/engine.hpp:33-61).  All arithmetic happens in libbito_amd.so on the
+GPU; this module only marshals numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+
+
+class BitoAmdError(RuntimeError):
+    """Raised for every non-zero status of the C ABI (the reference raises
+    std::runtime_error -> Python RuntimeError through pybind11)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+@dataclass
+class PhyloModelSpecification:
+    """reference src/phylo_model.hpp:13-17 / pybito ``PhyloModelSpecification``."""
+    substitution: str
+    site: str
+    clock: str
+
+
+@dataclass
+class PhyloGradient:
+    """reference src/phylo_gradient.hpp:10-35 / pybito ``PhyloGradient``."""
+    log_likelihood: float
+    gradient: Dict[str, np.ndarray] = field(default_factory=dict)
+
+
+def _dp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Engine:
+    def __init__(self, model: PhyloModelSpecification, patterns: np.ndarray, weights: np.ndarray,
+                 device_id: int = 0, use_tip_states: bool = True, arena_bytes: int = 0):
+        self._h = None
+        L = _capi.lib()
+        self.patterns = np.ascontiguousarray(patterns, dtype=np.int32)
+        self.weights = np.ascontiguousarray(weights, dtype=np.float64)
+        if self.patterns.ndim != 2 or self.patterns.shape[1] != self.weights.shape[0]:
+            raise BitoAmdError(_capi.ERR_BAD_ARG, "patterns must be [taxon_count][pattern_count] and match weights")
+        n, P = self.patterns.shape
+        spec = _capi.EngineSpec(device_id, int(use_tip_states), arena_bytes)
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.bito_amd_engine_create(C.byref(spec), model.substitution.encode(), model.site.encode(),
+                                      model.clock.encode(), n, P, _ip(self.patterns), _dp(self.weights),
+                                      C.byref(h), err, 512)
+        if rc:
+            raise BitoAmdError(rc, err.value.decode())
+        self._h = h
+        self.model = model
+        self.taxon_count = n
+        self.pattern_count = P
+        self.param_count = L.bito_amd_engine_param_count(h)
+        self.category_count = L.bito_amd_engine_category_count(h)
+        self.tree_count = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _capi.lib().bito_amd_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- BlockSpecification -------------------------------------------------
+    def block_map(self) -> Dict[str, Tuple[int, int]]:
+        L = _capi.lib()
+        out = {}
+        name = C.create_string_buffer(64)
+        s, ln = C.c_int32(), C.c_int32()
+        for i in range(L.bito_amd_engine_block_count(self._h)):
+            L.bito_amd_engine_block(self._h, i, name, 64, C.byref(s), C.byref(ln))
+            out[name.value.decode()] = (s.value, ln.value)
+        return out
+
+    def default_params(self, tree_count: int) -> np.ndarray:
+        """Defaults of the reference's model classes (GTR rates 1/6 and frequencies 1/4,
+        src/substitution_model.hpp:82-89; HKY kappa 1; Weibull shape 1; clock rate 1)."""
+        p = np.zeros((tree_count, self.param_count))
+        for key, (s, ln) in self.block_map().items():
+            if key == "substitution_model_frequencies":
+                p[:, s:s + ln] = 0.25
+            elif key == "substitution_model_rates":
+                p[:, s:s + ln] = 1.0 / 6 if ln == 6 else 1.0
+            elif key in ("Weibull_shape", "clock_rate"):
+                p[:, s:s + ln] = 1.0
+        return p
+
+    # -- helpers -------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc:
+            raise BitoAmdError(rc, _capi.lib().bito_amd_engine_last_error(self._h).decode())
+
+    def _prep(self, parent_ids, branch_lengths, rates, params):
+        parent_ids = np.ascontiguousarray(parent_ids, dtype=np.int32)
+        branch_lengths = np.ascontiguousarray(branch_lengths, dtype=np.float64)
+        if branch_lengths.ndim != 2 or parent_ids.ndim != 2:
+            raise BitoAmdError(_capi.ERR_BAD_ARG, "parent_ids and branch_lengths must be 2-D (one row per tree)")
+        T, M = branch_lengths.shape
+        if parent_ids.shape != (T, M - 1):
+            raise BitoAmdError(_capi.ERR_BAD_ARG, "parent_ids must have one entry fewer per tree than branch_lengths")
+        rooted = int(M == 2 * self.taxon_count - 1)
+        if rates is not None:
+            rates = np.ascontiguousarray(rates, dtype=np.float64)
+            if rates.shape != (T, M - 1):
+                raise BitoAmdError(_capi.ERR_BAD_ARG, "rates must be [tree_count][node_count-1]")
+        if params is None:
+            params = self.default_params(T)
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        # "We param_matrix needs as many rows as we have trees." (reference fat_beagle.hpp:170-171)
+        if params.shape != (T, self.param_count):
+            raise BitoAmdError(_capi.ERR_BAD_ARG,
+                               f"param matrix needs shape ({T}, {self.param_count}), got {params.shape}")
+        return parent_ids, branch_lengths, rates, params, T, M, rooted
+
+    # -- Engine::LogLikelihoods / Gradients -----------------------------------
+    def log_likelihoods(self, parent_ids, branch_lengths, params=None, rates=None, rescaling=False) -> np.ndarray:
+        parent_ids, branch_lengths, rates, params, T, M, rooted = self._prep(parent_ids, branch_lengths, rates, params)
+        out = np.zeros(T)
+        self._check(_capi.lib().bito_amd_engine_log_likelihoods(
+            self._h, T, rooted, M, _ip(parent_ids), _dp(branch_lengths), _dp(rates), _dp(params), int(rescaling),
+            _dp(out)))
+        self.tree_count = T
+        return out
+
+    def gradients(self, parent_ids, branch_lengths, params=None, rates=None, rescaling=False, flags=0,
+                  fd_delta=1e-6) -> Dict[str, np.ndarray]:
+        parent_ids, branch_lengths, rates, params, T, M, rooted = self._prep(parent_ids, branch_lengths, rates, params)
+        N = 2 * self.taxon_count - 1
+        ll = np.zeros(T)
+        branch = np.zeros((T, N))
+        bm = self.block_map()
+        sub_len = bm["entire_substitution"][1] if "entire_substitution" in bm else 0
+        site = np.zeros(T) if flags & _capi.GRAD_SITE_MODEL else None
+        subst = np.zeros((T, max(sub_len, 1))) if flags & _capi.GRAD_SUBSTITUTION_MODEL else None
+        clock = np.zeros(T) if flags & _capi.GRAD_CLOCK_MODEL else None
+        self._check(_capi.lib().bito_amd_engine_gradients(
+            self._h, T, rooted, M, _ip(parent_ids), _dp(branch_lengths), _dp(rates), _dp(params), int(rescaling),
+            flags, fd_delta, _dp(ll), _dp(branch), _dp(site), _dp(subst), _dp(clock)))
+        self.tree_count = T
+        out = {"log_likelihood": ll, "branch_lengths": branch}
+        if site is not None and self.category_count > 1:
+            out["site_model"] = site
+        if subst is not None and sub_len:
+            if flags & _capi.GRAD_STICKBREAKING:
+                rl = bm["substitution_model_rates"][1]
+                sub_len = (rl - 1 if rl == 6 else rl) + 3
+            out["substitution_model"] = subst[:, :sub_len]
+        if clock is not None and rooted:
+            out["clock_model"] = clock
+        return out
+
+    # -- HBM-resident batch ---------------------------------------------------
+    def upload(self, parent_ids, branch_lengths, params=None, rates=None):
+        parent_ids, branch_lengths, rates, params, T, M, rooted = self._prep(parent_ids, branch_lengths, rates, params)
+        self._check(_capi.lib().bito_amd_engine_upload(self._h, T, rooted, M, _ip(parent_ids), _dp(branch_lengths),
+                                                       _dp(rates), _dp(params)))
+        self.tree_count = T
+        self._node_count = 2 * self.taxon_count - 1
+
+    def update(self, branch_lengths=None, params=None):
+        bl = None if branch_lengths is None else np.ascontiguousarray(branch_lengths, dtype=np.float64)
+        pr = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
+        self._check(_capi.lib().bito_amd_engine_update(self._h, _dp(bl), _dp(pr)))
+
+    def run(self, want_gradient: bool, rescaling: bool = False):
+        self._check(_capi.lib().bito_amd_engine_run(self._h, int(want_gradient), int(rescaling)))
+
+    def sync(self):
+        self._check(_capi.lib().bito_amd_engine_sync(self._h))
+
+    def download(self, want_gradient: bool = True):
+        ll = np.zeros(self.tree_count)
+        grad = np.zeros((self.tree_count, self._node_count)) if want_gradient else None
+        self._check(_capi.lib().bito_amd_engine_download(self._h, ll.ctypes.data,
+                                                         None if grad is None else grad.ctypes.data))
+        return ll, grad
+
+    def download_to(self, ll_ptr: int, grad_ptr: Optional[int]):
+        """Copy results to raw (host or device) addresses, e.g. torch tensor data_ptr()."""
+        self._check(_capi.lib().bito_amd_engine_download(self._h, ll_ptr, grad_ptr))
+
+    def set_kernel(self, kernel: int):
+        self._check(_capi.lib().bito_amd_engine_set_kernel(self._h, kernel))
+
+    def kernel_name(self) -> str:
+        return _capi.lib().bito_amd_engine_kernel_name(self._h).decode()
+
+    def kernel_timing(self, enable: bool):
+        self._check(_capi.lib().bito_amd_engine_kernel_timing(self._h, int(enable)))
+
+    def kernel_elapsed(self):
+        kern, launches = C.c_double(), C.c_int32()
+        self._check(_capi.lib().bito_amd_engine_kernel_elapsed(self._h, C.byref(kern), C.byref(launches)))
+        return kern.value, launches.value
+
+    def time_runs(self, want_gradient: bool, rescaling: bool, steps: int):
+        total, kern, launches = C.c_double(), C.c_double(), C.c_int32()
+        self._check(_capi.lib().bito_amd_engine_time_runs(self._h, int(want_gradient), int(rescaling), steps,
+                                                          C.byref(total), C.byref(kern), C.byref(launches)))
+        return total.value, kern.value, launches.value
+
+
+def version() -> str:
+    return _capi.lib().bito_amd_version().decode()

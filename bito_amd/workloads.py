@@ -1,0 +1,194 @@
+"""Workload builders for the BASELINE.json configurations (harness code).
+
+Everything here produces *inputs* in the engine's wire format: site patterns,
+parent-id vectors, branch lengths, parameter rows.  Used by bench.py, by
+__graft_entry__.smoke() and by the parity tests so that CPU oracle and GPU engine
+see byte-identical inputs.  Data files come from tests/golden/data (copies of the
+reference's own test data); nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import treeio
+from .site_pattern import SitePattern
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
+
+_MASK = (1 << 64) - 1
+
+
+class Xoshiro256ss:
+    """xoshiro256** seeded through splitmix64 (the generator BASELINE.md names for
+    the config-3 branch lengths)."""
+
+    def __init__(self, seed: int):
+        x = seed & _MASK
+        self.s = []
+        for _ in range(4):
+            x = (x + 0x9E3779B97F4A7C15) & _MASK
+            z = x
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
+            self.s.append(z ^ (z >> 31))
+
+    @staticmethod
+    def _rotl(x, k):
+        return ((x << k) & _MASK) | (x >> (64 - k))
+
+    def next_u64(self) -> int:
+        s = self.s
+        result = (self._rotl((s[1] * 5) & _MASK, 7) * 9) & _MASK
+        t = (s[1] << 17) & _MASK
+        s[2] ^= s[0]
+        s[3] ^= s[1]
+        s[1] ^= s[2]
+        s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = self._rotl(s[3], 45)
+        return result
+
+    def uniform(self) -> float:
+        return (self.next_u64() >> 11) * (1.0 / (1 << 53))
+
+    def exponential(self, mean: float) -> float:
+        return -mean * np.log1p(-self.uniform())
+
+
+@dataclass
+class Workload:
+    name: str
+    substitution: str
+    site: str
+    clock: str
+    patterns: np.ndarray  # int32 [n][P]
+    weights: np.ndarray  # float64 [P]
+    parent_ids: np.ndarray  # int32 [T][M-1]
+    branch_lengths: np.ndarray  # float64 [T][M]
+    params: np.ndarray  # float64 [T][param_count]
+    rescaling: bool
+    want_gradient: bool
+    rates: Optional[np.ndarray] = None
+
+    @property
+    def tree_count(self) -> int:
+        return int(self.parent_ids.shape[0])
+
+    @property
+    def taxon_count(self) -> int:
+        return int(self.patterns.shape[0])
+
+    def subset(self, count: int) -> "Workload":
+        return Workload(self.name, self.substitution, self.site, self.clock, self.patterns, self.weights,
+                        self.parent_ids[:count].copy(), self.branch_lengths[:count].copy(),
+                        self.params[:count].copy(), self.rescaling, self.want_gradient,
+                        None if self.rates is None else self.rates[:count].copy())
+
+    def shard(self, rank: int, world: int) -> "Workload":
+        """Contiguous block of trees for one rank."""
+        T = self.tree_count
+        lo, hi = (T * rank) // world, (T * (rank + 1)) // world
+        return Workload(self.name, self.substitution, self.site, self.clock, self.patterns, self.weights,
+                        self.parent_ids[lo:hi].copy(), self.branch_lengths[lo:hi].copy(), self.params[lo:hi].copy(),
+                        self.rescaling, self.want_gradient, None if self.rates is None else self.rates[lo:hi].copy())
+
+
+GTR_FREQS = [0.1, 0.2, 0.3, 0.4]  # the reference's GTR test values, src/rooted_sbn_instance.hpp:357-358
+GTR_RATES = [0.05, 0.1, 0.15, 0.20, 0.25, 0.25]
+
+
+def gtr_weibull_params(tree_count: int, shape: float = 0.5, clock: bool = False) -> np.ndarray:
+    row = GTR_FREQS + GTR_RATES + [shape] + ([1.0] if clock else [])
+    return np.tile(np.array(row), (tree_count, 1))
+
+
+def load_ds1(trees: str = "DS1.100_topologies.nwk") -> Tuple[treeio.TreeCollection, SitePattern]:
+    path = os.path.join(DATA_DIR, trees)
+    tc = treeio.read_nexus_file(path) if trees.endswith(".t") else treeio.read_newick_file(path)
+    sp = SitePattern(treeio.read_fasta(os.path.join(DATA_DIR, "DS1.fasta")), tc.taxon_names)
+    return tc, sp
+
+
+def ds1_jc69(replicas: int = 1) -> Workload:
+    """BASELINE config 2: DS1, 100 topologies, every branch 0.1, JC69, log-likelihood only."""
+    tc, sp = load_ds1()
+    pid = np.tile(tc.parent_id_matrix(), (replicas, 1))
+    bl = np.full((pid.shape[0], pid.shape[1] + 1), 0.1)
+    return Workload("DS1 x100 topologies JC69 LL", "JC69", "constant", "none", sp.patterns, sp.weights, pid, bl,
+                    np.zeros((pid.shape[0], 0)), False, False)
+
+
+def ds1_gtr_weibull4(replicas: int = 1) -> Workload:
+    """BASELINE config 3 (headline): DS1, 100 topologies, GTR + weibull+4, shape 0.5,
+    branch lengths Exp(mean 0.1) clamped to [1e-6, 1] from xoshiro256** seeded with
+    20240601 + tree index; log-likelihood + branch-length gradient.  Replicas re-seed
+    with their own tree index so every tree of the batch is distinct work."""
+    tc, sp = load_ds1()
+    base = tc.parent_id_matrix()
+    pid = np.tile(base, (replicas, 1))
+    T, M1 = pid.shape
+    bl = np.zeros((T, M1 + 1))
+    for t in range(T):
+        rng = Xoshiro256ss(20240601 + t)
+        for b in range(M1):
+            bl[t, b] = min(max(rng.exponential(0.1), 1e-6), 1.0)
+    return Workload("DS1 x100 topologies GTR+weibull4 LL+grad", "GTR", "weibull+4", "none", sp.patterns, sp.weights,
+                    pid, bl, gtr_weibull_params(T), False, True)
+
+
+class _N:
+    __slots__ = ("children", "name", "length", "id")
+
+    def __init__(self, name="", children=None, length=None):
+        self.children = children or []
+        self.name = name
+        self.length = length
+        self.id = -1
+
+
+def random_unrooted_tree(n: int, rng: np.random.Generator, mean_bl: float) -> treeio.ParsedTree:
+    """Random topology by random pair joining, trifurcating at the root, ids as Node::Polish."""
+    nodes = [_N(str(i), length=rng.exponential(mean_bl)) for i in range(n)]
+    while len(nodes) > 3:
+        i, j = sorted(rng.choice(len(nodes), 2, replace=False))
+        b = nodes.pop(j)
+        a = nodes.pop(i)
+        nodes.append(_N(children=[a, b], length=rng.exponential(mean_bl)))
+    root = _N(children=nodes)
+    return treeio._polish(root, {str(i): i for i in range(n)})
+
+
+def simulate_patterns(n: int, P: int, seed: int, mean_bl: float = 0.05) -> np.ndarray:
+    """JC69 evolution down one seeded random tree -> int32 [n][P] states."""
+    rng = np.random.default_rng(seed)
+    tree = random_unrooted_tree(n, rng, mean_bl)
+    M = tree.node_count
+    children: List[List[int]] = [[] for _ in range(M)]
+    for child, parent in enumerate(tree.parent_ids):
+        children[parent].append(child)
+    states = np.zeros((M, P), dtype=np.int8)
+    states[M - 1] = rng.integers(0, 4, P)
+    for node in range(M - 1, -1, -1):
+        for ch in children[node]:
+            p_same = 0.25 + 0.75 * np.exp(-4.0 / 3.0 * tree.branch_lengths[ch])
+            change = rng.random(P) >= p_same
+            shift = rng.integers(1, 4, P)
+            states[ch] = np.where(change, (states[node] + shift) % 4, states[node])
+    return states[:n].astype(np.int32)
+
+
+def synthetic_gtr_weibull4(n: int = 1000, P: int = 10000, tree_count: int = 125, first_tree: int = 0) -> Workload:
+    """BASELINE config 4: synthetic n-taxon x P-pattern alignment (seed 1), seeded random
+    topologies (seed 2 + tree index) with Exp(0.1) branch lengths, GTR + weibull+4,
+    rescaling on, log-likelihood + gradient."""
+    patterns = simulate_patterns(n, P, seed=1)
+    trees = [random_unrooted_tree(n, np.random.default_rng(2 + first_tree + i), 0.1) for i in range(tree_count)]
+    pid = np.stack([t.parent_ids for t in trees]).astype(np.int32)
+    bl = np.stack([t.branch_lengths for t in trees])
+    bl[:, -1] = 0.0
+    return Workload(f"synthetic {n}x{P} GTR+weibull4 LL+grad", "GTR", "weibull+4", "none", patterns, np.ones(P), pid,
+                    bl, gtr_weibull_params(tree_count), True, True)

@@ -1,0 +1,180 @@
+/*
+ * bito_amd.h -- C ABI of the MI355X-native likelihood engine that replaces
+ * bito's FatBeagle/Engine path (seam 2).
+ *
+ * Plain C: opaque handle, pointers and sizes only.  One engine = one GPU
+ * (one process per GPU).  Every entry point below names the reference
+ * interface it stands in for; bito's own host code above this line (tree
+ * collections, SBN instances, pybind11 module) stays as it is -- see
+ * INTEGRATION.md for the binding a bito maintainer would add.
+ *
+ * All calls are blocking unless stated otherwise, return 0 on success and a
+ * negative BITO_AMD_ERR_* code on failure; the message is kept on the handle
+ * (bito_amd_engine_last_error) so a C++ caller can rethrow it as
+ * std::runtime_error exactly like Failwith (reference src/sugar.hpp:119-130).
+ * An engine is used by one host thread at a time; distinct engines may run
+ * concurrently (the reference's contract for FatBeagle instances,
+ * src/task_processor.hpp:96-138).
+ */
+#ifndef BITO_AMD_H
+#define BITO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BITO_AMD_OK 0
+#define BITO_AMD_ERR_BAD_MODEL (-1)  /* unknown model string (substitution_model.cpp:17, site_model.cpp:24) */
+#define BITO_AMD_ERR_BAD_PARAMS (-2) /* GTR/HKY sums off by >= 1e-3 (substitution_model.cpp:37-44,124-139) */
+#define BITO_AMD_ERR_BAD_TREE (-3)   /* parent-id vector is not a valid bito topology */
+#define BITO_AMD_ERR_BAD_ARG (-4)
+#define BITO_AMD_ERR_DEVICE (-5)     /* HIP runtime failure / no gfx950 device */
+#define BITO_AMD_ERR_STATE (-6)      /* call sequence error (e.g. run before upload) */
+
+/* Gradient request bits: the PhyloGradientFlagOptions that change what the hot
+ * path computes (reference src/phylo_flags.hpp:322-354, fat_beagle.cpp:524-616). */
+#define BITO_AMD_GRAD_SUBSTITUTION_MODEL 1
+#define BITO_AMD_GRAD_SITE_MODEL 2
+#define BITO_AMD_GRAD_CLOCK_MODEL 4
+#define BITO_AMD_GRAD_STICKBREAKING 8 /* use_stickbreaking_transform (reference default) */
+
+/* Kernel selection (diagnostics / benchmarking).  AUTO picks the LDS-resident
+ * kernel when the tree fits, the HBM-arena kernel otherwise. */
+#define BITO_AMD_KERNEL_AUTO 0
+#define BITO_AMD_KERNEL_HBM_ARENA 1
+#define BITO_AMD_KERNEL_LDS 2
+
+typedef struct bito_amd_engine bito_amd_engine;
+
+/* Replaces EngineSpecification (reference src/engine.hpp:20-24).  thread_count
+ * has no meaning on a GPU; what remains is which device this engine owns. */
+typedef struct {
+  int32_t device_id;      /* HIP device ordinal */
+  int32_t use_tip_states; /* accepted for API parity (engine.hpp:23); tips are always
+                             held as compact states, which is what BEAGLE's
+                             tip-state path computes (fat_beagle.cpp:269-275) */
+  uint64_t arena_bytes;   /* cap on the HBM PLV arena; 0 = default (1/4 of free HBM) */
+} bito_amd_engine_spec;
+
+/*
+ * Engine::Engine (reference src/engine.cpp:10-31) + FatBeagle ctor
+ * (src/fat_beagle.cpp:12-28): uploads the compressed alignment once.
+ *   substitution: "JC69" | "HKY" | "GTR"      (src/substitution_model.cpp:6-18)
+ *   site:         "constant" | "weibull+K"    (src/site_model.cpp:10-25)
+ *   clock:        "none" | "strict"           (src/clock_model.cpp:6-15)
+ *   patterns: row-major [taxon_count][pattern_count], 0..3 = ACGT, >= 4 = gap
+ *             (SitePattern::GetPatterns, src/site_pattern.cpp:16-115)
+ *   weights:  [pattern_count]                 (SitePattern::GetWeights)
+ * On failure *out is NULL and err (if given) holds the message.
+ */
+int bito_amd_engine_create(const bito_amd_engine_spec *spec, const char *substitution,
+                           const char *site, const char *clock, int32_t taxon_count,
+                           int32_t pattern_count, const int32_t *patterns,
+                           const double *weights, bito_amd_engine **out, char *err,
+                           size_t err_len);
+
+/* ~Engine / beagleFinalizeInstance (src/fat_beagle.cpp:30-36). */
+void bito_amd_engine_destroy(bito_amd_engine *e);
+
+const char *bito_amd_engine_last_error(const bito_amd_engine *e);
+
+/* Engine::GetPhyloModelBlockSpecification (src/engine.cpp:52-56):
+ * BlockSpecification::ParameterCount and GetMap (src/block_specification.hpp:60-62).
+ * Row layout [substitution | site | clock], keys alphabetical inside a model. */
+int32_t bito_amd_engine_param_count(const bito_amd_engine *e);
+int32_t bito_amd_engine_category_count(const bito_amd_engine *e);
+int32_t bito_amd_engine_block_count(const bito_amd_engine *e);
+int bito_amd_engine_block(const bito_amd_engine *e, int32_t idx, char *name,
+                          size_t name_len, int32_t *start, int32_t *len);
+
+/*
+ * Engine::LogLikelihoods (reference src/engine.cpp:58-74) ->
+ * FatBeagle::LogLikelihood (src/fat_beagle.cpp:71-98).
+ *   rooted == 0: UnrootedTree, node_count = 2n-2, trifurcating root; resolved
+ *                on the device as UnrootedTree::Detrifurcate does
+ *                (src/unrooted_tree.cpp:27-37).
+ *   rooted == 1: RootedTree, node_count = 2n-1; branch lengths are multiplied by
+ *                rates[tree][branch] (fat_beagle.cpp:86-90); rates may be NULL.
+ *   parent_ids:     [tree_count][node_count-1]  Node::ParentIdVector (src/node.hpp:182-185)
+ *   branch_lengths: [tree_count][node_count]    by child id (src/tree.cpp:16-30)
+ *   params:         [tree_count][param_count]   one row per tree (fat_beagle.hpp:177)
+ *   rescaling:      Engine's `rescaling` argument (BEAGLE manual scaling)
+ * Host pointers.  out_log_likelihoods: [tree_count].
+ */
+int bito_amd_engine_log_likelihoods(bito_amd_engine *e, int32_t tree_count, int32_t rooted,
+                                    int32_t node_count, const int32_t *parent_ids,
+                                    const double *branch_lengths, const double *rates,
+                                    const double *params, int32_t rescaling,
+                                    double *out_log_likelihoods);
+
+/*
+ * Engine::Gradients (reference src/engine.cpp:94-110) -> FatBeagle::Gradient
+ * (src/fat_beagle.cpp:510-619).  out_branch_gradients: [tree_count][2n-1]
+ * (PhyloGradient "branch_lengths"; root entry 0, unrooted fixed node 0).
+ * Optional outputs, honoured when non-NULL and the flag bit is set:
+ *   out_site_model:  [tree_count]                 "site_model"
+ *   out_subst_model: [tree_count][rates+freqs]    "substitution_model", rates first
+ *                    (row stride stays rates+freqs with the stick-breaking transform,
+ *                    which yields (rates-1 if GTR else rates)+(freqs-1) entries)
+ *   out_clock_model: [tree_count]                 "clock_model", strict clock
+ */
+int bito_amd_engine_gradients(bito_amd_engine *e, int32_t tree_count, int32_t rooted,
+                              int32_t node_count, const int32_t *parent_ids,
+                              const double *branch_lengths, const double *rates,
+                              const double *params, int32_t rescaling, int32_t flags,
+                              double fd_delta, double *out_log_likelihoods,
+                              double *out_branch_gradients, double *out_site_model,
+                              double *out_subst_model, double *out_clock_model);
+
+/* ---- HBM-resident batch interface ----------------------------------------
+ * The two calls above are upload + run + download.  Callers that keep a batch
+ * on the device across steps (vip's particle loop re-evaluates the same
+ * topologies with new branch lengths every step, reference vip/burrito.py:84-117)
+ * use the split form; bench.py times bito_amd_engine_run with inputs resident. */
+
+/* Host -> HBM.  Same argument meaning as bito_amd_engine_log_likelihoods. */
+int bito_amd_engine_upload(bito_amd_engine *e, int32_t tree_count, int32_t rooted,
+                           int32_t node_count, const int32_t *parent_ids,
+                           const double *branch_lengths, const double *rates,
+                           const double *params);
+/* Refresh only branch lengths / params of the resident batch (either may be NULL). */
+int bito_amd_engine_update(bito_amd_engine *e, const double *branch_lengths,
+                           const double *params);
+/* Enqueue one pass of the hot path over the resident batch on the engine's HIP
+ * stream (asynchronous): per-tree model setup + eigendecomposition, transition
+ * matrices, partial-likelihood traversal, (gradient) pre-order pass and edge
+ * derivatives, per-tree reductions.  want_gradient: 0 = LogLikelihoods, 1 = Gradients. */
+int bito_amd_engine_run(bito_amd_engine *e, int32_t want_gradient, int32_t rescaling);
+/* Wait for the stream; reports per-tree validation errors found on the device. */
+int bito_amd_engine_sync(bito_amd_engine *e);
+/* HBM -> caller.  Destinations may be host or device pointers (hipMemcpyDefault);
+ * out_branch_gradients may be NULL. */
+int bito_amd_engine_download(bito_amd_engine *e, double *out_log_likelihoods,
+                             double *out_branch_gradients);
+
+/* Diagnostics / benchmarking. */
+int bito_amd_engine_set_kernel(bito_amd_engine *e, int32_t kernel);
+/* Runs `steps` passes back to back with HIP events on the engine's stream.
+ * total_ms: wall time of all steps; kernel_ms: summed duration of the dominant
+ * (traversal) kernel only; kernel_launches: how many such launches that was. */
+int bito_amd_engine_time_runs(bito_amd_engine *e, int32_t want_gradient, int32_t rescaling,
+                              int32_t steps, double *total_ms, double *kernel_ms,
+                              int32_t *kernel_launches);
+/* Event timing of the traversal kernel inside ordinary bito_amd_engine_run calls:
+ * enable, run any number of passes, sync, then read the summed duration of the
+ * traversal-kernel launches since enabling (HIP events recorded on the engine's
+ * stream around each launch).  Reading resets the accumulation. */
+int bito_amd_engine_kernel_timing(bito_amd_engine *e, int32_t enable);
+int bito_amd_engine_kernel_elapsed(bito_amd_engine *e, double *kernel_ms, int32_t *kernel_launches);
+/* Name of the traversal kernel the last run used (for matching rocprof rows). */
+const char *bito_amd_engine_kernel_name(const bito_amd_engine *e);
+/* Library/device info string, e.g. "bito_amd 0.1 gfx950 256CU". */
+const char *bito_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BITO_AMD_H */

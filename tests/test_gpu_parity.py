@@ -1,0 +1,316 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle and the
+reference's golden values.  Needs a real MI355X: run with ``-m gpu``.
+
+Tolerances (BASELINE.json north_star): 1e-10 on log-likelihoods, 1e-6 on gradients;
+for log-likelihoods whose magnitude makes 1e-10 smaller than a few ulps the bound is
+relative (LL_RTOL).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bito_amd
+from bito_amd import _capi, treeio, workloads
+from bito_amd.site_pattern import SitePattern
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_goldens.json")) as fh:
+    GOLD = json.load(fh)
+
+LL_ATOL = 1e-10
+LL_RTOL = 2e-14
+GRAD_ATOL = 1e-6
+GRAD_RTOL = 1e-9
+
+
+def ll_close(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.all(np.abs(a - b) <= LL_ATOL + LL_RTOL * np.abs(b))
+
+
+def grad_close(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.all(np.abs(a - b) <= GRAD_ATOL + GRAD_RTOL * np.abs(b))
+
+
+def spec(sub, site, clock="none"):
+    return bito_amd.PhyloModelSpecification(sub, site, clock)
+
+
+def engines(sub, site, clock, patterns, weights, threads=8):
+    gpu = bito_amd.Engine(spec(sub, site, clock), patterns, weights)
+    cpu = oracle.OracleEngine(sub, site, clock, patterns, weights, threads)
+    return gpu, cpu
+
+
+def load(data_dir, fasta, trees):
+    path = os.path.join(data_dir, trees)
+    tc = treeio.read_nexus_file(path) if trees.endswith(".t") else treeio.read_newick_file(path)
+    sp = SitePattern(treeio.read_fasta(os.path.join(data_dir, fasta)), tc.taxon_names)
+    return tc, sp
+
+
+def test_hello_jc69_instance_api(data_dir):
+    """Reads like the reference's own test (src/unrooted_sbn_instance.hpp:236-244)."""
+    inst = bito_amd.unrooted_instance("charlie")
+    inst.read_newick_file(os.path.join(data_dir, "hello.nwk"), False)
+    inst.read_fasta_file(os.path.join(data_dir, "hello.fasta"))
+    inst.prepare_for_phylo_likelihood(spec("JC69", "constant", "strict"), 2)
+    for ll in inst.log_likelihoods():
+        assert abs(ll - -84.852358) < 0.000001
+    grads = inst.phylo_gradients()
+    assert abs(grads[0].log_likelihood - -84.852358) < 0.000001
+    assert grads[0].gradient["branch_lengths"].shape == (5,)
+
+
+@pytest.mark.parametrize("rescaling", [False, True])
+def test_ds1_jc69_goldens(data_dir, rescaling):
+    g = GOLD["ds1_jc69"]
+    tc, sp = load(data_dir, g["fasta"], g["trees"])
+    gpu, cpu = engines("JC69", "constant", "strict", sp.patterns, sp.weights)
+    pid, bl = tc.parent_id_matrix(), tc.branch_length_matrix()
+    ll = gpu.log_likelihoods(pid, bl, rescaling=rescaling)
+    assert np.abs(ll - g["log_likelihoods"]).max() < 5e-10  # 17-digit pybeagle values
+    assert ll_close(ll, cpu.log_likelihoods(pid, bl, rescaling=rescaling))
+    out = gpu.gradients(pid, bl, rescaling=rescaling)
+    ref = cpu.gradients(pid, bl, rescaling=rescaling)
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    last = np.sort(out["branch_lengths"][-1])
+    assert np.abs(last - g["last_tree_sorted_branch_gradient"]).max() < g["gradient_tol"]
+    assert out["branch_lengths"][-1][-1] == 0.0 and out["branch_lengths"][-1][-2] == 0.0
+
+
+def test_ds1_jc69_weibull_goldens(data_dir):
+    g = GOLD["ds1_jc69_weibull4_shape0.1"]
+    tc, sp = load(data_dir, g["fasta"], g["trees"])
+    gpu, cpu = engines("JC69", "weibull+4", "strict", sp.patterns, sp.weights)
+    params = gpu.default_params(len(tc.trees))
+    params[:, gpu.block_map()["Weibull_shape"][0]] = g["shape"]
+    pid, bl = tc.parent_id_matrix(), tc.branch_length_matrix()
+    for rescaling in (False, True):
+        ll = gpu.log_likelihoods(pid, bl, params, rescaling=rescaling)
+        assert np.abs(ll - g["log_likelihoods"]).max() < 5e-10
+        out = gpu.gradients(pid, bl, params, rescaling=rescaling)
+        assert np.abs(out["branch_lengths"][:, 0] - g["branch_gradient_entry0"]).max() < 2e-6
+        ref = cpu.gradients(pid, bl, params, rescaling=rescaling)
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+        assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+
+
+def test_config2_ds1_jc69_100_topologies():
+    w = workloads.ds1_jc69(1)
+    gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights)
+    ll = gpu.log_likelihoods(w.parent_ids, w.branch_lengths, w.params)
+    assert ll_close(ll, cpu.log_likelihoods(w.parent_ids, w.branch_lengths, w.params))
+    # JC69 == GTR with equal rates and frequencies (reference test/test_bito.py:97-122)
+    gtr = bito_amd.Engine(spec("GTR", "constant"), w.patterns, w.weights)
+    ll_gtr = gtr.log_likelihoods(w.parent_ids, w.branch_lengths)
+    assert np.abs(ll - ll_gtr).max() < 1e-9
+
+
+def test_config3_ds1_gtr_weibull4_vs_oracle():
+    w = workloads.ds1_gtr_weibull4(1)
+    gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights)
+    out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    assert ll_close(gpu.log_likelihoods(w.parent_ids, w.branch_lengths, w.params), ref["log_likelihood"])
+    # rescaled == unrescaled (reference src/unrooted_sbn_instance.hpp:289-311)
+    res = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
+    assert np.abs(res["log_likelihood"] - out["log_likelihood"]).max() < 1e-9
+    assert grad_close(res["branch_lengths"], out["branch_lengths"])
+
+
+def test_flua_rooted_with_rates(data_dir):
+    g = GOLD["flua_jc69_strict"]
+    tc, sp = load(data_dir, "fluA.fa", "fluA.tree")
+    rates = np.full((1, tc.trees[0].node_count - 1), g["clock_rate"])
+    pid, bl = tc.parent_id_matrix(), tc.branch_length_matrix()
+    gpu, cpu = engines("JC69", "constant", "strict", sp.patterns, sp.weights, 1)
+    ll = gpu.log_likelihoods(pid, bl, rates=rates)
+    assert abs(ll[0] - g["log_likelihood"]) < 2e-6
+    out = gpu.gradients(pid, bl, rates=rates, flags=_capi.GRAD_CLOCK_MODEL)
+    ref = cpu.gradients(pid, bl, rates=rates, flags=oracle.GRAD_CLOCK_MODEL)
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert np.abs(out["branch_lengths"] - ref["branch_lengths"]).max() < 1e-6 * max(1.0, np.abs(ref["branch_lengths"]).max())
+    assert abs(out["clock_model"][0] - ref["clock_model"][0]) < 1e-6 * abs(ref["clock_model"][0])
+    # GTR / HKY log-likelihood goldens of the reference (pinned to 1e-3 / 1e-4 there)
+    for key, sub, row in (("flua_gtr", "GTR", GOLD["flua_gtr"]["frequencies"] + GOLD["flua_gtr"]["rates"]),
+                          ("flua_hky", "HKY", GOLD["flua_hky"]["frequencies"] + [GOLD["flua_hky"]["kappa"]])):
+        gpu2, cpu2 = engines(sub, "constant", "strict", sp.patterns, sp.weights, 1)
+        params = gpu2.default_params(1)
+        params[0, :len(row)] = row
+        ll2 = gpu2.log_likelihoods(pid, bl, params, rates=rates)
+        assert abs(ll2[0] - GOLD[key]["log_likelihood"]) < GOLD[key]["tol"]
+        assert ll_close(ll2, cpu2.log_likelihoods(pid, bl, params, rates=rates))
+
+
+@pytest.mark.parametrize("categories", [1, 2, 3, 5, 8])
+def test_category_counts(categories):
+    w = workloads.ds1_gtr_weibull4(1).subset(6)
+    site = f"weibull+{categories}"
+    gpu, cpu = engines("HKY", site, "none", w.patterns, w.weights, 4)
+    params = gpu.default_params(6)
+    bm = gpu.block_map()
+    params[:, bm["substitution_model_frequencies"][0]:][:, :4] = [0.3, 0.2, 0.1, 0.4]
+    params[:, bm["substitution_model_rates"][0]] = np.linspace(0.5, 4.0, 6)
+    params[:, bm["Weibull_shape"][0]] = np.linspace(0.3, 2.0, 6)
+    for rescaling in (False, True):
+        out = gpu.gradients(w.parent_ids, w.branch_lengths, params, rescaling=rescaling)
+        ref = cpu.gradients(w.parent_ids, w.branch_lengths, params, rescaling=rescaling)
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+        assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+
+
+def test_edge_cases(data_dir):
+    tc, sp = load(data_dir, "hello.fasta", "hello.nwk")
+    pid, bl = tc.parent_id_matrix(), tc.branch_length_matrix()
+    # one pattern; an all-gap column; heavy weights
+    for patterns, weights in (
+        (sp.patterns[:, :1], sp.weights[:1]),
+        (np.full((3, 1), 4, dtype=np.int32), np.array([7.0])),
+        (np.concatenate([sp.patterns, np.full((3, 2), 4, dtype=np.int32)], axis=1),
+         np.concatenate([sp.weights, [3.0, 1e6]])),
+    ):
+        gpu, cpu = engines("JC69", "weibull+4", "none", patterns, weights, 1)
+        out = gpu.gradients(pid, bl)
+        ref = cpu.gradients(pid, bl)
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+        assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    # zero and tiny branch lengths
+    gpu, cpu = engines("GTR", "constant", "none", sp.patterns, sp.weights, 1)
+    bl0 = bl.copy()
+    bl0[0, 0] = 0.0
+    bl0[0, 1] = 1e-12
+    out = gpu.gradients(pid, bl0)
+    ref = cpu.gradients(pid, bl0)
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    # two-taxon rooted tree: the smallest bifurcating tree
+    pats = sp.patterns[:2]
+    gpu, cpu = engines("JC69", "constant", "none", pats, sp.weights, 1)
+    pid2 = np.array([[2, 2]], dtype=np.int32)
+    bl2 = np.array([[0.1, 0.25, 0.0]])
+    out = gpu.gradients(pid2, bl2)
+    ref = cpu.gradients(pid2, bl2)
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+
+
+def test_pattern_counts_around_tile_edges():
+    w = workloads.ds1_gtr_weibull4(1).subset(3)
+    for P in (63, 64, 65, 255, 256, 257, 934):
+        gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns[:, :P], w.weights[:P], 3)
+        out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+        ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"]), P
+        assert grad_close(out["branch_lengths"], ref["branch_lengths"]), P
+
+
+def test_resident_batch_interface():
+    w = workloads.ds1_gtr_weibull4(1).subset(20)
+    gpu = bito_amd.Engine(spec(w.substitution, w.site, w.clock), w.patterns, w.weights)
+    direct = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+    gpu.upload(w.parent_ids, w.branch_lengths, w.params)
+    gpu.run(True)
+    gpu.sync()
+    ll, grad = gpu.download()
+    assert np.array_equal(ll, direct["log_likelihood"]) and np.array_equal(grad, direct["branch_lengths"])
+    # new branch lengths and parameters without re-uploading the topologies
+    bl2 = w.branch_lengths * 1.5
+    p2 = w.params.copy()
+    p2[:, 10] = 0.8
+    gpu.update(bl2, p2)
+    gpu.run(True)
+    ll2, grad2 = gpu.download()
+    fresh = bito_amd.Engine(spec(w.substitution, w.site, w.clock), w.patterns, w.weights)
+    again = fresh.gradients(w.parent_ids, bl2, p2)
+    assert np.array_equal(ll2, again["log_likelihood"]) and np.array_equal(grad2, again["branch_lengths"])
+    total, kern, launches = gpu.time_runs(True, False, 3)
+    assert total > 0 and kern > 0 and launches >= 3 and kern <= total * 1.05
+
+
+def test_full_size_batch_properties():
+    """BASELINE config 3 at bench size: per-tree results do not depend on what else is
+    in the batch, are bit-reproducible, and agree with the oracle on a sample."""
+    w = workloads.ds1_gtr_weibull4(8)  # 800 trees
+    gpu = bito_amd.Engine(spec(w.substitution, w.site, w.clock), w.patterns, w.weights)
+    full = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+    again = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert np.array_equal(full["log_likelihood"], again["log_likelihood"])
+    assert np.array_equal(full["branch_lengths"], again["branch_lengths"])
+    sl = slice(300, 400)
+    part = gpu.gradients(w.parent_ids[sl], w.branch_lengths[sl], w.params[sl])
+    assert np.array_equal(part["log_likelihood"], full["log_likelihood"][sl])
+    assert np.array_equal(part["branch_lengths"], full["branch_lengths"][sl])
+    cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
+    idx = np.arange(0, 800, 37)
+    ref = cpu.gradients(w.parent_ids[idx], w.branch_lengths[idx], w.params[idx])
+    assert ll_close(full["log_likelihood"][idx], ref["log_likelihood"])
+    assert grad_close(full["branch_lengths"][idx], ref["branch_lengths"])
+    # permuting the site patterns changes nothing beyond summation order
+    perm = np.random.default_rng(0).permutation(w.patterns.shape[1])
+    gpu_p = bito_amd.Engine(spec(w.substitution, w.site, w.clock), w.patterns[:, perm], w.weights[perm])
+    permuted = gpu_p.gradients(w.parent_ids[:50], w.branch_lengths[:50], w.params[:50])
+    assert np.abs(permuted["log_likelihood"] - full["log_likelihood"][:50]).max() < 1e-9
+    assert grad_close(permuted["branch_lengths"], full["branch_lengths"][:50])
+
+
+def test_large_tree_with_rescaling_vs_oracle():
+    """Config-4-shaped input (many taxa, rescaling on) at a size the oracle finishes in seconds."""
+    w = workloads.synthetic_gtr_weibull4(n=300, P=1500, tree_count=3)
+    gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 3)
+    out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    assert np.all(np.isfinite(out["branch_lengths"]))
+
+
+def test_config4_full_size_two_trees():
+    """BASELINE config 4 shape (1000 taxa x 10000 patterns): two trees against the oracle."""
+    w = workloads.synthetic_gtr_weibull4(n=1000, P=10000, tree_count=2)
+    gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 2)
+    out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
+    assert np.all(np.isfinite(out["log_likelihood"]))
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert np.abs(out["branch_lengths"] - ref["branch_lengths"]).max() <= GRAD_ATOL + 1e-9 * np.abs(ref["branch_lengths"]).max()
+
+
+def test_error_behaviour(data_dir):
+    tc, sp = load(data_dir, "hello.fasta", "hello.nwk")
+    pid, bl = tc.parent_id_matrix(), tc.branch_length_matrix()
+    with pytest.raises(bito_amd.BitoAmdError, match="Substitution model not known"):
+        bito_amd.Engine(spec("F81", "constant"), sp.patterns, sp.weights)
+    with pytest.raises(bito_amd.BitoAmdError, match="Site model not known"):
+        bito_amd.Engine(spec("JC69", "gamma"), sp.patterns, sp.weights)
+    with pytest.raises(bito_amd.BitoAmdError, match="Clock model not known"):
+        bito_amd.Engine(spec("JC69", "constant", "relaxed"), sp.patterns, sp.weights)
+    eng = bito_amd.Engine(spec("GTR", "constant"), sp.patterns, sp.weights)
+    bad = eng.default_params(1)
+    bad[0, 0] = 0.5
+    with pytest.raises(bito_amd.BitoAmdError, match="frequencies do not sum to 1"):
+        eng.log_likelihoods(pid, bl, bad)
+    bad = eng.default_params(1)
+    bad[0, 5] = 0.9
+    with pytest.raises(bito_amd.BitoAmdError, match="rates do not sum to 1"):
+        eng.log_likelihoods(pid, bl, bad)
+    with pytest.raises(bito_amd.BitoAmdError, match="param matrix"):
+        eng.log_likelihoods(pid, bl, eng.default_params(2))
+    with pytest.raises(bito_amd.BitoAmdError, match="not a valid internal id"):
+        eng.log_likelihoods(np.array([[3, 3, 1]], dtype=np.int32), bl)
+    with pytest.raises(bito_amd.BitoAmdError, match="does not match"):
+        eng.log_likelihoods(np.array([[4, 4, 5, 5, 6, 6]], dtype=np.int32), np.ones((1, 7)))
+    fresh = bito_amd.Engine(spec("JC69", "constant"), sp.patterns, sp.weights)
+    with pytest.raises(bito_amd.BitoAmdError, match="no batch is resident"):
+        fresh.run(False)
+    # the engine is still usable after an error
+    assert np.isfinite(eng.log_likelihoods(pid, bl)[0])

@@ -1,0 +1,143 @@
+"""CPU-side tests: host conventions (trees, alignments, site patterns, workloads), the
+C ABI library (loads, exports every declared symbol, fails loudly without a GPU).
+No compute call reaches a GPU here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bito_amd
+from bito_amd import _capi, treeio, workloads
+from bito_amd.site_pattern import SitePattern, symbol_vector
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _have_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_header_symbols_are_exported():
+    header = open(os.path.join(ROOT, "include", "bito_amd.h")).read()
+    declared = set(re.findall(r"\b(bito_amd_[a-z_]+)\s*\(", header))
+    assert declared == set(_capi.SYMBOLS)
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libbito_amd.so does not export {name}"
+    assert bito_amd.version().startswith("bito_amd")
+
+
+def test_no_signature_leaks_torch_or_cxx_types():
+    header = open(os.path.join(ROOT, "include", "bito_amd.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)  # declarations only, comments stripped
+    assert "torch" not in code and "std::" not in code and "hip" not in code.lower() and "&" not in code
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
+def test_engine_creation_fails_loudly_without_gpu():
+    spec = bito_amd.PhyloModelSpecification("JC69", "constant", "none")
+    with pytest.raises(bito_amd.BitoAmdError) as exc:
+        bito_amd.Engine(spec, np.zeros((3, 5), dtype=np.int32), np.ones(5))
+    assert exc.value.code == _capi.ERR_DEVICE and "no CPU fallback" in str(exc.value)
+
+
+def test_model_errors_precede_device_errors():
+    with pytest.raises(bito_amd.BitoAmdError, match="Substitution model not known"):
+        bito_amd.Engine(bito_amd.PhyloModelSpecification("K80", "constant", "none"),
+                        np.zeros((3, 5), dtype=np.int32), np.ones(5))
+    with pytest.raises(bito_amd.BitoAmdError, match="Site model not known"):
+        bito_amd.Engine(bito_amd.PhyloModelSpecification("JC69", "invgamma", "none"),
+                        np.zeros((3, 5), dtype=np.int32), np.ones(5))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "bito_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("CPU oracle and GPU engine", ""), f"{f} mentions the oracle"
+
+
+def test_newick_ids_follow_polish(data_dir):
+    tc = treeio.read_newick_file(os.path.join(data_dir, "hello.nwk"))
+    assert tc.taxon_names == ["mars", "saturn", "jupiter"]
+    t = tc.trees[0]
+    assert not t.rooted and t.node_count == 4
+    assert list(t.parent_ids) == [3, 3, 3]
+    assert np.allclose(t.branch_lengths, [0.1, 0.1, 0.3, 0.0])
+    tc = treeio.read_newick_file(os.path.join(data_dir, "hello.nwk"), sort_taxa=True)
+    assert tc.taxon_names == ["jupiter", "mars", "saturn"]
+    tc = treeio.read_newick_file(os.path.join(data_dir, "hello_rooted.nwk"))
+    t = tc.trees[0]
+    # (jupiter,(mars,saturn)): leaves 0,1,2 by first appearance; inner node 3; root 4
+    assert t.rooted and list(t.parent_ids) == [4, 3, 3, 4]
+    assert np.allclose(t.branch_lengths, [0.0594247559, 0.2072560544, 0.0694244266, 0.01, 0.0])
+
+
+def test_parse_inline_newick_features():
+    coll = treeio.parse_newick_strings(["tree t1 = [&U] ('a b':1e-1[&x=1],(c:2,d:3)lab:0.5,e);"])
+    assert coll.taxon_names == ["a b", "c", "d", "e"]
+    t = coll.trees[0]
+    assert list(t.parent_ids) == [5, 4, 4, 5, 5]
+    assert np.allclose(t.branch_lengths, [0.1, 2, 3, 0, 0.5, 0])
+    with pytest.raises(RuntimeError, match="not known in our taxon set"):
+        treeio.parse_newick_strings(["(a,b,c);", "(a,b,z);"])
+    with pytest.raises(RuntimeError, match="Float conversion failed"):
+        treeio.parse_newick_strings(["(a:x,b,c);"])
+
+
+def test_nexus_translate_order(data_dir):
+    tc = treeio.read_nexus_file(os.path.join(data_dir, "DS1.subsampled_10.t"))
+    assert len(tc.trees) == 10 and len(tc.taxon_names) == 27
+    assert tc.taxon_names[0] == "Alligator_mississippiensis" and tc.taxon_names[26] == "Xenopus_laevis"
+    for t in tc.trees:
+        assert t.node_count == 52 and not t.rooted
+        # post-order ids: every parent id exceeds its children
+        assert np.all(t.parent_ids > np.arange(51))
+
+
+def test_parent_id_vector_round_trip():
+    t = treeio.tree_from_parent_ids([5, 5, 6, 7, 7, 6, 8, 8])  # reference src/unrooted_sbn_instance.hpp:225-226
+    assert t.leaf_count == 5 and t.rooted and t.node_count == 9
+
+
+def test_site_pattern_compression(data_dir):
+    tc = treeio.read_newick_file(os.path.join(data_dir, "hello.nwk"))
+    sp = SitePattern(treeio.read_fasta(os.path.join(data_dir, "hello.fasta")), tc.taxon_names)
+    assert sp.patterns.shape == (3, 15) and sp.weights.sum() == 31 and sp.patterns.max() == 4
+    # symbol table of the reference (src/site_pattern.hpp:64-69): degenerate codes are gaps
+    assert list(symbol_vector("-tgcaTGCA?")) == [4, 3, 2, 1, 0, 3, 2, 1, 0, 4]
+    assert list(symbol_vector("RYKMSWBDHVN")) == [4] * 11
+    with pytest.raises(RuntimeError, match="Symbol 'Z' not known"):
+        symbol_vector("ACZ")
+    part = sp.partials(0).reshape(15, 4)
+    gap = sp.patterns[0] == 4
+    assert np.all(part[gap] == 1.0) and np.all(part[~gap].sum(axis=1) == 1.0)
+    # expansion by weights reproduces the column multiset
+    tc2, sp2 = workloads.load_ds1("DS1.subsampled_10.t")
+    assert sp2.patterns.shape == (27, 934) and sp2.weights.sum() == 1949
+    with pytest.raises(RuntimeError, match="not found in alignment"):
+        SitePattern({"mars": "A"}, ["mars", "venus"])
+
+
+def test_workloads_are_deterministic():
+    a = workloads.ds1_gtr_weibull4(1)
+    b = workloads.ds1_gtr_weibull4(2)
+    assert a.parent_ids.shape == (100, 51) and b.tree_count == 200
+    assert np.array_equal(a.branch_lengths, b.branch_lengths[:100])
+    assert not np.array_equal(b.branch_lengths[:100], b.branch_lengths[100:])
+    assert a.branch_lengths[:, :51].min() >= 1e-6 and a.branch_lengths.max() <= 1.0
+    assert np.all(a.branch_lengths[:, 51] == 0.0)
+    rng = workloads.Xoshiro256ss(20240601)
+    assert rng.next_u64() != rng.next_u64()
+    s = workloads.synthetic_gtr_weibull4(12, 40, 3)
+    t = workloads.synthetic_gtr_weibull4(12, 40, 3)
+    assert np.array_equal(s.patterns, t.patterns) and np.array_equal(s.parent_ids, t.parent_ids)
+    assert s.parent_ids.shape == (3, 21) and np.all(s.parent_ids > np.arange(21))
+    sh = [a.shard(r, 8) for r in range(8)]
+    assert sum(x.tree_count for x in sh) == 100
+    assert np.array_equal(np.concatenate([x.branch_lengths for x in sh]), a.branch_lengths)
