@@ -43,15 +43,23 @@ def cpu_baseline(w, seconds: float):
 
     threads = os.cpu_count() or 1
     eng = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, threads)
-    probe = min(w.tree_count, max(2 * threads, 8))
     run = eng.gradients if w.want_gradient else eng.log_likelihoods
-    run(w.parent_ids[:probe], w.branch_lengths[:probe], w.params[:probe], rescaling=w.rescaling)  # warm-up
+
+    def sample(count):
+        reps = -(-count // w.tree_count)
+        return (np.tile(w.parent_ids, (reps, 1))[:count], np.tile(w.branch_lengths, (reps, 1))[:count],
+                np.tile(w.params, (reps, 1))[:count])
+
+    probe = max(4 * threads, 64)
+    pid, bl, par = sample(probe)
+    run(pid, bl, par, rescaling=w.rescaling)  # warm-up: first touch of every thread's buffers
     t0 = time.perf_counter()
-    run(w.parent_ids[:probe], w.branch_lengths[:probe], w.params[:probe], rescaling=w.rescaling)
+    run(pid, bl, par, rescaling=w.rescaling)
     rate = probe / (time.perf_counter() - t0)
-    count = int(min(w.tree_count, max(probe, rate * seconds)))
+    count = int(max(probe, rate * seconds))
+    pid, bl, par = sample(count)
     t0 = time.perf_counter()
-    run(w.parent_ids[:count], w.branch_lengths[:count], w.params[:count], rescaling=w.rescaling)
+    run(pid, bl, par, rescaling=w.rescaling)
     dt = time.perf_counter() - t0
     return {"value": count / dt, "unit": "trees/s", "cores": threads, "kind": "port",
             "sample": f"{count} trees of the same workload, {dt:.1f} s, oracle/bito_oracle.c with {threads} threads "
@@ -208,7 +216,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(full.subset(min(full.tree_count, 4000)), args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(full, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -81,6 +81,8 @@ void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b
 
 __global__ void __launch_bounds__(256)
 transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient) {
+// No FMA contraction and a fixed summation order here: see model.hpp.
+#pragma clang fp contract(off)
   const int C = d.category_count, NB = d.node_count - 1;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)d.tree_count * NB * C;
@@ -92,33 +94,44 @@ transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient) {
   const TreeModel* __restrict__ m = b.model + t;
   const double rate = m->cat_rate[c];
   const double time = b.branch[(size_t)t * d.node_count + br] * rate;
-  double e[4], de[4];
+  double e[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    e[k] = exp(m->lambda[k] * time);
-    de[k] = m->lambda[k] * rate * e[k];
-  }
+  for (int k = 0; k < 4; k++) e[k] = exp(m->lambda[k] * time);
+  double P[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) s += m->V[i * 4 + k] * e[k] * m->Vinv[k * 4 + j];
+      P[i * 4 + j] = s;
+    }
   double* out = b.mats + idx * kMatStride;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      double s = 0, ds = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const double vv = m->V[i * 4 + k] * m->Vinv[k * 4 + j];
-        s += vv * e[k];
-        ds += vv * de[k];
-      }
-      out[kMatP + i * 4 + j] = s;
-      out[kMatPT + j * 4 + i] = s;
-      if (want_gradient) {
-        out[kMatDP + i * 4 + j] = ds;
-        out[kMatDPT + j * 4 + i] = ds;
-      }
+      out[kMatP + i * 4 + j] = P[i * 4 + j];
+      out[kMatPT + j * 4 + i] = P[i * 4 + j];
     }
     out[kMatPT + 16 + i] = 1.0;   // gap: the all-ones column BEAGLE appends
     out[kMatDPT + 16 + i] = 0.0;  // Q 1 = 0
+  }
+  if (want_gradient) {
+    // dP/dt = P (r_c Q): the differential matrix of the reference
+    // (BuildDifferentialMatrices, fat_beagle.cpp:101-111) folded into the branch's
+    // transition matrix, so that  pre^T (r_c Q) post  ==  (u . a_sibling)^T dP x.
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s += P[i * 4 + k] * (m->Q[k * 4 + j] * rate);
+        out[kMatDP + i * 4 + j] = s;
+        out[kMatDPT + j * 4 + i] = s;
+      }
   }
 }
 

@@ -28,14 +28,32 @@ GRAD_ATOL = 1e-6
 GRAD_RTOL = 1e-9
 
 
+class _Close:
+    """Truthy when |a-b| <= atol + rtol*|b| everywhere; repr shows the worst offender."""
+
+    def __init__(self, a, b, atol, rtol):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        self.err = np.abs(a - b)
+        self.bound = atol + rtol * np.abs(b)
+        self.ok = bool(np.all(self.err <= self.bound)) and a.shape == b.shape
+        k = int(np.argmax(self.err - self.bound)) if self.err.size else 0
+        self.msg = (f"max|a-b|={self.err.max() if self.err.size else 0:.3e} at flat index {k}: "
+                    f"a={a.reshape(-1)[k] if a.size else None!r} b={b.reshape(-1)[k] if b.size else None!r} "
+                    f"bound={self.bound.reshape(-1)[k] if self.err.size else 0:.3e}")
+
+    def __bool__(self):
+        return self.ok
+
+    def __repr__(self):
+        return self.msg
+
+
 def ll_close(a, b):
-    a, b = np.asarray(a), np.asarray(b)
-    return np.all(np.abs(a - b) <= LL_ATOL + LL_RTOL * np.abs(b))
+    return _Close(a, b, LL_ATOL, LL_RTOL)
 
 
 def grad_close(a, b):
-    a, b = np.asarray(a), np.asarray(b)
-    return np.all(np.abs(a - b) <= GRAD_ATOL + GRAD_RTOL * np.abs(b))
+    return _Close(a, b, GRAD_ATOL, GRAD_RTOL)
 
 
 def spec(sub, site, clock="none"):
