@@ -69,8 +69,8 @@ struct bito_amd_engine {
   BatchDims dims{};
   bool has_rates = false;
   DeviceBuffer<int32_t> parent_ids, children;
-  DeviceBuffer<double> branch_in, rates, params, branch, mats, arena, part_ll, part_grad, out_ll,
-      out_grad;
+  DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
+      out_ll, out_grad;
   DeviceBuffer<TreeModel> model;
   // host mirrors for the composed gradients
   std::vector<double> h_params;
@@ -83,7 +83,7 @@ struct bito_amd_engine {
     (void)hipSetDevice(device);
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
     tip_states.Free(); weights.Free(); parent_ids.Free(); children.Free(); branch_in.Free();
-    rates.Free(); params.Free(); branch.Free(); mats.Free(); arena.Free(); part_ll.Free();
+    rates.Free(); params.Free(); branch.Free(); mats.Free(); images.Free(); arena.Free(); part_ll.Free();
     part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free();
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -242,6 +242,7 @@ DeviceBatch MakeBatch(bito_amd_engine* e) {
   b.branch = e->branch.ptr;
   b.model = e->model.ptr;
   b.mats = e->mats.ptr;
+  b.images = e->images.ptr;
   b.arena = e->arena.ptr;
   b.part_ll = e->part_ll.ptr;
   b.part_grad = e->part_grad.ptr;
@@ -264,15 +265,44 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling) {
   HIP_TRY(e, hipSetDevice(e->device));
   const BatchDims& d = e->dims;
   const int T = d.tree_count;
-  const int tiles = HbmTiles(d.pattern_count);
+  const size_t NB = (size_t)d.node_count - 1;
+  // Kernel choice: the LDS-resident MFMA walk when the tree fits in LDS and no rescaling
+  // is requested, otherwise the HBM-arena walk.
+  const LdsPlan plan = PlanLds(d);
+  bool use_lds = plan.groups > 0 && !rescaling;
+  if (e->kernel_choice == BITO_AMD_KERNEL_HBM_ARENA) use_lds = false;
+  if (e->kernel_choice == BITO_AMD_KERNEL_LDS && !use_lds)
+    return Fail(e, BITO_AMD_ERR_STATE,
+                "the LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, "
+                "no rescaling, and a tree whose PLVs fit in 160 KB of LDS)");
+  const int tiles = use_lds ? plan.tiles : HbmTiles(d.pattern_count);
+  HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
+  if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
+  if (use_lds) {
+    HIP_TRY(e, e->images.Reserve((size_t)T * NB * kImgStride));
+    const DeviceBatch b = MakeBatch(e);
+    LaunchSetup(d, e->spec, b, want_gradient, e->stream);
+    LaunchMatrixImages(d, b, want_gradient, e->stream);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e->timing) {
+      ev0 = NextEvent(e);
+      ev1 = NextEvent(e);
+      HIP_TRY(e, hipEventRecord(ev0, e->stream));
+    }
+    LaunchWalkLds(d, b, plan, want_gradient, e->stream);
+    if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
+    e->kernel_name = "walk_lds_kernel";
+    LaunchReduce(d, b, tiles, want_gradient, e->stream);
+    HIP_TRY(e, hipGetLastError());
+    return BITO_AMD_OK;
+  }
   // scratch sized for this run
+  HIP_TRY(e, e->mats.Reserve((size_t)T * NB * d.category_count * kMatStride));
   const size_t per_tree = HbmArenaBytesPerTree(d);
   size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
   // grid.y limit
   chunk = std::min<size_t>(chunk, 65535);
   HIP_TRY(e, e->arena.Reserve(chunk * per_tree / sizeof(double)));
-  HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
-  if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
   const DeviceBatch b = MakeBatch(e);
   LaunchSetup(d, e->spec, b, want_gradient, e->stream);
   LaunchMatrices(d, b, want_gradient, e->stream);
@@ -354,7 +384,8 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
     return dev_fail("hipStreamCreate", hrc);
   e->n = taxon_count;
   e->P = pattern_count;
-  e->Ppad = (pattern_count + kHbmBlock - 1) / kHbmBlock * kHbmBlock;
+  // padded so that every kernel's last tile (at most 512 patterns wide) stays in bounds
+  e->Ppad = (pattern_count + 512 + kHbmBlock - 1) / kHbmBlock * kHbmBlock;
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
   e->arena_limit = (spec && spec->arena_bytes) ? spec->arena_bytes : std::max<size_t>(free_b / 4, (size_t)1 << 28);
@@ -419,7 +450,6 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   HIP_TRY(e, e->children.Reserve(T * (n - 1) * 2));
   HIP_TRY(e, e->branch.Reserve(T * N));
   HIP_TRY(e, e->model.Reserve(T));
-  HIP_TRY(e, e->mats.Reserve(T * (N - 1) * C * kMatStride));
   HIP_TRY(e, e->out_ll.Reserve(T));
   HIP_TRY(e, e->out_grad.Reserve(T * N));
   HIP_TRY(e, hipMemcpyAsync(e->parent_ids.ptr, parent_ids, T * (M - 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));

@@ -29,6 +29,15 @@ struct BatchDims {
   int32_t tree_count;     // T
 };
 
+// MFMA operand images, one set per (tree, branch), 3 x 64 doubles, lane order of
+// v_mfma_f64_4x4x4_4b's A operand (lane = 16 k + 4 block + row holds M_block[row][k];
+// block = category (+ C * pattern sub-group when C < 4)):
+//   [0,64)    P     ->  (P x)      child message
+//   [64,128)  dP    ->  (dP x)     its derivative wrt the branch length
+//   [128,192) P^T   ->  P^T (u.a)  pre-order partial of the child
+constexpr int kImgStride = 192;
+constexpr int kImgP = 0, kImgDP = 64, kImgPT = 128;
+
 struct DeviceBatch {
   // inputs, resident in HBM (wire format of the reference)
   const int32_t* parent_ids;  // [T][M-1]
@@ -42,7 +51,8 @@ struct DeviceBatch {
   int32_t* children;          // [T][n-1][2]  children of internal node n+k
   double* branch;             // [T][N]       effective branch lengths
   TreeModel* model;           // [T]
-  double* mats;               // [T][N-1][C][kMatStride]
+  double* mats;               // [T][N-1][C][kMatStride]   (HBM-arena kernel)
+  double* images;             // [T][N-1][kImgStride]      (LDS kernel)
   // traversal scratch + outputs
   double* arena;              // [chunk][n-1][C][4][Ppad]
   double* part_ll;            // [T][tiles]
@@ -54,6 +64,20 @@ struct DeviceBatch {
 void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int want_gradient,
                  hipStream_t stream);
 void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, hipStream_t stream);
+// Same arithmetic, written as MFMA operand images (one wave per tree-branch).
+void LaunchMatrixImages(const BatchDims& d, const DeviceBatch& b, int want_gradient, hipStream_t stream);
+
+// LDS-resident traversal (v_mfma_f64_4x4x4_4b): 4 waves per workgroup, each wave owns
+// G groups of 16/C site patterns and keeps all n-2 stored PLVs of its patterns in LDS.
+struct LdsPlan {
+  int groups;          // G (0 = the tree does not fit: use the HBM-arena kernel)
+  int patterns_per_block;
+  int tiles;           // workgroups per tree
+  size_t lds_bytes;
+};
+LdsPlan PlanLds(const BatchDims& d);
+void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
+                   hipStream_t stream);
 
 // HBM-arena traversal: one thread per site pattern walks the whole tree.
 constexpr int kHbmBlock = 256;

@@ -1,0 +1,471 @@
+// walk_lds.hip -- LDS-resident traversal on the FP64 matrix cores (gfx950).
+//
+// Why this shape.  Measured on MI355X (bito_amd/csrc/microbench.hip, profiles/):
+// v_mfma_f64_4x4x4_4b sustains 87 % of the FP64 peak from ONE wave per SIMD, while
+// v_fma_f64 needs >= 2 waves per SIMD for 77 %; and a tree's PLVs only fit in LDS for
+// ~3 waves' worth of patterns per CU.  So: one wave per SIMD, all FP64 contractions
+// on the 4x4x4 (4 blocks) MFMA whose four blocks are the four rate categories:
+//
+//   D_b[i][j] = sum_k A_b[i][k] B_b[k][j]        b = category, i,k = states, j = pattern
+//
+// A "group image" is 64 doubles, one per lane: lane = 16*state + 4*block + pattern.
+// The D layout of the instruction equals its B layout, so a child message P x, the
+// Hadamard product with the sibling's, and the result being the next step's B operand
+// never leave that lane layout.  (For C = 1 or 2 categories the spare block bits hold
+// more patterns.)  Transition matrices arrive as precomputed A-operand images
+// (LaunchMatrixImages), one 8-byte coalesced load per lane per matrix.
+//
+// Each wave owns G groups (G*16/C patterns) and a private LDS region holding the n-2
+// stored PLVs of those patterns; waves never exchange data until the final sums, so
+// the walk has no barriers.  Tips are fed to the MFMA as one-hot B operands built from
+// the state byte.  Loads for step k+1 (child list, matrix images, LDS operands, tip
+// states) are issued before the arithmetic of step k; a result needed by the very next
+// step is forwarded in registers.
+//
+// Arithmetic per step is the one documented in kernels.hip (walk_hbm_kernel): the
+// pre-order pass yields both child-edge derivatives and both child pre-order partials
+// per internal node, the child's pre-order partial overwriting its post-order partial.
+// The site likelihood L_p = sum_c w_c pi^T root_c is computed once per pattern after the
+// post-order pass; every edge derivative is then sum_p (w_p / L_p) sum_c w_c (...).
+// Not available here: rescaling (small trees do not need it; the engine routes
+// rescaling requests to the HBM-arena kernel).
+#include <type_traits>
+
+#include "kernels.hpp"
+
+namespace bito_amd {
+
+// --------------------------------------------------------------------------
+// A-operand images: one wave per (tree, branch); lane = 16 k + 4 b + i.
+
+__global__ void __launch_bounds__(256)
+matrix_images_kernel(BatchDims d, DeviceBatch b, int want_gradient) {
+#pragma clang fp contract(off)  // same operation order as transition_matrices_kernel
+  const int C = d.category_count, NB = d.node_count - 1;
+  const int lane = threadIdx.x & 63;
+  const size_t unit = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= (size_t)d.tree_count * NB) return;
+  const int br = (int)(unit % NB);
+  const int t = (int)(unit / NB);
+  const int k = lane >> 4, blk = (lane >> 2) & 3, i = lane & 3;
+  const int c = blk % C;
+  const TreeModel* __restrict__ m = b.model + t;
+  const double rate = m->cat_rate[c];
+  const double time = b.branch[(size_t)t * d.node_count + br] * rate;
+  double p = 0;  // P_c[i][k]
+#pragma unroll
+  for (int q = 0; q < 4; q++) p += m->V[i * 4 + q] * exp(m->lambda[q] * time) * m->Vinv[q * 4 + k];
+  double* out = b.images + unit * kImgStride;
+  out[kImgP + lane] = p;
+  out[kImgPT + 16 * i + 4 * blk + k] = p;  // image of P^T: lane 16 k' + 4 b + i' holds P[k'][i']
+  if (want_gradient) {
+    // dP_c[i][k] = sum_q P_c[i][q] (Q[q][k] r_c); P_c[i][q] lives in lane 16 q + 4 b + i.
+    double dp = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) dp += __shfl(p, 16 * q + (lane & 15)) * (m->Q[q * 4 + k] * rate);
+    out[kImgDP + lane] = dp;
+  }
+}
+
+void LaunchMatrixImages(const BatchDims& d, const DeviceBatch& b, int want_gradient, hipStream_t stream) {
+  const size_t units = (size_t)d.tree_count * (d.node_count - 1);
+  hipLaunchKernelGGL(matrix_images_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, d, b,
+                     want_gradient);
+}
+
+// --------------------------------------------------------------------------
+
+constexpr int kLdsWaves = 4;
+constexpr size_t kLdsBudget = 160 * 1024;
+
+__device__ __forceinline__ double Mfma(double a, double x, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, x, c, 0, 0, 0);
+}
+
+// Tips are held in LDS as 4-bit masks (bit k set when the observed symbol is compatible
+// with state k; a gap sets all four).  The MFMA B operand of a tip is then the double
+// 1.0 or 0.0 selected by this lane's state bit: only the high dword differs.
+__device__ __forceinline__ double TipOperand(int mask, int st) {
+  const int hi = (0 - ((mask >> st) & 1)) & 0x3FF00000;
+  return __hiloint2double(hi, 0);
+}
+
+// ---- cross-lane sums without LDS traffic (DPP / permlane swaps) -------------
+template <int kCtrl>
+__device__ __forceinline__ double DppMove(double v) {
+  const long long bits = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, kCtrl, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), kCtrl, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int kRowRor1 = 0x121, kRowRor2 = 0x122, kRowRor4 = 0x124, kRowRor8 = 0x128;
+
+// Sum over the 16 lanes of each DPP row; every lane of the row ends with the row sum.
+__device__ __forceinline__ double RowSum16(double v) {
+  v += DppMove<kRowRor8>(v);
+  v += DppMove<kRowRor4>(v);
+  v += DppMove<kRowRor2>(v);
+  v += DppMove<kRowRor1>(v);
+  return v;
+}
+
+// rows (16-lane groups) r0 r1 r2 r3 -> r0+r1, r0+r1, r2+r3, r2+r3
+__device__ __forceinline__ double PairRows(double v) {
+  const long long bits = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
+  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double a = __builtin_bit_cast(double, ((long long)h[0] << 32) | l[0]);
+  const double b = __builtin_bit_cast(double, ((long long)h[1] << 32) | l[1]);
+  return a + b;
+}
+
+// lanes 0-31 <- a[l] + a[l+32], lanes 32-63 <- b[l-32] + b[l]
+__device__ __forceinline__ double MergeHalves(double a, double b) {
+  const long long ab = __builtin_bit_cast(long long, a), bb = __builtin_bit_cast(long long, b);
+  const auto l = __builtin_amdgcn_permlane32_swap((unsigned)ab, (unsigned)bb, false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
+  const double x = __builtin_bit_cast(double, ((long long)h[0] << 32) | l[0]);
+  const double y = __builtin_bit_cast(double, ((long long)h[1] << 32) | l[1]);
+  return x + y;
+}
+
+template <int C, int G, bool GRAD>
+__global__ void __launch_bounds__(kLdsWaves * 64, 1)
+walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ children,
+                const double* __restrict__ images, const TreeModel* __restrict__ models,
+                const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
+                double* __restrict__ part_ll, double* __restrict__ part_grad) {
+  extern __shared__ double lds[];
+  constexpr int PG = 16 / C;                  // patterns per group
+  constexpr int PB = kLdsWaves * G * PG;      // patterns per workgroup
+  const int n = d.taxon_count, N = d.node_count, NI = n - 1, slots = n - 2, Ppad = d.pattern_stride;
+
+  // XCD-aware unit order: workgroup b runs on XCD b % 8; give each XCD a contiguous range
+  // of units so the tiles of one tree (same matrix images) share an L2.
+  int unit = blockIdx.x;
+  {
+    const int per = units / 8, rem = units % 8, x = unit % 8, q = unit / 8;
+    unit = x * per + (x < rem ? x : rem) + q;
+  }
+  const int tree = unit / tiles, tile = unit % tiles;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int st = lane >> 4, blk = (lane >> 2) & 3, pj = lane & 3;
+  const int cat = blk % C, sub = blk / C;
+
+  // LDS carve-up: per-wave arena | tip states of the workgroup's patterns | gradient rows | ll
+  double* arena = lds + (size_t)wave * slots * G * 64 + lane;  // cell (slot, g) at (slot*G+g)*64
+  uint8_t* tipbuf = reinterpret_cast<uint8_t*>(lds + (size_t)kLdsWaves * slots * G * 64);
+  double* grad_rows = lds + (size_t)kLdsWaves * slots * G * 64 + (n * PB + 7) / 8;
+  double* ll_slots = grad_rows + kLdsWaves * N;
+
+  const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
+  const double* __restrict__ img = images + (size_t)tree * (N - 1) * kImgStride + lane;
+  const TreeModel* __restrict__ tm = models + tree;
+
+  // The child list lives in registers, one entry per lane (the LDS kernel is only planned
+  // for n <= 80, i.e. at most 158 entries); a step fetches its two children with
+  // v_readlane, so the schedule costs no memory latency.
+  const int tab0 = lane < 2 * NI ? ch[lane] : 0;
+  const int tab1 = 64 + lane < 2 * NI ? ch[64 + lane] : 0;
+  const int tab2 = 128 + lane < 2 * NI ? ch[128 + lane] : 0;
+  auto child = [&](int idx) -> int {  // idx is wave-uniform
+    const int t = idx < 64 ? tab0 : (idx < 128 ? tab1 : tab2);
+    return __builtin_amdgcn_readlane(t, idx & 63);
+  };
+
+  // workgroup preamble: tip masks of this tile, zeroed gradient rows
+  for (int q = tid; q < n * PB; q += kLdsWaves * 64) {
+    const int sym = tip_states[(size_t)(q / PB) * Ppad + tile * PB + (q % PB)];
+    tipbuf[q] = (uint8_t)(sym < 4 ? 1 << sym : 15);
+  }
+  if (GRAD)
+    for (int q = tid; q < kLdsWaves * N; q += kLdsWaves * 64) grad_rows[q] = 0.0;
+  __syncthreads();
+
+  int loc[G];        // pattern index inside the workgroup tile
+  double wgt[G];     // pattern weight
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    loc[g] = (wave * G + g) * PG + sub * 4 + pj;
+    wgt[g] = weights[tile * PB + loc[g]];
+  }
+  const double pi_st = tm->pi[st];
+  const double w_cat = tm->cat_weight[cat];
+
+#define TIP_ADDR(c, g) tipbuf[(c) * PB + loc[g]]
+#define CELL(node_id, g) arena[(size_t)(((node_id) - n) * G + (g)) * 64]
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
+  // ---------------- post-order ----------------------------------------------
+  // A step is self-contained straight-line code, specialised on which children are tips
+  // (children are in ascending id order, so a tip never follows an internal node).  Only
+  // the matrix images are fetched ahead (two steps: an L2 round trip outlasts a step);
+  // the result of a step is handed to the next one in registers when that step's second
+  // child is this node, which is the common case in post-order numbering.
+  double res[G];
+  {
+    auto kchildren = [&](int k, int& a, int& b) {
+      const int kk = k < NI ? k : NI - 1;
+      a = child(kk * 2);
+      b = child(kk * 2 + 1);
+    };
+    int c0, c1, d0c, d1c;
+    kchildren(0, c0, c1);
+    kchildren(1, d0c, d1c);
+    double m0 = img[(size_t)c0 * kImgStride + kImgP], m1 = img[(size_t)c1 * kImgStride + kImgP];
+    double mm0 = img[(size_t)d0c * kImgStride + kImgP], mm1 = img[(size_t)d1c * kImgStride + kImgP];
+    bool x1_in_regs = false;  // wave-uniform: this step's second operand is the previous result
+    int k = 0;
+    auto step = [&](auto tip0_c, auto tip1_c) {
+      constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
+      const int node = n + k;
+      double x0[G], x1[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        if (kTip0) x0[g] = TipOperand(TIP_ADDR(c0, g), st);
+        else x0[g] = CELL(c0, g);
+        if (kTip1) x1[g] = TipOperand(TIP_ADDR(c1, g), st);
+      }
+      if (!kTip1) {
+        if (x1_in_regs) {
+#pragma unroll
+          for (int g = 0; g < G; g++) x1[g] = res[g];
+        } else {
+#pragma unroll
+          for (int g = 0; g < G; g++) x1[g] = CELL(c1, g);
+        }
+      }
+      int e0, e1;
+      kchildren(k + 2, e0, e1);
+      const double f0 = img[(size_t)e0 * kImgStride + kImgP];
+      const double f1 = img[(size_t)e1 * kImgStride + kImgP];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const double a0 = Mfma(m0, x0[g], 0.0);
+        const double a1 = Mfma(m1, x1[g], 0.0);
+        res[g] = a0 * a1;
+      }
+      if (k < NI - 1) {  // the root partial is consumed below, never stored
+#pragma unroll
+        for (int g = 0; g < G; g++) CELL(node, g) = res[g];
+      }
+      x1_in_regs = d1c == node;
+      c0 = d0c; c1 = d1c; d0c = e0; d1c = e1;
+      m0 = mm0; m1 = mm1; mm0 = f0; mm1 = f1;
+    };
+    for (; k < NI; k++) {
+      const int kind = (c0 < n ? 1 : 0) | (c1 < n ? 2 : 0);
+      if (kind == 3) step(T_{}, T_{});
+      else if (kind == 1) step(T_{}, F_{});
+      else if (kind == 0) step(F_{}, F_{});
+      else step(F_{}, T_{});
+    }
+  }
+
+  // ---------------- root: site likelihoods ----------------------------------
+  // res = root partial.  L_p = sum_c w_c sum_i pi_i root_c[i]: sum over the state bits
+  // (lane bits 4,5) and the category bits (lane bits 2..3 as far as C uses them).
+  double ll_acc = 0.0;
+  double coef[G];  // w_c * w_p / L_p for this lane's (category, pattern)
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    double L = res[g] * (pi_st * w_cat);
+    L += __shfl_xor(L, 16);
+    L += __shfl_xor(L, 32);
+    if (C >= 2) L += __shfl_xor(L, 4);
+    if (C == 4) L += __shfl_xor(L, 8);
+    if (st == 0 && cat == 0) ll_acc += wgt[g] * log(L);
+    coef[g] = w_cat * (wgt[g] / L);
+  }
+
+  // ---------------- pre-order + edge derivatives ----------------------------
+  if (GRAD) {
+    double* my_row = grad_rows + wave * N;
+    struct Img { double p, q, t; };  // P, dP, P^T images of one branch
+    auto load_img = [&](int c) { return Img{img[(size_t)c * kImgStride + kImgP], img[(size_t)c * kImgStride + kImgDP],
+                                            img[(size_t)c * kImgStride + kImgPT]}; };
+    auto node_children = [&](int nd, int& a, int& b) {
+      const int kk = nd >= n ? nd - n : 0;
+      a = child(kk * 2);
+      b = child(kk * 2 + 1);
+    };
+    int node = N - 1, c0, c1, d0c, d1c;
+    node_children(node, c0, c1);
+    node_children(node - 1, d0c, d1c);
+    Img A0 = load_img(c0), A1 = load_img(c1), B0 = load_img(d0c), B1 = load_img(d1c);
+    // U = pre-order partial of `node`; for the root the stationary frequencies
+    // (SetRootPreorderPartialsToStateFrequencies, fat_beagle.cpp:327-336).  It stays in
+    // registers when the next node is this node's second child (the usual case).
+    double U[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) U[g] = pi_st;
+    bool u_in_regs = true;
+    // edge sums of the previous step, reduced one step late so that the cross-lane chain
+    // fills the wait for this step's LDS operands
+    double ps0 = 0.0, ps1 = 0.0;
+    int pc0 = N - 1, pc1 = N - 1;  // root entry: the reduce kernel writes 0 there
+
+    auto step = [&](auto tip0_c, auto tip1_c) {
+      constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
+      double x0[G], x1[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        if (kTip0) x0[g] = TipOperand(TIP_ADDR(c0, g), st);
+        else x0[g] = CELL(c0, g);
+        if (kTip1) x1[g] = TipOperand(TIP_ADDR(c1, g), st);
+        else x1[g] = CELL(c1, g);
+      }
+      if (!u_in_regs) {
+#pragma unroll
+        for (int g = 0; g < G; g++) U[g] = CELL(node, g);
+      }
+      int e0, e1;
+      node_children(node - 2, e0, e1);
+      const Img F0 = load_img(e0), F1 = load_img(e1);
+      // previous step's two edge derivatives: lanes 0-31 carry edge pc0, lanes 32-63 edge pc1
+      const double sm = RowSum16(PairRows(MergeHalves(ps0, ps1)));
+      if (lane == 0) my_row[pc0] = sm;
+      if (lane == 32) my_row[pc1] = sm;
+      // this step
+      double s0 = 0.0, s1 = 0.0;
+      double ua0[G], ua1[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const double a0 = Mfma(A0.p, x0[g], 0.0);
+        const double dd0 = Mfma(A0.q, x0[g], 0.0);
+        const double a1 = Mfma(A1.p, x1[g], 0.0);
+        const double dd1 = Mfma(A1.q, x1[g], 0.0);
+        ua1[g] = U[g] * a1;
+        ua0[g] = U[g] * a0;
+        s0 = fma(coef[g], ua1[g] * dd0, s0);
+        s1 = fma(coef[g], ua0[g] * dd1, s1);
+      }
+      if (!kTip0) {
+#pragma unroll
+        for (int g = 0; g < G; g++) CELL(c0, g) = Mfma(A0.t, ua1[g], 0.0);
+      }
+      if (!kTip1) {
+        // the second child's pre-order partial goes straight into U: it is the next
+        // step's U whenever the next node is that child
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          U[g] = Mfma(A1.t, ua0[g], 0.0);
+          CELL(c1, g) = U[g];
+        }
+      }
+      u_in_regs = !kTip1 && c1 == node - 1;
+      ps0 = s0; ps1 = s1; pc0 = c0; pc1 = c1;
+      c0 = d0c; c1 = d1c; d0c = e0; d1c = e1;
+      A0 = B0; A1 = B1; B0 = F0; B1 = F1;
+    };
+    for (; node >= n; --node) {
+      const int kind = (c0 < n ? 1 : 0) | (c1 < n ? 2 : 0);
+      if (kind == 3) step(T_{}, T_{});
+      else if (kind == 1) step(T_{}, F_{});
+      else if (kind == 0) step(F_{}, F_{});
+      else step(F_{}, T_{});
+    }
+    const double sm = RowSum16(PairRows(MergeHalves(ps0, ps1)));
+    if (lane == 0) my_row[pc0] = sm;
+    if (lane == 32) my_row[pc1] = sm;
+  }
+#undef TIP_ADDR
+#undef CELL
+
+  // ---------------- workgroup sums, fixed order -----------------------------
+  double wll = ll_acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wll += __shfl_xor(wll, o);
+  if (lane == 0) ll_slots[wave] = wll;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < kLdsWaves; w++) s += ll_slots[w];
+    part_ll[(size_t)tree * tiles + tile] = s;
+  }
+  if (GRAD) {
+    double* out = part_grad + ((size_t)tree * tiles + tile) * N;
+    for (int e = tid; e < N; e += kLdsWaves * 64) {
+      double s = 0.0;
+      for (int w = 0; w < kLdsWaves; w++) s += grad_rows[w * N + e];
+      out[e] = s;
+    }
+  }
+}
+
+static size_t LdsBytes(const BatchDims& d, int G) {
+  const int PG = 16 / d.category_count, PB = kLdsWaves * G * PG, n = d.taxon_count;
+  const size_t arena = (size_t)kLdsWaves * (n - 2) * G * 64;
+  const size_t tips = ((size_t)n * PB + 7) / 8;
+  return (arena + tips + (size_t)kLdsWaves * d.node_count + kLdsWaves) * sizeof(double);
+}
+
+LdsPlan PlanLds(const BatchDims& d) {
+  LdsPlan plan{0, 0, 0, 0};
+  const int C = d.category_count;
+  if (C != 1 && C != 2 && C != 4) return plan;
+  if (d.taxon_count < 3 || d.taxon_count > 80) return plan;  // child list: three lane tables
+  // largest G in {1,2,3,4,6,8} that fits, but no more groups than the alignment can fill
+  const int candidates[] = {8, 6, 4, 3, 2, 1};
+  const int PG = 16 / C;
+  for (int G : candidates) {
+    if (LdsBytes(d, G) > kLdsBudget) continue;
+    const int PB = kLdsWaves * G * PG;
+    if (G > 1 && PB > d.pattern_count + PB / 2 && PB > 2 * kLdsWaves * PG) continue;  // mostly padding
+    plan.groups = G;
+    plan.patterns_per_block = PB;
+    plan.tiles = (d.pattern_count + PB - 1) / PB;
+    plan.lds_bytes = LdsBytes(d, G);
+    break;
+  }
+  return plan;
+}
+
+template <int C, int G>
+static void LaunchWalkLdsCG(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
+                            hipStream_t stream) {
+  const int units = d.tree_count * plan.tiles;
+  const dim3 grid(units), block(kLdsWaves * 64);
+  if (want_gradient) {
+    auto kern = walk_lds_kernel<C, G, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kLdsBudget);
+    hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, b.children, b.images,
+                       b.model, b.tip_states, b.weights, b.part_ll, b.part_grad);
+  } else {
+    auto kern = walk_lds_kernel<C, G, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kLdsBudget);
+    hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, b.children, b.images,
+                       b.model, b.tip_states, b.weights, b.part_ll, b.part_grad);
+  }
+}
+
+template <int C>
+static void LaunchWalkLdsC(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
+                           hipStream_t stream) {
+  switch (plan.groups) {
+    case 1: LaunchWalkLdsCG<C, 1>(d, b, plan, want_gradient, stream); break;
+    case 2: LaunchWalkLdsCG<C, 2>(d, b, plan, want_gradient, stream); break;
+    case 3: LaunchWalkLdsCG<C, 3>(d, b, plan, want_gradient, stream); break;
+    case 4: LaunchWalkLdsCG<C, 4>(d, b, plan, want_gradient, stream); break;
+    case 6: LaunchWalkLdsCG<C, 6>(d, b, plan, want_gradient, stream); break;
+    case 8: LaunchWalkLdsCG<C, 8>(d, b, plan, want_gradient, stream); break;
+    default: break;
+  }
+}
+
+void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
+                   hipStream_t stream) {
+  switch (d.category_count) {
+    case 1: LaunchWalkLdsC<1>(d, b, plan, want_gradient, stream); break;
+    case 2: LaunchWalkLdsC<2>(d, b, plan, want_gradient, stream); break;
+    case 4: LaunchWalkLdsC<4>(d, b, plan, want_gradient, stream); break;
+    default: break;
+  }
+}
+
+}  // namespace bito_amd
