@@ -130,7 +130,7 @@ __device__ __forceinline__ double MergeHalves(double a, double b) {
   return x + y;
 }
 
-template <int C, int G, bool GRAD>
+template <int C, int G, bool GRAD, int TABS>
 __global__ void __launch_bounds__(kLdsWaves * 64, 1)
 walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ children,
                 const double* __restrict__ images, const TreeModel* __restrict__ models,
@@ -164,13 +164,14 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
   const double* __restrict__ img = images + (size_t)tree * (N - 1) * kImgStride + lane;
   const TreeModel* __restrict__ tm = models + tree;
 
-  // The child list lives in registers, one entry per lane (the LDS kernel is only planned
-  // for n <= 80, i.e. at most 158 entries); a step fetches its two children with
-  // v_readlane, so the schedule costs no memory latency.
+  // The child list lives in registers, one entry per lane (TABS tables of 64 entries: one
+  // for n <= 33, three up to n = 80); a step fetches its two children with v_readlane,
+  // so the schedule costs no memory latency.
   const int tab0 = lane < 2 * NI ? ch[lane] : 0;
-  const int tab1 = 64 + lane < 2 * NI ? ch[64 + lane] : 0;
-  const int tab2 = 128 + lane < 2 * NI ? ch[128 + lane] : 0;
+  const int tab1 = TABS > 1 && 64 + lane < 2 * NI ? ch[64 + lane] : 0;
+  const int tab2 = TABS > 1 && 128 + lane < 2 * NI ? ch[128 + lane] : 0;
   auto child = [&](int idx) -> int {  // idx is wave-uniform
+    if (TABS == 1) return __builtin_amdgcn_readlane(tab0, idx);
     const int t = idx < 64 ? tab0 : (idx < 128 ? tab1 : tab2);
     return __builtin_amdgcn_readlane(t, idx & 63);
   };
@@ -202,24 +203,26 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
   // ---------------- post-order ----------------------------------------------
   // A step is self-contained straight-line code, specialised on which children are tips
   // (children are in ascending id order, so a tip never follows an internal node).  Only
-  // the matrix images are fetched ahead (two steps: an L2 round trip outlasts a step);
-  // the result of a step is handed to the next one in registers when that step's second
+  // the matrix images are fetched ahead: three register sets rotate through a 3-way
+  // unrolled loop, so a set is loaded two steps before it is used and never copied.
+  // The result of a step is handed to the next one in registers when that step's second
   // child is this node, which is the common case in post-order numbering.
   double res[G];
   {
+    struct Img2 { double m0, m1; };
     auto kchildren = [&](int k, int& a, int& b) {
       const int kk = k < NI ? k : NI - 1;
       a = child(kk * 2);
       b = child(kk * 2 + 1);
     };
+    auto load2 = [&](int a, int b) { return Img2{img[(size_t)a * kImgStride + kImgP], img[(size_t)b * kImgStride + kImgP]}; };
     int c0, c1, d0c, d1c;
     kchildren(0, c0, c1);
     kchildren(1, d0c, d1c);
-    double m0 = img[(size_t)c0 * kImgStride + kImgP], m1 = img[(size_t)c1 * kImgStride + kImgP];
-    double mm0 = img[(size_t)d0c * kImgStride + kImgP], mm1 = img[(size_t)d1c * kImgStride + kImgP];
+    Img2 S0 = load2(c0, c1), S1 = load2(d0c, d1c), S2 = S1;
     bool x1_in_regs = false;  // wave-uniform: this step's second operand is the previous result
     int k = 0;
-    auto step = [&](auto tip0_c, auto tip1_c) {
+    auto step = [&](auto tip0_c, auto tip1_c, const Img2& cur, Img2& fill) {
       constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
       const int node = n + k;
       double x0[G], x1[G];
@@ -240,28 +243,37 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
       }
       int e0, e1;
       kchildren(k + 2, e0, e1);
-      const double f0 = img[(size_t)e0 * kImgStride + kImgP];
-      const double f1 = img[(size_t)e1 * kImgStride + kImgP];
+      fill = load2(e0, e1);
+      double a0[G], a1[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        const double a0 = Mfma(m0, x0[g], 0.0);
-        const double a1 = Mfma(m1, x1[g], 0.0);
-        res[g] = a0 * a1;
+        a0[g] = Mfma(cur.m0, x0[g], 0.0);
+        a1[g] = Mfma(cur.m1, x1[g], 0.0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < G; g++) res[g] = a0[g] * a1[g];
       if (k < NI - 1) {  // the root partial is consumed below, never stored
 #pragma unroll
         for (int g = 0; g < G; g++) CELL(node, g) = res[g];
       }
       x1_in_regs = d1c == node;
       c0 = d0c; c1 = d1c; d0c = e0; d1c = e1;
-      m0 = mm0; m1 = mm1; mm0 = f0; mm1 = f1;
     };
-    for (; k < NI; k++) {
+    auto dispatch = [&](const Img2& cur, Img2& fill) {
       const int kind = (c0 < n ? 1 : 0) | (c1 < n ? 2 : 0);
-      if (kind == 3) step(T_{}, T_{});
-      else if (kind == 1) step(T_{}, F_{});
-      else if (kind == 0) step(F_{}, F_{});
-      else step(F_{}, T_{});
+      if (kind == 3) step(T_{}, T_{}, cur, fill);
+      else if (kind == 1) step(T_{}, F_{}, cur, fill);
+      else if (kind == 0) step(F_{}, F_{}, cur, fill);
+      else step(F_{}, T_{}, cur, fill);
+    };
+    while (true) {
+      dispatch(S0, S2);
+      if (++k >= NI) break;
+      dispatch(S1, S0);
+      if (++k >= NI) break;
+      dispatch(S2, S1);
+      if (++k >= NI) break;
     }
   }
 
@@ -284,9 +296,12 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
   // ---------------- pre-order + edge derivatives ----------------------------
   if (GRAD) {
     double* my_row = grad_rows + wave * N;
-    struct Img { double p, q, t; };  // P, dP, P^T images of one branch
-    auto load_img = [&](int c) { return Img{img[(size_t)c * kImgStride + kImgP], img[(size_t)c * kImgStride + kImgDP],
-                                            img[(size_t)c * kImgStride + kImgPT]}; };
+    struct Img { double p0, q0, t0, p1, q1, t1; };  // P, dP, P^T images of the two child branches
+    auto load_img = [&](int a, int b) {
+      return Img{img[(size_t)a * kImgStride + kImgP], img[(size_t)a * kImgStride + kImgDP],
+                 img[(size_t)a * kImgStride + kImgPT], img[(size_t)b * kImgStride + kImgP],
+                 img[(size_t)b * kImgStride + kImgDP], img[(size_t)b * kImgStride + kImgPT]};
+    };
     auto node_children = [&](int nd, int& a, int& b) {
       const int kk = nd >= n ? nd - n : 0;
       a = child(kk * 2);
@@ -295,7 +310,7 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
     int node = N - 1, c0, c1, d0c, d1c;
     node_children(node, c0, c1);
     node_children(node - 1, d0c, d1c);
-    Img A0 = load_img(c0), A1 = load_img(c1), B0 = load_img(d0c), B1 = load_img(d1c);
+    Img S0 = load_img(c0, c1), S1 = load_img(d0c, d1c), S2 = S1;
     // U = pre-order partial of `node`; for the root the stationary frequencies
     // (SetRootPreorderPartialsToStateFrequencies, fat_beagle.cpp:327-336).  It stays in
     // registers when the next node is this node's second child (the usual case).
@@ -307,8 +322,13 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
     // fills the wait for this step's LDS operands
     double ps0 = 0.0, ps1 = 0.0;
     int pc0 = N - 1, pc1 = N - 1;  // root entry: the reduce kernel writes 0 there
+    auto flush_edges = [&]() {
+      // lanes 0-31 carry edge pc0, lanes 32-63 edge pc1
+      const double sm = RowSum16(PairRows(MergeHalves(ps0, ps1)));
+      if ((lane & 31) == 0) my_row[lane == 0 ? pc0 : pc1] = sm;
+    };
 
-    auto step = [&](auto tip0_c, auto tip1_c) {
+    auto step = [&](auto tip0_c, auto tip1_c, const Img& cur, Img& fill) {
       constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
       double x0[G], x1[G];
 #pragma unroll
@@ -324,53 +344,66 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
       }
       int e0, e1;
       node_children(node - 2, e0, e1);
-      const Img F0 = load_img(e0), F1 = load_img(e1);
-      // previous step's two edge derivatives: lanes 0-31 carry edge pc0, lanes 32-63 edge pc1
-      const double sm = RowSum16(PairRows(MergeHalves(ps0, ps1)));
-      if (lane == 0) my_row[pc0] = sm;
-      if (lane == 32) my_row[pc1] = sm;
-      // this step
-      double s0 = 0.0, s1 = 0.0;
+      fill = load_img(e0, e1);
+      flush_edges();
+      // this step: all matrix products first, then the element-wise work
+      double a0[G], dd0[G], a1[G], dd1[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        a0[g] = Mfma(cur.p0, x0[g], 0.0);
+        a1[g] = Mfma(cur.p1, x1[g], 0.0);
+      }
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        dd0[g] = Mfma(cur.q0, x0[g], 0.0);
+        dd1[g] = Mfma(cur.q1, x1[g], 0.0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       double ua0[G], ua1[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        const double a0 = Mfma(A0.p, x0[g], 0.0);
-        const double dd0 = Mfma(A0.q, x0[g], 0.0);
-        const double a1 = Mfma(A1.p, x1[g], 0.0);
-        const double dd1 = Mfma(A1.q, x1[g], 0.0);
-        ua1[g] = U[g] * a1;
-        ua0[g] = U[g] * a0;
-        s0 = fma(coef[g], ua1[g] * dd0, s0);
-        s1 = fma(coef[g], ua0[g] * dd1, s1);
+        ua1[g] = U[g] * a1[g];
+        ua0[g] = U[g] * a0[g];
       }
       if (!kTip0) {
 #pragma unroll
-        for (int g = 0; g < G; g++) CELL(c0, g) = Mfma(A0.t, ua1[g], 0.0);
+        for (int g = 0; g < G; g++) CELL(c0, g) = Mfma(cur.t0, ua1[g], 0.0);
       }
       if (!kTip1) {
         // the second child's pre-order partial goes straight into U: it is the next
         // step's U whenever the next node is that child
 #pragma unroll
         for (int g = 0; g < G; g++) {
-          U[g] = Mfma(A1.t, ua0[g], 0.0);
+          U[g] = Mfma(cur.t1, ua0[g], 0.0);
           CELL(c1, g) = U[g];
         }
+      }
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        s0 = fma(coef[g], ua1[g] * dd0[g], s0);
+        s1 = fma(coef[g], ua0[g] * dd1[g], s1);
       }
       u_in_regs = !kTip1 && c1 == node - 1;
       ps0 = s0; ps1 = s1; pc0 = c0; pc1 = c1;
       c0 = d0c; c1 = d1c; d0c = e0; d1c = e1;
-      A0 = B0; A1 = B1; B0 = F0; B1 = F1;
     };
-    for (; node >= n; --node) {
+    auto dispatch = [&](const Img& cur, Img& fill) {
       const int kind = (c0 < n ? 1 : 0) | (c1 < n ? 2 : 0);
-      if (kind == 3) step(T_{}, T_{});
-      else if (kind == 1) step(T_{}, F_{});
-      else if (kind == 0) step(F_{}, F_{});
-      else step(F_{}, T_{});
+      if (kind == 3) step(T_{}, T_{}, cur, fill);
+      else if (kind == 1) step(T_{}, F_{}, cur, fill);
+      else if (kind == 0) step(F_{}, F_{}, cur, fill);
+      else step(F_{}, T_{}, cur, fill);
+    };
+    while (true) {
+      dispatch(S0, S2);
+      if (--node < n) break;
+      dispatch(S1, S0);
+      if (--node < n) break;
+      dispatch(S2, S1);
+      if (--node < n) break;
     }
-    const double sm = RowSum16(PairRows(MergeHalves(ps0, ps1)));
-    if (lane == 0) my_row[pc0] = sm;
-    if (lane == 32) my_row[pc1] = sm;
+    flush_edges();
   }
 #undef TIP_ADDR
 #undef CELL
@@ -430,13 +463,13 @@ static void LaunchWalkLdsCG(const BatchDims& d, const DeviceBatch& b, const LdsP
   const int units = d.tree_count * plan.tiles;
   const dim3 grid(units), block(kLdsWaves * 64);
   if (want_gradient) {
-    auto kern = walk_lds_kernel<C, G, true>;
+    auto kern = d.taxon_count <= 33 ? walk_lds_kernel<C, G, true, 1> : walk_lds_kernel<C, G, true, 3>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kLdsBudget);
     hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, b.children, b.images,
                        b.model, b.tip_states, b.weights, b.part_ll, b.part_grad);
   } else {
-    auto kern = walk_lds_kernel<C, G, false>;
+    auto kern = d.taxon_count <= 33 ? walk_lds_kernel<C, G, false, 1> : walk_lds_kernel<C, G, false, 3>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kLdsBudget);
     hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, b.children, b.images,
