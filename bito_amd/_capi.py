@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbito_amd.so")
+LIB_PATH = os.environ.get("BITO_AMD_LIB", os.path.join(_HERE, "libbito_amd.so"))  # env override: dev experiments
 
 OK = 0
 ERR_BAD_MODEL, ERR_BAD_PARAMS, ERR_BAD_TREE, ERR_BAD_ARG, ERR_DEVICE, ERR_STATE = -1, -2, -3, -4, -5, -6
@@ -19,7 +19,7 @@ GRAD_SITE_MODEL = 2
 GRAD_CLOCK_MODEL = 4
 GRAD_STICKBREAKING = 8
 
-KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS = 0, 1, 2
+KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS, KERNEL_LDS_TREE = 0, 1, 2, 3
 
 # Every symbol include/bito_amd.h declares (tests check that the library exports them all).
 SYMBOLS = [

@@ -269,16 +269,29 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling) {
   // Kernel choice: the LDS-resident MFMA walk when the tree fits in LDS and no rescaling
   // is requested, otherwise the HBM-arena walk.
   const LdsPlan plan = PlanLds(d);
+  const TreePlan tplan = PlanTree(d);
+  bool use_tree = tplan.waves > 0 && !rescaling;
   bool use_lds = plan.groups > 0 && !rescaling;
-  if (e->kernel_choice == BITO_AMD_KERNEL_HBM_ARENA) use_lds = false;
-  if (e->kernel_choice == BITO_AMD_KERNEL_LDS && !use_lds)
-    return Fail(e, BITO_AMD_ERR_STATE,
-                "the LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, "
-                "no rescaling, and a tree whose PLVs fit in 160 KB of LDS)");
-  const int tiles = use_lds ? plan.tiles : HbmTiles(d.pattern_count);
+  switch (e->kernel_choice) {
+    case BITO_AMD_KERNEL_HBM_ARENA: use_tree = use_lds = false; break;
+    case BITO_AMD_KERNEL_LDS:
+      use_tree = false;
+      if (!use_lds) return Fail(e, BITO_AMD_ERR_STATE, "the LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, and a tree whose PLVs fit in 160 KB of LDS)");
+      break;
+    case BITO_AMD_KERNEL_LDS_TREE:
+      if (!use_tree) return Fail(e, BITO_AMD_ERR_STATE, "the LDS tree kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, and a tree whose images + PLVs fit in 160 KB of LDS)");
+      break;
+    default: break;
+  }
+  // Measured on config 3 (profiles/): walk_lds_kernel 2.81 ms, walk_tree_kernel 3.79 ms per 1600
+  // trees -- the single-wave software pipeline beats two latency-bound waves per SIMD, so the
+  // tree-resident variant is only used when forced or when walk_lds cannot run.
+  if (e->kernel_choice != BITO_AMD_KERNEL_LDS_TREE && use_lds) use_tree = false;
+  if (use_tree) use_lds = false;
+  const int tiles = use_tree ? tplan.tiles : (use_lds ? plan.tiles : HbmTiles(d.pattern_count));
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
   if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
-  if (use_lds) {
+  if (use_tree || use_lds) {
     HIP_TRY(e, e->images.Reserve((size_t)T * NB * kImgStride));
     const DeviceBatch b = MakeBatch(e);
     LaunchSetup(d, e->spec, b, want_gradient, e->stream);
@@ -289,9 +302,10 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling) {
       ev1 = NextEvent(e);
       HIP_TRY(e, hipEventRecord(ev0, e->stream));
     }
-    LaunchWalkLds(d, b, plan, want_gradient, e->stream);
+    if (use_tree) LaunchWalkTree(d, b, tplan, want_gradient, e->stream);
+    else LaunchWalkLds(d, b, plan, want_gradient, e->stream);
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
-    e->kernel_name = "walk_lds_kernel";
+    e->kernel_name = use_tree ? "walk_tree_kernel" : "walk_lds_kernel";
     LaunchReduce(d, b, tiles, want_gradient, e->stream);
     HIP_TRY(e, hipGetLastError());
     return BITO_AMD_OK;

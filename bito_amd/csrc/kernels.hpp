@@ -79,6 +79,20 @@ LdsPlan PlanLds(const BatchDims& d);
 void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
                    hipStream_t stream);
 
+// LDS-resident traversal, second generation (walk_tree.hip): 8 waves per workgroup (two per
+// SIMD), one group image per wave, the tree's P/dP images staged in LDS and shared.
+struct TreePlan {
+  int waves;            // 0 = not available for this batch
+  int patterns_per_tile;
+  int tiles;            // pattern tiles per tree
+  int tiles_per_block;  // a workgroup serves this many consecutive tiles of one tree
+  int blocks_per_tree;
+  size_t lds_bytes;
+};
+TreePlan PlanTree(const BatchDims& d);
+void LaunchWalkTree(const BatchDims& d, const DeviceBatch& b, const TreePlan& plan, int want_gradient,
+                    hipStream_t stream);
+
 // HBM-arena traversal: one thread per site pattern walks the whole tree.
 constexpr int kHbmBlock = 256;
 inline int HbmTiles(int pattern_count) { return (pattern_count + kHbmBlock - 1) / kHbmBlock; }

@@ -45,7 +45,8 @@ extern "C" {
  * kernel when the tree fits, the HBM-arena kernel otherwise. */
 #define BITO_AMD_KERNEL_AUTO 0
 #define BITO_AMD_KERNEL_HBM_ARENA 1
-#define BITO_AMD_KERNEL_LDS 2
+#define BITO_AMD_KERNEL_LDS 2      /* walk_lds_kernel: one wave per SIMD, images from L2 */
+#define BITO_AMD_KERNEL_LDS_TREE 3 /* walk_tree_kernel: two waves per SIMD, images staged in LDS */
 
 typedef struct bito_amd_engine bito_amd_engine;
 

@@ -1,0 +1,24 @@
+#!/bin/bash
+# usage: scripts/pmc_lds.sh <tag>   (run on the GPU box through gpurun)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+T=$1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_${T}_a -o a -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${T}_a.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM --output-format csv -d $R/gpurun_out/pmc_${T}_b -o b -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${T}_b.log 2>&1
+python3 - <<PY
+import csv, collections
+out={}
+for f in ('$R/gpurun_out/pmc_${T}_a/a_counter_collection.csv','$R/gpurun_out/pmc_${T}_b/b_counter_collection.csv'):
+    agg=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if 'walk_tree' in r['Kernel_Name'] or 'walk_lds' in r['Kernel_Name']:
+            agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    for k,v in agg.items(): out[k]=sum(v)/len(v)
+waves=1600*30*8
+wc=out['SQ_WAVE_CYCLES']
+print('per wave-step: instr VALU %.1f MFMA %.1f LDS %.1f SALU %.1f VMEM %.1f'%tuple(out[k]/waves/52 for k in ('SQ_INSTS_VALU','SQ_INSTS_MFMA','SQ_INSTS_LDS','SQ_INSTS_SALU','SQ_INSTS_VMEM_RD')))
+print('wave cycles per step (x4): %.0f'%(wc*4/waves/52))
+for k in ('SQ_ACTIVE_INST_ANY','SQ_WAIT_ANY','SQ_WAIT_INST_ANY','SQ_ACTIVE_INST_VALU','SQ_ACTIVE_INST_LDS','SQ_ACTIVE_INST_SCA','SQ_ACTIVE_INST_VMEM'):
+    if k in out: print(k, '%.3f'%(out[k]/wc))
+print('MFMA busy cycles per SIMD', out['SQ_VALU_MFMA_BUSY_CYCLES']/1024)
+PY

@@ -146,6 +146,31 @@ def test_config3_ds1_gtr_weibull4_vs_oracle():
     assert grad_close(res["branch_lengths"], out["branch_lengths"])
 
 
+@pytest.mark.parametrize("kernel", [_capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE])
+@pytest.mark.parametrize("model", [("JC69", "constant"), ("HKY", "weibull+2"), ("GTR", "weibull+4")])
+def test_every_traversal_kernel_matches_oracle(kernel, model):
+    """The three traversal kernels (HBM arena, LDS one wave/SIMD, LDS tree-resident images)
+    are interchangeable: same inputs, same answers, for 1, 2 and 4 rate categories."""
+    sub, site = model
+    w = workloads.ds1_gtr_weibull4(1).subset(12)
+    gpu, cpu = engines(sub, site, "none", w.patterns, w.weights, 4)
+    gpu.set_kernel(kernel)
+    params = gpu.default_params(12)
+    bm = gpu.block_map()
+    if "substitution_model_frequencies" in bm:
+        params[:, bm["substitution_model_frequencies"][0]:][:, :4] = [0.15, 0.35, 0.3, 0.2]
+    if site != "constant":
+        params[:, bm["Weibull_shape"][0]] = np.linspace(0.4, 1.6, 12)
+    out = gpu.gradients(w.parent_ids, w.branch_lengths, params)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, params)
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    assert ll_close(gpu.log_likelihoods(w.parent_ids, w.branch_lengths, params), ref["log_likelihood"])
+    expect = {_capi.KERNEL_HBM_ARENA: "walk_hbm_kernel", _capi.KERNEL_LDS: "walk_lds_kernel",
+              _capi.KERNEL_LDS_TREE: "walk_tree_kernel"}[kernel]
+    assert gpu.kernel_name() == expect
+
+
 def test_flua_rooted_with_rates(data_dir):
     g = GOLD["flua_jc69_strict"]
     tc, sp = load(data_dir, "fluA.fa", "fluA.tree")
