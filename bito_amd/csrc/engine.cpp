@@ -260,7 +260,7 @@ hipEvent_t NextEvent(bito_amd_engine* e) {
   return e->ev_pool[e->ev_used++];
 }
 
-int RunResident(bito_amd_engine* e, int want_gradient, int rescaling) {
+int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_mode = 0) {
   if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
   HIP_TRY(e, hipSetDevice(e->device));
   const BatchDims& d = e->dims;
@@ -295,7 +295,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling) {
     HIP_TRY(e, e->images.Reserve((size_t)T * NB * kImgStride));
     const DeviceBatch b = MakeBatch(e);
     LaunchSetup(d, e->spec, b, want_gradient, e->stream);
-    LaunchMatrixImages(d, b, want_gradient, e->stream);
+    LaunchMatrixImages(d, b, want_gradient, deriv_mode, e->stream);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing) {
       ev0 = NextEvent(e);
@@ -319,7 +319,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling) {
   HIP_TRY(e, e->arena.Reserve(chunk * per_tree / sizeof(double)));
   const DeviceBatch b = MakeBatch(e);
   LaunchSetup(d, e->spec, b, want_gradient, e->stream);
-  LaunchMatrices(d, b, want_gradient, e->stream);
+  LaunchMatrices(d, b, want_gradient, deriv_mode, e->stream);
   for (int t0 = 0; t0 < T; t0 += (int)chunk) {
     const int ct = std::min<int>((int)chunk, T - t0);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -540,6 +540,77 @@ int bito_amd_engine_log_likelihoods(bito_amd_engine* e, int32_t tree_count, int3
   return bito_amd_engine_download(e, out, nullptr);
 }
 
+// StickBreakingTransform (reference src/stick_breaking_transform.cpp:10-44): the Stan
+// simplex transform; x = T(y) has K entries, y has K-1.
+static void StickForward(const double* y, int K, double* x) {
+  double stick = 1.0;
+  for (int k = 0; k < K - 1; k++) {
+    const double z = 1.0 / (1 + std::exp(-(y[k] - std::log((double)(K - k - 1)))));
+    x[k] = stick * z;
+    stick -= x[k];
+  }
+  x[K - 1] = stick;
+}
+static void StickInverse(const double* x, int K, double* y) {
+  double sum = 0;
+  for (int k = 0; k < K - 1; k++) {
+    const double z = x[k] / (1.0 - sum);
+    y[k] = std::log(z / (1.0 - z)) + std::log((double)(K - k - 1));
+    sum += x[k];
+  }
+}
+
+// FatBeagle::SubstitutionModelGradient (reference src/fat_beagle.cpp:412-508): central finite
+// differences of the tree log-likelihood in every free substitution-model parameter, rates
+// first then frequencies, in stick-breaking coordinates when requested (frequencies always,
+// rates only for GTR's six).  The 2 x (#parameters) perturbed evaluations of every tree are
+// run as ONE batch of log-likelihood-only passes on the device.
+static int SubstitutionGradients(bito_amd_engine* e, int T, int rooted, int node_count,
+                                 const int32_t* parent_ids, const double* branch_lengths,
+                                 const double* rates, const double* params, int rescaling, bool stick,
+                                 double delta, double* out_subst) {
+  const ModelSpec& m = e->spec;
+  const int pc = m.param_count;
+  struct Dir { int start, len, index; bool stick; };
+  std::vector<Dir> dirs;
+  const bool rates_stick = stick && m.rates_len == 6;
+  for (int i = 0; i < (rates_stick ? 5 : m.rates_len); i++) dirs.push_back({m.rates_start, m.rates_len, i, rates_stick});
+  for (int i = 0; i < (stick ? 3 : 4); i++) dirs.push_back({m.freq_start, 4, i, stick});
+  const int K = (int)dirs.size(), M = node_count;
+  const size_t big = (size_t)T * 2 * K;
+  std::vector<int32_t> pid(big * (M - 1));
+  std::vector<double> bl(big * M), par(big * pc), rt;
+  if (rooted && rates) rt.resize(big * (M - 1));
+  for (int t = 0; t < T; t++)
+    for (int j = 0; j < 2 * K; j++) {
+      const size_t r = (size_t)t * 2 * K + j;
+      std::copy(parent_ids + (size_t)t * (M - 1), parent_ids + (size_t)(t + 1) * (M - 1), pid.begin() + r * (M - 1));
+      std::copy(branch_lengths + (size_t)t * M, branch_lengths + (size_t)(t + 1) * M, bl.begin() + r * M);
+      if (!rt.empty()) std::copy(rates + (size_t)t * (M - 1), rates + (size_t)(t + 1) * (M - 1), rt.begin() + r * (M - 1));
+      double* row = par.data() + r * pc;
+      std::copy(params + (size_t)t * pc, params + (size_t)(t + 1) * pc, row);
+      const Dir& dr = dirs[j / 2];
+      const double sign = (j % 2 == 0) ? 1.0 : -1.0;
+      double y[8];
+      if (dr.stick) {
+        StickInverse(row + dr.start, dr.len, y);
+        y[dr.index] += sign * delta;
+        StickForward(y, dr.len, row + dr.start);
+      } else {
+        row[dr.start + dr.index] += sign * delta;
+      }
+    }
+  std::vector<double> ll(big);
+  int rc = bito_amd_engine_log_likelihoods(e, (int32_t)big, rooted, node_count, pid.data(), bl.data(),
+                                           rt.empty() ? nullptr : rt.data(), par.data(), rescaling, ll.data());
+  if (rc) return rc;
+  const int stride = m.rates_len + 4;
+  for (int t = 0; t < T; t++)
+    for (int k = 0; k < K; k++)
+      out_subst[(size_t)t * stride + k] = (ll[((size_t)t * K + k) * 2] - ll[((size_t)t * K + k) * 2 + 1]) / (2. * delta);
+  return BITO_AMD_OK;
+}
+
 int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t rooted,
                               int32_t node_count, const int32_t* parent_ids,
                               const double* branch_lengths, const double* rates,
@@ -547,15 +618,41 @@ int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t ro
                               double fd_delta, double* out_ll, double* out_branch,
                               double* out_site, double* out_subst, double* out_clock) {
   if (!e || !out_ll || !out_branch) return BITO_AMD_ERR_BAD_ARG;
-  (void)flags; (void)fd_delta; (void)out_site; (void)out_subst;
-  int rc = bito_amd_engine_upload(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params);
+  int rc;
+  // the finite-difference batch first: the main batch must be the resident one on return
+  if ((flags & BITO_AMD_GRAD_SUBSTITUTION_MODEL) && out_subst && e->spec.rates_len > 0) {
+    rc = SubstitutionGradients(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params,
+                               rescaling, (flags & BITO_AMD_GRAD_STICKBREAKING) != 0,
+                               fd_delta > 0 ? fd_delta : 1e-6, out_subst);
+    if (rc) return rc;
+  }
+  rc = bito_amd_engine_upload(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params);
   if (rc) return rc;
   if ((rc = RunResident(e, 1, rescaling != 0))) return rc;
   if ((rc = bito_amd_engine_download(e, out_ll, out_branch))) return rc;
+  const int N = 2 * e->n - 1;
+  if ((flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && e->spec.category_count > 1) {
+    // second gradient pass with dQ = Q * d r_c / d shape, then sum_b g_b t_b over the
+    // effective branch lengths (DiscreteSiteModelGradient, reference src/fat_beagle.cpp:401-410,538-550)
+    if ((rc = RunResident(e, 1, rescaling != 0, /*deriv_mode=*/1))) return rc;
+    std::vector<double> g2((size_t)tree_count * N);
+    if ((rc = bito_amd_engine_download(e, nullptr, g2.data()))) return rc;
+    for (int t = 0; t < tree_count; t++) {
+      double s = 0;
+      for (int i = 0; i < node_count - 1; i++) {
+        double bl = branch_lengths[(size_t)t * node_count + i];
+        if (rooted && rates) bl *= rates[(size_t)t * (node_count - 1) + i];
+        s += g2[(size_t)t * N + i] * bl;
+      }
+      out_site[t] = s;  // unrooted: the two extra nodes of the detrifurcated tree have branch length 0
+    }
+    // leave the device results of the main pass in place for bito_amd_engine_download
+    if ((rc = RunResident(e, 1, rescaling != 0))) return rc;
+    if ((rc = bito_amd_engine_sync(e))) return rc;
+  }
   if (rooted && (flags & BITO_AMD_GRAD_CLOCK_MODEL) && out_clock) {
     // ClockGradient, strict clock (reference src/fat_beagle.cpp:379-399): sum of
     // branch gradient times the tree's own (time) branch length.
-    const int N = 2 * e->n - 1;
     for (int t = 0; t < tree_count; t++) {
       double s = 0;
       for (int i = 0; i < N - 1; i++) s += out_branch[(size_t)t * N + i] * branch_lengths[(size_t)t * node_count + i];

@@ -80,7 +80,7 @@ void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b
 // Transition matrices: one thread per (tree, branch, category).
 
 __global__ void __launch_bounds__(256)
-transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient) {
+transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient, int deriv_mode) {
 // No FMA contraction and a fixed summation order here: see model.hpp.
 #pragma clang fp contract(off)
   const int C = d.category_count, NB = d.node_count - 1;
@@ -118,6 +118,8 @@ transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient) {
     out[kMatPT + 16 + i] = 1.0;   // gap: the all-ones column BEAGLE appends
     out[kMatDPT + 16 + i] = 0.0;  // Q 1 = 0
   }
+  // deriv_mode 1: the site-model pass, Q scaled by d r_c / d shape (fat_beagle.cpp:542-546)
+  const double drate = deriv_mode ? m->cat_rate_deriv[c] : rate;
   if (want_gradient) {
     // dP/dt = P (r_c Q): the differential matrix of the reference
     // (BuildDifferentialMatrices, fat_beagle.cpp:101-111) folded into the branch's
@@ -128,18 +130,19 @@ transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient) {
       for (int j = 0; j < 4; j++) {
         double s = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) s += P[i * 4 + k] * (m->Q[k * 4 + j] * rate);
+        for (int k = 0; k < 4; k++) s += P[i * 4 + k] * (m->Q[k * 4 + j] * drate);
         out[kMatDP + i * 4 + j] = s;
         out[kMatDPT + j * 4 + i] = s;
       }
   }
 }
 
-void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, hipStream_t stream) {
+void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, int deriv_mode,
+                    hipStream_t stream) {
   const size_t total = (size_t)d.tree_count * (d.node_count - 1) * d.category_count;
   const int blocks = (int)((total + 255) / 256);
   hipLaunchKernelGGL(transition_matrices_kernel, dim3(blocks), dim3(256), 0, stream, d, b,
-                     want_gradient);
+                     want_gradient, deriv_mode);
 }
 
 // --------------------------------------------------------------------------

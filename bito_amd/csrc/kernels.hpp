@@ -63,9 +63,12 @@ struct DeviceBatch {
 
 void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int want_gradient,
                  hipStream_t stream);
-void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, hipStream_t stream);
+// deriv_mode 0: dP = P (r_c Q); 1: dP = P ((d r_c / d shape) Q) for the site-model gradient pass.
+void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, int deriv_mode,
+                    hipStream_t stream);
 // Same arithmetic, written as MFMA operand images (one wave per tree-branch).
-void LaunchMatrixImages(const BatchDims& d, const DeviceBatch& b, int want_gradient, hipStream_t stream);
+void LaunchMatrixImages(const BatchDims& d, const DeviceBatch& b, int want_gradient, int deriv_mode,
+                        hipStream_t stream);
 
 // LDS-resident traversal (v_mfma_f64_4x4x4_4b): 4 waves per workgroup, each wave owns
 // G groups of 16/C site patterns and keeps all n-2 stored PLVs of its patterns in LDS.

@@ -39,7 +39,7 @@ namespace bito_amd {
 // A-operand images: one wave per (tree, branch); lane = 16 k + 4 b + i.
 
 __global__ void __launch_bounds__(256)
-matrix_images_kernel(BatchDims d, DeviceBatch b, int want_gradient) {
+matrix_images_kernel(BatchDims d, DeviceBatch b, int want_gradient, int deriv_mode) {
 #pragma clang fp contract(off)  // same operation order as transition_matrices_kernel
   const int C = d.category_count, NB = d.node_count - 1;
   const int lane = threadIdx.x & 63;
@@ -61,16 +61,18 @@ matrix_images_kernel(BatchDims d, DeviceBatch b, int want_gradient) {
   if (want_gradient) {
     // dP_c[i][k] = sum_q P_c[i][q] (Q[q][k] r_c); P_c[i][q] lives in lane 16 q + 4 b + i.
     double dp = 0;
+    const double drate = deriv_mode ? m->cat_rate_deriv[c] : rate;  // site-model pass: d r_c / d shape
 #pragma unroll
-    for (int q = 0; q < 4; q++) dp += __shfl(p, 16 * q + (lane & 15)) * (m->Q[q * 4 + k] * rate);
+    for (int q = 0; q < 4; q++) dp += __shfl(p, 16 * q + (lane & 15)) * (m->Q[q * 4 + k] * drate);
     out[kImgDP + lane] = dp;
   }
 }
 
-void LaunchMatrixImages(const BatchDims& d, const DeviceBatch& b, int want_gradient, hipStream_t stream) {
+void LaunchMatrixImages(const BatchDims& d, const DeviceBatch& b, int want_gradient, int deriv_mode,
+                        hipStream_t stream) {
   const size_t units = (size_t)d.tree_count * (d.node_count - 1);
   hipLaunchKernelGGL(matrix_images_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, d, b,
-                     want_gradient);
+                     want_gradient, deriv_mode);
 }
 
 // --------------------------------------------------------------------------

@@ -74,6 +74,7 @@ class Engine:
         self.param_count = L.bito_amd_engine_param_count(h)
         self.category_count = L.bito_amd_engine_category_count(h)
         self.tree_count = 0
+        self._node_count = 2 * n - 1
 
     def close(self):
         if getattr(self, "_h", None):
@@ -170,6 +171,10 @@ class Engine:
                 rl = bm["substitution_model_rates"][1]
                 sub_len = (rl - 1 if rl == 6 else rl) + 3
             out["substitution_model"] = subst[:, :sub_len]
+            # rates first, then frequencies (reference src/fat_beagle.cpp:528-534)
+            n_freq = 3 if flags & _capi.GRAD_STICKBREAKING else 4
+            out["substitution_model_rates"] = subst[:, :sub_len - n_freq]
+            out["substitution_model_frequencies"] = subst[:, sub_len - n_freq:sub_len]
         if clock is not None and rooted:
             out["clock_model"] = clock
         return out

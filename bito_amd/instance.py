@@ -18,6 +18,12 @@ from .engine import BitoAmdError, Engine, PhyloGradient, PhyloModelSpecification
 from .site_pattern import SitePattern
 
 
+# PhyloGradientFlagOptions of the reference all default to "on", stick-breaking included
+# (src/phylo_flags.hpp:322-343); ratios_root_height is a time-tree transform outside the GPU path.
+DEFAULT_GRADIENT_FLAGS = (_capi.GRAD_SUBSTITUTION_MODEL | _capi.GRAD_SITE_MODEL | _capi.GRAD_CLOCK_MODEL |
+                          _capi.GRAD_STICKBREAKING)
+
+
 class _Tree:
     """pybito ``UnrootedTree`` / ``RootedTree``: ``branch_lengths`` is a writable numpy
     view (the reference exposes the vector through the buffer protocol,
@@ -150,7 +156,7 @@ class unrooted_instance(_GenericInstance):
         pid, bl = self._wire()
         return self._get_engine().log_likelihoods(pid, bl, self._params, rescaling=self._rescaling)
 
-    def phylo_gradients(self, flags: int = 0) -> List[PhyloGradient]:
+    def phylo_gradients(self, flags: int = DEFAULT_GRADIENT_FLAGS) -> List[PhyloGradient]:
         pid, bl = self._wire()
         out = self._get_engine().gradients(pid, bl, self._params, rescaling=self._rescaling, flags=flags)
         return _to_gradients(out)
@@ -169,7 +175,7 @@ class rooted_instance(_GenericInstance):
         return self._get_engine().log_likelihoods(pid, bl, self._params, rates=self._rates(),
                                                   rescaling=self._rescaling)
 
-    def phylo_gradients(self, flags: int = _capi.GRAD_CLOCK_MODEL) -> List[PhyloGradient]:
+    def phylo_gradients(self, flags: int = DEFAULT_GRADIENT_FLAGS) -> List[PhyloGradient]:
         pid, bl = self._wire()
         out = self._get_engine().gradients(pid, bl, self._params, rates=self._rates(), rescaling=self._rescaling,
                                            flags=flags)

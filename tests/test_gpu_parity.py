@@ -257,6 +257,62 @@ def test_pattern_counts_around_tile_edges():
         assert grad_close(out["branch_lengths"], ref["branch_lengths"]), P
 
 
+def test_model_parameter_gradients(data_dir):
+    """site_model / substitution_model / clock_model entries of PhyloGradient: the reference's
+    fluA goldens (src/rooted_sbn_instance.hpp:347-430) and the oracle on DS1."""
+    tc, sp = load(data_dir, "fluA.fa", "fluA.tree")
+    pid, bl = tc.parent_id_matrix(), tc.branch_length_matrix()
+    rates = np.full((1, tc.trees[0].node_count - 1), 0.001)
+    allflags = (_capi.GRAD_SUBSTITUTION_MODEL | _capi.GRAD_SITE_MODEL | _capi.GRAD_CLOCK_MODEL |
+                _capi.GRAD_STICKBREAKING)
+    # Weibull shape gradient
+    g = GOLD["flua_jc69_weibull4_shape0.1"]
+    gpu, cpu = engines("JC69", "weibull+4", "strict", sp.patterns, sp.weights, 1)
+    params = gpu.default_params(1)
+    params[:, gpu.block_map()["Weibull_shape"][0]] = g["shape"]
+    out = gpu.gradients(pid, bl, params, rates=rates, flags=allflags)
+    assert abs(out["log_likelihood"][0] - g["log_likelihood"]) < 1e-8
+    assert abs(out["site_model"][0] - g["site_model_gradient"]) < 1e-6
+    assert "substitution_model" not in out  # JC69 has no free parameters (fat_beagle.cpp:525)
+    # GTR and HKY finite-difference gradients in stick-breaking coordinates
+    for key, sub, row in (("flua_gtr", "GTR", GOLD["flua_gtr"]["frequencies"] + GOLD["flua_gtr"]["rates"]),
+                          ("flua_hky", "HKY", GOLD["flua_hky"]["frequencies"] + [GOLD["flua_hky"]["kappa"]])):
+        gpu2, cpu2 = engines(sub, "constant", "strict", sp.patterns, sp.weights, 1)
+        p2 = gpu2.default_params(1)
+        p2[0, :len(row)] = row
+        out2 = gpu2.gradients(pid, bl, p2, rates=rates, flags=allflags)
+        ref2 = cpu2.gradients(pid, bl, p2, rates=rates, flags=oracle.GRAD_SUBSTITUTION_MODEL | oracle.GRAD_STICKBREAKING |
+                              oracle.GRAD_CLOCK_MODEL)
+        assert np.abs(out2["substitution_model"][0] - GOLD[key]["substitution_model_gradient"]).max() < GOLD[key]["gradient_tol"]
+        assert np.abs(out2["substitution_model"] - ref2["substitution_model"]).max() < 2e-3  # FD of two FP64 codes, delta 1e-6
+        assert abs(out2["clock_model"][0] - ref2["clock_model"][0]) < 1e-6 * abs(ref2["clock_model"][0])
+        assert out2["substitution_model_rates"].shape[1] + out2["substitution_model_frequencies"].shape[1] == \
+            out2["substitution_model"].shape[1]
+        # the main batch stays resident and consistent after the composed call
+        ll_again, grad_again = gpu2.download()
+        assert np.array_equal(ll_again, out2["log_likelihood"]) and np.array_equal(grad_again, out2["branch_lengths"])
+    # unrooted, headline model, identity transform, every kernel path that supports it
+    w = workloads.ds1_gtr_weibull4(1).subset(5)
+    gpu3, cpu3 = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 5)
+    out3 = gpu3.gradients(w.parent_ids, w.branch_lengths, w.params,
+                          flags=_capi.GRAD_SITE_MODEL | _capi.GRAD_SUBSTITUTION_MODEL)
+    ref3 = cpu3.gradients(w.parent_ids, w.branch_lengths, w.params,
+                          flags=oracle.GRAD_SITE_MODEL | oracle.GRAD_SUBSTITUTION_MODEL)
+    assert np.abs(out3["site_model"] - ref3["site_model"]).max() < 1e-6 * max(1.0, np.abs(ref3["site_model"]).max())
+    assert out3["substitution_model"].shape == (5, 10)
+    assert np.abs(out3["substitution_model"] - ref3["substitution_model"]).max() < 1e-3 * max(1.0, np.abs(ref3["substitution_model"]).max())
+    assert grad_close(out3["branch_lengths"], ref3["branch_lengths"])
+    # the instance API returns every key by default, like the reference's default flags
+    inst = bito_amd.unrooted_instance("x")
+    inst.read_nexus_file(os.path.join(data_dir, "DS1.subsampled_10.t"))
+    inst.read_fasta_file(os.path.join(data_dir, "DS1.fasta"))
+    inst.prepare_for_phylo_likelihood(spec("GTR", "weibull+4", "strict"), 1)
+    grads = inst.phylo_gradients()
+    assert set(grads[0].gradient) == {"branch_lengths", "site_model", "substitution_model", "substitution_model_rates",
+                                      "substitution_model_frequencies"}
+    assert grads[0].gradient["substitution_model"].shape == (8,)
+
+
 def test_resident_batch_interface():
     w = workloads.ds1_gtr_weibull4(1).subset(20)
     gpu = bito_amd.Engine(spec(w.substitution, w.site, w.clock), w.patterns, w.weights)
