@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 DATA = os.path.join(ROOT, "tests", "golden", "data")
+TESTS_DIR = os.path.join(ROOT, "tests")
+if TESTS_DIR not in sys.path:
+    sys.path.insert(0, TESTS_DIR)
 
 
 def pytest_configure(config):

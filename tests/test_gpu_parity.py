@@ -413,3 +413,37 @@ def test_error_behaviour(data_dir):
         fresh.run(False)
     # the engine is still usable after an error
     assert np.isfinite(eng.log_likelihoods(pid, bl)[0])
+
+
+@pytest.mark.parametrize("use_tip_states", [True, False])
+@pytest.mark.parametrize("rescaling", [False, True])
+def test_beagle_shim_with_fatbeagle_call_sequence(data_dir, use_tip_states, rescaling):
+    """SURVEY 8b seam 1: the 17 BEAGLE symbols FatBeagle calls, driven in FatBeagle's own
+    order (tests/beagle_driver.py), reproduce the reference's DS1 goldens and the oracle."""
+    from beagle_driver import FatBeagleDriver
+
+    g = GOLD["ds1_jc69"]
+    tc, sp = load(data_dir, g["fasta"], g["trees"])
+    Q, V, Vi, lam, pi = oracle.substitution_model("JC69")
+    drv = FatBeagleDriver(sp.patterns, sp.weights, V, Vi, lam, pi, Q, [1.0], [1.0], use_tip_states)
+    assert "bito_amd" in drv.impl
+    pid, bl = tc.parent_id_matrix(), tc.branch_length_matrix()
+    for t in (0, 9):
+        ll = drv.log_likelihood(pid[t], bl[t], rescaling)
+        assert abs(ll - g["log_likelihoods"][t]) < 5e-10
+    ll, grad = drv.gradient(pid[9], bl[9], rescaling)
+    assert abs(ll - g["log_likelihoods"][9]) < 5e-10
+    assert np.abs(np.sort(grad) - g["last_tree_sorted_branch_gradient"]).max() < g["gradient_tol"]
+    drv.close()
+    # GTR + weibull+4 against the oracle
+    w = workloads.ds1_gtr_weibull4(1).subset(3)
+    cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 1)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+    Q, V, Vi, lam, pi = oracle.substitution_model("GTR", w.params[0, :10])
+    rates, props, _ = oracle.weibull_rates(4, w.params[0, 10])
+    drv = FatBeagleDriver(w.patterns, w.weights, V, Vi, lam, pi, Q, rates, props, use_tip_states)
+    for t in range(3):
+        ll, grad = drv.gradient(w.parent_ids[t], w.branch_lengths[t], rescaling)
+        assert ll_close(ll, ref["log_likelihood"][t])
+        assert grad_close(grad, ref["branch_lengths"][t])
+    drv.close()

@@ -30,6 +30,17 @@ def test_header_symbols_are_exported():
     assert bito_amd.version().startswith("bito_amd")
 
 
+def test_beagle_shim_symbols_are_exported():
+    from beagle_driver import BEAGLE_SYMBOLS
+
+    header = open(os.path.join(ROOT, "include", "bito_amd_beagle.h")).read()
+    declared = set(re.findall(r"\b(beagle[A-Z][A-Za-z]+)\s*\(", header))
+    assert declared == set(BEAGLE_SYMBOLS) and len(declared) == 17
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libbito_amd.so does not export {name}"
+
+
 def test_no_signature_leaks_torch_or_cxx_types():
     header = open(os.path.join(ROOT, "include", "bito_amd.h")).read()
     code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)  # declarations only, comments stripped
