@@ -70,7 +70,7 @@ struct bito_amd_engine {
   bool has_rates = false;
   DeviceBuffer<int32_t> parent_ids, children;
   DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
-      out_ll, out_grad;
+      out_ll, out_grad, scale_arena;
   DeviceBuffer<TreeModel> model;
   // host mirrors for the composed gradients
   std::vector<double> h_params;
@@ -83,7 +83,7 @@ struct bito_amd_engine {
     (void)hipSetDevice(device);
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
     tip_states.Free(); weights.Free(); parent_ids.Free(); children.Free(); branch_in.Free();
-    rates.Free(); params.Free(); branch.Free(); mats.Free(); images.Free(); arena.Free(); part_ll.Free();
+    rates.Free(); params.Free(); branch.Free(); mats.Free(); images.Free(); arena.Free(); scale_arena.Free(); part_ll.Free();
     part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free();
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -244,6 +244,7 @@ DeviceBatch MakeBatch(bito_amd_engine* e) {
   b.mats = e->mats.ptr;
   b.images = e->images.ptr;
   b.arena = e->arena.ptr;
+  b.scale_arena = e->scale_arena.ptr;
   b.part_ll = e->part_ll.ptr;
   b.part_grad = e->part_grad.ptr;
   b.out_ll = e->out_ll.ptr;
@@ -317,6 +318,8 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   // grid.y limit
   chunk = std::min<size_t>(chunk, 65535);
   HIP_TRY(e, e->arena.Reserve(chunk * per_tree / sizeof(double)));
+  if (want_gradient && rescaling)
+    HIP_TRY(e, e->scale_arena.Reserve(chunk * (size_t)(d.taxon_count - 1) * d.pattern_stride));
   const DeviceBatch b = MakeBatch(e);
   LaunchSetup(d, e->spec, b, want_gradient, e->stream);
   LaunchMatrices(d, b, want_gradient, deriv_mode, e->stream);

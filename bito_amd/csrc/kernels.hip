@@ -190,8 +190,8 @@ __global__ void __launch_bounds__(kHbmBlock)
 walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
                 const double* __restrict__ all_mats, const TreeModel* __restrict__ models,
                 const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
-                double* __restrict__ arena_base, double* __restrict__ part_ll,
-                double* __restrict__ part_grad) {
+                double* __restrict__ arena_base, double* __restrict__ scale_base,
+                double* __restrict__ part_ll, double* __restrict__ part_grad) {
   extern __shared__ double lds[];  // [waves][N] gradient rows, then [waves] log-likelihoods
   constexpr int kWaves = kHbmBlock / 64;
   const int n = d.taxon_count, N = d.node_count, NI = n - 1, Ppad = d.pattern_stride;
@@ -203,6 +203,8 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
   const TreeModel* __restrict__ tm = models + tree;
   const uint8_t* __restrict__ tips = tip_states + p;
   double* __restrict__ arena = arena_base + (size_t)blockIdx.y * NI * C * 4 * Ppad + p;
+  // per-node, per-pattern reciprocal scale factors of the post-order pass (RESCALE && GRAD)
+  double* __restrict__ inv_scale = scale_base + (size_t)blockIdx.y * NI * Ppad + p;
   const double weight = weights[p];
 
   if (GRAD) {
@@ -258,6 +260,7 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
 #pragma unroll
         for (int i = 0; i < 4; i++) dd[c][i] *= inv;
       log_scale += log(mx);
+      if (GRAD) inv_scale[(size_t)(node - n) * Ppad] = inv;
     }
     if (node == N - 1) {
 #pragma unroll
@@ -335,54 +338,29 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
         if (!tip0) MatVecT(m0 + kMatP, UA1, q0);
         if (!tip1) MatVecT(m1 + kMatP, UA0, q1);
       };
-      if constexpr (RESCALE) {
-        // Pre-order partials are rescaled per pattern over all categories like the
-        // post-order ones (BEAGLE scaleWrite on the pre-order ops, fat_beagle.cpp:362-363);
-        // the factor cancels in num/den, so it is not accumulated.
-        double pre0[C][4], pre1[C][4];
-#pragma unroll
-        for (int c = 0; c < C; c++) category_step(c, pre0[c], pre1[c]);
+      // Rescaling of the pre-order partials.  BEAGLE rescales each pre-order partial by its
+      // own maximum (scaleWrite on the pre-order ops, fat_beagle.cpp:362-363); the factor
+      // cancels in num/den, so any positive per-pattern factor gives the same derivatives.
+      // Dividing by the parent's POST-order factor m_node keeps pre(X) * exp(S(X) - S(root))
+      // (S = summed log factors of a subtree), whose product with the scaled post-order
+      // partial of X sums to the scaled site likelihood, i.e. stays O(1) -- and the factor
+      // is known before the category loop, so nothing has to be held across categories.
+      const double step_inv = RESCALE ? inv_scale[(size_t)(node - n) * Ppad] : 1.0;
+      // In place, one category at a time: cell (child, c) is read (as the child's
+      // post-order partial) before it is overwritten with its pre-order partial.
+#pragma unroll 1
+      for (int c = 0; c < C; c++) {
+        double q0[4], q1[4];
+        category_step(c, q0, q1);
         if (!tip0) {
-          double mx = 0.0;
 #pragma unroll
-          for (int c = 0; c < C; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) mx = fmax(mx, pre0[c][i]);
-          const double inv = 1.0 / (mx == 0.0 ? 1.0 : mx);
-#pragma unroll
-          for (int c = 0; c < C; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-              arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad] = pre0[c][i] * inv;
+          for (int i = 0; i < 4; i++)
+            arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad] = RESCALE ? q0[i] * step_inv : q0[i];
         }
         if (!tip1) {
-          double mx = 0.0;
 #pragma unroll
-          for (int c = 0; c < C; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) mx = fmax(mx, pre1[c][i]);
-          const double inv = 1.0 / (mx == 0.0 ? 1.0 : mx);
-#pragma unroll
-          for (int c = 0; c < C; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-              arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad] = pre1[c][i] * inv;
-        }
-      } else {
-        // In place, one category at a time: cell (child, c) is read (as the child's
-        // post-order partial) before it is overwritten with its pre-order partial.
-#pragma unroll 1
-        for (int c = 0; c < C; c++) {
-          double q0[4], q1[4];
-          category_step(c, q0, q1);
-          if (!tip0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad] = q0[i];
-          }
-          if (!tip1) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad] = q1[i];
-          }
+          for (int i = 0; i < 4; i++)
+            arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad] = RESCALE ? q1[i] * step_inv : q1[i];
         }
       }
       const double scale = weight / den;
@@ -428,17 +406,17 @@ static void LaunchWalkHbmC(const BatchDims& d, const DeviceBatch& b, int tree0, 
   if (want_gradient) {
     if (rescaling)
       hipLaunchKernelGGL((walk_hbm_kernel<C, true, true>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model,
-                         b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+                         b.tip_states, b.weights, b.arena, b.scale_arena, b.part_ll, b.part_grad);
     else
       hipLaunchKernelGGL((walk_hbm_kernel<C, true, false>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model,
-                         b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+                         b.tip_states, b.weights, b.arena, b.scale_arena, b.part_ll, b.part_grad);
   } else {
     if (rescaling)
       hipLaunchKernelGGL((walk_hbm_kernel<C, false, true>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model,
-                         b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+                         b.tip_states, b.weights, b.arena, b.scale_arena, b.part_ll, b.part_grad);
     else
       hipLaunchKernelGGL((walk_hbm_kernel<C, false, false>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model,
-                         b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+                         b.tip_states, b.weights, b.arena, b.scale_arena, b.part_ll, b.part_grad);
   }
 }
 

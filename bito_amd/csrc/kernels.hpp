@@ -55,6 +55,7 @@ struct DeviceBatch {
   double* images;             // [T][N-1][kImgStride]      (LDS kernel)
   // traversal scratch + outputs
   double* arena;              // [chunk][n-1][C][4][Ppad]
+  double* scale_arena;        // [chunk][n-1][Ppad]  post-order 1/scale factors (rescaled gradients)
   double* part_ll;            // [T][tiles]
   double* part_grad;          // [T][tiles][N]
   double* out_ll;             // [T]
