@@ -1,0 +1,438 @@
+// gp_engine.hip -- GPU executor for bito's GPOperation streams (include/bito_amd_gp.h).
+//
+// Arena in HBM: PLV i is [4][Ppad] doubles (state-major rows, so a wave touches 64
+// consecutive patterns), with one int32 rescaling count per (PLV, pattern).  The reference
+// keeps ONE rescaling count per PLV decided from the whole-PLV maximum
+// (src/gp_engine.cpp:583-597); here the same rule is applied per pattern column, which
+// removes the only cross-pattern coupling of the PLV ops -- log-likelihoods are invariant
+// to how often a column was rescaled (the reference's own invariance test,
+// src/gp_doctest.cpp:348-360), so results agree to rounding.  With that, a whole run of
+// ops is one kernel launch: each thread owns a pattern and interprets the op stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/bito_amd.h"
+#include "../../include/bito_amd_gp.h"
+
+struct bito_amd_gp_engine {
+  int device = 0, n = 0, P = 0, Ppad = 0, nodes = 0, gpcsps = 0, plvs = 0;
+  double threshold = 1e-40, log_threshold = 0;
+  double *plv = nullptr, *weights = nullptr, *bl = nullptr, *q = nullptr, *ll = nullptr, *marginal = nullptr;
+  double* scratch = nullptr;
+  int* counts = nullptr;
+  bito_amd_gp_op* d_ops = nullptr;
+  uint64_t* d_side = nullptr;
+  size_t ops_cap = 0, side_cap = 0;
+  std::string err;
+  ~bito_amd_gp_engine() {
+    (void)hipSetDevice(device);
+    for (void* p : {(void*)plv, (void*)weights, (void*)bl, (void*)q, (void*)ll, (void*)marginal, (void*)scratch,
+                    (void*)counts, (void*)d_ops, (void*)d_side})
+      if (p) (void)hipFree(p);
+  }
+};
+
+namespace {
+
+__constant__ double cV[16] = {1.0, 2.0, 0.0, 0.5, 1.0, -2.0, 0.5, 0.0, 1.0, 2.0, 0.0, -0.5, 1.0, -2.0, -0.5, 0.0};
+__constant__ double cVi[16] = {0.25, 0.25, 0.25, 0.25, 0.125, -0.125, 0.125, -0.125,
+                               0.0, 1.0, 0.0, -1.0, 1.0, 0.0, -1.0, 0.0};
+constexpr double kLam = -1.3333333333333333;
+
+// P(t), and optionally P'(t), P''(t), through the eigensystem like the reference
+// (src/gp_engine.cpp:341-364); fixed operation order, no FMA contraction (see model.hpp).
+__device__ inline void Matrices(double t, double* M, double* dM, double* ddM) {
+#pragma clang fp contract(off)
+  const double e = exp(kLam * t);
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double s = 0, d = 0, dd = 0;
+      for (int k = 0; k < 4; k++) {
+        const double ek = k == 0 ? 1.0 : e, lk = k == 0 ? 0.0 : kLam;
+        s += cV[i * 4 + k] * ek * cVi[k * 4 + j];
+        d += cV[i * 4 + k] * (lk * ek) * cVi[k * 4 + j];
+        dd += cV[i * 4 + k] * (lk * lk * ek) * cVi[k * 4 + j];
+      }
+      M[i * 4 + j] = s;
+      if (dM) dM[i * 4 + j] = d;
+      if (ddM) ddM[i * 4 + j] = dd;
+    }
+}
+
+__device__ inline double LogAdd(double x, double y) {
+  if (y > x) { const double t = x; x = y; y = t; }
+  if (x == -INFINITY) return x;
+  const double nd = y - x;
+  if (nd < -36.04365338911715) return x;
+  return x + log(1.0 + exp(nd));
+}
+
+__global__ void __launch_bounds__(64)
+gp_ops_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const uint64_t* __restrict__ side,
+              double* __restrict__ plv, int* __restrict__ counts, const double* __restrict__ bl,
+              const double* __restrict__ q, double* __restrict__ ll, double* __restrict__ marginal, int P, int Ppad,
+              double threshold, double log_threshold) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  auto cell = [&](uint64_t idx, int i) -> double& { return plv[((size_t)idx * 4 + i) * Ppad + p]; };
+  auto cnt = [&](uint64_t idx) -> int& { return counts[(size_t)idx * Ppad + p]; };
+  for (int64_t o = 0; o < op_count; o++) {
+    const bito_amd_gp_op op = ops[o];
+    switch (op.opcode) {
+      case BITO_AMD_GP_ZERO_PLV:
+        for (int i = 0; i < 4; i++) cell(op.a, i) = 0.0;
+        cnt(op.a) = 0;
+        break;
+      case BITO_AMD_GP_SET_TO_STATIONARY_DISTRIBUTION:
+        for (int i = 0; i < 4; i++) cell(op.a, i) = q[op.b] * 0.25;
+        cnt(op.a) = 0;
+        break;
+      case BITO_AMD_GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV: {
+        double M[16];
+        Matrices(bl[op.b], M, nullptr, nullptr);
+        const int diff = cnt(op.c) - cnt(op.a);
+        const double f = (diff == 0 ? 1.0 : pow(threshold, (double)diff)) * q[op.b];
+        double s[4];
+        for (int i = 0; i < 4; i++) s[i] = cell(op.c, i);
+        for (int i = 0; i < 4; i++)
+          cell(op.a, i) += f * (M[i * 4] * s[0] + M[i * 4 + 1] * s[1] + M[i * 4 + 2] * s[2] + M[i * 4 + 3] * s[3]);
+        break;
+      }
+      case BITO_AMD_GP_MULTIPLY: {
+        double d[4], mx = 0;
+        for (int i = 0; i < 4; i++) {
+          d[i] = cell(op.b, i) * cell(op.c, i);
+          mx = fmax(mx, d[i]);
+        }
+        int c = cnt(op.b) + cnt(op.c);
+        if (mx != 0) {  // RescalePLVIfNeeded, per pattern column
+          int extra = 0;
+          while (mx < threshold) {
+            mx /= threshold;
+            extra++;
+          }
+          if (extra) {
+            const double f = pow(threshold, (double)extra);
+            for (int i = 0; i < 4; i++) d[i] /= f;
+            c += extra;
+          }
+        }
+        for (int i = 0; i < 4; i++) cell(op.a, i) = d[i];
+        cnt(op.a) = c;
+        break;
+      }
+      case BITO_AMD_GP_LIKELIHOOD: {
+        double M[16];
+        Matrices(bl[op.a], M, nullptr, nullptr);
+        double s = 0;
+        for (int i = 0; i < 4; i++)
+          s += cell(op.c, i) * (M[i * 4] * cell(op.b, 0) + M[i * 4 + 1] * cell(op.b, 1) + M[i * 4 + 2] * cell(op.b, 2) +
+                                M[i * 4 + 3] * cell(op.b, 3));
+        ll[(size_t)op.a * Ppad + p] = log(s) + (cnt(op.b) + cnt(op.c)) * log_threshold;
+        break;
+      }
+      case BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD:
+        marginal[p] = -INFINITY;
+        break;
+      case BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD: {
+        double s = 0;
+        for (int i = 0; i < 4; i++) s += cell(op.a, i) * cell(op.c, i);
+        const double row = log(s) + cnt(op.c) * log_threshold;
+        marginal[p] = LogAdd(marginal[p], row);
+        ll[(size_t)op.b * Ppad + p] = row - log(q[op.b]);
+        break;
+      }
+      case BITO_AMD_GP_PREP_FOR_MARGINALIZATION: {
+        int mn = cnt(side[op.b]);
+        for (uint32_t k = 1; k < op.count; k++) mn = min(mn, cnt(side[op.b + k]));
+        cnt(op.a) = mn;
+        break;
+      }
+      default:
+        break;
+    }
+  }
+}
+
+// block per row: out[row] = sum_p w_p * rows[row][p]
+__global__ void __launch_bounds__(256)
+gp_weighted_rows_kernel(const double* __restrict__ rows, const double* __restrict__ weights, int P, int Ppad,
+                        double* __restrict__ out) {
+  __shared__ double sh[4];
+  double acc = 0;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) acc += weights[p] * rows[(size_t)blockIdx.x * Ppad + p];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ void __launch_bounds__(256)
+gp_derivatives_kernel(const double* __restrict__ plv, const int* __restrict__ counts, const double* __restrict__ weights,
+                      double t, uint64_t rootward, uint64_t leafward, int P, int Ppad, double log_threshold,
+                      double* __restrict__ out) {
+  __shared__ double sh[3][4];
+  double M[16], dM[16], ddM[16];
+  Matrices(t, M, dM, ddM);
+  double a0 = 0, a1 = 0, a2 = 0;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    double r[4], x[4];
+    for (int i = 0; i < 4; i++) {
+      r[i] = plv[((size_t)rootward * 4 + i) * Ppad + p];
+      x[i] = plv[((size_t)leafward * 4 + i) * Ppad + p];
+    }
+    double l = 0, a = 0, b = 0;
+    for (int i = 0; i < 4; i++) {
+      l += r[i] * (M[i * 4] * x[0] + M[i * 4 + 1] * x[1] + M[i * 4 + 2] * x[2] + M[i * 4 + 3] * x[3]);
+      a += r[i] * (dM[i * 4] * x[0] + dM[i * 4 + 1] * x[1] + dM[i * 4 + 2] * x[2] + dM[i * 4 + 3] * x[3]);
+      b += r[i] * (ddM[i * 4] * x[0] + ddM[i * 4 + 1] * x[1] + ddM[i * 4 + 2] * x[2] + ddM[i * 4 + 3] * x[3]);
+    }
+    const double resc = (counts[(size_t)rootward * Ppad + p] + counts[(size_t)leafward * Ppad + p]) * log_threshold;
+    a0 += weights[p] * (log(l) + resc);
+    a1 += weights[p] * (a / l);
+    a2 += weights[p] * ((b * l - a * a) / (l * l));
+  }
+  double v[3] = {a0, a1, a2};
+  for (int k = 0; k < 3; k++) {
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) out[threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+
+int Fail(bito_amd_gp_engine* e, int code, const std::string& msg) {
+  e->err = msg;
+  return code;
+}
+
+#define GP_TRY(e, call)                                                                                     \
+  do {                                                                                                      \
+    hipError_t rc_ = (call);                                                                                \
+    if (rc_ != hipSuccess) return Fail(e, BITO_AMD_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(rc_)); \
+  } while (0)
+
+int RunSegment(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t count) {
+  if (count <= 0) return BITO_AMD_OK;
+  if ((size_t)count > e->ops_cap) {
+    if (e->d_ops) (void)hipFree(e->d_ops);
+    e->ops_cap = 0;
+    GP_TRY(e, hipMalloc((void**)&e->d_ops, count * sizeof(bito_amd_gp_op)));
+    e->ops_cap = count;
+  }
+  GP_TRY(e, hipMemcpy(e->d_ops, ops, count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64), dim3(64), 0, 0, e->d_ops, count, e->d_side, e->plv,
+                     e->counts, e->bl, e->q, e->ll, e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
+  GP_TRY(e, hipGetLastError());
+  return BITO_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bito_amd_gp_create(int32_t device_id, int32_t taxon_count, int32_t pattern_count, const int32_t* patterns,
+                       const double* weights, int32_t node_count, int32_t gpcsp_count, double rescaling_threshold,
+                       bito_amd_gp_engine** out, char* err, size_t err_len) {
+  auto report = [&](int code, const std::string& msg) {
+    if (err && err_len) std::snprintf(err, err_len, "%s", msg.c_str());
+    return code;
+  };
+  if (!out) return report(BITO_AMD_ERR_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  if (taxon_count < 2 || pattern_count < 1 || node_count < taxon_count || gpcsp_count < 1 || !patterns || !weights)
+    return report(BITO_AMD_ERR_BAD_ARG, "bad sizes or NULL arrays");
+  if (!(rescaling_threshold > 0 && rescaling_threshold < 1))
+    return report(BITO_AMD_ERR_BAD_ARG, "rescaling threshold must be in (0,1)");
+  int devices = 0;
+  if (hipGetDeviceCount(&devices) != hipSuccess || devices <= 0 || device_id < 0 || device_id >= devices)
+    return report(BITO_AMD_ERR_DEVICE, "no HIP device available: the GP executor needs an MI355X (no CPU fallback)");
+  auto e = new bito_amd_gp_engine();
+  e->device = device_id; e->n = taxon_count; e->P = pattern_count; e->Ppad = (pattern_count + 63) / 64 * 64;
+  e->nodes = node_count; e->gpcsps = gpcsp_count; e->plvs = 6 * node_count;
+  e->threshold = rescaling_threshold; e->log_threshold = std::log(rescaling_threshold);
+  (void)hipSetDevice(device_id);
+  const size_t plv_bytes = (size_t)e->plvs * 4 * e->Ppad * sizeof(double);
+  bool ok = hipMalloc((void**)&e->plv, plv_bytes) == hipSuccess &&
+            hipMalloc((void**)&e->counts, (size_t)e->plvs * e->Ppad * sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&e->weights, e->Ppad * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&e->bl, gpcsp_count * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&e->q, gpcsp_count * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&e->ll, (size_t)gpcsp_count * e->Ppad * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&e->marginal, e->Ppad * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&e->scratch, (size_t)(gpcsp_count + 4) * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&e->d_side, sizeof(uint64_t)) == hipSuccess;
+  if (!ok) { delete e; return report(BITO_AMD_ERR_DEVICE, "hipMalloc failed for the PLV arena"); }
+  e->side_cap = 1;
+  (void)hipMemset(e->plv, 0, plv_bytes);
+  (void)hipMemset(e->counts, 0, (size_t)e->plvs * e->Ppad * sizeof(int));
+  (void)hipMemset(e->ll, 0, (size_t)gpcsp_count * e->Ppad * sizeof(double));
+  (void)hipMemset(e->marginal, 0, e->Ppad * sizeof(double));
+  // InitializePLVsWithSitePatterns: leaf P-PLVs (type 0): one-hot, all ones for a gap
+  std::vector<double> leaf((size_t)taxon_count * 4 * e->Ppad, 0.0);
+  for (int t = 0; t < taxon_count; t++)
+    for (int p = 0; p < pattern_count; p++) {
+      const int s = patterns[(size_t)t * pattern_count + p];
+      for (int i = 0; i < 4; i++) leaf[((size_t)t * 4 + i) * e->Ppad + p] = (s >= 4 || s == i) ? 1.0 : 0.0;
+    }
+  std::vector<double> w(e->Ppad, 0.0), ones(gpcsp_count, 1.0), zeros(gpcsp_count, 0.0);
+  for (int p = 0; p < pattern_count; p++) w[p] = weights[p];
+  ok = hipMemcpy(e->plv, leaf.data(), leaf.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(e->weights, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(e->q, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(e->bl, zeros.data(), zeros.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { delete e; return report(BITO_AMD_ERR_DEVICE, "hipMemcpy failed"); }
+  *out = e;
+  return BITO_AMD_OK;
+}
+
+void bito_amd_gp_destroy(bito_amd_gp_engine* e) { delete e; }
+const char* bito_amd_gp_last_error(const bito_amd_gp_engine* e) { return e ? e->err.c_str() : ""; }
+
+int bito_amd_gp_set_branch_lengths(bito_amd_gp_engine* e, const double* v) {
+  if (!e || !v) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  GP_TRY(e, hipMemcpy(e->bl, v, e->gpcsps * sizeof(double), hipMemcpyHostToDevice));
+  return BITO_AMD_OK;
+}
+int bito_amd_gp_get_branch_lengths(bito_amd_gp_engine* e, double* out) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  GP_TRY(e, hipMemcpy(out, e->bl, e->gpcsps * sizeof(double), hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+int bito_amd_gp_set_sbn_parameters(bito_amd_gp_engine* e, const double* v) {
+  if (!e || !v) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  GP_TRY(e, hipMemcpy(e->q, v, e->gpcsps * sizeof(double), hipMemcpyHostToDevice));
+  return BITO_AMD_OK;
+}
+int bito_amd_gp_get_sbn_parameters(bito_amd_gp_engine* e, double* out) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  GP_TRY(e, hipMemcpy(out, e->q, e->gpcsps * sizeof(double), hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_per_gpcsp_log_likelihoods(bito_amd_gp_engine* e, double* out) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(gp_weighted_rows_kernel, dim3(e->gpcsps), dim3(256), 0, 0, e->ll, e->weights, e->P, e->Ppad,
+                     e->scratch);
+  GP_TRY(e, hipMemcpy(out, e->scratch, e->gpcsps * sizeof(double), hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_log_marginal_likelihood(bito_amd_gp_engine* e, double* out) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(gp_weighted_rows_kernel, dim3(1), dim3(256), 0, 0, e->marginal, e->weights, e->P, e->Ppad,
+                     e->scratch);
+  GP_TRY(e, hipMemcpy(out, e->scratch, sizeof(double), hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_log_likelihood_matrix(bito_amd_gp_engine* e, double* out) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  GP_TRY(e, hipMemcpy2D(out, e->P * sizeof(double), e->ll, e->Ppad * sizeof(double), e->P * sizeof(double), e->gpcsps,
+                        hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count,
+                                   const uint64_t* side, int64_t side_count) {
+  if (!e || (op_count > 0 && !ops)) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  // validate ids once on the host
+  for (int64_t o = 0; o < op_count; o++) {
+    const bito_amd_gp_op& op = ops[o];
+    auto plv_ok = [&](uint64_t id) { return id < (uint64_t)e->plvs; };
+    auto gp_ok = [&](uint64_t id) { return id < (uint64_t)e->gpcsps; };
+    bool ok = true;
+    switch (op.opcode) {
+      case BITO_AMD_GP_ZERO_PLV: ok = plv_ok(op.a); break;
+      case BITO_AMD_GP_SET_TO_STATIONARY_DISTRIBUTION: ok = plv_ok(op.a) && gp_ok(op.b); break;
+      case BITO_AMD_GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV: ok = plv_ok(op.a) && gp_ok(op.b) && plv_ok(op.c); break;
+      case BITO_AMD_GP_MULTIPLY: ok = plv_ok(op.a) && plv_ok(op.b) && plv_ok(op.c); break;
+      case BITO_AMD_GP_LIKELIHOOD: ok = gp_ok(op.a) && plv_ok(op.b) && plv_ok(op.c); break;
+      case BITO_AMD_GP_UPDATE_SBN_PROBABILITIES: ok = op.a < op.b && op.b <= (uint64_t)e->gpcsps; break;
+      case BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD: break;
+      case BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD: ok = plv_ok(op.a) && gp_ok(op.b) && plv_ok(op.c); break;
+      case BITO_AMD_GP_PREP_FOR_MARGINALIZATION:
+        ok = plv_ok(op.a) && op.count > 0 && side && op.b + op.count <= (uint64_t)side_count;
+        for (uint32_t k = 0; ok && k < op.count; k++) ok = plv_ok(side[op.b + k]);
+        break;
+      case BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH:
+        return Fail(e, BITO_AMD_ERR_BAD_ARG,
+                    "OptimizeBranchLength is not executed on the device: drive the optimiser on the host with "
+                    "bito_amd_gp_log_likelihood_and_first_two_derivatives (SURVEY 8f row f1)");
+      default:
+        return Fail(e, BITO_AMD_ERR_BAD_ARG, "unknown GP opcode " + std::to_string(op.opcode));
+    }
+    if (!ok) return Fail(e, BITO_AMD_ERR_BAD_ARG, "GP op " + std::to_string(o) + " has an index out of range");
+  }
+  if (side_count > 0 && side) {
+    if ((size_t)side_count > e->side_cap) {
+      (void)hipFree(e->d_side);
+      e->side_cap = 0;
+      GP_TRY(e, hipMalloc((void**)&e->d_side, side_count * sizeof(uint64_t)));
+      e->side_cap = side_count;
+    }
+    GP_TRY(e, hipMemcpy(e->d_side, side, side_count * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
+  int64_t start = 0;
+  for (int64_t o = 0; o <= op_count; o++) {
+    const bool boundary = o == op_count || ops[o].opcode == BITO_AMD_GP_UPDATE_SBN_PROBABILITIES;
+    if (!boundary) continue;
+    int rc = RunSegment(e, ops + start, o - start);
+    if (rc) return rc;
+    if (o < op_count) {
+      // UpdateSBNProbabilities (src/gp_engine.cpp:297-321): softmax over sibling GPCSPs of the
+      // weighted per-GPCSP log-likelihood plus the log prior.
+      const uint64_t a = ops[o].a, b = ops[o].b;
+      const int len = (int)(b - a);
+      std::vector<double> qv(e->gpcsps);
+      GP_TRY(e, hipMemcpy(qv.data(), e->q, e->gpcsps * sizeof(double), hipMemcpyDeviceToHost));
+      if (len == 1) {
+        qv[a] = 1.0;
+      } else {
+        std::vector<double> per(e->gpcsps);
+        rc = bito_amd_gp_per_gpcsp_log_likelihoods(e, per.data());
+        if (rc) return rc;
+        double norm = -INFINITY;
+        std::vector<double> lu(len);
+        for (int k = 0; k < len; k++) {
+          lu[k] = per[a + k] + std::log(qv[a + k]);
+          const double x = std::max(norm, lu[k]), y = std::min(norm, lu[k]);
+          norm = (x == -INFINITY || y - x < -36.04365338911715) ? x : x + std::log(1.0 + std::exp(y - x));
+        }
+        for (int k = 0; k < len; k++) qv[a + k] = std::exp(lu[k] - norm);
+      }
+      GP_TRY(e, hipMemcpy(e->q, qv.data(), e->gpcsps * sizeof(double), hipMemcpyHostToDevice));
+    }
+    start = o + 1;
+  }
+  GP_TRY(e, hipDeviceSynchronize());
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_log_likelihood_and_first_two_derivatives(bito_amd_gp_engine* e, int64_t gpcsp, int64_t rootward,
+                                                         int64_t leafward, double* out) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  if (gpcsp < 0 || gpcsp >= e->gpcsps || rootward < 0 || rootward >= e->plvs || leafward < 0 || leafward >= e->plvs)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "index out of range");
+  GP_TRY(e, hipSetDevice(e->device));
+  double t = 0;
+  GP_TRY(e, hipMemcpy(&t, e->bl + gpcsp, sizeof(double), hipMemcpyDeviceToHost));
+  hipLaunchKernelGGL(gp_derivatives_kernel, dim3(1), dim3(256), 0, 0, e->plv, e->counts, e->weights, t,
+                     (uint64_t)rootward, (uint64_t)leafward, e->P, e->Ppad, e->log_threshold, e->scratch);
+  GP_TRY(e, hipMemcpy(out, e->scratch, 3 * sizeof(double), hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+
+}  // extern "C"

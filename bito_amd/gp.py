@@ -1,0 +1,242 @@
+"""Generalized-pruning (GPEngine) seam: op-stream encoding, a schedule generator for
+single-tree DAGs, and the ctypes mirror of the GPU executor (SURVEY.md section 8b seam 3).
+
+The reference turns subsplit-DAG traversals into a flat ``GPOperationVector``
+(src/gp_dag.cpp:177-411, src/gp_operation.hpp:24-170) that ``GPEngine::ProcessOperations``
+executes one op at a time (src/gp_engine.cpp:213-339).  The subsplit DAG itself is out of
+scope; what crosses the seam is the op stream, encoded here as POD records
+``{uint32 opcode, uint32 count, uint64 a, b, c}`` plus a side array of PLV ids for
+``PrepForMarginalization``.  ``single_tree_schedule`` emits the stream GPDAG would emit for
+the DAG of ONE rooted tree (every SBN probability 1), which is what the reference's
+``hello`` / ``fluA`` GP tests use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi
+from .engine import BitoAmdError
+
+# opcodes = alternative index in the reference's std::variant GPOperation (gp_operation.hpp:162-167)
+ZERO_PLV, SET_TO_STATIONARY, INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, MULTIPLY, LIKELIHOOD = 0, 1, 2, 3, 4
+OPTIMIZE_BRANCH_LENGTH, UPDATE_SBN_PROBABILITIES, RESET_MARGINAL_LIKELIHOOD = 5, 6, 7
+INCREMENT_MARGINAL_LIKELIHOOD, PREP_FOR_MARGINALIZATION = 8, 9
+
+# PLV types in the order of PLVTypeEnum (reference src/pv_handler.hpp:26-34)
+P, PHAT_RIGHT, PHAT_LEFT, RHAT, R_RIGHT, R_LEFT = range(6)
+
+OP_DTYPE = np.dtype([("opcode", np.uint32), ("count", np.uint32), ("a", np.uint64), ("b", np.uint64),
+                     ("c", np.uint64)])
+
+
+class OpStream:
+    def __init__(self):
+        self.ops: List[Tuple[int, int, int, int, int]] = []
+        self.side: List[int] = []
+
+    def add(self, opcode, a=0, b=0, c=0):
+        self.ops.append((opcode, 0, a, b, c))
+
+    def prep_for_marginalization(self, dest: int, sources: Sequence[int]):
+        self.ops.append((PREP_FOR_MARGINALIZATION, len(sources), dest, len(self.side), 0))
+        self.side.extend(int(x) for x in sources)
+
+    def arrays(self):
+        ops = np.array(self.ops, dtype=OP_DTYPE) if self.ops else np.zeros(0, dtype=OP_DTYPE)
+        side = np.array(self.side if self.side else [0], dtype=np.uint64)
+        return ops, side
+
+    def extend(self, other: "OpStream"):
+        base = len(self.side)
+        for opcode, count, a, b, c in other.ops:
+            if opcode == PREP_FOR_MARGINALIZATION:
+                b += base
+            self.ops.append((opcode, count, a, b, c))
+        self.side.extend(other.side)
+
+
+@dataclass
+class SingleTreeDAG:
+    """The subsplit DAG of one rooted tree: DAG node ids = tree node ids, GPCSP 0 is the
+    rootsplit edge, GPCSP 1+c the edge above tree node c."""
+    taxon_count: int
+    node_count: int  # without the DAG root
+    gpcsp_count: int
+    children: Dict[int, Tuple[int, int]]  # (left, right)
+    parent: Dict[int, Tuple[int, bool]]  # node -> (parent, node is the left child)
+    root: int
+
+    def pv(self, plv_type: int, node: int) -> int:
+        """PVId = type * node_count + node (reference src/pv_handler.hpp:487-490)."""
+        return plv_type * self.node_count + node
+
+    def edge(self, child: int) -> int:
+        return 0 if child == self.root else 1 + child
+
+    def branch_lengths(self, tree_branch_lengths: np.ndarray) -> np.ndarray:
+        out = np.zeros(self.gpcsp_count)
+        out[1:] = tree_branch_lengths[: self.node_count - 1]
+        return out
+
+    # -- GPDAG::PopulatePLVs (reference src/gp_dag.cpp:296-304) ---------------------
+    def populate_plvs(self) -> OpStream:
+        s = OpStream()
+        n = self.taxon_count
+        for node in range(n, self.node_count):  # SetRootwardZero
+            for t in (P, PHAT_RIGHT, PHAT_LEFT):
+                s.add(ZERO_PLV, self.pv(t, node))
+        for node in range(self.node_count):  # SetLeafwardZero
+            for t in (RHAT, R_RIGHT, R_LEFT):
+                s.add(ZERO_PLV, self.pv(t, node))
+        s.add(SET_TO_STATIONARY, self.pv(RHAT, self.root), 0)  # SetRhatToStationary
+        for node in range(n, self.node_count):  # RootwardPass: ids are a post-order
+            left, right = self.children[node]
+            for t, child in ((PHAT_RIGHT, right), (PHAT_LEFT, left)):
+                s.prep_for_marginalization(self.pv(t, node), [self.pv(P, child)])
+                s.add(INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, self.pv(t, node), self.edge(child), self.pv(P, child))
+            s.add(MULTIPLY, self.pv(P, node), self.pv(PHAT_RIGHT, node), self.pv(PHAT_LEFT, node))
+        order, stack = [], [self.root]  # LeafwardPass: parents before children
+        while stack:
+            node = stack.pop()
+            order.append(node)
+            if node in self.children:
+                stack.extend(reversed(self.children[node]))
+        for node in order:
+            if node != self.root:
+                parent, is_left = self.parent[node]
+                src = self.pv(R_LEFT if is_left else R_RIGHT, parent)
+                s.prep_for_marginalization(self.pv(RHAT, node), [src])
+                s.add(INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, self.pv(RHAT, node), self.edge(node), src)
+            s.add(MULTIPLY, self.pv(R_RIGHT, node), self.pv(RHAT, node), self.pv(PHAT_LEFT, node))
+            s.add(MULTIPLY, self.pv(R_LEFT, node), self.pv(RHAT, node), self.pv(PHAT_RIGHT, node))
+        return s
+
+    # -- GPDAG::ComputeLikelihoods + MarginalLikelihood (src/gp_dag.cpp:177-211) -------
+    def compute_likelihoods(self) -> OpStream:
+        s = OpStream()
+        for node in range(self.taxon_count, self.node_count):
+            left, right = self.children[node]
+            for child, is_left in ((left, True), (right, False)):
+                s.add(LIKELIHOOD, self.edge(child), self.pv(R_LEFT if is_left else R_RIGHT, node), self.pv(P, child))
+        s.add(RESET_MARGINAL_LIKELIHOOD)
+        s.add(INCREMENT_MARGINAL_LIKELIHOOD, self.pv(RHAT, self.root), 0, self.pv(P, self.root))
+        return s
+
+
+def single_tree_dag(parent_ids: Sequence[int]) -> SingleTreeDAG:
+    parent_ids = [int(x) for x in parent_ids]
+    node_count = len(parent_ids) + 1
+    n = (node_count + 1) // 2
+    kids: Dict[int, List[int]] = {}
+    for child, p in enumerate(parent_ids):
+        kids.setdefault(p, []).append(child)
+    children = {k: (v[0], v[1]) for k, v in kids.items()}
+    parent = {}
+    for k, (left, right) in children.items():
+        parent[left] = (k, True)
+        parent[right] = (k, False)
+    return SingleTreeDAG(n, node_count, node_count, children, parent, node_count - 1)
+
+
+# ------------------------------------------------------------------------------------
+# ctypes mirror of the GPU executor (include/bito_amd_gp.h)
+
+GP_SYMBOLS = [
+    "bito_amd_gp_create", "bito_amd_gp_destroy", "bito_amd_gp_last_error", "bito_amd_gp_set_branch_lengths",
+    "bito_amd_gp_get_branch_lengths", "bito_amd_gp_set_sbn_parameters", "bito_amd_gp_get_sbn_parameters",
+    "bito_amd_gp_process_operations", "bito_amd_gp_log_marginal_likelihood",
+    "bito_amd_gp_per_gpcsp_log_likelihoods", "bito_amd_gp_log_likelihood_matrix",
+    "bito_amd_gp_log_likelihood_and_first_two_derivatives",
+]
+
+
+def _lib():
+    L = _capi.lib()
+    if not getattr(L, "_gp_ready", False):
+        dp, vp = C.POINTER(C.c_double), C.c_void_p
+        L.bito_amd_gp_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), dp, C.c_int32,
+                                         C.c_int32, C.c_double, C.POINTER(vp), C.c_char_p, C.c_size_t]
+        L.bito_amd_gp_destroy.restype = None
+        L.bito_amd_gp_destroy.argtypes = [vp]
+        L.bito_amd_gp_last_error.restype = C.c_char_p
+        L.bito_amd_gp_last_error.argtypes = [vp]
+        for name in ("set_branch_lengths", "get_branch_lengths", "set_sbn_parameters", "get_sbn_parameters",
+                     "per_gpcsp_log_likelihoods", "log_likelihood_matrix", "log_marginal_likelihood"):
+            getattr(L, f"bito_amd_gp_{name}").argtypes = [vp, dp]
+        L.bito_amd_gp_process_operations.argtypes = [vp, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.bito_amd_gp_log_likelihood_and_first_two_derivatives.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, dp]
+        L._gp_ready = True
+    return L
+
+
+class GPEngine:
+    """Mirror of the reference ``GPEngine`` (src/gp_engine.hpp:24-141), hot-path subset."""
+
+    def __init__(self, patterns: np.ndarray, weights: np.ndarray, node_count: int, gpcsp_count: int,
+                 rescaling_threshold: float = 1e-40, device_id: int = 0):
+        L = _lib()
+        self.patterns = np.ascontiguousarray(patterns, dtype=np.int32)
+        self.weights = np.ascontiguousarray(weights, dtype=np.float64)
+        n, Pn = self.patterns.shape
+        self.pattern_count, self.gpcsp_count, self.node_count = Pn, gpcsp_count, node_count
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.bito_amd_gp_create(device_id, n, Pn, self.patterns.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  self.weights.ctypes.data_as(C.POINTER(C.c_double)), node_count, gpcsp_count,
+                                  rescaling_threshold, C.byref(h), err, 512)
+        if rc:
+            raise BitoAmdError(rc, err.value.decode())
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().bito_amd_gp_destroy(self._h)
+            self._h = None
+
+    def _check(self, rc):
+        if rc:
+            raise BitoAmdError(rc, _lib().bito_amd_gp_last_error(self._h).decode())
+
+    def _vec(self, fn, count):
+        out = np.zeros(count)
+        self._check(fn(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def set_branch_lengths(self, bl):
+        bl = np.ascontiguousarray(bl, dtype=np.float64)
+        assert bl.shape == (self.gpcsp_count,)
+        self._check(_lib().bito_amd_gp_set_branch_lengths(self._h, bl.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def get_branch_lengths(self):
+        return self._vec(_lib().bito_amd_gp_get_branch_lengths, self.gpcsp_count)
+
+    def set_sbn_parameters(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        self._check(_lib().bito_amd_gp_set_sbn_parameters(self._h, q.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def get_sbn_parameters(self):
+        return self._vec(_lib().bito_amd_gp_get_sbn_parameters, self.gpcsp_count)
+
+    def process_operations(self, stream: OpStream):
+        ops, side = stream.arrays()
+        self._check(_lib().bito_amd_gp_process_operations(self._h, ops.ctypes.data, len(ops), side.ctypes.data, len(side)))
+
+    def get_log_marginal_likelihood(self) -> float:
+        return float(self._vec(_lib().bito_amd_gp_log_marginal_likelihood, 1)[0])
+
+    def get_per_gpcsp_log_likelihoods(self):
+        return self._vec(_lib().bito_amd_gp_per_gpcsp_log_likelihoods, self.gpcsp_count)
+
+    def get_log_likelihood_matrix(self):
+        return self._vec(_lib().bito_amd_gp_log_likelihood_matrix, self.gpcsp_count * self.pattern_count).reshape(
+            self.gpcsp_count, self.pattern_count)
+
+    def log_likelihood_and_first_two_derivatives(self, gpcsp: int, rootward: int, leafward: int):
+        out = np.zeros(3)
+        self._check(_lib().bito_amd_gp_log_likelihood_and_first_two_derivatives(
+            self._h, gpcsp, rootward, leafward, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return tuple(out)

@@ -1,0 +1,78 @@
+/*
+ * bito_amd_gp.h -- C ABI of the generalized-pruning executor (seam 3):
+ * the part of bito's GPEngine that owns the PLV arena and executes a GPOperationVector
+ * (reference src/gp_engine.hpp:24-141, src/gp_engine.cpp:213-339).  The subsplit DAG and the
+ * schedule generator (GPDAG) stay on the caller's side; what crosses the seam is the op stream.
+ *
+ * JC69, one rate category, 4 states (what the reference's GPEngine supports,
+ * src/gp_engine.hpp:364-377).  PLV ids follow PLVHandler: type * node_count + node with types
+ * {P, PHatRight, PHatLeft, RHat, RRight, RLeft} (src/pv_handler.hpp:26-34,487-490).
+ * Returns 0 or a negative BITO_AMD_ERR_* code (bito_amd.h); message via bito_amd_gp_last_error.
+ */
+#ifndef BITO_AMD_GP_H
+#define BITO_AMD_GP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* opcode = alternative index of the reference's std::variant GPOperation (src/gp_operation.hpp:162-167) */
+enum {
+  BITO_AMD_GP_ZERO_PLV = 0,                            /* a = dest */
+  BITO_AMD_GP_SET_TO_STATIONARY_DISTRIBUTION = 1,      /* a = dest, b = root gpcsp */
+  BITO_AMD_GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV = 2, /* a = dest, b = gpcsp, c = src */
+  BITO_AMD_GP_MULTIPLY = 3,                            /* a = dest, b = src1, c = src2 */
+  BITO_AMD_GP_LIKELIHOOD = 4,                          /* a = dest gpcsp, b = child_, c = parent_ */
+  BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH = 5,              /* not executed here: host-side optimiser (row f1) */
+  BITO_AMD_GP_UPDATE_SBN_PROBABILITIES = 6,            /* a = start, b = stop */
+  BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD = 7,
+  BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD = 8,       /* a = stationary_times_prior, b = rootsplit, c = p */
+  BITO_AMD_GP_PREP_FOR_MARGINALIZATION = 9             /* a = dest, b = offset into side[], count sources */
+};
+
+typedef struct {
+  uint32_t opcode;
+  uint32_t count;
+  uint64_t a, b, c;
+} bito_amd_gp_op;
+
+typedef struct bito_amd_gp_engine bito_amd_gp_engine;
+
+/* GPEngine::GPEngine + InitializePLVsWithSitePatterns (src/gp_engine.hpp:26-29, gp_engine.cpp:544-562).
+ * The arena holds 6 * node_count PLVs in HBM (the reference memory-maps a file). */
+int bito_amd_gp_create(int32_t device_id, int32_t taxon_count, int32_t pattern_count, const int32_t *patterns,
+                       const double *weights, int32_t node_count, int32_t gpcsp_count, double rescaling_threshold,
+                       bito_amd_gp_engine **out, char *err, size_t err_len);
+void bito_amd_gp_destroy(bito_amd_gp_engine *e);
+const char *bito_amd_gp_last_error(const bito_amd_gp_engine *e);
+
+/* SetBranchLengths / GetBranchLengths / SBN parameters q (src/gp_engine.hpp:88-101): [gpcsp_count] */
+int bito_amd_gp_set_branch_lengths(bito_amd_gp_engine *e, const double *branch_lengths);
+int bito_amd_gp_get_branch_lengths(bito_amd_gp_engine *e, double *out);
+int bito_amd_gp_set_sbn_parameters(bito_amd_gp_engine *e, const double *q);
+int bito_amd_gp_get_sbn_parameters(bito_amd_gp_engine *e, double *out);
+
+/* GPEngine::ProcessOperations (src/gp_engine.hpp:74).  Every op except UpdateSBNProbabilities is
+ * independent across site patterns, so a run of such ops is ONE kernel (one thread per pattern
+ * interprets the stream); an UpdateSBNProbabilities op ends the run. */
+int bito_amd_gp_process_operations(bito_amd_gp_engine *e, const bito_amd_gp_op *ops, int64_t op_count,
+                                   const uint64_t *side, int64_t side_count);
+
+/* GetLogMarginalLikelihood (gp_engine.cpp:413-415): out[1];
+ * GetPerGPCSPLogLikelihoods (:437-440): out[gpcsp_count];
+ * GetLogLikelihoodMatrix: out[gpcsp_count][pattern_count]. */
+int bito_amd_gp_log_marginal_likelihood(bito_amd_gp_engine *e, double *out);
+int bito_amd_gp_per_gpcsp_log_likelihoods(bito_amd_gp_engine *e, double *out);
+int bito_amd_gp_log_likelihood_matrix(bito_amd_gp_engine *e, double *out);
+
+/* LogLikelihoodAndFirstTwoDerivatives(gpcsp, rootward_pv, leafward_pv) (gp_engine.cpp:505-542): out[3] */
+int bito_amd_gp_log_likelihood_and_first_two_derivatives(bito_amd_gp_engine *e, int64_t gpcsp, int64_t rootward,
+                                                         int64_t leafward, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+"""ctypes wrapper of the GPEngine CPU oracle (oracle/libgp_oracle.so). Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "libgp_oracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
+        L = C.CDLL(_PATH)
+        dp, vp = C.POINTER(C.c_double), C.c_void_p
+        L.gp_oracle_create.restype = vp
+        L.gp_oracle_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), dp, C.c_int, C.c_int, C.c_double]
+        L.gp_oracle_destroy.argtypes = [vp]
+        L.gp_oracle_set_branch_lengths.argtypes = [vp, dp]
+        L.gp_oracle_set_sbn_parameters.argtypes = [vp, dp]
+        L.gp_oracle_get_sbn_parameters.argtypes = [vp, dp]
+        L.gp_oracle_process.argtypes = [vp, C.c_void_p, C.c_int, C.c_void_p]
+        L.gp_oracle_log_marginal_likelihood.restype = C.c_double
+        L.gp_oracle_log_marginal_likelihood.argtypes = [vp]
+        L.gp_oracle_per_gpcsp_log_likelihoods.argtypes = [vp, dp]
+        L.gp_oracle_derivatives.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, dp]
+        L.gp_oracle_transition_matrix.argtypes = [C.c_double, dp]
+        _lib = L
+    return _lib
+
+
+class OracleGPEngine:
+    def __init__(self, patterns, weights, node_count, gpcsp_count, rescaling_threshold=1e-40):
+        self.patterns = np.ascontiguousarray(patterns, dtype=np.int32)
+        self.weights = np.ascontiguousarray(weights, dtype=np.float64)
+        n, P = self.patterns.shape
+        self.gpcsp_count = gpcsp_count
+        self._h = lib().gp_oracle_create(n, P, self.patterns.ctypes.data_as(C.POINTER(C.c_int)),
+                                         self.weights.ctypes.data_as(C.POINTER(C.c_double)), node_count, gpcsp_count,
+                                         rescaling_threshold)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gp_oracle_destroy(self._h)
+            self._h = None
+
+    def set_branch_lengths(self, bl):
+        bl = np.ascontiguousarray(bl, dtype=np.float64)
+        lib().gp_oracle_set_branch_lengths(self._h, bl.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def set_sbn_parameters(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        lib().gp_oracle_set_sbn_parameters(self._h, q.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def get_sbn_parameters(self):
+        q = np.zeros(self.gpcsp_count)
+        lib().gp_oracle_get_sbn_parameters(self._h, q.ctypes.data_as(C.POINTER(C.c_double)))
+        return q
+
+    def process_operations(self, stream):
+        ops, side = stream.arrays()
+        rc = lib().gp_oracle_process(self._h, ops.ctypes.data, len(ops), side.ctypes.data)
+        if rc:
+            raise RuntimeError(f"gp oracle: op stream rejected ({rc})")
+
+    def get_log_marginal_likelihood(self):
+        return lib().gp_oracle_log_marginal_likelihood(self._h)
+
+    def get_per_gpcsp_log_likelihoods(self):
+        out = np.zeros(self.gpcsp_count)
+        lib().gp_oracle_per_gpcsp_log_likelihoods(self._h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def log_likelihood_and_first_two_derivatives(self, gpcsp, rootward, leafward):
+        out = np.zeros(3)
+        lib().gp_oracle_derivatives(self._h, gpcsp, rootward, leafward, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return tuple(out)
+
+
+def transition_matrix(t):
+    P = np.zeros(16)
+    lib().gp_oracle_transition_matrix(float(t), P.ctypes.data_as(C.POINTER(C.c_double)))
+    return P.reshape(4, 4)

@@ -1,0 +1,272 @@
+/*
+ * gp_oracle.c -- CPU ORACLE for bito's GPEngine (generalized pruning on the subsplit DAG).
+ * TEST INFRASTRUCTURE ONLY (see bito_oracle.h for the rules).
+ *
+ * Restates, operation by operation, what GPEngine does to its PLV arena when it visits a
+ * GPOperationVector (reference src/gp_engine.cpp:213-339, src/gp_engine.hpp:248-282,
+ * src/gp_operation.hpp:24-170): JC69, one rate category, 4 x P column-major PLVs, 6 PLVs per
+ * DAG node indexed type*node_count + node (src/pv_handler.hpp:487-490), whole-PLV rescaling
+ * by powers of the threshold (src/gp_engine.cpp:564-601), per-edge log-likelihood matrix,
+ * log-add marginal over rootsplits (src/numerical_utils.hpp:35-52).
+ *
+ * Parity status: PINNED by tests/test_gp.py against the reference's known answers for this
+ * path (src/gp_doctest.cpp:119-131,257-308; src/gp_engine.hpp:382-393).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum {
+  GP_ZERO_PLV = 0,
+  GP_SET_TO_STATIONARY = 1,
+  GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV = 2,
+  GP_MULTIPLY = 3,
+  GP_LIKELIHOOD = 4,
+  GP_OPTIMIZE_BRANCH_LENGTH = 5,
+  GP_UPDATE_SBN_PROBABILITIES = 6,
+  GP_RESET_MARGINAL_LIKELIHOOD = 7,
+  GP_INCREMENT_MARGINAL_LIKELIHOOD = 8,
+  GP_PREP_FOR_MARGINALIZATION = 9
+};
+
+typedef struct {
+  uint32_t opcode, count;
+  uint64_t a, b, c;
+} gp_op;
+
+typedef struct {
+  int P, plv_count, gpcsp_count;
+  double threshold, log_threshold;
+  double *plv;       /* [plv_count][P][4]  (column-major 4 x P per PLV) */
+  int *counts;       /* [plv_count] */
+  double *weights;   /* [P] */
+  double *bl, *q;    /* [gpcsp_count] */
+  double *ll;        /* [gpcsp_count][P] */
+  double *marginal;  /* [P] */
+} gp_oracle;
+
+/* JC69 eigensystem exactly as the reference builds it (src/substitution_model.cpp:20-26,
+ * src/gp_engine.cpp:341-364). */
+static const double kV[16] = {1.0, 2.0, 0.0, 0.5, 1.0, -2.0, 0.5, 0.0, 1.0, 2.0, 0.0, -0.5, 1.0, -2.0, -0.5, 0.0};
+static const double kVi[16] = {0.25, 0.25, 0.25, 0.25, 0.125, -0.125, 0.125, -0.125,
+                               0.0, 1.0, 0.0, -1.0, 1.0, 0.0, -1.0, 0.0};
+static const double kLam[4] = {0.0, -1.3333333333333333, -1.3333333333333333, -1.3333333333333333};
+
+static void matrices(double t, double *P, double *dP, double *ddP) {
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double s = 0, d = 0, dd = 0;
+      for (int k = 0; k < 4; k++) {
+        const double e = exp(kLam[k] * t), vv = kV[i * 4 + k];
+        s += vv * e * kVi[k * 4 + j];
+        d += vv * (kLam[k] * e) * kVi[k * 4 + j];
+        dd += vv * (kLam[k] * kLam[k] * e) * kVi[k * 4 + j];
+      }
+      P[i * 4 + j] = s;
+      if (dP) dP[i * 4 + j] = d;
+      if (ddP) ddP[i * 4 + j] = dd;
+    }
+}
+
+gp_oracle *gp_oracle_create(int taxon_count, int pattern_count, const int *patterns, const double *weights,
+                            int node_count, int gpcsp_count, double threshold) {
+  gp_oracle *g = (gp_oracle *)calloc(1, sizeof(*g));
+  g->P = pattern_count;
+  g->plv_count = 6 * node_count;
+  g->gpcsp_count = gpcsp_count;
+  g->threshold = threshold;
+  g->log_threshold = log(threshold);
+  g->plv = (double *)calloc((size_t)g->plv_count * pattern_count * 4, sizeof(double));
+  g->counts = (int *)calloc(g->plv_count, sizeof(int));
+  g->weights = (double *)malloc(sizeof(double) * pattern_count);
+  memcpy(g->weights, weights, sizeof(double) * pattern_count);
+  g->bl = (double *)calloc(gpcsp_count, sizeof(double));
+  g->q = (double *)malloc(sizeof(double) * gpcsp_count);
+  for (int i = 0; i < gpcsp_count; i++) g->q[i] = 1.0;
+  g->ll = (double *)calloc((size_t)gpcsp_count * pattern_count, sizeof(double));
+  g->marginal = (double *)calloc(pattern_count, sizeof(double));
+  /* InitializePLVsWithSitePatterns (src/gp_engine.cpp:544-562): leaf P-PLVs (type 0) */
+  for (int t = 0; t < taxon_count; t++)
+    for (int p = 0; p < pattern_count; p++) {
+      const int s = patterns[(size_t)t * pattern_count + p];
+      double *col = g->plv + ((size_t)t * pattern_count + p) * 4;
+      for (int i = 0; i < 4; i++) col[i] = (s >= 4 || s == i) ? 1.0 : 0.0;
+    }
+  return g;
+}
+
+void gp_oracle_destroy(gp_oracle *g) {
+  if (!g) return;
+  free(g->plv); free(g->counts); free(g->weights); free(g->bl); free(g->q); free(g->ll); free(g->marginal);
+  free(g);
+}
+
+void gp_oracle_set_branch_lengths(gp_oracle *g, const double *bl) { memcpy(g->bl, bl, sizeof(double) * g->gpcsp_count); }
+void gp_oracle_set_sbn_parameters(gp_oracle *g, const double *q) { memcpy(g->q, q, sizeof(double) * g->gpcsp_count); }
+void gp_oracle_get_sbn_parameters(const gp_oracle *g, double *q) { memcpy(q, g->q, sizeof(double) * g->gpcsp_count); }
+
+static double *PLV(gp_oracle *g, uint64_t idx) { return g->plv + (size_t)idx * g->P * 4; }
+
+static double log_add(double x, double y) { /* src/numerical_utils.hpp:35-52 */
+  if (y > x) { double t = x; x = y; y = t; }
+  if (x == -INFINITY) return x;
+  const double neg_diff = y - x;
+  if (neg_diff < -36.04365338911715) return x; /* LOG_EPS = log(DBL_EPSILON), numerical_utils.hpp:15-19 */
+  return x + log(1.0 + exp(neg_diff));
+}
+
+/* RescalePLVIfNeeded (src/gp_engine.cpp:583-597): one decision for the whole PLV. */
+static void rescale_if_needed(gp_oracle *g, uint64_t idx) {
+  double *v = PLV(g, idx), mx = 0;
+  for (int k = 0; k < g->P * 4; k++)
+    if (v[k] > mx) mx = v[k];
+  if (mx == 0) return;
+  int count = 0;
+  while (mx < g->threshold) {
+    mx /= g->threshold;
+    count++;
+  }
+  if (count == 0) return;
+  const double f = pow(g->threshold, (double)count);
+  for (int k = 0; k < g->P * 4; k++) v[k] /= f;
+  g->counts[idx] += count;
+}
+
+/* per-pattern r^T M p */
+static double bilinear(const double *r, const double *M, const double *p) {
+  double s = 0;
+  for (int i = 0; i < 4; i++) s += r[i] * (M[i * 4] * p[0] + M[i * 4 + 1] * p[1] + M[i * 4 + 2] * p[2] + M[i * 4 + 3] * p[3]);
+  return s;
+}
+
+int gp_oracle_process(gp_oracle *g, const gp_op *ops, int op_count, const uint64_t *side) {
+  const int P = g->P;
+  for (int o = 0; o < op_count; o++) {
+    const gp_op *op = &ops[o];
+    switch (op->opcode) {
+      case GP_ZERO_PLV:
+        memset(PLV(g, op->a), 0, sizeof(double) * P * 4);
+        g->counts[op->a] = 0;
+        break;
+      case GP_SET_TO_STATIONARY: {
+        double *v = PLV(g, op->a);
+        for (int p = 0; p < P; p++)
+          for (int i = 0; i < 4; i++) v[p * 4 + i] = g->q[op->b] * 0.25;
+        g->counts[op->a] = 0;
+        break;
+      }
+      case GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV: {
+        double M[16];
+        matrices(g->bl[op->b], M, NULL, NULL);
+        const int diff = g->counts[op->c] - g->counts[op->a];
+        if (diff < 0) return -1;
+        const double f = (diff == 0 ? 1.0 : pow(g->threshold, (double)diff)) * g->q[op->b];
+        double *d = PLV(g, op->a);
+        const double *s = PLV(g, op->c);
+        for (int p = 0; p < P; p++)
+          for (int i = 0; i < 4; i++)
+            d[p * 4 + i] += f * (M[i * 4] * s[p * 4] + M[i * 4 + 1] * s[p * 4 + 1] + M[i * 4 + 2] * s[p * 4 + 2] +
+                                 M[i * 4 + 3] * s[p * 4 + 3]);
+        break;
+      }
+      case GP_MULTIPLY: {
+        double *d = PLV(g, op->a);
+        const double *x = PLV(g, op->b), *y = PLV(g, op->c);
+        for (int k = 0; k < P * 4; k++) d[k] = x[k] * y[k];
+        g->counts[op->a] = g->counts[op->b] + g->counts[op->c];
+        rescale_if_needed(g, op->a);
+        break;
+      }
+      case GP_LIKELIHOOD: { /* dest = gpcsp, b = child_ (r-PLV of the parent), c = parent_ (p-PLV of the child):
+                               field order of GPOperations::Likelihood{dest, child, parent} as GPDAG fills it
+                               (src/gp_dag.cpp:183-188): child_ <- RPLV(parent node), parent_ <- P(child node). */
+        double M[16];
+        matrices(g->bl[op->a], M, NULL, NULL);
+        const double *r = PLV(g, op->c), *pp = PLV(g, op->b);
+        const double resc = (g->counts[op->b] + g->counts[op->c]) * g->log_threshold;
+        for (int p = 0; p < P; p++) g->ll[(size_t)op->a * P + p] = log(bilinear(r + p * 4, M, pp + p * 4)) + resc;
+        break;
+      }
+      case GP_RESET_MARGINAL_LIKELIHOOD:
+        for (int p = 0; p < P; p++) g->marginal[p] = -INFINITY;
+        break;
+      case GP_INCREMENT_MARGINAL_LIKELIHOOD: { /* a = stationary_times_prior, b = rootsplit, c = p */
+        if (g->counts[op->a] != 0) return -2;
+        const double *r = PLV(g, op->a), *pp = PLV(g, op->c);
+        const double resc = g->counts[op->c] * g->log_threshold;
+        for (int p = 0; p < P; p++) {
+          double s = 0;
+          for (int i = 0; i < 4; i++) s += r[p * 4 + i] * pp[p * 4 + i];
+          const double row = log(s) + resc;
+          g->marginal[p] = log_add(g->marginal[p], row);
+          g->ll[(size_t)op->b * P + p] = row - log(g->q[op->b]);
+        }
+        break;
+      }
+      case GP_UPDATE_SBN_PROBABILITIES: { /* a = start, b = stop (src/gp_engine.cpp:297-321) */
+        const int len = (int)(op->b - op->a);
+        if (len == 1) {
+          g->q[op->a] = 1.0;
+          break;
+        }
+        double *lu = (double *)malloc(sizeof(double) * len), norm = -INFINITY;
+        for (int k = 0; k < len; k++) {
+          double s = 0;
+          for (int p = 0; p < P; p++) s += g->ll[(size_t)(op->a + k) * P + p] * g->weights[p];
+          lu[k] = s + log(g->q[op->a + k]);
+          norm = log_add(norm, lu[k]);
+        }
+        for (int k = 0; k < len; k++) g->q[op->a + k] = exp(lu[k] - norm);
+        free(lu);
+        break;
+      }
+      case GP_PREP_FOR_MARGINALIZATION: { /* a = dest, b = offset into side, count sources */
+        int mn = g->counts[side[op->b]];
+        for (uint32_t k = 1; k < op->count; k++)
+          if (g->counts[side[op->b + k]] < mn) mn = g->counts[side[op->b + k]];
+        g->counts[op->a] = mn;
+        break;
+      }
+      default:
+        return -3; /* OptimizeBranchLength: host-side optimiser, not part of this oracle */
+    }
+  }
+  return 0;
+}
+
+double gp_oracle_log_marginal_likelihood(const gp_oracle *g) { /* src/gp_engine.cpp:413-415 */
+  double s = 0;
+  for (int p = 0; p < g->P; p++) s += g->marginal[p] * g->weights[p];
+  return s;
+}
+
+void gp_oracle_per_gpcsp_log_likelihoods(const gp_oracle *g, double *out) { /* :437-440 */
+  for (int e = 0; e < g->gpcsp_count; e++) {
+    double s = 0;
+    for (int p = 0; p < g->P; p++) s += g->ll[(size_t)e * g->P + p] * g->weights[p];
+    out[e] = s;
+  }
+}
+
+/* LogLikelihoodAndFirstTwoDerivatives (src/gp_engine.cpp:505-542) */
+void gp_oracle_derivatives(gp_oracle *g, int gpcsp, uint64_t rootward, uint64_t leafward, double out[3]) {
+  double M[16], dM[16], ddM[16];
+  matrices(g->bl[gpcsp], M, dM, ddM);
+  const double *r = PLV(g, rootward), *pp = PLV(g, leafward);
+  const double resc = (g->counts[rootward] + g->counts[leafward]) * g->log_threshold;
+  double ll = 0, d1 = 0, d2 = 0;
+  for (int p = 0; p < g->P; p++) {
+    const double l = bilinear(r + p * 4, M, pp + p * 4);
+    const double a = bilinear(r + p * 4, dM, pp + p * 4);
+    const double b = bilinear(r + p * 4, ddM, pp + p * 4);
+    ll += g->weights[p] * (log(l) + resc);
+    d1 += g->weights[p] * (a / l);
+    d2 += g->weights[p] * ((b * l - a * a) / (l * l));
+  }
+  out[0] = ll;
+  out[1] = d1;
+  out[2] = d2;
+}
+
+void gp_oracle_transition_matrix(double t, double *P16) { matrices(t, P16, NULL, NULL); }

@@ -41,6 +41,33 @@ def test_beagle_shim_symbols_are_exported():
         assert hasattr(lib, name), f"libbito_amd.so does not export {name}"
 
 
+def test_gp_symbols_are_exported():
+    from bito_amd import gp
+
+    header = open(os.path.join(ROOT, "include", "bito_amd_gp.h")).read()
+    declared = set(re.findall(r"\b(bito_amd_gp_[a-z_]+)\s*\(", header))
+    assert declared == set(gp.GP_SYMBOLS)
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libbito_amd.so does not export {name}"
+    # the op record is the POD the header declares
+    assert gp.OP_DTYPE.itemsize == 32
+
+
+def test_single_tree_gp_schedule_shape():
+    from bito_amd import gp
+
+    dag = gp.single_tree_dag([4, 3, 3, 4])  # (0,(1,2)3)4
+    assert dag.node_count == 5 and dag.gpcsp_count == 5 and dag.root == 4
+    assert dag.children == {3: (1, 2), 4: (0, 3)} and dag.parent[3] == (4, False)
+    assert dag.pv(gp.R_LEFT, 4) == 5 * 5 + 4 and dag.edge(4) == 0 and dag.edge(0) == 1
+    pop, lik = dag.populate_plvs(), dag.compute_likelihoods()
+    ops, side = pop.arrays()
+    # 2 internal nodes x 3 + 5 nodes x 3 zeroings, 1 stationary, rootward 2 x 5, leafward 4 x 4 + 2
+    assert len(ops) == 6 + 15 + 1 + 10 + 18 and len(side) == 8
+    assert [o[0] for o in lik.ops] == [gp.LIKELIHOOD] * 4 + [gp.RESET_MARGINAL_LIKELIHOOD, gp.INCREMENT_MARGINAL_LIKELIHOOD]
+
+
 def test_no_signature_leaks_torch_or_cxx_types():
     header = open(os.path.join(ROOT, "include", "bito_amd.h")).read()
     code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)  # declarations only, comments stripped
