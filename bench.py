@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+FP64_MFMA_PEAK_TFLOPS = 68.0  # measured, scripts: bito_amd/csrc/microbench.hip
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -64,6 +65,16 @@ def cpu_baseline(w, seconds: float):
     return {"value": count / dt, "unit": "trees/s", "cores": threads, "kind": "port",
             "sample": f"{count} trees of the same workload, {dt:.1f} s, oracle/bito_oracle.c with {threads} threads "
                       "(FP64 restatement of the BEAGLE CPU path; the reference binary cannot be built here)"}
+
+
+def arithmetic_view(n, P, C, want_gradient, trees_per_launch, avg_kernel_s):
+    """FP64 flops of the 4x4 matrix-vector products per launch against the FP64 MFMA rate measured
+    on this part (profiles/r1_microbench.json: v_mfma_f64_4x4x4_4b, 68 TFLOP/s)."""
+    matvecs = 2 * (n - 1) + (4 * (n - 1) if want_gradient else 0)  # post: 2 per internal node; walk: dP.x and PT.y per child
+    flops = matvecs * 32.0 * C * P * trees_per_launch
+    achieved = flops / avg_kernel_s / 1e12
+    return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP64_MFMA_PEAK_TFLOPS}
 
 
 def measured_traffic(kernel: str, trees_per_launch: int):
@@ -126,21 +137,9 @@ def main():
     eng.set_kernel(args.kernel)
     eng.upload(w.parent_ids, w.branch_lengths, w.params)
 
-    ll_dev = torch.empty(T, dtype=torch.float64, device="cuda")
-    grad_dev = torch.empty(T, N, dtype=torch.float64, device="cuda")
-    if world > 1:
-        ll_all = torch.empty(world * T, dtype=torch.float64, device="cuda")
-        grad_all = torch.empty(world * T, N, dtype=torch.float64, device="cuda")
-        ll_sum = torch.zeros(1, dtype=torch.float64, device="cuda")
-
     def step():
+        # trees are independent: each rank evaluates its own block, no data-path collective
         eng.run(w.want_gradient, w.rescaling)
-        if world > 1:
-            eng.download_to(ll_dev.data_ptr(), grad_dev.data_ptr())  # device -> device, then RCCL
-            dist.all_gather_into_tensor(ll_all, ll_dev)
-            dist.all_gather_into_tensor(grad_all, grad_dev)
-            ll_sum.copy_(ll_dev.sum().reshape(1))
-            dist.all_reduce(ll_sum)
 
     def fence():
         eng.sync()
@@ -199,8 +198,8 @@ def main():
                 "trees_per_gpu": T,
                 "trees_total": total_trees,
                 "kernel": kernel,
-                "multi_gpu": "trees sharded by rank; all-gather of per-tree results + all-reduce of the summed "
-                             "log-likelihood per step" if world > 1 else "single GPU, no collective",
+                "multi_gpu": "trees sharded by rank, no data-path collective (barrier + max-over-ranks timing "
+                             "only)" if world > 1 else "single GPU, no collective",
             },
             "roofline": {
                 "bound": "hbm",
@@ -213,6 +212,9 @@ def main():
                 "avg_kernel_ms": avg_kernel_s * 1e3,
                 "trees_per_launch": trees_per_launch,
                 "algorithmic_bytes_per_tree": algorithmic_bytes_per_tree(n, P, C, w.want_gradient),
+                # the fused kernels keep the partials on chip, so the op-by-op byte model above can exceed
+                # the HBM peak; the arithmetic view of the same launch is reported beside it
+                "arithmetic": arithmetic_view(n, P, C, w.want_gradient, trees_per_launch, avg_kernel_s),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
