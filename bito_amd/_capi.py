@@ -18,6 +18,8 @@ GRAD_SUBSTITUTION_MODEL = 1
 GRAD_SITE_MODEL = 2
 GRAD_CLOCK_MODEL = 4
 GRAD_STICKBREAKING = 8
+GRAD_RATIOS_ROOT_HEIGHT = 16
+GRAD_LOG_DET_JACOBIAN_GRADIENT = 32
 
 KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS, KERNEL_LDS_TREE = 0, 1, 2, 3
 
@@ -30,6 +32,10 @@ SYMBOLS = [
     "bito_amd_engine_download", "bito_amd_engine_set_kernel", "bito_amd_engine_time_runs",
     "bito_amd_engine_kernel_timing", "bito_amd_engine_kernel_elapsed", "bito_amd_engine_kernel_name",
     "bito_amd_version",
+    "bito_amd_engine_time_trees_from_branch_lengths", "bito_amd_engine_time_trees_from_height_ratios",
+    "bito_amd_engine_log_det_jacobian", "bito_amd_engine_gradient_log_det_jacobian",
+    "bito_amd_engine_ratio_gradient_of_height_gradient", "bito_amd_engine_time_tree_log_likelihoods",
+    "bito_amd_engine_time_tree_gradients",
 ]
 
 
@@ -79,5 +85,14 @@ def lib():
     L.bito_amd_engine_kernel_elapsed.argtypes = [vp, dp, ip]
     L.bito_amd_engine_kernel_name.restype = C.c_char_p
     L.bito_amd_engine_kernel_name.argtypes = [vp]
+    L.bito_amd_engine_time_trees_from_branch_lengths.argtypes = [vp, C.c_int32, ip, dp, dp, dp, dp, dp]
+    L.bito_amd_engine_time_trees_from_height_ratios.argtypes = [vp, C.c_int32, ip, dp, dp, dp, dp]
+    L.bito_amd_engine_log_det_jacobian.argtypes = [vp, C.c_int32, ip, dp, dp, dp]
+    L.bito_amd_engine_gradient_log_det_jacobian.argtypes = [vp, C.c_int32, ip, dp, dp, dp, dp]
+    L.bito_amd_engine_ratio_gradient_of_height_gradient.argtypes = [vp, C.c_int32, ip, dp, dp, dp, dp, dp]
+    L.bito_amd_engine_time_tree_log_likelihoods.argtypes = [vp, C.c_int32, ip, dp, dp, dp, dp, dp, C.c_int32,
+                                                            C.c_int32, dp]
+    L.bito_amd_engine_time_tree_gradients.argtypes = [vp, C.c_int32, ip, dp, dp, C.c_int32, dp, dp, dp, dp,
+                                                      C.c_int32, C.c_int32, C.c_double, dp, dp, dp, dp, dp, dp]
     _lib = L
     return L

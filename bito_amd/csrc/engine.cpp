@@ -72,6 +72,9 @@ struct bito_amd_engine {
   DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
       out_ll, out_grad, scale_arena;
   DeviceBuffer<TreeModel> model;
+  // time-tree transforms (row f2): staging for host inputs, scratch and results
+  DeviceBuffer<int32_t> tt_parents;
+  DeviceBuffer<double> tt_heights, tt_bounds, tt_ratios, tt_in, tt_work, tt_out, tt_aux;
   // host mirrors for the composed gradients
   std::vector<double> h_params;
   // timing
@@ -85,6 +88,8 @@ struct bito_amd_engine {
     tip_states.Free(); weights.Free(); parent_ids.Free(); children.Free(); branch_in.Free();
     rates.Free(); params.Free(); branch.Free(); mats.Free(); images.Free(); arena.Free(); scale_arena.Free(); part_ll.Free();
     part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free();
+    tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
+    tt_out.Free(); tt_aux.Free();
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -661,6 +666,212 @@ int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t ro
       for (int i = 0; i < N - 1; i++) s += out_branch[(size_t)t * N + i] * branch_lengths[(size_t)t * node_count + i];
       out_clock[t] = s;
     }
+  }
+  return BITO_AMD_OK;
+}
+
+// ---- time trees -------------------------------------------------------------
+extern "C++" {
+namespace {
+
+template <typename T>
+int ToDevice(bito_amd_engine* e, DeviceBuffer<T>& buf, const T* host, size_t count) {
+  HIP_TRY(e, buf.Reserve(count));
+  HIP_TRY(e, hipMemcpyAsync(buf.ptr, host, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
+  return BITO_AMD_OK;
+}
+
+int ToHost(bito_amd_engine* e, double* host, const double* dev, size_t count) {
+  HIP_TRY(e, hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return BITO_AMD_OK;
+}
+
+// common front end of the stand-alone transforms: validate, stage the topologies
+int StageTimeTrees(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  if (tree_count < 1 || !parent_ids) return Fail(e, BITO_AMD_ERR_BAD_ARG, "need at least one tree and parent_ids");
+  const int N = 2 * e->n - 1;
+  int rc = ValidateTrees(e, tree_count, 1, N, parent_ids);
+  if (rc) return rc;
+  HIP_TRY(e, hipSetDevice(e->device));
+  return ToDevice(e, e->tt_parents, parent_ids, (size_t)tree_count * (N - 1));
+}
+
+}  // namespace
+}  // extern "C++"
+
+int bito_amd_engine_time_trees_from_branch_lengths(bito_amd_engine* e, int32_t tree_count,
+                                                   const int32_t* parent_ids, const double* branch_lengths,
+                                                   const double* tip_dates, double* out_node_bounds,
+                                                   double* out_node_heights, double* out_height_ratios) {
+  int rc = StageTimeTrees(e, tree_count, parent_ids);
+  if (rc) return rc;
+  if (!branch_lengths || !tip_dates || !out_node_bounds || !out_node_heights || !out_height_ratios)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "NULL argument");
+  const int n = e->n, N = 2 * n - 1;
+  const size_t T = tree_count;
+  if ((rc = ToDevice(e, e->tt_in, branch_lengths, T * N))) return rc;
+  if ((rc = ToDevice(e, e->tt_aux, tip_dates, (size_t)n))) return rc;
+  HIP_TRY(e, e->tt_bounds.Reserve(T * N));
+  HIP_TRY(e, e->tt_heights.Reserve(T * N));
+  HIP_TRY(e, e->tt_ratios.Reserve(T * (n - 1)));
+  HIP_TRY(e, e->tt_out.Reserve(T));
+  LaunchTimeTreeFromBranchLengths(tree_count, n, e->tt_parents.ptr, e->tt_in.ptr, e->tt_aux.ptr, e->tt_bounds.ptr,
+                                  e->tt_heights.ptr, e->tt_ratios.ptr, e->tt_out.ptr, e->stream);
+  HIP_TRY(e, hipGetLastError());
+  std::vector<double> diff(T);
+  if ((rc = ToHost(e, diff.data(), e->tt_out.ptr, T))) return rc;
+  for (size_t t = 0; t < T; t++)
+    if (!(diff[t] <= 1e-4)) {  // BRANCH_LENGTH_TOLERANCE, rooted_tree.cpp:7
+      char buf[200];
+      std::snprintf(buf, sizeof(buf),
+                    "Tree isn't time-calibrated in RootedTree::InitializeTimeTreeUsingBranchLengths. "
+                    "Height difference: %f (tree %zu)", diff[t], t);
+      return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
+    }
+  if ((rc = ToHost(e, out_node_bounds, e->tt_bounds.ptr, T * N))) return rc;
+  if ((rc = ToHost(e, out_node_heights, e->tt_heights.ptr, T * N))) return rc;
+  return ToHost(e, out_height_ratios, e->tt_ratios.ptr, T * (n - 1));
+}
+
+int bito_amd_engine_time_trees_from_height_ratios(bito_amd_engine* e, int32_t tree_count,
+                                                  const int32_t* parent_ids, const double* node_bounds,
+                                                  const double* height_ratios, double* out_node_heights,
+                                                  double* out_branch_lengths) {
+  int rc = StageTimeTrees(e, tree_count, parent_ids);
+  if (rc) return rc;
+  if (!node_bounds || !height_ratios || !out_node_heights || !out_branch_lengths)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "NULL argument");
+  const int n = e->n, N = 2 * n - 1;
+  const size_t T = tree_count;
+  if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
+  if ((rc = ToDevice(e, e->tt_ratios, height_ratios, T * (n - 1)))) return rc;
+  HIP_TRY(e, e->tt_heights.Reserve(T * N));
+  HIP_TRY(e, e->tt_in.Reserve(T * N));
+  LaunchTimeTreeFromRatios(tree_count, n, e->tt_parents.ptr, e->tt_bounds.ptr, e->tt_ratios.ptr, e->tt_heights.ptr,
+                           e->tt_in.ptr, e->stream);
+  HIP_TRY(e, hipGetLastError());
+  if ((rc = ToHost(e, out_node_heights, e->tt_heights.ptr, T * N))) return rc;
+  return ToHost(e, out_branch_lengths, e->tt_in.ptr, T * N);
+}
+
+int bito_amd_engine_log_det_jacobian(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
+                                     const double* node_heights, const double* node_bounds, double* out) {
+  int rc = StageTimeTrees(e, tree_count, parent_ids);
+  if (rc) return rc;
+  if (!node_heights || !node_bounds || !out) return Fail(e, BITO_AMD_ERR_BAD_ARG, "NULL argument");
+  const int n = e->n, N = 2 * n - 1;
+  const size_t T = tree_count;
+  if ((rc = ToDevice(e, e->tt_heights, node_heights, T * N))) return rc;
+  if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
+  HIP_TRY(e, e->tt_out.Reserve(T));
+  LaunchLogDetJacobian(tree_count, n, e->tt_parents.ptr, e->tt_heights.ptr, e->tt_bounds.ptr, e->tt_out.ptr, nullptr,
+                       e->stream);
+  HIP_TRY(e, hipGetLastError());
+  return ToHost(e, out, e->tt_out.ptr, T);
+}
+
+// shared by the two stand-alone ratio-space transforms (mode 0 / 1 of ratio_gradient_kernel)
+static int RatioTransform(bito_amd_engine* e, int mode, int32_t tree_count, const int32_t* parent_ids,
+                          const double* node_heights, const double* node_bounds, const double* height_ratios,
+                          const double* height_gradient, double* out) {
+  int rc = StageTimeTrees(e, tree_count, parent_ids);
+  if (rc) return rc;
+  if (!node_heights || !node_bounds || !height_ratios || !out || (mode == 0 && !height_gradient))
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "NULL argument");
+  const int n = e->n, N = 2 * n - 1;
+  const size_t T = tree_count;
+  if ((rc = ToDevice(e, e->tt_heights, node_heights, T * N))) return rc;
+  if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
+  if ((rc = ToDevice(e, e->tt_ratios, height_ratios, T * (n - 1)))) return rc;
+  if (mode == 0 && (rc = ToDevice(e, e->tt_in, height_gradient, T * (n - 1)))) return rc;
+  HIP_TRY(e, e->tt_work.Reserve(T * 3 * (n - 1)));
+  HIP_TRY(e, e->tt_out.Reserve(T * (n - 1)));
+  LaunchRatioGradient(tree_count, n, mode, e->tt_parents.ptr, e->tt_heights.ptr, e->tt_bounds.ptr, e->tt_ratios.ptr,
+                      e->tt_in.ptr, n - 1, nullptr, e->tt_work.ptr, e->tt_out.ptr, e->stream);
+  HIP_TRY(e, hipGetLastError());
+  return ToHost(e, out, e->tt_out.ptr, T * (n - 1));
+}
+
+int bito_amd_engine_gradient_log_det_jacobian(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
+                                              const double* node_heights, const double* node_bounds,
+                                              const double* height_ratios, double* out) {
+  return RatioTransform(e, 1, tree_count, parent_ids, node_heights, node_bounds, height_ratios, nullptr, out);
+}
+
+int bito_amd_engine_ratio_gradient_of_height_gradient(bito_amd_engine* e, int32_t tree_count,
+                                                      const int32_t* parent_ids, const double* node_heights,
+                                                      const double* node_bounds, const double* height_ratios,
+                                                      const double* height_gradient, double* out) {
+  return RatioTransform(e, 0, tree_count, parent_ids, node_heights, node_bounds, height_ratios, height_gradient,
+                        out);
+}
+
+int bito_amd_engine_time_tree_log_likelihoods(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
+                                              const double* branch_lengths, const double* rates,
+                                              const double* node_heights, const double* node_bounds,
+                                              const double* params, int32_t rescaling,
+                                              int32_t include_log_det_jacobian, double* out) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  const int n = e->n, N = 2 * n - 1;
+  if (include_log_det_jacobian && (!node_heights || !node_bounds))
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "node_heights / node_bounds are needed for the log-det-Jacobian");
+  int rc = bito_amd_engine_upload(e, tree_count, 1, N, parent_ids, branch_lengths, rates, params);
+  if (rc) return rc;
+  if ((rc = RunResident(e, 0, rescaling != 0))) return rc;
+  if (include_log_det_jacobian) {
+    const size_t T = tree_count;
+    if ((rc = ToDevice(e, e->tt_heights, node_heights, T * N))) return rc;
+    if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
+    LaunchLogDetJacobian(tree_count, n, e->parent_ids.ptr, e->tt_heights.ptr, e->tt_bounds.ptr, nullptr,
+                         e->out_ll.ptr, e->stream);
+    HIP_TRY(e, hipGetLastError());
+  }
+  return bito_amd_engine_download(e, out, nullptr);
+}
+
+int bito_amd_engine_time_tree_gradients(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
+                                        const double* branch_lengths, const double* rates, int32_t rate_count,
+                                        const double* node_heights, const double* node_bounds,
+                                        const double* height_ratios, const double* params, int32_t rescaling,
+                                        int32_t flags, double fd_delta, double* out_ll, double* out_branch,
+                                        double* out_site, double* out_subst, double* out_clock,
+                                        double* out_ratios) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  const int n = e->n, N = 2 * n - 1;
+  const size_t T = tree_count;
+  const bool want_clock = (flags & BITO_AMD_GRAD_CLOCK_MODEL) && out_clock;
+  const bool want_ratios = (flags & BITO_AMD_GRAD_RATIOS_ROOT_HEIGHT) && out_ratios;
+  if (want_clock && rate_count != 1 && rate_count != N - 1)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG,
+                "The number of rates should be equal to 1 (i.e. strict clock) or equal to the number of branches.");
+  if (want_ratios && (!node_heights || !node_bounds || !height_ratios))
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "time trees are not initialised: node_heights / node_bounds / height_ratios");
+  // everything except the clock and ratio outputs; leaves the main pass resident on the device
+  int rc = bito_amd_engine_gradients(e, tree_count, 1, N, parent_ids, branch_lengths, rates, params, rescaling,
+                                     flags & ~BITO_AMD_GRAD_CLOCK_MODEL, fd_delta, out_ll, out_branch, out_site,
+                                     out_subst, nullptr);
+  if (rc) return rc;
+  if (want_clock) {
+    const size_t count = T * (rate_count == 1 ? 1 : N - 1);
+    HIP_TRY(e, e->tt_out.Reserve(count));
+    LaunchClockGradient(tree_count, N, rate_count, e->out_grad.ptr, e->branch_in.ptr, N, e->tt_out.ptr, e->stream);
+    HIP_TRY(e, hipGetLastError());
+    if ((rc = ToHost(e, out_clock, e->tt_out.ptr, count))) return rc;
+  }
+  if (want_ratios) {
+    if ((rc = ToDevice(e, e->tt_heights, node_heights, T * N))) return rc;
+    if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
+    if ((rc = ToDevice(e, e->tt_ratios, height_ratios, T * (n - 1)))) return rc;
+    HIP_TRY(e, e->tt_work.Reserve(T * 3 * (n - 1)));
+    HIP_TRY(e, e->tt_out.Reserve(T * (n - 1)));
+    const int mode = 2 | ((flags & BITO_AMD_GRAD_LOG_DET_JACOBIAN_GRADIENT) ? 4 : 0);
+    LaunchRatioGradient(tree_count, n, mode, e->parent_ids.ptr, e->tt_heights.ptr, e->tt_bounds.ptr, e->tt_ratios.ptr,
+                        e->out_grad.ptr, N, e->has_rates ? e->rates.ptr : nullptr, e->tt_work.ptr, e->tt_out.ptr,
+                        e->stream);
+    HIP_TRY(e, hipGetLastError());
+    if ((rc = ToHost(e, out_ratios, e->tt_out.ptr, T * (n - 1)))) return rc;
   }
   return BITO_AMD_OK;
 }

@@ -108,4 +108,21 @@ const char* WalkHbmKernelName(int category_count, int want_gradient, int rescali
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
                   hipStream_t stream);
 
+// time_tree.hip: RootedTree's height-ratio parameterisation and the rooted gradient transforms,
+// one thread per tree (reference src/rooted_tree.cpp:36-121, src/rooted_gradient_transforms.cpp)
+void LaunchTimeTreeFromBranchLengths(int T, int n, const int32_t* parent_ids, const double* branch_lengths,
+                                     const double* tip_dates, double* bounds, double* heights, double* ratios,
+                                     double* max_diff, hipStream_t stream);
+void LaunchTimeTreeFromRatios(int T, int n, const int32_t* parent_ids, const double* bounds, const double* ratios,
+                              double* heights, double* branch_lengths, hipStream_t stream);
+void LaunchLogDetJacobian(int T, int n, const int32_t* parent_ids, const double* heights, const double* bounds,
+                          double* out, double* add_to, hipStream_t stream);
+// mode: 0 height gradient -> ratio gradient, 1 gradient of the log-det-Jacobian,
+// 2 branch gradient -> ratio gradient (+4: add the log-det-Jacobian gradient); work [T][3(n-1)]
+void LaunchRatioGradient(int T, int n, int mode, const int32_t* parent_ids, const double* heights,
+                         const double* bounds, const double* ratios, const double* in, int in_stride,
+                         const double* rates, double* work, double* out, hipStream_t stream);
+void LaunchClockGradient(int T, int N, int rate_count, const double* branch_grad, const double* branch_lengths,
+                         int bl_stride, double* out, hipStream_t stream);
+
 }  // namespace bito_amd

@@ -163,6 +163,11 @@ class Engine:
             self._h, T, rooted, M, _ip(parent_ids), _dp(branch_lengths), _dp(rates), _dp(params), int(rescaling),
             flags, fd_delta, _dp(ll), _dp(branch), _dp(site), _dp(subst), _dp(clock)))
         self.tree_count = T
+        return self._package(flags, rooted, ll, branch, site, subst, clock)
+
+    def _package(self, flags, rooted, ll, branch, site, subst, clock) -> Dict[str, np.ndarray]:
+        bm = self.block_map()
+        sub_len = bm["entire_substitution"][1] if "entire_substitution" in bm else 0
         out = {"log_likelihood": ll, "branch_lengths": branch}
         if site is not None and self.category_count > 1:
             out["site_model"] = site
@@ -177,6 +182,97 @@ class Engine:
             out["substitution_model_frequencies"] = subst[:, sub_len - n_freq:sub_len]
         if clock is not None and rooted:
             out["clock_model"] = clock
+        return out
+
+    # -- time trees (reference src/rooted_tree.cpp, src/rooted_gradient_transforms.cpp) --------
+    def _tt(self, parent_ids, *node_arrays):
+        pid = np.ascontiguousarray(parent_ids, dtype=np.int32)
+        if pid.ndim != 2:
+            raise BitoAmdError(_capi.ERR_BAD_ARG, "parent_ids must be [tree_count][2n-2]")
+        return (pid, pid.shape[0]) + tuple(np.ascontiguousarray(a, dtype=np.float64) for a in node_arrays)
+
+    def time_trees_from_branch_lengths(self, parent_ids, branch_lengths, tip_dates):
+        """-> (node_bounds, node_heights, height_ratios); RuntimeError for a tree that is not
+        time-calibrated (RootedTree::InitializeTimeTreeUsingBranchLengths)."""
+        pid, T, bl, dates = self._tt(parent_ids, branch_lengths, tip_dates)
+        n, N = self.taxon_count, 2 * self.taxon_count - 1
+        bounds, heights, ratios = np.zeros((T, N)), np.zeros((T, N)), np.zeros((T, n - 1))
+        self._check(_capi.lib().bito_amd_engine_time_trees_from_branch_lengths(
+            self._h, T, _ip(pid), _dp(bl), _dp(dates), _dp(bounds), _dp(heights), _dp(ratios)))
+        return bounds, heights, ratios
+
+    def time_trees_from_height_ratios(self, parent_ids, node_bounds, height_ratios):
+        """-> (node_heights, branch_lengths) (RootedTree::InitializeTimeTreeUsingHeightRatios)."""
+        pid, T, bounds, ratios = self._tt(parent_ids, node_bounds, height_ratios)
+        N = 2 * self.taxon_count - 1
+        heights, bl = np.zeros((T, N)), np.zeros((T, N))
+        self._check(_capi.lib().bito_amd_engine_time_trees_from_height_ratios(
+            self._h, T, _ip(pid), _dp(bounds), _dp(ratios), _dp(heights), _dp(bl)))
+        return heights, bl
+
+    def log_det_jacobian(self, parent_ids, node_heights, node_bounds) -> np.ndarray:
+        pid, T, heights, bounds = self._tt(parent_ids, node_heights, node_bounds)
+        out = np.zeros(T)
+        self._check(_capi.lib().bito_amd_engine_log_det_jacobian(self._h, T, _ip(pid), _dp(heights), _dp(bounds),
+                                                                 _dp(out)))
+        return out
+
+    def gradient_log_det_jacobian(self, parent_ids, node_heights, node_bounds, height_ratios) -> np.ndarray:
+        pid, T, heights, bounds, ratios = self._tt(parent_ids, node_heights, node_bounds, height_ratios)
+        out = np.zeros((T, self.taxon_count - 1))
+        self._check(_capi.lib().bito_amd_engine_gradient_log_det_jacobian(
+            self._h, T, _ip(pid), _dp(heights), _dp(bounds), _dp(ratios), _dp(out)))
+        return out
+
+    def ratio_gradient_of_height_gradient(self, parent_ids, node_heights, node_bounds, height_ratios,
+                                          height_gradient) -> np.ndarray:
+        pid, T, heights, bounds, ratios, hg = self._tt(parent_ids, node_heights, node_bounds, height_ratios,
+                                                       height_gradient)
+        out = np.zeros((T, self.taxon_count - 1))
+        self._check(_capi.lib().bito_amd_engine_ratio_gradient_of_height_gradient(
+            self._h, T, _ip(pid), _dp(heights), _dp(bounds), _dp(ratios), _dp(hg), _dp(out)))
+        return out
+
+    def time_tree_log_likelihoods(self, parent_ids, branch_lengths, node_heights, node_bounds, params=None,
+                                  rates=None, rescaling=False, include_log_det_jacobian=True) -> np.ndarray:
+        parent_ids, branch_lengths, rates, params, T, M, rooted = self._prep(parent_ids, branch_lengths, rates, params)
+        if not rooted:
+            raise BitoAmdError(_capi.ERR_BAD_TREE, "time trees are rooted")
+        heights = np.ascontiguousarray(node_heights, dtype=np.float64)
+        bounds = np.ascontiguousarray(node_bounds, dtype=np.float64)
+        out = np.zeros(T)
+        self._check(_capi.lib().bito_amd_engine_time_tree_log_likelihoods(
+            self._h, T, _ip(parent_ids), _dp(branch_lengths), _dp(rates), _dp(heights), _dp(bounds), _dp(params),
+            int(rescaling), int(include_log_det_jacobian), _dp(out)))
+        self.tree_count = T
+        return out
+
+    def time_tree_gradients(self, parent_ids, branch_lengths, node_heights, node_bounds, height_ratios, params=None,
+                            rates=None, rate_count=1, rescaling=False, flags=0, fd_delta=1e-6):
+        """``Engine::Gradients(RootedTreeCollection)`` for time trees: the ``gradients`` outputs plus
+        ``ratios_root_height`` and a strict or per-branch ``clock_model``."""
+        parent_ids, branch_lengths, rates, params, T, M, rooted = self._prep(parent_ids, branch_lengths, rates, params)
+        if not rooted:
+            raise BitoAmdError(_capi.ERR_BAD_TREE, "time trees are rooted")
+        n, N = self.taxon_count, 2 * self.taxon_count - 1
+        heights = np.ascontiguousarray(node_heights, dtype=np.float64)
+        bounds = np.ascontiguousarray(node_bounds, dtype=np.float64)
+        ratios = np.ascontiguousarray(height_ratios, dtype=np.float64)
+        ll, branch = np.zeros(T), np.zeros((T, N))
+        bm = self.block_map()
+        sub_len = bm["entire_substitution"][1] if "entire_substitution" in bm else 0
+        site = np.zeros(T) if flags & _capi.GRAD_SITE_MODEL else None
+        subst = np.zeros((T, max(sub_len, 1))) if flags & _capi.GRAD_SUBSTITUTION_MODEL else None
+        clock = np.zeros((T, 1 if rate_count == 1 else N - 1)) if flags & _capi.GRAD_CLOCK_MODEL else None
+        ratio_grad = np.zeros((T, n - 1)) if flags & _capi.GRAD_RATIOS_ROOT_HEIGHT else None
+        self._check(_capi.lib().bito_amd_engine_time_tree_gradients(
+            self._h, T, _ip(parent_ids), _dp(branch_lengths), _dp(rates), int(rate_count), _dp(heights), _dp(bounds),
+            _dp(ratios), _dp(params), int(rescaling), flags, fd_delta, _dp(ll), _dp(branch), _dp(site), _dp(subst),
+            _dp(clock), _dp(ratio_grad)))
+        self.tree_count = T
+        out = self._package(flags, rooted, ll, branch, site, subst, clock)
+        if ratio_grad is not None:
+            out["ratios_root_height"] = ratio_grad
         return out
 
     # -- HBM-resident batch ---------------------------------------------------

@@ -19,9 +19,11 @@ from .site_pattern import SitePattern
 
 
 # PhyloGradientFlagOptions of the reference all default to "on", stick-breaking included
-# (src/phylo_flags.hpp:322-343); ratios_root_height is a time-tree transform outside the GPU path.
+# (src/phylo_flags.hpp:322-343); rooted instances add ratios_root_height and the log-det-Jacobian gradient.
 DEFAULT_GRADIENT_FLAGS = (_capi.GRAD_SUBSTITUTION_MODEL | _capi.GRAD_SITE_MODEL | _capi.GRAD_CLOCK_MODEL |
                           _capi.GRAD_STICKBREAKING)
+DEFAULT_ROOTED_GRADIENT_FLAGS = (DEFAULT_GRADIENT_FLAGS | _capi.GRAD_RATIOS_ROOT_HEIGHT |
+                                 _capi.GRAD_LOG_DET_JACOBIAN_GRADIENT)
 
 
 class _Tree:
@@ -35,9 +37,30 @@ class _Tree:
         self.leaf_count = parsed.leaf_count
         self.rates = np.ones(parsed.node_count - 1)
         self.rate_count = 1
+        # time-tree state of RootedTree (reference src/rooted_tree.hpp); empty until dates are set
+        self.node_bounds = np.zeros(0)
+        self.node_heights = np.zeros(0)
+        self.height_ratios = np.zeros(0)
+        self._engine_ref = None
 
     def parent_id_vector(self) -> List[int]:
         return [int(x) for x in self._parent_ids]
+
+    def initialize_time_tree_using_height_ratios(self, height_ratios):
+        """``RootedTree::InitializeTimeTreeUsingHeightRatios`` (reference src/rooted_tree.cpp:101-121,
+        pybito ``initialize_time_tree_using_height_ratios``): node heights and branch lengths from
+        the ratios, evaluated on the device."""
+        if self.node_bounds.size == 0:
+            raise RuntimeError("Have you set dates for your time trees?")
+        if self._engine_ref is None or self._engine_ref() is None:
+            raise RuntimeError("Engine not available. Call prepare_for_phylo_likelihood to make an engine for "
+                               "phylogenetic likelihood computation.")
+        ratios = np.asarray(height_ratios, dtype=np.float64)
+        heights, bl = self._engine_ref().time_trees_from_height_ratios(self._parent_ids[None, :],
+                                                                       self.node_bounds[None, :], ratios[None, :])
+        self.height_ratios = ratios.copy()
+        self.node_heights[:] = heights[0]
+        self.branch_lengths[:] = bl[0]
 
 
 class _TreeCollection:
@@ -163,22 +186,140 @@ class unrooted_instance(_GenericInstance):
 
 
 class rooted_instance(_GenericInstance):
-    """pybito ``rooted_instance`` (reference src/pybito.cpp:289-421); time-tree
-    parameterisations (height ratios, log-det-Jacobian) are not on the GPU path."""
+    """pybito ``rooted_instance`` (reference src/pybito.cpp:289-421), time trees included: tip
+    dates, height ratios, the log-det-Jacobian of the height transform and the
+    ``ratios_root_height`` gradient (reference src/rooted_sbn_instance.cpp:43-131)."""
     _rooted = True
+
+    def __init__(self, name: str = ""):
+        super().__init__(name)
+        self._tip_dates: Optional[np.ndarray] = None
+        self._init_from_branch_lengths = False
+
+    # -- tip dates (reference src/rooted_tree_collection.cpp:30-81) -------------
+    def set_dates_to_be_constant(self, initialize_time_trees_using_branch_lengths: bool):
+        self._process_dates(np.zeros(len(self._taxon_names)), initialize_time_trees_using_branch_lengths)
+
+    def parse_dates_from_taxon_names(self, initialize_time_trees_using_branch_lengths: bool):
+        self._process_dates(treeio.parse_dates_from_taxon_names(self._taxon_names),
+                            initialize_time_trees_using_branch_lengths)
+
+    def parse_dates_from_csv(self, csv_path: str, initialize_time_trees_using_branch_lengths: bool):
+        self._process_dates(treeio.parse_dates_from_csv(csv_path, self._taxon_names),
+                            initialize_time_trees_using_branch_lengths)
+
+    def tip_dates(self) -> Dict[str, float]:
+        """``RootedTreeCollection::GetTagDateMap`` keyed by taxon name."""
+        if self._tip_dates is None:
+            return {}
+        return {nm: float(d) for nm, d in zip(self._taxon_names, self._tip_dates)}
+
+    def _process_dates(self, dates: np.ndarray, initialize: bool):
+        self._tip_dates = np.asarray(dates, dtype=np.float64)
+        self._init_from_branch_lengths = bool(initialize)
+        for t in self.tree_collection.trees:  # RootedTree::SetTipDates (src/rooted_tree.cpp:36-44)
+            t.node_heights = np.zeros(2 * t.leaf_count - 1)
+            t.node_heights[:t.leaf_count] = self._tip_dates
+            t.rates = np.ones(2 * t.leaf_count - 2)
+            t.rate_count = 1
+            t.height_ratios = np.zeros(0)
+        if self._engine is not None:
+            self._initialize_time_trees()
+
+    def _initialize_time_trees(self):
+        """SetNodeBoundsUsingDates for every tree and, if asked, InitializeTimeTreeUsingBranchLengths
+        -- on the device, so it waits for the engine (the reference runs it on the host at parse
+        time; the observable state after prepare_for_phylo_likelihood is the same)."""
+        trees = self.tree_collection.trees
+        if self._tip_dates is None or not trees:
+            return
+        eng = self._get_engine()
+        import weakref
+        ref = weakref.ref(eng)
+        pid, bl = self._wire_trees()
+        if self._init_from_branch_lengths:
+            bounds, heights, ratios = eng.time_trees_from_branch_lengths(pid, bl, self._tip_dates)
+        else:
+            bounds, heights, ratios = self._bounds_only(pid), None, None
+        for i, t in enumerate(trees):
+            t.node_bounds = bounds[i].copy()
+            t._engine_ref = ref
+            if heights is not None:
+                t.node_heights = heights[i].copy()
+                t.height_ratios = ratios[i].copy()
+
+    def _bounds_only(self, pid: np.ndarray) -> np.ndarray:
+        """RootedTree::SetNodeBoundsUsingDates alone (src/rooted_tree.cpp:46-60): the latest tip
+        date below every node."""
+        n = len(self._tip_dates)
+        bounds = np.full((pid.shape[0], 2 * n - 1), -np.inf)
+        bounds[:, :n] = self._tip_dates
+        rows = np.arange(pid.shape[0])
+        for child in range(2 * n - 2):  # ids are post-order: children before parents
+            bounds[rows, pid[:, child]] = np.maximum(bounds[rows, pid[:, child]], bounds[:, child])
+        return bounds
+
+    def prepare_for_phylo_likelihood(self, *args, **kwargs):
+        super().prepare_for_phylo_likelihood(*args, **kwargs)
+        self._initialize_time_trees()
+
+    def _wire_trees(self):
+        trees = self.tree_collection.trees
+        pid = np.stack([t._parent_ids for t in trees]).astype(np.int32)
+        bl = np.stack([np.asarray(t.branch_lengths, dtype=np.float64) for t in trees])
+        return pid, bl
 
     def _rates(self) -> np.ndarray:
         return np.stack([np.asarray(t.rates, dtype=np.float64) for t in self.tree_collection.trees])
 
-    def log_likelihoods(self) -> np.ndarray:
-        pid, bl = self._wire()
-        return self._get_engine().log_likelihoods(pid, bl, self._params, rates=self._rates(),
-                                                  rescaling=self._rescaling)
+    def _time_state(self, need_ratios: bool):
+        trees = self.tree_collection.trees
+        if any(t.node_bounds.size == 0 or t.node_heights.size == 0 for t in trees) or \
+                (need_ratios and any(t.height_ratios.size == 0 for t in trees)):
+            raise RuntimeError("Time trees have not been initialized: set tip dates (parse_dates_from_taxon_names, "
+                               "parse_dates_from_csv, set_dates_to_be_constant) with "
+                               "initialize_time_trees_using_branch_lengths=True or set height ratios.")
+        heights = np.stack([t.node_heights for t in trees])
+        bounds = np.stack([t.node_bounds for t in trees])
+        ratios = np.stack([t.height_ratios for t in trees]) if need_ratios else None
+        return heights, bounds, ratios
 
-    def phylo_gradients(self, flags: int = DEFAULT_GRADIENT_FLAGS) -> List[PhyloGradient]:
+    def log_likelihoods(self, include_log_det_jacobian: bool = True) -> np.ndarray:
+        """``RootedSBNInstance::LogLikelihoods``; the log-det-Jacobian of the height transform is
+        part of the value by default (include_log_det_jacobian_likelihood, reference
+        src/phylo_flags.hpp:347-354), which needs initialised time trees."""
         pid, bl = self._wire()
-        out = self._get_engine().gradients(pid, bl, self._params, rates=self._rates(), rescaling=self._rescaling,
-                                           flags=flags)
+        eng = self._get_engine()
+        if not include_log_det_jacobian:
+            return eng.log_likelihoods(pid, bl, self._params, rates=self._rates(), rescaling=self._rescaling)
+        heights, bounds, _ = self._time_state(False)
+        return eng.time_tree_log_likelihoods(pid, bl, heights, bounds, self._params, rates=self._rates(),
+                                             rescaling=self._rescaling, include_log_det_jacobian=True)
+
+    def unrooted_log_likelihoods(self) -> np.ndarray:
+        """``RootedSBNInstance::UnrootedLogLikelihoods``: no clock rates, no Jacobian."""
+        pid, bl = self._wire()
+        return self._get_engine().log_likelihoods(pid, bl, self._params, rescaling=self._rescaling)
+
+    def log_det_jacobian_of_height_transform(self) -> np.ndarray:
+        pid, _ = self._wire()
+        heights, bounds, _ = self._time_state(False)
+        return self._get_engine().log_det_jacobian(pid, heights, bounds)
+
+    def gradient_log_det_jacobian_of_height_transform(self) -> np.ndarray:
+        pid, _ = self._wire()
+        heights, bounds, ratios = self._time_state(True)
+        return self._get_engine().gradient_log_det_jacobian(pid, heights, bounds, ratios)
+
+    def phylo_gradients(self, flags: int = DEFAULT_ROOTED_GRADIENT_FLAGS) -> List[PhyloGradient]:
+        pid, bl = self._wire()
+        heights, bounds, ratios = self._time_state(True)  # the reference throws on uninitialised time trees
+        rate_counts = {t.rate_count for t in self.tree_collection.trees}
+        if len(rate_counts) != 1:
+            raise RuntimeError("All trees of a collection must share one clock parameterisation.")
+        out = self._get_engine().time_tree_gradients(pid, bl, heights, bounds, ratios, self._params,
+                                                     rates=self._rates(), rate_count=rate_counts.pop(),
+                                                     rescaling=self._rescaling, flags=flags)
         return _to_gradients(out)
 
 

@@ -303,5 +303,35 @@ def parse_dates_from_taxon_names(names: Sequence[str]) -> np.ndarray:
     """``TaxonNameMunging::ParseDatesFromTagTaxonMap`` + ``MakeDatesRelativeToMaximum``
     (reference src/taxon_name_munging.cpp): the date is the text after the last
     underscore; heights are max(date) - date."""
-    dates = np.array([float(nm.rsplit("_", 1)[1]) for nm in names])
+    dates = []
+    for nm in names:
+        m = _DATE_RE.match(nm)
+        if not m:
+            raise RuntimeError("Couldn't parse a date from:" + nm)
+        dates.append(float(m.group(1)))
+    dates = np.array(dates)
+    return dates.max() - dates
+
+
+_DATE_RE = re.compile(r"^.+_(\d*\.?\d+(?:[eE][-+]?\d+)?)$")
+
+
+def parse_dates_from_csv(path: str, names: Sequence[str]) -> np.ndarray:
+    """``RootedTreeCollection::ParseDatesFromCSVButDontInitializeTimeTrees`` (reference
+    src/rooted_tree_collection.cpp:48-63): headerless two-column CSV of quoted taxon names and
+    dates; heights are max(date) - date."""
+    table = {}
+    with open(path) as fh:
+        for line in fh:
+            line = line.strip()
+            if not line:
+                continue
+            name, value = line.rsplit(",", 1)
+            table[name.strip().strip('"')] = float(value)
+    dates = []
+    for nm in names:
+        if nm not in table:
+            raise RuntimeError("Taxon " + nm + " found in current tree collection but not in " + path)
+        dates.append(table[nm])
+    dates = np.array(dates)
     return dates.max() - dates

@@ -40,6 +40,8 @@ extern "C" {
 #define BITO_AMD_GRAD_SITE_MODEL 2
 #define BITO_AMD_GRAD_CLOCK_MODEL 4
 #define BITO_AMD_GRAD_STICKBREAKING 8 /* use_stickbreaking_transform (reference default) */
+#define BITO_AMD_GRAD_RATIOS_ROOT_HEIGHT 16        /* ratios_root_height (time trees only) */
+#define BITO_AMD_GRAD_LOG_DET_JACOBIAN_GRADIENT 32 /* include_log_det_jacobian_gradient */
 
 /* Kernel selection (diagnostics / benchmarking).  AUTO picks the LDS-resident
  * kernel when the tree fits, the HBM-arena kernel otherwise. */
@@ -129,6 +131,71 @@ int bito_amd_engine_gradients(bito_amd_engine *e, int32_t tree_count, int32_t ro
                               double fd_delta, double *out_log_likelihoods,
                               double *out_branch_gradients, double *out_site_model,
                               double *out_subst_model, double *out_clock_model);
+
+/* ---- time trees: RootedTree's height-ratio parameterisation and the rooted gradient
+ * post-transforms.  A time tree is a rooted tree (node_count = 2n-1) with
+ *   node_bounds   [tree_count][2n-1]  latest tip date below each node (rooted_tree.cpp:46-60)
+ *   node_heights  [tree_count][2n-1]
+ *   height_ratios [tree_count][n-1]   entry id-n; the root's entry is the root height
+ * All per-tree recursions run on the device, one thread per tree. ---- */
+
+/* RootedTree::SetTipDates + InitializeTimeTreeUsingBranchLengths (src/rooted_tree.cpp:36-99).
+ * tip_dates: [n] (already relative to the latest tip, taxon_name_munging.cpp:46-56).
+ * BITO_AMD_ERR_BAD_TREE when a tree's branch lengths disagree with the dates by more than 1e-4. */
+int bito_amd_engine_time_trees_from_branch_lengths(bito_amd_engine *e, int32_t tree_count,
+                                                   const int32_t *parent_ids, const double *branch_lengths,
+                                                   const double *tip_dates, double *out_node_bounds,
+                                                   double *out_node_heights, double *out_height_ratios);
+
+/* RootedTree::InitializeTimeTreeUsingHeightRatios (src/rooted_tree.cpp:101-121):
+ * out_node_heights [tree_count][2n-1], out_branch_lengths [tree_count][2n-1] (root entry 0). */
+int bito_amd_engine_time_trees_from_height_ratios(bito_amd_engine *e, int32_t tree_count,
+                                                  const int32_t *parent_ids, const double *node_bounds,
+                                                  const double *height_ratios, double *out_node_heights,
+                                                  double *out_branch_lengths);
+
+/* Engine::LogDetJacobianHeightTransform (src/engine.cpp:85-92,
+ * rooted_gradient_transforms.cpp:243-256): out [tree_count]. */
+int bito_amd_engine_log_det_jacobian(bito_amd_engine *e, int32_t tree_count, const int32_t *parent_ids,
+                                     const double *node_heights, const double *node_bounds, double *out);
+
+/* Engine::GradientLogDeterminantJacobian (src/engine.cpp:112-119,
+ * rooted_gradient_transforms.cpp:148-168): out [tree_count][n-1]. */
+int bito_amd_engine_gradient_log_det_jacobian(bito_amd_engine *e, int32_t tree_count, const int32_t *parent_ids,
+                                              const double *node_heights, const double *node_bounds,
+                                              const double *height_ratios, double *out);
+
+/* RootedGradientTransforms::RatioGradientOfHeightGradient (rooted_gradient_transforms.cpp:170-184;
+ * pybito ratio_gradient_of_height_gradient): height_gradient, out [tree_count][n-1]. */
+int bito_amd_engine_ratio_gradient_of_height_gradient(bito_amd_engine *e, int32_t tree_count,
+                                                      const int32_t *parent_ids, const double *node_heights,
+                                                      const double *node_bounds, const double *height_ratios,
+                                                      const double *height_gradient, double *out);
+
+/* Engine::LogLikelihoods(RootedTreeCollection) with the include_log_det_jacobian_likelihood flag
+ * (src/fat_beagle.cpp:83-98): the tree log-likelihood plus, when the flag is non-zero, the
+ * log-det-Jacobian of the height transform. */
+int bito_amd_engine_time_tree_log_likelihoods(bito_amd_engine *e, int32_t tree_count, const int32_t *parent_ids,
+                                              const double *branch_lengths, const double *rates,
+                                              const double *node_heights, const double *node_bounds,
+                                              const double *params, int32_t rescaling,
+                                              int32_t include_log_det_jacobian, double *out_log_likelihoods);
+
+/* Engine::Gradients(RootedTreeCollection) (src/fat_beagle.cpp:559-619) for time trees: everything
+ * bito_amd_engine_gradients returns, plus
+ *   out_clock_model:        [tree_count][rate_count], rate_count 1 (strict) or 2n-2 (one rate per
+ *                           branch) as RootedTree::rate_count_ (fat_beagle.cpp:379-399)
+ *   out_ratios_root_height: [tree_count][n-1] "ratios_root_height", with the log-det-Jacobian
+ *                           gradient added when BITO_AMD_GRAD_LOG_DET_JACOBIAN_GRADIENT is set.
+ * The branch gradient stays on the device between the traversal and the ratio transform. */
+int bito_amd_engine_time_tree_gradients(bito_amd_engine *e, int32_t tree_count, const int32_t *parent_ids,
+                                        const double *branch_lengths, const double *rates, int32_t rate_count,
+                                        const double *node_heights, const double *node_bounds,
+                                        const double *height_ratios, const double *params, int32_t rescaling,
+                                        int32_t flags, double fd_delta, double *out_log_likelihoods,
+                                        double *out_branch_gradients, double *out_site_model,
+                                        double *out_subst_model, double *out_clock_model,
+                                        double *out_ratios_root_height);
 
 /* ---- HBM-resident batch interface ----------------------------------------
  * The two calls above are upload + run + download.  Callers that keep a batch

@@ -108,6 +108,31 @@ int oracle_weibull_rates(int category_count, double shape, double *rates,
 void oracle_transition_matrix(const double *V16, const double *Vinv16,
                               const double *lambda4, double t, double *P16);
 
+/*
+ * Time-tree parameterisation of RootedTree and the rooted gradient post-transforms
+ * (time_tree_oracle.c; reference src/rooted_tree.cpp:36-121,
+ * src/rooted_gradient_transforms.cpp:19-256).  One tree per call: parent_ids[2n-2],
+ * node vectors [2n-1], internal-node vectors [n-1] (entry id-n, root last).
+ */
+void oracle_time_tree_bounds(int n, const int *parent_ids, const double *tip_dates, double *bounds);
+int oracle_time_tree_from_branch_lengths(int n, const int *parent_ids, const double *branch_lengths,
+                                         const double *tip_dates, double *bounds, double *heights,
+                                         double *ratios);
+void oracle_time_tree_from_height_ratios(int n, const int *parent_ids, const double *bounds,
+                                         const double *ratios, double *heights, double *branch_lengths);
+double oracle_log_det_jacobian(int n, const int *parent_ids, const double *heights, const double *bounds);
+void oracle_height_gradient(int n, const int *parent_ids, const double *rates, const double *branch_gradient,
+                            double *out);
+void oracle_ratio_gradient_of_height_gradient(int n, const int *parent_ids, const double *heights,
+                                              const double *bounds, const double *ratios,
+                                              const double *height_gradient, double *out);
+void oracle_gradient_log_det_jacobian(int n, const int *parent_ids, const double *heights, const double *bounds,
+                                      const double *ratios, double *out);
+void oracle_ratio_gradient_of_branch_gradient(int n, const int *parent_ids, const double *heights,
+                                              const double *bounds, const double *ratios, const double *rates,
+                                              const double *branch_gradient, int include_log_det_jacobian,
+                                              double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,8 +22,8 @@ GRAD_STICKBREAKING = 8
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "bito_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("bito_oracle.c", "time_tree_oracle.c", "bito_oracle.h")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -55,6 +55,15 @@ def lib():
         L.oracle_substitution_model.argtypes = [C.c_char_p, dp, dp, dp, dp, dp, dp]
         L.oracle_weibull_rates.argtypes = [C.c_int, C.c_double, dp, dp, dp]
         L.oracle_transition_matrix.argtypes = [dp, dp, dp, C.c_double, dp]
+        L.oracle_time_tree_bounds.argtypes = [C.c_int, ip, dp, dp]
+        L.oracle_time_tree_from_branch_lengths.argtypes = [C.c_int, ip, dp, dp, dp, dp, dp]
+        L.oracle_time_tree_from_height_ratios.argtypes = [C.c_int, ip, dp, dp, dp, dp]
+        L.oracle_log_det_jacobian.restype = C.c_double
+        L.oracle_log_det_jacobian.argtypes = [C.c_int, ip, dp, dp]
+        L.oracle_height_gradient.argtypes = [C.c_int, ip, dp, dp, dp]
+        L.oracle_ratio_gradient_of_height_gradient.argtypes = [C.c_int, ip, dp, dp, dp, dp, dp]
+        L.oracle_gradient_log_det_jacobian.argtypes = [C.c_int, ip, dp, dp, dp, dp]
+        L.oracle_ratio_gradient_of_branch_gradient.argtypes = [C.c_int, ip, dp, dp, dp, dp, dp, C.c_int, dp]
         _lib = L
     return _lib
 
@@ -193,3 +202,56 @@ def transition_matrix(V, Vinv, lam, t: float) -> np.ndarray:
     lam = np.ascontiguousarray(lam, dtype=np.float64)
     lib().oracle_transition_matrix(_dp(V), _dp(Vinv), _dp(lam), float(t), _dp(P))
     return P.reshape(4, 4)
+
+
+class TimeTree:
+    """One RootedTree with its time parameterisation (reference src/rooted_tree.hpp): built from
+    branch lengths + tip dates, or re-set from height ratios."""
+
+    def __init__(self, parent_ids, branch_lengths, tip_dates):
+        self.parent_ids = np.ascontiguousarray(parent_ids, dtype=np.int32)
+        self.n = (self.parent_ids.shape[0] + 2) // 2
+        N = 2 * self.n - 1
+        self.tip_dates = np.ascontiguousarray(tip_dates, dtype=np.float64)
+        self.branch_lengths = np.ascontiguousarray(branch_lengths, dtype=np.float64).copy()
+        self.node_bounds = np.zeros(N)
+        self.node_heights = np.zeros(N)
+        self.height_ratios = np.zeros(self.n - 1)
+        rc = lib().oracle_time_tree_from_branch_lengths(self.n, _ip(self.parent_ids), _dp(self.branch_lengths),
+                                                        _dp(self.tip_dates), _dp(self.node_bounds),
+                                                        _dp(self.node_heights), _dp(self.height_ratios))
+        if rc:
+            raise RuntimeError("Tree isn't time-calibrated in RootedTree::InitializeTimeTreeUsingBranchLengths.")
+
+    def initialize_time_tree_using_height_ratios(self, ratios):
+        self.height_ratios = np.ascontiguousarray(ratios, dtype=np.float64).copy()
+        lib().oracle_time_tree_from_height_ratios(self.n, _ip(self.parent_ids), _dp(self.node_bounds),
+                                                  _dp(self.height_ratios), _dp(self.node_heights),
+                                                  _dp(self.branch_lengths))
+
+    def log_det_jacobian(self) -> float:
+        return lib().oracle_log_det_jacobian(self.n, _ip(self.parent_ids), _dp(self.node_heights),
+                                             _dp(self.node_bounds))
+
+    def gradient_log_det_jacobian(self) -> np.ndarray:
+        out = np.zeros(self.n - 1)
+        lib().oracle_gradient_log_det_jacobian(self.n, _ip(self.parent_ids), _dp(self.node_heights),
+                                               _dp(self.node_bounds), _dp(self.height_ratios), _dp(out))
+        return out
+
+    def ratio_gradient_of_height_gradient(self, height_gradient) -> np.ndarray:
+        hg = np.ascontiguousarray(height_gradient, dtype=np.float64)
+        out = np.zeros(self.n - 1)
+        lib().oracle_ratio_gradient_of_height_gradient(self.n, _ip(self.parent_ids), _dp(self.node_heights),
+                                                       _dp(self.node_bounds), _dp(self.height_ratios), _dp(hg),
+                                                       _dp(out))
+        return out
+
+    def ratio_gradient_of_branch_gradient(self, branch_gradient, rates, include_log_det_jacobian=True):
+        bg = np.ascontiguousarray(branch_gradient, dtype=np.float64)
+        rt = np.ascontiguousarray(rates, dtype=np.float64)
+        out = np.zeros(self.n - 1)
+        lib().oracle_ratio_gradient_of_branch_gradient(self.n, _ip(self.parent_ids), _dp(self.node_heights),
+                                                       _dp(self.node_bounds), _dp(self.height_ratios), _dp(rt),
+                                                       _dp(bg), int(include_log_det_jacobian), _dp(out))
+        return out

@@ -237,3 +237,48 @@ def test_error_paths(data_dir):
     bad[0, 5] = 0.5
     with pytest.raises(oracle.OracleError, match="rates do not sum"):
         eng.log_likelihoods(tc.parent_id_matrix(), tc.branch_length_matrix(), bad)
+
+
+def test_rooted_tree_example_time_parameterisation():
+    """RootedTree doctest (reference src/rooted_tree.hpp:133-168): exact equality."""
+    g = GOLD["rooted_tree_example"]
+    tt = oracle.TimeTree(g["parent_ids"], g["branch_lengths"], g["tip_dates"])
+    assert list(tt.height_ratios) == g["height_ratios"]
+    assert list(tt.node_heights) == g["node_heights"]
+    assert list(tt.node_bounds) == g["node_bounds"]
+    tt.initialize_time_tree_using_height_ratios(g["new_height_ratios"])
+    assert list(tt.node_heights) == g["new_node_heights"]
+    assert list(tt.branch_lengths[:-1]) == g["new_branch_lengths"]
+    with pytest.raises(RuntimeError):
+        oracle.TimeTree(g["parent_ids"], [2.0, 1.5, 2.0, 1.5, 2.5, 2.5, 0.0], g["tip_dates"])
+
+
+def test_flua_ratio_gradient_and_log_det_jacobian(data_dir):
+    """fluA: log-det-Jacobian and the 68 ratio / root-height gradients
+    (reference src/rooted_sbn_instance.hpp:277-307)."""
+    g = GOLD["flua_time_tree"]
+    tc, sp, rates = _flu(data_dir)
+    dates = treeio.parse_dates_from_taxon_names(tc.taxon_names)
+    tt = oracle.TimeTree(tc.parent_id_matrix()[0], tc.branch_length_matrix()[0], dates)
+    assert abs(tt.log_det_jacobian() - g["log_det_jacobian"]) < 1e-6
+    eng = oracle.OracleEngine("JC69", "constant", "strict", sp.patterns, sp.weights, 1)
+    grads = eng.gradients(tc.parent_id_matrix(), tc.branch_length_matrix(), rates=rates)
+    assert abs(grads["log_likelihood"][0] - g["log_likelihood"]) < g["tol"]
+    ratio = tt.ratio_gradient_of_branch_gradient(grads["branch_lengths"][0], rates[0])
+    assert np.abs(ratio - g["ratios_root_height_gradient"]).max() < g["gradient_tol"]
+    # round trip: ratios -> heights / branch lengths reproduces the tree
+    bl = tt.branch_lengths.copy()
+    tt.initialize_time_tree_using_height_ratios(tt.height_ratios)
+    assert np.abs(tt.branch_lengths[:-1] - bl[:-1]).max() < 1e-4  # the file's branch lengths are rounded
+    # gradient of the log-det-Jacobian agrees with central differences in the ratios
+    base = tt.height_ratios.copy()
+    gj = tt.gradient_log_det_jacobian()
+    for i in (0, 17, len(base) - 1):
+        eps = 1e-6 * max(1.0, abs(base[i]))
+        vals = []
+        for sgn in (1, -1):
+            r = base.copy()
+            r[i] += sgn * eps
+            tt.initialize_time_tree_using_height_ratios(r)
+            vals.append(tt.log_det_jacobian())
+        assert abs((vals[0] - vals[1]) / (2 * eps) - gj[i]) < 1e-5 * max(1.0, abs(gj[i]))
