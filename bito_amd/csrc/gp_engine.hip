@@ -23,6 +23,8 @@ struct bito_amd_gp_engine {
   double threshold = 1e-40, log_threshold = 0;
   double *plv = nullptr, *weights = nullptr, *bl = nullptr, *q = nullptr, *ll = nullptr, *marginal = nullptr;
   double* scratch = nullptr;
+  double *diff = nullptr, *coef = nullptr;  // DAGBranchHandler differences_; per-pattern optimiser coefficients
+  int method = 0, significant_digits = 10, optimization_count = 0;
   int* counts = nullptr;
   bito_amd_gp_op* d_ops = nullptr;
   uint64_t* d_side = nullptr;
@@ -30,7 +32,7 @@ struct bito_amd_gp_engine {
   std::string err;
   ~bito_amd_gp_engine() {
     (void)hipSetDevice(device);
-    for (void* p : {(void*)plv, (void*)weights, (void*)bl, (void*)q, (void*)ll, (void*)marginal, (void*)scratch,
+    for (void* p : {(void*)plv, (void*)weights, (void*)bl, (void*)q, (void*)ll, (void*)marginal, (void*)scratch, (void*)diff, (void*)coef,
                     (void*)counts, (void*)d_ops, (void*)d_side})
       if (p) (void)hipFree(p);
   }
@@ -205,6 +207,232 @@ gp_derivatives_kernel(const double* __restrict__ plv, const int* __restrict__ co
   if (threadIdx.x < 3) out[threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
 }
 
+// ---- OptimizeBranchLength on the device --------------------------------------
+// One workgroup runs the whole one-dimensional optimisation of an edge: the per-pattern
+// likelihood of the edge as a function of its length t is l_p(t) = A_p + B_p exp(lambda t) under
+// JC69 (A, B from the rootward and leafward PLVs through the eigenbasis), so after one pass over
+// the PLVs every function evaluation of Brent / Newton / gradient ascent is a block reduction
+// over 2 doubles per pattern -- no host round trip per evaluation as in the reference
+// (src/dag_branch_handler.cpp:123-300 calling back into GPEngine, src/gp_engine.cpp:603-661).
+// The optimisers restate src/optimization.hpp:71-417; constants from src/dag_branch_handler.hpp:266-295.
+struct OptSettings {
+  int method, significant_digits, check_convergence;
+};
+
+constexpr double kMinLogBl = -13.9, kMaxLogBl = 1.1, kNewtonEps = 1e-10, kStep = 5e-4, kLogStep = 1.0005,
+                 kDiffThreshold = 1e-15;
+constexpr int kOptMaxIter = 1000;
+
+struct EdgeFunction {
+  const double* A;
+  const double* B;
+  const double* weights;
+  double* sh;  // [3][4] block-reduction scratch in LDS
+  double resc;
+  int P;
+
+  // log-likelihood and its first two derivatives in t; every thread of the block gets the values
+  __device__ void operator()(double t, double out[3]) const {
+    const double e = exp(kLam * t);
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+      const double be = B[p] * e;
+      const double l = A[p] + be, d = kLam * be, dd = kLam * kLam * be;
+      const double w = weights[p];
+      a0 += w * log(l);
+      a1 += w * (d / l);
+      a2 += w * ((dd * l - d * d) / (l * l));
+    }
+    double v[3] = {a0, a1, a2};
+    __syncthreads();  // the previous evaluation's readers are done with sh
+    for (int k = 0; k < 3; k++) {
+      for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+      if ((threadIdx.x & 63) == 0) sh[k * 4 + (threadIdx.x >> 6)] = v[k];
+    }
+    __syncthreads();
+    out[0] = sh[0] + sh[1] + sh[2] + sh[3] + resc;
+    out[1] = sh[4] + sh[5] + sh[6] + sh[7];
+    out[2] = sh[8] + sh[9] + sh[10] + sh[11];
+  }
+  __device__ double NegLL(double x) const {  // brent_nongrad_func: x is the LOG branch length
+    double o[3];
+    (*this)(exp(x), o);
+    return -o[0];
+  }
+};
+
+// Optimization::BrentMinimize / BrentMinimizeWithGradients (src/optimization.hpp:71-331)
+__device__ void BrentMinimize(const EdgeFunction& f, bool with_gradients, double guess, double mn, double mx,
+                              int significant_digits, int max_iter, double step_size, double* x_out, double* fx_out) {
+  const double tolerance = ldexp(1.0, 1 - significant_digits);
+  const double golden = 0.3819660f;
+  double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
+  w = v = x = guess;
+  fw = fv = fx = f.NegLL(x);
+  delta2 = delta = 0;
+  int count = max_iter;
+  do {
+    mid = (mn + mx) / 2;
+    fract1 = tolerance * fabs(x) + tolerance / 4;
+    fract2 = 2 * fract1;
+    if (fabs(x - mid) <= (fract2 - (mx - mn) / 2)) break;
+    bool use_bisection = true;
+    if (fabs(delta2) > fract1) {
+      double r = (x - w) * (fx - fv);
+      double q = (x - v) * (fx - fw);
+      double p = (x - v) * q - (x - w) * r;
+      q = 2 * (q - r);
+      if (q > 0) p = -p;
+      q = fabs(q);
+      const double td = delta2;
+      delta2 = delta;
+      if (!(fabs(p) >= fabs(q * td / 2)) && !(p <= q * (mn - x)) && !(p >= q * (mx - x))) {
+        delta = p / q;
+        u = x + delta;
+        if (((u - mn) < fract2) || ((mx - u) < fract2)) delta = (mid - x) < 0 ? -fabs(fract1) : fabs(fract1);
+        use_bisection = false;
+      }
+    }
+    if (use_bisection) {
+      delta2 = (x >= mid) ? mn - x : mx - x;
+      delta = golden * delta2;
+    }
+    u = (fabs(delta) >= fract1) ? x + delta : (delta > 0 ? x + fabs(fract1) : x - fabs(fract1));
+    fu = f.NegLL(u);
+    bool accepted = false;
+    if (fu <= fx) {
+      if (u >= x) mn = x; else mx = x;
+      v = w; w = x; x = u;
+      fv = fw; fw = fx; fx = fu;
+      accepted = true;
+    } else if (with_gradients) {
+      double o[3];
+      const double t = exp(x);
+      f(t, o);
+      const double u2 = x - step_size * (-t * o[1]);
+      const double fu2 = f.NegLL(u2);
+      if (fu2 <= fx) {
+        if (u2 >= x) mn = x; else mx = x;
+        v = w; w = x; x = u2;
+        fv = fw; fw = fx; fx = fu2;
+        accepted = true;
+      }
+    }
+    if (!accepted) {
+      if (u < x) mn = u; else mx = u;
+      if ((fu <= fw) || (w == x)) {
+        v = w; w = u;
+        fv = fw; fw = fu;
+      } else if ((fu <= fv) || (v == x) || (v == w)) {
+        v = u;
+        fv = fu;
+      }
+    }
+  } while (--count);
+  *x_out = x;
+  *fx_out = fx;
+}
+
+__global__ void __launch_bounds__(256)
+gp_optimize_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const double* __restrict__ plv,
+                   const int* __restrict__ counts, const double* __restrict__ weights, double* __restrict__ bl,
+                   double* __restrict__ diff, double* __restrict__ coef, int P, int Ppad, double log_threshold,
+                   OptSettings cfg) {
+  __shared__ double sh[12];
+  __shared__ double sh_resc[4];
+  for (int64_t o = 0; o < op_count; o++) {
+    const bito_amd_gp_op op = ops[o];  // a = leafward_, b = rootward_, c = gpcsp_ (src/gp_operation.hpp:118-127)
+    const uint64_t leafward = op.a, rootward = op.b, edge = op.c;
+    __syncthreads();  // bl / diff writes of the previous op are visible; coef may be overwritten
+    if (cfg.check_convergence && diff[edge] < kDiffThreshold) continue;  // dag_branch_handler.cpp:127-131
+    // eigenbasis coefficients: l_p(t) = sum_k (r^T V)_k (V^-1 x)_k exp(lambda_k t)
+    double resc = 0;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+      double r[4], x[4];
+      for (int i = 0; i < 4; i++) {
+        r[i] = plv[((size_t)rootward * 4 + i) * Ppad + p];
+        x[i] = plv[((size_t)leafward * 4 + i) * Ppad + p];
+      }
+      double c[4];
+      for (int k = 0; k < 4; k++) {
+        const double rv = r[0] * cV[k] + r[1] * cV[4 + k] + r[2] * cV[8 + k] + r[3] * cV[12 + k];
+        const double vx = cVi[k * 4] * x[0] + cVi[k * 4 + 1] * x[1] + cVi[k * 4 + 2] * x[2] + cVi[k * 4 + 3] * x[3];
+        c[k] = rv * vx;
+      }
+      coef[p] = c[0];
+      coef[Ppad + p] = c[1] + c[2] + c[3];
+      resc += weights[p] * ((counts[(size_t)rootward * Ppad + p] + counts[(size_t)leafward * Ppad + p]) * log_threshold);
+    }
+    for (int s = 32; s > 0; s >>= 1) resc += __shfl_xor(resc, s);
+    if ((threadIdx.x & 63) == 0) sh_resc[threadIdx.x >> 6] = resc;
+    __syncthreads();
+    const EdgeFunction f{coef, coef + Ppad, weights, sh, sh_resc[0] + sh_resc[1] + sh_resc[2] + sh_resc[3], P};
+    const double current = bl[edge];
+    double result = current;
+    switch (cfg.method) {
+      case 0:
+      case 1: {  // BrentOptimization(WithGradients), dag_branch_handler.cpp:150-211
+        const double cur_log = log(current);
+        const double cur_nll = f.NegLL(cur_log);
+        double x, fx;
+        BrentMinimize(f, cfg.method == 1, cur_log, kMinLogBl, kMaxLogBl, cfg.significant_digits, kOptMaxIter, kLogStep,
+                      &x, &fx);
+        result = fx > cur_nll ? exp(cur_log) : exp(x);
+        break;
+      }
+      case 2: {  // GradientAscent (optimization.hpp:333-347); the floor is the handler's min LOG length, as there
+        const double tolerance = pow(10.0, -cfg.significant_digits);
+        double x = current;
+        for (int iter = 0;; iter++) {
+          double v[3];
+          f(x, v);
+          x = fmax(x + v[1] * kStep, kMinLogBl);
+          if (fabs(v[1]) < fabs(v[0]) * tolerance || iter >= kOptMaxIter) break;
+        }
+        result = x;
+        break;
+      }
+      case 3: {  // LogSpaceGradientAscent (optimization.hpp:349-367)
+        const double tolerance = pow(10.0, -cfg.significant_digits), min_x = exp(kMinLogBl);
+        double x = current;
+        for (int iter = 0;; iter++) {
+          double v[3];
+          const double y = log(x);
+          f(x, v);
+          x = fmax(exp(y + x * v[1] * kLogStep), min_x);
+          if (fabs(v[1]) < fabs(v[0]) * tolerance || iter >= kOptMaxIter) break;
+        }
+        result = x;
+        break;
+      }
+      default: {  // NewtonRaphsonOptimization in the log length (optimization.hpp:369-405, gp_engine.cpp:643-655)
+        const double tolerance = pow(10.0, -cfg.significant_digits);
+        double x = log(current);
+        for (int iter = 0;; iter++) {
+          double v[3];
+          const double t = exp(x);
+          f(t, v);
+          const double f1 = t * v[1], f2 = f1 + t * t * v[2];
+          if (fabs(f2) < kNewtonEps) break;
+          double new_x = x - f1 / f2;
+          if (new_x < kMinLogBl) new_x = x - 0.5 * (x - kMinLogBl);
+          if (new_x > kMaxLogBl) new_x = x - 0.5 * (x - kMaxLogBl);
+          const double delta = fabs(x - new_x);
+          if (delta < tolerance || fabs(f1) < fabs(v[0]) * tolerance || iter == kOptMaxIter) break;
+          x = new_x;
+        }
+        result = exp(x);
+        break;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      bl[edge] = result;
+      diff[edge] = fabs(current - result);
+    }
+  }
+}
+
 int Fail(bito_amd_gp_engine* e, int code, const std::string& msg) {
   e->err = msg;
   return code;
@@ -216,17 +444,19 @@ int Fail(bito_amd_gp_engine* e, int code, const std::string& msg) {
     if (rc_ != hipSuccess) return Fail(e, BITO_AMD_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(rc_)); \
   } while (0)
 
-int RunSegment(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t count) {
+// the op stream is resident in d_ops; a segment is [first, first + count)
+int RunSegment(bito_amd_gp_engine* e, int64_t first, int64_t count) {
   if (count <= 0) return BITO_AMD_OK;
-  if ((size_t)count > e->ops_cap) {
-    if (e->d_ops) (void)hipFree(e->d_ops);
-    e->ops_cap = 0;
-    GP_TRY(e, hipMalloc((void**)&e->d_ops, count * sizeof(bito_amd_gp_op)));
-    e->ops_cap = count;
-  }
-  GP_TRY(e, hipMemcpy(e->d_ops, ops, count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64), dim3(64), 0, 0, e->d_ops, count, e->d_side, e->plv,
+  hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64), dim3(64), 0, 0, e->d_ops + first, count, e->d_side, e->plv,
                      e->counts, e->bl, e->q, e->ll, e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
+  GP_TRY(e, hipGetLastError());
+  return BITO_AMD_OK;
+}
+
+int RunOptimize(bito_amd_gp_engine* e, int64_t first, int64_t count) {
+  const OptSettings cfg{e->method, e->significant_digits, e->optimization_count != 0};  // !IsFirstOptimization()
+  hipLaunchKernelGGL(gp_optimize_kernel, dim3(1), dim3(256), 0, 0, e->d_ops + first, count, e->plv, e->counts,
+                     e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, cfg);
   GP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
 }
@@ -265,6 +495,8 @@ int bito_amd_gp_create(int32_t device_id, int32_t taxon_count, int32_t pattern_c
             hipMalloc((void**)&e->ll, (size_t)gpcsp_count * e->Ppad * sizeof(double)) == hipSuccess &&
             hipMalloc((void**)&e->marginal, e->Ppad * sizeof(double)) == hipSuccess &&
             hipMalloc((void**)&e->scratch, (size_t)(gpcsp_count + 4) * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&e->diff, gpcsp_count * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&e->coef, (size_t)2 * e->Ppad * sizeof(double)) == hipSuccess &&
             hipMalloc((void**)&e->d_side, sizeof(uint64_t)) == hipSuccess;
   if (!ok) { delete e; return report(BITO_AMD_ERR_DEVICE, "hipMalloc failed for the PLV arena"); }
   e->side_cap = 1;
@@ -272,6 +504,7 @@ int bito_amd_gp_create(int32_t device_id, int32_t taxon_count, int32_t pattern_c
   (void)hipMemset(e->counts, 0, (size_t)e->plvs * e->Ppad * sizeof(int));
   (void)hipMemset(e->ll, 0, (size_t)gpcsp_count * e->Ppad * sizeof(double));
   (void)hipMemset(e->marginal, 0, e->Ppad * sizeof(double));
+  (void)hipMemset(e->diff, 0, gpcsp_count * sizeof(double));  // init_default_difference_ (dag_branch_handler.hpp:269)
   // InitializePLVsWithSitePatterns: leaf P-PLVs (type 0): one-hot, all ones for a gap
   std::vector<double> leaf((size_t)taxon_count * 4 * e->Ppad, 0.0);
   for (int t = 0; t < taxon_count; t++)
@@ -315,6 +548,35 @@ int bito_amd_gp_get_sbn_parameters(bito_amd_gp_engine* e, double* out) {
   if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
   GP_TRY(e, hipSetDevice(e->device));
   GP_TRY(e, hipMemcpy(out, e->q, e->gpcsps * sizeof(double), hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_get_branch_length_differences(bito_amd_gp_engine* e, double* out) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  GP_TRY(e, hipMemcpy(out, e->diff, e->gpcsps * sizeof(double), hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+int bito_amd_gp_set_optimization_method(bito_amd_gp_engine* e, int32_t method) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  if (method < 0 || method > 4)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "DAGBranchHandler::Optimization(): Invalid OptimizationMethod given.");
+  e->method = method;
+  return BITO_AMD_OK;
+}
+int bito_amd_gp_set_significant_digits_for_optimization(bito_amd_gp_engine* e, int32_t digits) {
+  if (!e || digits < 1) return BITO_AMD_ERR_BAD_ARG;
+  e->significant_digits = digits;
+  return BITO_AMD_OK;
+}
+int bito_amd_gp_reset_optimization_count(bito_amd_gp_engine* e) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  e->optimization_count = 0;
+  return BITO_AMD_OK;
+}
+int bito_amd_gp_increment_optimization_count(bito_amd_gp_engine* e) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  e->optimization_count++;
   return BITO_AMD_OK;
 }
 
@@ -367,10 +629,7 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
         ok = plv_ok(op.a) && op.count > 0 && side && op.b + op.count <= (uint64_t)side_count;
         for (uint32_t k = 0; ok && k < op.count; k++) ok = plv_ok(side[op.b + k]);
         break;
-      case BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH:
-        return Fail(e, BITO_AMD_ERR_BAD_ARG,
-                    "OptimizeBranchLength is not executed on the device: drive the optimiser on the host with "
-                    "bito_amd_gp_log_likelihood_and_first_two_derivatives (SURVEY 8f row f1)");
+      case BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH: ok = plv_ok(op.a) && plv_ok(op.b) && gp_ok(op.c); break;
       default:
         return Fail(e, BITO_AMD_ERR_BAD_ARG, "unknown GP opcode " + std::to_string(op.opcode));
     }
@@ -385,12 +644,31 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
     }
     GP_TRY(e, hipMemcpy(e->d_side, side, side_count * sizeof(uint64_t), hipMemcpyHostToDevice));
   }
+  if ((size_t)op_count > e->ops_cap) {
+    if (e->d_ops) (void)hipFree(e->d_ops);
+    e->ops_cap = 0;
+    GP_TRY(e, hipMalloc((void**)&e->d_ops, op_count * sizeof(bito_amd_gp_op)));
+    e->ops_cap = op_count;
+  }
+  if (op_count > 0) GP_TRY(e, hipMemcpy(e->d_ops, ops, op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
+  // Segments: runs of per-pattern ops are one launch each; a run of OptimizeBranchLength ops is one
+  // single-workgroup launch (they couple the patterns through the reductions); UpdateSBNProbabilities
+  // is a host step.  Everything is issued in stream order, so the sequential semantics hold.
   int64_t start = 0;
   for (int64_t o = 0; o <= op_count; o++) {
-    const bool boundary = o == op_count || ops[o].opcode == BITO_AMD_GP_UPDATE_SBN_PROBABILITIES;
+    const bool is_opt = o < op_count && ops[o].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH;
+    const bool boundary = o == op_count || is_opt || ops[o].opcode == BITO_AMD_GP_UPDATE_SBN_PROBABILITIES;
     if (!boundary) continue;
-    int rc = RunSegment(e, ops + start, o - start);
+    int rc = RunSegment(e, start, o - start);
     if (rc) return rc;
+    if (is_opt) {
+      int64_t end = o;
+      while (end < op_count && ops[end].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH) end++;
+      if ((rc = RunOptimize(e, o, end - o))) return rc;
+      start = end;
+      o = end - 1;
+      continue;
+    }
     if (o < op_count) {
       // UpdateSBNProbabilities (src/gp_engine.cpp:297-321): softmax over sibling GPCSPs of the
       // weighted per-GPCSP log-likelihood plus the log prior.

@@ -122,19 +122,93 @@ class SingleTreeDAG:
             left, right = self.children[node]
             for child, is_left in ((left, True), (right, False)):
                 s.add(LIKELIHOOD, self.edge(child), self.pv(R_LEFT if is_left else R_RIGHT, node), self.pv(P, child))
+        s.extend(self.marginal_likelihood())
+        return s
+
+    def marginal_likelihood(self) -> OpStream:
+        """GPDAG::MarginalLikelihood (src/gp_dag.cpp:201-211)."""
+        s = OpStream()
         s.add(RESET_MARGINAL_LIKELIHOOD)
         s.add(INCREMENT_MARGINAL_LIKELIHOOD, self.pv(RHAT, self.root), 0, self.pv(P, self.root))
         return s
 
+    # -- GPDAG::BranchLengthOptimization (src/gp_dag.cpp:126-175) over the tidy depth-first
+    #    traversal (src/tidy_subsplit_dag.hpp:82-173).  In the DAG of one tree a modification
+    #    below one clade never dirties the sister clade, so the traversal never enters its
+    #    "updating" mode and reduces to the recursion below.
+    def branch_length_optimization(self, edges_to_optimize=None) -> OpStream:
+        s = OpStream()
+
+        def visit(node: int):
+            if node != self.root:  # BeforeNode: UpdateRHat (src/gp_dag.cpp:349-363)
+                parent, is_left = self.parent[node]
+                src = self.pv(R_LEFT if is_left else R_RIGHT, parent)
+                s.add(ZERO_PLV, self.pv(RHAT, node))
+                s.prep_for_marginalization(self.pv(RHAT, node), [src])
+                s.add(INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, self.pv(RHAT, node), self.edge(node), src)
+            left, right = self.children[node]
+            for child, is_left in ((left, True), (right, False)):
+                # BeforeNodeClade: RUpdateOfRotated (src/gp_dag.cpp:17-24), then zero the p-hat
+                if is_left:
+                    s.add(MULTIPLY, self.pv(R_LEFT, node), self.pv(RHAT, node), self.pv(PHAT_RIGHT, node))
+                else:
+                    s.add(MULTIPLY, self.pv(R_RIGHT, node), self.pv(RHAT, node), self.pv(PHAT_LEFT, node))
+                phat = self.pv(PHAT_LEFT if is_left else PHAT_RIGHT, node)
+                s.add(ZERO_PLV, phat)
+                if child in self.children:
+                    visit(child)
+                # ModifyEdge: OptimizeBranchLengthUpdatePHat (src/gp_dag.cpp:386-405)
+                if edges_to_optimize is None or self.edge(child) in edges_to_optimize:
+                    s.add(OPTIMIZE_BRANCH_LENGTH, self.pv(P, child), self.pv(R_LEFT if is_left else R_RIGHT, node),
+                          self.edge(child))
+                s.prep_for_marginalization(phat, [self.pv(P, child)])
+                s.add(INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, phat, self.edge(child), self.pv(P, child))
+            # AfterNode
+            s.add(MULTIPLY, self.pv(P, node), self.pv(PHAT_RIGHT, node), self.pv(PHAT_LEFT, node))
+
+        visit(self.root)
+        return s
+
+
+# OptimizationMethod (reference src/optimization.hpp:28-34)
+BRENT, BRENT_WITH_GRADIENTS, GRADIENT_ASCENT, LOGSPACE_GRADIENT_ASCENT, NEWTON = range(5)
+
+
+def estimate_branch_lengths(engine, dag: "SingleTreeDAG", tol: float, max_iter: int, method=None) -> int:
+    """``GPInstance::EstimateBranchLengths`` (reference src/gp_instance.cpp:241-300): sweeps of
+    BranchLengthOptimization + PopulatePLVs + MarginalLikelihood until the mean absolute change
+    of the branch lengths drops below ``tol``.  Works with any engine exposing the GPEngine
+    mirror's methods; returns the number of sweeps."""
+    if method is not None:
+        engine.set_optimization_method(method)
+    engine.reset_optimization_count()
+    optimize, populate, marginal = dag.branch_length_optimization(), dag.populate_plvs(), dag.marginal_likelihood()
+    engine.process_operations(populate)
+    engine.process_operations(marginal)
+    sweeps = 0
+    for _ in range(max_iter):
+        engine.process_operations(optimize)
+        engine.process_operations(populate)
+        engine.process_operations(marginal)
+        sweeps += 1
+        if float(np.mean(engine.get_branch_length_differences())) < tol:
+            break
+        engine.increment_optimization_count()
+    return sweeps
+
 
 def single_tree_dag(parent_ids: Sequence[int]) -> SingleTreeDAG:
+    """Left ("rotated") clade of a subsplit = the clade holding the smaller taxon id
+    (Bitset::SubsplitFromUnorderedClades / CladeCompare, reference src/bitset.cpp:268-272,326-331)."""
     parent_ids = [int(x) for x in parent_ids]
     node_count = len(parent_ids) + 1
     n = (node_count + 1) // 2
     kids: Dict[int, List[int]] = {}
-    for child, p in enumerate(parent_ids):
+    min_taxon = list(range(n)) + [node_count] * (node_count - n)
+    for child, p in enumerate(parent_ids):  # ids are a post-order: children before parents
         kids.setdefault(p, []).append(child)
-    children = {k: (v[0], v[1]) for k, v in kids.items()}
+        min_taxon[p] = min(min_taxon[p], min_taxon[child])
+    children = {k: tuple(sorted(v, key=lambda c: min_taxon[c])) for k, v in kids.items()}
     parent = {}
     for k, (left, right) in children.items():
         parent[left] = (k, True)
@@ -150,7 +224,9 @@ GP_SYMBOLS = [
     "bito_amd_gp_get_branch_lengths", "bito_amd_gp_set_sbn_parameters", "bito_amd_gp_get_sbn_parameters",
     "bito_amd_gp_process_operations", "bito_amd_gp_log_marginal_likelihood",
     "bito_amd_gp_per_gpcsp_log_likelihoods", "bito_amd_gp_log_likelihood_matrix",
-    "bito_amd_gp_log_likelihood_and_first_two_derivatives",
+    "bito_amd_gp_log_likelihood_and_first_two_derivatives", "bito_amd_gp_get_branch_length_differences",
+    "bito_amd_gp_set_optimization_method", "bito_amd_gp_set_significant_digits_for_optimization",
+    "bito_amd_gp_reset_optimization_count", "bito_amd_gp_increment_optimization_count",
 ]
 
 
@@ -164,8 +240,13 @@ def _lib():
         L.bito_amd_gp_destroy.argtypes = [vp]
         L.bito_amd_gp_last_error.restype = C.c_char_p
         L.bito_amd_gp_last_error.argtypes = [vp]
+        L.bito_amd_gp_set_optimization_method.argtypes = [vp, C.c_int32]
+        L.bito_amd_gp_set_significant_digits_for_optimization.argtypes = [vp, C.c_int32]
+        L.bito_amd_gp_reset_optimization_count.argtypes = [vp]
+        L.bito_amd_gp_increment_optimization_count.argtypes = [vp]
         for name in ("set_branch_lengths", "get_branch_lengths", "set_sbn_parameters", "get_sbn_parameters",
-                     "per_gpcsp_log_likelihoods", "log_likelihood_matrix", "log_marginal_likelihood"):
+                     "per_gpcsp_log_likelihoods", "log_likelihood_matrix", "log_marginal_likelihood",
+                     "get_branch_length_differences"):
             getattr(L, f"bito_amd_gp_{name}").argtypes = [vp, dp]
         L.bito_amd_gp_process_operations.argtypes = [vp, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.bito_amd_gp_log_likelihood_and_first_two_derivatives.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, dp]
@@ -213,6 +294,21 @@ class GPEngine:
 
     def get_branch_lengths(self):
         return self._vec(_lib().bito_amd_gp_get_branch_lengths, self.gpcsp_count)
+
+    def get_branch_length_differences(self):
+        return self._vec(_lib().bito_amd_gp_get_branch_length_differences, self.gpcsp_count)
+
+    def set_optimization_method(self, method: int):
+        self._check(_lib().bito_amd_gp_set_optimization_method(self._h, int(method)))
+
+    def set_significant_digits_for_optimization(self, digits: int):
+        self._check(_lib().bito_amd_gp_set_significant_digits_for_optimization(self._h, int(digits)))
+
+    def reset_optimization_count(self):
+        self._check(_lib().bito_amd_gp_reset_optimization_count(self._h))
+
+    def increment_optimization_count(self):
+        self._check(_lib().bito_amd_gp_increment_optimization_count(self._h))
 
     def set_sbn_parameters(self, q):
         q = np.ascontiguousarray(q, dtype=np.float64)

@@ -26,7 +26,7 @@ enum {
   BITO_AMD_GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV = 2, /* a = dest, b = gpcsp, c = src */
   BITO_AMD_GP_MULTIPLY = 3,                            /* a = dest, b = src1, c = src2 */
   BITO_AMD_GP_LIKELIHOOD = 4,                          /* a = dest gpcsp, b = child_, c = parent_ */
-  BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH = 5,              /* not executed here: host-side optimiser (row f1) */
+  BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH = 5,              /* a = leafward_, b = rootward_, c = gpcsp_ */
   BITO_AMD_GP_UPDATE_SBN_PROBABILITIES = 6,            /* a = start, b = stop */
   BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD = 7,
   BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD = 8,       /* a = stationary_times_prior, b = rootsplit, c = p */
@@ -55,9 +55,28 @@ int bito_amd_gp_get_branch_lengths(bito_amd_gp_engine *e, double *out);
 int bito_amd_gp_set_sbn_parameters(bito_amd_gp_engine *e, const double *q);
 int bito_amd_gp_get_sbn_parameters(bito_amd_gp_engine *e, double *out);
 
+/* DAGBranchHandler state behind GPEngine (src/gp_engine.hpp:103-121, src/dag_branch_handler.hpp:40-60):
+ * GetBranchLengthDifferences out[gpcsp_count]; SetOptimizationMethod with the values of
+ * Optimization::OptimizationMethod (src/optimization.hpp:28-34): 0 Brent, 1 Brent with gradients,
+ * 2 gradient ascent, 3 log-space gradient ascent, 4 Newton; SetSignificantDigitsForOptimization;
+ * Reset/IncrementOptimizationCount (the first sweep skips the per-edge convergence test). */
+#define BITO_AMD_GP_OPT_BRENT 0
+#define BITO_AMD_GP_OPT_BRENT_WITH_GRADIENTS 1
+#define BITO_AMD_GP_OPT_GRADIENT_ASCENT 2
+#define BITO_AMD_GP_OPT_LOGSPACE_GRADIENT_ASCENT 3
+#define BITO_AMD_GP_OPT_NEWTON 4
+int bito_amd_gp_get_branch_length_differences(bito_amd_gp_engine *e, double *out);
+int bito_amd_gp_set_optimization_method(bito_amd_gp_engine *e, int32_t method);
+int bito_amd_gp_set_significant_digits_for_optimization(bito_amd_gp_engine *e, int32_t digits);
+int bito_amd_gp_reset_optimization_count(bito_amd_gp_engine *e);
+int bito_amd_gp_increment_optimization_count(bito_amd_gp_engine *e);
+
 /* GPEngine::ProcessOperations (src/gp_engine.hpp:74).  Every op except UpdateSBNProbabilities is
  * independent across site patterns, so a run of such ops is ONE kernel (one thread per pattern
- * interprets the stream); an UpdateSBNProbabilities op ends the run. */
+ * interprets the stream); an UpdateSBNProbabilities op ends the run.  OptimizeBranchLength
+ * (GPEngine::OptimizeBranchLength, src/gp_engine.cpp:663-666 -> DAGBranchHandler::OptimizeBranchLength,
+ * src/dag_branch_handler.cpp:123-300) runs the whole one-dimensional optimisation of the edge in one
+ * single-workgroup launch: no host round trip per function evaluation. */
 int bito_amd_gp_process_operations(bito_amd_gp_engine *e, const bito_amd_gp_op *ops, int64_t op_count,
                                    const uint64_t *side, int64_t side_count);
 

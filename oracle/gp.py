@@ -29,6 +29,12 @@ def lib():
         L.gp_oracle_per_gpcsp_log_likelihoods.argtypes = [vp, dp]
         L.gp_oracle_derivatives.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, dp]
         L.gp_oracle_transition_matrix.argtypes = [C.c_double, dp]
+        L.gp_oracle_get_branch_lengths.argtypes = [vp, dp]
+        L.gp_oracle_get_branch_length_differences.argtypes = [vp, dp]
+        L.gp_oracle_set_optimization_method.argtypes = [vp, C.c_int]
+        L.gp_oracle_set_significant_digits.argtypes = [vp, C.c_int]
+        L.gp_oracle_reset_optimization_count.argtypes = [vp]
+        L.gp_oracle_increment_optimization_count.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -51,6 +57,28 @@ class OracleGPEngine:
     def set_branch_lengths(self, bl):
         bl = np.ascontiguousarray(bl, dtype=np.float64)
         lib().gp_oracle_set_branch_lengths(self._h, bl.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def get_branch_lengths(self):
+        out = np.zeros(self.gpcsp_count)
+        lib().gp_oracle_get_branch_lengths(self._h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def get_branch_length_differences(self):
+        out = np.zeros(self.gpcsp_count)
+        lib().gp_oracle_get_branch_length_differences(self._h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def set_optimization_method(self, method: int):
+        lib().gp_oracle_set_optimization_method(self._h, int(method))
+
+    def set_significant_digits_for_optimization(self, digits: int):
+        lib().gp_oracle_set_significant_digits(self._h, int(digits))
+
+    def reset_optimization_count(self):
+        lib().gp_oracle_reset_optimization_count(self._h)
+
+    def increment_optimization_count(self):
+        lib().gp_oracle_increment_optimization_count(self._h)
 
     def set_sbn_parameters(self, q):
         q = np.ascontiguousarray(q, dtype=np.float64)

@@ -9,8 +9,12 @@
  * by powers of the threshold (src/gp_engine.cpp:564-601), per-edge log-likelihood matrix,
  * log-add marginal over rootsplits (src/numerical_utils.hpp:35-52).
  *
+ * OptimizeBranchLength restates the five one-dimensional optimisers of
+ * src/optimization.hpp:71-417 as DAGBranchHandler drives them
+ * (src/dag_branch_handler.cpp:123-300, src/gp_engine.cpp:603-661).
+ *
  * Parity status: PINNED by tests/test_gp.py against the reference's known answers for this
- * path (src/gp_doctest.cpp:119-131,257-308; src/gp_engine.hpp:382-393).
+ * path (src/gp_doctest.cpp:119-131,257-346; src/gp_engine.hpp:382-393).
  */
 #include <math.h>
 #include <stdint.h>
@@ -44,7 +48,19 @@ typedef struct {
   double *bl, *q;    /* [gpcsp_count] */
   double *ll;        /* [gpcsp_count][P] */
   double *marginal;  /* [P] */
+  /* DAGBranchHandler state (src/dag_branch_handler.hpp:255-296) */
+  double *diff;      /* [gpcsp_count] branch length differences of the last optimisation */
+  int method;        /* OptimizationMethod, src/optimization.hpp:28-34 */
+  int opt_count;     /* optimization_count_ */
+  int significant_digits;
 } gp_oracle;
+
+enum { OPT_BRENT = 0, OPT_BRENT_WITH_GRADIENTS = 1, OPT_GRADIENT_ASCENT = 2, OPT_LOGSPACE_GRADIENT_ASCENT = 3,
+       OPT_NEWTON = 4 };
+/* src/dag_branch_handler.hpp:266-295 */
+static const double kMinLogBl = -13.9, kMaxLogBl = 1.1, kNewtonEps = 1e-10, kStep = 5e-4, kLogStep = 1.0005,
+                    kDiffThreshold = 1e-15;
+static const int kMaxIter = 1000;
 
 /* JC69 eigensystem exactly as the reference builds it (src/substitution_model.cpp:20-26,
  * src/gp_engine.cpp:341-364). */
@@ -86,6 +102,10 @@ gp_oracle *gp_oracle_create(int taxon_count, int pattern_count, const int *patte
   for (int i = 0; i < gpcsp_count; i++) g->q[i] = 1.0;
   g->ll = (double *)calloc((size_t)gpcsp_count * pattern_count, sizeof(double));
   g->marginal = (double *)calloc(pattern_count, sizeof(double));
+  g->diff = (double *)calloc(gpcsp_count, sizeof(double));
+  g->method = OPT_BRENT; /* GPEngine default: UseGradientOptimization(false) */
+  g->opt_count = 0;
+  g->significant_digits = 10;
   /* InitializePLVsWithSitePatterns (src/gp_engine.cpp:544-562): leaf P-PLVs (type 0) */
   for (int t = 0; t < taxon_count; t++)
     for (int p = 0; p < pattern_count; p++) {
@@ -98,7 +118,7 @@ gp_oracle *gp_oracle_create(int taxon_count, int pattern_count, const int *patte
 
 void gp_oracle_destroy(gp_oracle *g) {
   if (!g) return;
-  free(g->plv); free(g->counts); free(g->weights); free(g->bl); free(g->q); free(g->ll); free(g->marginal);
+  free(g->plv); free(g->counts); free(g->weights); free(g->bl); free(g->q); free(g->ll); free(g->marginal); free(g->diff);
   free(g);
 }
 
@@ -139,6 +159,8 @@ static double bilinear(const double *r, const double *M, const double *p) {
   for (int i = 0; i < 4; i++) s += r[i] * (M[i * 4] * p[0] + M[i * 4 + 1] * p[1] + M[i * 4 + 2] * p[2] + M[i * 4 + 3] * p[3]);
   return s;
 }
+
+static void optimize_branch_length(gp_oracle *g, int edge, uint64_t rootward, uint64_t leafward);
 
 int gp_oracle_process(gp_oracle *g, const gp_op *ops, int op_count, const uint64_t *side) {
   const int P = g->P;
@@ -228,8 +250,11 @@ int gp_oracle_process(gp_oracle *g, const gp_op *ops, int op_count, const uint64
         g->counts[op->a] = mn;
         break;
       }
+      case GP_OPTIMIZE_BRANCH_LENGTH: /* a = leafward_, b = rootward_, c = gpcsp_ (src/gp_operation.hpp:118-127) */
+        optimize_branch_length(g, (int)op->c, op->b, op->a);
+        break;
       default:
-        return -3; /* OptimizeBranchLength: host-side optimiser, not part of this oracle */
+        return -3;
     }
   }
   return 0;
@@ -270,3 +295,186 @@ void gp_oracle_derivatives(gp_oracle *g, int gpcsp, uint64_t rootward, uint64_t 
 }
 
 void gp_oracle_transition_matrix(double t, double *P16) { matrices(t, P16, NULL, NULL); }
+
+void gp_oracle_get_branch_lengths(const gp_oracle *g, double *out) { memcpy(out, g->bl, sizeof(double) * g->gpcsp_count); }
+void gp_oracle_get_branch_length_differences(const gp_oracle *g, double *out) {
+  memcpy(out, g->diff, sizeof(double) * g->gpcsp_count);
+}
+void gp_oracle_set_optimization_method(gp_oracle *g, int method) { g->method = method; }
+void gp_oracle_set_significant_digits(gp_oracle *g, int digits) { g->significant_digits = digits; }
+void gp_oracle_reset_optimization_count(gp_oracle *g) { g->opt_count = 0; }
+void gp_oracle_increment_optimization_count(gp_oracle *g) { g->opt_count++; }
+
+/* ---- branch-length optimisation ----------------------------------------------------------- */
+
+typedef struct {
+  gp_oracle *g;
+  int edge;
+  uint64_t rootward, leafward;
+} opt_ctx;
+
+/* log-likelihood (and derivatives) of one edge at branch length t; does not touch g->bl */
+static void eval_at(const opt_ctx *c, double t, double out[3]) {
+  const double keep = c->g->bl[c->edge];
+  c->g->bl[c->edge] = t;
+  gp_oracle_derivatives(c->g, c->edge, c->rootward, c->leafward, out);
+  c->g->bl[c->edge] = keep;
+}
+
+/* brent_nongrad_func / brent_grad_func (src/gp_engine.cpp:605-625): x is the LOG branch length */
+static double neg_ll(const opt_ctx *c, double x) {
+  double o[3];
+  eval_at(c, exp(x), o);
+  return -o[0];
+}
+static void neg_ll_and_derivative(const opt_ctx *c, double x, double *f, double *df) {
+  double o[3];
+  const double t = exp(x);
+  eval_at(c, t, o);
+  *f = -o[0];
+  *df = -t * o[1];
+}
+
+/* Optimization::BrentMinimize / BrentMinimizeWithGradients (src/optimization.hpp:71-331) */
+static void brent_minimize(const opt_ctx *c, int with_gradients, double guess, double min, double max,
+                           int significant_digits, int max_iter, double step_size, double *x_out, double *fx_out) {
+  const double tolerance = ldexp(1.0, 1 - significant_digits);
+  const double golden = 0.3819660f;
+  double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
+  w = v = x = guess;
+  fw = fv = fx = neg_ll(c, x);
+  delta2 = delta = 0;
+  int count = max_iter;
+  do {
+    mid = (min + max) / 2;
+    fract1 = tolerance * fabs(x) + tolerance / 4;
+    fract2 = 2 * fract1;
+    if (fabs(x - mid) <= (fract2 - (max - min) / 2)) break;
+    int use_bisection = 1;
+    if (fabs(delta2) > fract1) {
+      double r = (x - w) * (fx - fv);
+      double q = (x - v) * (fx - fw);
+      double p = (x - v) * q - (x - w) * r;
+      q = 2 * (q - r);
+      if (q > 0) p = -p;
+      q = fabs(q);
+      const double td = delta2;
+      delta2 = delta;
+      if (!(fabs(p) >= fabs(q * td / 2)) && !(p <= q * (min - x)) && !(p >= q * (max - x))) {
+        delta = p / q;
+        u = x + delta;
+        if (((u - min) < fract2) || ((max - u) < fract2)) delta = (mid - x) < 0 ? -fabs(fract1) : fabs(fract1);
+        use_bisection = 0;
+      }
+    }
+    if (use_bisection) {
+      delta2 = (x >= mid) ? min - x : max - x;
+      delta = golden * delta2;
+    }
+    u = (fabs(delta) >= fract1) ? x + delta : (delta > 0 ? x + fabs(fract1) : x - fabs(fract1));
+    fu = neg_ll(c, u);
+    int accepted = 0;
+    if (fu <= fx) {
+      if (u >= x) min = x; else max = x;
+      v = w; w = x; x = u;
+      fv = fw; fw = fx; fx = fu;
+      accepted = 1;
+    } else if (with_gradients) {
+      double f0, df;
+      neg_ll_and_derivative(c, x, &f0, &df);
+      const double u2 = x - step_size * df;
+      const double fu2 = neg_ll(c, u2);
+      if (fu2 <= fx) {
+        if (u2 >= x) min = x; else max = x;
+        v = w; w = x; x = u2;
+        fv = fw; fw = fx; fx = fu2;
+        accepted = 1;
+      }
+    }
+    if (!accepted) {
+      if (u < x) min = u; else max = u;
+      if ((fu <= fw) || (w == x)) {
+        v = w; w = u;
+        fv = fw; fw = fu;
+      } else if ((fu <= fv) || (v == x) || (v == w)) {
+        v = u;
+        fv = fu;
+      }
+    }
+  } while (--count);
+  *x_out = x;
+  *fx_out = fx;
+}
+
+/* DAGBranchHandler::OptimizeBranchLength (src/dag_branch_handler.cpp:123-300) */
+static void optimize_branch_length(gp_oracle *g, int edge, uint64_t rootward, uint64_t leafward) {
+  const int check_convergence = g->opt_count != 0; /* !IsFirstOptimization() */
+  if (check_convergence && g->diff[edge] < kDiffThreshold) return;
+  opt_ctx c = {g, edge, rootward, leafward};
+  const double current = g->bl[edge];
+  switch (g->method) {
+    case OPT_BRENT:
+    case OPT_BRENT_WITH_GRADIENTS: {
+      const double cur_log = log(current);
+      const double cur_nll = neg_ll(&c, cur_log);
+      double x, fx;
+      brent_minimize(&c, g->method == OPT_BRENT_WITH_GRADIENTS, cur_log, kMinLogBl, kMaxLogBl, g->significant_digits,
+                     kMaxIter, kLogStep, &x, &fx);
+      g->bl[edge] = fx > cur_nll ? exp(cur_log) : exp(x);
+      g->diff[edge] = fabs(exp(cur_log) - g->bl[edge]);
+      break;
+    }
+    case OPT_GRADIENT_ASCENT: { /* Optimization::GradientAscent (optimization.hpp:333-347); min_x is the
+                                   handler's min LOG branch length, as the reference passes it */
+      const double tolerance = pow(10, -g->significant_digits);
+      double x = current;
+      for (int iter = 0;; iter++) {
+        double o[3];
+        eval_at(&c, x, o);
+        const double new_x = x + o[1] * kStep;
+        x = new_x > kMinLogBl ? new_x : kMinLogBl;
+        if (fabs(o[1]) < fabs(o[0]) * tolerance || iter >= kMaxIter) break;
+      }
+      g->bl[edge] = x;
+      g->diff[edge] = fabs(current - x);
+      break;
+    }
+    case OPT_LOGSPACE_GRADIENT_ASCENT: { /* optimization.hpp:349-367 */
+      const double tolerance = pow(10, -g->significant_digits), min_x = exp(kMinLogBl);
+      double x = current;
+      for (int iter = 0;; iter++) {
+        double o[3];
+        const double y = log(x);
+        eval_at(&c, x, o);
+        const double new_x = exp(y + x * o[1] * kLogStep);
+        x = new_x > min_x ? new_x : min_x;
+        if (fabs(o[1]) < fabs(o[0]) * tolerance || iter >= kMaxIter) break;
+      }
+      g->bl[edge] = x;
+      g->diff[edge] = fabs(current - x);
+      break;
+    }
+    case OPT_NEWTON: { /* optimization.hpp:369-405 in the log branch length (gp_engine.cpp:643-655) */
+      const double tolerance = pow(10, -g->significant_digits);
+      double x = log(current);
+      for (int iter = 0;; iter++) {
+        double o[3];
+        const double t = exp(x);
+        eval_at(&c, t, o);
+        const double f1 = t * o[1], f2 = f1 + t * t * o[2];
+        if (fabs(f2) < kNewtonEps) break;
+        double new_x = x - f1 / f2;
+        if (new_x < kMinLogBl) new_x = x - 0.5 * (x - kMinLogBl);
+        if (new_x > kMaxLogBl) new_x = x - 0.5 * (x - kMaxLogBl);
+        const double delta = fabs(x - new_x);
+        if (delta < tolerance || fabs(f1) < fabs(o[0]) * tolerance || iter == kMaxIter) break;
+        x = new_x;
+      }
+      g->bl[edge] = exp(x);
+      g->diff[edge] = fabs(current - g->bl[edge]);
+      break;
+    }
+    default:
+      break;
+  }
+}
