@@ -1,0 +1,216 @@
+"""Subsplit DAG of a set of rooted trees and the GPDAG schedules over it.
+
+Host-side mirror of what the generalized-pruning executor consumes: the reference builds a
+``SubsplitDAG`` from the loaded topologies (src/subsplit_dag.cpp:16-60,1085-1140) and ``GPDAG``
+turns traversals of it into ``GPOperation`` streams (src/gp_dag.cpp:177-411).  No arithmetic
+happens here -- the streams are executed on the GPU through ``bito_amd.gp.GPEngine``.
+
+Conventions (chosen here; what the executor sees is only ids):
+  * a clade is an int bit mask, bit t = taxon t; a subsplit is (left, right) with the left
+    ("rotated") clade the one holding the smaller taxon id (Bitset::SubsplitFromUnorderedClades,
+    reference src/bitset.cpp:268-272,326-331);
+  * DAG node ids: leaves = taxon ids, then internal subsplits by increasing clade size, so every
+    child id is below its parents' ids; the DAG root ("universal ancestor") has no id here;
+  * edge (GPCSP) ids: rootsplit edges first, then the edges below each (parent, clade) as one
+    contiguous range (what UpdateSBNProbabilities{start, stop} needs, src/gp_engine.cpp:297-321);
+  * PV id = type * node_count + node (src/pv_handler.hpp:487-490).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from .gp import (INCREMENT_MARGINAL_LIKELIHOOD, INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, LIKELIHOOD, MULTIPLY, P, PHAT_LEFT,
+                 PHAT_RIGHT, RESET_MARGINAL_LIKELIHOOD, RHAT, R_LEFT, R_RIGHT, SET_TO_STATIONARY,
+                 UPDATE_SBN_PROBABILITIES, ZERO_PLV, OpStream)
+
+
+def _low_bit(mask: int) -> int:
+    return mask & -mask
+
+
+class SubsplitDAG:
+    def __init__(self, taxon_count: int, parent_id_vectors: Sequence[Sequence[int]]):
+        n = taxon_count
+        self.taxon_count = n
+        subsplits = set()
+        pcsps = set()  # (parent subsplit, is_left, child subsplit-or-leaf mask)
+        for parents in parent_id_vectors:
+            parents = [int(x) for x in parents]
+            node_count = len(parents) + 1
+            if node_count != 2 * n - 1:
+                raise ValueError("every tree must be a rooted bifurcating tree on the same taxa")
+            clade = [1 << i for i in range(n)] + [0] * (node_count - n)
+            kids: Dict[int, List[int]] = {}
+            for child, p in enumerate(parents):  # post-order ids: children before parents
+                clade[p] |= clade[child]
+                kids.setdefault(p, []).append(child)
+            key = {}
+            for v in range(node_count):
+                if v < n:
+                    key[v] = (0, clade[v])
+                else:
+                    a, b = kids[v]
+                    ca, cb = clade[a], clade[b]
+                    key[v] = (ca, cb) if _low_bit(ca) < _low_bit(cb) else (cb, ca)
+                    subsplits.add(key[v])
+            for v in range(n, node_count):
+                for c in kids[v]:
+                    pcsps.add((key[v], clade[c] == key[v][0], key[c]))
+        full = (1 << n) - 1
+        internal = sorted(subsplits, key=lambda s: (bin(s[0] | s[1]).count("1"), s))
+        self.subsplits: List[Tuple[int, int]] = [(0, 1 << i) for i in range(n)] + internal
+        self.node_count = len(self.subsplits)  # without the DAG root
+        self.node_id = {s: i for i, s in enumerate(self.subsplits)}
+        self.rootsplits = [i for i, s in enumerate(self.subsplits) if (s[0] | s[1]) == full and i >= n]
+        # children[node][side] with side 1 = left clade, 0 = right clade; parents[node] = [(parent, side)]
+        self.children: List[List[List[int]]] = [[[], []] for _ in range(self.node_count)]
+        self.parents: List[List[Tuple[int, int]]] = [[] for _ in range(self.node_count)]
+        for ps, is_left, cs in sorted(pcsps):
+            p, c = self.node_id[ps], self.node_id[cs]
+            self.children[p][1 if is_left else 0].append(c)
+            self.parents[c].append((p, 1 if is_left else 0))
+        # edge ids
+        self.edge_id: Dict[Tuple[int, int], int] = {}
+        self.sibling_ranges: List[Tuple[int, int]] = [(0, len(self.rootsplits))]
+        for r in self.rootsplits:
+            self.edge_id[(-1, r)] = len(self.edge_id)
+        for node in range(n, self.node_count):
+            for side in (1, 0):
+                start = len(self.edge_id)
+                for c in self.children[node][side]:
+                    self.edge_id[(node, c)] = len(self.edge_id)
+                self.sibling_ranges.append((start, len(self.edge_id)))
+        self.gpcsp_count = len(self.edge_id)
+        # number of topologies below every node (SubsplitDAG::topology_count_below_)
+        self.topology_count_below = [1.0] * self.node_count
+        for node in range(n, self.node_count):
+            self.topology_count_below[node] = (sum(self.topology_count_below[c] for c in self.children[node][1]) *
+                                               sum(self.topology_count_below[c] for c in self.children[node][0]))
+        self.topology_count = sum(self.topology_count_below[r] for r in self.rootsplits)
+
+    # -- ids -------------------------------------------------------------------
+    def pv(self, plv_type: int, node: int) -> int:
+        return plv_type * self.node_count + node
+
+    def edge(self, parent: int, child: int) -> int:
+        return self.edge_id[(parent, child)]
+
+    def rootsplit_edge(self, rootsplit: int) -> int:
+        return self.edge_id[(-1, rootsplit)]
+
+    def uniform_on_topological_support_prior(self) -> np.ndarray:
+        """SubsplitDAG::BuildUniformOnTopologicalSupportPrior (src/subsplit_dag.cpp:644-664)."""
+        q = np.ones(self.gpcsp_count)
+        for r in self.rootsplits:
+            q[self.rootsplit_edge(r)] = self.topology_count_below[r] / self.topology_count
+        for node in range(self.taxon_count, self.node_count):
+            for side in (0, 1):
+                kids = self.children[node][side]
+                total = sum(self.topology_count_below[c] for c in kids)
+                for c in kids:
+                    q[self.edge(node, c)] = self.topology_count_below[c] / total
+        return q
+
+    # -- schedules (src/gp_dag.cpp:177-347) -------------------------------------
+    def _rootward_pass(self, s: OpStream):
+        for node in range(self.taxon_count, self.node_count):
+            for side, phat in ((0, PHAT_RIGHT), (1, PHAT_LEFT)):  # AddPhatOperations(node, false) then (node, true)
+                kids = self.children[node][side]
+                dest = self.pv(phat, node)
+                s.prep_for_marginalization(dest, [self.pv(P, c) for c in kids])
+                for c in kids:
+                    s.add(INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, dest, self.edge(node, c), self.pv(P, c))
+            s.add(MULTIPLY, self.pv(P, node), self.pv(PHAT_RIGHT, node), self.pv(PHAT_LEFT, node))
+
+    def _leafward_pass(self, s: OpStream):
+        for node in range(self.node_count - 1, -1, -1):  # parents before children
+            if self.parents[node]:
+                srcs = [(self.pv(R_LEFT if side else R_RIGHT, p), self.edge(p, node)) for p, side in self.parents[node]]
+                s.prep_for_marginalization(self.pv(RHAT, node), [src for src, _ in srcs])
+                for src, e in srcs:
+                    s.add(INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, self.pv(RHAT, node), e, src)
+            s.add(MULTIPLY, self.pv(R_RIGHT, node), self.pv(RHAT, node), self.pv(PHAT_LEFT, node))
+            s.add(MULTIPLY, self.pv(R_LEFT, node), self.pv(RHAT, node), self.pv(PHAT_RIGHT, node))
+
+    def populate_plvs(self) -> OpStream:
+        s = OpStream()
+        for node in range(self.taxon_count, self.node_count):  # SetRootwardZero
+            for t in (P, PHAT_RIGHT, PHAT_LEFT):
+                s.add(ZERO_PLV, self.pv(t, node))
+        for node in range(self.node_count):  # SetLeafwardZero
+            for t in (RHAT, R_RIGHT, R_LEFT):
+                s.add(ZERO_PLV, self.pv(t, node))
+        for r in self.rootsplits:  # SetRhatToStationary
+            s.add(SET_TO_STATIONARY, self.pv(RHAT, r), self.rootsplit_edge(r))
+        self._rootward_pass(s)
+        self._leafward_pass(s)
+        return s
+
+    def marginal_likelihood(self) -> OpStream:
+        s = OpStream()
+        s.add(RESET_MARGINAL_LIKELIHOOD)
+        for r in self.rootsplits:
+            s.add(INCREMENT_MARGINAL_LIKELIHOOD, self.pv(RHAT, r), self.rootsplit_edge(r), self.pv(P, r))
+        return s
+
+    def compute_likelihoods(self) -> OpStream:
+        s = OpStream()
+        for node in range(self.taxon_count, self.node_count):
+            for side in (1, 0):
+                for c in self.children[node][side]:
+                    s.add(LIKELIHOOD, self.edge(node, c), self.pv(R_LEFT if side else R_RIGHT, node), self.pv(P, c))
+        s.extend(self.marginal_likelihood())
+        return s
+
+    def optimize_sbn_parameters(self) -> OpStream:
+        """GPDAG::OptimizeSBNParameters (src/gp_dag.cpp:213-224): one softmax per (parent, clade)
+        with more than one child, then the rootsplits."""
+        s = OpStream()
+        for start, stop in self.sibling_ranges[1:]:
+            if stop - start > 1:
+                s.add(UPDATE_SBN_PROBABILITIES, start, stop)
+        s.add(UPDATE_SBN_PROBABILITIES, 0, len(self.rootsplits))
+        return s
+
+    # -- every tree the DAG spans (SubsplitDAG::GenerateAllTopologies, src/subsplit_dag.cpp:666-715) --
+    def all_trees(self):
+        """Yields (parent_ids, edge_of_node): a bito parent-id vector (leaves = taxon ids, internal
+        ids in post-order, root last) and, per non-root tree node, the GPCSP id of the edge above it;
+        the last entry is the rootsplit edge."""
+        n = self.taxon_count
+
+        def below(node):
+            if node < n:
+                return [(node,)]
+            out = []
+            for lc in self.children[node][1]:
+                for lt in below(lc):
+                    for rc in self.children[node][0]:
+                        for rt in below(rc):
+                            out.append((node, lc, lt, rc, rt))
+            return out
+
+        for r in self.rootsplits:
+            for shape in below(r):
+                parents: Dict[int, int] = {}
+                edge_above: Dict[int, int] = {}
+                counter = [n]
+
+                def walk(t):
+                    if len(t) == 1:
+                        return t[0]
+                    node, lc, lt, rc, rt = t
+                    a, b = walk(lt), walk(rt)
+                    me = counter[0]
+                    counter[0] += 1
+                    parents[a], parents[b] = me, me
+                    edge_above[a], edge_above[b] = self.edge(node, lc), self.edge(node, rc)
+                    return me
+
+                root = walk(shape)
+                assert root == 2 * n - 2
+                pid = np.array([parents[v] for v in range(2 * n - 2)], dtype=np.int32)
+                edges = [edge_above[v] for v in range(2 * n - 2)] + [self.rootsplit_edge(r)]
+                yield pid, edges

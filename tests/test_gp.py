@@ -236,3 +236,89 @@ def test_gp_branch_length_optimization_on_device(data_dir):
     eng.set_optimization_method(gp.NEWTON)
     sweeps = gp.estimate_branch_lengths(eng, dag, 1e-6, 20)
     assert 1 < sweeps <= 20 and float(np.mean(eng.get_branch_length_differences())) < 1e-6
+
+
+# ---- multi-tree subsplit DAGs: GP marginal == brute force over every tree of the DAG ------------
+# (the reference's TestCompositeMarginal, src/gp_doctest.cpp:140-254; the identity holds for any
+# per-PCSP branch lengths, so seeded ones are used instead of an optimisation run)
+
+from bito_amd import gp_dag  # noqa: E402
+
+COMPOSITE_CASES = [("hello.fasta", "hello_rooted_two_trees.nwk"), ("five_taxon.fasta", "five_taxon_rooted.nwk"),
+                   ("ds1-reduced-5.fasta", "ds1-reduced-5.nwk"),
+                   ("7-taxon-slice-of-ds1.fasta", "simplest-hybrid-marginal-all-trees.nwk")]
+
+
+def _composite_case(data_dir, fasta, newick):
+    tc = treeio.read_newick_file(os.path.join(data_dir, newick))
+    sp = SitePattern(treeio.read_fasta(os.path.join(data_dir, fasta)), tc.taxon_names)
+    dag = gp_dag.SubsplitDAG(sp.taxon_count, [t.parent_ids for t in tc.trees])
+    rng = np.random.default_rng(11)
+    bl = rng.uniform(0.01, 0.3, dag.gpcsp_count)
+    bl[:len(dag.rootsplits)] = 0.0  # rootsplit edges carry no length
+    return sp, dag, bl
+
+
+def _exact_marginals(sp, dag, bl):
+    """ComputeExactMarginal (src/gp_doctest.cpp:140-187) with site patterns in place of columns:
+    the tree likelihoods come from the Path A oracle, one single-pattern engine per pattern."""
+    trees = list(dag.all_trees())
+    assert len(trees) == dag.topology_count
+    n = sp.taxon_count
+    pid = np.stack([t[0] for t in trees])
+    lengths = np.array([[bl[e] for e in t[1]] for t in trees])
+    log_prior = np.log(1.0 / len(trees))
+    total, per_pcsp = 0.0, np.zeros(dag.gpcsp_count)
+    for p in range(sp.patterns.shape[1]):
+        eng = oracle.OracleEngine("JC69", "constant", "strict", sp.patterns[:, p:p + 1], np.ones(1), 1)
+        ll = eng.log_likelihoods(pid, lengths)
+        total += sp.weights[p] * (np.logaddexp.reduce(ll) + log_prior)
+        for e in range(dag.gpcsp_count):
+            members = [ll[k] for k, t in enumerate(trees) if e in t[1]]
+            per_pcsp[e] += sp.weights[p] * (np.logaddexp.reduce(members) + log_prior)
+    return total, per_pcsp
+
+
+def _check_composite(engine, sp, dag, bl):
+    engine.set_branch_lengths(bl)
+    q = dag.uniform_on_topological_support_prior()
+    engine.set_sbn_parameters(q)
+    engine.process_operations(dag.populate_plvs())
+    engine.process_operations(dag.compute_likelihoods())
+    exact, exact_per_pcsp = _exact_marginals(sp, dag, bl)
+    assert abs(engine.get_log_marginal_likelihood() - exact) < 1e-6
+    # PerGPCSPComponentsOfFullLogMarginal (src/gp_engine.cpp:455-458)
+    components = engine.get_per_gpcsp_log_likelihoods() + sp.weights.sum() * np.log(q)
+    assert np.abs(components - exact_per_pcsp).max() < 1e-5
+
+
+@pytest.mark.parametrize("fasta,newick", COMPOSITE_CASES)
+def test_gp_oracle_composite_marginal(data_dir, fasta, newick):
+    sp, dag, bl = _composite_case(data_dir, fasta, newick)
+    _check_composite(ogp.OracleGPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count), sp, dag, bl)
+
+
+def test_subsplit_dag_shape(data_dir):
+    """DAGSummaryStatistics of the two-tree hello DAG (src/gp_doctest.cpp:105-109): 8 nodes and 10
+    edges with the DAG root and its rootsplit edges counted."""
+    sp, dag, _ = _composite_case(data_dir, "hello.fasta", "hello_rooted_two_trees.nwk")
+    assert dag.node_count + 1 == 8 and dag.gpcsp_count == 10
+    assert dag.topology_count == 2 and len(dag.rootsplits) == 2
+    assert abs(dag.uniform_on_topological_support_prior()[:2].sum() - 1.0) < 1e-15
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fasta,newick", COMPOSITE_CASES)
+def test_gp_executor_composite_marginal(data_dir, fasta, newick):
+    sp, dag, bl = _composite_case(data_dir, fasta, newick)
+    gpu = gp.GPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+    _check_composite(gpu, sp, dag, bl)
+    # SBN parameter optimisation on the multi-parent DAG, device against the oracle
+    cpu = ogp.OracleGPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+    for eng in (gpu, cpu):
+        eng.set_branch_lengths(bl)
+        eng.set_sbn_parameters(dag.uniform_on_topological_support_prior())
+        eng.process_operations(dag.populate_plvs())
+        eng.process_operations(dag.compute_likelihoods())
+        eng.process_operations(dag.optimize_sbn_parameters())
+    assert np.abs(gpu.get_sbn_parameters() - cpu.get_sbn_parameters()).max() < 1e-10
