@@ -96,8 +96,10 @@ __device__ __forceinline__ double TipOperand(int mask, int st) {
 template <int kCtrl>
 __device__ __forceinline__ double DppMove(double v) {
   const long long bits = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, kCtrl, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), kCtrl, 0xF, 0xF, true);
+  // row rotations read every lane, so the "old" operand is never used: mov_dpp leaves it undefined
+  // and saves the v_mov that update_dpp(0, ...) needs to materialise it
+  const int lo = __builtin_amdgcn_mov_dpp((int)bits, kCtrl, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(bits >> 32), kCtrl, 0xF, 0xF, true);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 constexpr int kRowRor1 = 0x121, kRowRor2 = 0x122, kRowRor4 = 0x124, kRowRor8 = 0x128;
@@ -160,10 +162,11 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
   double* arena = lds + (size_t)wave * slots * G * 64 + lane;  // cell (slot, g) at (slot*G+g)*64
   uint8_t* tipbuf = reinterpret_cast<uint8_t*>(lds + (size_t)kLdsWaves * slots * G * 64);
   double* grad_rows = lds + (size_t)kLdsWaves * slots * G * 64 + (n * PB + 7) / 8;
-  double* ll_slots = grad_rows + kLdsWaves * N;
+  double* ll_slots = grad_rows + kLdsWaves * 4 * N;
 
   const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
   const double* __restrict__ img = images + (size_t)tree * (N - 1) * kImgStride + lane;
+  auto img_at = [&](int branch, int which) -> double { return img[(size_t)branch * kImgStride + which]; };
   const TreeModel* __restrict__ tm = models + tree;
 
   // The child list lives in registers, one entry per lane (TABS tables of 64 entries: one
@@ -184,7 +187,7 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
     tipbuf[q] = (uint8_t)(sym < 4 ? 1 << sym : 15);
   }
   if (GRAD)
-    for (int q = tid; q < kLdsWaves * N; q += kLdsWaves * 64) grad_rows[q] = 0.0;
+    for (int q = tid; q < kLdsWaves * 4 * N; q += kLdsWaves * 64) grad_rows[q] = 0.0;
   __syncthreads();
 
   int loc[G];        // pattern index inside the workgroup tile
@@ -217,7 +220,7 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
       a = child(kk * 2);
       b = child(kk * 2 + 1);
     };
-    auto load2 = [&](int a, int b) { return Img2{img[(size_t)a * kImgStride + kImgP], img[(size_t)b * kImgStride + kImgP]}; };
+    auto load2 = [&](int a, int b) { return Img2{img_at(a, kImgP), img_at(b, kImgP)}; };
     int c0, c1, d0c, d1c;
     kchildren(0, c0, c1);
     kchildren(1, d0c, d1c);
@@ -297,12 +300,11 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
 
   // ---------------- pre-order + edge derivatives ----------------------------
   if (GRAD) {
-    double* my_row = grad_rows + wave * N;
+    double* my_row = grad_rows + wave * 4 * N;  // [block][edge]
     struct Img { double p0, q0, t0, p1, q1, t1; };  // P, dP, P^T images of the two child branches
     auto load_img = [&](int a, int b) {
-      return Img{img[(size_t)a * kImgStride + kImgP], img[(size_t)a * kImgStride + kImgDP],
-                 img[(size_t)a * kImgStride + kImgPT], img[(size_t)b * kImgStride + kImgP],
-                 img[(size_t)b * kImgStride + kImgDP], img[(size_t)b * kImgStride + kImgPT]};
+      return Img{img_at(a, kImgP), img_at(a, kImgDP), img_at(a, kImgPT),
+                 img_at(b, kImgP), img_at(b, kImgDP), img_at(b, kImgPT)};
     };
     auto node_children = [&](int nd, int& a, int& b) {
       const int kk = nd >= n ? nd - n : 0;
@@ -324,10 +326,15 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
     // fills the wait for this step's LDS operands
     double ps0 = 0.0, ps1 = 0.0;
     int pc0 = N - 1, pc1 = N - 1;  // root entry: the reduce kernel writes 0 there
+    // The 64-lane sum of an edge on the matrix pipe: with the per-lane terms as the A operand and
+    // ones as B, D_b[i][j] = sum_k v[16k+4b+i] (the four state rows); fed back as the B operand
+    // under an all-ones A, D_b[i][j] = sum over the block's 16 lanes.  What is left, the sum over
+    // the four blocks, is folded into the workgroup sum at the end: a row per block.
+    const bool row_writer = (lane & 0x13) == 0;  // lanes 4b (edge pc0) and 32+4b (edge pc1)
     auto flush_edges = [&]() {
-      // lanes 0-31 carry edge pc0, lanes 32-63 edge pc1
-      const double sm = RowSum16(PairRows(MergeHalves(ps0, ps1)));
-      if ((lane & 31) == 0) my_row[lane == 0 ? pc0 : pc1] = sm;
+      const double r0 = Mfma(ps0, 1.0, 0.0), r1 = Mfma(ps1, 1.0, 0.0);
+      const double t0 = Mfma(1.0, r0, 0.0), t1 = Mfma(1.0, r1, 0.0);
+      if (row_writer) my_row[blk * N + (lane < 32 ? pc0 : pc1)] = lane < 32 ? t0 : t1;
     };
 
     auto step = [&](auto tip0_c, auto tip1_c, const Img& cur, Img& fill) {
@@ -425,7 +432,7 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
     double* out = part_grad + ((size_t)tree * tiles + tile) * N;
     for (int e = tid; e < N; e += kLdsWaves * 64) {
       double s = 0.0;
-      for (int w = 0; w < kLdsWaves; w++) s += grad_rows[w * N + e];
+      for (int w = 0; w < kLdsWaves * 4; w++) s += grad_rows[w * N + e];
       out[e] = s;
     }
   }
@@ -435,7 +442,7 @@ static size_t LdsBytes(const BatchDims& d, int G) {
   const int PG = 16 / d.category_count, PB = kLdsWaves * G * PG, n = d.taxon_count;
   const size_t arena = (size_t)kLdsWaves * (n - 2) * G * 64;
   const size_t tips = ((size_t)n * PB + 7) / 8;
-  return (arena + tips + (size_t)kLdsWaves * d.node_count + kLdsWaves) * sizeof(double);
+  return (arena + tips + (size_t)kLdsWaves * 4 * d.node_count + kLdsWaves) * sizeof(double);
 }
 
 LdsPlan PlanLds(const BatchDims& d) {
