@@ -87,8 +87,11 @@ __device__ __forceinline__ double Mfma(double a, double x, double c) {
 // Tips are held in LDS as 4-bit masks (bit k set when the observed symbol is compatible
 // with state k; a gap sets all four).  The MFMA B operand of a tip is then the double
 // 1.0 or 0.0 selected by this lane's state bit: only the high dword differs.
+// A set bit becomes 2.0, whose high dword is the single bit 30 (one shift instead of a
+// compare + select); every site likelihood then carries the exact factor 2^n, removed from the
+// log-likelihood at the end, and the gradients are ratios in which it cancels.
 __device__ __forceinline__ double TipOperand(int mask, int st) {
-  const int hi = (0 - ((mask >> st) & 1)) & 0x3FF00000;
+  const int hi = (mask << (30 - st)) & 0x40000000;  // 30 - st is loop-invariant per lane
   return __hiloint2double(hi, 0);
 }
 
@@ -294,7 +297,7 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
     L += __shfl_xor(L, 32);
     if (C >= 2) L += __shfl_xor(L, 4);
     if (C == 4) L += __shfl_xor(L, 8);
-    if (st == 0 && cat == 0) ll_acc += wgt[g] * log(L);
+    if (st == 0 && cat == 0) ll_acc += wgt[g] * (log(L) - n * 0.6931471805599453);
     coef[g] = w_cat * (wgt[g] / L);
   }
 
