@@ -212,35 +212,74 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
     __syncthreads();
   }
 
+  // A child of a step is a tip, a stored internal node, or a CHERRY (internal node over two tips).
+  // Cherries are never stored: their post-order partial is the product of two tip look-ups,
+  // cheaper to rebuild than to move through HBM, and their own pre-order step (two tip edges) is
+  // folded into the parent's step below.  That removes every PLV transfer of about a third of
+  // the internal nodes.  (Cherries are not rescaled: a product of two probabilities cannot
+  // underflow, and the log-likelihood does not depend on which nodes carry a scale factor.)
+  struct Child {
+    int kind;  // 0 tip, 1 stored internal node, 2 cherry
+    int a, b;  // cherry: its two tips (wave-uniform)
+    int s, sb; // this pattern's state at the tip / at the cherry's tips
+  };
+  auto classify = [&](int cc) {
+    Child ci{0, 0, 0, 0, 0};
+    if (cc < n) {
+      ci.s = tips[(size_t)cc * Ppad];
+    } else {
+      ci.a = __builtin_amdgcn_readfirstlane(ch[(cc - n) * 2]);
+      ci.b = __builtin_amdgcn_readfirstlane(ch[(cc - n) * 2 + 1]);
+      if (ci.a < n && ci.b < n) {
+        ci.kind = 2;
+        ci.s = tips[(size_t)ci.a * Ppad];
+        ci.sb = tips[(size_t)ci.b * Ppad];
+      } else {
+        ci.kind = 1;
+      }
+    }
+    return ci;
+  };
+  // post-order partial of internal child cc in category c
+  auto fetch = [&](const Child& ci, int cc, int c, double x[4]) {
+    if (ci.kind == 2) {
+      const double* ma = mats + (size_t)(ci.a * C + c) * kMatStride + kMatPT + ci.s * 4;
+      const double* mb = mats + (size_t)(ci.b * C + c) * kMatStride + kMatPT + ci.sb * 4;
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = ma[i] * mb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((cc - n) * C + c) * 4 + i) * Ppad];
+    }
+  };
+
   // ---- post-order: dest = (P0 x0) . (P1 x1) per category -------------------
   double log_scale = 0.0, site = 0.0;
   for (int node = n; node < N; ++node) {
     const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
     const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
-    const int s0 = c0 < n ? tips[(size_t)c0 * Ppad] : 0;
-    const int s1 = c1 < n ? tips[(size_t)c1 * Ppad] : 0;
+    if (c0 < n && c1 < n && node != N - 1) continue;  // a cherry: rebuilt where it is used
+    const Child k0 = classify(c0), k1 = classify(c1);
     double dd[C][4];
 #pragma unroll
     for (int c = 0; c < C; c++) {
       double A[4], B[4];
       const double* m0 = mats + (size_t)(c0 * C + c) * kMatStride;
       const double* m1 = mats + (size_t)(c1 * C + c) * kMatStride;
-      if (c0 < n) {
+      if (k0.kind == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) A[i] = m0[kMatPT + s0 * 4 + i];
+        for (int i = 0; i < 4; i++) A[i] = m0[kMatPT + k0.s * 4 + i];
       } else {
         double x[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad];
+        fetch(k0, c0, c, x);
         MatVec(m0 + kMatP, x, A);
       }
-      if (c1 < n) {
+      if (k1.kind == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) B[i] = m1[kMatPT + s1 * 4 + i];
+        for (int i = 0; i < 4; i++) B[i] = m1[kMatPT + k1.s * 4 + i];
       } else {
         double x[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad];
+        fetch(k1, c1, c, x);
         MatVec(m1 + kMatP, x, B);
       }
 #pragma unroll
@@ -282,10 +321,27 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
     for (int node = N - 1; node >= n; --node) {
       const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
       const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
-      const bool tip0 = c0 < n, tip1 = c1 < n;
-      const int s0 = tip0 ? tips[(size_t)c0 * Ppad] : 0;
-      const int s1 = tip1 ? tips[(size_t)c1 * Ppad] : 0;
+      if (c0 < n && c1 < n && node != N - 1) continue;  // a cherry: handled inside its parent's step
+      const Child k0 = classify(c0), k1 = classify(c1);
+      const bool tip0 = k0.kind == 0, tip1 = k1.kind == 0;
       double num0 = 0.0, num1 = 0.0, den = 0.0;
+      double numa0 = 0.0, numb0 = 0.0, numa1 = 0.0, numb1 = 0.0;  // tip edges of cherry children
+      // The cherry's own step with q = its pre-order partial: dL/dt of its two tip edges.  Its site
+      // likelihood sum_i q_i x_i equals this step's `den`, so only the numerators are new.
+      auto cherry_edges = [&](const Child& ci, int c, double wc, const double q[4], double& na, double& nb) {
+        const double* ma = mats + (size_t)(ci.a * C + c) * kMatStride;
+        const double* mb = mats + (size_t)(ci.b * C + c) * kMatStride;
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const double aa = ma[kMatPT + ci.s * 4 + i], da = ma[kMatDPT + ci.s * 4 + i];
+          const double ab = mb[kMatPT + ci.sb * 4 + i], db = mb[kMatDPT + ci.sb * 4 + i];
+          sa += q[i] * (ab * da);
+          sb += q[i] * (aa * db);
+        }
+        na += wc * sa;
+        nb += wc * sb;
+      };
       // One category of the step: accumulates the three site sums and returns the
       // two child pre-order partials (only meaningful for internal children).
       auto category_step = [&](int c, double q0[4], double q1[4]) {
@@ -302,26 +358,24 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
         if (tip0) {
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            A0[i] = m0[kMatPT + s0 * 4 + i];
-            D0[i] = m0[kMatDPT + s0 * 4 + i];
+            A0[i] = m0[kMatPT + k0.s * 4 + i];
+            D0[i] = m0[kMatDPT + k0.s * 4 + i];
           }
         } else {
           double x[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad];
+          fetch(k0, c0, c, x);
           MatVec(m0 + kMatP, x, A0);
           MatVec(m0 + kMatDP, x, D0);
         }
         if (tip1) {
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            A1[i] = m1[kMatPT + s1 * 4 + i];
-            D1[i] = m1[kMatDPT + s1 * 4 + i];
+            A1[i] = m1[kMatPT + k1.s * 4 + i];
+            D1[i] = m1[kMatDPT + k1.s * 4 + i];
           }
         } else {
           double x[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad];
+          fetch(k1, c1, c, x);
           MatVec(m1 + kMatP, x, A1);
           MatVec(m1 + kMatDP, x, D1);
         }
@@ -337,6 +391,8 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
         num1 += wc * (UA0[0] * D1[0] + UA0[1] * D1[1] + UA0[2] * D1[2] + UA0[3] * D1[3]);
         if (!tip0) MatVecT(m0 + kMatP, UA1, q0);
         if (!tip1) MatVecT(m1 + kMatP, UA0, q1);
+        if (k0.kind == 2) cherry_edges(k0, c, wc, q0, numa0, numb0);
+        if (k1.kind == 2) cherry_edges(k1, c, wc, q1, numa1, numb1);
       };
       // Rescaling of the pre-order partials.  BEAGLE rescales each pre-order partial by its
       // own maximum (scaleWrite on the pre-order ops, fat_beagle.cpp:362-363); the factor
@@ -352,12 +408,12 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
       for (int c = 0; c < C; c++) {
         double q0[4], q1[4];
         category_step(c, q0, q1);
-        if (!tip0) {
+        if (k0.kind == 1) {
 #pragma unroll
           for (int i = 0; i < 4; i++)
             arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad] = RESCALE ? q0[i] * step_inv : q0[i];
         }
-        if (!tip1) {
+        if (k1.kind == 1) {
 #pragma unroll
           for (int i = 0; i < 4; i++)
             arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad] = RESCALE ? q1[i] * step_inv : q1[i];
@@ -369,6 +425,20 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
       if (lane == 0) {
         my_row[c0] = g0;
         my_row[c1] = g1;
+      }
+      if (k0.kind == 2) {
+        const double ga = WaveSum(numa0 * scale), gb = WaveSum(numb0 * scale);
+        if (lane == 0) {
+          my_row[k0.a] = ga;
+          my_row[k0.b] = gb;
+        }
+      }
+      if (k1.kind == 2) {
+        const double ga = WaveSum(numa1 * scale), gb = WaveSum(numb1 * scale);
+        if (lane == 0) {
+          my_row[k1.a] = ga;
+          my_row[k1.b] = gb;
+        }
       }
     }
   }
