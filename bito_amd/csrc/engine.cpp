@@ -68,7 +68,7 @@ struct bito_amd_engine {
   bool resident = false;
   BatchDims dims{};
   bool has_rates = false;
-  DeviceBuffer<int32_t> parent_ids, children;
+  DeviceBuffer<int32_t> parent_ids, children, sched;
   DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
       out_ll, out_grad, scale_arena;
   DeviceBuffer<TreeModel> model;
@@ -87,7 +87,7 @@ struct bito_amd_engine {
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
     tip_states.Free(); weights.Free(); parent_ids.Free(); children.Free(); branch_in.Free();
     rates.Free(); params.Free(); branch.Free(); mats.Free(); images.Free(); arena.Free(); scale_arena.Free(); part_ll.Free();
-    part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free();
+    part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
     tt_out.Free(); tt_aux.Free();
     if (stream) (void)hipStreamDestroy(stream);
@@ -248,6 +248,7 @@ DeviceBatch MakeBatch(bito_amd_engine* e) {
   b.model = e->model.ptr;
   b.mats = e->mats.ptr;
   b.images = e->images.ptr;
+  b.sched = e->sched.ptr;
   b.arena = e->arena.ptr;
   b.scale_arena = e->scale_arena.ptr;
   b.part_ll = e->part_ll.ptr;
@@ -299,9 +300,11 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
   if (use_tree || use_lds) {
     HIP_TRY(e, e->images.Reserve((size_t)T * NB * kImgStride));
+    if (use_lds) HIP_TRY(e, e->sched.Reserve(LdsScheduleInts(d)));
     const DeviceBatch b = MakeBatch(e);
     LaunchSetup(d, e->spec, b, want_gradient, e->stream);
     LaunchMatrixImages(d, b, want_gradient, deriv_mode, e->stream);
+    if (use_lds) LaunchLdsSchedule(d, b, plan, e->stream);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing) {
       ev0 = NextEvent(e);

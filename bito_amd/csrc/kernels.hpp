@@ -53,6 +53,7 @@ struct DeviceBatch {
   TreeModel* model;           // [T]
   double* mats;               // [T][N-1][C][kMatStride]   (HBM-arena kernel)
   double* images;             // [T][N-1][kImgStride]      (LDS kernel)
+  int32_t* sched;             // [T][2][n-1][8]            step descriptors (LDS kernel)
   // traversal scratch + outputs
   double* arena;              // [chunk][n-1][C][4][Ppad]
   double* scale_arena;        // [chunk][n-1][Ppad]  post-order 1/scale factors (rescaled gradients)
@@ -80,6 +81,8 @@ struct LdsPlan {
   size_t lds_bytes;
 };
 LdsPlan PlanLds(const BatchDims& d);
+size_t LdsScheduleInts(const BatchDims& d);
+void LaunchLdsSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream);
 void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
                    hipStream_t stream);
 

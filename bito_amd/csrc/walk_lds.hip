@@ -137,9 +137,76 @@ __device__ __forceinline__ double MergeHalves(double a, double b) {
   return x + y;
 }
 
-template <int C, int G, bool GRAD, int TABS>
+// ---- step schedule ---------------------------------------------------------------------------
+// Everything a step needs that depends only on the topology is tabulated once per tree and read
+// with ONE scalar load per step (s_load_dwordx8, issued two steps ahead): LDS byte offsets of
+// the two operands (tip row or arena cell), of the node's own cell, which children are tips,
+// whether an operand is forwarded in registers, the child ids (gradient rows) and the image
+// offsets to prefetch for the step after next.  Two tables per tree: post-order (ascending node)
+// and pre-order (descending node), NI entries each.
+struct alignas(32) StepDesc {
+  unsigned off0, off1;  // LDS byte offset of operand 0 / 1: tip row c*PB in the tip buffer, or arena cell
+  unsigned cell;        // LDS byte offset of this node's arena cell
+  unsigned flags;       // bit 0: child 0 is a tip; bit 1: child 1 is a tip; bit 2: forwarded operand
+  unsigned c0, c1;      // child ids
+  unsigned pf0, pf1;    // image byte offsets of the children of the step after next
+};
+// A descriptor is fetched with an explicit scalar load: the compiler only selects s_load for
+// memory it can prove unclobbered, which it does not here.  The caller waits (lgkmcnt) before
+// the first use: StepFetch two steps ahead, StepWait at the top of every step.
+typedef unsigned StepWords __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ StepWords StepFetch(const StepDesc* p) {
+  StepWords w;
+  asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(w) : "s"(p));
+  return w;
+}
+// the wait "produces" the descriptor, so no use of it can be scheduled above the wait
+__device__ __forceinline__ void StepWait(StepWords& w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w)::"memory"); }
+// word indices of the fields
+enum { kOff0 = 0, kOff1 = 1, kCell = 2, kFlags = 3, kC0 = 4, kC1 = 5, kPf0 = 6, kPf1 = 7 };
+// entries per pass: one per internal node plus two trailing copies of the last one, so the
+// two-steps-ahead fetch needs no clamp
+__host__ __device__ constexpr int SchedEntries(int NI) { return NI + 2; }
+constexpr int kFlagTip0 = 1, kFlagTip1 = 2, kFlagForward = 4;
+
+__global__ void __launch_bounds__(256)
+lds_schedule_kernel(BatchDims d, int G, int PB, const int32_t* __restrict__ children, StepDesc* __restrict__ sched) {
+  const int n = d.taxon_count, N = d.node_count, NI = n - 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= d.tree_count * NI) return;
+  const int tree = idx / NI, j = idx % NI;
+  const int32_t* ch = children + (size_t)tree * NI * 2;
+  auto off = [&](int c) -> unsigned { return c < n ? c * PB : (c - n) * G * 512; };
+  auto image = [&](int c) -> unsigned { return c * kImgStride * 8; };
+  const int E = SchedEntries(NI);
+  StepDesc* post = sched + (size_t)tree * 2 * E;
+  StepDesc* pre = post + E;
+  {  // post-order step j: node n + j
+    const int node = n + j, c0 = ch[2 * j], c1 = ch[2 * j + 1];
+    const int a = j + 2 < NI ? j + 2 : NI - 1;
+    const StepDesc e{off(c0), off(c1), (unsigned)(j * G * 512),
+                     (unsigned)((c0 < n ? kFlagTip0 : 0) | (c1 < n ? kFlagTip1 : 0) |
+                                (c1 >= n && c1 == node - 1 ? kFlagForward : 0)),
+                     (unsigned)c0, (unsigned)c1, image(ch[2 * a]), image(ch[2 * a + 1])};
+    post[j] = e;
+    if (j == NI - 1) post[NI] = post[NI + 1] = e;
+  }
+  {  // pre-order step j: node N - 1 - j
+    const int k = NI - 1 - j, node = n + k, c0 = ch[2 * k], c1 = ch[2 * k + 1];
+    const int a = k - 2 >= 0 ? k - 2 : 0;
+    // U is still in registers when this node is the second child of the node processed just before
+    const bool fwd = node == N - 1 || ch[2 * (k + 1) + 1] == node;
+    const StepDesc e{off(c0), off(c1), (unsigned)(k * G * 512),
+                     (unsigned)((c0 < n ? kFlagTip0 : 0) | (c1 < n ? kFlagTip1 : 0) | (fwd ? kFlagForward : 0)),
+                     (unsigned)c0, (unsigned)c1, image(ch[2 * a]), image(ch[2 * a + 1])};
+    pre[j] = e;
+    if (j == NI - 1) pre[NI] = pre[NI + 1] = e;
+  }
+}
+
+template <int C, int G, bool GRAD>
 __global__ void __launch_bounds__(kLdsWaves * 64, 1)
-walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ children,
+walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ sched,
                 const double* __restrict__ images, const TreeModel* __restrict__ models,
                 const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
                 double* __restrict__ part_ll, double* __restrict__ part_grad) {
@@ -162,27 +229,17 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
   const int cat = blk % C, sub = blk / C;
 
   // LDS carve-up: per-wave arena | tip states of the workgroup's patterns | gradient rows | ll
-  double* arena = lds + (size_t)wave * slots * G * 64 + lane;  // cell (slot, g) at (slot*G+g)*64
+  char* const arena_b = reinterpret_cast<char*>(lds + (size_t)wave * slots * G * 64 + lane);
   uint8_t* tipbuf = reinterpret_cast<uint8_t*>(lds + (size_t)kLdsWaves * slots * G * 64);
   double* grad_rows = lds + (size_t)kLdsWaves * slots * G * 64 + (n * PB + 7) / 8;
   double* ll_slots = grad_rows + kLdsWaves * 4 * N;
 
-  const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
-  const double* __restrict__ img = images + (size_t)tree * (N - 1) * kImgStride + lane;
-  auto img_at = [&](int branch, int which) -> double { return img[(size_t)branch * kImgStride + which]; };
+  // wave-uniform base + 32-bit per-lane byte offset: global loads in the SGPR-base form
+  const char* __restrict__ img_b = reinterpret_cast<const char*>(images + (size_t)tree * (N - 1) * kImgStride);
+  const unsigned lane8 = (unsigned)lane * 8u;
   const TreeModel* __restrict__ tm = models + tree;
-
-  // The child list lives in registers, one entry per lane (TABS tables of 64 entries: one
-  // for n <= 33, three up to n = 80); a step fetches its two children with v_readlane,
-  // so the schedule costs no memory latency.
-  const int tab0 = lane < 2 * NI ? ch[lane] : 0;
-  const int tab1 = TABS > 1 && 64 + lane < 2 * NI ? ch[64 + lane] : 0;
-  const int tab2 = TABS > 1 && 128 + lane < 2 * NI ? ch[128 + lane] : 0;
-  auto child = [&](int idx) -> int {  // idx is wave-uniform
-    if (TABS == 1) return __builtin_amdgcn_readlane(tab0, idx);
-    const int t = idx < 64 ? tab0 : (idx < 128 ? tab1 : tab2);
-    return __builtin_amdgcn_readlane(t, idx & 63);
-  };
+  const StepDesc* __restrict__ post_tab = sched + (size_t)tree * 2 * SchedEntries(NI);
+  const StepDesc* __restrict__ pre_tab = post_tab + SchedEntries(NI);
 
   // workgroup preamble: tip masks of this tile, zeroed gradient rows
   for (int q = tid; q < n * PB; q += kLdsWaves * 64) {
@@ -193,94 +250,88 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
     for (int q = tid; q < kLdsWaves * 4 * N; q += kLdsWaves * 64) grad_rows[q] = 0.0;
   __syncthreads();
 
-  int loc[G];        // pattern index inside the workgroup tile
+  const int loc0 = wave * G * PG + sub * 4 + pj;  // pattern of group 0 inside the tile; group g: + g*PG
+  const uint8_t* tip_b = tipbuf + loc0;
   double wgt[G];     // pattern weight
 #pragma unroll
-  for (int g = 0; g < G; g++) {
-    loc[g] = (wave * G + g) * PG + sub * 4 + pj;
-    wgt[g] = weights[tile * PB + loc[g]];
-  }
+  for (int g = 0; g < G; g++) wgt[g] = weights[tile * PB + loc0 + g * PG];
   const double pi_st = tm->pi[st];
   const double w_cat = tm->cat_weight[cat];
 
-#define TIP_ADDR(c, g) tipbuf[(c) * PB + loc[g]]
-#define CELL(node_id, g) arena[(size_t)(((node_id) - n) * G + (g)) * 64]
+#define TIP_AT(off, g) tip_b[(off) + (g) * PG]
+#define CELL_AT(off, g) (*reinterpret_cast<double*>(arena_b + (off) + (g) * 512))
+#define IMAGE_AT(off, which) (*reinterpret_cast<const double*>(img_b + (size_t)((off) + lane8 + (unsigned)((which) * 8))))
   using T_ = std::true_type;
   using F_ = std::false_type;
 
   // ---------------- post-order ----------------------------------------------
   // A step is self-contained straight-line code, specialised on which children are tips
-  // (children are in ascending id order, so a tip never follows an internal node).  Only
-  // the matrix images are fetched ahead: three register sets rotate through a 3-way
-  // unrolled loop, so a set is loaded two steps before it is used and never copied.
-  // The result of a step is handed to the next one in registers when that step's second
-  // child is this node, which is the common case in post-order numbering.
+  // (children are in ascending id order, so a tip never follows an internal node).  Matrix
+  // images and step descriptors are fetched two steps ahead into three rotating register sets
+  // (3-way unrolled loop: a set is never copied).  The result of a step is handed to the next
+  // one in registers when that step's second child is this node, the common case.
   double res[G];
   {
     struct Img2 { double m0, m1; };
-    auto kchildren = [&](int k, int& a, int& b) {
-      const int kk = k < NI ? k : NI - 1;
-      a = child(kk * 2);
-      b = child(kk * 2 + 1);
-    };
-    auto load2 = [&](int a, int b) { return Img2{img_at(a, kImgP), img_at(b, kImgP)}; };
-    int c0, c1, d0c, d1c;
-    kchildren(0, c0, c1);
-    kchildren(1, d0c, d1c);
-    Img2 S0 = load2(c0, c1), S1 = load2(d0c, d1c), S2 = S1;
-    bool x1_in_regs = false;  // wave-uniform: this step's second operand is the previous result
+    auto load2 = [&](int o0, int o1) { return Img2{IMAGE_AT(o0, kImgP), IMAGE_AT(o1, kImgP)}; };
+    StepWords D0 = StepFetch(post_tab), D1 = StepFetch(post_tab + 1), D2;
+    StepWait(D0);
+    StepWait(D1);
+    D2 = D1;
+    Img2 S0 = load2(D0[kC0] * (kImgStride * 8), D0[kC1] * (kImgStride * 8));
+    Img2 S1 = load2(D1[kC0] * (kImgStride * 8), D1[kC1] * (kImgStride * 8)), S2 = S1;
     int k = 0;
-    auto step = [&](auto tip0_c, auto tip1_c, const Img2& cur, Img2& fill) {
+    auto step = [&](auto tip0_c, auto tip1_c, const StepWords& ds, const Img2& cur, StepWords& dfill, Img2& fill) {
       constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
-      const int node = n + k;
       double x0[G], x1[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        if (kTip0) x0[g] = TipOperand(TIP_ADDR(c0, g), st);
-        else x0[g] = CELL(c0, g);
-        if (kTip1) x1[g] = TipOperand(TIP_ADDR(c1, g), st);
+        if (kTip0) x0[g] = TipOperand(TIP_AT(ds[kOff0], g), st);
+        else x0[g] = CELL_AT(ds[kOff0], g);
+        if (kTip1) x1[g] = TipOperand(TIP_AT(ds[kOff1], g), st);
       }
       if (!kTip1) {
-        if (x1_in_regs) {
+        if (ds[kFlags] & kFlagForward) {
 #pragma unroll
           for (int g = 0; g < G; g++) x1[g] = res[g];
         } else {
 #pragma unroll
-          for (int g = 0; g < G; g++) x1[g] = CELL(c1, g);
+          for (int g = 0; g < G; g++) x1[g] = CELL_AT(ds[kOff1], g);
         }
       }
-      int e0, e1;
-      kchildren(k + 2, e0, e1);
-      fill = load2(e0, e1);
+      fill = load2(ds[kPf0], ds[kPf1]);
       double a0[G], a1[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
         a0[g] = Mfma(cur.m0, x0[g], 0.0);
         a1[g] = Mfma(cur.m1, x1[g], 0.0);
       }
+      // scalar fetch of the descriptor two steps ahead, issued where no LDS wait follows soon
+      // (scalar and LDS loads share a counter that can only be waited to zero)
+      __builtin_amdgcn_sched_barrier(0);
+      dfill = StepFetch(post_tab + k + 2);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < G; g++) res[g] = a0[g] * a1[g];
       if (k < NI - 1) {  // the root partial is consumed below, never stored
 #pragma unroll
-        for (int g = 0; g < G; g++) CELL(node, g) = res[g];
+        for (int g = 0; g < G; g++) CELL_AT(ds[kCell], g) = res[g];
       }
-      x1_in_regs = d1c == node;
-      c0 = d0c; c1 = d1c; d0c = e0; d1c = e1;
     };
-    auto dispatch = [&](const Img2& cur, Img2& fill) {
-      const int kind = (c0 < n ? 1 : 0) | (c1 < n ? 2 : 0);
-      if (kind == 3) step(T_{}, T_{}, cur, fill);
-      else if (kind == 1) step(T_{}, F_{}, cur, fill);
-      else if (kind == 0) step(F_{}, F_{}, cur, fill);
-      else step(F_{}, T_{}, cur, fill);
+    auto dispatch = [&](StepWords& ds, const Img2& cur, StepWords& dfill, Img2& fill) {
+      StepWait(ds);  // the descriptor fetched two steps ago
+      const int kind = ds[kFlags] & 3;
+      if (kind == 3) step(T_{}, T_{}, ds, cur, dfill, fill);
+      else if (kind == 1) step(T_{}, F_{}, ds, cur, dfill, fill);
+      else if (kind == 0) step(F_{}, F_{}, ds, cur, dfill, fill);
+      else step(F_{}, T_{}, ds, cur, dfill, fill);
     };
     while (true) {
-      dispatch(S0, S2);
+      dispatch(D0, S0, D2, S2);
       if (++k >= NI) break;
-      dispatch(S1, S0);
+      dispatch(D1, S1, D0, S0);
       if (++k >= NI) break;
-      dispatch(S2, S1);
+      dispatch(D2, S2, D1, S1);
       if (++k >= NI) break;
     }
   }
@@ -305,28 +356,24 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
   if (GRAD) {
     double* my_row = grad_rows + wave * 4 * N;  // [block][edge]
     struct Img { double p0, q0, t0, p1, q1, t1; };  // P, dP, P^T images of the two child branches
-    auto load_img = [&](int a, int b) {
-      return Img{img_at(a, kImgP), img_at(a, kImgDP), img_at(a, kImgPT),
-                 img_at(b, kImgP), img_at(b, kImgDP), img_at(b, kImgPT)};
+    auto load_img = [&](int o0, int o1) {
+      return Img{IMAGE_AT(o0, kImgP), IMAGE_AT(o0, kImgDP), IMAGE_AT(o0, kImgPT),
+                 IMAGE_AT(o1, kImgP), IMAGE_AT(o1, kImgDP), IMAGE_AT(o1, kImgPT)};
     };
-    auto node_children = [&](int nd, int& a, int& b) {
-      const int kk = nd >= n ? nd - n : 0;
-      a = child(kk * 2);
-      b = child(kk * 2 + 1);
-    };
-    int node = N - 1, c0, c1, d0c, d1c;
-    node_children(node, c0, c1);
-    node_children(node - 1, d0c, d1c);
-    Img S0 = load_img(c0, c1), S1 = load_img(d0c, d1c), S2 = S1;
-    // U = pre-order partial of `node`; for the root the stationary frequencies
+    StepWords D0 = StepFetch(pre_tab), D1 = StepFetch(pre_tab + 1), D2;
+    StepWait(D0);
+    StepWait(D1);
+    D2 = D1;
+    Img S0 = load_img(D0[kC0] * (kImgStride * 8), D0[kC1] * (kImgStride * 8));
+    Img S1 = load_img(D1[kC0] * (kImgStride * 8), D1[kC1] * (kImgStride * 8)), S2 = S1;
+    // U = pre-order partial of the step's node; for the root the stationary frequencies
     // (SetRootPreorderPartialsToStateFrequencies, fat_beagle.cpp:327-336).  It stays in
     // registers when the next node is this node's second child (the usual case).
     double U[G];
 #pragma unroll
     for (int g = 0; g < G; g++) U[g] = pi_st;
-    bool u_in_regs = true;
-    // edge sums of the previous step, reduced one step late so that the cross-lane chain
-    // fills the wait for this step's LDS operands
+    // edge sums of the previous step, reduced one step late so that the reduction fills the
+    // wait for this step's LDS operands
     double ps0 = 0.0, ps1 = 0.0;
     int pc0 = N - 1, pc1 = N - 1;  // root entry: the reduce kernel writes 0 there
     // The 64-lane sum of an edge on the matrix pipe: with the per-lane terms as the A operand and
@@ -339,24 +386,22 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
       const double t0 = Mfma(1.0, r0, 0.0), t1 = Mfma(1.0, r1, 0.0);
       if (row_writer) my_row[blk * N + (lane < 32 ? pc0 : pc1)] = lane < 32 ? t0 : t1;
     };
-
-    auto step = [&](auto tip0_c, auto tip1_c, const Img& cur, Img& fill) {
+    int j = 0;
+    auto step = [&](auto tip0_c, auto tip1_c, const StepWords& ds, const Img& cur, StepWords& dfill, Img& fill) {
       constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
       double x0[G], x1[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        if (kTip0) x0[g] = TipOperand(TIP_ADDR(c0, g), st);
-        else x0[g] = CELL(c0, g);
-        if (kTip1) x1[g] = TipOperand(TIP_ADDR(c1, g), st);
-        else x1[g] = CELL(c1, g);
+        if (kTip0) x0[g] = TipOperand(TIP_AT(ds[kOff0], g), st);
+        else x0[g] = CELL_AT(ds[kOff0], g);
+        if (kTip1) x1[g] = TipOperand(TIP_AT(ds[kOff1], g), st);
+        else x1[g] = CELL_AT(ds[kOff1], g);
       }
-      if (!u_in_regs) {
+      if (!(ds[kFlags] & kFlagForward)) {
 #pragma unroll
-        for (int g = 0; g < G; g++) U[g] = CELL(node, g);
+        for (int g = 0; g < G; g++) U[g] = CELL_AT(ds[kCell], g);
       }
-      int e0, e1;
-      node_children(node - 2, e0, e1);
-      fill = load_img(e0, e1);
+      fill = load_img(ds[kPf0], ds[kPf1]);
       flush_edges();
       // this step: all matrix products first, then the element-wise work
       double a0[G], dd0[G], a1[G], dd1[G];
@@ -371,6 +416,8 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
         dd1[g] = Mfma(cur.q1, x1[g], 0.0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      dfill = StepFetch(pre_tab + j + 2);  // see the post-order pass
+      __builtin_amdgcn_sched_barrier(0);
       double ua0[G], ua1[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
@@ -379,7 +426,7 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
       }
       if (!kTip0) {
 #pragma unroll
-        for (int g = 0; g < G; g++) CELL(c0, g) = Mfma(cur.t0, ua1[g], 0.0);
+        for (int g = 0; g < G; g++) CELL_AT(ds[kOff0], g) = Mfma(cur.t0, ua1[g], 0.0);
       }
       if (!kTip1) {
         // the second child's pre-order partial goes straight into U: it is the next
@@ -387,7 +434,7 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
 #pragma unroll
         for (int g = 0; g < G; g++) {
           U[g] = Mfma(cur.t1, ua0[g], 0.0);
-          CELL(c1, g) = U[g];
+          CELL_AT(ds[kOff1], g) = U[g];
         }
       }
       double s0 = 0.0, s1 = 0.0;
@@ -396,29 +443,29 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const int32_t* __restrict__ c
         s0 = fma(coef[g], ua1[g] * dd0[g], s0);
         s1 = fma(coef[g], ua0[g] * dd1[g], s1);
       }
-      u_in_regs = !kTip1 && c1 == node - 1;
-      ps0 = s0; ps1 = s1; pc0 = c0; pc1 = c1;
-      c0 = d0c; c1 = d1c; d0c = e0; d1c = e1;
+      ps0 = s0; ps1 = s1; pc0 = ds[kC0]; pc1 = ds[kC1];
     };
-    auto dispatch = [&](const Img& cur, Img& fill) {
-      const int kind = (c0 < n ? 1 : 0) | (c1 < n ? 2 : 0);
-      if (kind == 3) step(T_{}, T_{}, cur, fill);
-      else if (kind == 1) step(T_{}, F_{}, cur, fill);
-      else if (kind == 0) step(F_{}, F_{}, cur, fill);
-      else step(F_{}, T_{}, cur, fill);
+    auto dispatch = [&](StepWords& ds, const Img& cur, StepWords& dfill, Img& fill) {
+      StepWait(ds);
+      const int kind = ds[kFlags] & 3;
+      if (kind == 3) step(T_{}, T_{}, ds, cur, dfill, fill);
+      else if (kind == 1) step(T_{}, F_{}, ds, cur, dfill, fill);
+      else if (kind == 0) step(F_{}, F_{}, ds, cur, dfill, fill);
+      else step(F_{}, T_{}, ds, cur, dfill, fill);
     };
     while (true) {
-      dispatch(S0, S2);
-      if (--node < n) break;
-      dispatch(S1, S0);
-      if (--node < n) break;
-      dispatch(S2, S1);
-      if (--node < n) break;
+      dispatch(D0, S0, D2, S2);
+      if (++j >= NI) break;
+      dispatch(D1, S1, D0, S0);
+      if (++j >= NI) break;
+      dispatch(D2, S2, D1, S1);
+      if (++j >= NI) break;
     }
     flush_edges();
   }
-#undef TIP_ADDR
-#undef CELL
+#undef TIP_AT
+#undef CELL_AT
+#undef IMAGE_AT
 
   // ---------------- workgroup sums, fixed order -----------------------------
   double wll = ll_acc;
@@ -452,7 +499,7 @@ LdsPlan PlanLds(const BatchDims& d) {
   LdsPlan plan{0, 0, 0, 0};
   const int C = d.category_count;
   if (C != 1 && C != 2 && C != 4) return plan;
-  if (d.taxon_count < 3 || d.taxon_count > 80) return plan;  // child list: three lane tables
+  if (d.taxon_count < 3) return plan;
   // largest G in {1,2,3,4,6,8} that fits, but no more groups than the alignment can fill
   const int candidates[] = {8, 6, 4, 3, 2, 1};
   const int PG = 16 / C;
@@ -474,19 +521,12 @@ static void LaunchWalkLdsCG(const BatchDims& d, const DeviceBatch& b, const LdsP
                             hipStream_t stream) {
   const int units = d.tree_count * plan.tiles;
   const dim3 grid(units), block(kLdsWaves * 64);
-  if (want_gradient) {
-    auto kern = d.taxon_count <= 33 ? walk_lds_kernel<C, G, true, 1> : walk_lds_kernel<C, G, true, 3>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kLdsBudget);
-    hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, b.children, b.images,
-                       b.model, b.tip_states, b.weights, b.part_ll, b.part_grad);
-  } else {
-    auto kern = d.taxon_count <= 33 ? walk_lds_kernel<C, G, false, 1> : walk_lds_kernel<C, G, false, 3>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kLdsBudget);
-    hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, b.children, b.images,
-                       b.model, b.tip_states, b.weights, b.part_ll, b.part_grad);
-  }
+  const StepDesc* sched = reinterpret_cast<const StepDesc*>(b.sched);
+  auto kern = want_gradient ? walk_lds_kernel<C, G, true> : walk_lds_kernel<C, G, false>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsBudget);
+  hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, sched, b.images, b.model,
+                     b.tip_states, b.weights, b.part_ll, b.part_grad);
 }
 
 template <int C>
@@ -501,6 +541,14 @@ static void LaunchWalkLdsC(const BatchDims& d, const DeviceBatch& b, const LdsPl
     case 8: LaunchWalkLdsCG<C, 8>(d, b, plan, want_gradient, stream); break;
     default: break;
   }
+}
+
+size_t LdsScheduleInts(const BatchDims& d) { return (size_t)d.tree_count * 2 * SchedEntries(d.taxon_count - 1) * 8; }
+
+void LaunchLdsSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream) {
+  const int total = d.tree_count * (d.taxon_count - 1);
+  hipLaunchKernelGGL(lds_schedule_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, d, plan.groups,
+                     plan.patterns_per_block, b.children, reinterpret_cast<StepDesc*>(b.sched));
 }
 
 void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
