@@ -241,15 +241,19 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
   const StepDesc* __restrict__ post_tab = sched + (size_t)tree * 2 * SchedEntries(NI);
   const StepDesc* __restrict__ pre_tab = post_tab + SchedEntries(NI);
 
-  // workgroup preamble: tip masks of this tile, zeroed gradient rows
-  for (int q = tid; q < n * PB; q += kLdsWaves * 64) {
-    const int sym = tip_states[(size_t)(q / PB) * Ppad + tile * PB + (q % PB)];
-    tipbuf[q] = (uint8_t)(sym < 4 ? 1 << sym : 15);
+  // Workgroup preamble.  Only one workgroup fits a CU (LDS), so nothing hides its start-up
+  // latency: every global load of the prologue is issued before the first wait -- the first two
+  // step descriptors (scalar), the tile's tip states, the pattern weights and model constants --
+  // and the first matrix images as soon as the descriptors are in.
+  StepWords PD0 = StepFetch(post_tab), PD1 = StepFetch(post_tab + 1);
+  constexpr int kTipBatch = 8;
+  const int tip_total = n * PB;
+  int tip_sym[kTipBatch];
+#pragma unroll
+  for (int u = 0; u < kTipBatch; u++) {
+    const int q = tid + u * kLdsWaves * 64;
+    tip_sym[u] = q < tip_total ? tip_states[(size_t)(q / PB) * Ppad + tile * PB + (q % PB)] : 4;
   }
-  if (GRAD)
-    for (int q = tid; q < kLdsWaves * 4 * N; q += kLdsWaves * 64) grad_rows[q] = 0.0;
-  __syncthreads();
-
   const int loc0 = wave * G * PG + sub * 4 + pj;  // pattern of group 0 inside the tile; group g: + g*PG
   const uint8_t* tip_b = tipbuf + loc0;
   double wgt[G];     // pattern weight
@@ -257,10 +261,28 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
   for (int g = 0; g < G; g++) wgt[g] = weights[tile * PB + loc0 + g * PG];
   const double pi_st = tm->pi[st];
   const double w_cat = tm->cat_weight[cat];
+  StepWait(PD0);
+  StepWait(PD1);
+  struct Img2 { double m0, m1; };
+#define IMAGE_AT(off, which) (*reinterpret_cast<const double*>(img_b + (size_t)((off) + lane8 + (unsigned)((which) * 8))))
+  auto load2 = [&](int o0, int o1) { return Img2{IMAGE_AT(o0, kImgP), IMAGE_AT(o1, kImgP)}; };
+  const Img2 PS0 = load2(PD0[kC0] * (kImgStride * 8), PD0[kC1] * (kImgStride * 8));
+  const Img2 PS1 = load2(PD1[kC0] * (kImgStride * 8), PD1[kC1] * (kImgStride * 8));
+#pragma unroll
+  for (int u = 0; u < kTipBatch; u++) {
+    const int q = tid + u * kLdsWaves * 64;
+    if (q < tip_total) tipbuf[q] = (uint8_t)(tip_sym[u] < 4 ? 1 << tip_sym[u] : 15);
+  }
+  for (int q = tid + kTipBatch * kLdsWaves * 64; q < tip_total; q += kLdsWaves * 64) {  // trees beyond 8*256/PB taxa
+    const int sym = tip_states[(size_t)(q / PB) * Ppad + tile * PB + (q % PB)];
+    tipbuf[q] = (uint8_t)(sym < 4 ? 1 << sym : 15);
+  }
+  if (GRAD)
+    for (int q = tid; q < kLdsWaves * 4 * N; q += kLdsWaves * 64) grad_rows[q] = 0.0;
+  __syncthreads();
 
 #define TIP_AT(off, g) tip_b[(off) + (g) * PG]
 #define CELL_AT(off, g) (*reinterpret_cast<double*>(arena_b + (off) + (g) * 512))
-#define IMAGE_AT(off, which) (*reinterpret_cast<const double*>(img_b + (size_t)((off) + lane8 + (unsigned)((which) * 8))))
   using T_ = std::true_type;
   using F_ = std::false_type;
 
@@ -272,14 +294,8 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
   // one in registers when that step's second child is this node, the common case.
   double res[G];
   {
-    struct Img2 { double m0, m1; };
-    auto load2 = [&](int o0, int o1) { return Img2{IMAGE_AT(o0, kImgP), IMAGE_AT(o1, kImgP)}; };
-    StepWords D0 = StepFetch(post_tab), D1 = StepFetch(post_tab + 1), D2;
-    StepWait(D0);
-    StepWait(D1);
-    D2 = D1;
-    Img2 S0 = load2(D0[kC0] * (kImgStride * 8), D0[kC1] * (kImgStride * 8));
-    Img2 S1 = load2(D1[kC0] * (kImgStride * 8), D1[kC1] * (kImgStride * 8)), S2 = S1;
+    StepWords D0 = PD0, D1 = PD1, D2 = PD1;
+    Img2 S0 = PS0, S1 = PS1, S2 = PS1;
     int k = 0;
     auto step = [&](auto tip0_c, auto tip1_c, const StepWords& ds, const Img2& cur, StepWords& dfill, Img2& fill) {
       constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
