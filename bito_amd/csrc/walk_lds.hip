@@ -153,8 +153,16 @@ struct alignas(32) StepDesc {
 };
 // A descriptor is fetched with an explicit scalar load: the compiler only selects s_load for
 // memory it can prove unclobbered, which it does not here.  The caller waits (lgkmcnt) before
-// the first use: StepFetch two steps ahead, StepWait at the top of every step.
+// the first use: StepFetch two steps ahead, StepWait one step ahead (mid-step, where it is free).
 typedef unsigned StepWords __attribute__((ext_vector_type(8)));
+// Pull 64 bytes (two descriptors) into the scalar cache; the data itself is discarded.
+typedef unsigned WarmWords __attribute__((ext_vector_type(16)));
+// (The destination tuple is an in/out operand that stays live up to a final wait: the load
+// lands asynchronously, so its registers must not be handed to anything else meanwhile.)
+__device__ __forceinline__ void StepWarm(const StepDesc* p, WarmWords& w) {
+  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "+s"(w) : "s"(p));
+}
+__device__ __forceinline__ void StepWarmDone(WarmWords& w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w)::"memory"); }
 __device__ __forceinline__ StepWords StepFetch(const StepDesc* p) {
   StepWords w;
   asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(w) : "s"(p));
@@ -245,6 +253,8 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
   // latency: every global load of the prologue is issued before the first wait -- the first two
   // step descriptors (scalar), the tile's tip states, the pattern weights and model constants --
   // and the first matrix images as soon as the descriptors are in.
+  // Both step tables (2 x (NI+2) x 32 B) are pulled into the scalar cache now: a step's descriptor
+  // fetch then never waits on L2, which matters because scalar loads share their counter with LDS.
   StepWords PD0 = StepFetch(post_tab), PD1 = StepFetch(post_tab + 1);
   constexpr int kTipBatch = 8;
   const int tip_total = n * PB;
@@ -268,6 +278,9 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
   auto load2 = [&](int o0, int o1) { return Img2{IMAGE_AT(o0, kImgP), IMAGE_AT(o1, kImgP)}; };
   const Img2 PS0 = load2(PD0[kC0] * (kImgStride * 8), PD0[kC1] * (kImgStride * 8));
   const Img2 PS1 = load2(PD1[kC0] * (kImgStride * 8), PD1[kC1] * (kImgStride * 8));
+  // (issued behind the image loads: its latency hides under theirs and the tip states')
+  WarmWords warm = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * SchedEntries(NI); i += 2) StepWarm(post_tab + i, warm);
 #pragma unroll
   for (int u = 0; u < kTipBatch; u++) {
     const int q = tid + u * kLdsWaves * 64;
@@ -279,6 +292,7 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
   }
   if (GRAD)
     for (int q = tid; q < kLdsWaves * 4 * N; q += kLdsWaves * 64) grad_rows[q] = 0.0;
+  StepWarmDone(warm);
   __syncthreads();
 
 #define TIP_AT(off, g) tip_b[(off) + (g) * PG]
@@ -297,7 +311,8 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
     StepWords D0 = PD0, D1 = PD1, D2 = PD1;
     Img2 S0 = PS0, S1 = PS1, S2 = PS1;
     int k = 0;
-    auto step = [&](auto tip0_c, auto tip1_c, const StepWords& ds, const Img2& cur, StepWords& dfill, Img2& fill) {
+    auto step = [&](auto tip0_c, auto tip1_c, const StepWords& ds, const Img2& cur, StepWords& nd, StepWords& dfill,
+                    Img2& fill) {
       constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
       double x0[G], x1[G];
 #pragma unroll
@@ -325,6 +340,10 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
       // scalar fetch of the descriptor two steps ahead, issued where no LDS wait follows soon
       // (scalar and LDS loads share a counter that can only be waited to zero)
       __builtin_amdgcn_sched_barrier(0);
+      // Every LDS access issued so far has been consumed, so waiting the shared counter to zero
+      // here is free: it confirms the NEXT step's descriptor (fetched a step ago), and the top of
+      // a step then needs no wait -- this step's LDS stores drain under the next step's loads.
+      StepWait(nd);
       dfill = StepFetch(post_tab + k + 2);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -334,20 +353,19 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
         for (int g = 0; g < G; g++) CELL_AT(ds[kCell], g) = res[g];
       }
     };
-    auto dispatch = [&](StepWords& ds, const Img2& cur, StepWords& dfill, Img2& fill) {
-      StepWait(ds);  // the descriptor fetched two steps ago
+    auto dispatch = [&](const StepWords& ds, const Img2& cur, StepWords& nd, StepWords& dfill, Img2& fill) {
       const int kind = ds[kFlags] & 3;
-      if (kind == 3) step(T_{}, T_{}, ds, cur, dfill, fill);
-      else if (kind == 1) step(T_{}, F_{}, ds, cur, dfill, fill);
-      else if (kind == 0) step(F_{}, F_{}, ds, cur, dfill, fill);
-      else step(F_{}, T_{}, ds, cur, dfill, fill);
+      if (kind == 3) step(T_{}, T_{}, ds, cur, nd, dfill, fill);
+      else if (kind == 1) step(T_{}, F_{}, ds, cur, nd, dfill, fill);
+      else if (kind == 0) step(F_{}, F_{}, ds, cur, nd, dfill, fill);
+      else step(F_{}, T_{}, ds, cur, nd, dfill, fill);
     };
     while (true) {
-      dispatch(D0, S0, D2, S2);
+      dispatch(D0, S0, D1, D2, S2);
       if (++k >= NI) break;
-      dispatch(D1, S1, D0, S0);
+      dispatch(D1, S1, D2, D0, S0);
       if (++k >= NI) break;
-      dispatch(D2, S2, D1, S1);
+      dispatch(D2, S2, D0, D1, S1);
       if (++k >= NI) break;
     }
   }
@@ -357,6 +375,7 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
   // (lane bits 4,5) and the category bits (lane bits 2..3 as far as C uses them).
   double ll_acc = 0.0;
   double coef[G];  // w_c * w_p / L_p for this lane's (category, pattern)
+  double Ls[G];
 #pragma unroll
   for (int g = 0; g < G; g++) {
     double L = res[g] * (pi_st * w_cat);
@@ -364,8 +383,24 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
     L += __shfl_xor(L, 32);
     if (C >= 2) L += __shfl_xor(L, 4);
     if (C == 4) L += __shfl_xor(L, 8);
-    if (st == 0 && cat == 0) ll_acc += wgt[g] * (log(L) - n * 0.6931471805599453);
+    Ls[g] = L;  // the same value on every (state, category) lane of a pattern
     coef[g] = w_cat * (wgt[g] / L);
+  }
+  // log-likelihood: each (group, pattern) is counted on the lane whose (state, category) index
+  // equals the group number, so one log() call serves 4C groups instead of one call per group
+  {
+    const int sel = st * C + cat;
+#pragma unroll
+    for (int g0 = 0; g0 < G; g0 += 4 * C) {
+      double Lsel = 1.0, wsel = 0.0;
+#pragma unroll
+      for (int g = g0; g < G && g < g0 + 4 * C; g++)
+        if (sel == g - g0) {
+          Lsel = Ls[g];
+          wsel = wgt[g];
+        }
+      ll_acc += wsel * (log(Lsel) - n * 0.6931471805599453);
+    }
   }
 
   // ---------------- pre-order + edge derivatives ----------------------------
@@ -403,7 +438,8 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
       if (row_writer) my_row[blk * N + (lane < 32 ? pc0 : pc1)] = lane < 32 ? t0 : t1;
     };
     int j = 0;
-    auto step = [&](auto tip0_c, auto tip1_c, const StepWords& ds, const Img& cur, StepWords& dfill, Img& fill) {
+    auto step = [&](auto tip0_c, auto tip1_c, const StepWords& ds, const Img& cur, StepWords& nd, StepWords& dfill,
+                    Img& fill) {
       constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
       double x0[G], x1[G];
 #pragma unroll
@@ -432,7 +468,8 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
         dd1[g] = Mfma(cur.q1, x1[g], 0.0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      dfill = StepFetch(pre_tab + j + 2);  // see the post-order pass
+      StepWait(nd);  // free here, see the post-order pass
+      dfill = StepFetch(pre_tab + j + 2);
       __builtin_amdgcn_sched_barrier(0);
       double ua0[G], ua1[G];
 #pragma unroll
@@ -461,20 +498,19 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
       }
       ps0 = s0; ps1 = s1; pc0 = ds[kC0]; pc1 = ds[kC1];
     };
-    auto dispatch = [&](StepWords& ds, const Img& cur, StepWords& dfill, Img& fill) {
-      StepWait(ds);
+    auto dispatch = [&](const StepWords& ds, const Img& cur, StepWords& nd, StepWords& dfill, Img& fill) {
       const int kind = ds[kFlags] & 3;
-      if (kind == 3) step(T_{}, T_{}, ds, cur, dfill, fill);
-      else if (kind == 1) step(T_{}, F_{}, ds, cur, dfill, fill);
-      else if (kind == 0) step(F_{}, F_{}, ds, cur, dfill, fill);
-      else step(F_{}, T_{}, ds, cur, dfill, fill);
+      if (kind == 3) step(T_{}, T_{}, ds, cur, nd, dfill, fill);
+      else if (kind == 1) step(T_{}, F_{}, ds, cur, nd, dfill, fill);
+      else if (kind == 0) step(F_{}, F_{}, ds, cur, nd, dfill, fill);
+      else step(F_{}, T_{}, ds, cur, nd, dfill, fill);
     };
     while (true) {
-      dispatch(D0, S0, D2, S2);
+      dispatch(D0, S0, D1, D2, S2);
       if (++j >= NI) break;
-      dispatch(D1, S1, D0, S0);
+      dispatch(D1, S1, D2, D0, S0);
       if (++j >= NI) break;
-      dispatch(D2, S2, D1, S1);
+      dispatch(D2, S2, D0, D1, S1);
       if (++j >= NI) break;
     }
     flush_edges();
