@@ -21,17 +21,17 @@ GRAD_STICKBREAKING = 8
 GRAD_RATIOS_ROOT_HEIGHT = 16
 GRAD_LOG_DET_JACOBIAN_GRADIENT = 32
 
-KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS, KERNEL_LDS_TREE = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS, KERNEL_LDS_TREE, KERNEL_GENERAL = 0, 1, 2, 3, 4
 
 # Every symbol include/bito_amd.h declares (tests check that the library exports them all).
 SYMBOLS = [
     "bito_amd_engine_create", "bito_amd_engine_destroy", "bito_amd_engine_last_error",
-    "bito_amd_engine_param_count", "bito_amd_engine_category_count", "bito_amd_engine_block_count",
+    "bito_amd_engine_param_count", "bito_amd_engine_category_count", "bito_amd_engine_state_count", "bito_amd_engine_block_count",
     "bito_amd_engine_block", "bito_amd_engine_log_likelihoods", "bito_amd_engine_gradients",
     "bito_amd_engine_upload", "bito_amd_engine_update", "bito_amd_engine_run", "bito_amd_engine_sync",
     "bito_amd_engine_download", "bito_amd_engine_set_kernel", "bito_amd_engine_time_runs",
     "bito_amd_engine_kernel_timing", "bito_amd_engine_kernel_elapsed", "bito_amd_engine_kernel_name",
-    "bito_amd_version",
+    "bito_amd_version", "bito_amd_engine_read_general_model",
     "bito_amd_engine_time_trees_from_branch_lengths", "bito_amd_engine_time_trees_from_height_ratios",
     "bito_amd_engine_log_det_jacobian", "bito_amd_engine_gradient_log_det_jacobian",
     "bito_amd_engine_ratio_gradient_of_height_gradient", "bito_amd_engine_time_tree_log_likelihoods",
@@ -65,7 +65,7 @@ def lib():
     L.bito_amd_engine_destroy.argtypes = [vp]
     L.bito_amd_engine_last_error.restype = C.c_char_p
     L.bito_amd_engine_last_error.argtypes = [vp]
-    for name in ("param_count", "category_count", "block_count"):
+    for name in ("param_count", "category_count", "state_count", "block_count"):
         fn = getattr(L, f"bito_amd_engine_{name}")
         fn.restype = C.c_int32
         fn.argtypes = [vp]
@@ -83,6 +83,7 @@ def lib():
     L.bito_amd_engine_time_runs.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, ip]
     L.bito_amd_engine_kernel_timing.argtypes = [vp, C.c_int32]
     L.bito_amd_engine_kernel_elapsed.argtypes = [vp, dp, ip]
+    L.bito_amd_engine_read_general_model.argtypes = [vp, C.c_int32, dp, C.c_size_t]
     L.bito_amd_engine_kernel_name.restype = C.c_char_p
     L.bito_amd_engine_kernel_name.argtypes = [vp]
     L.bito_amd_engine_time_trees_from_branch_lengths.argtypes = [vp, C.c_int32, ip, dp, dp, dp, dp, dp]

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/bito_amd.h"
@@ -72,6 +73,8 @@ struct bito_amd_engine {
   DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
       out_ll, out_grad, scale_arena;
   DeviceBuffer<TreeModel> model;
+  DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
+  DeviceBuffer<int32_t> gs_model_index;  // [T] first tree with the same parameter row
   // time-tree transforms (row f2): staging for host inputs, scratch and results
   DeviceBuffer<int32_t> tt_parents;
   DeviceBuffer<double> tt_heights, tt_bounds, tt_ratios, tt_in, tt_work, tt_out, tt_aux;
@@ -87,7 +90,7 @@ struct bito_amd_engine {
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
     tip_states.Free(); weights.Free(); parent_ids.Free(); children.Free(); branch_in.Free();
     rates.Free(); params.Free(); branch.Free(); mats.Free(); images.Free(); arena.Free(); scale_arena.Free(); part_ll.Free();
-    part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free(); sched.Free();
+    part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
     tt_out.Free(); tt_aux.Free();
     if (stream) (void)hipStreamDestroy(stream);
@@ -118,6 +121,7 @@ int ParseSpec(const char* sub, const char* site, const char* clock, ModelSpec* m
   if (s == "JC69") m->substitution = kJC69;
   else if (s == "HKY") m->substitution = kHKY;
   else if (s == "GTR") m->substitution = kGTR;
+  else if (s == "GY94") m->substitution = kGY94;  // 61-state codon model: defined by this build (bito_amd.h)
   else { *err = "Substitution model not known: " + s; return BITO_AMD_ERR_BAD_MODEL; }
   if (si == "constant") {
     m->weibull = 0;
@@ -142,7 +146,7 @@ int ParseSpec(const char* sub, const char* site, const char* clock, ModelSpec* m
     m->freq_start = at;
     at += 4;
     m->rates_start = at;
-    m->rates_len = (m->substitution == kGTR) ? 6 : 1;
+    m->rates_len = (m->substitution == kGTR) ? 6 : (m->substitution == kGY94 ? 2 : 1);
     at += m->rates_len;
     blocks->push_back({"substitution_model_frequencies", m->freq_start, 4});
     blocks->push_back({"substitution_model_rates", m->rates_start, m->rates_len});
@@ -159,6 +163,7 @@ int ParseSpec(const char* sub, const char* site, const char* clock, ModelSpec* m
     blocks->push_back({"entire_clock", m->clock_start, 1});
   }
   m->param_count = at;
+  m->state_count = (m->substitution == kGY94) ? 61 : 4;
   blocks->push_back({"entire", 0, at});
   return BITO_AMD_OK;
 }
@@ -167,7 +172,7 @@ int ParseSpec(const char* sub, const char* site, const char* clock, ModelSpec* m
 int ValidateParams(bito_amd_engine* e, int tree_count, const double* params) {
   const ModelSpec& m = e->spec;
   if (m.substitution == kJC69) return BITO_AMD_OK;
-  const char* name = m.substitution == kGTR ? "GTR" : "HKY";
+  const char* name = m.substitution == kGTR ? "GTR" : (m.substitution == kGY94 ? "GY94" : "HKY");
   for (int t = 0; t < tree_count; t++) {
     const double* row = params + (size_t)t * m.param_count;
     const double* f = row + m.freq_start;
@@ -177,6 +182,14 @@ int ValidateParams(bito_amd_engine* e, int tree_count, const double* params) {
                     "%s frequencies do not sum to 1 +/- 0.001! frequency vector: (%g,%g,%g,%g) [tree %d]",
                     name, f[0], f[1], f[2], f[3], t);
       return Fail(e, BITO_AMD_ERR_BAD_PARAMS, buf);
+    }
+    if (m.substitution == kGY94) {
+      const double* r = row + m.rates_start;
+      if (!(r[0] > 0.) || !(r[1] > 0.)) {
+        char buf[256];
+        std::snprintf(buf, sizeof(buf), "GY94 kappa and omega must be positive: (%g,%g) [tree %d]", r[0], r[1], t);
+        return Fail(e, BITO_AMD_ERR_BAD_PARAMS, buf);
+      }
     }
     if (m.substitution == kGTR) {
       const double* r = row + m.rates_start;
@@ -235,6 +248,22 @@ int ValidateTrees(bito_amd_engine* e, int tree_count, int rooted, int node_count
   return BITO_AMD_OK;
 }
 
+// General-state path: trees whose parameter rows are bit-identical share one model record (rate
+// matrix, eigensystem); index[t] = first tree carrying t's row.
+int UploadModelIndex(bito_amd_engine* e, int tree_count, const double* params) {
+  const int pc = e->spec.param_count;
+  std::vector<int32_t> index(tree_count);
+  std::unordered_map<std::string, int32_t> first;
+  for (int t = 0; t < tree_count; t++) {
+    std::string key(reinterpret_cast<const char*>(params + (size_t)t * pc), pc * sizeof(double));
+    index[t] = first.emplace(std::move(key), t).first->second;
+  }
+  HIP_TRY(e, e->gs_model_index.Reserve(tree_count));
+  HIP_TRY(e, hipMemcpyAsync(e->gs_model_index.ptr, index.data(), tree_count * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return BITO_AMD_OK;
+}
+
 DeviceBatch MakeBatch(bito_amd_engine* e) {
   DeviceBatch b{};
   b.parent_ids = e->parent_ids.ptr;
@@ -267,12 +296,56 @@ hipEvent_t NextEvent(bito_amd_engine* e) {
   return e->ev_pool[e->ev_used++];
 }
 
+// General-state-count path (gs_kernels.hip): the codon model, or a 4-state model when the
+// general kernels are selected explicitly.  Trees are processed in chunks sized so that a chunk's
+// matrix records and PLV arena fit the arena budget.
+int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_mode) {
+  if (rescaling)
+    return Fail(e, BITO_AMD_ERR_STATE,
+                "rescaling is not available on the general-state kernels yet (the 4-state kernels provide it)");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const BatchDims& d = e->dims;
+  const int T = d.tree_count, S = e->spec.state_count;
+  if (e->gs_model_index.capacity < (size_t)T)
+    return Fail(e, BITO_AMD_ERR_STATE, "select the general-state kernels before uploading the batch");
+  const int tiles = GsTiles(d.pattern_count);
+  const size_t img_per_tree = GsImageDoublesPerTree(d), arena_per_tree = GsArenaDoublesPerTree(d, tiles);
+  const size_t per_tree = (img_per_tree + arena_per_tree) * sizeof(double);
+  size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
+  chunk = std::min<size_t>(chunk, 65535);
+  HIP_TRY(e, e->gs_model.Reserve((size_t)T * kGsModelStride));
+  HIP_TRY(e, e->images.Reserve(chunk * img_per_tree));
+  HIP_TRY(e, e->arena.Reserve(chunk * arena_per_tree));
+  HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
+  if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
+  const DeviceBatch b = MakeBatch(e);
+  LaunchGsSetup(d, e->spec, b, e->gs_model_index.ptr, e->gs_model.ptr, e->stream);
+  for (int t0 = 0; t0 < T; t0 += (int)chunk) {
+    const int ct = std::min<int>((int)chunk, T - t0);
+    LaunchGsMatrices(d, S, t0, ct, e->branch.ptr, e->gs_model_index.ptr, e->gs_model.ptr, e->images.ptr, want_gradient, deriv_mode, e->stream);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e->timing) {
+      ev0 = NextEvent(e);
+      ev1 = NextEvent(e);
+      HIP_TRY(e, hipEventRecord(ev0, e->stream));
+    }
+    LaunchGsWalk(d, S, b, e->gs_model_index.ptr, e->gs_model.ptr, t0, ct, tiles, want_gradient, e->stream);
+    if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
+  }
+  e->kernel_name = "gs_walk_kernel";
+  LaunchReduce(d, b, tiles, want_gradient, e->stream);
+  HIP_TRY(e, hipGetLastError());
+  return BITO_AMD_OK;
+}
+
 int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_mode = 0) {
   if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
   HIP_TRY(e, hipSetDevice(e->device));
   const BatchDims& d = e->dims;
   const int T = d.tree_count;
   const size_t NB = (size_t)d.node_count - 1;
+  if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL)
+    return RunResidentGeneral(e, want_gradient, rescaling, deriv_mode);
   // Kernel choice: the LDS-resident MFMA walk when the tree fits in LDS and no rescaling
   // is requested, otherwise the HBM-arena walk.
   const LdsPlan plan = PlanLds(d);
@@ -416,12 +489,13 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
   e->arena_limit = (spec && spec->arena_bytes) ? spec->arena_bytes : std::max<size_t>(free_b / 4, (size_t)1 << 28);
   // Compact tip states, gap for every symbol >= 4 and for the padding columns
   // (SitePattern symbol table, reference src/site_pattern.cpp:16-46).
-  std::vector<uint8_t> tips((size_t)e->n * e->Ppad, 4);
+  const int S = e->spec.state_count;
+  std::vector<uint8_t> tips((size_t)e->n * e->Ppad, (uint8_t)S);
   for (int t = 0; t < e->n; t++)
     for (int p = 0; p < e->P; p++) {
       const int32_t s = patterns[(size_t)t * e->P + p];
       if (s < 0) { delete e; return report(BITO_AMD_ERR_BAD_ARG, "negative pattern symbol"); }
-      tips[(size_t)t * e->Ppad + p] = (uint8_t)(s >= 4 ? 4 : s);
+      tips[(size_t)t * e->Ppad + p] = (uint8_t)(s >= S ? S : s);
     }
   std::vector<double> w(e->Ppad, 0.0);
   std::copy(weights, weights + e->P, w.begin());
@@ -441,6 +515,7 @@ const char* bito_amd_engine_last_error(const bito_amd_engine* e) { return e ? e-
 
 int32_t bito_amd_engine_param_count(const bito_amd_engine* e) { return e->spec.param_count; }
 int32_t bito_amd_engine_category_count(const bito_amd_engine* e) { return e->spec.category_count; }
+int32_t bito_amd_engine_state_count(const bito_amd_engine* e) { return e->spec.state_count; }
 int32_t bito_amd_engine_block_count(const bito_amd_engine* e) { return (int32_t)e->blocks.size(); }
 
 int bito_amd_engine_block(const bito_amd_engine* e, int32_t idx, char* name, size_t name_len,
@@ -481,6 +556,10 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * M * sizeof(double), hipMemcpyHostToDevice, e->stream));
   if (e->spec.param_count > 0)
     HIP_TRY(e, hipMemcpyAsync(e->params.ptr, params, T * e->spec.param_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL) {
+    static const double none = 0.0;
+    if ((rc = UploadModelIndex(e, tree_count, e->spec.param_count > 0 ? params : &none))) return rc;
+  }
   e->has_rates = rooted && rates != nullptr;
   if (e->has_rates) {
     HIP_TRY(e, e->rates.Reserve(T * (M - 1)));
@@ -508,6 +587,8 @@ int bito_amd_engine_update(bito_amd_engine* e, const double* branch_lengths, con
     int rc = ValidateParams(e, (int)T, params);
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(e->params.ptr, params, T * e->spec.param_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL)
+      if ((rc = UploadModelIndex(e, (int)T, params))) return rc;
   }
   if (branch_lengths)
     HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * e->dims.in_node_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -907,6 +988,19 @@ int bito_amd_engine_kernel_elapsed(bito_amd_engine* e, double* kernel_ms, int32_
   e->ev_used = 0;
   if (kernel_ms) *kernel_ms = k;
   if (kernel_launches) *kernel_launches = launches;
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_read_general_model(bito_amd_engine* e, int32_t tree, double* out, size_t capacity) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  if (!e->resident || tree < 0 || tree >= e->dims.tree_count || !e->gs_model.ptr || !e->gs_model_index.ptr)
+    return Fail(e, BITO_AMD_ERR_STATE, "no general-state model is resident for that tree");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  const size_t count = std::min<size_t>(capacity, (size_t)kGsModelStride);
+  int32_t slot = tree;
+  HIP_TRY(e, hipMemcpy(&slot, e->gs_model_index.ptr + tree, sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(e, hipMemcpy(out, e->gs_model.ptr + (size_t)slot * kGsModelStride, count * sizeof(double), hipMemcpyDeviceToHost));
   return BITO_AMD_OK;
 }
 

@@ -1,0 +1,627 @@
+// gs_kernels.hip -- general-state-count likelihood path for gfx950 (BASELINE config 5: the 61-state
+// codon model; any state count up to 64 runs through the same kernels).
+//
+// Same pipeline as the 4-state path (kernels.hip), same reference rows:
+//   gs_setup_kernel     topology + rate matrix + eigendecomposition of the symmetrised matrix
+//                       (src/substitution_model.cpp:120-187, src/site_model.cpp:37-62); one wave
+//                       per tree, the 64x64 Jacobi iteration runs out of LDS
+//   gs_matrices_kernel  P(t r_c) = V exp(Lambda t r_c) V^-1 and dP/dt for every branch and
+//                       category (beagleUpdateTransitionMatrices, src/fat_beagle.cpp:315-325),
+//                       written as MFMA A-operand images (internal branches) or transposed tip
+//                       look-up tables (leaf branches)
+//   gs_walk_kernel      post-order partials + root log-likelihood (src/fat_beagle.cpp:54-68) and the
+//                       fused pre-order pass + edge derivatives (:138-160); a wave owns 16 site
+//                       patterns of one tree and walks the whole tree; the states x states
+//                       contraction is v_mfma_f64_16x16x4 with the partial-likelihood vector kept in
+//                       the instruction's own D/B register layout from step to step
+// The reference has no model with more than four states; the codon model ("GY94") is defined by
+// this build (include/bito_amd.h) and checked against the CPU restatement the tests hold.
+//
+// FP64 throughout, no atomics, every sum in a fixed order.
+#include "kernels.hpp"
+
+namespace bito_amd {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int kLd = 65;  // LDS row stride of the 64 x 64 work matrices (odd: column walks hit all banks)
+
+// Standard genetic code, TCAG order; bito's nucleotides are A,C,G,T = 0..3.
+__device__ const char kCodeTCAG[65] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+
+__device__ __forceinline__ double WaveMax(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double WaveSum64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------
+// Set-up, part 1: one wave per tree -- topology, rate matrix, its symmetrised form.  The arithmetic
+// order is fixed and documented in DESIGN.md section 3 (no FMA contraction): errors in P(t) are
+// coherent across site patterns.  Trees whose parameter row equals an earlier tree's share that
+// tree's model record (model_index, built by the host while it validates the rows).
+
+__global__ void __launch_bounds__(64)
+gs_model_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, const int32_t* __restrict__ model_index,
+                double* __restrict__ gs_model) {
+#pragma clang fp contract(off)
+  __shared__ double A[64 * kLd];
+  __shared__ double pi[64], sq[64], rowsum[64];
+  __shared__ int codon[64];  // n1 | n2<<2 | n3<<4 | aa<<8
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int S = spec.state_count;
+  if (lane == 0) SetupTopology(d, b, t);
+  if (model_index[t] != t) return;
+  const double* __restrict__ row = b.params + (size_t)t * spec.param_count;
+  double* __restrict__ out = gs_model + (size_t)t * kGsModelStride;
+
+  for (int j = 0; j < 64; j++) A[lane * kLd + j] = 0.0;
+  rowsum[lane] = 0.0;
+  double mypi = 0.0;
+  if (spec.substitution == kGY94) {
+    // sense codons in lexicographic ACGT order: lane = raw codon, state = rank among sense codons
+    {
+      const int a = lane >> 4, bq = (lane >> 2) & 3, c = lane & 3;
+      const int to_tcag[4] = {2, 1, 3, 0};
+      const char aa = kCodeTCAG[16 * to_tcag[a] + 4 * to_tcag[bq] + to_tcag[c]];
+      const bool sense = aa != '*';
+      const unsigned long long mask = __ballot(sense);
+      const int state = __popcll(mask & ((1ull << lane) - 1ull));
+      if (sense) codon[state] = a | (bq << 2) | (c << 4) | ((int)aa << 8);
+    }
+    __syncthreads();
+    const double f[4] = {row[spec.freq_start], row[spec.freq_start + 1], row[spec.freq_start + 2],
+                         row[spec.freq_start + 3]};
+    const double kappa = row[spec.rates_start], omega = row[spec.rates_start + 1];
+    double praw = 0.0;
+    if (lane < S) {
+      const int cd = codon[lane];
+      praw = (f[cd & 3] * f[(cd >> 2) & 3]) * f[(cd >> 4) & 3];  // F1x4
+    }
+    pi[lane] = praw;
+    __syncthreads();
+    double tot = 0.0;
+    for (int j = 0; j < S; j++) tot += pi[j];
+    __syncthreads();
+    mypi = lane < S ? praw / tot : 0.0;
+    pi[lane] = mypi;
+    __syncthreads();
+    if (lane < S) {
+      const int ci = codon[lane];
+      double rs = 0.0;
+      for (int j = 0; j < S; j++) {
+        if (j == lane) continue;
+        const int cj = codon[j];
+        const int x = (ci ^ cj) & 63;
+        const int d0 = (x & 3) != 0, d1 = (x & 12) != 0, d2 = (x & 48) != 0;
+        double q = 0.0;
+        if (d0 + d1 + d2 == 1) {
+          const int sh = d0 ? 0 : (d1 ? 2 : 4);
+          q = pi[j];
+          if ((((ci >> sh) ^ (cj >> sh)) & 3) == 2) q *= kappa;  // transition: A<->G, C<->T
+          if ((ci >> 8) != (cj >> 8)) q *= omega;                // amino acid changes
+        }
+        A[lane * kLd + j] = q;
+        rs += q;
+      }
+      A[lane * kLd + lane] = -rs;
+      rowsum[lane] = rs;
+    }
+  } else {
+    // 4-state models through the general path: GTR, and JC69 / HKY written as GTR
+    // (GTRModel::UpdateQMatrix, src/substitution_model.cpp:141-166)
+    double r[6] = {1. / 6, 1. / 6, 1. / 6, 1. / 6, 1. / 6, 1. / 6}, f[4] = {0.25, 0.25, 0.25, 0.25};
+    if (spec.substitution != kJC69)
+      for (int i = 0; i < 4; i++) f[i] = row[spec.freq_start + i];
+    if (spec.substitution == kGTR)
+      for (int i = 0; i < 6; i++) r[i] = row[spec.rates_start + i];
+    if (spec.substitution == kHKY) {
+      const double kappa = row[spec.rates_start];
+      r[0] = r[2] = r[3] = r[5] = 1.0;
+      r[1] = r[4] = kappa;
+    }
+    mypi = lane < 4 ? f[lane] : 0.0;
+    pi[lane] = mypi;
+    if (lane < 4) {
+      double rs = 0.0;
+      for (int j = 0; j < 4; j++) {
+        if (j == lane) continue;
+        const int lo = lane < j ? lane : j, hi = lane < j ? j : lane;
+        const int k = lo == 0 ? hi - 1 : (lo == 1 ? hi + 1 : 5);  // AC,AG,AT,CG,CT,GT
+        const double q = r[k] * f[j];
+        A[lane * kLd + j] = q;
+        rs += q;
+      }
+      A[lane * kLd + lane] = -rs;
+      rowsum[lane] = rs;
+    }
+  }
+  __syncthreads();
+  double total = 0.0;
+  for (int i = 0; i < S; i++) total += rowsum[i] * pi[i];
+  if (lane < S)
+    for (int j = 0; j < S; j++) A[lane * kLd + j] /= total;
+  __syncthreads();
+  for (int i = 0; i < 64; i++) out[kGsQ + i * 64 + lane] = A[i * kLd + lane];
+  // symmetrise: D^{1/2} Q D^{-1/2}, lower triangle computed, upper mirrored; parked in the V slot
+  // of the record until the eigensolver kernel replaces it
+  const double mysq = lane < S ? sqrt(mypi) : 1.0;
+  sq[lane] = mysq;
+  __syncthreads();
+  for (int j = 0; j <= lane; j++) A[lane * kLd + j] = mysq * A[lane * kLd + j] / sq[j];
+  __syncthreads();
+  for (int j = lane + 1; j < 64; j++) A[lane * kLd + j] = A[j * kLd + lane];
+  __syncthreads();
+  for (int i = 0; i < 64; i++) out[kGsV + i * 64 + lane] = A[i * kLd + lane];
+  out[kGsPi + lane] = mypi;
+  out[kGsSq + lane] = mysq;
+  if (lane == 0) {
+    // WeibullSiteModel::UpdateRates (src/site_model.cpp:37-62), as SetupTreeModel
+    const int C = spec.category_count;
+    double* rate = out + kGsCatRate;
+    double* weight = out + kGsCatWeight;
+    double* deriv = out + kGsCatRateDeriv;
+    if (spec.weibull) {
+      const double shape = row[spec.shape_start];
+      double mean = 0, dmean = 0;
+      double du[kMaxCategories];
+      for (int i = 0; i < C; i++) {
+        const double quantile = (2.0 * i + 1.0) / (2.0 * C);
+        const double l = -log(1.0 - quantile);
+        const double rr = pow(l, 1.0 / shape);
+        rate[i] = rr;
+        mean += rr;
+        du[i] = -rr * log(l) / (shape * shape);
+        dmean += du[i];
+      }
+      mean /= C;
+      dmean /= C;
+      for (int i = 0; i < C; i++) {
+        deriv[i] = (du[i] * mean - rate[i] * dmean) / (mean * mean);
+        rate[i] /= mean;
+        weight[i] = 1.0 / C;
+      }
+    } else {
+      rate[0] = 1.0;
+      weight[0] = 1.0;
+      deriv[0] = 0.0;
+    }
+  }
+}
+
+// Set-up, part 2: symmetric eigensolve, one workgroup (4 waves) per distinct model.  Jacobi
+// iteration with the round-robin ordering: 63 rounds of 32 independent rotations per sweep; all
+// angles of a round are taken first, then the column updates (A and U), then the row updates, then
+// the annihilated pairs are set to exactly zero.  Wave g owns pairs 8 g .. 8 g + 7 of a round;
+// their LDS traffic is issued as eight independent streams.
+__device__ __forceinline__ void GsPair(int r, int k, int& p, int& q) {
+  const int a = k == 0 ? 63 : (r + k) % 63;
+  const int bb = k == 0 ? r : (r - k + 63) % 63;
+  p = a < bb ? a : bb;
+  q = a < bb ? bb : a;
+}
+
+__global__ void __launch_bounds__(256)
+gs_eigen_kernel(const int32_t* __restrict__ model_index, double* __restrict__ gs_model) {
+#pragma clang fp contract(off)
+  __shared__ double A[64 * kLd];
+  __shared__ double U[64 * kLd];
+  __shared__ double cs[32], sn[32], wmax[4];
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  if (model_index[t] != t) return;
+  double* __restrict__ out = gs_model + (size_t)t * kGsModelStride;
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int i = idx >> 6, j = idx & 63;
+    A[i * kLd + j] = out[kGsV + idx];
+    U[i * kLd + j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double mo = 0.0;
+    for (int j = g * 16; j < g * 16 + 16; j++)
+      if (j != lane) mo = fmax(mo, fabs(A[lane * kLd + j]));
+    mo = WaveMax(mo);
+    if (lane == 0) wmax[g] = mo;
+    __syncthreads();
+    mo = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    __syncthreads();
+    if (mo < 1e-20) break;
+    for (int r = 0; r < 63; r++) {
+      if (tid < 32) {
+        int p, q;
+        GsPair(r, tid, p, q);
+        const double apq = A[p * kLd + q];
+        double c = 1.0, s = 0.0;
+        if (apq != 0.0) {
+          const double theta = (A[q * kLd + q] - A[p * kLd + p]) / (2.0 * apq);
+          const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(tt * tt + 1.0);
+          s = tt * c;
+        }
+        cs[tid] = c;
+        sn[tid] = s;
+      }
+      __syncthreads();
+      int p[8], q[8];
+      double c[8], s[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        GsPair(r, g * 8 + k, p[k], q[k]);
+        c[k] = cs[g * 8 + k];
+        s[k] = sn[g * 8 + k];
+      }
+      {  // column updates: lane = row
+        double ap[8], aq[8], up[8], uq[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          ap[k] = A[lane * kLd + p[k]];
+          aq[k] = A[lane * kLd + q[k]];
+          up[k] = U[lane * kLd + p[k]];
+          uq[k] = U[lane * kLd + q[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          A[lane * kLd + p[k]] = c[k] * ap[k] - s[k] * aq[k];
+          A[lane * kLd + q[k]] = s[k] * ap[k] + c[k] * aq[k];
+          U[lane * kLd + p[k]] = c[k] * up[k] - s[k] * uq[k];
+          U[lane * kLd + q[k]] = s[k] * up[k] + c[k] * uq[k];
+        }
+      }
+      __syncthreads();
+      {  // row updates: lane = column
+        double ap[8], aq[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          ap[k] = A[p[k] * kLd + lane];
+          aq[k] = A[q[k] * kLd + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          A[p[k] * kLd + lane] = c[k] * ap[k] - s[k] * aq[k];
+          A[q[k] * kLd + lane] = s[k] * ap[k] + c[k] * aq[k];
+        }
+      }
+      __syncthreads();
+      if (tid < 32) {
+        int pp, qq;
+        GsPair(r, tid, pp, qq);
+        A[pp * kLd + qq] = 0.0;
+        A[qq * kLd + pp] = 0.0;
+      }
+      __syncthreads();
+    }
+  }
+  // V = D^{-1/2} U, V^-1 = U^T D^{1/2}
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int i = idx >> 6, j = idx & 63;
+    out[kGsV + idx] = U[i * kLd + j] / out[kGsSq + i];
+    out[kGsVinv + idx] = U[j * kLd + i] * out[kGsSq + j];
+  }
+  if (tid < 64) out[kGsLambda + tid] = A[tid * kLd + tid];
+}
+
+void LaunchGsSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, const int32_t* model_index,
+                   double* gs_model, hipStream_t stream) {
+  hipLaunchKernelGGL(gs_model_kernel, dim3(d.tree_count), dim3(64), 0, stream, d, spec, b, model_index, gs_model);
+  hipLaunchKernelGGL(gs_eigen_kernel, dim3(d.tree_count), dim3(256), 0, stream, model_index, gs_model);
+}
+
+// --------------------------------------------------------------------------------------------
+// Transition matrices.  One workgroup (256 threads) per (branch, category, tree): thread (ib, j)
+// accumulates rows 16 ib .. 16 ib + 15 of column j of P and dP as explicit fma chains over
+// ascending k.
+//
+// Output record per (tree, branch, category): 3 x 4096 doubles.
+//   internal branch:  [0] image of P, [1] image of dP, [2] image of P^T       (MFMA A operands)
+//   leaf branch:      [0] PT[s][i] = P[i][s], [1] dPT[s][i]  row-major 64 x 64; row S (gap) is
+//                     1 (P) / 0 (dP) on the real states
+// Image of a matrix M (out = M x): element M[16 mb + ii][4 ks + kq] sits at
+//   ((mb * 8 + ks / 2) * 64 + (16 kq + ii)) * 2 + (ks & 1)
+// i.e. the A operand (lane = 16 k + row) of the MFMA for row block mb and k-step ks, two k-steps per
+// 16-byte load.  Measured on the device (probe_mfma16.hip, profiles/): register r of lane 16 q + j of
+// the result holds D[4 r + q][j], so register r of block m of a vector holds state 16 m + 4 r + q --
+// which is the B operand (lane = 16 k + column) of k-step 4 m + r: a vector flows from one MFMA's
+// result into the next one's operand without leaving its registers.  Leaf tables are stored with
+// the same permutation inside each block of 16 states (position 16 m + 4 q + r) so that a lane's
+// four values are one 32-byte load.
+
+__device__ __forceinline__ int GsImageIndex(int row, int col) {
+  const int mb = row >> 4, ii = row & 15, ks = col >> 2, kq = col & 3;
+  return ((mb * 8 + (ks >> 1)) * 64 + 16 * kq + ii) * 2 + (ks & 1);
+}
+
+__global__ void __launch_bounds__(256)
+gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ branch,
+                   const int32_t* __restrict__ model_index, const double* __restrict__ gs_model,
+                   double* __restrict__ imgs, int want_gradient, int deriv_mode) {
+#pragma clang fp contract(off)
+  __shared__ double W[64 * 64];  // [k][i]: V[i][k] e[k], then P[i][k]
+  __shared__ double e[64];
+  const int C = d.category_count, NB = d.node_count - 1, n = d.taxon_count;
+  const int br = blockIdx.x / C, c = blockIdx.x % C;
+  const int tree = tree0 + blockIdx.y;
+  const int tid = threadIdx.x, j = tid & 63, ib = tid >> 6;
+  const double* __restrict__ m = gs_model + (size_t)model_index[tree] * kGsModelStride;
+  const double rate = m[kGsCatRate + c];
+  const double time = branch[(size_t)tree * d.node_count + br] * rate;
+  if (tid < 64) e[tid] = exp(m[kGsLambda + tid] * time);
+  __syncthreads();
+  for (int idx = tid; idx < 4096; idx += 256) W[(idx & 63) * 64 + (idx >> 6)] = m[kGsV + idx] * e[idx & 63];
+  __syncthreads();
+  double accP[16], accD[16];
+#pragma unroll
+  for (int ii = 0; ii < 16; ii++) accP[ii] = accD[ii] = 0.0;
+  {
+    const double* __restrict__ vinv = m + kGsVinv + j;
+    for (int k = 0; k < 64; k++) {
+      const double vi = vinv[k * 64];
+      const double* wk = W + k * 64 + ib * 16;
+#pragma unroll
+      for (int ii = 0; ii < 16; ii++) accP[ii] = fma(wk[ii], vi, accP[ii]);
+    }
+  }
+  if (want_gradient) {
+    // dP/dt = P (r_c Q), formed from the ROUNDED P exactly as the reference's edge derivative
+    // pre^T (r_c Q) post sees it (BuildDifferentialMatrices, src/fat_beagle.cpp:101-111): entries of P
+    // that are O(t^2) carry a large relative rounding error, which must enter numerator and
+    // denominator of the derivative alike.  deriv_mode 1: the site-model pass, r_c -> d r_c / d shape.
+    const double drate = deriv_mode ? m[kGsCatRateDeriv + c] : rate;
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < 16; ii++) W[j * 64 + ib * 16 + ii] = accP[ii];
+    __syncthreads();
+    const double* __restrict__ qcol = m + kGsQ + j;
+    for (int k = 0; k < 64; k++) {
+      const double qk = qcol[k * 64] * drate;
+      const double* wk = W + k * 64 + ib * 16;
+#pragma unroll
+      for (int ii = 0; ii < 16; ii++) accD[ii] = fma(wk[ii], qk, accD[ii]);
+    }
+  }
+  double* __restrict__ rec = imgs + (((size_t)blockIdx.y * NB + br) * C + c) * (3 * 4096);
+  if (br < n) {
+    // leaf branch: transposed tables, row = tip state j, 16 contiguous entries per thread
+    const bool gap = (j == S);
+#pragma unroll
+    for (int ii = 0; ii < 16; ii++) {
+      const int i = ib * 16 + ii, at = j * 64 + ib * 16 + 4 * (ii & 3) + (ii >> 2);
+      rec[at] = gap ? (i < S ? 1.0 : 0.0) : accP[ii];
+      if (want_gradient) rec[4096 + at] = gap ? 0.0 : accD[ii];
+    }
+  } else {
+#pragma unroll
+    for (int ii = 0; ii < 16; ii++) {
+      const int i = ib * 16 + ii;
+      rec[GsImageIndex(i, j)] = accP[ii];
+      if (want_gradient) {
+        rec[4096 + GsImageIndex(i, j)] = accD[ii];
+        rec[8192 + GsImageIndex(j, i)] = accP[ii];  // P^T
+      }
+    }
+  }
+}
+
+void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const double* branch,
+                      const int32_t* model_index, const double* gs_model, double* imgs, int want_gradient,
+                      int deriv_mode, hipStream_t stream) {
+  const dim3 grid((d.node_count - 1) * d.category_count, chunk);
+  hipLaunchKernelGGL(gs_matrices_kernel, grid, dim3(256), 0, stream, d, S, tree0, branch, model_index, gs_model,
+                     imgs, want_gradient, deriv_mode);
+}
+
+// --------------------------------------------------------------------------------------------
+// Traversal.  A wave owns 16 consecutive site patterns of one tree.  A partial-likelihood vector of
+// those patterns (64 padded states x 16 patterns) lives in 32 VGPRs per lane in the MFMA's D layout:
+// lane = 16 kq + pn holds, for block m and register r, state 16 m + 4 r + kq of pattern pn.
+// Stored vectors (post-order partials, overwritten in place by pre-order partials exactly as in
+// walk_hbm_kernel) live in an HBM arena in that same layout, [m][lane][r]: 2 KB coalesced rows.
+
+struct GsPlv {
+  v4d b[4];
+};
+
+__device__ __forceinline__ void GsMatVec(const double* __restrict__ img, int lane, const GsPlv& x, GsPlv& out) {
+  const v2d* __restrict__ p = reinterpret_cast<const v2d*>(img) + lane;
+#pragma unroll
+  for (int mb = 0; mb < 4; mb++) {
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+      const v2d a = p[(mb * 8 + k2) * 64];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x.b[k2 >> 1][(k2 & 1) * 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x.b[k2 >> 1][(k2 & 1) * 2 + 1], acc, 0, 0, 0);
+    }
+    out.b[mb] = acc;
+  }
+}
+
+__device__ __forceinline__ void GsLoad(const double* __restrict__ slot, int lane, GsPlv& x) {
+#pragma unroll
+  for (int m = 0; m < 4; m++) x.b[m] = *reinterpret_cast<const v4d*>(slot + m * 256 + lane * 4);
+}
+__device__ __forceinline__ void GsStore(double* __restrict__ slot, int lane, const GsPlv& x) {
+#pragma unroll
+  for (int m = 0; m < 4; m++) *reinterpret_cast<v4d*>(slot + m * 256 + lane * 4) = x.b[m];
+}
+// tip child: row `state` of the transposed table
+__device__ __forceinline__ void GsTip(const double* __restrict__ table, int state, int kq, GsPlv& x) {
+#pragma unroll
+  for (int m = 0; m < 4; m++) x.b[m] = *reinterpret_cast<const v4d*>(table + state * 64 + 16 * m + 4 * kq);
+}
+__device__ __forceinline__ double GsDot3(const GsPlv& u, const GsPlv& a, const GsPlv& b) {
+  double s = 0.0;
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) s += u.b[m][r] * a.b[m][r] * b.b[m][r];
+  return s;
+}
+// sum over the four lanes that hold one pattern's states (kq = 0..3)
+__device__ __forceinline__ double GsPatternSum(double v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <bool GRAD>
+__global__ void __launch_bounds__(256)
+gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, const int32_t* __restrict__ children,
+               const double* __restrict__ imgs, const int32_t* __restrict__ model_index,
+               const double* __restrict__ gs_model,
+               const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
+               double* __restrict__ arena, double* __restrict__ part_ll, double* __restrict__ part_grad) {
+  const int n = d.taxon_count, N = d.node_count, NI = n - 1, C = d.category_count, Ppad = d.pattern_stride;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, pn = lane & 15;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= tiles) return;  // whole waves leave; the kernel has no workgroup barrier
+  const int tree = tree0 + blockIdx.y;
+  const int p = tile * 16 + pn;
+  const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
+  const double* __restrict__ model = gs_model + (size_t)model_index[tree] * kGsModelStride;
+  const double* __restrict__ recs = imgs + (size_t)blockIdx.y * (N - 1) * C * (3 * 4096);
+  double* __restrict__ slots = arena + (size_t)blockIdx.y * NI * C * tiles * 1024;
+  const uint8_t* __restrict__ tips = tip_states + p;
+  const double weight = weights[p];
+  auto slot = [&](int node, int c) { return slots + (((size_t)(node - n) * C + c) * tiles + tile) * 1024; };
+  auto rec = [&](int br, int c, int which) { return recs + (((size_t)br * C + c) * 3 + which) * 4096; };
+
+  GsPlv pi;
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) pi.b[m][r] = model[kGsPi + 16 * m + 4 * r + kq];
+
+  // ---- post-order: dest = (P0 x0) . (P1 x1) per category -----------------------------------
+  double site = 0.0;
+  for (int node = n; node < N; ++node) {
+    const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
+    const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
+    const int s0 = c0 < n ? tips[(size_t)c0 * Ppad] : 0;
+    const int s1 = c1 < n ? tips[(size_t)c1 * Ppad] : 0;
+    for (int c = 0; c < C; c++) {
+      GsPlv a, bb, x;
+      if (c0 < n) {
+        GsTip(rec(c0, c, 0), s0, kq, a);
+      } else {
+        GsLoad(slot(c0, c), lane, x);
+        GsMatVec(rec(c0, c, 0), lane, x, a);
+      }
+      if (c1 < n) {
+        GsTip(rec(c1, c, 0), s1, kq, bb);
+      } else {
+        GsLoad(slot(c1, c), lane, x);
+        GsMatVec(rec(c1, c, 0), lane, x, bb);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++) a.b[m] *= bb.b[m];
+      if (node == N - 1) {
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) s += pi.b[m][r] * a.b[m][r];
+        site += model[kGsCatWeight + c] * s;
+      } else {
+        GsStore(slot(node, c), lane, a);
+      }
+    }
+  }
+  site = GsPatternSum(site);
+  const double ll = kq == 0 ? weight * log(site) : 0.0;
+  const double wll = WaveSum64(ll);
+  if (lane == 0) part_ll[(size_t)tree * tiles + tile] = wll;
+
+  // ---- pre-order + edge derivatives: one step per internal node, parents first -------------
+  if (GRAD) {
+    double* __restrict__ grow = part_grad + ((size_t)tree * tiles + tile) * N;
+    if (lane == 0) grow[N - 1] = 0.0;
+    for (int node = N - 1; node >= n; --node) {
+      const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
+      const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
+      const int s0 = c0 < n ? tips[(size_t)c0 * Ppad] : 0;
+      const int s1 = c1 < n ? tips[(size_t)c1 * Ppad] : 0;
+      double den = 0.0, num0 = 0.0, num1 = 0.0;
+      for (int c = 0; c < C; c++) {
+        GsPlv u, a0, d0, a1, d1, x;
+        if (node == N - 1) {
+          u = pi;
+        } else {
+          GsLoad(slot(node, c), lane, u);
+        }
+        if (c0 < n) {
+          GsTip(rec(c0, c, 0), s0, kq, a0);
+          GsTip(rec(c0, c, 1), s0, kq, d0);
+        } else {
+          GsLoad(slot(c0, c), lane, x);
+          GsMatVec(rec(c0, c, 0), lane, x, a0);
+          GsMatVec(rec(c0, c, 1), lane, x, d0);
+        }
+        if (c1 < n) {
+          GsTip(rec(c1, c, 0), s1, kq, a1);
+          GsTip(rec(c1, c, 1), s1, kq, d1);
+        } else {
+          GsLoad(slot(c1, c), lane, x);
+          GsMatVec(rec(c1, c, 0), lane, x, a1);
+          GsMatVec(rec(c1, c, 1), lane, x, d1);
+        }
+        const double wc = model[kGsCatWeight + c];
+        den += wc * GsDot3(u, a0, a1);
+        num0 += wc * GsDot3(u, a1, d0);
+        num1 += wc * GsDot3(u, a0, d1);
+        if (c0 >= n) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) x.b[m] = u.b[m] * a1.b[m];
+          GsMatVec(rec(c0, c, 2), lane, x, d0);
+          GsStore(slot(c0, c), lane, d0);
+        }
+        if (c1 >= n) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) x.b[m] = u.b[m] * a0.b[m];
+          GsMatVec(rec(c1, c, 2), lane, x, d1);
+          GsStore(slot(c1, c), lane, d1);
+        }
+      }
+      den = GsPatternSum(den);
+      num0 = GsPatternSum(num0);
+      num1 = GsPatternSum(num1);
+      const double scale = kq == 0 ? weight / den : 0.0;
+      const double g0 = WaveSum64(num0 * scale);
+      const double g1 = WaveSum64(num1 * scale);
+      if (lane == 0) {
+        grow[c0] = g0;
+        grow[c1] = g1;
+      }
+    }
+  }
+}
+
+size_t GsArenaDoublesPerTree(const BatchDims& d, int tiles) {
+  return (size_t)(d.taxon_count - 1) * d.category_count * tiles * 1024;
+}
+size_t GsImageDoublesPerTree(const BatchDims& d) {
+  return (size_t)(d.node_count - 1) * d.category_count * 3 * 4096;
+}
+
+void LaunchGsWalk(const BatchDims& d, int S, const DeviceBatch& b, const int32_t* model_index,
+                  const double* gs_model, int tree0, int chunk, int tiles, int want_gradient,
+                  hipStream_t stream) {
+  const dim3 grid((tiles + 3) / 4, chunk), block(256);
+  if (want_gradient)
+    hipLaunchKernelGGL((gs_walk_kernel<true>), grid, block, 0, stream, d, S, tree0, tiles, b.children, b.images,
+                       model_index, gs_model, b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+  else
+    hipLaunchKernelGGL((gs_walk_kernel<false>), grid, block, 0, stream, d, S, tree0, tiles, b.children, b.images,
+                       model_index, gs_model, b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+}
+
+}  // namespace bito_amd

@@ -28,45 +28,7 @@ __global__ void __launch_bounds__(64)
 setup_trees_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= d.tree_count) return;
-  const int n = d.taxon_count, N = d.node_count, M = d.in_node_count, NI = n - 1;
-  int32_t* ch = b.children + (size_t)t * NI * 2;
-  for (int k = 0; k < NI * 2; k++) ch[k] = -1;
-  const int32_t* parent = b.parent_ids + (size_t)t * (M - 1);
-  int third = -1;
-  // Children in ascending id order, as Node::OfParentIdVector builds them
-  // (reference src/node.cpp:511-551).
-  for (int child = 0; child < M - 1; child++) {
-    const int k = parent[child] - n;
-    if (ch[k * 2] < 0) {
-      ch[k * 2] = child;
-    } else if (ch[k * 2 + 1] < 0) {
-      ch[k * 2 + 1] = child;
-    } else {
-      third = child;
-    }
-  }
-  double* bl = b.branch + (size_t)t * N;
-  const double* bl_in = b.branch_in + (size_t)t * M;
-  for (int i = 0; i < M; i++) bl[i] = bl_in[i];
-  if (!d.rooted) {
-    // UnrootedTree::Detrifurcate (reference src/unrooted_tree.cpp:27-37): children 1 and
-    // 2 of the trifurcation are joined under a node that re-uses the old root id
-    // with branch length 0; the new root (id+1) joins child 0 with it.
-    // Tree::SlideRootPosition (src/tree.cpp:82-88) is then the identity apart from
-    // pinning that branch to 0.
-    const int r = M - 1;
-    const int a = ch[(r - n) * 2], bb = ch[(r - n) * 2 + 1];
-    ch[(r - n) * 2] = bb;
-    ch[(r - n) * 2 + 1] = third;
-    bl[r] = 0.0;
-    ch[(r + 1 - n) * 2] = a;
-    ch[(r + 1 - n) * 2 + 1] = r;
-    bl[r + 1] = 0.0;
-  } else if (b.rates != nullptr) {
-    // FatBeagle::LogLikelihood(RootedTree) (reference src/fat_beagle.cpp:86-90).
-    const double* rates = b.rates + (size_t)t * (M - 1);
-    for (int i = 0; i < N - 1; i++) bl[i] *= rates[i];
-  }
+  SetupTopology(d, b, t);
   SetupTreeModel(spec, b.params + (size_t)t * spec.param_count, &b.model[t]);
 }
 

@@ -63,6 +63,50 @@ struct DeviceBatch {
   double* out_grad;           // [T][N]
 };
 
+// Topology set-up of tree t, shared by the 4-state and the general-state set-up kernels:
+// parent-id vector -> child lists (+ detrifurcation), effective branch lengths.
+__device__ inline void SetupTopology(const BatchDims& d, const DeviceBatch& b, int t) {
+  const int n = d.taxon_count, N = d.node_count, M = d.in_node_count, NI = n - 1;
+  int32_t* ch = b.children + (size_t)t * NI * 2;
+  for (int k = 0; k < NI * 2; k++) ch[k] = -1;
+  const int32_t* parent = b.parent_ids + (size_t)t * (M - 1);
+  int third = -1;
+  // Children in ascending id order, as Node::OfParentIdVector builds them
+  // (reference src/node.cpp:511-551).
+  for (int child = 0; child < M - 1; child++) {
+    const int k = parent[child] - n;
+    if (ch[k * 2] < 0) {
+      ch[k * 2] = child;
+    } else if (ch[k * 2 + 1] < 0) {
+      ch[k * 2 + 1] = child;
+    } else {
+      third = child;
+    }
+  }
+  double* bl = b.branch + (size_t)t * N;
+  const double* bl_in = b.branch_in + (size_t)t * M;
+  for (int i = 0; i < M; i++) bl[i] = bl_in[i];
+  if (!d.rooted) {
+    // UnrootedTree::Detrifurcate (reference src/unrooted_tree.cpp:27-37): children 1 and
+    // 2 of the trifurcation are joined under a node that re-uses the old root id
+    // with branch length 0; the new root (id+1) joins child 0 with it.
+    // Tree::SlideRootPosition (src/tree.cpp:82-88) is then the identity apart from
+    // pinning that branch to 0.
+    const int r = M - 1;
+    const int a = ch[(r - n) * 2], bb = ch[(r - n) * 2 + 1];
+    ch[(r - n) * 2] = bb;
+    ch[(r - n) * 2 + 1] = third;
+    bl[r] = 0.0;
+    ch[(r + 1 - n) * 2] = a;
+    ch[(r + 1 - n) * 2 + 1] = r;
+    bl[r + 1] = 0.0;
+  } else if (b.rates != nullptr) {
+    // FatBeagle::LogLikelihood(RootedTree) (reference src/fat_beagle.cpp:86-90).
+    const double* rates = b.rates + (size_t)t * (M - 1);
+    for (int i = 0; i < N - 1; i++) bl[i] *= rates[i];
+  }
+}
+
 void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int want_gradient,
                  hipStream_t stream);
 // deriv_mode 0: dP = P (r_c Q); 1: dP = P ((d r_c / d shape) Q) for the site-model gradient pass.
@@ -110,6 +154,27 @@ const char* WalkHbmKernelName(int category_count, int want_gradient, int rescali
 
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
                   hipStream_t stream);
+
+// ---- general-state-count path (gs_kernels.hip): the 61-state codon model, states padded to 64 ----
+// Per-model record, doubles: V [64][64], V^-1 [64][64], Q [64][64], lambda [64], pi [64] (padding 0),
+// sqrt(pi) [64], category rates / weights / d rate / d shape.  Trees with identical parameter rows
+// share one record: model_index[t] = first tree with t's row.
+constexpr int kGsV = 0, kGsVinv = 4096, kGsQ = 8192, kGsLambda = 12288, kGsPi = kGsLambda + 64, kGsSq = kGsPi + 64,
+              kGsCatRate = kGsSq + 64, kGsCatWeight = kGsCatRate + kMaxCategories,
+              kGsCatRateDeriv = kGsCatWeight + kMaxCategories, kGsModelStride = kGsCatRateDeriv + kMaxCategories;
+inline int GsTiles(int pattern_count) { return (pattern_count + 15) / 16; }  // 16 site patterns per wave
+size_t GsArenaDoublesPerTree(const BatchDims& d, int tiles);
+size_t GsImageDoublesPerTree(const BatchDims& d);
+void LaunchGsSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, const int32_t* model_index,
+                   double* gs_model, hipStream_t stream);
+// b.images is the chunk's record array [chunk][N-1][C][3][4096]; b.arena the chunk's PLV arena
+void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const double* branch,
+                      const int32_t* model_index, const double* gs_model, double* imgs, int want_gradient,
+                      int deriv_mode, hipStream_t stream);
+void LaunchGsWalk(const BatchDims& d, int S, const DeviceBatch& b, const int32_t* model_index,
+                  const double* gs_model, int tree0, int chunk, int tiles, int want_gradient,
+                  hipStream_t stream);
+
 
 // time_tree.hip: RootedTree's height-ratio parameterisation and the rooted gradient transforms,
 // one thread per tree (reference src/rooted_tree.cpp:36-121, src/rooted_gradient_transforms.cpp)

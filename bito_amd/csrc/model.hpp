@@ -26,7 +26,7 @@ namespace bito_amd {
 constexpr int kStates = 4;
 constexpr int kMaxCategories = 16;
 
-enum SubstitutionKind : int32_t { kJC69 = 0, kHKY = 1, kGTR = 2 };
+enum SubstitutionKind : int32_t { kJC69 = 0, kHKY = 1, kGTR = 2, kGY94 = 3 };
 
 // Layout of one row of phylo_model_params_ (reference src/phylo_model.cpp:6-31):
 // [substitution: frequencies(4) | rates] [site: Weibull_shape] [clock: clock_rate].
@@ -37,6 +37,7 @@ struct ModelSpec {
   int32_t strict_clock;  // 0 = "none"
   int32_t freq_start, rates_start, rates_len, shape_start, clock_start;
   int32_t param_count;
+  int32_t state_count;  // 4, or 61 for the codon model "GY94" (general-state kernels, gs_kernels.hip)
 };
 
 // Per-tree model state produced by the set-up kernel and consumed by the

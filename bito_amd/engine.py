@@ -73,6 +73,7 @@ class Engine:
         self.pattern_count = P
         self.param_count = L.bito_amd_engine_param_count(h)
         self.category_count = L.bito_amd_engine_category_count(h)
+        self.state_count = L.bito_amd_engine_state_count(h)
         self.tree_count = 0
         self._node_count = 2 * n - 1
 
@@ -106,7 +107,7 @@ class Engine:
             if key == "substitution_model_frequencies":
                 p[:, s:s + ln] = 0.25
             elif key == "substitution_model_rates":
-                p[:, s:s + ln] = 1.0 / 6 if ln == 6 else 1.0
+                p[:, s:s + ln] = 1.0 / 6 if ln == 6 else 1.0  # GTR rates; HKY kappa; GY94 kappa, omega
             elif key in ("Weibull_shape", "clock_rate"):
                 p[:, s:s + ln] = 1.0
         return p
@@ -307,6 +308,15 @@ class Engine:
 
     def set_kernel(self, kernel: int):
         self._check(_capi.lib().bito_amd_engine_set_kernel(self._h, kernel))
+
+    def read_general_model(self, tree: int) -> Dict[str, np.ndarray]:
+        """Diagnostics (general-state kernels): the model record the set-up kernel built for one tree."""
+        buf = np.zeros(3 * 4096 + 3 * 64 + 48)
+        self._check(_capi.lib().bito_amd_engine_read_general_model(self._h, tree, _dp(buf), buf.size))
+        m = 3 * 4096
+        return {"V": buf[:4096].reshape(64, 64), "Vinv": buf[4096:8192].reshape(64, 64),
+                "Q": buf[8192:m].reshape(64, 64), "lambda": buf[m:m + 64], "pi": buf[m + 64:m + 128],
+                "cat_rate": buf[m + 192:m + 208], "cat_weight": buf[m + 208:m + 224]}
 
     def kernel_name(self) -> str:
         return _capi.lib().bito_amd_engine_kernel_name(self._h).decode()

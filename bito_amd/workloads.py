@@ -15,7 +15,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import treeio
-from .site_pattern import SitePattern
+from .site_pattern import CodonSitePattern, SitePattern
 
 DATA_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
 
@@ -192,3 +192,23 @@ def synthetic_gtr_weibull4(n: int = 1000, P: int = 10000, tree_count: int = 125,
     bl[:, -1] = 0.0
     return Workload(f"synthetic {n}x{P} GTR+weibull4 LL+grad", "GTR", "weibull+4", "none", patterns, np.ones(P), pid,
                     bl, gtr_weibull_params(tree_count), True, True)
+
+
+CODON_PARAMS = [0.3, 0.2, 0.25, 0.25, 2.5, 0.3]  # nucleotide frequencies A,C,G,T | kappa, omega
+
+
+def flua_codon(tree_count: int = 64, site: str = "constant", seed: int = 20240605) -> Workload:
+    """BASELINE config 5: fluA.fa read as codons (69 taxa, 329 codon columns -> 242 patterns, 61 states),
+    the fluA.tree topology (rooted), GY94 with F1x4 frequencies; every tree of the batch is the same
+    topology with its own seeded branch lengths (fluA.tree's, in substitutions per codon site, times
+    U(0.5, 1.5)), so each tree is distinct work: log-likelihood + branch-length gradient.  The
+    reference has no codon model: model and workload are defined by this build."""
+    tc = treeio.read_newick_file(os.path.join(DATA_DIR, "fluA.tree"))
+    sp = CodonSitePattern(treeio.read_fasta(os.path.join(DATA_DIR, "fluA.fa")), tc.taxon_names)
+    pid = np.tile(tc.parent_id_matrix(), (tree_count, 1))
+    rng = np.random.default_rng(seed)
+    bl = np.tile(tc.branch_length_matrix(), (tree_count, 1)) * 0.002 * rng.uniform(0.5, 1.5, (tree_count, pid.shape[1] + 1))
+    bl[:, -1] = 0.0
+    row = CODON_PARAMS + ([0.7] if site != "constant" else [])
+    return Workload(f"fluA codon GY94+{site} LL+grad", "GY94", site, "none", sp.patterns, sp.weights, pid, bl,
+                    np.tile(np.array(row), (tree_count, 1)), False, True)

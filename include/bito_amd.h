@@ -49,6 +49,8 @@ extern "C" {
 #define BITO_AMD_KERNEL_HBM_ARENA 1
 #define BITO_AMD_KERNEL_LDS 2      /* walk_lds_kernel: one wave per SIMD, images from L2 */
 #define BITO_AMD_KERNEL_LDS_TREE 3 /* walk_tree_kernel: two waves per SIMD, images staged in LDS */
+#define BITO_AMD_KERNEL_GENERAL 4  /* gs_walk_kernel: the general-state-count kernels (any model; the only
+                                      choice for the 61-state codon model) */
 
 typedef struct bito_amd_engine bito_amd_engine;
 
@@ -66,9 +68,17 @@ typedef struct {
  * Engine::Engine (reference src/engine.cpp:10-31) + FatBeagle ctor
  * (src/fat_beagle.cpp:12-28): uploads the compressed alignment once.
  *   substitution: "JC69" | "HKY" | "GTR"      (src/substitution_model.cpp:6-18)
+ *                 | "GY94": 61-state codon model (BASELINE config 5).  The reference has no
+ *                 model with more than four states; this one is defined here: sense codons of
+ *                 the standard genetic code in lexicographic A,C,G,T order (stop codons removed),
+ *                 Q_ij = pi_j [kappa if transition] [omega if the amino acid changes] for codons
+ *                 that differ at one position, F1x4 frequencies from the four nucleotide
+ *                 frequencies, one expected substitution per unit time.  Parameter row:
+ *                 substitution_model_frequencies (4) | substitution_model_rates (kappa, omega).
+ *                 patterns then hold codon states 0..60, >= 61 = gap.
  *   site:         "constant" | "weibull+K"    (src/site_model.cpp:10-25)
  *   clock:        "none" | "strict"           (src/clock_model.cpp:6-15)
- *   patterns: row-major [taxon_count][pattern_count], 0..3 = ACGT, >= 4 = gap
+ *   patterns: row-major [taxon_count][pattern_count], 0..3 = ACGT, >= 4 = gap (codon model: see above)
  *             (SitePattern::GetPatterns, src/site_pattern.cpp:16-115)
  *   weights:  [pattern_count]                 (SitePattern::GetWeights)
  * On failure *out is NULL and err (if given) holds the message.
@@ -89,6 +99,7 @@ const char *bito_amd_engine_last_error(const bito_amd_engine *e);
  * Row layout [substitution | site | clock], keys alphabetical inside a model. */
 int32_t bito_amd_engine_param_count(const bito_amd_engine *e);
 int32_t bito_amd_engine_category_count(const bito_amd_engine *e);
+int32_t bito_amd_engine_state_count(const bito_amd_engine *e); /* 4, or 61 for "GY94" */
 int32_t bito_amd_engine_block_count(const bito_amd_engine *e);
 int bito_amd_engine_block(const bito_amd_engine *e, int32_t idx, char *name,
                           size_t name_len, int32_t *start, int32_t *len);
@@ -237,6 +248,11 @@ int bito_amd_engine_time_runs(bito_amd_engine *e, int32_t want_gradient, int32_t
  * stream around each launch).  Reading resets the accumulation. */
 int bito_amd_engine_kernel_timing(bito_amd_engine *e, int32_t enable);
 int bito_amd_engine_kernel_elapsed(bito_amd_engine *e, double *kernel_ms, int32_t *kernel_launches);
+/* General-state kernels only: the per-tree model record the set-up kernel produced for `tree` of the
+ * resident batch after a run -- V [64][64], V^-1 [64][64], Q [64][64], lambda [64], pi [64],
+ * sqrt(pi) [64], then 16 category rates, 16 weights, 16 d rate / d shape (row-major, padded to 64
+ * states); at most `capacity` doubles. */
+int bito_amd_engine_read_general_model(bito_amd_engine *e, int32_t tree, double *out, size_t capacity);
 /* Name of the traversal kernel the last run used (for matching rocprof rows). */
 const char *bito_amd_engine_kernel_name(const bito_amd_engine *e);
 /* Library/device info string, e.g. "bito_amd 0.1 gfx950 256CU". */

@@ -174,7 +174,8 @@ static void jacobi_round_pairs(int r, int *p, int *q) {
  * rotations (stands in for Eigen::SelfAdjointEigenSolver, src/substitution_model.cpp:172; the
  * eigenvalue order is immaterial because only V f(Lambda) V^-1 products are formed).  Within a
  * round all rotation angles are taken from the matrix as it stands at the start of the round,
- * then all column updates (A and U), then all row updates. */
+ * then all column updates (A and U), then all row updates, then the annihilated entries are set to
+ * exactly zero. */
 static int jacobi_padded(double *A, double *U, double *w) {
   for (int i = 0; i < MS; i++)
     for (int j = 0; j < MS; j++) U[i * MS + j] = (i == j) ? 1.0 : 0.0;
@@ -184,7 +185,7 @@ static int jacobi_padded(double *A, double *U, double *w) {
     for (int i = 0; i < MS; i++)
       for (int j = 0; j < MS; j++)
         if (i != j && fabs(A[i * MS + j]) > maxoff) maxoff = fabs(A[i * MS + j]);
-    if (maxoff < 1e-30) break;
+    if (maxoff < 1e-20) break;
     for (int r = 0; r < MS - 1; r++) {
       int p[MS / 2], q[MS / 2];
       double cs[MS / 2], sn[MS / 2];
@@ -222,6 +223,8 @@ static int jacobi_padded(double *A, double *U, double *w) {
           A[q[k] * MS + j] = s * apj + c * aqj;
         }
       }
+      for (int k = 0; k < MS / 2; k++) /* the rotation annihilates its own pair */
+        A[p[k] * MS + q[k]] = A[q[k] * MS + p[k]] = 0.0;
     }
   }
   for (int i = 0; i < MS; i++) w[i] = A[i * MS + i];

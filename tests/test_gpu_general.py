@@ -1,0 +1,109 @@
+"""Parity of the general-state-count HIP kernels (gs_kernels.hip) through the C ABI: the 61-state
+codon model of BASELINE config 5 against oracle/gs_oracle.c, and the same kernels at S = 4 against
+the reference's goldens.  Needs a real MI355X: run with ``-m gpu``.
+
+Tolerances (BASELINE.json north_star): 1e-10 on log-likelihoods, 1e-6 on gradients."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bito_amd
+from bito_amd import _capi, treeio, workloads
+from bito_amd.site_pattern import SitePattern
+from oracle import gs
+
+from test_gpu_parity import grad_close, ll_close, spec
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_goldens.json")) as fh:
+    GOLD = json.load(fh)
+
+
+def _general(sub, site, patterns, weights):
+    eng = bito_amd.Engine(spec(sub, site), patterns, weights)
+    eng.set_kernel(_capi.KERNEL_GENERAL)
+    return eng
+
+
+def test_general_kernels_reproduce_ds1_jc69_goldens(data_dir):
+    """src/unrooted_sbn_instance.hpp:245-287 through the general kernels at S = 4."""
+    g = GOLD["ds1_jc69"]
+    tc = treeio.read_nexus_file(os.path.join(data_dir, g["trees"]))
+    sp = SitePattern(treeio.read_fasta(os.path.join(data_dir, g["fasta"])), tc.taxon_names)
+    eng = _general("JC69", "constant", sp.patterns, sp.weights)
+    pid, bl = tc.parent_id_matrix(), tc.branch_length_matrix()
+    out = eng.gradients(pid, bl)
+    assert eng.kernel_name() == "gs_walk_kernel"
+    assert np.abs(out["log_likelihood"] - g["log_likelihoods"]).max() < 5e-10
+    last = np.sort(out["branch_lengths"][-1])
+    assert np.abs(last - g["last_tree_sorted_branch_gradient"]).max() < g["gradient_tol"]
+    ll = eng.log_likelihoods(pid, bl)
+    assert np.array_equal(ll, out["log_likelihood"])
+
+
+def test_general_kernels_match_oracle_on_headline_model():
+    """GTR + weibull+4 on DS1 (config 3's model) through the general kernels vs the general oracle."""
+    w = workloads.ds1_gtr_weibull4(1).subset(12)
+    eng = _general(w.substitution, w.site, w.patterns, w.weights)
+    cpu = gs.GsOracleEngine("GTR", w.site, w.patterns, w.weights, 8)
+    out = eng.gradients(w.parent_ids, w.branch_lengths, w.params)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+
+
+def test_codon_model_setup_is_bitwise_the_oracles():
+    """Rate matrix, Jacobi eigensystem and F1x4 frequencies of the set-up kernel equal the oracle's bit
+    for bit (same operation order, no FMA contraction) -- errors there are coherent across patterns."""
+    w = workloads.flua_codon(2)
+    eng = bito_amd.Engine(spec(w.substitution, w.site), w.patterns, w.weights)
+    assert eng.state_count == 61 and eng.param_count == 6
+    eng.log_likelihoods(w.parent_ids, w.branch_lengths, w.params)
+    got = eng.read_general_model(1)
+    Q, V, Vi = (np.zeros(64 * 64) for _ in range(3))
+    lam, pi = np.zeros(64), np.zeros(64)
+    assert gs.lib().gs_substitution_model(b"GY94", gs._dp(np.ascontiguousarray(w.params[1])), gs._dp(Q), gs._dp(V),
+                                          gs._dp(Vi), gs._dp(lam), gs._dp(pi)) == 0
+    assert np.array_equal(got["pi"], pi)
+    assert np.array_equal(got["Q"], Q.reshape(64, 64))
+    assert np.array_equal(got["lambda"], lam)
+    assert np.array_equal(got["V"], V.reshape(64, 64))
+    assert np.array_equal(got["Vinv"], Vi.reshape(64, 64))
+
+
+@pytest.mark.parametrize("site", ["constant", "weibull+3"])
+def test_codon_model_matches_oracle(site):
+    """BASELINE config 5: fluA as codons, GY94, log-likelihood + branch gradient vs oracle/gs_oracle.c."""
+    w = workloads.flua_codon(5, site)
+    eng = bito_amd.Engine(spec(w.substitution, w.site), w.patterns, w.weights)
+    cpu = gs.GsOracleEngine("GY94", site, w.patterns, w.weights, 8)
+    params = w.params.copy()
+    params[1, :4] = [0.1, 0.2, 0.3, 0.4]  # rows differ: the model is per tree
+    params[2, 4:6] = [1.0, 1.0]
+    out = eng.gradients(w.parent_ids, w.branch_lengths, params)
+    assert eng.kernel_name() == "gs_walk_kernel"
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, params)
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    assert np.all(out["branch_lengths"][:, -1] == 0.0)
+    ll = eng.log_likelihoods(w.parent_ids, w.branch_lengths, params)
+    assert ll_close(ll, ref["log_likelihood"])
+
+
+def test_codon_model_errors():
+    w = workloads.flua_codon(1)
+    eng = bito_amd.Engine(spec("GY94", "constant"), w.patterns, w.weights)
+    bad = w.params.copy()
+    bad[0, 4] = -1.0
+    with pytest.raises(bito_amd.BitoAmdError, match="kappa and omega"):
+        eng.log_likelihoods(w.parent_ids, w.branch_lengths, bad)
+    bad = w.params.copy()
+    bad[0, 0] = 0.5
+    with pytest.raises(bito_amd.BitoAmdError, match="frequencies do not sum to 1"):
+        eng.log_likelihoods(w.parent_ids, w.branch_lengths, bad)
+    with pytest.raises(bito_amd.BitoAmdError, match="rescaling"):
+        eng.log_likelihoods(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
