@@ -318,8 +318,10 @@ int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int
   HIP_TRY(e, e->arena.Reserve(chunk * arena_per_tree));
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
   if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
+  HIP_TRY(e, e->sched.Reserve((size_t)T * GsScheduleStride(d)));
   const DeviceBatch b = MakeBatch(e);
   LaunchGsSetup(d, e->spec, b, e->gs_model_index.ptr, e->gs_model.ptr, e->stream);
+  LaunchGsSchedule(d, b, e->stream);
   for (int t0 = 0; t0 < T; t0 += (int)chunk) {
     const int ct = std::min<int>((int)chunk, T - t0);
     LaunchGsMatrices(d, S, t0, ct, e->branch.ptr, e->gs_model_index.ptr, e->gs_model.ptr, e->images.ptr, want_gradient, deriv_mode, e->stream);

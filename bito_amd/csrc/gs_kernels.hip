@@ -420,29 +420,57 @@ void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const dou
 }
 
 // --------------------------------------------------------------------------------------------
-// Traversal.  A wave owns 16 consecutive site patterns of one tree.  A partial-likelihood vector of
-// those patterns (64 padded states x 16 patterns) lives in 32 VGPRs per lane in the MFMA's D layout:
-// lane = 16 kq + pn holds, for block m and register r, state 16 m + 4 r + kq of pattern pn.
-// Stored vectors (post-order partials, overwritten in place by pre-order partials exactly as in
-// walk_hbm_kernel) live in an HBM arena in that same layout, [m][lane][r]: 2 KB coalesced rows.
+// Traversal.  A wave owns 16 consecutive site patterns of one tree; the four waves of a workgroup
+// own four consecutive tiles of the SAME tree and therefore need the same matrix images in the same
+// order.  A partial-likelihood vector of a wave's patterns (64 padded states x 16 patterns) lives in
+// 32 VGPRs per lane in the MFMA's D layout: lane = 16 kq + pn holds, for block m and register r, state
+// 16 m + 4 r + kq of pattern pn.  Stored vectors (post-order partials, overwritten in place by
+// pre-order partials exactly as in walk_hbm_kernel) live in an HBM arena in that same layout,
+// [m][lane][r]: 2 KB coalesced rows.
+//
+// Images go through LDS: the order in which a tree's images are needed is written once per tree by
+// gs_schedule_kernel (a list of record numbers); while the workgroup contracts with image j out of
+// one 32 KB LDS buffer, every thread already holds its 128-byte slice of image j+1 in registers
+// (global loads issued before the MFMAs) and drops it into the other buffer afterwards -- one
+// workgroup barrier per image, L2 read once per workgroup instead of once per wave.
 
 struct GsPlv {
   v4d b[4];
 };
 
-__device__ __forceinline__ void GsMatVec(const double* __restrict__ img, int lane, const GsPlv& x, GsPlv& out) {
-  const v2d* __restrict__ p = reinterpret_cast<const v2d*>(img) + lane;
-#pragma unroll
-  for (int mb = 0; mb < 4; mb++) {
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k2 = 0; k2 < 8; k2++) {
-      const v2d a = p[(mb * 8 + k2) * 64];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x.b[k2 >> 1][(k2 & 1) * 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x.b[k2 >> 1][(k2 & 1) * 2 + 1], acc, 0, 0, 0);
-    }
-    out.b[mb] = acc;
-  }
+// Image order of one tree.  Post-order: per internal node and category, P of each internal child.
+// Pre-order: per internal node (parents first) and category: P of each internal child, dP of each
+// internal child, P^T of each internal child.  Entries are record numbers (br * C + c) * 3 + which.
+__global__ void __launch_bounds__(64)
+gs_schedule_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __restrict__ jobs, int stride) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= d.tree_count) return;
+  const int n = d.taxon_count, N = d.node_count, C = d.category_count;
+  const int32_t* ch = children + (size_t)t * (n - 1) * 2;
+  int32_t* out = jobs + (size_t)t * stride;
+  int at = 0;
+  for (int node = n; node < N; node++)
+    for (int c = 0; c < C; c++)
+      for (int side = 0; side < 2; side++) {
+        const int k = ch[(node - n) * 2 + side];
+        if (k >= n) out[at++] = (k * C + c) * 3;
+      }
+  for (int node = N - 1; node >= n; node--)
+    for (int c = 0; c < C; c++)
+      for (int which = 0; which < 3; which++)
+        for (int side = 0; side < 2; side++) {
+          const int k = ch[(node - n) * 2 + side];
+          if (k >= n) out[at++] = (k * C + c) * 3 + which;
+        }
+  const int last = at ? out[at - 1] : 0;
+  for (; at < stride; at++) out[at] = last;
+}
+
+int GsScheduleStride(const BatchDims& d) { return (d.taxon_count - 1) * d.category_count * 8 + 1; }
+
+void LaunchGsSchedule(const BatchDims& d, const DeviceBatch& b, hipStream_t stream) {
+  hipLaunchKernelGGL(gs_schedule_kernel, dim3((d.tree_count + 63) / 64), dim3(64), 0, stream, d, b.children, b.sched,
+                     GsScheduleStride(d));
 }
 
 __device__ __forceinline__ void GsLoad(const double* __restrict__ slot, int lane, GsPlv& x) {
@@ -458,12 +486,12 @@ __device__ __forceinline__ void GsTip(const double* __restrict__ table, int stat
 #pragma unroll
   for (int m = 0; m < 4; m++) x.b[m] = *reinterpret_cast<const v4d*>(table + state * 64 + 16 * m + 4 * kq);
 }
-__device__ __forceinline__ double GsDot3(const GsPlv& u, const GsPlv& a, const GsPlv& b) {
+__device__ __forceinline__ double GsDot(const GsPlv& a, const GsPlv& b) {
   double s = 0.0;
 #pragma unroll
   for (int m = 0; m < 4; m++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) s += u.b[m][r] * a.b[m][r] * b.b[m][r];
+    for (int r = 0; r < 4; r++) s += a.b[m][r] * b.b[m][r];
   return s;
 }
 // sum over the four lanes that hold one pattern's states (kq = 0..3)
@@ -473,17 +501,75 @@ __device__ __forceinline__ double GsPatternSum(double v) {
   return v;
 }
 
+// The workgroup's image pipeline (all 256 threads call every member together).
+struct GsImagePipe {
+  double* lds;                        // two 4096-double buffers
+  const double* __restrict__ recs;    // the tree's records
+  const int32_t* __restrict__ jobs;   // the tree's image order
+  int j;                              // image now in lds[(j & 1) * 4096]
+  int tid, lane;
+
+  __device__ __forceinline__ void Begin() {
+    j = 0;
+    const v2d* src = reinterpret_cast<const v2d*>(recs + (size_t)jobs[0] * 4096) + tid;
+    v2d* dst = reinterpret_cast<v2d*>(lds) + tid;
+#pragma unroll
+    for (int i = 0; i < 8; i++) dst[i * 256] = src[i * 256];
+    __syncthreads();
+  }
+
+  // out = (image j) x; leaves image j+1 in the other buffer
+  __device__ __forceinline__ void MatVec(const GsPlv& x, GsPlv& out) {
+    const int next = __builtin_amdgcn_readfirstlane(jobs[j + 1]);
+    const v2d* src = reinterpret_cast<const v2d*>(recs + (size_t)next * 4096) + tid;
+    v2d pre[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) pre[i] = src[i * 256];
+    const v2d* p = reinterpret_cast<const v2d*>(lds + (j & 1) * 4096) + lane;
+    v4d acc[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; mb++) acc[mb] = v4d{0.0, 0.0, 0.0, 0.0};
+    v2d a[4], an[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; mb++) a[mb] = p[(mb * 8) * 64];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+      if (k2 < 7) {
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++) an[mb] = p[(mb * 8 + k2 + 1) * 64];
+      }
+      const double b0 = x.b[k2 >> 1][(k2 & 1) * 2], b1 = x.b[k2 >> 1][(k2 & 1) * 2 + 1];
+#pragma unroll
+      for (int mb = 0; mb < 4; mb++) acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb].x, b0, acc[mb], 0, 0, 0);
+#pragma unroll
+      for (int mb = 0; mb < 4; mb++) acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb].y, b1, acc[mb], 0, 0, 0);
+#pragma unroll
+      for (int mb = 0; mb < 4; mb++) a[mb] = an[mb];
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; mb++) out.b[mb] = acc[mb];
+    v2d* dst = reinterpret_cast<v2d*>(lds + ((j + 1) & 1) * 4096) + tid;
+#pragma unroll
+    for (int i = 0; i < 8; i++) dst[i * 256] = pre[i];
+    j++;
+    __syncthreads();
+  }
+};
+
 template <bool GRAD>
 __global__ void __launch_bounds__(256)
-gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, const int32_t* __restrict__ children,
-               const double* __restrict__ imgs, const int32_t* __restrict__ model_index,
-               const double* __restrict__ gs_model,
+gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, int sched_stride, const int32_t* __restrict__ children,
+               const int32_t* __restrict__ sched, const double* __restrict__ imgs,
+               const int32_t* __restrict__ model_index, const double* __restrict__ gs_model,
                const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
                double* __restrict__ arena, double* __restrict__ part_ll, double* __restrict__ part_grad) {
+  extern __shared__ double lds[];  // two image buffers
   const int n = d.taxon_count, N = d.node_count, NI = n - 1, C = d.category_count, Ppad = d.pattern_stride;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, pn = lane & 15;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= tiles) return;  // whole waves leave; the kernel has no workgroup barrier
+  // a wave past the last tile repeats the last tile's work (it must take part in the image
+  // pipeline) and stores nothing
+  const bool active = blockIdx.x * 4 + wave < tiles;
+  const int tile = active ? blockIdx.x * 4 + wave : tiles - 1;
   const int tree = tree0 + blockIdx.y;
   const int p = tile * 16 + pn;
   const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
@@ -494,6 +580,8 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, const int32_t* __restri
   const double weight = weights[p];
   auto slot = [&](int node, int c) { return slots + (((size_t)(node - n) * C + c) * tiles + tile) * 1024; };
   auto rec = [&](int br, int c, int which) { return recs + (((size_t)br * C + c) * 3 + which) * 4096; };
+  GsImagePipe pipe{lds, recs, sched + (size_t)tree * sched_stride, 0, (int)threadIdx.x, lane};
+  pipe.Begin();
 
   GsPlv pi;
 #pragma unroll
@@ -514,24 +602,19 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, const int32_t* __restri
         GsTip(rec(c0, c, 0), s0, kq, a);
       } else {
         GsLoad(slot(c0, c), lane, x);
-        GsMatVec(rec(c0, c, 0), lane, x, a);
+        pipe.MatVec(x, a);
       }
       if (c1 < n) {
         GsTip(rec(c1, c, 0), s1, kq, bb);
       } else {
         GsLoad(slot(c1, c), lane, x);
-        GsMatVec(rec(c1, c, 0), lane, x, bb);
+        pipe.MatVec(x, bb);
       }
 #pragma unroll
       for (int m = 0; m < 4; m++) a.b[m] *= bb.b[m];
       if (node == N - 1) {
-        double s = 0.0;
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) s += pi.b[m][r] * a.b[m][r];
-        site += model[kGsCatWeight + c] * s;
-      } else {
+        site += model[kGsCatWeight + c] * GsDot(pi, a);
+      } else if (active) {
         GsStore(slot(node, c), lane, a);
       }
     }
@@ -539,12 +622,12 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, const int32_t* __restri
   site = GsPatternSum(site);
   const double ll = kq == 0 ? weight * log(site) : 0.0;
   const double wll = WaveSum64(ll);
-  if (lane == 0) part_ll[(size_t)tree * tiles + tile] = wll;
+  if (lane == 0 && active) part_ll[(size_t)tree * tiles + tile] = wll;
 
   // ---- pre-order + edge derivatives: one step per internal node, parents first -------------
   if (GRAD) {
     double* __restrict__ grow = part_grad + ((size_t)tree * tiles + tile) * N;
-    if (lane == 0) grow[N - 1] = 0.0;
+    if (lane == 0 && active) grow[N - 1] = 0.0;
     for (int node = N - 1; node >= n; --node) {
       const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
       const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
@@ -552,43 +635,62 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, const int32_t* __restri
       const int s1 = c1 < n ? tips[(size_t)c1 * Ppad] : 0;
       double den = 0.0, num0 = 0.0, num1 = 0.0;
       for (int c = 0; c < C; c++) {
-        GsPlv u, a0, d0, a1, d1, x;
+        GsPlv u, w0, w1, x, y;
         if (node == N - 1) {
           u = pi;
         } else {
           GsLoad(slot(node, c), lane, u);
         }
+        // child messages a0 -> w1 = u . a0, a1 -> w0 = u . a1
         if (c0 < n) {
-          GsTip(rec(c0, c, 0), s0, kq, a0);
-          GsTip(rec(c0, c, 1), s0, kq, d0);
+          GsTip(rec(c0, c, 0), s0, kq, w1);
         } else {
           GsLoad(slot(c0, c), lane, x);
-          GsMatVec(rec(c0, c, 0), lane, x, a0);
-          GsMatVec(rec(c0, c, 1), lane, x, d0);
+          pipe.MatVec(x, w1);
         }
         if (c1 < n) {
-          GsTip(rec(c1, c, 0), s1, kq, a1);
-          GsTip(rec(c1, c, 1), s1, kq, d1);
+          GsTip(rec(c1, c, 0), s1, kq, w0);
         } else {
           GsLoad(slot(c1, c), lane, x);
-          GsMatVec(rec(c1, c, 0), lane, x, a1);
-          GsMatVec(rec(c1, c, 1), lane, x, d1);
+          pipe.MatVec(x, w0);
         }
         const double wc = model[kGsCatWeight + c];
-        den += wc * GsDot3(u, a0, a1);
-        num0 += wc * GsDot3(u, a1, d0);
-        num1 += wc * GsDot3(u, a0, d1);
-        if (c0 >= n) {
+        {
+          double sden = 0.0;
 #pragma unroll
-          for (int m = 0; m < 4; m++) x.b[m] = u.b[m] * a1.b[m];
-          GsMatVec(rec(c0, c, 2), lane, x, d0);
-          GsStore(slot(c0, c), lane, d0);
+          for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const double a0 = w1.b[m][r], a1 = w0.b[m][r], uu = u.b[m][r];
+              w0.b[m][r] = uu * a1;
+              w1.b[m][r] = uu * a0;
+              sden += w0.b[m][r] * a0;
+            }
+          den += wc * sden;
+        }
+        // derivatives of the child messages against the opposite products
+        if (c0 < n) {
+          GsTip(rec(c0, c, 1), s0, kq, y);
+        } else {
+          GsLoad(slot(c0, c), lane, x);
+          pipe.MatVec(x, y);
+        }
+        num0 += wc * GsDot(w0, y);
+        if (c1 < n) {
+          GsTip(rec(c1, c, 1), s1, kq, y);
+        } else {
+          GsLoad(slot(c1, c), lane, x);
+          pipe.MatVec(x, y);
+        }
+        num1 += wc * GsDot(w1, y);
+        // pre-order partials of the internal children, in place
+        if (c0 >= n) {
+          pipe.MatVec(w0, y);
+          if (active) GsStore(slot(c0, c), lane, y);
         }
         if (c1 >= n) {
-#pragma unroll
-          for (int m = 0; m < 4; m++) x.b[m] = u.b[m] * a0.b[m];
-          GsMatVec(rec(c1, c, 2), lane, x, d1);
-          GsStore(slot(c1, c), lane, d1);
+          pipe.MatVec(w1, y);
+          if (active) GsStore(slot(c1, c), lane, y);
         }
       }
       den = GsPatternSum(den);
@@ -597,7 +699,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, const int32_t* __restri
       const double scale = kq == 0 ? weight / den : 0.0;
       const double g0 = WaveSum64(num0 * scale);
       const double g1 = WaveSum64(num1 * scale);
-      if (lane == 0) {
+      if (lane == 0 && active) {
         grow[c0] = g0;
         grow[c1] = g1;
       }
@@ -616,12 +718,14 @@ void LaunchGsWalk(const BatchDims& d, int S, const DeviceBatch& b, const int32_t
                   const double* gs_model, int tree0, int chunk, int tiles, int want_gradient,
                   hipStream_t stream) {
   const dim3 grid((tiles + 3) / 4, chunk), block(256);
+  const size_t lds = 2 * 4096 * sizeof(double);
+  const int stride = GsScheduleStride(d);
   if (want_gradient)
-    hipLaunchKernelGGL((gs_walk_kernel<true>), grid, block, 0, stream, d, S, tree0, tiles, b.children, b.images,
-                       model_index, gs_model, b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+    hipLaunchKernelGGL((gs_walk_kernel<true>), grid, block, lds, stream, d, S, tree0, tiles, stride, b.children, b.sched,
+                       b.images, model_index, gs_model, b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
   else
-    hipLaunchKernelGGL((gs_walk_kernel<false>), grid, block, 0, stream, d, S, tree0, tiles, b.children, b.images,
-                       model_index, gs_model, b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+    hipLaunchKernelGGL((gs_walk_kernel<false>), grid, block, lds, stream, d, S, tree0, tiles, stride, b.children, b.sched,
+                       b.images, model_index, gs_model, b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
 }
 
 }  // namespace bito_amd

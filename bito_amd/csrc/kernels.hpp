@@ -171,6 +171,8 @@ void LaunchGsSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch&
 void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const double* branch,
                       const int32_t* model_index, const double* gs_model, double* imgs, int want_gradient,
                       int deriv_mode, hipStream_t stream);
+int GsScheduleStride(const BatchDims& d);  // int32 entries per tree of the image-order list (b.sched)
+void LaunchGsSchedule(const BatchDims& d, const DeviceBatch& b, hipStream_t stream);
 void LaunchGsWalk(const BatchDims& d, int S, const DeviceBatch& b, const int32_t* model_index,
                   const double* gs_model, int tree0, int chunk, int tiles, int want_gradient,
                   hipStream_t stream);
