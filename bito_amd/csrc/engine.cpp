@@ -164,6 +164,8 @@ int ParseSpec(const char* sub, const char* site, const char* clock, ModelSpec* m
   }
   m->param_count = at;
   m->state_count = (m->substitution == kGY94) ? 61 : 4;
+  for (int i = 0; i < m->category_count && i < 16; i++)
+    m->weibull_log_l[i] = std::log(-std::log(1.0 - (2.0 * i + 1.0) / (2.0 * m->category_count)));
   blocks->push_back({"entire", 0, at});
   return BITO_AMD_OK;
 }
@@ -309,7 +311,7 @@ int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int
   if (e->gs_model_index.capacity < (size_t)T)
     return Fail(e, BITO_AMD_ERR_STATE, "select the general-state kernels before uploading the batch");
   const int tiles = GsTiles(d.pattern_count);
-  const size_t img_per_tree = GsImageDoublesPerTree(d), arena_per_tree = GsArenaDoublesPerTree(d, tiles);
+  const size_t img_per_tree = GsImageDoublesPerTree(d), arena_per_tree = GsArenaDoublesPerTree(d, tiles, want_gradient);
   const size_t per_tree = (img_per_tree + arena_per_tree) * sizeof(double);
   size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
   chunk = std::min<size_t>(chunk, 65535);
@@ -331,7 +333,7 @@ int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int
       ev1 = NextEvent(e);
       HIP_TRY(e, hipEventRecord(ev0, e->stream));
     }
-    LaunchGsWalk(d, S, b, e->gs_model_index.ptr, e->gs_model.ptr, t0, ct, tiles, want_gradient, e->stream);
+    LaunchGsWalk(d, S, b, e->gs_model_index.ptr, e->gs_model.ptr, t0, ct, tiles, want_gradient, deriv_mode, e->stream);
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
   }
   e->kernel_name = "gs_walk_kernel";

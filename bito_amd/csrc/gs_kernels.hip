@@ -43,6 +43,12 @@ __device__ __forceinline__ double WaveSum64(double v) {
   return v;
 }
 
+// MFMA A-operand image position of matrix element (row, col); see the matrices kernel below.
+__device__ __forceinline__ int GsImageIndex(int row, int col) {
+  const int mb = row >> 4, ii = row & 15, ks = col >> 2, kq = col & 3;
+  return ((mb * 8 + (ks >> 1)) * 64 + 16 * kq + ii) * 2 + (ks & 1);
+}
+
 }  // namespace
 
 // --------------------------------------------------------------------------------------------
@@ -152,7 +158,10 @@ gs_model_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, const int32_t* __res
   if (lane < S)
     for (int j = 0; j < S; j++) A[lane * kLd + j] /= total;
   __syncthreads();
-  for (int i = 0; i < 64; i++) out[kGsQ + i * 64 + lane] = A[i * kLd + lane];
+  for (int i = 0; i < 64; i++) {
+    out[kGsQ + i * 64 + lane] = A[i * kLd + lane];
+    out[kGsQtImage + GsImageIndex(lane, i)] = A[i * kLd + lane];  // MFMA image of Q^T: M[lane][i] = Q[i][lane]
+  }
   // symmetrise: D^{1/2} Q D^{-1/2}, lower triangle computed, upper mirrored; parked in the V slot
   // of the record until the eigensolver kernel replaces it
   const double mysq = lane < S ? sqrt(mypi) : 1.0;
@@ -176,12 +185,11 @@ gs_model_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, const int32_t* __res
       double mean = 0, dmean = 0;
       double du[kMaxCategories];
       for (int i = 0; i < C; i++) {
-        const double quantile = (2.0 * i + 1.0) / (2.0 * C);
-        const double l = -log(1.0 - quantile);
-        const double rr = pow(l, 1.0 / shape);
+        const double log_l = spec.weibull_log_l[i];
+        const double rr = DetExp(log_l / shape);  // = pow(-log(1 - quantile), 1 / shape)
         rate[i] = rr;
         mean += rr;
-        du[i] = -rr * log(l) / (shape * shape);
+        du[i] = -rr * log_l / (shape * shape);
         dmean += du[i];
       }
       mean /= C;
@@ -322,7 +330,7 @@ void LaunchGsSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch&
 // ascending k.
 //
 // Output record per (tree, branch, category): 3 x 4096 doubles.
-//   internal branch:  [0] image of P, [1] image of dP, [2] image of P^T       (MFMA A operands)
+//   internal branch:  [0] image of P, [2] image of P^T                         (MFMA A operands)
 //   leaf branch:      [0] PT[s][i] = P[i][s], [1] dPT[s][i]  row-major 64 x 64; row S (gap) is
 //                     1 (P) / 0 (dP) on the real states
 // Image of a matrix M (out = M x): element M[16 mb + ii][4 ks + kq] sits at
@@ -334,11 +342,6 @@ void LaunchGsSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch&
 // result into the next one's operand without leaving its registers.  Leaf tables are stored with
 // the same permutation inside each block of 16 states (position 16 m + 4 q + r) so that a lane's
 // four values are one 32-byte load.
-
-__device__ __forceinline__ int GsImageIndex(int row, int col) {
-  const int mb = row >> 4, ii = row & 15, ks = col >> 2, kq = col & 3;
-  return ((mb * 8 + (ks >> 1)) * 64 + 16 * kq + ii) * 2 + (ks & 1);
-}
 
 __global__ void __launch_bounds__(256)
 gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ branch,
@@ -354,7 +357,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
   const double* __restrict__ m = gs_model + (size_t)model_index[tree] * kGsModelStride;
   const double rate = m[kGsCatRate + c];
   const double time = branch[(size_t)tree * d.node_count + br] * rate;
-  if (tid < 64) e[tid] = exp(m[kGsLambda + tid] * time);
+  if (tid < 64) e[tid] = DetExp(m[kGsLambda + tid] * time);
   __syncthreads();
   for (int idx = tid; idx < 4096; idx += 256) W[(idx & 63) * 64 + (idx >> 6)] = m[kGsV + idx] * e[idx & 63];
   __syncthreads();
@@ -370,7 +373,8 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
       for (int ii = 0; ii < 16; ii++) accP[ii] = fma(wk[ii], vi, accP[ii]);
     }
   }
-  if (want_gradient) {
+  if (want_gradient && br < n) {
+    // leaf branches only (internal branches use Q^T in the traversal).
     // dP/dt = P (r_c Q), formed from the ROUNDED P exactly as the reference's edge derivative
     // pre^T (r_c Q) post sees it (BuildDifferentialMatrices, src/fat_beagle.cpp:101-111): entries of P
     // that are O(t^2) carry a large relative rounding error, which must enter numerator and
@@ -403,10 +407,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
     for (int ii = 0; ii < 16; ii++) {
       const int i = ib * 16 + ii;
       rec[GsImageIndex(i, j)] = accP[ii];
-      if (want_gradient) {
-        rec[4096 + GsImageIndex(i, j)] = accD[ii];
-        rec[8192 + GsImageIndex(j, i)] = accP[ii];  // P^T
-      }
+      if (want_gradient) rec[8192 + GsImageIndex(j, i)] = accP[ii];  // P^T
     }
   }
 }
@@ -439,8 +440,8 @@ struct GsPlv {
 };
 
 // Image order of one tree.  Post-order: per internal node and category, P of each internal child.
-// Pre-order: per internal node (parents first) and category: P of each internal child, dP of each
-// internal child, P^T of each internal child.  Entries are record numbers (br * C + c) * 3 + which.
+// Pre-order: per internal node (parents first), category and internal child: P^T of the child, then
+// the model's Q^T (entry -1).  Other entries are record numbers (br * C + c) * 3 + which.
 __global__ void __launch_bounds__(64)
 gs_schedule_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __restrict__ jobs, int stride) {
   const int t = blockIdx.x * 64 + threadIdx.x;
@@ -457,11 +458,13 @@ gs_schedule_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* _
       }
   for (int node = N - 1; node >= n; node--)
     for (int c = 0; c < C; c++)
-      for (int which = 0; which < 3; which++)
-        for (int side = 0; side < 2; side++) {
-          const int k = ch[(node - n) * 2 + side];
-          if (k >= n) out[at++] = (k * C + c) * 3 + which;
+      for (int side = 0; side < 2; side++) {
+        const int k = ch[(node - n) * 2 + side];
+        if (k >= n) {
+          out[at++] = (k * C + c) * 3 + 2;
+          out[at++] = -1;
         }
+      }
   const int last = at ? out[at - 1] : 0;
   for (; at < stride; at++) out[at] = last;
 }
@@ -505,13 +508,18 @@ __device__ __forceinline__ double GsPatternSum(double v) {
 struct GsImagePipe {
   double* lds;                        // two 4096-double buffers
   const double* __restrict__ recs;    // the tree's records
+  const double* __restrict__ qt;      // the model's Q^T image (entry -1 of the image order)
   const int32_t* __restrict__ jobs;   // the tree's image order
   int j;                              // image now in lds[(j & 1) * 4096]
   int tid, lane;
 
+  __device__ __forceinline__ const double* Image(int entry) const {
+    return entry < 0 ? qt : recs + (size_t)entry * 4096;
+  }
+
   __device__ __forceinline__ void Begin() {
     j = 0;
-    const v2d* src = reinterpret_cast<const v2d*>(recs + (size_t)jobs[0] * 4096) + tid;
+    const v2d* src = reinterpret_cast<const v2d*>(Image(jobs[0])) + tid;
     v2d* dst = reinterpret_cast<v2d*>(lds) + tid;
 #pragma unroll
     for (int i = 0; i < 8; i++) dst[i * 256] = src[i * 256];
@@ -521,7 +529,7 @@ struct GsImagePipe {
   // out = (image j) x; leaves image j+1 in the other buffer
   __device__ __forceinline__ void MatVec(const GsPlv& x, GsPlv& out) {
     const int next = __builtin_amdgcn_readfirstlane(jobs[j + 1]);
-    const v2d* src = reinterpret_cast<const v2d*>(recs + (size_t)next * 4096) + tid;
+    const v2d* src = reinterpret_cast<const v2d*>(Image(next)) + tid;
     v2d pre[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) pre[i] = src[i * 256];
@@ -558,7 +566,7 @@ struct GsImagePipe {
 
 template <bool GRAD>
 __global__ void __launch_bounds__(256)
-gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, int sched_stride, const int32_t* __restrict__ children,
+gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_stride, int deriv_mode, const int32_t* __restrict__ children,
                const int32_t* __restrict__ sched, const double* __restrict__ imgs,
                const int32_t* __restrict__ model_index, const double* __restrict__ gs_model,
                const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
@@ -568,19 +576,27 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, int sched_stride, const
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, pn = lane & 15;
   // a wave past the last tile repeats the last tile's work (it must take part in the image
   // pipeline) and stores nothing
-  const bool active = blockIdx.x * 4 + wave < tiles;
-  const int tile = active ? blockIdx.x * 4 + wave : tiles - 1;
-  const int tree = tree0 + blockIdx.y;
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id: id % 8 picks the XCD.  All tile groups
+  // of a tree get the same id % 8, so that a tree's images are fetched into one L2 only.
+  const int groups = (tiles + 3) / 4;
+  const int tree_local = (int)(blockIdx.x / 8 / groups) * 8 + (int)(blockIdx.x % 8);
+  const int group = (int)(blockIdx.x / 8) % groups;
+  if (tree_local >= chunk) return;
+  const bool active = group * 4 + wave < tiles;
+  const int tile = active ? group * 4 + wave : tiles - 1;
+  const int tree = tree0 + tree_local;
   const int p = tile * 16 + pn;
   const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
   const double* __restrict__ model = gs_model + (size_t)model_index[tree] * kGsModelStride;
-  const double* __restrict__ recs = imgs + (size_t)blockIdx.y * (N - 1) * C * (3 * 4096);
-  double* __restrict__ slots = arena + (size_t)blockIdx.y * NI * C * tiles * 1024;
+  const double* __restrict__ recs = imgs + (size_t)tree_local * (N - 1) * C * (3 * 4096);
+  double* __restrict__ slots = arena + (size_t)tree_local * (GRAD ? 2 : 1) * NI * C * tiles * 1024;
   const uint8_t* __restrict__ tips = tip_states + p;
   const double weight = weights[p];
   auto slot = [&](int node, int c) { return slots + (((size_t)(node - n) * C + c) * tiles + tile) * 1024; };
+  // message P x of an internal child, kept for the pre-order pass (second half of the tree's arena)
+  auto mslot = [&](int node, int c) { return slots + (((size_t)(NI + node - n) * C + c) * tiles + tile) * 1024; };
   auto rec = [&](int br, int c, int which) { return recs + (((size_t)br * C + c) * 3 + which) * 4096; };
-  GsImagePipe pipe{lds, recs, sched + (size_t)tree * sched_stride, 0, (int)threadIdx.x, lane};
+  GsImagePipe pipe{lds, recs, model + kGsQtImage, sched + (size_t)tree * sched_stride, 0, (int)threadIdx.x, lane};
   pipe.Begin();
 
   GsPlv pi;
@@ -603,12 +619,14 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, int sched_stride, const
       } else {
         GsLoad(slot(c0, c), lane, x);
         pipe.MatVec(x, a);
+        if (GRAD && active) GsStore(mslot(c0, c), lane, a);
       }
       if (c1 < n) {
         GsTip(rec(c1, c, 0), s1, kq, bb);
       } else {
         GsLoad(slot(c1, c), lane, x);
         pipe.MatVec(x, bb);
+        if (GRAD && active) GsStore(mslot(c1, c), lane, bb);
       }
 #pragma unroll
       for (int m = 0; m < 4; m++) a.b[m] *= bb.b[m];
@@ -645,14 +663,12 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, int sched_stride, const
         if (c0 < n) {
           GsTip(rec(c0, c, 0), s0, kq, w1);
         } else {
-          GsLoad(slot(c0, c), lane, x);
-          pipe.MatVec(x, w1);
+          GsLoad(mslot(c0, c), lane, w1);
         }
         if (c1 < n) {
           GsTip(rec(c1, c, 0), s1, kq, w0);
         } else {
-          GsLoad(slot(c1, c), lane, x);
-          pipe.MatVec(x, w0);
+          GsLoad(mslot(c1, c), lane, w0);
         }
         const double wc = model[kGsCatWeight + c];
         {
@@ -668,29 +684,29 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, int sched_stride, const
             }
           den += wc * sden;
         }
-        // derivatives of the child messages against the opposite products
+        // per child: pre-order partial q = P^T w (stored in place of the child's post-order partial
+        // x), and the edge derivative in the reference's own form  pre^T (r_c Q) post = (Q^T q) . x r_c
+        // (src/fat_beagle.cpp:101-160); a tip child reads dP's column instead
+        const double rc = model[(deriv_mode ? kGsCatRateDeriv : kGsCatRate) + c];  // site-model pass: d r_c / d shape
         if (c0 < n) {
           GsTip(rec(c0, c, 1), s0, kq, y);
+          num0 += wc * GsDot(w0, y);
         } else {
+          pipe.MatVec(w0, y);
           GsLoad(slot(c0, c), lane, x);
-          pipe.MatVec(x, y);
+          if (active) GsStore(slot(c0, c), lane, y);
+          pipe.MatVec(y, w0);
+          num0 += wc * rc * GsDot(w0, x);
         }
-        num0 += wc * GsDot(w0, y);
         if (c1 < n) {
           GsTip(rec(c1, c, 1), s1, kq, y);
+          num1 += wc * GsDot(w1, y);
         } else {
-          GsLoad(slot(c1, c), lane, x);
-          pipe.MatVec(x, y);
-        }
-        num1 += wc * GsDot(w1, y);
-        // pre-order partials of the internal children, in place
-        if (c0 >= n) {
-          pipe.MatVec(w0, y);
-          if (active) GsStore(slot(c0, c), lane, y);
-        }
-        if (c1 >= n) {
           pipe.MatVec(w1, y);
+          GsLoad(slot(c1, c), lane, x);
           if (active) GsStore(slot(c1, c), lane, y);
+          pipe.MatVec(y, w1);
+          num1 += wc * rc * GsDot(w1, x);
         }
       }
       den = GsPatternSum(den);
@@ -707,24 +723,24 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int tiles, int sched_stride, const
   }
 }
 
-size_t GsArenaDoublesPerTree(const BatchDims& d, int tiles) {
-  return (size_t)(d.taxon_count - 1) * d.category_count * tiles * 1024;
+size_t GsArenaDoublesPerTree(const BatchDims& d, int tiles, int want_gradient) {
+  return (size_t)(want_gradient ? 2 : 1) * (d.taxon_count - 1) * d.category_count * tiles * 1024;
 }
 size_t GsImageDoublesPerTree(const BatchDims& d) {
   return (size_t)(d.node_count - 1) * d.category_count * 3 * 4096;
 }
 
 void LaunchGsWalk(const BatchDims& d, int S, const DeviceBatch& b, const int32_t* model_index,
-                  const double* gs_model, int tree0, int chunk, int tiles, int want_gradient,
+                  const double* gs_model, int tree0, int chunk, int tiles, int want_gradient, int deriv_mode,
                   hipStream_t stream) {
-  const dim3 grid((tiles + 3) / 4, chunk), block(256);
+  const dim3 grid((unsigned)((chunk + 7) / 8 * 8 * ((tiles + 3) / 4))), block(256);
   const size_t lds = 2 * 4096 * sizeof(double);
   const int stride = GsScheduleStride(d);
   if (want_gradient)
-    hipLaunchKernelGGL((gs_walk_kernel<true>), grid, block, lds, stream, d, S, tree0, tiles, stride, b.children, b.sched,
+    hipLaunchKernelGGL((gs_walk_kernel<true>), grid, block, lds, stream, d, S, tree0, chunk, tiles, stride, deriv_mode, b.children, b.sched,
                        b.images, model_index, gs_model, b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
   else
-    hipLaunchKernelGGL((gs_walk_kernel<false>), grid, block, lds, stream, d, S, tree0, tiles, stride, b.children, b.sched,
+    hipLaunchKernelGGL((gs_walk_kernel<false>), grid, block, lds, stream, d, S, tree0, chunk, tiles, stride, deriv_mode, b.children, b.sched,
                        b.images, model_index, gs_model, b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
 }
 

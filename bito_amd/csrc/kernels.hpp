@@ -161,9 +161,10 @@ void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_
 // share one record: model_index[t] = first tree with t's row.
 constexpr int kGsV = 0, kGsVinv = 4096, kGsQ = 8192, kGsLambda = 12288, kGsPi = kGsLambda + 64, kGsSq = kGsPi + 64,
               kGsCatRate = kGsSq + 64, kGsCatWeight = kGsCatRate + kMaxCategories,
-              kGsCatRateDeriv = kGsCatWeight + kMaxCategories, kGsModelStride = kGsCatRateDeriv + kMaxCategories;
+              kGsCatRateDeriv = kGsCatWeight + kMaxCategories, kGsQtImage = kGsCatRateDeriv + kMaxCategories,
+              kGsModelStride = kGsQtImage + 4096;  // kGsQtImage: Q^T as an MFMA A-operand image
 inline int GsTiles(int pattern_count) { return (pattern_count + 15) / 16; }  // 16 site patterns per wave
-size_t GsArenaDoublesPerTree(const BatchDims& d, int tiles);
+size_t GsArenaDoublesPerTree(const BatchDims& d, int tiles, int want_gradient);
 size_t GsImageDoublesPerTree(const BatchDims& d);
 void LaunchGsSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, const int32_t* model_index,
                    double* gs_model, hipStream_t stream);
@@ -174,7 +175,7 @@ void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const dou
 int GsScheduleStride(const BatchDims& d);  // int32 entries per tree of the image-order list (b.sched)
 void LaunchGsSchedule(const BatchDims& d, const DeviceBatch& b, hipStream_t stream);
 void LaunchGsWalk(const BatchDims& d, int S, const DeviceBatch& b, const int32_t* model_index,
-                  const double* gs_model, int tree0, int chunk, int tiles, int want_gradient,
+                  const double* gs_model, int tree0, int chunk, int tiles, int want_gradient, int deriv_mode,
                   hipStream_t stream);
 
 

@@ -38,7 +38,38 @@ struct ModelSpec {
   int32_t freq_start, rates_start, rates_len, shape_start, clock_start;
   int32_t param_count;
   int32_t state_count;  // 4, or 61 for the codon model "GY94" (general-state kernels, gs_kernels.hip)
+  // log(-log(1 - (2i+1)/(2C))) of the Weibull category medians: depends on the category count only,
+  // evaluated once on the host (general-state kernels)
+  double weibull_log_l[16];
 };
+
+// exp() with a fixed operation sequence (argument reduction by ln 2, degree-13 Taylor polynomial in
+// Horner form, every step an IEEE multiply or a correctly rounded fma, exact scaling by 2^k): the same
+// bits on any IEEE machine.  About 1 ulp.  The general-state set-up uses it for exp(lambda t r_c) and
+// the category rates: the O(t^2) entries of a codon P(t) are ill-conditioned,
+// so results must not depend on which math library evaluated exp.
+__host__ __device__ inline double DetExp(double x) {
+  if (x < -745.0) return 0.0;
+  if (x > 709.0) return HUGE_VAL;
+  const double k = rint(x * 1.4426950408889634);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
 
 // Per-tree model state produced by the set-up kernel and consumed by the
 // transition-matrix and traversal kernels.  Row-major 4x4.

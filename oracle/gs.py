@@ -36,9 +36,11 @@ def lib():
             getattr(L, f).argtypes = [C.c_void_p]
         L.gs_engine_last_error.restype = C.c_char_p
         L.gs_engine_last_error.argtypes = [C.c_void_p]
-        L.gs_engine_evaluate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, dp, dp, dp, C.c_int, dp, dp]
+        L.gs_engine_evaluate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, dp, dp, dp, C.c_int, dp, dp, dp]
         L.gs_substitution_model.argtypes = [C.c_char_p, dp, dp, dp, dp, dp, dp]
         L.gs_transition_matrix.argtypes = [dp, dp, dp, C.c_double, dp]
+        L.gs_det_exp.restype = C.c_double
+        L.gs_det_exp.argtypes = [C.c_double]
         L.gs_codon_table.argtypes = [ip]
         L.gs_codon_state.argtypes = [C.c_int, C.c_int, C.c_int]
         _lib = L
@@ -112,7 +114,7 @@ class GsOracleEngine:
             lib().gs_engine_destroy(self._h)
             self._h = None
 
-    def _run(self, parent_ids, branch_lengths, params, rates, rescaling, want_gradient):
+    def _run(self, parent_ids, branch_lengths, params, rates, rescaling, want_gradient, want_site=False):
         parent_ids = np.ascontiguousarray(parent_ids, dtype=np.int32)
         branch_lengths = np.ascontiguousarray(branch_lengths, dtype=np.float64)
         T, M = branch_lengths.shape
@@ -123,15 +125,19 @@ class GsOracleEngine:
             rates = np.ascontiguousarray(rates, dtype=np.float64)
         ll = np.zeros(T)
         grad = np.zeros((T, 2 * self.taxon_count - 1)) if want_gradient else None
+        site = np.zeros(T) if want_site else None
         rc = lib().gs_engine_evaluate(self._h, T, rooted, M, _ip(parent_ids), _dp(branch_lengths), _dp(rates),
-                                      _dp(params), int(rescaling), _dp(ll), _dp(grad))
+                                      _dp(params), int(rescaling), _dp(ll), _dp(grad), _dp(site))
         if rc:
             raise GsOracleError(lib().gs_engine_last_error(self._h).decode())
-        return ll, grad
+        return (ll, grad, site) if want_site else (ll, grad)
 
     def log_likelihoods(self, parent_ids, branch_lengths, params, rates=None, rescaling=False):
         return self._run(parent_ids, branch_lengths, params, rates, rescaling, False)[0]
 
-    def gradients(self, parent_ids, branch_lengths, params, rates=None, rescaling=False):
-        ll, grad = self._run(parent_ids, branch_lengths, params, rates, rescaling, True)
-        return {"log_likelihood": ll, "branch_lengths": grad}
+    def gradients(self, parent_ids, branch_lengths, params, rates=None, rescaling=False, site_model=False):
+        res = self._run(parent_ids, branch_lengths, params, rates, rescaling, True, site_model)
+        out = {"log_likelihood": res[0], "branch_lengths": res[1]}
+        if site_model:
+            out["site_model"] = res[2]
+        return out

@@ -252,10 +252,39 @@ static void eigen_reversible(int S, const double *Q, const double *pi, double *V
   free(U);
 }
 
+/* exp() with a fixed operation sequence (argument reduction by ln 2, degree-13 Taylor polynomial in
+ * Horner form, every step an IEEE multiply or a correctly rounded fma, exact scaling by 2^k): the
+ * same bits on any IEEE machine, CPU or GPU.  Accuracy about 1 ulp.  Errors in P(t) are coherent
+ * across site patterns and its O(t^2) entries are ill-conditioned, so the
+ * set-up arithmetic must not depend on whose libm is linked. */
+static double det_exp(double x) {
+  if (x < -745.0) return 0.0;
+  if (x > 709.0) return HUGE_VAL;
+  const double k = rint(x * 1.4426950408889634);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+double gs_det_exp(double x) { return det_exp(x); }
+
 /* P = V diag(exp(lam t)) V^-1: W = V diag(e) rounded, then an fma chain over ascending k. */
 static void transition_matrix(const double *V, const double *Vinv, const double *lam, double t, double *P) {
   double e[MS], W[MS];
-  for (int k = 0; k < MS; k++) e[k] = exp(lam[k] * t);
+  for (int k = 0; k < MS; k++) e[k] = det_exp(lam[k] * t);
   for (int i = 0; i < MS; i++) {
     for (int k = 0; k < MS; k++) W[k] = V[i * MS + k] * e[k];
     for (int j = 0; j < MS; j++) {
@@ -267,15 +296,20 @@ static void transition_matrix(const double *V, const double *Vinv, const double 
 }
 
 /* WeibullSiteModel::UpdateRates (src/site_model.cpp:37-62), as bito_oracle.c */
-static void weibull_rates(int C, double shape, double *rates, double *weights) {
-  double mean = 0;
+static void weibull_rates(int C, double shape, double *rates, double *weights, double *derivs) {
+  double mean = 0, dmean = 0, du[16];
   for (int i = 0; i < C; i++) {
     const double quantile = (2.0 * i + 1.0) / (2.0 * C);
-    rates[i] = pow(-log(1.0 - quantile), 1.0 / shape);
+    const double log_l = log(-log(1.0 - quantile)); /* depends on (i, C) only */
+    rates[i] = det_exp(log_l / shape);              /* = pow(-log(1 - quantile), 1 / shape) */
     mean += rates[i];
+    du[i] = -rates[i] * log_l / (shape * shape);
+    dmean += du[i];
   }
   mean /= C;
+  dmean /= C;
   for (int i = 0; i < C; i++) {
+    derivs[i] = (du[i] * mean - rates[i] * dmean) / (mean * mean);
     rates[i] /= mean;
     weights[i] = 1.0 / C;
   }
@@ -395,10 +429,12 @@ void gs_transition_matrix(const double *V, const double *Vinv, const double *lam
   transition_matrix(V, Vinv, lam, t, P);
 }
 
-/* One tree: log-likelihood and (if grad != NULL) branch gradient [2n-1]. */
+/* One tree: log-likelihood and (if grad != NULL) branch gradient [2n-1].  deriv_mode 1 is the
+ * site-model pass of FatBeagle::Gradient (src/fat_beagle.cpp:538-550): the differential matrices are
+ * scaled by d r_c / d shape instead of r_c, and *out_site (if given) receives sum_b g_b t_b. */
 static int tree_eval(const gs_engine *e, int rooted, int M, const int *parent_ids, const double *bl_in,
                      const double *rates, const double *row, int rescaling, double *out_ll, double *grad,
-                     char *err, int err_len) {
+                     int deriv_mode, double *out_site, char *err, int err_len) {
   const gs_spec *m = &e->spec;
   const int S = m->S, C = m->C, n = e->n, P = e->P, N = 2 * n - 1;
   if (M != (rooted ? N : N - 1)) {
@@ -441,7 +477,7 @@ static int tree_eval(const gs_engine *e, int rooted, int M, const int *parent_id
   /* model */
   const size_t MM = (size_t)MS * MS;
   double *Q = (double *)malloc(sizeof(double) * MM * 3), *V = Q + MM, *Vinv = Q + 2 * MM;
-  double lam[MS], pi[MS], cat_rate[16], cat_w[16];
+  double lam[MS], pi[MS], cat_rate[16], cat_w[16], cat_dr[16];
   rc = model_setup(m, row, Q, V, Vinv, lam, pi, err, err_len);
   if (rc) {
     free(Q);
@@ -449,8 +485,12 @@ static int tree_eval(const gs_engine *e, int rooted, int M, const int *parent_id
     free(bl);
     return rc;
   }
-  if (m->weibull) weibull_rates(C, row[m->shape_start], cat_rate, cat_w);
-  else cat_rate[0] = cat_w[0] = 1.0;
+  if (m->weibull) {
+    weibull_rates(C, row[m->shape_start], cat_rate, cat_w, cat_dr);
+  } else {
+    cat_rate[0] = cat_w[0] = 1.0;
+    cat_dr[0] = 0.0;
+  }
   /* transition matrices [branch][c] (beagleUpdateTransitionMatrices) */
   double *mats = (double *)malloc(sizeof(double) * MM * (size_t)(N - 1) * C);
   for (int b = 0; b < N - 1; b++)
@@ -551,7 +591,7 @@ static int tree_eval(const gs_engine *e, int rooted, int M, const int *parent_id
           double nc = 0, dc = 0;
           for (int i = 0; i < S; i++) {
             double qx = 0;
-            for (int j = 0; j < S; j++) qx += (Q[i * MS + j] * cat_rate[c]) * x[j];
+            for (int j = 0; j < S; j++) qx += (Q[i * MS + j] * (deriv_mode ? cat_dr[c] : cat_rate[c])) * x[j];
             nc += u[i] * qx;
             dc += u[i] * x[i];
           }
@@ -563,6 +603,11 @@ static int tree_eval(const gs_engine *e, int rooted, int M, const int *parent_id
       grad[br] = g;
     }
     if (!rooted) grad[N - 2] = 0.0; /* the fixed node (src/fat_beagle.cpp:148,553) */
+    if (out_site) {
+      double sum = 0;
+      for (int i = 0; i < N - 1; i++) sum += grad[i] * bl[i];
+      *out_site = sum;
+    }
     free(pre);
   }
 #undef CHILD_MSG
@@ -580,7 +625,7 @@ typedef struct {
   int T, rooted, M, rescaling, next, rc;
   const int *parent_ids;
   const double *bl, *rates, *params;
-  double *out_ll, *out_grad;
+  double *out_ll, *out_grad, *out_site;
   pthread_mutex_t mu;
   char err[256];
 } gs_job;
@@ -598,8 +643,15 @@ static void *gs_worker(void *arg) {
     const int rc = tree_eval(j->e, j->rooted, j->M, j->parent_ids + (size_t)t * (j->M - 1), j->bl + (size_t)t * j->M,
                              j->rates ? j->rates + (size_t)t * (j->M - 1) : NULL,
                              j->params + (size_t)t * j->e->spec.param_count, j->rescaling, &ll,
-                             j->out_grad ? j->out_grad + (size_t)t * N : NULL, err, sizeof(err));
+                             j->out_grad ? j->out_grad + (size_t)t * N : NULL, 0, NULL, err, sizeof(err));
     j->out_ll[t] = ll;
+    if (!rc && j->out_site) {
+      double *g2 = (double *)malloc(sizeof(double) * N), ll2;
+      tree_eval(j->e, j->rooted, j->M, j->parent_ids + (size_t)t * (j->M - 1), j->bl + (size_t)t * j->M,
+                j->rates ? j->rates + (size_t)t * (j->M - 1) : NULL, j->params + (size_t)t * j->e->spec.param_count,
+                j->rescaling, &ll2, g2, 1, &j->out_site[t], err, sizeof(err));
+      free(g2);
+    }
     if (rc) {
       pthread_mutex_lock(&j->mu);
       if (!j->rc) {
@@ -612,10 +664,11 @@ static void *gs_worker(void *arg) {
   return NULL;
 }
 
-/* Engine::LogLikelihoods / Engine::Gradients (src/engine.cpp:58-110): out_grad may be NULL. */
+/* Engine::LogLikelihoods / Engine::Gradients (src/engine.cpp:58-110): out_grad and out_site_model
+ * ([tree_count], the "site_model" gradient) may be NULL. */
 int gs_engine_evaluate(gs_engine *e, int tree_count, int rooted, int node_count, const int *parent_ids,
                        const double *branch_lengths, const double *rates, const double *params, int rescaling,
-                       double *out_ll, double *out_grad) {
+                       double *out_ll, double *out_grad, double *out_site_model) {
   gs_job j;
   memset(&j, 0, sizeof(j));
   j.e = e;
@@ -629,6 +682,7 @@ int gs_engine_evaluate(gs_engine *e, int tree_count, int rooted, int node_count,
   j.params = params;
   j.out_ll = out_ll;
   j.out_grad = out_grad;
+  j.out_site = out_site_model;
   pthread_mutex_init(&j.mu, NULL);
   int nt = e->threads < tree_count ? e->threads : tree_count;
   if (nt <= 1) {

@@ -171,3 +171,27 @@ def test_codon_gradient_is_the_derivative_of_the_log_likelihood(data_dir):
     res = eng.gradients(pid, bl, params, rescaling=True)
     assert abs(res["log_likelihood"][0] - out["log_likelihood"][0]) < 1e-9
     assert np.abs(res["branch_lengths"] - out["branch_lengths"]).max() < 1e-7
+
+
+def test_site_model_gradient_generic_path(data_dir):
+    """src/rooted_sbn_instance.hpp:409-430: fluA, JC69 + weibull+4 shape 0.1, d/d shape = -5.231329
+    (the S-generic site-model pass at S = 4), and the codon model's against a central difference."""
+    g = GOLD["flua_jc69_weibull4_shape0.1"]
+    tc, sp = _load(data_dir, "fluA.fa", "fluA.tree")
+    rates = np.full((1, tc.trees[0].node_count - 1), 0.001)
+    eng = gs.GsOracleEngine("GTR", "weibull+4", sp.patterns, sp.weights)
+    out = eng.gradients(tc.parent_id_matrix(), tc.branch_length_matrix(), _equal_gtr(1, g["shape"]), rates=rates,
+                        site_model=True)
+    assert abs(out["log_likelihood"][0] - g["log_likelihood"]) < 1e-9
+    assert abs(out["site_model"][0] - g["site_model_gradient"]) < 1e-6
+    sp, pid, bl = _flu_codon(data_dir)
+    keep = slice(0, 40)
+    eng = gs.GsOracleEngine("GY94", "weibull+3", sp.patterns[:, keep], sp.weights[keep], 8)
+    params = np.array([list(CODON_PARAMS) + [0.7]])
+    got = eng.gradients(pid, bl, params, site_model=True)["site_model"][0]
+    eps = 1e-6
+    plus, minus = params.copy(), params.copy()
+    plus[0, 6] += eps
+    minus[0, 6] -= eps
+    fd = (eng.log_likelihoods(pid, bl, plus)[0] - eng.log_likelihoods(pid, bl, minus)[0]) / (2 * eps)
+    assert abs(got - fd) < 1e-5 * max(1.0, abs(fd))
