@@ -31,19 +31,34 @@ FP64_MFMA_PEAK_TFLOPS = 68.0  # measured, scripts: bito_amd/csrc/microbench.hip
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def algorithmic_bytes_per_tree(n: int, P: int, C: int, gradient: bool) -> float:
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (MI355X_MICROARCH.md); codon workload
+
+
+def algorithmic_bytes_per_tree(n: int, P: int, C: int, gradient: bool, S: int = 4) -> float:
     """B_plv = C*P*S*8; LL: (3(n-1)+1) B_plv; LL+grad: (13n-12) B_plv."""
-    b_plv = C * P * 4 * 8
+    b_plv = C * P * S * 8
     return ((13 * n - 12) if gradient else (3 * (n - 1) + 1)) * b_plv
+
+
+def algorithmic_flops_per_tree(n: int, P: int, C: int, S: int) -> float:
+    """SURVEY.md section 8d, LL + gradient: C P [(3n-3)(4S^2-S) + (2n-2)(2S^2+3S-1)]."""
+    return C * P * ((3 * n - 3) * (4 * S * S - S) + (2 * n - 2) * (2 * S * S + 3 * S - 1))
 
 
 def cpu_baseline(w, seconds: float):
     """The CPU oracle driven like the reference Engine (one instance per thread, dynamic
     queue over trees) on a bounded sample of the same workload."""
-    from oracle import oracle
-
     threads = os.cpu_count() or 1
-    eng = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, threads)
+    if w.substitution == "GY94":
+        from oracle import gs
+
+        eng = gs.GsOracleEngine(w.substitution, w.site, w.patterns, w.weights, threads)
+        source = "oracle/gs_oracle.c"
+    else:
+        from oracle import oracle
+
+        eng = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, threads)
+        source = "oracle/bito_oracle.c"
     run = eng.gradients if w.want_gradient else eng.log_likelihoods
 
     def sample(count):
@@ -63,7 +78,7 @@ def cpu_baseline(w, seconds: float):
     run(pid, bl, par, rescaling=w.rescaling)
     dt = time.perf_counter() - t0
     return {"value": count / dt, "unit": "trees/s", "cores": threads, "kind": "port",
-            "sample": f"{count} trees of the same workload, {dt:.1f} s, oracle/bito_oracle.c with {threads} threads "
+            "sample": f"{count} trees of the same workload, {dt:.1f} s, {source} with {threads} threads "
                       "(FP64 restatement of the BEAGLE CPU path; the reference binary cannot be built here)"}
 
 
@@ -97,6 +112,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=16, help="x100 DS1 topologies per GPU")
+    ap.add_argument("--workload", choices=["ds1", "codon"], default="ds1",
+                    help="ds1 = BASELINE config 3 (the headline metric); codon = config 5 (fluA as codons, GY94)")
+    ap.add_argument("--trees", type=int, default=1024, help="codon workload: trees per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 HBM arena, 2 LDS")
@@ -125,16 +143,18 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # every rank builds the same replicated workload and takes its own block of trees
-    full = workloads.ds1_gtr_weibull4(args.replicas * world)
+    codon = args.workload == "codon"
+    full = workloads.flua_codon(args.trees * world) if codon else workloads.ds1_gtr_weibull4(args.replicas * world)
     w = full.shard(rank, world)
     T = w.tree_count
     n, P = w.patterns.shape
-    C = 4
-    N = 2 * n - 1
+    C = 1 if codon else 4
+    S = 61 if codon else 4
 
     eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights,
                           device_id=local_rank)
-    eng.set_kernel(args.kernel)
+    if not codon:
+        eng.set_kernel(args.kernel)
     eng.upload(w.parent_ids, w.branch_lengths, w.params)
 
     def step():
@@ -175,11 +195,26 @@ def main():
         value = total_trees * args.steps / elapsed
         trees_per_launch = T * args.steps / max(launches, 1)
         avg_kernel_s = kernel_ms * 1e-3 / max(launches, 1)
-        alg_bytes = algorithmic_bytes_per_tree(n, P, C, w.want_gradient) * trees_per_launch
+        alg_bytes = algorithmic_bytes_per_tree(n, P, C, w.want_gradient, S) * trees_per_launch
         achieved = alg_bytes / avg_kernel_s / 1e9
         kernel = eng.kernel_name()
+        if codon:
+            flops = algorithmic_flops_per_tree(n, P, C, S) * trees_per_launch
+            arithmetic = {"bound": "mfma", "achieved": flops / avg_kernel_s / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": flops / avg_kernel_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                          "note": "algorithmic flops of SURVEY 8d (tip children counted as full products); "
+                                  "v_mfma_f64_16x16x4 sustains 47.6 TFLOP/s on this part (profiles/r1_microbench.json)"}
+            workload = (f"BASELINE config 5: fluA.fa as codons (69 taxa, 329 codon columns = {P} patterns, 61 states), "
+                        f"fluA.tree topology x {T} trees per GPU with seeded branch lengths, GY94 (kappa, omega, F1x4), "
+                        "log-likelihood + branch-length gradient")
+        else:
+            arithmetic = arithmetic_view(n, P, C, w.want_gradient, trees_per_launch, avg_kernel_s)
+            workload = ("BASELINE config 3: DS1.fasta (27 taxa, 934 patterns) x 100 topologies x "
+                        f"{args.replicas} replicas per GPU, GTR+weibull4 (4 categories), seeded Exp(0.1) branch "
+                        "lengths, log-likelihood + branch-length gradient")
         out = {
-            "metric": "tree log-likelihoods+gradients/sec (DS1 GTR+Gamma4)",
+            "metric": ("tree log-likelihoods+gradients/sec (fluA codon GY94, 61 states)" if codon
+                       else "tree log-likelihoods+gradients/sec (DS1 GTR+Gamma4)"),
             "value": value,
             "unit": "trees/s",
             "n_gpus": world,
@@ -192,9 +227,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE config 3: DS1.fasta (27 taxa, 934 patterns) x 100 topologies x "
-                            f"{args.replicas} replicas per GPU, GTR+weibull4 (4 categories), seeded Exp(0.1) branch "
-                            "lengths, log-likelihood + branch-length gradient",
+                "workload": workload,
                 "trees_per_gpu": T,
                 "trees_total": total_trees,
                 "kernel": kernel,
@@ -211,10 +244,10 @@ def main():
                 "kernel": kernel,
                 "avg_kernel_ms": avg_kernel_s * 1e3,
                 "trees_per_launch": trees_per_launch,
-                "algorithmic_bytes_per_tree": algorithmic_bytes_per_tree(n, P, C, w.want_gradient),
+                "algorithmic_bytes_per_tree": algorithmic_bytes_per_tree(n, P, C, w.want_gradient, S),
                 # the fused kernels keep the partials on chip, so the op-by-op byte model above can exceed
                 # the HBM peak; the arithmetic view of the same launch is reported beside it
-                "arithmetic": arithmetic_view(n, P, C, w.want_gradient, trees_per_launch, avg_kernel_s),
+                "arithmetic": arithmetic,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

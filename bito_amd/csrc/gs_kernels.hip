@@ -325,91 +325,110 @@ void LaunchGsSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch&
 }
 
 // --------------------------------------------------------------------------------------------
-// Transition matrices.  One workgroup (256 threads) per (branch, category, tree): thread (ib, j)
-// accumulates rows 16 ib .. 16 ib + 15 of column j of P and dP as explicit fma chains over
-// ascending k.
+// Transition matrices.  One workgroup (4 waves) per (branch, category, tree); wave w forms rows
+// 16 w .. 16 w + 15 of  P = (V diag(e)) V^-1  on the matrix pipe: 16 chained v_mfma_f64_16x16x4 per
+// 16 x 16 block.  Measured on the device (probe_mfma16.hip): such a chain rounds exactly like a
+// sequential fma() chain over k = 0..63, which is the fixed operation order of DESIGN.md section 3, so
+// P is bit-identical to the CPU restatement's.  P then sits row-major in LDS and every output record
+// is written with coalesced 16-byte stores.
 //
 // Output record per (tree, branch, category): 3 x 4096 doubles.
 //   internal branch:  [0] image of P, [2] image of P^T                         (MFMA A operands)
-//   leaf branch:      [0] PT[s][i] = P[i][s], [1] dPT[s][i]  row-major 64 x 64; row S (gap) is
-//                     1 (P) / 0 (dP) on the real states
+//   leaf branch:      [0] PT[s][.] = P[.][s], [1] dPT[s][.]; row S (gap) is 1 (P) / 0 (dP) on the
+//                     real states; dP = P (r_c Q) is formed from the ROUNDED P exactly as the
+//                     reference's edge derivative pre^T (r_c Q) post sees it (src/fat_beagle.cpp:101-111)
 // Image of a matrix M (out = M x): element M[16 mb + ii][4 ks + kq] sits at
 //   ((mb * 8 + ks / 2) * 64 + (16 kq + ii)) * 2 + (ks & 1)
 // i.e. the A operand (lane = 16 k + row) of the MFMA for row block mb and k-step ks, two k-steps per
-// 16-byte load.  Measured on the device (probe_mfma16.hip, profiles/): register r of lane 16 q + j of
-// the result holds D[4 r + q][j], so register r of block m of a vector holds state 16 m + 4 r + q --
-// which is the B operand (lane = 16 k + column) of k-step 4 m + r: a vector flows from one MFMA's
-// result into the next one's operand without leaving its registers.  Leaf tables are stored with
-// the same permutation inside each block of 16 states (position 16 m + 4 q + r) so that a lane's
-// four values are one 32-byte load.
+// 16-byte load.  Register r of lane 16 q + j of an MFMA result holds D[4 r + q][j], so register r of
+// block m of a vector holds state 16 m + 4 r + q -- which is the B operand (lane = 16 k + column) of
+// k-step 4 m + r: a vector flows from one MFMA's result into the next one's operand without leaving
+// its registers.  Leaf tables use the same permutation inside each block of 16 states (position
+// 16 m + 4 q + r) so that a lane's four values are one 32-byte load.
+
+constexpr int kPld = 66;  // LDS row stride of P (even: 16-byte aligned pairs)
 
 __global__ void __launch_bounds__(256)
 gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ branch,
                    const int32_t* __restrict__ model_index, const double* __restrict__ gs_model,
                    double* __restrict__ imgs, int want_gradient, int deriv_mode) {
 #pragma clang fp contract(off)
-  __shared__ double W[64 * 64];  // [k][i]: V[i][k] e[k], then P[i][k]
+  __shared__ double Pl[64 * kPld];
   __shared__ double e[64];
   const int C = d.category_count, NB = d.node_count - 1, n = d.taxon_count;
   const int br = blockIdx.x / C, c = blockIdx.x % C;
   const int tree = tree0 + blockIdx.y;
-  const int tid = threadIdx.x, j = tid & 63, ib = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, ii = lane & 15;
   const double* __restrict__ m = gs_model + (size_t)model_index[tree] * kGsModelStride;
   const double rate = m[kGsCatRate + c];
   const double time = branch[(size_t)tree * d.node_count + br] * rate;
   if (tid < 64) e[tid] = DetExp(m[kGsLambda + tid] * time);
   __syncthreads();
-  for (int idx = tid; idx < 4096; idx += 256) W[(idx & 63) * 64 + (idx >> 6)] = m[kGsV + idx] * e[idx & 63];
-  __syncthreads();
-  double accP[16], accD[16];
-#pragma unroll
-  for (int ii = 0; ii < 16; ii++) accP[ii] = accD[ii] = 0.0;
-  {
-    const double* __restrict__ vinv = m + kGsVinv + j;
-    for (int k = 0; k < 64; k++) {
-      const double vi = vinv[k * 64];
-      const double* wk = W + k * 64 + ib * 16;
-#pragma unroll
-      for (int ii = 0; ii < 16; ii++) accP[ii] = fma(wk[ii], vi, accP[ii]);
-    }
-  }
-  if (want_gradient && br < n) {
-    // leaf branches only (internal branches use Q^T in the traversal).
-    // dP/dt = P (r_c Q), formed from the ROUNDED P exactly as the reference's edge derivative
-    // pre^T (r_c Q) post sees it (BuildDifferentialMatrices, src/fat_beagle.cpp:101-111): entries of P
-    // that are O(t^2) carry a large relative rounding error, which must enter numerator and
-    // denominator of the derivative alike.  deriv_mode 1: the site-model pass, r_c -> d r_c / d shape.
-    const double drate = deriv_mode ? m[kGsCatRateDeriv + c] : rate;
-    __syncthreads();
-#pragma unroll
-    for (int ii = 0; ii < 16; ii++) W[j * 64 + ib * 16 + ii] = accP[ii];
-    __syncthreads();
-    const double* __restrict__ qcol = m + kGsQ + j;
-    for (int k = 0; k < 64; k++) {
-      const double qk = qcol[k * 64] * drate;
-      const double* wk = W + k * 64 + ib * 16;
-#pragma unroll
-      for (int ii = 0; ii < 16; ii++) accD[ii] = fma(wk[ii], qk, accD[ii]);
-    }
-  }
   double* __restrict__ rec = imgs + (((size_t)blockIdx.y * NB + br) * C + c) * (3 * 4096);
-  if (br < n) {
-    // leaf branch: transposed tables, row = tip state j, 16 contiguous entries per thread
-    const bool gap = (j == S);
+
+  // rows 16 w .. 16 w + 15 of A B, A given by a(ks) = A[16 w + ii][4 ks + kq], B row-major in global
+  auto gemm = [&](auto a_of, const double* __restrict__ B, double scale, v4d acc[4]) {
 #pragma unroll
-    for (int ii = 0; ii < 16; ii++) {
-      const int i = ib * 16 + ii, at = j * 64 + ib * 16 + 4 * (ii & 3) + (ii >> 2);
-      rec[at] = gap ? (i < S ? 1.0 : 0.0) : accP[ii];
-      if (want_gradient) rec[4096 + at] = gap ? 0.0 : accD[ii];
-    }
-  } else {
+    for (int nb = 0; nb < 4; nb++) acc[nb] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ks++) {
+      const double a = a_of(ks);
+      const double* brow = B + (4 * ks + kq) * 64 + ii;
 #pragma unroll
-    for (int ii = 0; ii < 16; ii++) {
-      const int i = ib * 16 + ii;
-      rec[GsImageIndex(i, j)] = accP[ii];
-      if (want_gradient) rec[8192 + GsImageIndex(j, i)] = accP[ii];  // P^T
+      for (int nb = 0; nb < 4; nb++)
+        acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[16 * nb] * scale, acc[nb], 0, 0, 0);
     }
+  };
+  // result registers -> row-major LDS: register r of lane 16 q + j holds row 4 r + q, column j
+  auto to_lds = [&](const v4d acc[4]) {
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Pl[(16 * w + 4 * r + kq) * kPld + 16 * nb + ii] = acc[nb][r];
+  };
+  v4d acc[4];
+  gemm([&](int ks) { return m[kGsV + (16 * w + ii) * 64 + 4 * ks + kq] * e[4 * ks + kq]; }, m + kGsVinv, 1.0, acc);
+  to_lds(acc);
+  __syncthreads();
+
+  if (br >= n) {
+    // internal branch: image of P, and of P^T for the pre-order pass; 16-byte coalesced stores
+    v2d* __restrict__ out0 = reinterpret_cast<v2d*>(rec);
+    v2d* __restrict__ out2 = reinterpret_cast<v2d*>(rec + 8192);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int pos = i * 256 + tid;  // = (mb * 8 + ks2) * 64 + 16 kq' + ii'
+      const int l = pos & 63, blk = pos >> 6, mb = blk >> 3, ks2 = blk & 7;
+      const int row = 16 * mb + (l & 15), col = 8 * ks2 + (l >> 4);
+      out0[pos] = v2d{Pl[row * kPld + col], Pl[row * kPld + col + 4]};
+      if (want_gradient) out2[pos] = v2d{Pl[col * kPld + row], Pl[(col + 4) * kPld + row]};
+    }
+    return;
   }
+  // leaf branch: transposed look-up tables; position 16 m + 4 q + r of row s holds state 16 m + 4 r + q
+  auto table = [&](double* __restrict__ dst, bool is_p) {
+    v2d* __restrict__ out = reinterpret_cast<v2d*>(dst);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int pos = i * 256 + tid;  // pair index: row s = pos / 32, positions 2 (pos % 32), +1
+      const int s = pos >> 5, at = (pos & 31) * 2;
+      const int mm = at >> 4, q = (at >> 2) & 3, r = at & 3;  // r in {0, 2}
+      const int st0 = 16 * mm + 4 * r + q, st1 = st0 + 4;
+      v2d v{Pl[st0 * kPld + s], Pl[st1 * kPld + s]};
+      if (s == S) v = is_p ? v2d{st0 < S ? 1.0 : 0.0, st1 < S ? 1.0 : 0.0} : v2d{0.0, 0.0};
+      out[pos] = v;
+    }
+  };
+  table(rec, true);
+  if (!want_gradient) return;
+  // dP = P (r_c Q); deriv_mode 1: the site-model pass, r_c -> d r_c / d shape
+  const double drate = deriv_mode ? m[kGsCatRateDeriv + c] : rate;
+  v4d accd[4];
+  gemm([&](int ks) { return Pl[(16 * w + ii) * kPld + 4 * ks + kq]; }, m + kGsQ, drate, accd);
+  __syncthreads();
+  to_lds(accd);
+  __syncthreads();
+  table(rec + 4096, false);
 }
 
 void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const double* branch,
@@ -431,9 +450,9 @@ void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const dou
 //
 // Images go through LDS: the order in which a tree's images are needed is written once per tree by
 // gs_schedule_kernel (a list of record numbers); while the workgroup contracts with image j out of
-// one 32 KB LDS buffer, every thread already holds its 128-byte slice of image j+1 in registers
-// (global loads issued before the MFMAs) and drops it into the other buffer afterwards -- one
-// workgroup barrier per image, L2 read once per workgroup instead of once per wave.
+// one 32 KB LDS buffer, image j+1 is already on its way from L2 straight into the other buffer
+// (global_load_lds_dwordx4 issued before the MFMAs) -- one workgroup barrier per image, L2 read once
+// per workgroup instead of once per wave.
 
 struct GsPlv {
   v4d b[4];
@@ -517,22 +536,26 @@ struct GsImagePipe {
     return entry < 0 ? qt : recs + (size_t)entry * 4096;
   }
 
+  // global -> LDS without passing through registers (global_load_lds_dwordx4): every thread moves
+  // 8 x 16 bytes of the 32 KB image; the LDS address is wave-uniform base + 16 * lane
+  __device__ __forceinline__ void Fetch(int entry, int buffer) {
+    const double* src = Image(entry) + tid * 2;
+    double* dst = lds + buffer * 4096 + (tid & ~63) * 2;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 512),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 512), 16, 0, 0);
+  }
+
   __device__ __forceinline__ void Begin() {
     j = 0;
-    const v2d* src = reinterpret_cast<const v2d*>(Image(jobs[0])) + tid;
-    v2d* dst = reinterpret_cast<v2d*>(lds) + tid;
-#pragma unroll
-    for (int i = 0; i < 8; i++) dst[i * 256] = src[i * 256];
+    Fetch(jobs[0], 0);
     __syncthreads();
   }
 
   // out = (image j) x; leaves image j+1 in the other buffer
   __device__ __forceinline__ void MatVec(const GsPlv& x, GsPlv& out) {
-    const int next = __builtin_amdgcn_readfirstlane(jobs[j + 1]);
-    const v2d* src = reinterpret_cast<const v2d*>(Image(next)) + tid;
-    v2d pre[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) pre[i] = src[i * 256];
+    Fetch(__builtin_amdgcn_readfirstlane(jobs[j + 1]), (j + 1) & 1);
     const v2d* p = reinterpret_cast<const v2d*>(lds + (j & 1) * 4096) + lane;
     v4d acc[4];
 #pragma unroll
@@ -556,16 +579,13 @@ struct GsImagePipe {
     }
 #pragma unroll
     for (int mb = 0; mb < 4; mb++) out.b[mb] = acc[mb];
-    v2d* dst = reinterpret_cast<v2d*>(lds + ((j + 1) & 1) * 4096) + tid;
-#pragma unroll
-    for (int i = 0; i < 8; i++) dst[i * 256] = pre[i];
     j++;
     __syncthreads();
   }
 };
 
 template <bool GRAD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_stride, int deriv_mode, const int32_t* __restrict__ children,
                const int32_t* __restrict__ sched, const double* __restrict__ imgs,
                const int32_t* __restrict__ model_index, const double* __restrict__ gs_model,
@@ -599,11 +619,12 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
   GsImagePipe pipe{lds, recs, model + kGsQtImage, sched + (size_t)tree * sched_stride, 0, (int)threadIdx.x, lane};
   pipe.Begin();
 
-  GsPlv pi;
+  auto load_pi = [&](GsPlv& v) {  // stationary frequencies in the vector layout (root only)
 #pragma unroll
-  for (int m = 0; m < 4; m++)
+    for (int m = 0; m < 4; m++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) pi.b[m][r] = model[kGsPi + 16 * m + 4 * r + kq];
+      for (int r = 0; r < 4; r++) v.b[m][r] = model[kGsPi + 16 * m + 4 * r + kq];
+  };
 
   // ---- post-order: dest = (P0 x0) . (P1 x1) per category -----------------------------------
   double site = 0.0;
@@ -631,7 +652,8 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
 #pragma unroll
       for (int m = 0; m < 4; m++) a.b[m] *= bb.b[m];
       if (node == N - 1) {
-        site += model[kGsCatWeight + c] * GsDot(pi, a);
+        load_pi(bb);
+        site += model[kGsCatWeight + c] * GsDot(bb, a);
       } else if (active) {
         GsStore(slot(node, c), lane, a);
       }
@@ -655,7 +677,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       for (int c = 0; c < C; c++) {
         GsPlv u, w0, w1, x, y;
         if (node == N - 1) {
-          u = pi;
+          load_pi(u);
         } else {
           GsLoad(slot(node, c), lane, u);
         }
