@@ -20,6 +20,14 @@
 // FP64 throughout, no atomics, every sum in a fixed order.
 #include "kernels.hpp"
 
+// build-time knobs of the traversal kernel (scripts/build_gs_variants.sh measures the alternatives)
+#ifndef GS_SCHED_BARRIER
+#define GS_SCHED_BARRIER 1
+#endif
+#ifndef GS_WAVES
+#define GS_WAVES 2  // waves per SIMD the register allocation is held to
+#endif
+
 namespace bito_amd {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -469,23 +477,32 @@ gs_schedule_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* _
   const int32_t* ch = children + (size_t)t * (n - 1) * 2;
   int32_t* out = jobs + (size_t)t * stride;
   int at = 0;
-  for (int node = n; node < N; node++)
-    for (int c = 0; c < C; c++)
-      for (int side = 0; side < 2; side++) {
-        const int k = ch[(node - n) * 2 + side];
-        if (k >= n) out[at++] = (k * C + c) * 3;
+  // child order of the walk: the chained child (the second child if internal, else the first) is
+  // contracted first on the way up and last on the way down
+  for (int node = n; node < N; node++) {
+    const int c0 = ch[(node - n) * 2], c1 = ch[(node - n) * 2 + 1];
+    const int first = c1 >= n ? c1 : c0, second = c1 >= n ? c0 : c1;
+    for (int c = 0; c < C; c++) {
+      if (first >= n) out[at++] = (first * C + c) * 3;
+      if (second >= n) out[at++] = (second * C + c) * 3;
+    }
+  }
+  for (int node = N - 1; node >= n; node--) {
+    const int c0 = ch[(node - n) * 2], c1 = ch[(node - n) * 2 + 1];
+    const int last = c1 >= n ? c1 : c0, first = c1 >= n ? c0 : c1;
+    for (int c = 0; c < C; c++) {
+      if (first >= n) {
+        out[at++] = (first * C + c) * 3 + 2;
+        out[at++] = -1;
       }
-  for (int node = N - 1; node >= n; node--)
-    for (int c = 0; c < C; c++)
-      for (int side = 0; side < 2; side++) {
-        const int k = ch[(node - n) * 2 + side];
-        if (k >= n) {
-          out[at++] = (k * C + c) * 3 + 2;
-          out[at++] = -1;
-        }
+      if (last >= n) {
+        out[at++] = (last * C + c) * 3 + 2;
+        out[at++] = -1;
       }
-  const int last = at ? out[at - 1] : 0;
-  for (; at < stride; at++) out[at] = last;
+    }
+  }
+  const int tail = at ? out[at - 1] : 0;
+  for (; at < stride; at++) out[at] = tail;
 }
 
 int GsScheduleStride(const BatchDims& d) { return (d.taxon_count - 1) * d.category_count * 8 + 1; }
@@ -555,6 +572,9 @@ struct GsImagePipe {
 
   // out = (image j) x; leaves image j+1 in the other buffer
   __device__ __forceinline__ void MatVec(const GsPlv& x, GsPlv& out) {
+#if GS_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);  // keep the caller's loads from being hoisted across the contraction
+#endif
     Fetch(__builtin_amdgcn_readfirstlane(jobs[j + 1]), (j + 1) & 1);
     const v2d* p = reinterpret_cast<const v2d*>(lds + (j & 1) * 4096) + lane;
     v4d acc[4];
@@ -581,11 +601,14 @@ struct GsImagePipe {
     for (int mb = 0; mb < 4; mb++) out.b[mb] = acc[mb];
     j++;
     __syncthreads();
+#if GS_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 };
 
 template <bool GRAD>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, GS_WAVES)
 gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_stride, int deriv_mode, const int32_t* __restrict__ children,
                const int32_t* __restrict__ sched, const double* __restrict__ imgs,
                const int32_t* __restrict__ model_index, const double* __restrict__ gs_model,
@@ -620,41 +643,57 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
   pipe.Begin();
 
   auto load_pi = [&](GsPlv& v) {  // stationary frequencies in the vector layout (root only)
+    const double* mp = model + kGsPi + kq;
+    asm volatile("" : "+v"(mp));  // opaque address: keeps these 32 registers from being hoisted out of the node loops
 #pragma unroll
     for (int m = 0; m < 4; m++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) v.b[m][r] = model[kGsPi + 16 * m + 4 * r + kq];
+      for (int r = 0; r < 4; r++) v.b[m][r] = mp[16 * m + 4 * r];
   };
 
-  // ---- post-order: dest = (P0 x0) . (P1 x1) per category -----------------------------------
+  // Ids are in post-order, so an internal node v with an internal child has child v - 1 (its second
+  // child if that is internal, else its first): the CHAINED child.  With one rate category the
+  // chained child's vector is still in registers when v is processed in the post-order pass (it is the
+  // previous iteration's result), and in the pre-order pass -- which visits v - 1 right after v -- the
+  // chained child's pre-order partial, produced last in v's step, is the next iteration's input.  That
+  // removes one 8 KB load per internal node and pass.  The image order written by gs_schedule_kernel
+  // follows the same child order: chained child first on the way up, last on the way down.
+  const bool chain = C == 1;
+
+  // ---- post-order: dest = (P_f x_f) . (P_s x_s) per category ------------------------------
   double site = 0.0;
+  GsPlv a;  // the node's partial; survives into the next iteration
   for (int node = n; node < N; ++node) {
     const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
     const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
-    const int s0 = c0 < n ? tips[(size_t)c0 * Ppad] : 0;
-    const int s1 = c1 < n ? tips[(size_t)c1 * Ppad] : 0;
+    const int cf = c1 >= n ? c1 : c0, cs = c1 >= n ? c0 : c1;  // chained child (if any) first
+    const int sf = cf < n ? tips[(size_t)cf * Ppad] : 0;
+    const int ss = cs < n ? tips[(size_t)cs * Ppad] : 0;
     for (int c = 0; c < C; c++) {
-      GsPlv a, bb, x;
-      if (c0 < n) {
-        GsTip(rec(c0, c, 0), s0, kq, a);
+      GsPlv bb, x;
+      if (cf < n) {
+        GsTip(rec(cf, c, 0), sf, kq, a);
       } else {
-        GsLoad(slot(c0, c), lane, x);
+        if (chain && cf == node - 1) x = a;  // (always so when ids are in post-order)
+        else GsLoad(slot(cf, c), lane, x);
         pipe.MatVec(x, a);
-        if (GRAD && active) GsStore(mslot(c0, c), lane, a);
+        if (GRAD && active) GsStore(mslot(cf, c), lane, a);
       }
-      if (c1 < n) {
-        GsTip(rec(c1, c, 0), s1, kq, bb);
+      if (cs < n) {
+        GsTip(rec(cs, c, 0), ss, kq, bb);
       } else {
-        GsLoad(slot(c1, c), lane, x);
+        GsLoad(slot(cs, c), lane, x);
         pipe.MatVec(x, bb);
-        if (GRAD && active) GsStore(mslot(c1, c), lane, bb);
+        if (GRAD && active) GsStore(mslot(cs, c), lane, bb);
       }
 #pragma unroll
       for (int m = 0; m < 4; m++) a.b[m] *= bb.b[m];
       if (node == N - 1) {
         load_pi(bb);
         site += model[kGsCatWeight + c] * GsDot(bb, a);
-      } else if (active) {
+      } else if (active && (GRAD || !chain || node + 1 >= N || (ch[(node + 1 - n) * 2] != node && ch[(node + 1 - n) * 2 + 1] != node))) {
+        // (a log-likelihood-only walk needs no copy in memory of a vector that is consumed from
+        // registers by the next node)
         GsStore(slot(node, c), lane, a);
       }
     }
@@ -668,30 +707,29 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
   if (GRAD) {
     double* __restrict__ grow = part_grad + ((size_t)tree * tiles + tile) * N;
     if (lane == 0 && active) grow[N - 1] = 0.0;
+    GsPlv y;              // pre-order partial of the child processed last; survives into the next iteration
+    bool have_u = false;  // y is node's own pre-order partial (wave-uniform)
     for (int node = N - 1; node >= n; --node) {
       const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
       const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
-      const int s0 = c0 < n ? tips[(size_t)c0 * Ppad] : 0;
-      const int s1 = c1 < n ? tips[(size_t)c1 * Ppad] : 0;
-      double den = 0.0, num0 = 0.0, num1 = 0.0;
+      const int cl = c1 >= n ? c1 : c0, cf = c1 >= n ? c0 : c1;  // chained child (if any) last
+      const int sf = cf < n ? tips[(size_t)cf * Ppad] : 0;
+      const int sl = cl < n ? tips[(size_t)cl * Ppad] : 0;
+      double den = 0.0, numf = 0.0, numl = 0.0;
       for (int c = 0; c < C; c++) {
-        GsPlv u, w0, w1, x, y;
+        GsPlv u, wf, wl, x;
         if (node == N - 1) {
           load_pi(u);
+        } else if (have_u) {
+          u = y;
         } else {
           GsLoad(slot(node, c), lane, u);
         }
-        // child messages a0 -> w1 = u . a0, a1 -> w0 = u . a1
-        if (c0 < n) {
-          GsTip(rec(c0, c, 0), s0, kq, w1);
-        } else {
-          GsLoad(mslot(c0, c), lane, w1);
-        }
-        if (c1 < n) {
-          GsTip(rec(c1, c, 0), s1, kq, w0);
-        } else {
-          GsLoad(mslot(c1, c), lane, w0);
-        }
+        // child messages: a_f -> w_l = u . a_f (what the LAST child sees), a_l -> w_f = u . a_l
+        if (cf < n) GsTip(rec(cf, c, 0), sf, kq, wl);
+        else GsLoad(mslot(cf, c), lane, wl);
+        if (cl < n) GsTip(rec(cl, c, 0), sl, kq, wf);
+        else GsLoad(mslot(cl, c), lane, wf);
         const double wc = model[kGsCatWeight + c];
         {
           double sden = 0.0;
@@ -699,10 +737,10 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-              const double a0 = w1.b[m][r], a1 = w0.b[m][r], uu = u.b[m][r];
-              w0.b[m][r] = uu * a1;
-              w1.b[m][r] = uu * a0;
-              sden += w0.b[m][r] * a0;
+              const double af = wl.b[m][r], al = wf.b[m][r], uu = u.b[m][r];
+              wf.b[m][r] = uu * al;
+              wl.b[m][r] = uu * af;
+              sden += wf.b[m][r] * af;
             }
           den += wc * sden;
         }
@@ -710,36 +748,39 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
         // x), and the edge derivative in the reference's own form  pre^T (r_c Q) post = (Q^T q) . x r_c
         // (src/fat_beagle.cpp:101-160); a tip child reads dP's column instead
         const double rc = model[(deriv_mode ? kGsCatRateDeriv : kGsCatRate) + c];  // site-model pass: d r_c / d shape
-        if (c0 < n) {
-          GsTip(rec(c0, c, 1), s0, kq, y);
-          num0 += wc * GsDot(w0, y);
+        if (cf < n) {
+          GsTip(rec(cf, c, 1), sf, kq, x);
+          numf += wc * GsDot(wf, x);
         } else {
-          pipe.MatVec(w0, y);
-          GsLoad(slot(c0, c), lane, x);
-          if (active) GsStore(slot(c0, c), lane, y);
-          pipe.MatVec(y, w0);
-          num0 += wc * rc * GsDot(w0, x);
+          pipe.MatVec(wf, y);
+          pipe.MatVec(y, wf);
+          GsLoad(slot(cf, c), lane, x);  // (x is read before q takes its place)
+          numf += wc * rc * GsDot(wf, x);
+          if (active) GsStore(slot(cf, c), lane, y);
         }
-        if (c1 < n) {
-          GsTip(rec(c1, c, 1), s1, kq, y);
-          num1 += wc * GsDot(w1, y);
+        if (cl < n) {
+          GsTip(rec(cl, c, 1), sl, kq, x);
+          numl += wc * GsDot(wl, x);
         } else {
-          pipe.MatVec(w1, y);
-          GsLoad(slot(c1, c), lane, x);
-          if (active) GsStore(slot(c1, c), lane, y);
-          pipe.MatVec(y, w1);
-          num1 += wc * rc * GsDot(w1, x);
+          pipe.MatVec(wl, y);
+          pipe.MatVec(y, wl);
+          GsLoad(slot(cl, c), lane, x);
+          numl += wc * rc * GsDot(wl, x);
+          // the chained child's pre-order partial goes to memory only if its own step will not take
+          // it from registers (it always will with one category; the store is then not needed)
+          if (active && !(chain && cl == node - 1)) GsStore(slot(cl, c), lane, y);
         }
       }
+      have_u = chain && cl >= n && cl == node - 1;  // the next node's own pre-order partial is in y
       den = GsPatternSum(den);
-      num0 = GsPatternSum(num0);
-      num1 = GsPatternSum(num1);
+      numf = GsPatternSum(numf);
+      numl = GsPatternSum(numl);
       const double scale = kq == 0 ? weight / den : 0.0;
-      const double g0 = WaveSum64(num0 * scale);
-      const double g1 = WaveSum64(num1 * scale);
+      const double gf = WaveSum64(numf * scale);
+      const double gl = WaveSum64(numl * scale);
       if (lane == 0 && active) {
-        grow[c0] = g0;
-        grow[c1] = g1;
+        grow[cf] = gf;
+        grow[cl] = gl;
       }
     }
   }
