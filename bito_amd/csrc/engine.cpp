@@ -302,9 +302,6 @@ hipEvent_t NextEvent(bito_amd_engine* e) {
 // general kernels are selected explicitly.  Trees are processed in chunks sized so that a chunk's
 // matrix records and PLV arena fit the arena budget.
 int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_mode) {
-  if (rescaling)
-    return Fail(e, BITO_AMD_ERR_STATE,
-                "rescaling is not available on the general-state kernels yet (the 4-state kernels provide it)");
   HIP_TRY(e, hipSetDevice(e->device));
   const BatchDims& d = e->dims;
   const int T = d.tree_count, S = e->spec.state_count;
@@ -320,6 +317,7 @@ int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int
   HIP_TRY(e, e->arena.Reserve(chunk * arena_per_tree));
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
   if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
+  if (want_gradient && rescaling) HIP_TRY(e, e->scale_arena.Reserve(chunk * (size_t)(d.taxon_count - 1) * tiles * 16));
   HIP_TRY(e, e->sched.Reserve((size_t)T * GsScheduleStride(d)));
   const DeviceBatch b = MakeBatch(e);
   LaunchGsSetup(d, e->spec, b, e->gs_model_index.ptr, e->gs_model.ptr, e->stream);
@@ -333,7 +331,7 @@ int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int
       ev1 = NextEvent(e);
       HIP_TRY(e, hipEventRecord(ev0, e->stream));
     }
-    LaunchGsWalk(d, S, b, e->gs_model_index.ptr, e->gs_model.ptr, t0, ct, tiles, want_gradient, deriv_mode, e->stream);
+    LaunchGsWalk(d, S, b, e->gs_model_index.ptr, e->gs_model.ptr, t0, ct, tiles, want_gradient, rescaling, deriv_mode, e->stream);
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
   }
   e->kernel_name = "gs_walk_kernel";

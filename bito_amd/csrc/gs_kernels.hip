@@ -607,13 +607,14 @@ struct GsImagePipe {
   }
 };
 
-template <bool GRAD>
+template <bool GRAD, bool RESCALE>
 __global__ void __launch_bounds__(256, GS_WAVES)
 gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_stride, int deriv_mode, const int32_t* __restrict__ children,
                const int32_t* __restrict__ sched, const double* __restrict__ imgs,
                const int32_t* __restrict__ model_index, const double* __restrict__ gs_model,
                const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
-               double* __restrict__ arena, double* __restrict__ part_ll, double* __restrict__ part_grad) {
+               double* __restrict__ arena, double* __restrict__ scale_arena, double* __restrict__ part_ll,
+               double* __restrict__ part_grad) {
   extern __shared__ double lds[];  // two image buffers
   const int n = d.taxon_count, N = d.node_count, NI = n - 1, C = d.category_count, Ppad = d.pattern_stride;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, pn = lane & 15;
@@ -639,6 +640,8 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
   // message P x of an internal child, kept for the pre-order pass (second half of the tree's arena)
   auto mslot = [&](int node, int c) { return slots + (((size_t)(NI + node - n) * C + c) * tiles + tile) * 1024; };
   auto rec = [&](int br, int c, int which) { return recs + (((size_t)br * C + c) * 3 + which) * 4096; };
+  // RESCALE && GRAD: reciprocal post-order scale factor of (node, pattern)
+  auto inv_at = [&](int node) { return scale_arena + (((size_t)tree_local * NI + (node - n)) * tiles + tile) * 16 + pn; };
   GsImagePipe pipe{lds, recs, model + kGsQtImage, sched + (size_t)tree * sched_stride, 0, (int)threadIdx.x, lane};
   pipe.Begin();
 
@@ -661,7 +664,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
   const bool chain = C == 1;
 
   // ---- post-order: dest = (P_f x_f) . (P_s x_s) per category ------------------------------
-  double site = 0.0;
+  double site = 0.0, log_scale = 0.0;
   GsPlv a;  // the node's partial; survives into the next iteration
   for (int node = n; node < N; ++node) {
     const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
@@ -669,6 +672,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
     const int cf = c1 >= n ? c1 : c0, cs = c1 >= n ? c0 : c1;  // chained child (if any) first
     const int sf = cf < n ? tips[(size_t)cf * Ppad] : 0;
     const int ss = cs < n ? tips[(size_t)cs * Ppad] : 0;
+    double cat_max = 0.0;  // RESCALE with several categories: maximum over all of them
     for (int c = 0; c < C; c++) {
       GsPlv bb, x;
       if (cf < n) {
@@ -688,6 +692,29 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       }
 #pragma unroll
       for (int m = 0; m < 4; m++) a.b[m] *= bb.b[m];
+      if (RESCALE && C == 1) {
+        // BEAGLE manual scaling (src/fat_beagle.cpp:353-364): per pattern, divide by the maximum over
+        // states (and categories) and accumulate its logarithm.  A pattern's 64 states sit in four lanes.
+        double mx = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) mx = fmax(mx, a.b[m][r]);
+        mx = fmax(mx, __shfl_xor(mx, 16));
+        mx = fmax(mx, __shfl_xor(mx, 32));
+        if (mx == 0.0) mx = 1.0;
+        const double inv = 1.0 / mx;
+#pragma unroll
+        for (int m = 0; m < 4; m++) a.b[m] *= inv;
+        log_scale += log(mx);
+        if (GRAD && active && kq == 0) *inv_at(node) = inv;
+      }
+      if (RESCALE && C > 1) {
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) cat_max = fmax(cat_max, a.b[m][r]);
+      }
       if (node == N - 1) {
         load_pi(bb);
         site += model[kGsCatWeight + c] * GsDot(bb, a);
@@ -697,9 +724,29 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
         GsStore(slot(node, c), lane, a);
       }
     }
+    if (RESCALE && C > 1) {
+      // several categories share one factor per pattern: the partials were stored unscaled, now the
+      // maximum over all categories is known.  (The root is left unscaled: it is never stored.)
+      double inv = 1.0;
+      if (node != N - 1) {
+        double mx = fmax(cat_max, __shfl_xor(cat_max, 16));
+        mx = fmax(mx, __shfl_xor(mx, 32));
+        if (mx == 0.0) mx = 1.0;
+        inv = 1.0 / mx;
+        log_scale += log(mx);
+        for (int c = 0; c < C; c++) {
+          GsPlv v;
+          GsLoad(slot(node, c), lane, v);
+#pragma unroll
+          for (int m = 0; m < 4; m++) v.b[m] *= inv;
+          if (active) GsStore(slot(node, c), lane, v);
+        }
+      }
+      if (GRAD && active && kq == 0) *inv_at(node) = inv;
+    }
   }
   site = GsPatternSum(site);
-  const double ll = kq == 0 ? weight * log(site) : 0.0;
+  const double ll = kq == 0 ? weight * (log(site) + log_scale) : 0.0;
   const double wll = WaveSum64(ll);
   if (lane == 0 && active) part_ll[(size_t)tree * tiles + tile] = wll;
 
@@ -716,6 +763,10 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       const int sf = cf < n ? tips[(size_t)cf * Ppad] : 0;
       const int sl = cl < n ? tips[(size_t)cl * Ppad] : 0;
       double den = 0.0, numf = 0.0, numl = 0.0;
+      // Rescaled pre-order partials: a child's partial is divided by this node's POST-order factor
+      // (any positive per-pattern factor cancels in num / den; this one keeps the products O(1), see
+      // walk_hbm_kernel)
+      const double step_inv = RESCALE ? *inv_at(node) : 1.0;
       for (int c = 0; c < C; c++) {
         GsPlv u, wf, wl, x;
         if (node == N - 1) {
@@ -756,6 +807,10 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           pipe.MatVec(y, wf);
           GsLoad(slot(cf, c), lane, x);  // (x is read before q takes its place)
           numf += wc * rc * GsDot(wf, x);
+          if (RESCALE) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) y.b[m] *= step_inv;
+          }
           if (active) GsStore(slot(cf, c), lane, y);
         }
         if (cl < n) {
@@ -766,6 +821,10 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           pipe.MatVec(y, wl);
           GsLoad(slot(cl, c), lane, x);
           numl += wc * rc * GsDot(wl, x);
+          if (RESCALE) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) y.b[m] *= step_inv;
+          }
           // the chained child's pre-order partial goes to memory only if its own step will not take
           // it from registers (it always will with one category; the store is then not needed)
           if (active && !(chain && cl == node - 1)) GsStore(slot(cl, c), lane, y);
@@ -794,17 +853,23 @@ size_t GsImageDoublesPerTree(const BatchDims& d) {
 }
 
 void LaunchGsWalk(const BatchDims& d, int S, const DeviceBatch& b, const int32_t* model_index,
-                  const double* gs_model, int tree0, int chunk, int tiles, int want_gradient, int deriv_mode,
-                  hipStream_t stream) {
+                  const double* gs_model, int tree0, int chunk, int tiles, int want_gradient, int rescaling,
+                  int deriv_mode, hipStream_t stream) {
   const dim3 grid((unsigned)((chunk + 7) / 8 * 8 * ((tiles + 3) / 4))), block(256);
   const size_t lds = 2 * 4096 * sizeof(double);
   const int stride = GsScheduleStride(d);
-  if (want_gradient)
-    hipLaunchKernelGGL((gs_walk_kernel<true>), grid, block, lds, stream, d, S, tree0, chunk, tiles, stride, deriv_mode, b.children, b.sched,
-                       b.images, model_index, gs_model, b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
-  else
-    hipLaunchKernelGGL((gs_walk_kernel<false>), grid, block, lds, stream, d, S, tree0, chunk, tiles, stride, deriv_mode, b.children, b.sched,
-                       b.images, model_index, gs_model, b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, d, S, tree0, chunk, tiles, stride, deriv_mode, b.children, b.sched,
+                       b.images, model_index, gs_model, b.tip_states, b.weights, b.arena, b.scale_arena, b.part_ll,
+                       b.part_grad);
+  };
+  if (want_gradient) {
+    if (rescaling) launch(gs_walk_kernel<true, true>);
+    else launch(gs_walk_kernel<true, false>);
+  } else {
+    if (rescaling) launch(gs_walk_kernel<false, true>);
+    else launch(gs_walk_kernel<false, false>);
+  }
 }
 
 }  // namespace bito_amd

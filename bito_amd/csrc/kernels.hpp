@@ -175,8 +175,8 @@ void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const dou
 int GsScheduleStride(const BatchDims& d);  // int32 entries per tree of the image-order list (b.sched)
 void LaunchGsSchedule(const BatchDims& d, const DeviceBatch& b, hipStream_t stream);
 void LaunchGsWalk(const BatchDims& d, int S, const DeviceBatch& b, const int32_t* model_index,
-                  const double* gs_model, int tree0, int chunk, int tiles, int want_gradient, int deriv_mode,
-                  hipStream_t stream);
+                  const double* gs_model, int tree0, int chunk, int tiles, int want_gradient, int rescaling,
+                  int deriv_mode, hipStream_t stream);
 
 
 // time_tree.hip: RootedTree's height-ratio parameterisation and the rooted gradient transforms,

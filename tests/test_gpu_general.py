@@ -105,8 +105,6 @@ def test_codon_model_errors():
     bad[0, 0] = 0.5
     with pytest.raises(bito_amd.BitoAmdError, match="frequencies do not sum to 1"):
         eng.log_likelihoods(w.parent_ids, w.branch_lengths, bad)
-    with pytest.raises(bito_amd.BitoAmdError, match="rescaling"):
-        eng.log_likelihoods(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
 
 
 def test_codon_model_parameter_gradients():
@@ -180,3 +178,35 @@ def test_codon_model_parity_over_many_trees_and_models():
     ref = cpu.gradients(w.parent_ids, bl, params)
     assert ll_close(out["log_likelihood"], ref["log_likelihood"])
     assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+
+
+@pytest.mark.parametrize("site", ["constant", "weibull+2"])
+def test_codon_rescaling(site):
+    """Engine's `rescaling` argument (BEAGLE manual scaling, src/fat_beagle.cpp:353-364) on the general-state
+    kernels: same results as without on fluA, and finite results where the unscaled partials underflow."""
+    w = workloads.flua_codon(3, site)
+    eng = bito_amd.Engine(spec(w.substitution, w.site), w.patterns, w.weights)
+    cpu = gs.GsOracleEngine("GY94", site, w.patterns, w.weights, 8)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
+    out = eng.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    assert ll_close(eng.log_likelihoods(w.parent_ids, w.branch_lengths, w.params, rescaling=True), ref["log_likelihood"])
+    # 300 taxa of random codons on a random tree: every site likelihood is far below 1e-308
+    n, P, T = 300, 24, 2
+    rng = np.random.default_rng(5)
+    patterns = rng.integers(0, 62, (n, P)).astype(np.int32)
+    trees = [workloads.random_unrooted_tree(n, np.random.default_rng(50 + i), 0.05) for i in range(T)]
+    pid = np.stack([t.parent_ids for t in trees]).astype(np.int32)
+    bl = np.stack([t.branch_lengths for t in trees])
+    bl[:, -1] = 0.0
+    params = np.tile(w.params[:1], (T, 1))
+    eng = bito_amd.Engine(spec("GY94", site), patterns, np.ones(P))
+    cpu = gs.GsOracleEngine("GY94", site, patterns, np.ones(P), 8)
+    ref = cpu.gradients(pid, bl, params, rescaling=True)
+    out = eng.gradients(pid, bl, params, rescaling=True)
+    assert np.all(np.isfinite(ref["log_likelihood"])) and ref["log_likelihood"].max() < -20000
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    plain = eng.log_likelihoods(pid, bl, params, rescaling=False)
+    assert not np.all(np.isfinite(plain))  # which is why the argument exists
