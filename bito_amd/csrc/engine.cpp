@@ -488,7 +488,7 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
   e->Ppad = (pattern_count + 512 + kHbmBlock - 1) / kHbmBlock * kHbmBlock;
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  e->arena_limit = (spec && spec->arena_bytes) ? spec->arena_bytes : std::max<size_t>(free_b / 4, (size_t)1 << 28);
+  e->arena_limit = (spec && spec->arena_bytes) ? spec->arena_bytes : std::max<size_t>(free_b / 4 * 3, (size_t)1 << 28);
   // Compact tip states, gap for every symbol >= 4 and for the padding columns
   // (SitePattern symbol table, reference src/site_pattern.cpp:16-46).
   const int S = e->spec.state_count;

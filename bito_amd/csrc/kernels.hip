@@ -112,8 +112,8 @@ void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient,
 //
 // One thread owns one site pattern and walks the whole tree for it; patterns are
 // independent end to end, so there is no inter-thread dependency until the final
-// sums.  Arena cell (node, category, state) of a tree is a row of Ppad doubles:
-// a wave reads/writes 64 consecutive doubles (512 B) per access.  Transition
+// sums.  Arena cell (node, category, state) of a workgroup's 256 patterns is a 2 KB row
+// (the arena is tiled by workgroup): a wave reads/writes 64 consecutive doubles (512 B) per access.  Transition
 // matrices and the child lists are wave-uniform and come through scalar loads.
 //
 // Gradient pass.  With u = pre-order partial at the top of a node's two child
@@ -164,9 +164,13 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
   const double* __restrict__ mats = all_mats + (size_t)tree * (N - 1) * C * kMatStride;
   const TreeModel* __restrict__ tm = models + tree;
   const uint8_t* __restrict__ tips = tip_states + p;
-  double* __restrict__ arena = arena_base + (size_t)blockIdx.y * NI * C * 4 * Ppad + p;
+  // The arena is tiled by workgroup: [tree][tile][node][category][state][kHbmBlock patterns], so that the
+  // rows a workgroup walks lie in one contiguous region (TLB reach) instead of Ppad doubles apart.
+  const int tile_count = gridDim.x;
+  double* __restrict__ arena =
+      arena_base + ((size_t)blockIdx.y * tile_count + blockIdx.x) * NI * C * 4 * kHbmBlock + tid;
   // per-node, per-pattern reciprocal scale factors of the post-order pass (RESCALE && GRAD)
-  double* __restrict__ inv_scale = scale_base + (size_t)blockIdx.y * NI * Ppad + p;
+  double* __restrict__ inv_scale = scale_base + ((size_t)blockIdx.y * tile_count + blockIdx.x) * NI * kHbmBlock + tid;
   const double weight = weights[p];
 
   if (GRAD) {
@@ -211,7 +215,7 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
       for (int i = 0; i < 4; i++) x[i] = ma[i] * mb[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((cc - n) * C + c) * 4 + i) * Ppad];
+      for (int i = 0; i < 4; i++) x[i] = arena[((size_t)((cc - n) * C + c) * 4 + i) * kHbmBlock];
     }
   };
 
@@ -261,7 +265,7 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
 #pragma unroll
         for (int i = 0; i < 4; i++) dd[c][i] *= inv;
       log_scale += log(mx);
-      if (GRAD) inv_scale[(size_t)(node - n) * Ppad] = inv;
+      if (GRAD) inv_scale[(size_t)(node - n) * kHbmBlock] = inv;
     }
     if (node == N - 1) {
 #pragma unroll
@@ -272,7 +276,7 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
 #pragma unroll
       for (int c = 0; c < C; c++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) arena[((size_t)((node - n) * C + c) * 4 + i) * Ppad] = dd[c][i];
+        for (int i = 0; i < 4; i++) arena[((size_t)((node - n) * C + c) * 4 + i) * kHbmBlock] = dd[c][i];
     }
   }
   const double ll = weight * (log(site) + log_scale);
@@ -313,7 +317,7 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
           for (int i = 0; i < 4; i++) U[i] = tm->pi[i];
         } else {
 #pragma unroll
-          for (int i = 0; i < 4; i++) U[i] = arena[((size_t)((node - n) * C + c) * 4 + i) * Ppad];
+          for (int i = 0; i < 4; i++) U[i] = arena[((size_t)((node - n) * C + c) * 4 + i) * kHbmBlock];
         }
         const double* m0 = mats + (size_t)(c0 * C + c) * kMatStride;
         const double* m1 = mats + (size_t)(c1 * C + c) * kMatStride;
@@ -363,7 +367,7 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
       // (S = summed log factors of a subtree), whose product with the scaled post-order
       // partial of X sums to the scaled site likelihood, i.e. stays O(1) -- and the factor
       // is known before the category loop, so nothing has to be held across categories.
-      const double step_inv = RESCALE ? inv_scale[(size_t)(node - n) * Ppad] : 1.0;
+      const double step_inv = RESCALE ? inv_scale[(size_t)(node - n) * kHbmBlock] : 1.0;
       // In place, one category at a time: cell (child, c) is read (as the child's
       // post-order partial) before it is overwritten with its pre-order partial.
 #pragma unroll 1
@@ -373,12 +377,12 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
         if (k0.kind == 1) {
 #pragma unroll
           for (int i = 0; i < 4; i++)
-            arena[((size_t)((c0 - n) * C + c) * 4 + i) * Ppad] = RESCALE ? q0[i] * step_inv : q0[i];
+            arena[((size_t)((c0 - n) * C + c) * 4 + i) * kHbmBlock] = RESCALE ? q0[i] * step_inv : q0[i];
         }
         if (k1.kind == 1) {
 #pragma unroll
           for (int i = 0; i < 4; i++)
-            arena[((size_t)((c1 - n) * C + c) * 4 + i) * Ppad] = RESCALE ? q1[i] * step_inv : q1[i];
+            arena[((size_t)((c1 - n) * C + c) * 4 + i) * kHbmBlock] = RESCALE ? q1[i] * step_inv : q1[i];
         }
       }
       const double scale = weight / den;

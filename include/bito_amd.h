@@ -61,7 +61,7 @@ typedef struct {
   int32_t use_tip_states; /* accepted for API parity (engine.hpp:23); tips are always
                              held as compact states, which is what BEAGLE's
                              tip-state path computes (fat_beagle.cpp:269-275) */
-  uint64_t arena_bytes;   /* cap on the HBM PLV arena; 0 = default (1/4 of free HBM) */
+  uint64_t arena_bytes;   /* cap on the HBM PLV arena; 0 = default (3/4 of free HBM: one engine owns its GPU) */
 } bito_amd_engine_spec;
 
 /*
