@@ -22,7 +22,12 @@
 namespace bito_amd {
 
 // --------------------------------------------------------------------------
-// Set-up: one thread per tree.
+// Set-up: one thread per tree.  The per-tree recursions are serial, so what matters is that
+// their memory accesses do not queue up behind each other: a workgroup stages the wire-format
+// rows of its 16 trees in LDS with coalesced loads, each tree's thread works out of LDS, and the
+// results leave with coalesced stores (trees too large for that use the direct form).
+
+constexpr int kSetupTrees = 16;  // trees per workgroup
 
 __global__ void __launch_bounds__(64)
 setup_trees_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
@@ -32,8 +37,39 @@ setup_trees_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
   SetupTreeModel(spec, b.params + (size_t)t * spec.param_count, &b.model[t]);
 }
 
+static size_t SetupLdsBytes(const BatchDims& d) {
+  return (size_t)kSetupTrees * (d.node_count * sizeof(double) + (d.in_node_count - 1 + 2 * (d.taxon_count - 1)) * sizeof(int32_t));
+}
+
+__global__ void __launch_bounds__(64)
+setup_trees_lds_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
+  extern __shared__ double setup_lds[];
+  const int n = d.taxon_count, N = d.node_count, M = d.in_node_count, NI = n - 1;
+  const int t0 = blockIdx.x * kSetupTrees, tid = threadIdx.x;
+  const int count = min(kSetupTrees, d.tree_count - t0);
+  double* bl = setup_lds;                                              // [trees][N]
+  int32_t* par = reinterpret_cast<int32_t*>(bl + kSetupTrees * N);     // [trees][M-1]
+  int32_t* ch = par + kSetupTrees * (M - 1);                           // [trees][2 NI]
+  for (int i = tid; i < count * (M - 1); i += 64) par[i] = b.parent_ids[(size_t)t0 * (M - 1) + i];
+  for (int i = tid; i < count * M; i += 64) bl[(i / M) * N + i % M] = b.branch_in[(size_t)t0 * M + i];
+  __syncthreads();
+  if (tid < count)
+    SetupTopologyCore(d, par + tid * (M - 1), ch + tid * 2 * NI, bl + tid * N,
+                      b.rates != nullptr ? b.rates + (size_t)(t0 + tid) * (M - 1) : nullptr);
+  __syncthreads();
+  for (int i = tid; i < count * 2 * NI; i += 64) b.children[(size_t)t0 * 2 * NI + i] = ch[i];
+  for (int i = tid; i < count * N; i += 64) b.branch[(size_t)t0 * N + i] = bl[i];
+  if (tid < count) SetupTreeModel(spec, b.params + (size_t)(t0 + tid) * spec.param_count, &b.model[t0 + tid]);
+}
+
 void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int,
                  hipStream_t stream) {
+  const size_t lds = SetupLdsBytes(d);
+  if (lds <= 48 * 1024) {
+    const int blocks = (d.tree_count + kSetupTrees - 1) / kSetupTrees;
+    hipLaunchKernelGGL(setup_trees_lds_kernel, dim3(blocks), dim3(64), lds, stream, d, spec, b);
+    return;
+  }
   const int blocks = (d.tree_count + 63) / 64;
   hipLaunchKernelGGL(setup_trees_kernel, dim3(blocks), dim3(64), 0, stream, d, spec, b);
 }

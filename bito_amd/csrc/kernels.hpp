@@ -63,13 +63,13 @@ struct DeviceBatch {
   double* out_grad;           // [T][N]
 };
 
-// Topology set-up of tree t, shared by the 4-state and the general-state set-up kernels:
-// parent-id vector -> child lists (+ detrifurcation), effective branch lengths.
-__device__ inline void SetupTopology(const BatchDims& d, const DeviceBatch& b, int t) {
+// Topology set-up of one tree, shared by the 4-state and the general-state set-up kernels:
+// parent-id vector -> child lists (+ detrifurcation), effective branch lengths.  The arrays may live
+// in global memory or in LDS; bl must already hold the M input branch lengths.
+__device__ inline void SetupTopologyCore(const BatchDims& d, const int32_t* parent, int32_t* ch, double* bl,
+                                         const double* rates) {
   const int n = d.taxon_count, N = d.node_count, M = d.in_node_count, NI = n - 1;
-  int32_t* ch = b.children + (size_t)t * NI * 2;
   for (int k = 0; k < NI * 2; k++) ch[k] = -1;
-  const int32_t* parent = b.parent_ids + (size_t)t * (M - 1);
   int third = -1;
   // Children in ascending id order, as Node::OfParentIdVector builds them
   // (reference src/node.cpp:511-551).
@@ -83,9 +83,6 @@ __device__ inline void SetupTopology(const BatchDims& d, const DeviceBatch& b, i
       third = child;
     }
   }
-  double* bl = b.branch + (size_t)t * N;
-  const double* bl_in = b.branch_in + (size_t)t * M;
-  for (int i = 0; i < M; i++) bl[i] = bl_in[i];
   if (!d.rooted) {
     // UnrootedTree::Detrifurcate (reference src/unrooted_tree.cpp:27-37): children 1 and
     // 2 of the trifurcation are joined under a node that re-uses the old root id
@@ -100,11 +97,19 @@ __device__ inline void SetupTopology(const BatchDims& d, const DeviceBatch& b, i
     ch[(r + 1 - n) * 2] = a;
     ch[(r + 1 - n) * 2 + 1] = r;
     bl[r + 1] = 0.0;
-  } else if (b.rates != nullptr) {
+  } else if (rates != nullptr) {
     // FatBeagle::LogLikelihood(RootedTree) (reference src/fat_beagle.cpp:86-90).
-    const double* rates = b.rates + (size_t)t * (M - 1);
     for (int i = 0; i < N - 1; i++) bl[i] *= rates[i];
   }
+}
+
+__device__ inline void SetupTopology(const BatchDims& d, const DeviceBatch& b, int t) {
+  const int n = d.taxon_count, N = d.node_count, M = d.in_node_count;
+  double* bl = b.branch + (size_t)t * N;
+  const double* bl_in = b.branch_in + (size_t)t * M;
+  for (int i = 0; i < M; i++) bl[i] = bl_in[i];
+  SetupTopologyCore(d, b.parent_ids + (size_t)t * (M - 1), b.children + (size_t)t * (n - 1) * 2, bl,
+                    b.rates != nullptr ? b.rates + (size_t)t * (M - 1) : nullptr);
 }
 
 void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int want_gradient,

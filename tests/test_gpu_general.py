@@ -210,3 +210,29 @@ def test_codon_rescaling(site):
     assert grad_close(out["branch_lengths"], ref["branch_lengths"])
     plain = eng.log_likelihoods(pid, bl, params, rescaling=False)
     assert not np.all(np.isfinite(plain))  # which is why the argument exists
+
+
+def test_general_kernels_rooted_hky_eight_categories(data_dir):
+    """Rooted trees with per-branch rates (src/fat_beagle.cpp:86-90), HKY written as GTR inside the general
+    set-up kernel, eight rate categories: the general kernels against the pinned 4-state CPU oracle.  Two
+    correct FP64 set-ups differ coherently across patterns, hence 2e-9 / 1e-5."""
+    from oracle import oracle
+
+    tc = treeio.read_newick_file(os.path.join(data_dir, "fluA.tree"))
+    sp = SitePattern(treeio.read_fasta(os.path.join(data_dir, "fluA.fa")), tc.taxon_names)
+    T = 3
+    pid = np.tile(tc.parent_id_matrix(), (T, 1))
+    bl = np.tile(tc.branch_length_matrix(), (T, 1)) * np.array([[1.0], [0.5], [2.0]])
+    rates = np.full((T, pid.shape[1]), 0.001) * np.random.default_rng(3).uniform(0.5, 2.0, (T, pid.shape[1]))
+    params = np.tile(np.array([0.1, 0.2, 0.3, 0.4, 3.0, 0.6]), (T, 1))  # pi | kappa | shape
+    eng = _general("HKY", "weibull+8", sp.patterns, sp.weights)
+    cpu = oracle.OracleEngine("HKY", "weibull+8", "none", sp.patterns, sp.weights, 4)
+    out = eng.gradients(pid, bl, params, rates=rates)
+    ref = cpu.gradients(pid, bl, params, rates=rates)
+    assert eng.kernel_name() == "gs_walk_kernel"
+    assert np.abs(out["log_likelihood"] - ref["log_likelihood"]).max() < 2e-9
+    scale = np.maximum(1.0, np.abs(ref["branch_lengths"]))
+    assert (np.abs(out["branch_lengths"] - ref["branch_lengths"]) / scale).max() < 1e-5
+    res = eng.gradients(pid, bl, params, rates=rates, rescaling=True)
+    assert np.abs(res["log_likelihood"] - out["log_likelihood"]).max() < 1e-9
+    assert (np.abs(res["branch_lengths"] - out["branch_lengths"]) / scale).max() < 1e-8
