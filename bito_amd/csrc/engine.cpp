@@ -214,7 +214,7 @@ int ValidateParams(bito_amd_engine* e, int tree_count, const double* params) {
 // the trifurcating root of an unrooted tree (reference src/node.cpp:383-402,511-551;
 // src/unrooted_tree.cpp:46-52).
 int ValidateTrees(bito_amd_engine* e, int tree_count, int rooted, int node_count,
-                  const int32_t* parent_ids) {
+                  const int32_t* parent_ids, int* min_cherries = nullptr) {
   const int n = e->n, M = node_count;
   if (M != (rooted ? 2 * n - 1 : 2 * n - 2)) {
     char buf[200];
@@ -223,10 +223,12 @@ int ValidateTrees(bito_amd_engine* e, int tree_count, int rooted, int node_count
     return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
   }
   if (M < 3) return Fail(e, BITO_AMD_ERR_BAD_TREE, "tree too small");
-  std::vector<int> count(M);
+  std::vector<int> count(M), tip_children(M);
+  int fewest = M;
   for (int t = 0; t < tree_count; t++) {
     const int32_t* par = parent_ids + (size_t)t * (M - 1);
     std::fill(count.begin(), count.end(), 0);
+    std::fill(tip_children.begin(), tip_children.end(), 0);
     for (int child = 0; child < M - 1; child++) {
       const int p = par[child];
       if (p < n || p >= M || p <= child) {
@@ -236,7 +238,14 @@ int ValidateTrees(bito_amd_engine* e, int tree_count, int rooted, int node_count
         return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
       }
       count[p]++;
+      if (child < n) tip_children[p]++;
     }
+    // cherries of the (detrifurcated) tree: non-root internal nodes over two tips; the node that
+    // re-uses an unrooted tree's old root id joins children 1 and 2 of the trifurcation
+    int cherries = 0;
+    for (int i = n; i < M - 1; i++) cherries += tip_children[i] == 2;
+    if (!rooted) cherries += tip_children[M - 1] == 3;
+    fewest = std::min(fewest, cherries);
     for (int i = n; i < M; i++) {
       const int want = (!rooted && i == M - 1) ? 3 : 2;
       if (count[i] != want) {
@@ -247,6 +256,7 @@ int ValidateTrees(bito_amd_engine* e, int tree_count, int rooted, int node_count
       }
     }
   }
+  if (min_cherries) *min_cherries = fewest;
   return BITO_AMD_OK;
 }
 
@@ -539,7 +549,8 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
     return Fail(e, BITO_AMD_ERR_BAD_ARG, "need at least one tree and non-NULL parent_ids / branch_lengths");
   if (e->spec.param_count > 0 && !params)
     return Fail(e, BITO_AMD_ERR_BAD_ARG, "params is NULL but the model has parameters");
-  int rc = ValidateTrees(e, tree_count, rooted, node_count, parent_ids);
+  int min_cherries = 0;
+  int rc = ValidateTrees(e, tree_count, rooted, node_count, parent_ids, &min_cherries);
   if (rc) return rc;
   if (params && (rc = ValidateParams(e, tree_count, params))) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
@@ -576,6 +587,7 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   e->dims.pattern_stride = e->Ppad;
   e->dims.category_count = C;
   e->dims.tree_count = tree_count;
+  e->dims.min_cherries = min_cherries;
   e->resident = true;
   return BITO_AMD_OK;
 }

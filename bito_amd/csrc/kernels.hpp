@@ -27,6 +27,7 @@ struct BatchDims {
   int32_t pattern_stride; // Ppad (multiple of 64)
   int32_t category_count; // C
   int32_t tree_count;     // T
+  int32_t min_cherries;   // fewest cherries (internal nodes over two tips, root excepted) of any tree of the batch
 };
 
 // MFMA operand images, one set per (tree, branch), 3 x 64 doubles, lane order of
@@ -53,7 +54,7 @@ struct DeviceBatch {
   TreeModel* model;           // [T]
   double* mats;               // [T][N-1][C][kMatStride]   (HBM-arena kernel)
   double* images;             // [T][N-1][kImgStride]      (LDS kernel)
-  int32_t* sched;             // [T][2][n-1][8]            step descriptors (LDS kernel)
+  int32_t* sched;             // [T][2][n+1][16]           step descriptors (LDS kernel)
   // traversal scratch + outputs
   double* arena;              // [chunk][n-1][C][4][Ppad]
   double* scale_arena;        // [chunk][n-1][Ppad]  post-order 1/scale factors (rescaled gradients)

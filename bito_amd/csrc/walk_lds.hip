@@ -77,7 +77,23 @@ void LaunchMatrixImages(const BatchDims& d, const DeviceBatch& b, int want_gradi
 
 // --------------------------------------------------------------------------
 
-constexpr int kLdsWaves = 4;
+// build-time knobs for experiments (scripts/build_lds_variants.sh); the defaults are the shipped kernel
+#ifndef LDS_WAVES
+#define LDS_WAVES 4
+#endif
+#ifndef LDS_WAVES_PER_EU
+#define LDS_WAVES_PER_EU 1
+#endif
+#ifndef LDS_FORCE_G
+#define LDS_FORCE_G 0
+#endif
+#ifndef LDS_COND_LOADS
+#define LDS_COND_LOADS 0
+#endif
+#ifndef LDS_NO_CHERRIES
+#define LDS_NO_CHERRIES 0  // 1: store every internal node (ablation of the cherry folding)
+#endif
+constexpr int kLdsWaves = LDS_WAVES;
 constexpr size_t kLdsBudget = 160 * 1024;
 
 __device__ __forceinline__ double Mfma(double a, double x, double c) {
@@ -138,18 +154,27 @@ __device__ __forceinline__ double MergeHalves(double a, double b) {
 }
 
 // ---- step schedule ---------------------------------------------------------------------------
+// CHERRIES (internal nodes over two tips, the root excepted) are never stored and have no step of their
+// own: where a step's child is a cherry, its partial is rebuilt from the two tip look-ups
+// (x = (P_A e_A) . (P_B e_B), two MFMAs), and in the pre-order pass the cherry's own step -- the
+// derivatives of its two tip edges -- is folded into its parent's step.  A third of a tree's internal
+// nodes are cherries, so a wave's LDS region holds a third fewer cells and a workgroup a third more
+// pattern groups; that matters because a step costs about five groups' worth of fixed latency
+// (measured: scripts/gpu_lds_occupancy.py), so groups per SIMD are what fills the pipes.
+//
 // Everything a step needs that depends only on the topology is tabulated once per tree and read
-// with ONE scalar load per step (s_load_dwordx8, issued two steps ahead): LDS byte offsets of
-// the two operands (tip row or arena cell), of the node's own cell, which children are tips,
-// whether an operand is forwarded in registers, the child ids (gradient rows) and the image
-// offsets to prefetch for the step after next.  Two tables per tree: post-order (ascending node)
-// and pre-order (descending node), NI entries each.
+// with ONE scalar load per step (s_load_dwordx16, issued two steps ahead): LDS byte offsets of
+// the operands (tip row or arena cell), of the node's own cell, what kind each child is, whether an
+// operand is forwarded in registers, the child ids (gradient rows) and the image offsets to
+// prefetch for the step after next.  Two tables per tree: post-order (ascending node) and pre-order
+// (descending node), one entry per stored (non-cherry) internal node.
 struct alignas(32) StepDesc {
-  unsigned off0, off1;  // LDS byte offset of operand 0 / 1: tip row c*PB in the tip buffer, or arena cell
-  unsigned cell;        // LDS byte offset of this node's arena cell
-  unsigned flags;       // bit 0: child 0 is a tip; bit 1: child 1 is a tip; bit 2: forwarded operand
-  unsigned c0, c1;      // child ids
-  unsigned pf0, pf1;    // image byte offsets of the children of the step after next
+  unsigned off0, off1;  // LDS byte offset of operand 0 / 1: tip row c*PB, arena cell, or (cherry) tip row of its first tip
+  unsigned cell_flags;  // bits 0..17: LDS byte offset of this node's arena cell; bits 18..22: flags; bits 24..31: steps of the pass
+  unsigned c01;         // child ids, c0 | c1 << 16
+  unsigned pf01;        // ids of the children of the step after next (their images are prefetched)
+  unsigned pfab;        // cherry tips of the step after next, one byte each: a0, b0, a1, b1 (0: no cherry)
+  unsigned ab0, ab1;    // cherry child 0 / 1: its tips' ids, a | b << 16 (0xffffffff: no cherry)
 };
 // A descriptor is fetched with an explicit scalar load: the compiler only selects s_load for
 // memory it can prove unclobbered, which it does not here.  The caller waits (lgkmcnt) before
@@ -170,58 +195,99 @@ __device__ __forceinline__ StepWords StepFetch(const StepDesc* p) {
 }
 // the wait "produces" the descriptor, so no use of it can be scheduled above the wait
 __device__ __forceinline__ void StepWait(StepWords& w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w)::"memory"); }
-// word indices of the fields
-enum { kOff0 = 0, kOff1 = 1, kCell = 2, kFlags = 3, kC0 = 4, kC1 = 5, kPf0 = 6, kPf1 = 7 };
-// entries per pass: one per internal node plus two trailing copies of the last one, so the
+// word indices of the fields, and their unpacking
+enum { kOff0 = 0, kOff1 = 1, kCellFlags = 2, kC01 = 3, kPf01 = 4, kPfAb = 5, kAb0 = 6, kAb1 = 7 };
+#define DS_CELL(ds) ((ds)[kCellFlags] & 0x3ffffu)
+#define DS_FLAGS(ds) ((ds)[kCellFlags] >> 18)
+#define DS_C0(ds) ((ds)[kC01] & 0xffffu)
+#define DS_C1(ds) ((ds)[kC01] >> 16)
+// tip row of a cherry child's second tip (PB = patterns per workgroup, the tip buffer's row length)
+#define DS_OFFB0(ds) (((ds)[kAb0] >> 16) * (unsigned)PB)
+#define DS_OFFB1(ds) (((ds)[kAb1] >> 16) * (unsigned)PB)
+// entries per pass: at most one per internal node plus two trailing copies of the last one, so the
 // two-steps-ahead fetch needs no clamp
 __host__ __device__ constexpr int SchedEntries(int NI) { return NI + 2; }
-constexpr int kFlagTip0 = 1, kFlagTip1 = 2, kFlagForward = 4;
+constexpr int kFlagTip0 = 1, kFlagTip1 = 2, kFlagForward = 4, kFlagCherry0 = 8, kFlagCherry1 = 16;
+constexpr unsigned kNoCherry = 0xffffffffu;
 
-__global__ void __launch_bounds__(256)
+// One wave per tree: which nodes are cherries, compact cell numbers for the others, both tables
+// (one lane per step).
+constexpr int kMaxLdsTaxa = 256;  // (step count is an 8-bit field; larger trees do not fit LDS anyway)
+
+__global__ void __launch_bounds__(64)
 lds_schedule_kernel(BatchDims d, int G, int PB, const int32_t* __restrict__ children, StepDesc* __restrict__ sched) {
+  __shared__ int rank_of[kMaxLdsTaxa];  // internal node j: its cell number, or -1 for a cherry
+  __shared__ int nodes[kMaxLdsTaxa];    // stored nodes in ascending order
+  __shared__ int step_count;
   const int n = d.taxon_count, N = d.node_count, NI = n - 1;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= d.tree_count * NI) return;
-  const int tree = idx / NI, j = idx % NI;
+  const int tree = blockIdx.x, lane = threadIdx.x;
   const int32_t* ch = children + (size_t)tree * NI * 2;
-  auto off = [&](int c) -> unsigned { return c < n ? c * PB : (c - n) * G * 512; };
-  auto image = [&](int c) -> unsigned { return c * kImgStride * 8; };
   const int E = SchedEntries(NI);
   StepDesc* post = sched + (size_t)tree * 2 * E;
   StepDesc* pre = post + E;
-  {  // post-order step j: node n + j
-    const int node = n + j, c0 = ch[2 * j], c1 = ch[2 * j + 1];
-    const int a = j + 2 < NI ? j + 2 : NI - 1;
-    const StepDesc e{off(c0), off(c1), (unsigned)(j * G * 512),
-                     (unsigned)((c0 < n ? kFlagTip0 : 0) | (c1 < n ? kFlagTip1 : 0) |
-                                (c1 >= n && c1 == node - 1 ? kFlagForward : 0)),
-                     (unsigned)c0, (unsigned)c1, image(ch[2 * a]), image(ch[2 * a + 1])};
-    post[j] = e;
-    if (j == NI - 1) post[NI] = post[NI + 1] = e;
+  auto is_cherry = [&](int c) { return !LDS_NO_CHERRIES && c >= n && c != N - 1 && ch[2 * (c - n)] < n && ch[2 * (c - n) + 1] < n; };
+  for (int j = lane; j < NI; j += 64) rank_of[j] = is_cherry(n + j) ? -1 : 0;
+  __syncthreads();
+  if (lane == 0) {
+    int r = 0;
+    for (int j = 0; j < NI; j++)
+      if (rank_of[j] == 0) {
+        rank_of[j] = r;
+        nodes[r++] = n + j;
+      }
+    step_count = r;
   }
-  {  // pre-order step j: node N - 1 - j
-    const int k = NI - 1 - j, node = n + k, c0 = ch[2 * k], c1 = ch[2 * k + 1];
-    const int a = k - 2 >= 0 ? k - 2 : 0;
-    // U is still in registers when this node is the second child of the node processed just before
-    const bool fwd = node == N - 1 || ch[2 * (k + 1) + 1] == node;
-    const StepDesc e{off(c0), off(c1), (unsigned)(k * G * 512),
-                     (unsigned)((c0 < n ? kFlagTip0 : 0) | (c1 < n ? kFlagTip1 : 0) | (fwd ? kFlagForward : 0)),
-                     (unsigned)c0, (unsigned)c1, image(ch[2 * a]), image(ch[2 * a + 1])};
-    pre[j] = e;
-    if (j == NI - 1) pre[NI] = pre[NI + 1] = e;
+  __syncthreads();
+  const int steps = step_count;
+  auto cherry = [&](int c) { return c >= n && rank_of[c - n] < 0; };
+  auto operand = [&](int c) -> unsigned {
+    if (c < n) return (unsigned)(c * PB);
+    if (cherry(c)) return (unsigned)(ch[2 * (c - n)] * PB);
+    return (unsigned)(rank_of[c - n] * G * 512);
+  };
+  auto tip_bytes = [&](int c) -> unsigned {  // a | b << 8; tip 0 twice when c is no cherry (loaded, unused)
+    return cherry(c) ? (unsigned)ch[2 * (c - n)] | ((unsigned)ch[2 * (c - n) + 1] << 8) : 0u;
+  };
+  auto tips_of = [&](int c) -> unsigned {
+    return cherry(c) ? (unsigned)ch[2 * (c - n)] | ((unsigned)ch[2 * (c - n) + 1] << 16) : kNoCherry;
+  };
+  auto kinds = [&](int c0, int c1) -> unsigned {
+    return (c0 < n ? kFlagTip0 : 0) | (c1 < n ? kFlagTip1 : 0) | (cherry(c0) ? kFlagCherry0 : 0) |
+           (cherry(c1) ? kFlagCherry1 : 0);
+  };
+  auto entry = [&](int node, int ahead, bool fwd) {
+    const int c0 = ch[2 * (node - n)], c1 = ch[2 * (node - n) + 1];
+    const int a0 = ch[2 * (ahead - n)], a1 = ch[2 * (ahead - n) + 1];
+    return StepDesc{operand(c0), operand(c1),
+                    (unsigned)(rank_of[node - n] * G * 512) | ((kinds(c0, c1) | (fwd ? (unsigned)kFlagForward : 0u)) << 18) |
+                        ((unsigned)steps << 24),
+                    (unsigned)c0 | ((unsigned)c1 << 16), (unsigned)a0 | ((unsigned)a1 << 16),
+                    tip_bytes(a0) | (tip_bytes(a1) << 16), tips_of(c0), tips_of(c1)};
+  };
+  for (int s = lane; s < E; s += 64) {
+    const int q = s < steps ? s : steps - 1;  // the trailing entries repeat the last step
+    // post-order step q: node nodes[q]; the previous step's result is still in registers when its node
+    // is this step's second child
+    const int node = nodes[q];
+    post[s] = entry(node, nodes[q + 2 < steps ? q + 2 : steps - 1], q > 0 && ch[2 * (node - n) + 1] == nodes[q - 1]);
+    // pre-order step q: node nodes[steps-1-q]; U is still in registers when this node is the (stored)
+    // second child of the node processed just before
+    const int pnode = nodes[steps - 1 - q];
+    const bool fwd = q == 0 ? pnode == N - 1 : ch[2 * (nodes[steps - q] - n) + 1] == pnode;
+    pre[s] = entry(pnode, nodes[steps - 1 - (q + 2 < steps ? q + 2 : steps - 1)], fwd);
   }
 }
 
 template <int C, int G, bool GRAD>
-__global__ void __launch_bounds__(kLdsWaves * 64, 1)
-walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ sched,
+__global__ void __launch_bounds__(kLdsWaves * 64, LDS_WAVES_PER_EU)
+walk_lds_kernel(BatchDims d, int tiles, int units, int slots, const StepDesc* __restrict__ sched,
                 const double* __restrict__ images, const TreeModel* __restrict__ models,
                 const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
                 double* __restrict__ part_ll, double* __restrict__ part_grad) {
   extern __shared__ double lds[];
   constexpr int PG = 16 / C;                  // patterns per group
   constexpr int PB = kLdsWaves * G * PG;      // patterns per workgroup
-  const int n = d.taxon_count, N = d.node_count, NI = n - 1, slots = n - 2, Ppad = d.pattern_stride;
+  const int n = d.taxon_count, N = d.node_count, NI = n - 1, Ppad = d.pattern_stride;
 
   // XCD-aware unit order: workgroup b runs on XCD b % 8; give each XCD a contiguous range
   // of units so the tiles of one tree (same matrix images) share an L2.
@@ -273,11 +339,47 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
   const double w_cat = tm->cat_weight[cat];
   StepWait(PD0);
   StepWait(PD1);
-  struct Img2 { double m0, m1; };
+  const int steps = (int)(PD0[kCellFlags] >> 24);
 #define IMAGE_AT(off, which) (*reinterpret_cast<const double*>(img_b + (size_t)((off) + lane8 + (unsigned)((which) * 8))))
-  auto load2 = [&](int o0, int o1) { return Img2{IMAGE_AT(o0, kImgP), IMAGE_AT(o1, kImgP)}; };
-  const Img2 PS0 = load2(PD0[kC0] * (kImgStride * 8), PD0[kC1] * (kImgStride * 8));
-  const Img2 PS1 = load2(PD1[kC0] * (kImgStride * 8), PD1[kC1] * (kImgStride * 8));
+#define TIP_IMAGE(id, which) IMAGE_AT((id) * (unsigned)(kImgStride * 8), which)
+  // P images of the two child branches, and of the tip branches under a cherry child
+  struct Img2 { double m0, m1, a0, b0, a1, b1; };
+  constexpr unsigned kImgBytes = kImgStride * 8;
+  auto load2 = [&](Img2& r, unsigned id0, unsigned id1) {
+    r.m0 = IMAGE_AT(id0 * kImgBytes, kImgP);
+    r.m1 = IMAGE_AT(id1 * kImgBytes, kImgP);
+  };
+  // images of the tip branches under cherry children (prefetched two steps ahead like the others)
+  auto load2_cherries = [&](Img2& r, unsigned pfab) {  // bytes a0, b0, a1, b1 (tip 0 where there is no cherry)
+    if (LDS_NO_CHERRIES) return;
+    // (unconditional: a conditional load leaves a register set that must be merged with the old one at
+    // the join, and copying a register with a load in flight waits for the load)
+#if LDS_COND_LOADS
+    if (pfab & 0xffffu) {
+      r.a0 = TIP_IMAGE(pfab & 0xffu, kImgP);
+      r.b0 = TIP_IMAGE((pfab >> 8) & 0xffu, kImgP);
+    }
+    if (pfab >> 16) {
+      r.a1 = TIP_IMAGE((pfab >> 16) & 0xffu, kImgP);
+      r.b1 = TIP_IMAGE(pfab >> 24, kImgP);
+    }
+#else
+    r.a0 = TIP_IMAGE(pfab & 0xffu, kImgP);
+    r.b0 = TIP_IMAGE((pfab >> 8) & 0xffu, kImgP);
+    r.a1 = TIP_IMAGE((pfab >> 16) & 0xffu, kImgP);
+    r.b1 = TIP_IMAGE(pfab >> 24, kImgP);
+#endif
+  };
+  auto pack_ab = [](unsigned ab0, unsigned ab1) {  // a | b << 16 words -> the byte form
+    const unsigned lo = ab0 == kNoCherry ? 0u : (ab0 & 0xffu) | ((ab0 >> 8) & 0xff00u);
+    const unsigned hi = ab1 == kNoCherry ? 0u : (ab1 & 0xffu) | ((ab1 >> 8) & 0xff00u);
+    return lo | (hi << 16);
+  };
+  Img2 PS0 = {0, 0, 0, 0, 0, 0}, PS1 = PS0;
+  load2(PS0, DS_C0(PD0), DS_C1(PD0));
+  load2_cherries(PS0, pack_ab(PD0[kAb0], PD0[kAb1]));
+  load2(PS1, DS_C0(PD1), DS_C1(PD1));
+  load2_cherries(PS1, pack_ab(PD1[kAb0], PD1[kAb1]));
   // (issued behind the image loads: its latency hides under theirs and the tip states')
   WarmWords warm = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 2 * SchedEntries(NI); i += 2) StepWarm(post_tab + i, warm);
@@ -297,32 +399,58 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
 
 #define TIP_AT(off, g) tip_b[(off) + (g) * PG]
 #define CELL_AT(off, g) (*reinterpret_cast<double*>(arena_b + (off) + (g) * 512))
-  using T_ = std::true_type;
-  using F_ = std::false_type;
+  // Children are in ascending id order, so a tip never follows an internal node: the second child of a
+  // step is a stored cell or a cherry unless both children are tips (the root of a three-taxon tree).
+#define KIND_DISPATCH(flags_, ...)                                                        \
+  {                                                                                       \
+    const unsigned f_ = (flags_);                                                         \
+    using I0 = std::integral_constant<int, 0>;                                            \
+    using I1 = std::integral_constant<int, 1>;                                            \
+    using I2 = std::integral_constant<int, 2>;                                            \
+    if (f_ & kFlagTip1) step(I0{}, I0{}, __VA_ARGS__);                                    \
+    else if (f_ & kFlagCherry1) {                                                         \
+      if (f_ & kFlagTip0) step(I0{}, I2{}, __VA_ARGS__);                                  \
+      else if (f_ & kFlagCherry0) step(I2{}, I2{}, __VA_ARGS__);                          \
+      else step(I1{}, I2{}, __VA_ARGS__);                                                 \
+    } else {                                                                              \
+      if (f_ & kFlagTip0) step(I0{}, I1{}, __VA_ARGS__);                                  \
+      else if (f_ & kFlagCherry0) step(I2{}, I1{}, __VA_ARGS__);                          \
+      else step(I1{}, I1{}, __VA_ARGS__);                                                 \
+    }                                                                                     \
+  }
 
   // ---------------- post-order ----------------------------------------------
   // A step is self-contained straight-line code, specialised on which children are tips
-  // (children are in ascending id order, so a tip never follows an internal node).  Matrix
-  // images and step descriptors are fetched two steps ahead into three rotating register sets
-  // (3-way unrolled loop: a set is never copied).  The result of a step is handed to the next
-  // one in registers when that step's second child is this node, the common case.
+  // (children are in ascending id order, so a tip never follows an internal node); a cherry child
+  // is a uniform branch inside the non-tip form.  Matrix images and step descriptors are fetched two
+  // steps ahead into three rotating register sets (3-way unrolled loop: a set is never copied).  The
+  // result of a step is handed to the next one in registers when that step's second child is this
+  // node, the common case.
   double res[G];
   {
     StepWords D0 = PD0, D1 = PD1, D2 = PD1;
     Img2 S0 = PS0, S1 = PS1, S2 = PS1;
     int k = 0;
-    auto step = [&](auto tip0_c, auto tip1_c, const StepWords& ds, const Img2& cur, StepWords& nd, StepWords& dfill,
-                    Img2& fill) {
-      constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
+    auto step = [&](auto k0_c, auto k1_c, const StepWords& ds, const Img2& cur, StepWords& nd, Img2& nxt,
+                    StepWords& dfill, Img2& fill) {
+      // child kinds are compile-time: 0 tip, 1 stored cell, 2 cherry (rebuilt from its two tips)
+      constexpr int K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
+      const unsigned flags = DS_FLAGS(ds);
       double x0[G], x1[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        if (kTip0) x0[g] = TipOperand(TIP_AT(ds[kOff0], g), st);
-        else x0[g] = CELL_AT(ds[kOff0], g);
-        if (kTip1) x1[g] = TipOperand(TIP_AT(ds[kOff1], g), st);
+        if (K0 == 0) x0[g] = TipOperand(TIP_AT(ds[kOff0], g), st);
+        if (K0 == 1) x0[g] = CELL_AT(ds[kOff0], g);
+        if (K0 == 2)
+          x0[g] = Mfma(cur.a0, TipOperand(TIP_AT(ds[kOff0], g), st), 0.0) *
+                  Mfma(cur.b0, TipOperand(TIP_AT(DS_OFFB0(ds), g), st), 0.0);
+        if (K1 == 0) x1[g] = TipOperand(TIP_AT(ds[kOff1], g), st);
+        if (K1 == 2)
+          x1[g] = Mfma(cur.a1, TipOperand(TIP_AT(ds[kOff1], g), st), 0.0) *
+                  Mfma(cur.b1, TipOperand(TIP_AT(DS_OFFB1(ds), g), st), 0.0);
       }
-      if (!kTip1) {
-        if (ds[kFlags] & kFlagForward) {
+      if (K1 == 1) {
+        if (flags & kFlagForward) {
 #pragma unroll
           for (int g = 0; g < G; g++) x1[g] = res[g];
         } else {
@@ -330,7 +458,8 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
           for (int g = 0; g < G; g++) x1[g] = CELL_AT(ds[kOff1], g);
         }
       }
-      fill = load2(ds[kPf0], ds[kPf1]);
+      load2(fill, ds[kPf01] & 0xffffu, ds[kPf01] >> 16);
+      load2_cherries(fill, ds[kPfAb]);
       double a0[G], a1[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
@@ -348,25 +477,21 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < G; g++) res[g] = a0[g] * a1[g];
-      if (k < NI - 1) {  // the root partial is consumed below, never stored
+      if (k < steps - 1) {  // the root partial is consumed below, never stored
 #pragma unroll
-        for (int g = 0; g < G; g++) CELL_AT(ds[kCell], g) = res[g];
+        for (int g = 0; g < G; g++) CELL_AT(DS_CELL(ds), g) = res[g];
       }
     };
-    auto dispatch = [&](const StepWords& ds, const Img2& cur, StepWords& nd, StepWords& dfill, Img2& fill) {
-      const int kind = ds[kFlags] & 3;
-      if (kind == 3) step(T_{}, T_{}, ds, cur, nd, dfill, fill);
-      else if (kind == 1) step(T_{}, F_{}, ds, cur, nd, dfill, fill);
-      else if (kind == 0) step(F_{}, F_{}, ds, cur, nd, dfill, fill);
-      else step(F_{}, T_{}, ds, cur, nd, dfill, fill);
+    auto dispatch = [&](const StepWords& ds, const Img2& cur, StepWords& nd, Img2& nxt, StepWords& dfill, Img2& fill) {
+      KIND_DISPATCH(DS_FLAGS(ds), ds, cur, nd, nxt, dfill, fill)
     };
     while (true) {
-      dispatch(D0, S0, D1, D2, S2);
-      if (++k >= NI) break;
-      dispatch(D1, S1, D2, D0, S0);
-      if (++k >= NI) break;
-      dispatch(D2, S2, D0, D1, S1);
-      if (++k >= NI) break;
+      dispatch(D0, S0, D1, S1, D2, S2);
+      if (++k >= steps) break;
+      dispatch(D1, S1, D2, S2, D0, S0);
+      if (++k >= steps) break;
+      dispatch(D2, S2, D0, S0, D1, S1);
+      if (++k >= steps) break;
     }
   }
 
@@ -406,17 +531,42 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
   // ---------------- pre-order + edge derivatives ----------------------------
   if (GRAD) {
     double* my_row = grad_rows + wave * 4 * N;  // [block][edge]
-    struct Img { double p0, q0, t0, p1, q1, t1; };  // P, dP, P^T images of the two child branches
-    auto load_img = [&](int o0, int o1) {
-      return Img{IMAGE_AT(o0, kImgP), IMAGE_AT(o0, kImgDP), IMAGE_AT(o0, kImgPT),
-                 IMAGE_AT(o1, kImgP), IMAGE_AT(o1, kImgDP), IMAGE_AT(o1, kImgPT)};
+    // P, dP, P^T images of the two child branches; P and dP of the tip branches under a cherry child
+    struct Img { double p0, q0, t0, p1, q1, t1, pa0, da0, pb0, db0, pa1, da1, pb1, db1; };
+    auto load_img = [&](Img& r, unsigned id0, unsigned id1) {
+      const unsigned o0 = id0 * kImgBytes, o1 = id1 * kImgBytes;
+      r.p0 = IMAGE_AT(o0, kImgP); r.q0 = IMAGE_AT(o0, kImgDP); r.t0 = IMAGE_AT(o0, kImgPT);
+      r.p1 = IMAGE_AT(o1, kImgP); r.q1 = IMAGE_AT(o1, kImgDP); r.t1 = IMAGE_AT(o1, kImgPT);
+    };
+    auto load_img_cherries = [&](Img& r, unsigned pfab) {  // unconditional, see load2_cherries
+      if (LDS_NO_CHERRIES) return;
+      const unsigned a0 = pfab & 0xffu, b0 = (pfab >> 8) & 0xffu, a1 = (pfab >> 16) & 0xffu, b1 = pfab >> 24;
+#if LDS_COND_LOADS
+      if (pfab & 0xffffu) {
+        r.pa0 = TIP_IMAGE(a0, kImgP); r.da0 = TIP_IMAGE(a0, kImgDP);
+        r.pb0 = TIP_IMAGE(b0, kImgP); r.db0 = TIP_IMAGE(b0, kImgDP);
+      }
+      if (pfab >> 16) {
+        r.pa1 = TIP_IMAGE(a1, kImgP); r.da1 = TIP_IMAGE(a1, kImgDP);
+        r.pb1 = TIP_IMAGE(b1, kImgP); r.db1 = TIP_IMAGE(b1, kImgDP);
+      }
+#else
+      r.pa0 = TIP_IMAGE(a0, kImgP); r.da0 = TIP_IMAGE(a0, kImgDP);
+      r.pb0 = TIP_IMAGE(b0, kImgP); r.db0 = TIP_IMAGE(b0, kImgDP);
+      r.pa1 = TIP_IMAGE(a1, kImgP); r.da1 = TIP_IMAGE(a1, kImgDP);
+      r.pb1 = TIP_IMAGE(b1, kImgP); r.db1 = TIP_IMAGE(b1, kImgDP);
+#endif
     };
     StepWords D0 = StepFetch(pre_tab), D1 = StepFetch(pre_tab + 1), D2;
     StepWait(D0);
     StepWait(D1);
     D2 = D1;
-    Img S0 = load_img(D0[kC0] * (kImgStride * 8), D0[kC1] * (kImgStride * 8));
-    Img S1 = load_img(D1[kC0] * (kImgStride * 8), D1[kC1] * (kImgStride * 8)), S2 = S1;
+    Img S0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, S1 = S0, S2;
+    load_img(S0, DS_C0(D0), DS_C1(D0));
+    load_img_cherries(S0, pack_ab(D0[kAb0], D0[kAb1]));
+    load_img(S1, DS_C0(D1), DS_C1(D1));
+    load_img_cherries(S1, pack_ab(D1[kAb0], D1[kAb1]));
+    S2 = S1;
     // U = pre-order partial of the step's node; for the root the stationary frequencies
     // (SetRootPreorderPartialsToStateFrequencies, fat_beagle.cpp:327-336).  It stays in
     // registers when the next node is this node's second child (the usual case).
@@ -424,36 +574,61 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
 #pragma unroll
     for (int g = 0; g < G; g++) U[g] = pi_st;
     // edge sums of the previous step, reduced one step late so that the reduction fills the
-    // wait for this step's LDS operands
-    double ps0 = 0.0, ps1 = 0.0;
+    // wait for this step's LDS operands: the two child edges, and the tip edges of cherry children
+    double ps0 = 0.0, ps1 = 0.0, pa0 = 0.0, pb0 = 0.0, pa1 = 0.0, pb1 = 0.0;
     int pc0 = N - 1, pc1 = N - 1;  // root entry: the reduce kernel writes 0 there
+    unsigned pab0 = kNoCherry, pab1 = kNoCherry;
     // The 64-lane sum of an edge on the matrix pipe: with the per-lane terms as the A operand and
     // ones as B, D_b[i][j] = sum_k v[16k+4b+i] (the four state rows); fed back as the B operand
     // under an all-ones A, D_b[i][j] = sum over the block's 16 lanes.  What is left, the sum over
     // the four blocks, is folded into the workgroup sum at the end: a row per block.
-    const bool row_writer = (lane & 0x13) == 0;  // lanes 4b (edge pc0) and 32+4b (edge pc1)
-    auto flush_edges = [&]() {
-      const double r0 = Mfma(ps0, 1.0, 0.0), r1 = Mfma(ps1, 1.0, 0.0);
+    const bool row_writer = (lane & 0x13) == 0;  // lanes 4b (first edge) and 32+4b (second edge)
+    auto flush_pair = [&](double v0, double v1, int e0, int e1) {
+      const double r0 = Mfma(v0, 1.0, 0.0), r1 = Mfma(v1, 1.0, 0.0);
       const double t0 = Mfma(1.0, r0, 0.0), t1 = Mfma(1.0, r1, 0.0);
-      if (row_writer) my_row[blk * N + (lane < 32 ? pc0 : pc1)] = lane < 32 ? t0 : t1;
+      if (row_writer) my_row[blk * N + (lane < 32 ? e0 : e1)] = lane < 32 ? t0 : t1;
+    };
+    auto flush_edges = [&]() {
+      flush_pair(ps0, ps1, pc0, pc1);
+      if (pab0 != kNoCherry) flush_pair(pa0, pb0, (int)(pab0 & 0xffffu), (int)(pab0 >> 16));
+      if (pab1 != kNoCherry) flush_pair(pa1, pb1, (int)(pab1 & 0xffffu), (int)(pab1 >> 16));
     };
     int j = 0;
-    auto step = [&](auto tip0_c, auto tip1_c, const StepWords& ds, const Img& cur, StepWords& nd, StepWords& dfill,
-                    Img& fill) {
-      constexpr bool kTip0 = decltype(tip0_c)::value, kTip1 = decltype(tip1_c)::value;
+    auto step = [&](auto k0_c, auto k1_c, const StepWords& ds, const Img& cur, StepWords& nd, Img& nxt,
+                    StepWords& dfill, Img& fill) {
+      constexpr int K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;  // 0 tip, 1 stored cell, 2 cherry
+      constexpr bool kTip0 = K0 == 0, kTip1 = K1 == 0, cherry0 = K0 == 2, cherry1 = K1 == 2;
+      const unsigned flags = DS_FLAGS(ds);
       double x0[G], x1[G];
+      // cherry children: tip operands and tip messages, kept for the folded step below
+      double ta0[G], tb0[G], ma0[G], mb0[G], ta1[G], tb1[G], ma1[G], mb1[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        if (kTip0) x0[g] = TipOperand(TIP_AT(ds[kOff0], g), st);
-        else x0[g] = CELL_AT(ds[kOff0], g);
-        if (kTip1) x1[g] = TipOperand(TIP_AT(ds[kOff1], g), st);
-        else x1[g] = CELL_AT(ds[kOff1], g);
+        if (K0 == 0) x0[g] = TipOperand(TIP_AT(ds[kOff0], g), st);
+        if (K0 == 1) x0[g] = CELL_AT(ds[kOff0], g);
+        if (K0 == 2) {
+          ta0[g] = TipOperand(TIP_AT(ds[kOff0], g), st);
+          tb0[g] = TipOperand(TIP_AT(DS_OFFB0(ds), g), st);
+          ma0[g] = Mfma(cur.pa0, ta0[g], 0.0);
+          mb0[g] = Mfma(cur.pb0, tb0[g], 0.0);
+          x0[g] = ma0[g] * mb0[g];
+        }
+        if (K1 == 0) x1[g] = TipOperand(TIP_AT(ds[kOff1], g), st);
+        if (K1 == 1) x1[g] = CELL_AT(ds[kOff1], g);
+        if (K1 == 2) {
+          ta1[g] = TipOperand(TIP_AT(ds[kOff1], g), st);
+          tb1[g] = TipOperand(TIP_AT(DS_OFFB1(ds), g), st);
+          ma1[g] = Mfma(cur.pa1, ta1[g], 0.0);
+          mb1[g] = Mfma(cur.pb1, tb1[g], 0.0);
+          x1[g] = ma1[g] * mb1[g];
+        }
       }
-      if (!(ds[kFlags] & kFlagForward)) {
+      if (!(flags & kFlagForward)) {
 #pragma unroll
-        for (int g = 0; g < G; g++) U[g] = CELL_AT(ds[kCell], g);
+        for (int g = 0; g < G; g++) U[g] = CELL_AT(DS_CELL(ds), g);
       }
-      fill = load_img(ds[kPf0], ds[kPf1]);
+      load_img(fill, ds[kPf01] & 0xffffu, ds[kPf01] >> 16);
+      load_img_cherries(fill, ds[kPfAb]);
       flush_edges();
       // this step: all matrix products first, then the element-wise work
       double a0[G], dd0[G], a1[G], dd1[G];
@@ -477,17 +652,41 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
         ua1[g] = U[g] * a1[g];
         ua0[g] = U[g] * a0[g];
       }
+      pab0 = pab1 = kNoCherry;
       if (!kTip0) {
+        if (cherry0) {
+          // the cherry's own step, folded in: q = its pre-order partial; tip edges A and B
+          double sa = 0.0, sb = 0.0;
 #pragma unroll
-        for (int g = 0; g < G; g++) CELL_AT(ds[kOff0], g) = Mfma(cur.t0, ua1[g], 0.0);
+          for (int g = 0; g < G; g++) {
+            const double q = Mfma(cur.t0, ua1[g], 0.0);
+            sa = fma(coef[g], (q * mb0[g]) * Mfma(cur.da0, ta0[g], 0.0), sa);
+            sb = fma(coef[g], (q * ma0[g]) * Mfma(cur.db0, tb0[g], 0.0), sb);
+          }
+          pa0 = sa; pb0 = sb; pab0 = ds[kAb0];
+        } else {
+#pragma unroll
+          for (int g = 0; g < G; g++) CELL_AT(ds[kOff0], g) = Mfma(cur.t0, ua1[g], 0.0);
+        }
       }
       if (!kTip1) {
-        // the second child's pre-order partial goes straight into U: it is the next
-        // step's U whenever the next node is that child
+        if (cherry1) {
+          double sa = 0.0, sb = 0.0;
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-          U[g] = Mfma(cur.t1, ua0[g], 0.0);
-          CELL_AT(ds[kOff1], g) = U[g];
+          for (int g = 0; g < G; g++) {
+            const double q = Mfma(cur.t1, ua0[g], 0.0);
+            sa = fma(coef[g], (q * mb1[g]) * Mfma(cur.da1, ta1[g], 0.0), sa);
+            sb = fma(coef[g], (q * ma1[g]) * Mfma(cur.db1, tb1[g], 0.0), sb);
+          }
+          pa1 = sa; pb1 = sb; pab1 = ds[kAb1];
+        } else {
+          // the second child's pre-order partial goes straight into U: it is the next
+          // step's U whenever the next node is that child
+#pragma unroll
+          for (int g = 0; g < G; g++) {
+            U[g] = Mfma(cur.t1, ua0[g], 0.0);
+            CELL_AT(ds[kOff1], g) = U[g];
+          }
         }
       }
       double s0 = 0.0, s1 = 0.0;
@@ -496,28 +695,26 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
         s0 = fma(coef[g], ua1[g] * dd0[g], s0);
         s1 = fma(coef[g], ua0[g] * dd1[g], s1);
       }
-      ps0 = s0; ps1 = s1; pc0 = ds[kC0]; pc1 = ds[kC1];
+      ps0 = s0; ps1 = s1; pc0 = DS_C0(ds); pc1 = DS_C1(ds);
     };
-    auto dispatch = [&](const StepWords& ds, const Img& cur, StepWords& nd, StepWords& dfill, Img& fill) {
-      const int kind = ds[kFlags] & 3;
-      if (kind == 3) step(T_{}, T_{}, ds, cur, nd, dfill, fill);
-      else if (kind == 1) step(T_{}, F_{}, ds, cur, nd, dfill, fill);
-      else if (kind == 0) step(F_{}, F_{}, ds, cur, nd, dfill, fill);
-      else step(F_{}, T_{}, ds, cur, nd, dfill, fill);
+    auto dispatch = [&](const StepWords& ds, const Img& cur, StepWords& nd, Img& nxt, StepWords& dfill, Img& fill) {
+      KIND_DISPATCH(DS_FLAGS(ds), ds, cur, nd, nxt, dfill, fill)
     };
     while (true) {
-      dispatch(D0, S0, D1, D2, S2);
-      if (++j >= NI) break;
-      dispatch(D1, S1, D2, D0, S0);
-      if (++j >= NI) break;
-      dispatch(D2, S2, D0, D1, S1);
-      if (++j >= NI) break;
+      dispatch(D0, S0, D1, S1, D2, S2);
+      if (++j >= steps) break;
+      dispatch(D1, S1, D2, S2, D0, S0);
+      if (++j >= steps) break;
+      dispatch(D2, S2, D0, S0, D1, S1);
+      if (++j >= steps) break;
     }
     flush_edges();
   }
 #undef TIP_AT
 #undef CELL_AT
 #undef IMAGE_AT
+#undef TIP_IMAGE
+#undef KIND_DISPATCH
 
   // ---------------- workgroup sums, fixed order -----------------------------
   double wll = ll_acc;
@@ -540,9 +737,16 @@ walk_lds_kernel(BatchDims d, int tiles, int units, const StepDesc* __restrict__ 
   }
 }
 
+// cells per pattern group: the stored (non-cherry, non-root) internal nodes of the tree of the batch
+// that has the fewest cherries (BatchDims::min_cherries, counted by the host while it validates)
+static int LdsSlots(const BatchDims& d) {
+  const int cherries = LDS_NO_CHERRIES ? 0 : d.min_cherries;
+  return d.taxon_count - 2 - cherries > 1 ? d.taxon_count - 2 - cherries : 1;
+}
+
 static size_t LdsBytes(const BatchDims& d, int G) {
   const int PG = 16 / d.category_count, PB = kLdsWaves * G * PG, n = d.taxon_count;
-  const size_t arena = (size_t)kLdsWaves * (n - 2) * G * 64;
+  const size_t arena = (size_t)kLdsWaves * LdsSlots(d) * G * 64;
   const size_t tips = ((size_t)n * PB + 7) / 8;
   return (arena + tips + (size_t)kLdsWaves * 4 * d.node_count + kLdsWaves) * sizeof(double);
 }
@@ -551,11 +755,12 @@ LdsPlan PlanLds(const BatchDims& d) {
   LdsPlan plan{0, 0, 0, 0};
   const int C = d.category_count;
   if (C != 1 && C != 2 && C != 4) return plan;
-  if (d.taxon_count < 3) return plan;
+  if (d.taxon_count < 3 || d.taxon_count >= kMaxLdsTaxa) return plan;  // (ids and step counts are 8-bit fields)
   // largest G in {1,2,3,4,6,8} that fits, but no more groups than the alignment can fill
   const int candidates[] = {8, 6, 4, 3, 2, 1};
   const int PG = 16 / C;
   for (int G : candidates) {
+    if (LDS_FORCE_G && G != LDS_FORCE_G) continue;
     if (LdsBytes(d, G) > kLdsBudget) continue;
     const int PB = kLdsWaves * G * PG;
     if (G > 1 && PB > d.pattern_count + PB / 2 && PB > 2 * kLdsWaves * PG) continue;  // mostly padding
@@ -577,7 +782,7 @@ static void LaunchWalkLdsCG(const BatchDims& d, const DeviceBatch& b, const LdsP
   auto kern = want_gradient ? walk_lds_kernel<C, G, true> : walk_lds_kernel<C, G, false>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsBudget);
-  hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, sched, b.images, b.model,
+  hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, LdsSlots(d), sched, b.images, b.model,
                      b.tip_states, b.weights, b.part_ll, b.part_grad);
 }
 
@@ -595,11 +800,10 @@ static void LaunchWalkLdsC(const BatchDims& d, const DeviceBatch& b, const LdsPl
   }
 }
 
-size_t LdsScheduleInts(const BatchDims& d) { return (size_t)d.tree_count * 2 * SchedEntries(d.taxon_count - 1) * 8; }
+size_t LdsScheduleInts(const BatchDims& d) { return (size_t)d.tree_count * 2 * SchedEntries(d.taxon_count - 1) * 16; }
 
 void LaunchLdsSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream) {
-  const int total = d.tree_count * (d.taxon_count - 1);
-  hipLaunchKernelGGL(lds_schedule_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, d, plan.groups,
+  hipLaunchKernelGGL(lds_schedule_kernel, dim3(d.tree_count), dim3(64), 0, stream, d, plan.groups,
                      plan.patterns_per_block, b.children, reinterpret_cast<StepDesc*>(b.sched));
 }
 
