@@ -33,8 +33,8 @@ struct BatchDims {
 // MFMA operand images, one set per (tree, branch), 3 x 64 doubles, lane order of
 // v_mfma_f64_4x4x4_4b's A operand (lane = 16 k + 4 block + row holds M_block[row][k];
 // block = category (+ C * pattern sub-group when C < 4)):
-//   [0,64)    P     ->  (P x)      child message
-//   [64,128)  dP    ->  (dP x)     its derivative wrt the branch length
+//   [0,128)   (P, dP) pairs, one pair per lane: P -> (P x) child message, dP -> (dP x) its derivative
+//             wrt the branch length; interleaved so that one 16-byte load fetches both
 //   [128,192) P^T   ->  P^T (u.a)  pre-order partial of the child
 constexpr int kImgStride = 192;
 constexpr int kImgP = 0, kImgDP = 64, kImgPT = 128;

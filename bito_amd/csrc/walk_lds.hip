@@ -56,7 +56,7 @@ matrix_images_kernel(BatchDims d, DeviceBatch b, int want_gradient, int deriv_mo
 #pragma unroll
   for (int q = 0; q < 4; q++) p += m->V[i * 4 + q] * exp(m->lambda[q] * time) * m->Vinv[q * 4 + k];
   double* out = b.images + unit * kImgStride;
-  out[kImgP + lane] = p;
+  out[2 * lane] = p;  // P and dP interleaved per lane: the pre-order pass fetches both with one 16-byte load
   out[kImgPT + 16 * i + 4 * blk + k] = p;  // image of P^T: lane 16 k' + 4 b + i' holds P[k'][i']
   if (want_gradient) {
     // dP_c[i][k] = sum_q P_c[i][q] (Q[q][k] r_c); P_c[i][q] lives in lane 16 q + 4 b + i.
@@ -64,7 +64,7 @@ matrix_images_kernel(BatchDims d, DeviceBatch b, int want_gradient, int deriv_mo
     const double drate = deriv_mode ? m->cat_rate_deriv[c] : rate;  // site-model pass: d r_c / d shape
 #pragma unroll
     for (int q = 0; q < 4; q++) dp += __shfl(p, 16 * q + (lane & 15)) * (m->Q[q * 4 + k] * drate);
-    out[kImgDP + lane] = dp;
+    out[2 * lane + 1] = dp;
   }
 }
 
@@ -278,6 +278,8 @@ lds_schedule_kernel(BatchDims d, int G, int PB, const int32_t* __restrict__ chil
   }
 }
 
+struct alignas(16) PdPair { double p, d; };  // one lane's P and dP entries of a branch image
+
 template <int C, int G, bool GRAD>
 __global__ void __launch_bounds__(kLdsWaves * 64, LDS_WAVES_PER_EU)
 walk_lds_kernel(BatchDims d, int tiles, int units, int slots, const StepDesc* __restrict__ sched,
@@ -340,14 +342,18 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, const StepDesc* __
   StepWait(PD0);
   StepWait(PD1);
   const int steps = (int)(PD0[kCellFlags] >> 24);
-#define IMAGE_AT(off, which) (*reinterpret_cast<const double*>(img_b + (size_t)((off) + lane8 + (unsigned)((which) * 8))))
-#define TIP_IMAGE(id, which) IMAGE_AT((id) * (unsigned)(kImgStride * 8), which)
+// P of a branch image (lane pair slot 0), its (P, dP) pair, and its P^T
+#define IMAGE_P(off) (*reinterpret_cast<const double*>(img_b + (size_t)((off) + 2u * lane8)))
+#define IMAGE_PD(off) (*reinterpret_cast<const PdPair*>(img_b + (size_t)((off) + 2u * lane8)))
+#define IMAGE_PT(off) (*reinterpret_cast<const double*>(img_b + (size_t)((off) + 1024u + lane8)))
+#define TIP_P(id) IMAGE_P((id) * (unsigned)(kImgStride * 8))
+#define TIP_PD(id) IMAGE_PD((id) * (unsigned)(kImgStride * 8))
   // P images of the two child branches, and of the tip branches under a cherry child
   struct Img2 { double m0, m1, a0, b0, a1, b1; };
   constexpr unsigned kImgBytes = kImgStride * 8;
   auto load2 = [&](Img2& r, unsigned id0, unsigned id1) {
-    r.m0 = IMAGE_AT(id0 * kImgBytes, kImgP);
-    r.m1 = IMAGE_AT(id1 * kImgBytes, kImgP);
+    r.m0 = IMAGE_P(id0 * kImgBytes);
+    r.m1 = IMAGE_P(id1 * kImgBytes);
   };
   // images of the tip branches under cherry children (prefetched two steps ahead like the others)
   auto load2_cherries = [&](Img2& r, unsigned pfab) {  // bytes a0, b0, a1, b1 (tip 0 where there is no cherry)
@@ -356,18 +362,18 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, const StepDesc* __
     // the join, and copying a register with a load in flight waits for the load)
 #if LDS_COND_LOADS
     if (pfab & 0xffffu) {
-      r.a0 = TIP_IMAGE(pfab & 0xffu, kImgP);
-      r.b0 = TIP_IMAGE((pfab >> 8) & 0xffu, kImgP);
+      r.a0 = TIP_P(pfab & 0xffu);
+      r.b0 = TIP_P((pfab >> 8) & 0xffu);
     }
     if (pfab >> 16) {
-      r.a1 = TIP_IMAGE((pfab >> 16) & 0xffu, kImgP);
-      r.b1 = TIP_IMAGE(pfab >> 24, kImgP);
+      r.a1 = TIP_P((pfab >> 16) & 0xffu);
+      r.b1 = TIP_P(pfab >> 24);
     }
 #else
-    r.a0 = TIP_IMAGE(pfab & 0xffu, kImgP);
-    r.b0 = TIP_IMAGE((pfab >> 8) & 0xffu, kImgP);
-    r.a1 = TIP_IMAGE((pfab >> 16) & 0xffu, kImgP);
-    r.b1 = TIP_IMAGE(pfab >> 24, kImgP);
+    r.a0 = TIP_P(pfab & 0xffu);
+    r.b0 = TIP_P((pfab >> 8) & 0xffu);
+    r.a1 = TIP_P((pfab >> 16) & 0xffu);
+    r.b1 = TIP_P(pfab >> 24);
 #endif
   };
   auto pack_ab = [](unsigned ab0, unsigned ab1) {  // a | b << 16 words -> the byte form
@@ -535,26 +541,26 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, const StepDesc* __
     struct Img { double p0, q0, t0, p1, q1, t1, pa0, da0, pb0, db0, pa1, da1, pb1, db1; };
     auto load_img = [&](Img& r, unsigned id0, unsigned id1) {
       const unsigned o0 = id0 * kImgBytes, o1 = id1 * kImgBytes;
-      r.p0 = IMAGE_AT(o0, kImgP); r.q0 = IMAGE_AT(o0, kImgDP); r.t0 = IMAGE_AT(o0, kImgPT);
-      r.p1 = IMAGE_AT(o1, kImgP); r.q1 = IMAGE_AT(o1, kImgDP); r.t1 = IMAGE_AT(o1, kImgPT);
+      const PdPair c0 = IMAGE_PD(o0), c1 = IMAGE_PD(o1);
+      r.p0 = c0.p; r.q0 = c0.d; r.t0 = IMAGE_PT(o0);
+      r.p1 = c1.p; r.q1 = c1.d; r.t1 = IMAGE_PT(o1);
     };
     auto load_img_cherries = [&](Img& r, unsigned pfab) {  // unconditional, see load2_cherries
       if (LDS_NO_CHERRIES) return;
       const unsigned a0 = pfab & 0xffu, b0 = (pfab >> 8) & 0xffu, a1 = (pfab >> 16) & 0xffu, b1 = pfab >> 24;
 #if LDS_COND_LOADS
       if (pfab & 0xffffu) {
-        r.pa0 = TIP_IMAGE(a0, kImgP); r.da0 = TIP_IMAGE(a0, kImgDP);
-        r.pb0 = TIP_IMAGE(b0, kImgP); r.db0 = TIP_IMAGE(b0, kImgDP);
+        const PdPair ta = TIP_PD(a0), tb = TIP_PD(b0);
+        r.pa0 = ta.p; r.da0 = ta.d; r.pb0 = tb.p; r.db0 = tb.d;
       }
       if (pfab >> 16) {
-        r.pa1 = TIP_IMAGE(a1, kImgP); r.da1 = TIP_IMAGE(a1, kImgDP);
-        r.pb1 = TIP_IMAGE(b1, kImgP); r.db1 = TIP_IMAGE(b1, kImgDP);
+        const PdPair ta = TIP_PD(a1), tb = TIP_PD(b1);
+        r.pa1 = ta.p; r.da1 = ta.d; r.pb1 = tb.p; r.db1 = tb.d;
       }
 #else
-      r.pa0 = TIP_IMAGE(a0, kImgP); r.da0 = TIP_IMAGE(a0, kImgDP);
-      r.pb0 = TIP_IMAGE(b0, kImgP); r.db0 = TIP_IMAGE(b0, kImgDP);
-      r.pa1 = TIP_IMAGE(a1, kImgP); r.da1 = TIP_IMAGE(a1, kImgDP);
-      r.pb1 = TIP_IMAGE(b1, kImgP); r.db1 = TIP_IMAGE(b1, kImgDP);
+      const PdPair ta0 = TIP_PD(a0), tb0 = TIP_PD(b0), ta1 = TIP_PD(a1), tb1 = TIP_PD(b1);
+      r.pa0 = ta0.p; r.da0 = ta0.d; r.pb0 = tb0.p; r.db0 = tb0.d;
+      r.pa1 = ta1.p; r.da1 = ta1.d; r.pb1 = tb1.p; r.db1 = tb1.d;
 #endif
     };
     StepWords D0 = StepFetch(pre_tab), D1 = StepFetch(pre_tab + 1), D2;
@@ -712,8 +718,11 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, const StepDesc* __
   }
 #undef TIP_AT
 #undef CELL_AT
-#undef IMAGE_AT
-#undef TIP_IMAGE
+#undef IMAGE_P
+#undef IMAGE_PD
+#undef IMAGE_PT
+#undef TIP_P
+#undef TIP_PD
 #undef KIND_DISPATCH
 
   // ---------------- workgroup sums, fixed order -----------------------------

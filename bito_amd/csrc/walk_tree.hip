@@ -129,7 +129,7 @@ walk_tree_kernel(BatchDims d, int tiles, int tiles_per_block, int blocks_per_tre
   // stage the tree's P and dP images (the global layout also carries P^T: skipped)
   for (int q = tid; q < NB * 128; q += W * 64) {
     const int br = q >> 7, r = q & 127;
-    lds[q] = gimg[(size_t)br * kImgStride + r];
+    lds[q] = gimg[(size_t)br * kImgStride + (r < 64 ? 2 * r : 2 * (r - 64) + 1)];  // global layout: (P, dP) pairs per lane
   }
   const double pi_st = tm->pi[st];
   const double w_cat = tm->cat_weight[cat];
