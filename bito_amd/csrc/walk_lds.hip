@@ -406,15 +406,15 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, const StepDesc* __
 #define TIP_AT(off, g) tip_b[(off) + (g) * PG]
 #define CELL_AT(off, g) (*reinterpret_cast<double*>(arena_b + (off) + (g) * 512))
   // Children are in ascending id order, so a tip never follows an internal node: the second child of a
-  // step is a stored cell or a cherry unless both children are tips (the root of a three-taxon tree).
+  // step is a stored cell or a cherry (a node over two tips is itself a cherry and has no step, the root
+  // of a tree with at least three taxa always has an internal child).
 #define KIND_DISPATCH(flags_, ...)                                                        \
   {                                                                                       \
     const unsigned f_ = (flags_);                                                         \
     using I0 = std::integral_constant<int, 0>;                                            \
     using I1 = std::integral_constant<int, 1>;                                            \
     using I2 = std::integral_constant<int, 2>;                                            \
-    if (f_ & kFlagTip1) step(I0{}, I0{}, __VA_ARGS__);                                    \
-    else if (f_ & kFlagCherry1) {                                                         \
+    if (f_ & kFlagCherry1) {                                                              \
       if (f_ & kFlagTip0) step(I0{}, I2{}, __VA_ARGS__);                                  \
       else if (f_ & kFlagCherry0) step(I2{}, I2{}, __VA_ARGS__);                          \
       else step(I1{}, I2{}, __VA_ARGS__);                                                 \
