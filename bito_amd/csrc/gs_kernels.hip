@@ -27,6 +27,9 @@
 #ifndef GS_WAVES
 #define GS_WAVES 2  // waves per SIMD the register allocation is held to
 #endif
+#ifndef GS_WG_WAVES
+#define GS_WG_WAVES 4  // waves (16-pattern tiles of one tree) per workgroup of the traversal kernel (8: measured slower)
+#endif
 
 namespace bito_amd {
 
@@ -559,9 +562,9 @@ struct GsImagePipe {
     const double* src = Image(entry) + tid * 2;
     double* dst = lds + buffer * 4096 + (tid & ~63) * 2;
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 512),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 512), 16, 0, 0);
+    for (int i = 0; i < 32 / GS_WG_WAVES; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (GS_WG_WAVES * 128)),
+                                       (__attribute__((address_space(3))) void*)(dst + i * (GS_WG_WAVES * 128)), 16, 0, 0);
   }
 
   __device__ __forceinline__ void Begin() {
@@ -608,7 +611,7 @@ struct GsImagePipe {
 };
 
 template <bool GRAD, bool RESCALE>
-__global__ void __launch_bounds__(256, GS_WAVES)
+__global__ void __launch_bounds__(GS_WG_WAVES * 64, GS_WAVES)
 gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_stride, int deriv_mode, const int32_t* __restrict__ children,
                const int32_t* __restrict__ sched, const double* __restrict__ imgs,
                const int32_t* __restrict__ model_index, const double* __restrict__ gs_model,
@@ -622,12 +625,12 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
   // pipeline) and stores nothing
   // Workgroups are dealt to the 8 XCDs round-robin by linear id: id % 8 picks the XCD.  All tile groups
   // of a tree get the same id % 8, so that a tree's images are fetched into one L2 only.
-  const int groups = (tiles + 3) / 4;
+  const int groups = (tiles + GS_WG_WAVES - 1) / GS_WG_WAVES;
   const int tree_local = (int)(blockIdx.x / 8 / groups) * 8 + (int)(blockIdx.x % 8);
   const int group = (int)(blockIdx.x / 8) % groups;
   if (tree_local >= chunk) return;
-  const bool active = group * 4 + wave < tiles;
-  const int tile = active ? group * 4 + wave : tiles - 1;
+  const bool active = group * GS_WG_WAVES + wave < tiles;
+  const int tile = active ? group * GS_WG_WAVES + wave : tiles - 1;
   const int tree = tree0 + tree_local;
   const int p = tile * 16 + pn;
   const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
@@ -855,7 +858,7 @@ size_t GsImageDoublesPerTree(const BatchDims& d) {
 void LaunchGsWalk(const BatchDims& d, int S, const DeviceBatch& b, const int32_t* model_index,
                   const double* gs_model, int tree0, int chunk, int tiles, int want_gradient, int rescaling,
                   int deriv_mode, hipStream_t stream) {
-  const dim3 grid((unsigned)((chunk + 7) / 8 * 8 * ((tiles + 3) / 4))), block(256);
+  const dim3 grid((unsigned)((chunk + 7) / 8 * 8 * ((tiles + GS_WG_WAVES - 1) / GS_WG_WAVES))), block(GS_WG_WAVES * 64);
   const size_t lds = 2 * 4096 * sizeof(double);
   const int stride = GsScheduleStride(d);
   auto launch = [&](auto kern) {
