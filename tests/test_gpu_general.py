@@ -236,3 +236,30 @@ def test_general_kernels_rooted_hky_eight_categories(data_dir):
     res = eng.gradients(pid, bl, params, rates=rates, rescaling=True)
     assert np.abs(res["log_likelihood"] - out["log_likelihood"]).max() < 1e-9
     assert (np.abs(res["branch_lengths"] - out["branch_lengths"]) / scale).max() < 1e-8
+
+
+def test_codon_full_size_batch_properties():
+    """BASELINE config 5 at the bench's batch size (1024 trees): properties that need no oracle.  A tree's
+    result does not depend on what else is in the batch (bitwise), runs are bit-reproducible (no atomics),
+    doubling every pattern weight doubles log-likelihoods and gradients exactly, and the first trees agree
+    with the CPU restatement."""
+    w = workloads.flua_codon(1024)
+    eng = bito_amd.Engine(spec(w.substitution, w.site), w.patterns, w.weights)
+    out = eng.gradients(w.parent_ids, w.branch_lengths, w.params)
+    again = eng.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert np.array_equal(out["log_likelihood"], again["log_likelihood"])
+    assert np.array_equal(out["branch_lengths"], again["branch_lengths"])
+    assert np.all(np.isfinite(out["log_likelihood"])) and np.all(np.isfinite(out["branch_lengths"]))
+    k = 37
+    pick = np.arange(1024 - k, 1024)
+    part = eng.gradients(w.parent_ids[pick], w.branch_lengths[pick], w.params[pick])
+    assert np.array_equal(part["log_likelihood"], out["log_likelihood"][pick])
+    assert np.array_equal(part["branch_lengths"], out["branch_lengths"][pick])
+    twice = bito_amd.Engine(spec(w.substitution, w.site), w.patterns, 2.0 * w.weights)
+    dbl = twice.gradients(w.parent_ids[:64], w.branch_lengths[:64], w.params[:64])
+    assert np.array_equal(dbl["log_likelihood"], 2.0 * out["log_likelihood"][:64])
+    assert np.array_equal(dbl["branch_lengths"], 2.0 * out["branch_lengths"][:64])
+    cpu = gs.GsOracleEngine("GY94", w.site, w.patterns, w.weights, 8)
+    ref = cpu.gradients(w.parent_ids[:8], w.branch_lengths[:8], w.params[:8])
+    assert ll_close(out["log_likelihood"][:8], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"][:8], ref["branch_lengths"])
