@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _capi, treeio
 from .engine import BitoAmdError, Engine, PhyloGradient, PhyloModelSpecification
-from .site_pattern import SitePattern
+from .site_pattern import CodonSitePattern, SitePattern
 
 
 # PhyloGradientFlagOptions of the reference all default to "on", stick-breaking included
@@ -121,7 +121,9 @@ class _GenericInstance:
             raise RuntimeError("Thread count needs to be strictly positive.")
         if not self._alignment:
             raise RuntimeError("Load an alignment into your instance before preparing for phylogenetic likelihood.")
-        site_pattern = SitePattern(self._alignment, self._taxon_names)
+        # the codon model reads the alignment three nucleotides at a time (states 0..60, 61 = gap)
+        pattern_type = CodonSitePattern if model_specification.substitution == "GY94" else SitePattern
+        site_pattern = pattern_type(self._alignment, self._taxon_names)
         if self._engine is not None:
             self._engine.close()
         self._engine = Engine(model_specification, site_pattern.patterns, site_pattern.weights,

@@ -263,3 +263,28 @@ def test_codon_full_size_batch_properties():
     ref = cpu.gradients(w.parent_ids[:8], w.branch_lengths[:8], w.params[:8])
     assert ll_close(out["log_likelihood"][:8], ref["log_likelihood"])
     assert grad_close(out["branch_lengths"][:8], ref["branch_lengths"])
+
+
+def test_instance_mirror_with_the_codon_model(data_dir):
+    """The pybind-name mirror (bito_amd/instance.py) on the codon model: an unrooted instance reads
+    DS1.fasta as codons when the model specification says GY94, same calls as for DNA."""
+    inst = bito_amd.unrooted_instance("ds1")
+    inst.read_nexus_file(os.path.join(data_dir, "DS1.subsampled_10.t"))
+    inst.read_fasta_file(os.path.join(data_dir, "DS1.fasta"))
+    inst.prepare_for_phylo_likelihood(bito_amd.PhyloModelSpecification("GY94", "weibull+2", "none"), 1)
+    blocks = inst.get_phylo_model_param_block_map()
+    blocks["substitution_model_frequencies"][:] = [0.3, 0.2, 0.25, 0.25]
+    blocks["substitution_model_rates"][:] = [2.0, 0.4]
+    blocks["Weibull_shape"][:] = 0.8
+    ll = inst.log_likelihoods()
+    grads = inst.phylo_gradients(flags=0)
+    from bito_amd.site_pattern import CodonSitePattern
+
+    sp = CodonSitePattern(treeio.read_fasta(os.path.join(data_dir, "DS1.fasta")), inst.taxon_names())
+    assert sp.patterns.max() <= 61 and sp.weights.sum() == 1949 // 3
+    cpu = gs.GsOracleEngine("GY94", "weibull+2", sp.patterns, sp.weights, 8)
+    pid = np.stack([t._parent_ids for t in inst.tree_collection.trees]).astype(np.int32)
+    bl = np.stack([np.asarray(t.branch_lengths) for t in inst.tree_collection.trees])
+    ref = cpu.gradients(pid, bl, inst.get_phylo_model_params())
+    assert ll_close(ll, ref["log_likelihood"])
+    assert grad_close(np.stack([g.gradient["branch_lengths"] for g in grads]), ref["branch_lengths"])
