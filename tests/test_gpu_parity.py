@@ -447,3 +447,65 @@ def test_beagle_shim_with_fatbeagle_call_sequence(data_dir, use_tip_states, resc
         assert ll_close(ll, ref["log_likelihood"][t])
         assert grad_close(grad, ref["branch_lengths"][t])
     drv.close()
+
+
+def _random_rooted_parent_ids(n, rng):
+    """Random rooted bifurcating topology with bito ids (leaves 0..n-1, internal ids in post-order)."""
+    import itertools
+
+    counter = itertools.count()
+    nodes = [("leaf", i) for i in range(n)]
+    rng.shuffle(nodes)
+    while len(nodes) > 1:
+        i, j = sorted(rng.choice(len(nodes), 2, replace=False))
+        b, a = nodes.pop(j), nodes.pop(i)
+        nodes.append(("node", a, b, next(counter)))
+    parents, next_id = {}, [n]
+
+    def walk(t):
+        if t[0] == "leaf":
+            return t[1]
+        kids = [walk(t[1]), walk(t[2])]
+        me = next_id[0]
+        next_id[0] += 1
+        for k in kids:
+            parents[k] = me
+        return me
+
+    root = walk(nodes[0])
+    assert root == 2 * n - 2
+    return np.array([parents[v] for v in range(2 * n - 2)], dtype=np.int32)
+
+
+@pytest.mark.parametrize("kernel", [_capi.KERNEL_LDS, _capi.KERNEL_HBM_ARENA])
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 12, 33])
+def test_random_shapes_rooted_and_unrooted(kernel, n):
+    """Random topologies of many shapes -- caterpillars to balanced trees, cherries as first or second
+    child, roots over a tip -- with gaps in the alignment, rooted and unrooted, 1, 2 and 4 categories:
+    the kernels that rebuild cherries and forward vectors in registers against the oracle."""
+    rng = np.random.default_rng(1000 + n)
+    P, T = 37, 9
+    patterns = rng.integers(0, 5, (n, P)).astype(np.int32)  # 4 = gap
+    weights = rng.integers(1, 5, P).astype(np.float64)
+    for site, C in (("constant", 1), ("weibull+2", 2), ("weibull+4", 4)):
+        for rooted in (False, True):
+            if rooted:
+                pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(T)])
+                M = 2 * n - 1
+            else:
+                pid = np.stack([workloads.random_unrooted_tree(n, rng, 0.1).parent_ids for _ in range(T)]).astype(np.int32)
+                M = 2 * n - 2
+            bl = rng.exponential(0.1, (T, M))
+            bl[:, -1] = 0.0
+            gpu, cpu = engines("GTR", site, "none", patterns, weights, 4)
+            gpu.set_kernel(kernel)
+            params = gpu.default_params(T)
+            params[:, :4] = rng.dirichlet([5, 5, 5, 5], T)
+            params[:, 4:10] = rng.dirichlet([3] * 6, T)
+            if C > 1:
+                params[:, 10] = rng.uniform(0.3, 2.0, T)
+            out = gpu.gradients(pid, bl, params)
+            ref = cpu.gradients(pid, bl, params)
+            assert ll_close(out["log_likelihood"], ref["log_likelihood"]), (site, rooted)
+            assert grad_close(out["branch_lengths"], ref["branch_lengths"]), (site, rooted)
+            assert ll_close(gpu.log_likelihoods(pid, bl, params), ref["log_likelihood"]), (site, rooted)
