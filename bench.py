@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--replicas", type=int, default=16, help="x100 DS1 topologies per GPU")
     ap.add_argument("--workload", choices=["ds1", "codon"], default="ds1",
                     help="ds1 = BASELINE config 3 (the headline metric); codon = config 5 (fluA as codons, GY94)")
-    ap.add_argument("--trees", type=int, default=1024, help="codon workload: trees per GPU")
+    ap.add_argument("--trees", type=int, default=4096, help="codon workload: trees per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 HBM arena, 2 LDS")

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 T=$1
-N=${2:-1024}
+N=${2:-4096}
 B="python3 $R/bench.py --workload codon --trees $N --steps 10 --warmup 2 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_stats -o s -- $B > $R/gpurun_out/${T}_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${T}_fetch -o f -- $B > $R/gpurun_out/${T}_fetch.log 2>&1
