@@ -58,6 +58,13 @@ struct bito_amd_engine {
   int n = 0, P = 0, Ppad = 0;
   uint64_t arena_limit = 0;
   hipStream_t stream = nullptr;
+  // Set-up pipeline of the LDS kernels: the set-up kernels of pass k+1 (topology, model, matrix images,
+  // step tables) run on prep_stream while pass k's traversal is still on `stream`; they write into the
+  // other of two buffer sets.  Events order the two streams: a set is not rewritten before the
+  // traversal that read it has finished, and a traversal does not start before its set is ready.
+  hipStream_t prep_stream = nullptr;
+  hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_walk_done[2] = {nullptr, nullptr};
+  unsigned run_counter = 0;
   std::string err;
   int kernel_choice = BITO_AMD_KERNEL_AUTO;
   std::string kernel_name = "none";
@@ -69,10 +76,10 @@ struct bito_amd_engine {
   bool resident = false;
   BatchDims dims{};
   bool has_rates = false;
-  DeviceBuffer<int32_t> parent_ids, children, sched;
+  DeviceBuffer<int32_t> parent_ids, children, sched, children2, sched2;
   DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
-      out_ll, out_grad, scale_arena;
-  DeviceBuffer<TreeModel> model;
+      out_ll, out_grad, scale_arena, branch2, images2;
+  DeviceBuffer<TreeModel> model, model2;
   DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
   DeviceBuffer<int32_t> gs_model_index;  // [T] first tree with the same parameter row
   // time-tree transforms (row f2): staging for host inputs, scratch and results
@@ -93,6 +100,12 @@ struct bito_amd_engine {
     part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
     tt_out.Free(); tt_aux.Free();
+    children2.Free(); sched2.Free(); branch2.Free(); images2.Free(); model2.Free();
+    for (int i = 0; i < 2; i++) {
+      if (ev_prep_done[i]) (void)hipEventDestroy(ev_prep_done[i]);
+      if (ev_walk_done[i]) (void)hipEventDestroy(ev_walk_done[i]);
+    }
+    if (prep_stream) (void)hipStreamDestroy(prep_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -276,7 +289,7 @@ int UploadModelIndex(bito_amd_engine* e, int tree_count, const double* params) {
   return BITO_AMD_OK;
 }
 
-DeviceBatch MakeBatch(bito_amd_engine* e) {
+DeviceBatch MakeBatch(bito_amd_engine* e, int set = 0) {
   DeviceBatch b{};
   b.parent_ids = e->parent_ids.ptr;
   b.branch_in = e->branch_in.ptr;
@@ -284,12 +297,12 @@ DeviceBatch MakeBatch(bito_amd_engine* e) {
   b.params = e->params.ptr;
   b.tip_states = e->tip_states.ptr;
   b.weights = e->weights.ptr;
-  b.children = e->children.ptr;
-  b.branch = e->branch.ptr;
-  b.model = e->model.ptr;
+  b.children = set ? e->children2.ptr : e->children.ptr;
+  b.branch = set ? e->branch2.ptr : e->branch.ptr;
+  b.model = set ? e->model2.ptr : e->model.ptr;
   b.mats = e->mats.ptr;
-  b.images = e->images.ptr;
-  b.sched = e->sched.ptr;
+  b.images = set ? e->images2.ptr : e->images.ptr;
+  b.sched = set ? e->sched2.ptr : e->sched.ptr;
   b.arena = e->arena.ptr;
   b.scale_arena = e->scale_arena.ptr;
   b.part_ll = e->part_ll.ptr;
@@ -319,14 +332,19 @@ int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int
     return Fail(e, BITO_AMD_ERR_STATE, "select the general-state kernels before uploading the batch");
   const int tiles = GsTiles(d.pattern_count);
   const size_t img_per_tree = GsImageDoublesPerTree(d), arena_per_tree = GsArenaDoublesPerTree(d, tiles, want_gradient);
+  HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
+  if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
+  // (Not pipelined like the LDS path: the traversal fills the register file -- two 256-VGPR waves per
+  // SIMD -- so set-up kernels of the next pass cannot co-reside with it; measured +2 % for twice the
+  // matrix records.)
+  // serial on `stream`, buffer set 0, trees in chunks sized to the budget
+  HIP_TRY(e, hipStreamSynchronize(e->prep_stream));
   const size_t per_tree = (img_per_tree + arena_per_tree) * sizeof(double);
   size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
   chunk = std::min<size_t>(chunk, 65535);
   HIP_TRY(e, e->gs_model.Reserve((size_t)T * kGsModelStride));
   HIP_TRY(e, e->images.Reserve(chunk * img_per_tree));
   HIP_TRY(e, e->arena.Reserve(chunk * arena_per_tree));
-  HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
-  if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
   if (want_gradient && rescaling) HIP_TRY(e, e->scale_arena.Reserve(chunk * (size_t)(d.taxon_count - 1) * tiles * 16));
   HIP_TRY(e, e->sched.Reserve((size_t)T * GsScheduleStride(d)));
   const DeviceBatch b = MakeBatch(e);
@@ -346,6 +364,7 @@ int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int
   }
   e->kernel_name = "gs_walk_kernel";
   LaunchReduce(d, b, tiles, want_gradient, e->stream);
+  HIP_TRY(e, hipEventRecord(e->ev_walk_done[0], e->stream));
   HIP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
 }
@@ -384,12 +403,17 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
   if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
   if (use_tree || use_lds) {
-    HIP_TRY(e, e->images.Reserve((size_t)T * NB * kImgStride));
-    if (use_lds) HIP_TRY(e, e->sched.Reserve(LdsScheduleInts(d)));
-    const DeviceBatch b = MakeBatch(e);
-    LaunchSetup(d, e->spec, b, want_gradient, e->stream);
-    LaunchMatrixImages(d, b, want_gradient, deriv_mode, e->stream);
-    if (use_lds) LaunchLdsSchedule(d, b, plan, e->stream);
+    // pipelined: this pass's set-up goes to prep_stream and into buffer set (run_counter & 1)
+    const int set = (int)(e->run_counter++ & 1u);
+    HIP_TRY(e, (set ? e->images2 : e->images).Reserve((size_t)T * NB * kImgStride));
+    if (use_lds) HIP_TRY(e, (set ? e->sched2 : e->sched).Reserve(LdsScheduleInts(d)));
+    const DeviceBatch b = MakeBatch(e, set);
+    HIP_TRY(e, hipStreamWaitEvent(e->prep_stream, e->ev_walk_done[set], 0));
+    LaunchSetup(d, e->spec, b, want_gradient, e->prep_stream);
+    LaunchMatrixImages(d, b, want_gradient, deriv_mode, e->prep_stream);
+    if (use_lds) LaunchLdsSchedule(d, b, plan, e->prep_stream);
+    HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], e->prep_stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_prep_done[set], 0));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing) {
       ev0 = NextEvent(e);
@@ -401,9 +425,12 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
     e->kernel_name = use_tree ? "walk_tree_kernel" : "walk_lds_kernel";
     LaunchReduce(d, b, tiles, want_gradient, e->stream);
+    HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
     HIP_TRY(e, hipGetLastError());
     return BITO_AMD_OK;
   }
+  // the paths below are serial on `stream` and use buffer set 0: let the set-up stream drain first
+  HIP_TRY(e, hipStreamSynchronize(e->prep_stream));
   // scratch sized for this run
   HIP_TRY(e, e->mats.Reserve((size_t)T * NB * d.category_count * kMatStride));
   const size_t per_tree = HbmArenaBytesPerTree(d);
@@ -429,6 +456,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   }
   e->kernel_name = WalkHbmKernelName(d.category_count, want_gradient, rescaling);
   LaunchReduce(d, b, tiles, want_gradient, e->stream);
+  HIP_TRY(e, hipEventRecord(e->ev_walk_done[0], e->stream));
   HIP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
 }
@@ -492,6 +520,13 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
   if ((hrc = hipSetDevice(e->device)) != hipSuccess) return dev_fail("hipSetDevice", hrc);
   if ((hrc = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
     return dev_fail("hipStreamCreate", hrc);
+  if ((hrc = hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking)) != hipSuccess)
+    return dev_fail("hipStreamCreate", hrc);
+  for (int i = 0; i < 2; i++) {
+    if ((hrc = hipEventCreateWithFlags(&e->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess ||
+        (hrc = hipEventCreateWithFlags(&e->ev_walk_done[i], hipEventDisableTiming)) != hipSuccess)
+      return dev_fail("hipEventCreate", hrc);
+  }
   e->n = taxon_count;
   e->P = pattern_count;
   // padded so that every kernel's last tile (at most 512 patterns wide) stays in bounds
@@ -554,6 +589,9 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   if (rc) return rc;
   if (params && (rc = ValidateParams(e, tree_count, params))) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
+  // a set-up kernel of an earlier, still running pass may be reading the input buffers
+  HIP_TRY(e, hipStreamSynchronize(e->prep_stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
   const int n = e->n, N = 2 * n - 1, M = node_count, C = e->spec.category_count;
   const size_t T = tree_count;
   const int pc = std::max(e->spec.param_count, 1);
@@ -563,6 +601,9 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   HIP_TRY(e, e->children.Reserve(T * (n - 1) * 2));
   HIP_TRY(e, e->branch.Reserve(T * N));
   HIP_TRY(e, e->model.Reserve(T));
+  HIP_TRY(e, e->children2.Reserve(T * (n - 1) * 2));
+  HIP_TRY(e, e->branch2.Reserve(T * N));
+  HIP_TRY(e, e->model2.Reserve(T));
   HIP_TRY(e, e->out_ll.Reserve(T));
   HIP_TRY(e, e->out_grad.Reserve(T * N));
   HIP_TRY(e, hipMemcpyAsync(e->parent_ids.ptr, parent_ids, T * (M - 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
@@ -596,6 +637,7 @@ int bito_amd_engine_update(bito_amd_engine* e, const double* branch_lengths, con
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
   HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipStreamSynchronize(e->prep_stream));  // (see bito_amd_engine_upload)
   const size_t T = e->dims.tree_count;
   if (params && e->spec.param_count > 0) {
     int rc = ValidateParams(e, (int)T, params);
@@ -1007,14 +1049,15 @@ int bito_amd_engine_kernel_elapsed(bito_amd_engine* e, double* kernel_ms, int32_
 
 int bito_amd_engine_read_general_model(bito_amd_engine* e, int32_t tree, double* out, size_t capacity) {
   if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
-  if (!e->resident || tree < 0 || tree >= e->dims.tree_count || !e->gs_model.ptr || !e->gs_model_index.ptr)
+  const double* gs_model = e->gs_model.ptr;
+  if (!e->resident || tree < 0 || tree >= e->dims.tree_count || !gs_model || !e->gs_model_index.ptr)
     return Fail(e, BITO_AMD_ERR_STATE, "no general-state model is resident for that tree");
   HIP_TRY(e, hipSetDevice(e->device));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   const size_t count = std::min<size_t>(capacity, (size_t)kGsModelStride);
   int32_t slot = tree;
   HIP_TRY(e, hipMemcpy(&slot, e->gs_model_index.ptr + tree, sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(e, hipMemcpy(out, e->gs_model.ptr + (size_t)slot * kGsModelStride, count * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(e, hipMemcpy(out, gs_model + (size_t)slot * kGsModelStride, count * sizeof(double), hipMemcpyDeviceToHost));
   return BITO_AMD_OK;
 }
 
