@@ -394,7 +394,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
       break;
     default: break;
   }
-  // Measured on config 3 (profiles/): walk_lds_kernel 2.81 ms, walk_tree_kernel 3.79 ms per 1600
+  // Measured on config 3 (profiles/): walk_lds_kernel 2.1 ms, walk_tree_kernel 3.8 ms per 1600
   // trees -- the single-wave software pipeline beats two latency-bound waves per SIMD, so the
   // tree-resident variant is only used when forced or when walk_lds cannot run.
   if (e->kernel_choice != BITO_AMD_KERNEL_LDS_TREE && use_lds) use_tree = false;
