@@ -78,7 +78,8 @@ struct bito_amd_engine {
   bool has_rates = false;
   DeviceBuffer<int32_t> parent_ids, children, sched, children2, sched2;
   DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
-      out_ll, out_grad, scale_arena, branch2, images2;
+      out_ll, out_grad, out_site, scale_arena, branch2, images2;
+  bool site_ready = false;  // out_site holds the site-model gradient of the resident pass
   DeviceBuffer<TreeModel> model, model2;
   DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
   DeviceBuffer<int32_t> gs_model_index;  // [T] first tree with the same parameter row
@@ -100,7 +101,7 @@ struct bito_amd_engine {
     part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
     tt_out.Free(); tt_aux.Free();
-    children2.Free(); sched2.Free(); branch2.Free(); images2.Free(); model2.Free();
+    children2.Free(); sched2.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
     for (int i = 0; i < 2; i++) {
       if (ev_prep_done[i]) (void)hipEventDestroy(ev_prep_done[i]);
       if (ev_walk_done[i]) (void)hipEventDestroy(ev_walk_done[i]);
@@ -309,6 +310,7 @@ DeviceBatch MakeBatch(bito_amd_engine* e, int set = 0) {
   b.part_grad = e->part_grad.ptr;
   b.out_ll = e->out_ll.ptr;
   b.out_grad = e->out_grad.ptr;
+  b.out_site = e->out_site.ptr;
   return b;
 }
 
@@ -326,6 +328,7 @@ hipEvent_t NextEvent(bito_amd_engine* e) {
 // matrix records and PLV arena fit the arena budget.
 int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_mode) {
   HIP_TRY(e, hipSetDevice(e->device));
+  e->site_ready = false;
   const BatchDims& d = e->dims;
   const int T = d.tree_count, S = e->spec.state_count;
   if (e->gs_model_index.capacity < (size_t)T)
@@ -369,7 +372,7 @@ int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int
   return BITO_AMD_OK;
 }
 
-int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_mode = 0) {
+int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_mode = 0, int want_site = 0) {
   if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
   HIP_TRY(e, hipSetDevice(e->device));
   const BatchDims& d = e->dims;
@@ -421,9 +424,10 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
       HIP_TRY(e, hipEventRecord(ev0, e->stream));
     }
     if (use_tree) LaunchWalkTree(d, b, tplan, want_gradient, e->stream);
-    else LaunchWalkLds(d, b, plan, want_gradient, e->stream);
+    else LaunchWalkLds(d, b, plan, want_gradient, want_site && want_gradient && deriv_mode == 0, e->stream);
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
     e->kernel_name = use_tree ? "walk_tree_kernel" : "walk_lds_kernel";
+    e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
     LaunchReduce(d, b, tiles, want_gradient, e->stream);
     HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
     HIP_TRY(e, hipGetLastError());
@@ -431,6 +435,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   }
   // the paths below are serial on `stream` and use buffer set 0: let the set-up stream drain first
   HIP_TRY(e, hipStreamSynchronize(e->prep_stream));
+  e->site_ready = false;
   // scratch sized for this run
   HIP_TRY(e, e->mats.Reserve((size_t)T * NB * d.category_count * kMatStride));
   const size_t per_tree = HbmArenaBytesPerTree(d);
@@ -606,6 +611,7 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   HIP_TRY(e, e->model2.Reserve(T));
   HIP_TRY(e, e->out_ll.Reserve(T));
   HIP_TRY(e, e->out_grad.Reserve(T * N));
+  HIP_TRY(e, e->out_site.Reserve(T));
   HIP_TRY(e, hipMemcpyAsync(e->parent_ids.ptr, parent_ids, T * (M - 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * M * sizeof(double), hipMemcpyHostToDevice, e->stream));
   if (e->spec.param_count > 0)
@@ -776,10 +782,15 @@ int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t ro
   }
   rc = bito_amd_engine_upload(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params);
   if (rc) return rc;
-  if ((rc = RunResident(e, 1, rescaling != 0))) return rc;
+  const int want_site = (flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && e->spec.category_count > 1;
+  if ((rc = RunResident(e, 1, rescaling != 0, /*deriv_mode=*/0, want_site))) return rc;
   if ((rc = bito_amd_engine_download(e, out_ll, out_branch))) return rc;
   const int N = 2 * e->n - 1;
-  if ((flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && e->spec.category_count > 1) {
+  if ((flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && e->spec.category_count > 1 && e->site_ready) {
+    // the LDS traversal produced it in the same pass (per-category edge sums, see walk_lds_kernel)
+    HIP_TRY(e, hipMemcpyAsync(out_site, e->out_site.ptr, (size_t)tree_count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  } else if ((flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && e->spec.category_count > 1) {
     // second gradient pass with dQ = Q * d r_c / d shape, then sum_b g_b t_b over the
     // effective branch lengths (DiscreteSiteModelGradient, reference src/fat_beagle.cpp:401-410,538-550)
     if ((rc = RunResident(e, 1, rescaling != 0, /*deriv_mode=*/1))) return rc;

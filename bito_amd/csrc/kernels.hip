@@ -554,6 +554,9 @@ reduce_tiles_kernel(BatchDims d, DeviceBatch b, int tiles, int want_gradient) {
   }
   double s = 0.0;
   for (int k = 0; k < tiles; k++) s += b.part_grad[((size_t)t * tiles + k) * N + e];
+  // The root's slot carries the site-model gradient of kernels that produce it in the same pass
+  // (walk_lds_kernel); other kernels leave 0 there.
+  if (e == N - 1 && b.out_site != nullptr) b.out_site[t] = s;
   // Root has no branch; for unrooted trees the node that re-uses the old root id
   // is the fixed node whose gradient is pinned to 0 (reference fat_beagle.cpp:148,553).
   if (e == N - 1 || (!d.rooted && e == N - 2)) s = 0.0;

@@ -62,6 +62,7 @@ struct DeviceBatch {
   double* part_grad;          // [T][tiles][N]
   double* out_ll;             // [T]
   double* out_grad;           // [T][N]
+  double* out_site;           // [T] site-model gradient, when the traversal kernel produces it (else unused)
 };
 
 // Topology set-up of one tree, shared by the 4-state and the general-state set-up kernels:
@@ -133,7 +134,8 @@ struct LdsPlan {
 LdsPlan PlanLds(const BatchDims& d);
 size_t LdsScheduleInts(const BatchDims& d);
 void LaunchLdsSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream);
-void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
+// want_site: also produce the site-model gradient (per-tile value in the root's slot of part_grad)
+void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient, int want_site,
                    hipStream_t stream);
 
 // LDS-resident traversal, second generation (walk_tree.hip): 8 waves per workgroup (two per

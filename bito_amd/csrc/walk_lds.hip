@@ -282,10 +282,10 @@ struct alignas(16) PdPair { double p, d; };  // one lane's P and dP entries of a
 
 template <int C, int G, bool GRAD>
 __global__ void __launch_bounds__(kLdsWaves * 64, LDS_WAVES_PER_EU)
-walk_lds_kernel(BatchDims d, int tiles, int units, int slots, const StepDesc* __restrict__ sched,
+walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, const StepDesc* __restrict__ sched,
                 const double* __restrict__ images, const TreeModel* __restrict__ models,
                 const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
-                double* __restrict__ part_ll, double* __restrict__ part_grad) {
+                const double* __restrict__ branch, double* __restrict__ part_ll, double* __restrict__ part_grad) {
   extern __shared__ double lds[];
   constexpr int PG = 16 / C;                  // patterns per group
   constexpr int PB = kLdsWaves * G * PG;      // patterns per workgroup
@@ -737,11 +737,36 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, const StepDesc* __
     part_ll[(size_t)tree * tiles + tile] = s;
   }
   if (GRAD) {
+    // The rows are still separate per block, i.e. per rate category: the site-model gradient
+    // (DiscreteSiteModelGradient, fat_beagle.cpp:401-410,538-550 -- the same edge sums with r_c replaced by
+    // d r_c / d shape, times the branch lengths) is the same data weighted by (d r_c / d shape) / r_c, so
+    // it needs no second traversal.  Its per-tile value travels in the root's slot of the gradient row
+    // (the root has no branch; the reduce kernel moves it to out_site and writes the 0).
     double* out = part_grad + ((size_t)tree * tiles + tile) * N;
     for (int e = tid; e < N; e += kLdsWaves * 64) {
       double s = 0.0;
       for (int w = 0; w < kLdsWaves * 4; w++) s += grad_rows[w * N + e];
       out[e] = s;
+    }
+    if (want_site) {  // (only when the caller asked for the site-model gradient)
+      double ratio[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) ratio[c] = tm->cat_rate_deriv[c] / tm->cat_rate[c];
+      double site_acc = 0.0;
+      for (int e = tid; e < N; e += kLdsWaves * 64) {
+        double sr = 0.0;
+        for (int w = 0; w < kLdsWaves * 4; w++) sr += grad_rows[w * N + e] * ratio[(w & 3) % C];
+        site_acc += sr * branch[(size_t)tree * N + e];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) site_acc += __shfl_xor(site_acc, o);
+      if (lane == 0) ll_slots[kLdsWaves + wave] = site_acc;
+      __syncthreads();
+      if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < kLdsWaves; w++) s += ll_slots[kLdsWaves + w];
+        out[N - 1] = s;
+      }
     }
   }
 }
@@ -757,7 +782,7 @@ static size_t LdsBytes(const BatchDims& d, int G) {
   const int PG = 16 / d.category_count, PB = kLdsWaves * G * PG, n = d.taxon_count;
   const size_t arena = (size_t)kLdsWaves * LdsSlots(d) * G * 64;
   const size_t tips = ((size_t)n * PB + 7) / 8;
-  return (arena + tips + (size_t)kLdsWaves * 4 * d.node_count + kLdsWaves) * sizeof(double);
+  return (arena + tips + (size_t)kLdsWaves * 4 * d.node_count + 2 * kLdsWaves) * sizeof(double);
 }
 
 LdsPlan PlanLds(const BatchDims& d) {
@@ -784,27 +809,27 @@ LdsPlan PlanLds(const BatchDims& d) {
 
 template <int C, int G>
 static void LaunchWalkLdsCG(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
-                            hipStream_t stream) {
+                            int want_site, hipStream_t stream) {
   const int units = d.tree_count * plan.tiles;
   const dim3 grid(units), block(kLdsWaves * 64);
   const StepDesc* sched = reinterpret_cast<const StepDesc*>(b.sched);
   auto kern = want_gradient ? walk_lds_kernel<C, G, true> : walk_lds_kernel<C, G, false>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsBudget);
-  hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, LdsSlots(d), sched, b.images, b.model,
-                     b.tip_states, b.weights, b.part_ll, b.part_grad);
+  hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, LdsSlots(d), want_site, sched, b.images, b.model,
+                     b.tip_states, b.weights, b.branch, b.part_ll, b.part_grad);
 }
 
 template <int C>
 static void LaunchWalkLdsC(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
-                           hipStream_t stream) {
+                           int want_site, hipStream_t stream) {
   switch (plan.groups) {
-    case 1: LaunchWalkLdsCG<C, 1>(d, b, plan, want_gradient, stream); break;
-    case 2: LaunchWalkLdsCG<C, 2>(d, b, plan, want_gradient, stream); break;
-    case 3: LaunchWalkLdsCG<C, 3>(d, b, plan, want_gradient, stream); break;
-    case 4: LaunchWalkLdsCG<C, 4>(d, b, plan, want_gradient, stream); break;
-    case 6: LaunchWalkLdsCG<C, 6>(d, b, plan, want_gradient, stream); break;
-    case 8: LaunchWalkLdsCG<C, 8>(d, b, plan, want_gradient, stream); break;
+    case 1: LaunchWalkLdsCG<C, 1>(d, b, plan, want_gradient, want_site, stream); break;
+    case 2: LaunchWalkLdsCG<C, 2>(d, b, plan, want_gradient, want_site, stream); break;
+    case 3: LaunchWalkLdsCG<C, 3>(d, b, plan, want_gradient, want_site, stream); break;
+    case 4: LaunchWalkLdsCG<C, 4>(d, b, plan, want_gradient, want_site, stream); break;
+    case 6: LaunchWalkLdsCG<C, 6>(d, b, plan, want_gradient, want_site, stream); break;
+    case 8: LaunchWalkLdsCG<C, 8>(d, b, plan, want_gradient, want_site, stream); break;
     default: break;
   }
 }
@@ -816,12 +841,12 @@ void LaunchLdsSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& 
                      plan.patterns_per_block, b.children, reinterpret_cast<StepDesc*>(b.sched));
 }
 
-void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
+void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient, int want_site,
                    hipStream_t stream) {
   switch (d.category_count) {
-    case 1: LaunchWalkLdsC<1>(d, b, plan, want_gradient, stream); break;
-    case 2: LaunchWalkLdsC<2>(d, b, plan, want_gradient, stream); break;
-    case 4: LaunchWalkLdsC<4>(d, b, plan, want_gradient, stream); break;
+    case 1: LaunchWalkLdsC<1>(d, b, plan, want_gradient, want_site, stream); break;
+    case 2: LaunchWalkLdsC<2>(d, b, plan, want_gradient, want_site, stream); break;
+    case 4: LaunchWalkLdsC<4>(d, b, plan, want_gradient, want_site, stream); break;
     default: break;
   }
 }

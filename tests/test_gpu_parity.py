@@ -509,3 +509,23 @@ def test_random_shapes_rooted_and_unrooted(kernel, n):
             assert ll_close(out["log_likelihood"], ref["log_likelihood"]), (site, rooted)
             assert grad_close(out["branch_lengths"], ref["branch_lengths"]), (site, rooted)
             assert ll_close(gpu.log_likelihoods(pid, bl, params), ref["log_likelihood"]), (site, rooted)
+
+
+def test_site_model_gradient_fused_equals_second_pass():
+    """The LDS traversal yields the site-model gradient in the same pass (per-category edge sums weighted by
+    (d r_c / d shape) / r_c); the other kernels run FatBeagle's second traversal with the rate derivatives
+    (src/fat_beagle.cpp:538-550).  Same numbers, and the oracle's."""
+    w = workloads.ds1_gtr_weibull4(1).subset(9)
+    gpu, cpu = engines(w.substitution, w.site, "none", w.patterns, w.weights, 4)
+    params = w.params.copy()
+    params[:, 10] = np.linspace(0.3, 1.9, 9)
+    flags = _capi.GRAD_SITE_MODEL
+    fused = gpu.gradients(w.parent_ids, w.branch_lengths, params, flags=flags)
+    assert gpu.kernel_name() == "walk_lds_kernel"
+    gpu.set_kernel(_capi.KERNEL_HBM_ARENA)
+    twice = gpu.gradients(w.parent_ids, w.branch_lengths, params, flags=flags)
+    assert gpu.kernel_name() == "walk_hbm_kernel"
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, params, flags=oracle.GRAD_SITE_MODEL)
+    assert grad_close(fused["site_model"], ref["site_model"])
+    assert grad_close(twice["site_model"], ref["site_model"])
+    assert grad_close(fused["branch_lengths"], ref["branch_lengths"])
