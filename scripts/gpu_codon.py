@@ -9,7 +9,12 @@ from oracle import gs
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 site = sys.argv[2] if len(sys.argv) > 2 else "constant"
+distinct = len(sys.argv) > 3 and sys.argv[3] == "distinct"  # every tree its own kappa / omega: T eigensystems
 w = workloads.flua_codon(T, site)
+if distinct:
+    rng = np.random.default_rng(3)
+    w.params[:, 4] = rng.uniform(1.0, 4.0, T)
+    w.params[:, 5] = rng.uniform(0.1, 1.0, T)
 eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights)
 k = min(T, 4)
 cpu = gs.GsOracleEngine("GY94", site, w.patterns, w.weights, 8)
