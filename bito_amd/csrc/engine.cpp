@@ -404,7 +404,8 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   if (use_tree) use_lds = false;
   const int tiles = use_tree ? tplan.tiles : (use_lds ? plan.tiles : HbmTiles(d.pattern_count));
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
-  if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
+  const int grad_rows = (use_tree || use_lds) ? tiles : tiles * (kHbmBlock / 64);  // HBM kernel: a row per wave
+  if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * grad_rows * d.node_count));
   if (use_tree || use_lds) {
     // pipelined: this pass's set-up goes to prep_stream and into buffer set (run_counter & 1)
     const int set = (int)(e->run_counter++ & 1u);
@@ -460,7 +461,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
   }
   e->kernel_name = WalkHbmKernelName(d.category_count, want_gradient, rescaling);
-  LaunchReduce(d, b, tiles, want_gradient, e->stream);
+  LaunchReduce(d, b, tiles, want_gradient, e->stream, grad_rows);
   HIP_TRY(e, hipEventRecord(e->ev_walk_done[0], e->stream));
   HIP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;

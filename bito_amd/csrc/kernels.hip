@@ -192,7 +192,7 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
                 const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
                 double* __restrict__ arena_base, double* __restrict__ scale_base,
                 double* __restrict__ part_ll, double* __restrict__ part_grad) {
-  extern __shared__ double lds[];  // [waves][N] gradient rows, then [waves] log-likelihoods
+  extern __shared__ double lds[];  // [waves] log-likelihoods
   constexpr int kWaves = kHbmBlock / 64;
   const int n = d.taxon_count, N = d.node_count, NI = n - 1, Ppad = d.pattern_stride;
   const int tree = tree0 + blockIdx.y;
@@ -211,10 +211,6 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
   double* __restrict__ inv_scale = scale_base + ((size_t)blockIdx.y * tile_count + blockIdx.x) * NI * kHbmBlock + tid;
   const double weight = weights[p];
 
-  if (GRAD) {
-    for (int k = tid; k < kWaves * N; k += kHbmBlock) lds[k] = 0.0;
-    __syncthreads();
-  }
 
   // A child of a step is a tip, a stored internal node, or a CHERRY (internal node over two tips).
   // Cherries are never stored: their post-order partial is the product of two tip look-ups,
@@ -346,7 +342,9 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
 
   // ---- pre-order + edge derivatives ---------------------------------------
   if (GRAD) {
-    double* my_row = lds + wave * N;
+    // one gradient row per wave, straight in global memory (summed by the reduce kernel in a fixed order): rows
+    // in LDS would cost 4 N doubles per workgroup -- 64 KB at a thousand taxa, i.e. two workgroups per CU
+    double* __restrict__ my_row = part_grad + (((size_t)tree * gridDim.x + blockIdx.x) * kWaves + wave) * N;
     for (int node = N - 1; node >= n; --node) {
       const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
       const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
@@ -474,7 +472,7 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
 
   // ---- block-level sums, fixed order --------------------------------------
   const double wll = WaveSum(ll);
-  double* ll_slots = lds + kWaves * N;
+  double* ll_slots = lds;
   if (lane == 0) ll_slots[wave] = wll;
   __syncthreads();
   const int tiles = gridDim.x;
@@ -482,14 +480,6 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
     double s = 0.0;
     for (int w = 0; w < kWaves; w++) s += ll_slots[w];
     part_ll[(size_t)tree * tiles + blockIdx.x] = s;
-  }
-  if (GRAD) {
-    double* out = part_grad + ((size_t)tree * tiles + blockIdx.x) * N;
-    for (int e = tid; e < N; e += kHbmBlock) {
-      double s = 0.0;
-      for (int w = 0; w < kWaves; w++) s += lds[w * N + e];
-      out[e] = s;
-    }
   }
 }
 
@@ -501,7 +491,7 @@ template <int C>
 static void LaunchWalkHbmC(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk,
                            int want_gradient, int rescaling, hipStream_t stream) {
   const dim3 grid(HbmTiles(d.pattern_count), chunk), block(kHbmBlock);
-  const size_t lds = ((size_t)(kHbmBlock / 64) * d.node_count + kHbmBlock / 64) * sizeof(double);
+  const size_t lds = (size_t)(kHbmBlock / 64) * sizeof(double);
   if (want_gradient) {
     if (rescaling)
       hipLaunchKernelGGL((walk_hbm_kernel<C, true, true>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model,
@@ -540,7 +530,7 @@ const char* WalkHbmKernelName(int, int, int) { return "walk_hbm_kernel"; }
 // Final per-tree sums over pattern tiles, fixed order.
 
 __global__ void __launch_bounds__(256)
-reduce_tiles_kernel(BatchDims d, DeviceBatch b, int tiles, int want_gradient) {
+reduce_tiles_kernel(BatchDims d, DeviceBatch b, int tiles, int grad_rows, int want_gradient) {
   const int N = d.node_count;
   const int per_tree = want_gradient ? N + 1 : 1;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -553,7 +543,7 @@ reduce_tiles_kernel(BatchDims d, DeviceBatch b, int tiles, int want_gradient) {
     return;
   }
   double s = 0.0;
-  for (int k = 0; k < tiles; k++) s += b.part_grad[((size_t)t * tiles + k) * N + e];
+  for (int k = 0; k < grad_rows; k++) s += b.part_grad[((size_t)t * grad_rows + k) * N + e];
   // The root's slot carries the site-model gradient of kernels that produce it in the same pass
   // (walk_lds_kernel); other kernels leave 0 there.
   if (e == N - 1 && b.out_site != nullptr) b.out_site[t] = s;
@@ -564,10 +554,11 @@ reduce_tiles_kernel(BatchDims d, DeviceBatch b, int tiles, int want_gradient) {
 }
 
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
-                  hipStream_t stream) {
+                  hipStream_t stream, int grad_rows) {
+  if (grad_rows <= 0) grad_rows = tiles;
   const size_t total = (size_t)d.tree_count * (want_gradient ? d.node_count + 1 : 1);
   const int blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(reduce_tiles_kernel, dim3(blocks), dim3(256), 0, stream, d, b, tiles,
+  hipLaunchKernelGGL(reduce_tiles_kernel, dim3(blocks), dim3(256), 0, stream, d, b, tiles, grad_rows,
                      want_gradient);
 }
 

@@ -59,7 +59,7 @@ struct DeviceBatch {
   double* arena;              // [chunk][n-1][C][4][Ppad]
   double* scale_arena;        // [chunk][n-1][Ppad]  post-order 1/scale factors (rescaled gradients)
   double* part_ll;            // [T][tiles]
-  double* part_grad;          // [T][tiles][N]
+  double* part_grad;          // [T][tiles][N]  (HBM-arena kernel: [T][tiles][4 waves][N])
   double* out_ll;             // [T]
   double* out_grad;           // [T][N]
   double* out_site;           // [T] site-model gradient, when the traversal kernel produces it (else unused)
@@ -160,8 +160,9 @@ void LaunchWalkHbm(const BatchDims& d, const DeviceBatch& b, int tree0, int chun
                    int want_gradient, int rescaling, hipStream_t stream);
 const char* WalkHbmKernelName(int category_count, int want_gradient, int rescaling);
 
+// grad_rows: partial gradient rows per tree (default: one per tile; the HBM-arena kernel writes one per wave)
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
-                  hipStream_t stream);
+                  hipStream_t stream, int grad_rows = 0);
 
 // ---- general-state-count path (gs_kernels.hip): the 61-state codon model, states padded to 64 ----
 // Per-model record, doubles: V [64][64], V^-1 [64][64], Q [64][64], lambda [64], pi [64] (padding 0),
