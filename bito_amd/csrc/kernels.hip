@@ -350,6 +350,12 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
     // one gradient row per wave, straight in global memory (summed by the reduce kernel in a fixed order): rows
     // in LDS would cost 4 N doubles per workgroup -- 64 KB at a thousand taxa, i.e. two workgroups per CU
     double* __restrict__ my_row = part_grad + (((size_t)tree * gridDim.x + blockIdx.x) * kWaves + wave) * N;
+    // The pre-order partial of the child that is processed next (node - 1: ids are in post-order) is
+    // handed over through a thread-private LDS column instead of the HBM arena: one store and one load
+    // of a PLV less per such node.
+    constexpr bool kForward = C <= 4;                       // 32 KB of LDS per workgroup at C = 4
+    double* __restrict__ fwd = lds + kWaves + tid;          // [C][4][kHbmBlock]
+    bool u_forwarded = false;
     for (int node = N - 1; node >= n; --node) {
       const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
       const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
@@ -381,6 +387,9 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
         if (node == N - 1) {
 #pragma unroll
           for (int i = 0; i < 4; i++) U[i] = tm->pi[i];
+        } else if (kForward && u_forwarded) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) U[i] = fwd[(c * 4 + i) * kHbmBlock];
         } else {
 #pragma unroll
           for (int i = 0; i < 4; i++) U[i] = arena[((size_t)((node - n) * C + c) * 4 + i) * kHbmBlock];
@@ -436,21 +445,31 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
       const double step_inv = RESCALE ? inv_scale[(size_t)(node - n) * kHbmBlock] : 1.0;
       // In place, one category at a time: cell (child, c) is read (as the child's
       // post-order partial) before it is overwritten with its pre-order partial.
+      // (A forwarded partial takes LDS slot c after this node's own U, read from the same slot, is used.)
+      const bool fwd0 = kForward && k0.kind == 1 && c0 == node - 1;
+      const bool fwd1 = kForward && k1.kind == 1 && c1 == node - 1;
 #pragma unroll 1
       for (int c = 0; c < C; c++) {
         double q0[4], q1[4];
         category_step(c, q0, q1);
         if (k0.kind == 1) {
 #pragma unroll
-          for (int i = 0; i < 4; i++)
-            arena[((size_t)((c0 - n) * C + c) * 4 + i) * kHbmBlock] = RESCALE ? q0[i] * step_inv : q0[i];
+          for (int i = 0; i < 4; i++) {
+            const double v = RESCALE ? q0[i] * step_inv : q0[i];
+            if (fwd0) fwd[(c * 4 + i) * kHbmBlock] = v;
+            else arena[((size_t)((c0 - n) * C + c) * 4 + i) * kHbmBlock] = v;
+          }
         }
         if (k1.kind == 1) {
 #pragma unroll
-          for (int i = 0; i < 4; i++)
-            arena[((size_t)((c1 - n) * C + c) * 4 + i) * kHbmBlock] = RESCALE ? q1[i] * step_inv : q1[i];
+          for (int i = 0; i < 4; i++) {
+            const double v = RESCALE ? q1[i] * step_inv : q1[i];
+            if (fwd1) fwd[(c * 4 + i) * kHbmBlock] = v;
+            else arena[((size_t)((c1 - n) * C + c) * 4 + i) * kHbmBlock] = v;
+          }
         }
       }
+      u_forwarded = fwd0 || fwd1;
       const double scale = weight / den;
       const double g0 = WaveSum(num0 * scale);
       const double g1 = WaveSum(num1 * scale);
@@ -496,7 +515,8 @@ template <int C>
 static void LaunchWalkHbmC(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk,
                            int want_gradient, int rescaling, hipStream_t stream) {
   const dim3 grid(HbmTiles(d.pattern_count), chunk), block(kHbmBlock);
-  const size_t lds = (size_t)(kHbmBlock / 64) * sizeof(double);
+  // log-likelihood slots, and (gradients, up to four categories) the pre-order forwarding columns
+  const size_t lds = ((size_t)(kHbmBlock / 64) + (want_gradient && C <= 4 ? (size_t)C * 4 * kHbmBlock : 0)) * sizeof(double);
   if (want_gradient) {
     if (rescaling)
       hipLaunchKernelGGL((walk_hbm_kernel<C, true, true>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model,
