@@ -41,6 +41,50 @@ setup_trees_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
   SetupTreeModel(spec, b.params + (size_t)t * spec.param_count, &b.model[t]);
 }
 
+// Large trees: one workgroup per tree.  A bifurcating node's children in ascending id order are the
+// minimum and the maximum of its children's ids (integer atomics in LDS: the result does not depend on
+// the order of arrival); the trifurcating root of an unrooted tree also needs the middle one, sum - min - max.
+__global__ void __launch_bounds__(256)
+setup_large_trees_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
+  extern __shared__ int setup_ch[];  // [NI][2] min / max, then the root's id sum
+  const int n = d.taxon_count, N = d.node_count, M = d.in_node_count, NI = n - 1;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  int* root_sum = setup_ch + 2 * NI;
+  for (int k = tid; k < NI; k += 256) {
+    setup_ch[2 * k] = 0x7fffffff;
+    setup_ch[2 * k + 1] = -1;
+  }
+  if (tid == 0) *root_sum = 0;
+  __syncthreads();
+  const int32_t* parent = b.parent_ids + (size_t)t * (M - 1);
+  for (int child = tid; child < M - 1; child += 256) {
+    const int p = parent[child], k = p - n;
+    atomicMin(&setup_ch[2 * k], child);
+    atomicMax(&setup_ch[2 * k + 1], child);
+    if (p == M - 1) atomicAdd(root_sum, child);
+  }
+  double* bl = b.branch + (size_t)t * N;
+  const double* bl_in = b.branch_in + (size_t)t * M;
+  const double* rates = (d.rooted && b.rates != nullptr) ? b.rates + (size_t)t * (M - 1) : nullptr;
+  for (int i = tid; i < M; i += 256) bl[i] = (rates != nullptr && i < N - 1) ? bl_in[i] * rates[i] : bl_in[i];
+  __syncthreads();
+  if (!d.rooted && tid == 0) {
+    // UnrootedTree::Detrifurcate (reference src/unrooted_tree.cpp:27-37), as SetupTopologyCore
+    const int r = M - 1;
+    const int a = setup_ch[2 * (r - n)], c = setup_ch[2 * (r - n) + 1], mid = *root_sum - a - c;
+    setup_ch[2 * (r - n)] = mid;
+    setup_ch[2 * (r - n) + 1] = c;
+    setup_ch[2 * (r + 1 - n)] = a;
+    setup_ch[2 * (r + 1 - n) + 1] = r;
+    bl[r] = 0.0;
+    bl[r + 1] = 0.0;
+  }
+  __syncthreads();
+  int32_t* ch = b.children + (size_t)t * NI * 2;
+  for (int k = tid; k < 2 * NI; k += 256) ch[k] = setup_ch[k];
+  if (tid == 0) SetupTreeModel(spec, b.params + (size_t)t * spec.param_count, &b.model[t]);
+}
+
 static size_t SetupLdsBytes(const BatchDims& d) {
   return (size_t)kSetupTrees * (d.node_count * sizeof(double) + (d.in_node_count - 1 + 2 * (d.taxon_count - 1)) * sizeof(int32_t));
 }
@@ -72,6 +116,11 @@ void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b
   if (lds <= 48 * 1024) {
     const int blocks = (d.tree_count + kSetupTrees - 1) / kSetupTrees;
     hipLaunchKernelGGL(setup_trees_lds_kernel, dim3(blocks), dim3(64), lds, stream, d, spec, b);
+    return;
+  }
+  const size_t large = ((size_t)2 * (d.taxon_count - 1) + 1) * sizeof(int);
+  if (large <= 60 * 1024) {
+    hipLaunchKernelGGL(setup_large_trees_kernel, dim3(d.tree_count), dim3(256), large, stream, d, spec, b);
     return;
   }
   const int blocks = (d.tree_count + 63) / 64;
