@@ -1,0 +1,49 @@
+"""Path B on the GPU box: the GPDAG schedules (PopulatePLVs + ComputeLikelihoods + MarginalLikelihood) of
+the subsplit DAG of the ten DS1 golden trees (27 taxa, 934 patterns), GPU executor against the CPU oracle.
+usage: python scripts/gpu_gp.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from bito_amd import gp, treeio
+from bito_amd.gp_dag import SubsplitDAG
+from bito_amd.site_pattern import SitePattern
+from oracle import gp as ogp
+from test_tp import _renumber
+
+D = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
+tc = treeio.read_nexus_file(os.path.join(D, "DS1.subsampled_10.t"))
+sp = SitePattern(treeio.read_fasta(os.path.join(D, "DS1.fasta")), tc.taxon_names)
+pids = []
+for t in tc.trees:  # root the unrooted golden trees on their first root child
+    p = np.asarray(t.parent_ids).copy()
+    M = len(p) + 1
+    kids = [c for c in range(M - 1) if p[c] == M - 1]
+    q = np.append(p, M)
+    q[kids[0]] = M
+    pids.append(_renumber(q))
+dag = SubsplitDAG(len(tc.taxon_names), pids)
+bl = np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)
+streams = [dag.populate_plvs(), dag.compute_likelihoods(), dag.marginal_likelihood()]
+nops = sum(len(s.arrays()[0]) for s in streams)
+print(f"DAG: {dag.node_count} nodes, {dag.gpcsp_count} edges, {int(dag.topology_count)} trees spanned; {nops} operations per pass")
+
+
+def run(eng, reps):
+    eng.set_branch_lengths(bl)
+    eng.set_sbn_parameters(dag.uniform_on_topological_support_prior())
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for s in streams:
+            eng.process_operations(s)
+    value = eng.get_log_marginal_likelihood()
+    return (time.perf_counter() - t0) / reps, value
+
+
+gpu = gp.GPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+run(gpu, 2)
+tg, vg = run(gpu, 20)
+cpu = ogp.OracleGPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+tcpu, vc = run(cpu, 2)
+print(f"GPU executor: {tg*1e3:.3f} ms per pass ({nops/tg/1e6:.2f} M ops/s); CPU oracle (1 thread): {tcpu*1e3:.1f} ms per pass; "
+      f"log marginal {vg:.6f} vs {vc:.6f} (diff {abs(vg-vc):.2e})")
