@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bito_amd.h"
@@ -20,6 +21,7 @@
 
 struct bito_amd_gp_engine {
   int device = 0, n = 0, P = 0, Ppad = 0, nodes = 0, gpcsps = 0, plvs = 0;
+  int64_t spare_plvs = 0, spare_gpcsps = 0;  // GrowSparePLVs / GrowSpareGPCSPs: ids behind the DAG's own
   double threshold = 1e-40, log_threshold = 0;
   double *plv = nullptr, *weights = nullptr, *bl = nullptr, *q = nullptr, *ll = nullptr, *marginal = nullptr;
   double* scratch = nullptr;
@@ -28,12 +30,13 @@ struct bito_amd_gp_engine {
   int* counts = nullptr;
   bito_amd_gp_op* d_ops = nullptr;
   uint64_t* d_side = nullptr;
-  size_t ops_cap = 0, side_cap = 0;
+  int64_t* d_offsets = nullptr;
+  size_t ops_cap = 0, side_cap = 0, offsets_cap = 0;
   std::string err;
   ~bito_amd_gp_engine() {
     (void)hipSetDevice(device);
     for (void* p : {(void*)plv, (void*)weights, (void*)bl, (void*)q, (void*)ll, (void*)marginal, (void*)scratch, (void*)diff, (void*)coef,
-                    (void*)counts, (void*)d_ops, (void*)d_side})
+                    (void*)counts, (void*)d_ops, (void*)d_side, (void*)d_offsets})
       if (p) (void)hipFree(p);
   }
 };
@@ -74,12 +77,16 @@ __device__ inline double LogAdd(double x, double y) {
 }
 
 __global__ void __launch_bounds__(64)
-gp_ops_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const uint64_t* __restrict__ side,
-              double* __restrict__ plv, int* __restrict__ counts, const double* __restrict__ bl,
-              const double* __restrict__ q, double* __restrict__ ll, double* __restrict__ marginal, int P, int Ppad,
-              double threshold, double log_threshold) {
+gp_ops_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const int64_t* __restrict__ offsets,
+              const uint64_t* __restrict__ side, double* __restrict__ plv, int* __restrict__ counts,
+              const double* __restrict__ bl, const double* __restrict__ q, double* __restrict__ ll,
+              double* __restrict__ marginal, int P, int Ppad, double threshold, double log_threshold) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
+  if (offsets) {  // independent sub-streams side by side: blockIdx.y owns [offsets[y], offsets[y + 1])
+    ops += offsets[blockIdx.y];
+    op_count = offsets[blockIdx.y + 1] - offsets[blockIdx.y];
+  }
   auto cell = [&](uint64_t idx, int i) -> double& { return plv[((size_t)idx * 4 + i) * Ppad + p]; };
   auto cnt = [&](uint64_t idx) -> int& { return counts[(size_t)idx * Ppad + p]; };
   for (int64_t o = 0; o < op_count; o++) {
@@ -447,8 +454,9 @@ int Fail(bito_amd_gp_engine* e, int code, const std::string& msg) {
 // the op stream is resident in d_ops; a segment is [first, first + count)
 int RunSegment(bito_amd_gp_engine* e, int64_t first, int64_t count) {
   if (count <= 0) return BITO_AMD_OK;
-  hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64), dim3(64), 0, 0, e->d_ops + first, count, e->d_side, e->plv,
-                     e->counts, e->bl, e->q, e->ll, e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
+  hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64), dim3(64), 0, 0, e->d_ops + first, count,
+                     (const int64_t*)nullptr, e->d_side, e->plv, e->counts, e->bl, e->q, e->ll, e->marginal, e->P,
+                     e->Ppad, e->threshold, e->log_threshold);
   GP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
 }
@@ -606,15 +614,15 @@ int bito_amd_gp_log_likelihood_matrix(bito_amd_gp_engine* e, double* out) {
   return BITO_AMD_OK;
 }
 
-int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count,
-                                   const uint64_t* side, int64_t side_count) {
-  if (!e || (op_count > 0 && !ops)) return BITO_AMD_ERR_BAD_ARG;
-  GP_TRY(e, hipSetDevice(e->device));
-  // validate ids once on the host
+// ids are validated once on the host, then the stream and its side array go to the device
+static int ValidateAndUpload(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count, const uint64_t* side,
+                             int64_t side_count, bool batched) {
+  const uint64_t plv_limit = (uint64_t)e->plvs + (uint64_t)e->spare_plvs;
+  const uint64_t gp_limit = (uint64_t)e->gpcsps + (uint64_t)e->spare_gpcsps;
   for (int64_t o = 0; o < op_count; o++) {
     const bito_amd_gp_op& op = ops[o];
-    auto plv_ok = [&](uint64_t id) { return id < (uint64_t)e->plvs; };
-    auto gp_ok = [&](uint64_t id) { return id < (uint64_t)e->gpcsps; };
+    auto plv_ok = [&](uint64_t id) { return id < plv_limit; };
+    auto gp_ok = [&](uint64_t id) { return id < gp_limit; };
     bool ok = true;
     switch (op.opcode) {
       case BITO_AMD_GP_ZERO_PLV: ok = plv_ok(op.a); break;
@@ -622,18 +630,21 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
       case BITO_AMD_GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV: ok = plv_ok(op.a) && gp_ok(op.b) && plv_ok(op.c); break;
       case BITO_AMD_GP_MULTIPLY: ok = plv_ok(op.a) && plv_ok(op.b) && plv_ok(op.c); break;
       case BITO_AMD_GP_LIKELIHOOD: ok = gp_ok(op.a) && plv_ok(op.b) && plv_ok(op.c); break;
-      case BITO_AMD_GP_UPDATE_SBN_PROBABILITIES: ok = op.a < op.b && op.b <= (uint64_t)e->gpcsps; break;
-      case BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD: break;
-      case BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD: ok = plv_ok(op.a) && gp_ok(op.b) && plv_ok(op.c); break;
+      case BITO_AMD_GP_UPDATE_SBN_PROBABILITIES: ok = !batched && op.a < op.b && op.b <= (uint64_t)e->gpcsps; break;
+      case BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD: ok = !batched; break;
+      case BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD: ok = !batched && plv_ok(op.a) && gp_ok(op.b) && plv_ok(op.c); break;
       case BITO_AMD_GP_PREP_FOR_MARGINALIZATION:
         ok = plv_ok(op.a) && op.count > 0 && side && op.b + op.count <= (uint64_t)side_count;
         for (uint32_t k = 0; ok && k < op.count; k++) ok = plv_ok(side[op.b + k]);
         break;
-      case BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH: ok = plv_ok(op.a) && plv_ok(op.b) && gp_ok(op.c); break;
+      case BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH: ok = !batched && plv_ok(op.a) && plv_ok(op.b) && gp_ok(op.c); break;
       default:
         return Fail(e, BITO_AMD_ERR_BAD_ARG, "unknown GP opcode " + std::to_string(op.opcode));
     }
-    if (!ok) return Fail(e, BITO_AMD_ERR_BAD_ARG, "GP op " + std::to_string(o) + " has an index out of range");
+    if (!ok)
+      return Fail(e, BITO_AMD_ERR_BAD_ARG,
+                  "GP op " + std::to_string(o) + " has an index out of range" +
+                      (batched ? " or is not allowed in a batch of independent sub-streams" : ""));
   }
   if (side_count > 0 && side) {
     if ((size_t)side_count > e->side_cap) {
@@ -651,6 +662,14 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
     e->ops_cap = op_count;
   }
   if (op_count > 0) GP_TRY(e, hipMemcpy(e->d_ops, ops, op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count,
+                                   const uint64_t* side, int64_t side_count) {
+  if (!e || (op_count > 0 && !ops)) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  if (int rc = ValidateAndUpload(e, ops, op_count, side, side_count, false)) return rc;
   // Segments: runs of per-pattern ops are one launch each; a run of OptimizeBranchLength ops is one
   // single-workgroup launch (they couple the patterns through the reductions); UpdateSBNProbabilities
   // is a host step.  Everything is issued in stream order, so the sequential semantics hold.
@@ -699,10 +718,110 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
   return BITO_AMD_OK;
 }
 
+int bito_amd_gp_process_operation_batches(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count,
+                                          const uint64_t* side, int64_t side_count, const int64_t* offsets,
+                                          int64_t batch_count) {
+  if (!e || (op_count > 0 && !ops) || !offsets || batch_count < 0) return BITO_AMD_ERR_BAD_ARG;
+  if (batch_count == 0) return BITO_AMD_OK;
+  if (batch_count > 65535) return Fail(e, BITO_AMD_ERR_BAD_ARG, "at most 65535 sub-streams per call");
+  if (offsets[0] != 0 || offsets[batch_count] != op_count)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "offsets must run from 0 to op_count");
+  for (int64_t b = 0; b < batch_count; b++)
+    if (offsets[b + 1] < offsets[b]) return Fail(e, BITO_AMD_ERR_BAD_ARG, "offsets must be non-decreasing");
+  GP_TRY(e, hipSetDevice(e->device));
+  if (int rc = ValidateAndUpload(e, ops, op_count, side, side_count, true)) return rc;
+  if ((size_t)batch_count + 1 > e->offsets_cap) {
+    if (e->d_offsets) (void)hipFree(e->d_offsets);
+    e->offsets_cap = 0;
+    GP_TRY(e, hipMalloc((void**)&e->d_offsets, (batch_count + 1) * sizeof(int64_t)));
+    e->offsets_cap = batch_count + 1;
+  }
+  GP_TRY(e, hipMemcpy(e->d_offsets, offsets, (batch_count + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64, (unsigned)batch_count), dim3(64), 0, 0, e->d_ops,
+                     (int64_t)0, (const int64_t*)e->d_offsets, e->d_side, e->plv, e->counts, e->bl, e->q, e->ll,
+                     e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
+  GP_TRY(e, hipGetLastError());
+  GP_TRY(e, hipDeviceSynchronize());
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_grow_spare(bito_amd_gp_engine* e, int64_t spare_plv_count, int64_t spare_gpcsp_count) {
+  if (!e || spare_plv_count < 0 || spare_gpcsp_count < 0) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  auto grow = [&](auto*& ptr, size_t old_count, size_t new_count) -> hipError_t {
+    using T = std::remove_pointer_t<std::remove_reference_t<decltype(ptr)>>;
+    T* fresh = nullptr;
+    hipError_t rc = hipMalloc((void**)&fresh, new_count * sizeof(T));
+    if (rc != hipSuccess) return rc;
+    if ((rc = hipMemset(fresh, 0, new_count * sizeof(T))) != hipSuccess) return rc;
+    if ((rc = hipMemcpy(fresh, ptr, old_count * sizeof(T), hipMemcpyDeviceToDevice)) != hipSuccess) return rc;
+    (void)hipFree(ptr);
+    ptr = fresh;
+    return hipSuccess;
+  };
+  if (spare_plv_count > e->spare_plvs) {
+    const size_t have = (size_t)e->plvs + e->spare_plvs, want = (size_t)e->plvs + spare_plv_count;
+    GP_TRY(e, grow(e->plv, have * 4 * e->Ppad, want * 4 * e->Ppad));
+    GP_TRY(e, grow(e->counts, have * e->Ppad, want * e->Ppad));
+    e->spare_plvs = spare_plv_count;
+  }
+  if (spare_gpcsp_count > e->spare_gpcsps) {
+    const size_t have = (size_t)e->gpcsps + e->spare_gpcsps, want = (size_t)e->gpcsps + spare_gpcsp_count;
+    GP_TRY(e, grow(e->bl, have, want));
+    GP_TRY(e, grow(e->q, have, want));
+    GP_TRY(e, grow(e->diff, have, want));
+    GP_TRY(e, grow(e->ll, have * e->Ppad, want * e->Ppad));
+    GP_TRY(e, grow(e->scratch, have + 4, want + 4));
+    e->spare_gpcsps = spare_gpcsp_count;
+  }
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_copy_gpcsp_data(bito_amd_gp_engine* e, const int64_t* src, const int64_t* dst, int64_t count) {
+  if (!e || count < 0 || (count > 0 && (!src || !dst))) return BITO_AMD_ERR_BAD_ARG;
+  if (count == 0) return BITO_AMD_OK;
+  const int64_t limit = (int64_t)e->gpcsps + e->spare_gpcsps;
+  for (int64_t i = 0; i < count; i++)
+    if (src[i] < 0 || src[i] >= limit || dst[i] < 0 || dst[i] >= limit)
+      return Fail(e, BITO_AMD_ERR_BAD_ARG, "Cannot copy GPCSP data with src or dest index out-of-range.");
+  GP_TRY(e, hipSetDevice(e->device));
+  std::vector<double> bl(limit), q(limit);
+  GP_TRY(e, hipMemcpy(bl.data(), e->bl, limit * sizeof(double), hipMemcpyDeviceToHost));
+  GP_TRY(e, hipMemcpy(q.data(), e->q, limit * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < count; i++) {  // in order, like repeated CopyGPCSPData calls
+    bl[dst[i]] = bl[src[i]];
+    q[dst[i]] = q[src[i]];
+  }
+  GP_TRY(e, hipMemcpy(e->bl, bl.data(), limit * sizeof(double), hipMemcpyHostToDevice));
+  GP_TRY(e, hipMemcpy(e->q, q.data(), limit * sizeof(double), hipMemcpyHostToDevice));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_per_gpcsp_log_likelihoods_range(bito_amd_gp_engine* e, int64_t first, int64_t count, double* out) {
+  if (!e || !out || first < 0 || count < 0 || first + count > (int64_t)e->gpcsps + e->spare_gpcsps)
+    return BITO_AMD_ERR_BAD_ARG;
+  if (count == 0) return BITO_AMD_OK;
+  GP_TRY(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(gp_weighted_rows_kernel, dim3((unsigned)count), dim3(256), 0, 0, e->ll + (size_t)first * e->Ppad,
+                     e->weights, e->P, e->Ppad, e->scratch);
+  GP_TRY(e, hipMemcpy(out, e->scratch, count * sizeof(double), hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_branch_lengths_range(bito_amd_gp_engine* e, int64_t first, int64_t count, double* out) {
+  if (!e || !out || first < 0 || count < 0 || first + count > (int64_t)e->gpcsps + e->spare_gpcsps)
+    return BITO_AMD_ERR_BAD_ARG;
+  if (count == 0) return BITO_AMD_OK;
+  GP_TRY(e, hipSetDevice(e->device));
+  GP_TRY(e, hipMemcpy(out, e->bl + first, count * sizeof(double), hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+
 int bito_amd_gp_log_likelihood_and_first_two_derivatives(bito_amd_gp_engine* e, int64_t gpcsp, int64_t rootward,
                                                          int64_t leafward, double* out) {
   if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
-  if (gpcsp < 0 || gpcsp >= e->gpcsps || rootward < 0 || rootward >= e->plvs || leafward < 0 || leafward >= e->plvs)
+  if (gpcsp < 0 || gpcsp >= e->gpcsps + e->spare_gpcsps || rootward < 0 || rootward >= e->plvs + e->spare_plvs ||
+      leafward < 0 || leafward >= e->plvs + e->spare_plvs)
     return Fail(e, BITO_AMD_ERR_BAD_ARG, "index out of range");
   GP_TRY(e, hipSetDevice(e->device));
   double t = 0;

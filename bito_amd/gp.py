@@ -227,6 +227,8 @@ GP_SYMBOLS = [
     "bito_amd_gp_log_likelihood_and_first_two_derivatives", "bito_amd_gp_get_branch_length_differences",
     "bito_amd_gp_set_optimization_method", "bito_amd_gp_set_significant_digits_for_optimization",
     "bito_amd_gp_reset_optimization_count", "bito_amd_gp_increment_optimization_count",
+    "bito_amd_gp_grow_spare", "bito_amd_gp_copy_gpcsp_data", "bito_amd_gp_process_operation_batches",
+    "bito_amd_gp_per_gpcsp_log_likelihoods_range", "bito_amd_gp_branch_lengths_range",
 ]
 
 
@@ -250,6 +252,12 @@ def _lib():
             getattr(L, f"bito_amd_gp_{name}").argtypes = [vp, dp]
         L.bito_amd_gp_process_operations.argtypes = [vp, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.bito_amd_gp_log_likelihood_and_first_two_derivatives.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, dp]
+        ip = C.POINTER(C.c_int64)
+        L.bito_amd_gp_grow_spare.argtypes = [vp, C.c_int64, C.c_int64]
+        L.bito_amd_gp_copy_gpcsp_data.argtypes = [vp, ip, ip, C.c_int64]
+        L.bito_amd_gp_process_operation_batches.argtypes = [vp, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, ip, C.c_int64]
+        L.bito_amd_gp_per_gpcsp_log_likelihoods_range.argtypes = [vp, C.c_int64, C.c_int64, dp]
+        L.bito_amd_gp_branch_lengths_range.argtypes = [vp, C.c_int64, C.c_int64, dp]
         L._gp_ready = True
     return L
 
@@ -320,6 +328,40 @@ class GPEngine:
     def process_operations(self, stream: OpStream):
         ops, side = stream.arrays()
         self._check(_lib().bito_amd_gp_process_operations(self._h, ops.ctypes.data, len(ops), side.ctypes.data, len(side)))
+
+    # -- spare slots and side-by-side sub-streams (NNI proposals; src/gp_engine.cpp:196-211,401-409) --
+    def grow_spare(self, spare_plv_count: int, spare_gpcsp_count: int):
+        self._check(_lib().bito_amd_gp_grow_spare(self._h, int(spare_plv_count), int(spare_gpcsp_count)))
+
+    def copy_gpcsp_data(self, src: Sequence[int], dst: Sequence[int]):
+        a = np.ascontiguousarray(src, dtype=np.int64)
+        b = np.ascontiguousarray(dst, dtype=np.int64)
+        assert a.shape == b.shape
+        ip = C.POINTER(C.c_int64)
+        self._check(_lib().bito_amd_gp_copy_gpcsp_data(self._h, a.ctypes.data_as(ip), b.ctypes.data_as(ip), len(a)))
+
+    def process_operation_batches(self, streams: Sequence[OpStream]):
+        """Independent sub-streams (disjoint destinations) run side by side in one launch."""
+        merged, offsets = OpStream(), [0]
+        for s in streams:
+            merged.extend(s)
+            offsets.append(len(merged.ops))
+        ops, side = merged.arrays()
+        off = np.asarray(offsets, dtype=np.int64)
+        self._check(_lib().bito_amd_gp_process_operation_batches(
+            self._h, ops.ctypes.data, len(ops), side.ctypes.data, len(side), off.ctypes.data_as(C.POINTER(C.c_int64)),
+            len(streams)))
+
+    def _range(self, fn, first, count):
+        out = np.zeros(count)
+        self._check(fn(self._h, int(first), int(count), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def get_per_gpcsp_log_likelihoods_range(self, first: int, count: int):
+        return self._range(_lib().bito_amd_gp_per_gpcsp_log_likelihoods_range, first, count)
+
+    def get_branch_lengths_range(self, first: int, count: int):
+        return self._range(_lib().bito_amd_gp_branch_lengths_range, first, count)
 
     def get_log_marginal_likelihood(self) -> float:
         return float(self._vec(_lib().bito_amd_gp_log_marginal_likelihood, 1)[0])

@@ -31,11 +31,11 @@ def _low_bit(mask: int) -> int:
 
 
 class SubsplitDAG:
-    def __init__(self, taxon_count: int, parent_id_vectors: Sequence[Sequence[int]]):
+    def __init__(self, taxon_count: int, parent_id_vectors: Sequence[Sequence[int]] = (), subsplits=None, pcsps=None):
         n = taxon_count
         self.taxon_count = n
-        subsplits = set()
-        pcsps = set()  # (parent subsplit, is_left, child subsplit-or-leaf mask)
+        subsplits = set(subsplits or ())
+        pcsps = set(pcsps or ())  # (parent subsplit, is_left, child subsplit-or-leaf mask)
         for parents in parent_id_vectors:
             parents = [int(x) for x in parents]
             node_count = len(parents) + 1
@@ -58,6 +58,9 @@ class SubsplitDAG:
             for v in range(n, node_count):
                 for c in kids[v]:
                     pcsps.add((key[v], clade[c] == key[v][0], key[c]))
+        if not subsplits:
+            raise ValueError("a subsplit DAG needs at least one tree or one subsplit")
+        self._subsplit_set, self._pcsp_set = frozenset(subsplits), frozenset(pcsps)
         full = (1 << n) - 1
         internal = sorted(subsplits, key=lambda s: (bin(s[0] | s[1]).count("1"), s))
         self.subsplits: List[Tuple[int, int]] = [(0, 1 << i) for i in range(n)] + internal
@@ -89,6 +92,64 @@ class SubsplitDAG:
             self.topology_count_below[node] = (sum(self.topology_count_below[c] for c in self.children[node][1]) *
                                                sum(self.topology_count_below[c] for c in self.children[node][0]))
         self.topology_count = sum(self.topology_count_below[r] for r in self.rootsplits)
+
+    # -- growing the DAG (src/subsplit_dag.cpp:1902-2085): a new DAG object, ids re-derived -----
+    def contains_node(self, subsplit) -> bool:
+        return tuple(subsplit) in self.node_id
+
+    def contains_edge(self, parent_subsplit, child_subsplit) -> bool:
+        p, c = self.node_id.get(tuple(parent_subsplit)), self.node_id.get(tuple(child_subsplit))
+        return p is not None and c is not None and (p, c) in self.edge_id
+
+    def _compatible_pcsps(self, subsplits, only=None):
+        """Every (parent, side, child) with the child's taxon set equal to the parent's side clade;
+        with ``only``, just the pairs that involve one of those subsplits."""
+        n = self.taxon_count
+        by_clade: Dict[int, List[Tuple[int, int]]] = {}
+        for s in list(subsplits) + [(0, 1 << i) for i in range(n)]:
+            by_clade.setdefault(s[0] | s[1], []).append(s)
+        out = set()
+        for ps in subsplits:
+            for is_left, clade in ((True, ps[0]), (False, ps[1])):
+                for cs in by_clade.get(clade, ()):
+                    if only is None or ps in only or cs in only:
+                        out.add((ps, is_left, cs))
+        return out
+
+    def fully_connected(self) -> "SubsplitDAG":
+        """SubsplitDAG::FullyConnect: every compatible parent/child pair of existing nodes gets its edge."""
+        return SubsplitDAG(self.taxon_count, subsplits=self._subsplit_set,
+                           pcsps=self._pcsp_set | self._compatible_pcsps(self._subsplit_set))
+
+    def with_node_pair(self, parent_subsplit, child_subsplit) -> "SubsplitDAG":
+        """SubsplitDAG::AddNodePair (src/subsplit_dag.cpp:1965-2085): nodes that are new are connected to
+        all their compatible parents and children; the pair's own edge is added."""
+        parent_subsplit, child_subsplit = tuple(parent_subsplit), tuple(child_subsplit)
+        focal = child_subsplit[0] | child_subsplit[1]
+        if focal not in parent_subsplit:
+            raise ValueError("the child subsplit does not descend from the parent subsplit")
+        fresh = {x for x in (parent_subsplit, child_subsplit) if x not in self._subsplit_set}
+        subsplits = self._subsplit_set | fresh
+        pcsps = set(self._pcsp_set) | {(parent_subsplit, parent_subsplit[0] == focal, child_subsplit)}
+        if fresh:
+            pcsps |= self._compatible_pcsps(subsplits, only=fresh)
+        return SubsplitDAG(self.taxon_count, subsplits=subsplits, pcsps=pcsps)
+
+    # DAGBranchHandler::BuildBranchLengthMap / ApplyBranchLengthMap (src/dag_branch_handler.hpp:214-219):
+    # branch lengths keyed by the edge's (parent subsplit, child subsplit), None = the DAG root
+    def branch_length_map(self, branch_lengths) -> Dict:
+        out = {}
+        for (p, c), e in self.edge_id.items():
+            out[(None if p < 0 else self.subsplits[p], self.subsplits[c])] = float(branch_lengths[e])
+        return out
+
+    def apply_branch_length_map(self, length_map: Dict, default: float = 0.1) -> np.ndarray:
+        out = np.full(self.gpcsp_count, float(default))
+        for (p, c), e in self.edge_id.items():
+            key = (None if p < 0 else self.subsplits[p], self.subsplits[c])
+            if key in length_map:
+                out[e] = length_map[key]
+        return out
 
     # -- ids -------------------------------------------------------------------
     def pv(self, plv_type: int, node: int) -> int:

@@ -80,6 +80,33 @@ int bito_amd_gp_increment_optimization_count(bito_amd_gp_engine *e);
 int bito_amd_gp_process_operations(bito_amd_gp_engine *e, const bito_amd_gp_op *ops, int64_t op_count,
                                    const uint64_t *side, int64_t side_count);
 
+/* Spare slots behind the DAG's own ids -- GPEngine::GrowSparePLVs / GrowSpareGPCSPs
+ * (src/gp_engine.hpp:56-57, src/gp_engine.cpp:196-211): after the call PLV ids
+ * [6 * node_count, 6 * node_count + spare_plv_count) and GPCSP ids [gpcsp_count, gpcsp_count +
+ * spare_gpcsp_count) are valid in op streams (GetSparePVIndex / GetSpareGPCSPIndex).  Contents of the
+ * arena are kept; counts only grow.  Spare GPCSPs start with branch length 0 and q = 0: fill them
+ * with bito_amd_gp_copy_gpcsp_data. */
+int bito_amd_gp_grow_spare(bito_amd_gp_engine *e, int64_t spare_plv_count, int64_t spare_gpcsp_count);
+
+/* GPEngine::CopyGPCSPData(src, dest) (src/gp_engine.cpp:401-409) for count pairs, applied in order:
+ * branch length and q of src[i] are copied to dst[i]. */
+int bito_amd_gp_copy_gpcsp_data(bito_amd_gp_engine *e, const int64_t *src, const int64_t *dst, int64_t count);
+
+/* ProcessOperations for batch_count INDEPENDENT sub-streams laid side by side on the device:
+ * sub-stream b is ops[offsets[b] .. offsets[b + 1]) (offsets[0] = 0, offsets[batch_count] = op_count).
+ * The caller guarantees that no sub-stream writes a PLV or GPCSP slot another one reads or writes --
+ * e.g. one sub-stream per proposed NNI, each on its own spare slots (the reference runs
+ * NNIEvalEngineViaGP::ComputeAdjacentNNILikelihood once per NNI, src/nni_evaluation_engine.cpp:206-461).
+ * Only the per-pattern PLV ops and Likelihood are allowed (no marginal, SBN or optimiser ops). */
+int bito_amd_gp_process_operation_batches(bito_amd_gp_engine *e, const bito_amd_gp_op *ops, int64_t op_count,
+                                          const uint64_t *side, int64_t side_count, const int64_t *offsets,
+                                          int64_t batch_count);
+
+/* GetPerGPCSPLogLikelihoods(start, length) and GetBranchLengths / GetSpareBranchLengths(start, length)
+ * (src/gp_engine.cpp:421-456): ranges may reach into the spare GPCSPs. */
+int bito_amd_gp_per_gpcsp_log_likelihoods_range(bito_amd_gp_engine *e, int64_t first, int64_t count, double *out);
+int bito_amd_gp_branch_lengths_range(bito_amd_gp_engine *e, int64_t first, int64_t count, double *out);
+
 /* GetLogMarginalLikelihood (gp_engine.cpp:413-415): out[1];
  * GetPerGPCSPLogLikelihoods (:437-440): out[gpcsp_count];
  * GetLogLikelihoodMatrix: out[gpcsp_count][pattern_count]. */

@@ -35,6 +35,10 @@ def lib():
         L.gp_oracle_set_significant_digits.argtypes = [vp, C.c_int]
         L.gp_oracle_reset_optimization_count.argtypes = [vp]
         L.gp_oracle_increment_optimization_count.argtypes = [vp]
+        L.gp_oracle_grow_spare.argtypes = [vp, C.c_int, C.c_int]
+        L.gp_oracle_copy_gpcsp_data.argtypes = [vp, C.c_int, C.c_int]
+        L.gp_oracle_per_gpcsp_log_likelihoods_range.argtypes = [vp, C.c_int, C.c_int, dp]
+        L.gp_oracle_branch_lengths_range.argtypes = [vp, C.c_int, C.c_int, dp]
         _lib = L
     return _lib
 
@@ -94,6 +98,28 @@ class OracleGPEngine:
         rc = lib().gp_oracle_process(self._h, ops.ctypes.data, len(ops), side.ctypes.data)
         if rc:
             raise RuntimeError(f"gp oracle: op stream rejected ({rc})")
+
+    # spare slots (GPEngine::GrowSparePLVs / GrowSpareGPCSPs, CopyGPCSPData; src/gp_engine.cpp:196-211,401-409)
+    def grow_spare(self, spare_plv_count, spare_gpcsp_count):
+        lib().gp_oracle_grow_spare(self._h, int(spare_plv_count), int(spare_gpcsp_count))
+
+    def copy_gpcsp_data(self, src, dst):
+        for a, b in zip(src, dst):
+            lib().gp_oracle_copy_gpcsp_data(self._h, int(a), int(b))
+
+    def process_operation_batches(self, streams):
+        for s in streams:  # independent sub-streams: any order gives the same result
+            self.process_operations(s)
+
+    def get_per_gpcsp_log_likelihoods_range(self, first, count):
+        out = np.zeros(count)
+        lib().gp_oracle_per_gpcsp_log_likelihoods_range(self._h, int(first), int(count), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def get_branch_lengths_range(self, first, count):
+        out = np.zeros(count)
+        lib().gp_oracle_branch_lengths_range(self._h, int(first), int(count), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
 
     def get_log_marginal_likelihood(self):
         return lib().gp_oracle_log_marginal_likelihood(self._h)

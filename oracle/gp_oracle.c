@@ -41,6 +41,7 @@ typedef struct {
 
 typedef struct {
   int P, plv_count, gpcsp_count;
+  int spare_plvs, spare_gpcsps; /* GrowSparePLVs / GrowSpareGPCSPs: slots behind the DAG's own ids */
   double threshold, log_threshold;
   double *plv;       /* [plv_count][P][4]  (column-major 4 x P per PLV) */
   int *counts;       /* [plv_count] */
@@ -292,6 +293,46 @@ void gp_oracle_derivatives(gp_oracle *g, int gpcsp, uint64_t rootward, uint64_t 
   out[0] = ll;
   out[1] = d1;
   out[2] = d2;
+}
+
+/* GPEngine::GrowSparePLVs / GrowSpareGPCSPs (src/gp_engine.cpp:196-211): spare PLV ids start at
+ * plv_count, spare GPCSP ids at gpcsp_count; contents are kept, counts only grow. */
+static void *grow_zeroed(void *ptr, size_t old_bytes, size_t new_bytes) {
+  char *fresh = (char *)realloc(ptr, new_bytes);
+  memset(fresh + old_bytes, 0, new_bytes - old_bytes);
+  return fresh;
+}
+void gp_oracle_grow_spare(gp_oracle *g, int spare_plvs, int spare_gpcsps) {
+  if (spare_plvs > g->spare_plvs) {
+    const size_t have = (size_t)g->plv_count + g->spare_plvs, want = (size_t)g->plv_count + spare_plvs;
+    g->plv = (double *)grow_zeroed(g->plv, have * g->P * 4 * sizeof(double), want * g->P * 4 * sizeof(double));
+    g->counts = (int *)grow_zeroed(g->counts, have * sizeof(int), want * sizeof(int));
+    g->spare_plvs = spare_plvs;
+  }
+  if (spare_gpcsps > g->spare_gpcsps) {
+    const size_t have = (size_t)g->gpcsp_count + g->spare_gpcsps, want = (size_t)g->gpcsp_count + spare_gpcsps;
+    g->bl = (double *)grow_zeroed(g->bl, have * sizeof(double), want * sizeof(double));
+    g->q = (double *)grow_zeroed(g->q, have * sizeof(double), want * sizeof(double));
+    g->diff = (double *)grow_zeroed(g->diff, have * sizeof(double), want * sizeof(double));
+    g->ll = (double *)grow_zeroed(g->ll, have * g->P * sizeof(double), want * g->P * sizeof(double));
+    g->spare_gpcsps = spare_gpcsps;
+  }
+}
+/* GPEngine::CopyGPCSPData (src/gp_engine.cpp:401-409) */
+void gp_oracle_copy_gpcsp_data(gp_oracle *g, int src, int dst) {
+  g->bl[dst] = g->bl[src];
+  g->q[dst] = g->q[src];
+}
+/* GetPerGPCSPLogLikelihoods(start, length) / GetBranchLengths(start, length) (src/gp_engine.cpp:421-456) */
+void gp_oracle_per_gpcsp_log_likelihoods_range(const gp_oracle *g, int first, int count, double *out) {
+  for (int e = 0; e < count; e++) {
+    double s = 0;
+    for (int p = 0; p < g->P; p++) s += g->ll[(size_t)(first + e) * g->P + p] * g->weights[p];
+    out[e] = s;
+  }
+}
+void gp_oracle_branch_lengths_range(const gp_oracle *g, int first, int count, double *out) {
+  memcpy(out, g->bl + first, sizeof(double) * count);
 }
 
 void gp_oracle_transition_matrix(double t, double *P16) { matrices(t, P16, NULL, NULL); }

@@ -47,3 +47,32 @@ cpu = ogp.OracleGPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_coun
 tcpu, vc = run(cpu, 2)
 print(f"GPU executor: {tg*1e3:.3f} ms per pass ({nops/tg/1e6:.2f} M ops/s); CPU oracle (1 thread): {tcpu*1e3:.1f} ms per pass; "
       f"log marginal {vg:.6f} vs {vc:.6f} (diff {abs(vg-vc):.2e})")
+
+# -- NNI proposals on spare slots (bito_amd/nni.py): all proposals in one launch vs one call per proposal --
+from bito_amd.nni import NNIEvalEngineViaGP
+
+gpu.set_sbn_parameters(np.ones(dag.gpcsp_count))
+ev = NNIEvalEngineViaGP(dag, gpu)
+ev.prep()
+t0 = time.perf_counter()
+scores = ev.score_adjacent_nnis()
+t_first = time.perf_counter() - t0
+t0 = time.perf_counter()
+for _ in range(10):
+    gpu.process_operation_batches([p.stream for p in ev.proposals])
+t_batch = (time.perf_counter() - t0) / 10
+t0 = time.perf_counter()
+for p in ev.proposals:
+    gpu.process_operations(p.stream)
+t_seq = time.perf_counter() - t0
+nops = sum(len(p.stream.ops) for p in ev.proposals)
+cpu.set_sbn_parameters(np.ones(dag.gpcsp_count))
+evc = NNIEvalEngineViaGP(dag, cpu)
+evc.prep()
+t0 = time.perf_counter()
+cscores = evc.score_adjacent_nnis()
+t_cpu = time.perf_counter() - t0
+worst = max(abs(scores[k] - cscores[k]) for k in scores)
+print(f"NNI proposals: {len(scores)} adjacent NNIs, {nops} operations; batched launch {t_batch*1e3:.3f} ms "
+      f"({len(scores)/t_batch:.0f} NNIs/s; first call incl. schedule building {t_first*1e3:.1f} ms), "
+      f"one call per NNI {t_seq*1e3:.2f} ms, CPU (1 thread) {t_cpu*1e3:.1f} ms; max |GPU - CPU| = {worst:.2e}")

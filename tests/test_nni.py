@@ -1,0 +1,233 @@
+"""NNI proposals through the GP executor (bito_amd/nni.py).
+
+The reference's own check -- "NNIEngine via GPEngine: Proposed NNI vs DAG NNI GPLikelihoods"
+(src/gp_doctest.cpp:1937-2157) -- reads: the likelihood of a proposed NNI, computed on spare slots
+from the neighbours of the NNI it came from, equals the per-GPCSP likelihood of that NNI's edge in
+the DAG that really holds it (the "truth" DAG: AddNodePair, same branch lengths, full
+PopulatePLVs + ComputeLikelihoods), with the null prior.  The reference asks for 1e-3; the two
+routes multiply the same numbers, so 1e-9 is asked for here.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from bito_amd import nni as nni_mod
+from bito_amd import treeio
+from bito_amd.gp_dag import SubsplitDAG
+from bito_amd.nni import NNI, NNIEvalEngineViaGP, adjacent_nnis, find_nni_neighbor_in_dag, nni_edge_sources
+from bito_amd.site_pattern import SitePattern
+
+CASES = [("hello.fasta", "hello_rooted_diff_branches.nwk"), ("six_taxon_longer.fasta", "six_taxon_rooted_simple.nwk"),
+         ("five_taxon.fasta", "five_taxon_rooted.nwk")]
+
+
+def _load(data_dir, fasta, newick):
+    tc = treeio.read_newick_file(os.path.join(data_dir, newick))
+    sp = SitePattern(treeio.read_fasta(os.path.join(data_dir, fasta)), tc.taxon_names)
+    dag = SubsplitDAG(len(tc.taxon_names), [t.parent_ids for t in tc.trees]).fully_connected()
+    return sp, dag
+
+
+def _truth_score(make_engine, sp, dag, bl, pre, nni):
+    """The truth DAG of the reference's test: AddNodePair(nni), the pre-DAG's branch lengths by
+    PCSP, the edges around the new NNI take over the lengths of the pre-NNI's edges
+    (CopyGPEngineDataAfterAddingNNI), null prior, PopulatePLVs + ComputeLikelihoods."""
+    truth = dag.with_node_pair(nni.parent, nni.child)
+    lengths = truth.apply_branch_length_map(dag.branch_length_map(bl))
+    for (ps, cs), src in nni_edge_sources(dag, pre, nni).items():
+        p = -1 if ps is None else truth.node_id[ps]
+        lengths[truth.edge_id[(p, truth.node_id[cs])]] = bl[src]
+    eng = make_engine(sp.patterns, sp.weights, truth.node_count, truth.gpcsp_count)
+    eng.set_branch_lengths(lengths)
+    eng.set_sbn_parameters(np.ones(truth.gpcsp_count))
+    eng.process_operations(truth.populate_plvs())
+    eng.process_operations(truth.compute_likelihoods())
+    e = truth.edge(truth.node_id[nni.parent], truth.node_id[nni.child])
+    return eng.get_per_gpcsp_log_likelihoods()[e], truth, lengths
+
+
+def _proposed_vs_truth(make_engine, data_dir, fasta, newick, tol):
+    sp, dag = _load(data_dir, fasta, newick)
+    bl = np.random.default_rng(5).uniform(0.02, 0.4, dag.gpcsp_count)
+    eng = make_engine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+    eng.set_branch_lengths(bl)
+    eng.set_sbn_parameters(np.ones(dag.gpcsp_count))  # SetNullPrior
+    ev = NNIEvalEngineViaGP(dag, eng)
+    ev.prep()
+    before = eng.get_per_gpcsp_log_likelihoods()
+    nnis = ev.adjacent_nnis()
+    assert nnis, "every fixture has NNIs outside its DAG"
+    scores = ev.score_adjacent_nnis()
+    assert set(scores) == set(nnis)
+    # the DAG's own likelihoods are untouched by scoring on spare slots
+    assert np.array_equal(before, eng.get_per_gpcsp_log_likelihoods())
+    for prop in ev.proposals:
+        truth, truth_dag, _ = _truth_score(make_engine, sp, dag, bl, prop.pre_nni, prop.nni)
+        assert np.isfinite(truth)
+        assert abs(scores[prop.nni] - truth) < tol, (prop.nni, scores[prop.nni], truth)
+        assert nni_mod.contains_nni(truth_dag, prop.nni)
+    # an NNI the DAG holds is scored by its own edge (ScoreInternalNNIByNNI)
+    pre = ev.proposals[0].pre_nni
+    e = dag.edge(dag.node_id[pre.parent], dag.node_id[pre.child])
+    assert ev.score_internal_nni(pre) == before[e]
+    return len(nnis)
+
+
+# -- host logic -------------------------------------------------------------------------------
+
+def test_neighbors_are_mutual_and_keep_the_taxa():
+    parent, child = nni_mod.make_subsplit(0b000011, 0b111100), nni_mod.make_subsplit(0b001100, 0b110000)
+    x = NNI(parent, child)
+    assert x.focal_clade == 0b111100 and x.sister_clade == 0b000011
+    for nb in x.neighbors():
+        assert nb.parent[0] | nb.parent[1] == 0b111111  # same taxa under the parent
+        assert nb.focal_clade in nb.parent and nb.sister_clade in x.child  # a child clade became the sister
+        assert x in nb.neighbors()  # swapping back
+    assert len(set(x.neighbors())) == 2
+
+
+@pytest.mark.parametrize("fasta,newick", CASES)
+def test_adjacent_nnis_of_a_dag(data_dir, fasta, newick):
+    """NNIEngine::SyncAdjacentNNIsWithDAG: adjacent NNIs are outside the DAG, each has a neighbour inside,
+    and adding one makes it (and only new things) part of the DAG."""
+    sp, dag = _load(data_dir, fasta, newick)
+    nnis = adjacent_nnis(dag)
+    assert nnis and len(set(nnis)) == len(nnis)
+    internal_edges = [(p, c) for (p, c) in dag.edge_id if p >= 0 and c >= dag.taxon_count]
+    assert len(nnis) <= 2 * len(internal_edges)
+    for x in nnis:
+        assert not nni_mod.contains_nni(dag, x)
+        pre = find_nni_neighbor_in_dag(dag, x)
+        assert nni_mod.contains_nni(dag, pre) and x in pre.neighbors()
+        grown = dag.with_node_pair(x.parent, x.child)
+        assert nni_mod.contains_nni(grown, x)
+        assert grown.node_count - dag.node_count == (not dag.contains_node(x.parent)) + (not dag.contains_node(x.child))
+        assert grown.topology_count > dag.topology_count
+        # every old node and edge survives, by subsplit
+        assert set(dag.subsplits) <= set(grown.subsplits)
+        old = set(dag.branch_length_map(np.zeros(dag.gpcsp_count)))
+        assert old <= set(grown.branch_length_map(np.zeros(grown.gpcsp_count)))
+        # the grown DAG is still fully connected, as AddNodePair leaves it
+        assert grown.fully_connected().gpcsp_count == grown.gpcsp_count
+    assert adjacent_nnis(dag, include_rootsplits=False) == [
+        x for x in nnis if any(pre.parent not in [dag.subsplits[r] for r in dag.rootsplits]
+                               for pre in x.neighbors() if nni_mod.contains_nni(dag, pre))]
+
+
+def test_edge_sources_cover_every_edge_around_the_nni(data_dir):
+    sp, dag = _load(data_dir, "six_taxon_longer.fasta", "six_taxon_rooted_simple.nwk")
+    for x in adjacent_nnis(dag):
+        pre = find_nni_neighbor_in_dag(dag, x)
+        grown = dag.with_node_pair(x.parent, x.child)
+        src = nni_edge_sources(dag, pre, x)
+        p, c = grown.node_id[x.parent], grown.node_id[x.child]
+        around = {(-1 if ps is None else grown.node_id[ps], grown.node_id[cs]) for ps, cs in src}
+        expect = {(p, c)} | {(g, p) for g, _ in grown.parents[p]} | {(c, k) for side in (0, 1) for k in grown.children[c][side]}
+        sister_side = 1 if x.parent[0] == x.sister_clade else 0
+        expect |= {(p, k) for k in grown.children[p][sister_side]}
+        if not grown.parents[p]:
+            expect.add((-1, p))
+        assert around == expect
+        assert all(0 <= e < dag.gpcsp_count for e in src.values())
+
+
+@pytest.mark.parametrize("fasta,newick", CASES)
+def test_proposed_nni_likelihood_equals_truth_dag_cpu(data_dir, fasta, newick):
+    from oracle import gp as ogp
+
+    _proposed_vs_truth(ogp.OracleGPEngine, data_dir, fasta, newick, 1e-9)
+
+
+@pytest.mark.parametrize("fasta,newick", CASES)
+def test_proposed_nni_likelihood_is_the_sum_over_its_trees(data_dir, fasta, newick):
+    """Independent of the GP route: with the null prior the per-GPCSP likelihood of an edge is the sum of
+    the likelihoods of the trees through it (the composite identity of src/gp_doctest.cpp:140-254) --
+    evaluated tree by tree with the per-tree checker on the truth DAG."""
+    from oracle import gp as ogp
+    from oracle import oracle
+
+    sp, dag = _load(data_dir, fasta, newick)
+    bl = np.random.default_rng(5).uniform(0.02, 0.4, dag.gpcsp_count)
+    eng = ogp.OracleGPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+    eng.set_branch_lengths(bl)
+    eng.set_sbn_parameters(np.ones(dag.gpcsp_count))
+    ev = NNIEvalEngineViaGP(dag, eng)
+    ev.prep()
+    scores = ev.score_adjacent_nnis()
+    cpu = oracle.OracleEngine("JC69", "constant", "none", sp.patterns, sp.weights, 2)
+    n = dag.taxon_count
+    for prop in ev.proposals[:6]:
+        _, truth, lengths = _truth_score(ogp.OracleGPEngine, sp, dag, bl, prop.pre_nni, prop.nni)
+        e = truth.edge(truth.node_id[prop.nni.parent], truth.node_id[prop.nni.child])
+        pids, tbl = [], []
+        for pid, edges in truth.all_trees():
+            if e in edges:
+                pids.append(pid)
+                tbl.append(np.append(lengths[edges[: 2 * n - 2]], 0.0))
+        assert pids
+        # per site pattern: log sum over trees; the per-tree checker returns totals, so use one pattern at a time
+        total = 0.0
+        for k in range(sp.patterns.shape[1]):
+            one = oracle.OracleEngine("JC69", "constant", "none", sp.patterns[:, k:k + 1].copy(), np.ones(1), 1)
+            lls = one.log_likelihoods(np.array(pids), np.array(tbl))
+            total += sp.weights[k] * np.logaddexp.reduce(lls)
+        assert abs(scores[prop.nni] - total) < 1e-9, (prop.nni, scores[prop.nni], total)
+
+
+# -- GPU executor -------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fasta,newick", CASES)
+def test_proposed_nni_likelihood_equals_truth_dag_gpu(data_dir, fasta, newick):
+    from bito_amd import gp
+
+    _proposed_vs_truth(gp.GPEngine, data_dir, fasta, newick, 1e-9)
+
+
+@pytest.mark.gpu
+def test_batched_proposals_equal_the_cpu_checker_and_one_by_one(data_dir):
+    """All proposals in one launch = the same proposals one ProcessOperations call at a time = the CPU route."""
+    from bito_amd import gp
+    from oracle import gp as ogp
+
+    sp, dag = _load(data_dir, "six_taxon_longer.fasta", "six_taxon_rooted_simple.nwk")
+    bl = np.random.default_rng(8).uniform(0.02, 0.4, dag.gpcsp_count)
+    results = []
+    for make in (gp.GPEngine, ogp.OracleGPEngine):
+        eng = make(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+        eng.set_branch_lengths(bl)
+        eng.set_sbn_parameters(np.ones(dag.gpcsp_count))
+        ev = NNIEvalEngineViaGP(dag, eng)
+        ev.prep()
+        results.append((ev.score_adjacent_nnis(), ev, eng))
+    (gpu_scores, ev, eng), (cpu_scores, _, _) = results
+    assert gpu_scores.keys() == cpu_scores.keys()
+    for k in gpu_scores:
+        assert abs(gpu_scores[k] - cpu_scores[k]) < 1e-10
+    for prop in ev.proposals:  # sequential route on the same spare slots
+        eng.process_operations(prop.stream)
+        assert eng.get_per_gpcsp_log_likelihoods_range(prop.central_edge, 1)[0] == gpu_scores[prop.nni]
+    # spare branch lengths are the pre-NNI's
+    first = dag.gpcsp_count
+    spare = eng.get_branch_lengths_range(first, sum(len(p.copy_dst) for p in ev.proposals))
+    for prop in ev.proposals:
+        assert np.array_equal(spare[np.array(prop.copy_dst) - first], bl[prop.copy_src])
+
+
+@pytest.mark.gpu
+def test_batch_rejects_coupled_ops_and_bad_offsets(data_dir):
+    from bito_amd import BitoAmdError, gp
+
+    sp, dag = _load(data_dir, "hello.fasta", "hello_rooted_diff_branches.nwk")
+    eng = gp.GPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+    with pytest.raises(BitoAmdError):
+        eng.process_operation_batches([dag.marginal_likelihood()])  # marginal ops couple sub-streams
+    s = gp.OpStream()
+    s.add(gp.ZERO_PLV, 6 * dag.node_count)  # a spare id before any spare slot exists
+    with pytest.raises(BitoAmdError):
+        eng.process_operations(s)
+    eng.grow_spare(1, 0)
+    eng.process_operations(s)
+    with pytest.raises(BitoAmdError):
+        eng.copy_gpcsp_data([0], [dag.gpcsp_count])
