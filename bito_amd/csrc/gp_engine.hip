@@ -31,7 +31,7 @@ struct bito_amd_gp_engine {
   bito_amd_gp_op* d_ops = nullptr;
   uint64_t* d_side = nullptr;
   int64_t* d_offsets = nullptr;
-  size_t ops_cap = 0, side_cap = 0, offsets_cap = 0;
+  size_t ops_cap = 0, side_cap = 0, offsets_cap = 0, coef_blocks = 1;  // coef holds coef_blocks x [2][Ppad]
   std::string err;
   ~bito_amd_gp_engine() {
     (void)hipSetDevice(device);
@@ -76,6 +76,88 @@ __device__ inline double LogAdd(double x, double y) {
   return x + log(1.0 + exp(nd));
 }
 
+// One per-pattern operation for pattern p (everything in GPOperation except the optimiser and the SBN update)
+__device__ inline void PatternOp(const bito_amd_gp_op& op, int p, const uint64_t* __restrict__ side,
+                                 double* __restrict__ plv, int* __restrict__ counts, const double* __restrict__ bl,
+                                 const double* __restrict__ q, double* __restrict__ ll, double* __restrict__ marginal,
+                                 int Ppad, double threshold, double log_threshold) {
+  auto cell = [&](uint64_t idx, int i) -> double& { return plv[((size_t)idx * 4 + i) * Ppad + p]; };
+  auto cnt = [&](uint64_t idx) -> int& { return counts[(size_t)idx * Ppad + p]; };
+  switch (op.opcode) {
+    case BITO_AMD_GP_ZERO_PLV:
+      for (int i = 0; i < 4; i++) cell(op.a, i) = 0.0;
+      cnt(op.a) = 0;
+      break;
+    case BITO_AMD_GP_SET_TO_STATIONARY_DISTRIBUTION:
+      for (int i = 0; i < 4; i++) cell(op.a, i) = q[op.b] * 0.25;
+      cnt(op.a) = 0;
+      break;
+    case BITO_AMD_GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV: {
+      double M[16];
+      Matrices(bl[op.b], M, nullptr, nullptr);
+      const int diff = cnt(op.c) - cnt(op.a);
+      const double f = (diff == 0 ? 1.0 : pow(threshold, (double)diff)) * q[op.b];
+      double s[4];
+      for (int i = 0; i < 4; i++) s[i] = cell(op.c, i);
+      for (int i = 0; i < 4; i++)
+        cell(op.a, i) += f * (M[i * 4] * s[0] + M[i * 4 + 1] * s[1] + M[i * 4 + 2] * s[2] + M[i * 4 + 3] * s[3]);
+      break;
+    }
+    case BITO_AMD_GP_MULTIPLY: {
+      double d[4], mx = 0;
+      for (int i = 0; i < 4; i++) {
+        d[i] = cell(op.b, i) * cell(op.c, i);
+        mx = fmax(mx, d[i]);
+      }
+      int c = cnt(op.b) + cnt(op.c);
+      if (mx != 0) {  // RescalePLVIfNeeded, per pattern column
+        int extra = 0;
+        while (mx < threshold) {
+          mx /= threshold;
+          extra++;
+        }
+        if (extra) {
+          const double f = pow(threshold, (double)extra);
+          for (int i = 0; i < 4; i++) d[i] /= f;
+          c += extra;
+        }
+      }
+      for (int i = 0; i < 4; i++) cell(op.a, i) = d[i];
+      cnt(op.a) = c;
+      break;
+    }
+    case BITO_AMD_GP_LIKELIHOOD: {
+      double M[16];
+      Matrices(bl[op.a], M, nullptr, nullptr);
+      double s = 0;
+      for (int i = 0; i < 4; i++)
+        s += cell(op.c, i) * (M[i * 4] * cell(op.b, 0) + M[i * 4 + 1] * cell(op.b, 1) + M[i * 4 + 2] * cell(op.b, 2) +
+                              M[i * 4 + 3] * cell(op.b, 3));
+      ll[(size_t)op.a * Ppad + p] = log(s) + (cnt(op.b) + cnt(op.c)) * log_threshold;
+      break;
+    }
+    case BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD:
+      marginal[p] = -INFINITY;
+      break;
+    case BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD: {
+      double s = 0;
+      for (int i = 0; i < 4; i++) s += cell(op.a, i) * cell(op.c, i);
+      const double row = log(s) + cnt(op.c) * log_threshold;
+      marginal[p] = LogAdd(marginal[p], row);
+      ll[(size_t)op.b * Ppad + p] = row - log(q[op.b]);
+      break;
+    }
+    case BITO_AMD_GP_PREP_FOR_MARGINALIZATION: {
+      int mn = cnt(side[op.b]);
+      for (uint32_t k = 1; k < op.count; k++) mn = min(mn, cnt(side[op.b + k]));
+      cnt(op.a) = mn;
+      break;
+    }
+    default:
+      break;
+  }
+}
+
 __global__ void __launch_bounds__(64)
 gp_ops_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const int64_t* __restrict__ offsets,
               const uint64_t* __restrict__ side, double* __restrict__ plv, int* __restrict__ counts,
@@ -87,84 +169,8 @@ gp_ops_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const in
     ops += offsets[blockIdx.y];
     op_count = offsets[blockIdx.y + 1] - offsets[blockIdx.y];
   }
-  auto cell = [&](uint64_t idx, int i) -> double& { return plv[((size_t)idx * 4 + i) * Ppad + p]; };
-  auto cnt = [&](uint64_t idx) -> int& { return counts[(size_t)idx * Ppad + p]; };
-  for (int64_t o = 0; o < op_count; o++) {
-    const bito_amd_gp_op op = ops[o];
-    switch (op.opcode) {
-      case BITO_AMD_GP_ZERO_PLV:
-        for (int i = 0; i < 4; i++) cell(op.a, i) = 0.0;
-        cnt(op.a) = 0;
-        break;
-      case BITO_AMD_GP_SET_TO_STATIONARY_DISTRIBUTION:
-        for (int i = 0; i < 4; i++) cell(op.a, i) = q[op.b] * 0.25;
-        cnt(op.a) = 0;
-        break;
-      case BITO_AMD_GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV: {
-        double M[16];
-        Matrices(bl[op.b], M, nullptr, nullptr);
-        const int diff = cnt(op.c) - cnt(op.a);
-        const double f = (diff == 0 ? 1.0 : pow(threshold, (double)diff)) * q[op.b];
-        double s[4];
-        for (int i = 0; i < 4; i++) s[i] = cell(op.c, i);
-        for (int i = 0; i < 4; i++)
-          cell(op.a, i) += f * (M[i * 4] * s[0] + M[i * 4 + 1] * s[1] + M[i * 4 + 2] * s[2] + M[i * 4 + 3] * s[3]);
-        break;
-      }
-      case BITO_AMD_GP_MULTIPLY: {
-        double d[4], mx = 0;
-        for (int i = 0; i < 4; i++) {
-          d[i] = cell(op.b, i) * cell(op.c, i);
-          mx = fmax(mx, d[i]);
-        }
-        int c = cnt(op.b) + cnt(op.c);
-        if (mx != 0) {  // RescalePLVIfNeeded, per pattern column
-          int extra = 0;
-          while (mx < threshold) {
-            mx /= threshold;
-            extra++;
-          }
-          if (extra) {
-            const double f = pow(threshold, (double)extra);
-            for (int i = 0; i < 4; i++) d[i] /= f;
-            c += extra;
-          }
-        }
-        for (int i = 0; i < 4; i++) cell(op.a, i) = d[i];
-        cnt(op.a) = c;
-        break;
-      }
-      case BITO_AMD_GP_LIKELIHOOD: {
-        double M[16];
-        Matrices(bl[op.a], M, nullptr, nullptr);
-        double s = 0;
-        for (int i = 0; i < 4; i++)
-          s += cell(op.c, i) * (M[i * 4] * cell(op.b, 0) + M[i * 4 + 1] * cell(op.b, 1) + M[i * 4 + 2] * cell(op.b, 2) +
-                                M[i * 4 + 3] * cell(op.b, 3));
-        ll[(size_t)op.a * Ppad + p] = log(s) + (cnt(op.b) + cnt(op.c)) * log_threshold;
-        break;
-      }
-      case BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD:
-        marginal[p] = -INFINITY;
-        break;
-      case BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD: {
-        double s = 0;
-        for (int i = 0; i < 4; i++) s += cell(op.a, i) * cell(op.c, i);
-        const double row = log(s) + cnt(op.c) * log_threshold;
-        marginal[p] = LogAdd(marginal[p], row);
-        ll[(size_t)op.b * Ppad + p] = row - log(q[op.b]);
-        break;
-      }
-      case BITO_AMD_GP_PREP_FOR_MARGINALIZATION: {
-        int mn = cnt(side[op.b]);
-        for (uint32_t k = 1; k < op.count; k++) mn = min(mn, cnt(side[op.b + k]));
-        cnt(op.a) = mn;
-        break;
-      }
-      default:
-        break;
-    }
-  }
+  for (int64_t o = 0; o < op_count; o++)
+    PatternOp(ops[o], p, side, plv, counts, bl, q, ll, marginal, Ppad, threshold, log_threshold);
 }
 
 // block per row: out[row] = sum_p w_p * rows[row][p]
@@ -340,6 +346,103 @@ __device__ void BrentMinimize(const EdgeFunction& f, bool with_gradients, double
   *fx_out = fx;
 }
 
+// The whole optimisation of one edge by one workgroup of 256 threads; sh[12] and sh_resc[4] are LDS scratch,
+// coef holds 2 * Ppad doubles private to the workgroup.
+__device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict__ plv, const int* __restrict__ counts,
+                             const double* __restrict__ weights, double* __restrict__ bl, double* __restrict__ diff,
+                             double* __restrict__ coef, double* sh, double* sh_resc, int P, int Ppad,
+                             double log_threshold, const OptSettings& cfg) {
+  // a = leafward_, b = rootward_, c = gpcsp_ (src/gp_operation.hpp:118-127)
+  const uint64_t leafward = op.a, rootward = op.b, edge = op.c;
+  __syncthreads();  // bl / diff writes of the previous op are visible; coef may be overwritten
+  if (cfg.check_convergence && diff[edge] < kDiffThreshold) return;  // dag_branch_handler.cpp:127-131
+  // eigenbasis coefficients: l_p(t) = sum_k (r^T V)_k (V^-1 x)_k exp(lambda_k t)
+  double resc = 0;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    double r[4], x[4];
+    for (int i = 0; i < 4; i++) {
+      r[i] = plv[((size_t)rootward * 4 + i) * Ppad + p];
+      x[i] = plv[((size_t)leafward * 4 + i) * Ppad + p];
+    }
+    double c[4];
+    for (int k = 0; k < 4; k++) {
+      const double rv = r[0] * cV[k] + r[1] * cV[4 + k] + r[2] * cV[8 + k] + r[3] * cV[12 + k];
+      const double vx = cVi[k * 4] * x[0] + cVi[k * 4 + 1] * x[1] + cVi[k * 4 + 2] * x[2] + cVi[k * 4 + 3] * x[3];
+      c[k] = rv * vx;
+    }
+    coef[p] = c[0];
+    coef[Ppad + p] = c[1] + c[2] + c[3];
+    resc += weights[p] * ((counts[(size_t)rootward * Ppad + p] + counts[(size_t)leafward * Ppad + p]) * log_threshold);
+  }
+  for (int s = 32; s > 0; s >>= 1) resc += __shfl_xor(resc, s);
+  if ((threadIdx.x & 63) == 0) sh_resc[threadIdx.x >> 6] = resc;
+  __syncthreads();
+  const EdgeFunction f{coef, coef + Ppad, weights, sh, sh_resc[0] + sh_resc[1] + sh_resc[2] + sh_resc[3], P};
+  const double current = bl[edge];
+  double result = current;
+  switch (cfg.method) {
+    case 0:
+    case 1: {  // BrentOptimization(WithGradients), dag_branch_handler.cpp:150-211
+      const double cur_log = log(current);
+      const double cur_nll = f.NegLL(cur_log);
+      double x, fx;
+      BrentMinimize(f, cfg.method == 1, cur_log, kMinLogBl, kMaxLogBl, cfg.significant_digits, kOptMaxIter, kLogStep,
+                    &x, &fx);
+      result = fx > cur_nll ? exp(cur_log) : exp(x);
+      break;
+    }
+    case 2: {  // GradientAscent (optimization.hpp:333-347); the floor is the handler's min LOG length, as there
+      const double tolerance = pow(10.0, -cfg.significant_digits);
+      double x = current;
+      for (int iter = 0;; iter++) {
+        double v[3];
+        f(x, v);
+        x = fmax(x + v[1] * kStep, kMinLogBl);
+        if (fabs(v[1]) < fabs(v[0]) * tolerance || iter >= kOptMaxIter) break;
+      }
+      result = x;
+      break;
+    }
+    case 3: {  // LogSpaceGradientAscent (optimization.hpp:349-367)
+      const double tolerance = pow(10.0, -cfg.significant_digits), min_x = exp(kMinLogBl);
+      double x = current;
+      for (int iter = 0;; iter++) {
+        double v[3];
+        const double y = log(x);
+        f(x, v);
+        x = fmax(exp(y + x * v[1] * kLogStep), min_x);
+        if (fabs(v[1]) < fabs(v[0]) * tolerance || iter >= kOptMaxIter) break;
+      }
+      result = x;
+      break;
+    }
+    default: {  // NewtonRaphsonOptimization in the log length (optimization.hpp:369-405, gp_engine.cpp:643-655)
+      const double tolerance = pow(10.0, -cfg.significant_digits);
+      double x = log(current);
+      for (int iter = 0;; iter++) {
+        double v[3];
+        const double t = exp(x);
+        f(t, v);
+        const double f1 = t * v[1], f2 = f1 + t * t * v[2];
+        if (fabs(f2) < kNewtonEps) break;
+        double new_x = x - f1 / f2;
+        if (new_x < kMinLogBl) new_x = x - 0.5 * (x - kMinLogBl);
+        if (new_x > kMaxLogBl) new_x = x - 0.5 * (x - kMaxLogBl);
+        const double delta = fabs(x - new_x);
+        if (delta < tolerance || fabs(f1) < fabs(v[0]) * tolerance || iter == kOptMaxIter) break;
+        x = new_x;
+      }
+      result = exp(x);
+      break;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bl[edge] = result;
+    diff[edge] = fabs(current - result);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 gp_optimize_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const double* __restrict__ plv,
                    const int* __restrict__ counts, const double* __restrict__ weights, double* __restrict__ bl,
@@ -347,95 +450,34 @@ gp_optimize_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, con
                    OptSettings cfg) {
   __shared__ double sh[12];
   __shared__ double sh_resc[4];
-  for (int64_t o = 0; o < op_count; o++) {
-    const bito_amd_gp_op op = ops[o];  // a = leafward_, b = rootward_, c = gpcsp_ (src/gp_operation.hpp:118-127)
-    const uint64_t leafward = op.a, rootward = op.b, edge = op.c;
-    __syncthreads();  // bl / diff writes of the previous op are visible; coef may be overwritten
-    if (cfg.check_convergence && diff[edge] < kDiffThreshold) continue;  // dag_branch_handler.cpp:127-131
-    // eigenbasis coefficients: l_p(t) = sum_k (r^T V)_k (V^-1 x)_k exp(lambda_k t)
-    double resc = 0;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) {
-      double r[4], x[4];
-      for (int i = 0; i < 4; i++) {
-        r[i] = plv[((size_t)rootward * 4 + i) * Ppad + p];
-        x[i] = plv[((size_t)leafward * 4 + i) * Ppad + p];
-      }
-      double c[4];
-      for (int k = 0; k < 4; k++) {
-        const double rv = r[0] * cV[k] + r[1] * cV[4 + k] + r[2] * cV[8 + k] + r[3] * cV[12 + k];
-        const double vx = cVi[k * 4] * x[0] + cVi[k * 4 + 1] * x[1] + cVi[k * 4 + 2] * x[2] + cVi[k * 4 + 3] * x[3];
-        c[k] = rv * vx;
-      }
-      coef[p] = c[0];
-      coef[Ppad + p] = c[1] + c[2] + c[3];
-      resc += weights[p] * ((counts[(size_t)rootward * Ppad + p] + counts[(size_t)leafward * Ppad + p]) * log_threshold);
-    }
-    for (int s = 32; s > 0; s >>= 1) resc += __shfl_xor(resc, s);
-    if ((threadIdx.x & 63) == 0) sh_resc[threadIdx.x >> 6] = resc;
-    __syncthreads();
-    const EdgeFunction f{coef, coef + Ppad, weights, sh, sh_resc[0] + sh_resc[1] + sh_resc[2] + sh_resc[3], P};
-    const double current = bl[edge];
-    double result = current;
-    switch (cfg.method) {
-      case 0:
-      case 1: {  // BrentOptimization(WithGradients), dag_branch_handler.cpp:150-211
-        const double cur_log = log(current);
-        const double cur_nll = f.NegLL(cur_log);
-        double x, fx;
-        BrentMinimize(f, cfg.method == 1, cur_log, kMinLogBl, kMaxLogBl, cfg.significant_digits, kOptMaxIter, kLogStep,
-                      &x, &fx);
-        result = fx > cur_nll ? exp(cur_log) : exp(x);
-        break;
-      }
-      case 2: {  // GradientAscent (optimization.hpp:333-347); the floor is the handler's min LOG length, as there
-        const double tolerance = pow(10.0, -cfg.significant_digits);
-        double x = current;
-        for (int iter = 0;; iter++) {
-          double v[3];
-          f(x, v);
-          x = fmax(x + v[1] * kStep, kMinLogBl);
-          if (fabs(v[1]) < fabs(v[0]) * tolerance || iter >= kOptMaxIter) break;
-        }
-        result = x;
-        break;
-      }
-      case 3: {  // LogSpaceGradientAscent (optimization.hpp:349-367)
-        const double tolerance = pow(10.0, -cfg.significant_digits), min_x = exp(kMinLogBl);
-        double x = current;
-        for (int iter = 0;; iter++) {
-          double v[3];
-          const double y = log(x);
-          f(x, v);
-          x = fmax(exp(y + x * v[1] * kLogStep), min_x);
-          if (fabs(v[1]) < fabs(v[0]) * tolerance || iter >= kOptMaxIter) break;
-        }
-        result = x;
-        break;
-      }
-      default: {  // NewtonRaphsonOptimization in the log length (optimization.hpp:369-405, gp_engine.cpp:643-655)
-        const double tolerance = pow(10.0, -cfg.significant_digits);
-        double x = log(current);
-        for (int iter = 0;; iter++) {
-          double v[3];
-          const double t = exp(x);
-          f(t, v);
-          const double f1 = t * v[1], f2 = f1 + t * t * v[2];
-          if (fabs(f2) < kNewtonEps) break;
-          double new_x = x - f1 / f2;
-          if (new_x < kMinLogBl) new_x = x - 0.5 * (x - kMinLogBl);
-          if (new_x > kMaxLogBl) new_x = x - 0.5 * (x - kMaxLogBl);
-          const double delta = fabs(x - new_x);
-          if (delta < tolerance || fabs(f1) < fabs(v[0]) * tolerance || iter == kOptMaxIter) break;
-          x = new_x;
-        }
-        result = exp(x);
-        break;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      bl[edge] = result;
-      diff[edge] = fabs(current - result);
+  for (int64_t o = 0; o < op_count; o++)
+    OptimizeEdge(ops[o], plv, counts, weights, bl, diff, coef, sh, sh_resc, P, Ppad, log_threshold, cfg);
+}
+
+// A workgroup interprets a whole sub-stream, per-pattern ops and optimiser ops alike: thread t owns the
+// patterns t, t + 256, ... in every op, so per-pattern ops need no barrier between them; an optimiser op
+// is a block-wide reduction and publishes the new branch length to the whole workgroup.  Grid = one
+// workgroup per independent sub-stream (NNI proposals with optimize_new_edges).
+__global__ void __launch_bounds__(256)
+gp_block_stream_kernel(const bito_amd_gp_op* __restrict__ ops, const int64_t* __restrict__ offsets,
+                       const uint64_t* __restrict__ side, double* __restrict__ plv, int* __restrict__ counts,
+                       const double* __restrict__ weights, double* __restrict__ bl, const double* __restrict__ q,
+                       double* __restrict__ ll, double* __restrict__ marginal, double* __restrict__ diff,
+                       double* __restrict__ coef, int P, int Ppad, double threshold, double log_threshold,
+                       OptSettings cfg) {
+  __shared__ double sh[12];
+  __shared__ double sh_resc[4];
+  const int64_t first = offsets[blockIdx.x], last = offsets[blockIdx.x + 1];
+  double* my_coef = coef + (size_t)blockIdx.x * 2 * Ppad;
+  for (int64_t o = first; o < last; o++) {
+    const bito_amd_gp_op op = ops[o];
+    if (op.opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH) {
+      OptimizeEdge(op, plv, counts, weights, bl, diff, my_coef, sh, sh_resc, P, Ppad, log_threshold, cfg);
+      __threadfence_block();
+      __syncthreads();  // bl[edge] of thread 0 is visible to every thread's next op
+    } else {
+      for (int p = threadIdx.x; p < P; p += blockDim.x)
+        PatternOp(op, p, side, plv, counts, bl, q, ll, marginal, Ppad, threshold, log_threshold);
     }
   }
 }
@@ -637,7 +679,7 @@ static int ValidateAndUpload(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, i
         ok = plv_ok(op.a) && op.count > 0 && side && op.b + op.count <= (uint64_t)side_count;
         for (uint32_t k = 0; ok && k < op.count; k++) ok = plv_ok(side[op.b + k]);
         break;
-      case BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH: ok = !batched && plv_ok(op.a) && plv_ok(op.b) && gp_ok(op.c); break;
+      case BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH: ok = plv_ok(op.a) && plv_ok(op.b) && gp_ok(op.c); break;
       default:
         return Fail(e, BITO_AMD_ERR_BAD_ARG, "unknown GP opcode " + std::to_string(op.opcode));
     }
@@ -737,9 +779,26 @@ int bito_amd_gp_process_operation_batches(bito_amd_gp_engine* e, const bito_amd_
     e->offsets_cap = batch_count + 1;
   }
   GP_TRY(e, hipMemcpy(e->d_offsets, offsets, (batch_count + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64, (unsigned)batch_count), dim3(64), 0, 0, e->d_ops,
-                     (int64_t)0, (const int64_t*)e->d_offsets, e->d_side, e->plv, e->counts, e->bl, e->q, e->ll,
-                     e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
+  bool has_optimiser = false;
+  for (int64_t o = 0; o < op_count && !has_optimiser; o++) has_optimiser = ops[o].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH;
+  if (!has_optimiser) {
+    hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64, (unsigned)batch_count), dim3(64), 0, 0, e->d_ops,
+                       (int64_t)0, (const int64_t*)e->d_offsets, e->d_side, e->plv, e->counts, e->bl, e->q, e->ll,
+                       e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
+  } else {
+    // optimiser ops reduce over all patterns: one workgroup per sub-stream interprets everything
+    if ((size_t)batch_count > e->coef_blocks) {
+      (void)hipFree(e->coef);
+      e->coef = nullptr;
+      e->coef_blocks = 0;
+      GP_TRY(e, hipMalloc((void**)&e->coef, (size_t)batch_count * 2 * e->Ppad * sizeof(double)));
+      e->coef_blocks = batch_count;
+    }
+    const OptSettings cfg{e->method, e->significant_digits, e->optimization_count != 0};
+    hipLaunchKernelGGL(gp_block_stream_kernel, dim3((unsigned)batch_count), dim3(256), 0, 0, e->d_ops,
+                       (const int64_t*)e->d_offsets, e->d_side, e->plv, e->counts, e->weights, e->bl, e->q, e->ll,
+                       e->marginal, e->diff, e->coef, e->P, e->Ppad, e->threshold, e->log_threshold, cfg);
+  }
   GP_TRY(e, hipGetLastError());
   GP_TRY(e, hipDeviceSynchronize());
   return BITO_AMD_OK;

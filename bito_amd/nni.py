@@ -21,8 +21,8 @@ from typing import Dict, List, NamedTuple, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .gp import (INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, LIKELIHOOD, MULTIPLY, P, R_LEFT, R_RIGHT, SET_TO_STATIONARY,
-                 ZERO_PLV, OpStream)
+from .gp import (INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, LIKELIHOOD, MULTIPLY, OPTIMIZE_BRANCH_LENGTH, P, R_LEFT, R_RIGHT,
+                 SET_TO_STATIONARY, ZERO_PLV, OpStream)
 from .gp_dag import SubsplitDAG
 
 Subsplit = Tuple[int, int]
@@ -141,11 +141,15 @@ def nni_edge_sources(dag: SubsplitDAG, pre: NNI, nni: NNI) -> Dict[Tuple[Optiona
 
 
 def build_proposal(dag: SubsplitDAG, nni: NNI, spare_plv_base: int, spare_edge_base: int, plv_count: int,
-                   pre_nni: Optional[NNI] = None) -> NNIProposal:
+                   pre_nni: Optional[NNI] = None, optimize_new_edges: bool = False,
+                   optimization_max_iteration: int = 10) -> NNIProposal:
     """Operation list of NNIEvalEngineViaGP::ComputeAdjacentNNILikelihood (rootward pass, leafward
     pass, likelihood of the central edge; src/nni_evaluation_engine.cpp:206-461) on this proposal's
     own spare slots.  ``spare_edge_base`` is the first GPCSP id it may use, ``plv_count`` the
-    number of PLVs of the DAG itself (6 * node_count)."""
+    number of PLVs of the DAG itself (6 * node_count).  With ``optimize_new_edges`` the list carries
+    the reference's NNIBranchLengthOptimization round (left children, right children, sisters,
+    central, parents; each followed by the refresh of the partial vector it feeds) and a leafward
+    pass, ``optimization_max_iteration`` times, before the final passes."""
     pre = pre_nni or find_nni_neighbor_in_dag(dag, nni)
     adj, pre_central = _adjacent_by_clade(dag, pre)
     pv = lambda k: plv_count + spare_plv_base + k
@@ -174,24 +178,83 @@ def build_proposal(dag: SubsplitDAG, nni: NNI, spare_plv_base: int, spare_edge_b
         for src, e in zip(sources, edges):
             s.add(INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, dest, e, src)
 
-    # rootward
-    gather(pv(CHILD_PHAT_LEFT), [dag.pv(P, k) for k in left.nodes], e_left)
-    gather(pv(CHILD_PHAT_RIGHT), [dag.pv(P, k) for k in right.nodes], e_right)
-    s.add(MULTIPLY, pv(CHILD_P), pv(CHILD_PHAT_LEFT), pv(CHILD_PHAT_RIGHT))
-    gather(pv(PARENT_PHAT_FOCAL), [pv(CHILD_P)], [central])
-    gather(pv(PARENT_PHAT_SISTER), [dag.pv(P, k) for k in sis.nodes], e_sis)
-    s.add(MULTIPLY, pv(PARENT_P), pv(PARENT_PHAT_FOCAL), pv(PARENT_PHAT_SISTER))
-    # leafward
-    if up.nodes == [-1]:
-        s.add(ZERO_PLV, pv(PARENT_RHAT))
-        s.add(SET_TO_STATIONARY, pv(PARENT_RHAT), e_up[0])
-    else:
-        gather(pv(PARENT_RHAT), [dag.pv(R_LEFT if side else R_RIGHT, g) for g, side in zip(up.nodes, up.sides)], e_up)
-    s.add(MULTIPLY, pv(PARENT_R_FOCAL), pv(PARENT_RHAT), pv(PARENT_PHAT_SISTER))
-    gather(pv(CHILD_RHAT), [pv(PARENT_R_FOCAL)], [central])
-    s.add(MULTIPLY, pv(PARENT_R_SISTER), pv(PARENT_RHAT), pv(PARENT_PHAT_FOCAL))
-    s.add(MULTIPLY, pv(CHILD_R_LEFT), pv(CHILD_RHAT), pv(CHILD_PHAT_RIGHT))
-    s.add(MULTIPLY, pv(CHILD_R_RIGHT), pv(CHILD_RHAT), pv(CHILD_PHAT_LEFT))
+    left_p, right_p, sis_p = ([dag.pv(P, k) for k in adj.nodes] for adj in (left, right, sis))
+    at_root = up.nodes == [-1]
+    up_r = [] if at_root else [dag.pv(R_LEFT if side else R_RIGHT, g) for g, side in zip(up.nodes, up.sides)]
+
+    def optimize(rootward: int, leafward: int, edge: int):
+        s.add(OPTIMIZE_BRANCH_LENGTH, leafward, rootward, edge)
+
+    # the ten partial-vector updates of an NNI (Update*Rootward / Update*Leafward lambdas of the reference)
+    def left_rootward():
+        gather(pv(CHILD_PHAT_LEFT), left_p, e_left)
+
+    def right_rootward():
+        gather(pv(CHILD_PHAT_RIGHT), right_p, e_right)
+
+    def central_rootward():
+        s.add(MULTIPLY, pv(CHILD_P), pv(CHILD_PHAT_LEFT), pv(CHILD_PHAT_RIGHT))
+        gather(pv(PARENT_PHAT_FOCAL), [pv(CHILD_P)], [central])
+
+    def sister_rootward():
+        gather(pv(PARENT_PHAT_SISTER), sis_p, e_sis)
+
+    def parent_rootward():
+        s.add(MULTIPLY, pv(PARENT_P), pv(PARENT_PHAT_FOCAL), pv(PARENT_PHAT_SISTER))
+
+    def parent_leafward():
+        if at_root:
+            s.add(ZERO_PLV, pv(PARENT_RHAT))
+            s.add(SET_TO_STATIONARY, pv(PARENT_RHAT), e_up[0])
+        else:
+            gather(pv(PARENT_RHAT), up_r, e_up)
+
+    def central_leafward():
+        s.add(MULTIPLY, pv(PARENT_R_FOCAL), pv(PARENT_RHAT), pv(PARENT_PHAT_SISTER))
+        gather(pv(CHILD_RHAT), [pv(PARENT_R_FOCAL)], [central])
+
+    def sister_leafward():
+        s.add(MULTIPLY, pv(PARENT_R_SISTER), pv(PARENT_RHAT), pv(PARENT_PHAT_FOCAL))
+
+    def left_leafward():
+        s.add(MULTIPLY, pv(CHILD_R_LEFT), pv(CHILD_RHAT), pv(CHILD_PHAT_RIGHT))
+
+    def right_leafward():
+        s.add(MULTIPLY, pv(CHILD_R_RIGHT), pv(CHILD_RHAT), pv(CHILD_PHAT_LEFT))
+
+    def rootward_pass():
+        left_rootward(), right_rootward(), central_rootward(), sister_rootward(), parent_rootward()
+
+    def leafward_pass():
+        parent_leafward(), central_leafward(), sister_leafward(), left_leafward(), right_leafward()
+
+    if optimize_new_edges:
+        rootward_pass()
+        leafward_pass()
+        for _ in range(optimization_max_iteration):
+            for src, e in zip(left_p, e_left):  # OptimizeLeftChild
+                optimize(pv(CHILD_R_LEFT), src, e)
+            left_rootward()
+            for src, e in zip(right_p, e_right):  # OptimizeRightChild
+                optimize(pv(CHILD_R_RIGHT), src, e)
+            right_rootward()
+            sister_leafward()  # OptimizeSister
+            for src, e in zip(sis_p, e_sis):
+                optimize(pv(PARENT_R_SISTER), src, e)
+            sister_rootward()
+            central_leafward()  # OptimizeCentral
+            optimize(pv(PARENT_R_FOCAL), pv(CHILD_P), central)
+            central_rootward()
+            parent_leafward()  # OptimizeParent: nothing to optimise above a rootsplit
+            if at_root:
+                pass
+            else:
+                for src, e in zip(up_r, e_up):
+                    optimize(src, pv(PARENT_P), e)
+                parent_rootward()
+            leafward_pass()
+    rootward_pass()
+    leafward_pass()
     s.add(LIKELIHOOD, central, pv(PARENT_R_FOCAL), pv(CHILD_P))
     return NNIProposal(nni, pre, spare_plv_base, central, copy_src, copy_dst, s)
 
@@ -200,9 +263,13 @@ class NNIEvalEngineViaGP:
     """``NNIEvalEngineViaGP`` over a GPEngine mirror (anything with its methods: the GPU executor in
     production, the CPU checker in the tests)."""
 
-    def __init__(self, dag: SubsplitDAG, engine, include_rootsplit_nnis: bool = True):
+    def __init__(self, dag: SubsplitDAG, engine, include_rootsplit_nnis: bool = True,
+                 optimize_new_edges: bool = False, optimization_max_iteration: int = 10):
         self.dag, self.engine = dag, engine
         self.include_rootsplit_nnis = include_rootsplit_nnis
+        # SetOptimizeNewEdges / SetOptimizationMaxIteration (src/nni_evaluation_engine.hpp:127-138)
+        self.optimize_new_edges = optimize_new_edges
+        self.optimization_max_iteration = optimization_max_iteration
         self.scored_nnis: Dict[NNI, float] = {}
         self.proposals: List[NNIProposal] = []
 
@@ -230,7 +297,9 @@ class NNIEvalEngineViaGP:
         self.proposals = []
         edge_base = self.dag.gpcsp_count
         for i, nni in enumerate(nnis):
-            prop = build_proposal(self.dag, nni, SPARE_PLVS_PER_NNI * i, edge_base, plv_count)
+            prop = build_proposal(self.dag, nni, SPARE_PLVS_PER_NNI * i, edge_base, plv_count,
+                                  optimize_new_edges=self.optimize_new_edges,
+                                  optimization_max_iteration=self.optimization_max_iteration)
             edge_base += len(prop.copy_dst)
             self.proposals.append(prop)
         self.engine.grow_spare(SPARE_PLVS_PER_NNI * len(nnis), edge_base - self.dag.gpcsp_count)

@@ -97,7 +97,9 @@ int bito_amd_gp_copy_gpcsp_data(bito_amd_gp_engine *e, const int64_t *src, const
  * The caller guarantees that no sub-stream writes a PLV or GPCSP slot another one reads or writes --
  * e.g. one sub-stream per proposed NNI, each on its own spare slots (the reference runs
  * NNIEvalEngineViaGP::ComputeAdjacentNNILikelihood once per NNI, src/nni_evaluation_engine.cpp:206-461).
- * Only the per-pattern PLV ops and Likelihood are allowed (no marginal, SBN or optimiser ops). */
+ * Per-pattern PLV ops, Likelihood and OptimizeBranchLength are allowed (no marginal or SBN ops, which
+ * share state across sub-streams).  Without optimiser ops the grid is pattern tiles x sub-streams; with
+ * them one workgroup per sub-stream interprets its whole list (an optimiser op reduces over all patterns). */
 int bito_amd_gp_process_operation_batches(bito_amd_gp_engine *e, const bito_amd_gp_op *ops, int64_t op_count,
                                           const uint64_t *side, int64_t side_count, const int64_t *offsets,
                                           int64_t batch_count);

@@ -231,3 +231,89 @@ def test_batch_rejects_coupled_ops_and_bad_offsets(data_dir):
     eng.process_operations(s)
     with pytest.raises(BitoAmdError):
         eng.copy_gpcsp_data([0], [dag.gpcsp_count])
+
+
+# -- optimize_new_edges: branch lengths around the proposal optimised on its spare edges before scoring --
+
+def _optimised_scores(make_engine, sp, dag, bl, method, max_iter):
+    eng = make_engine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+    eng.set_branch_lengths(bl)
+    eng.set_sbn_parameters(np.ones(dag.gpcsp_count))
+    eng.set_optimization_method(method)
+    ev = NNIEvalEngineViaGP(dag, eng, optimize_new_edges=True, optimization_max_iteration=max_iter)
+    ev.prep()
+    scores = ev.score_adjacent_nnis()
+    first = dag.gpcsp_count
+    lengths = eng.get_branch_lengths_range(first, sum(len(p.copy_dst) for p in ev.proposals))
+    return scores, lengths, ev, eng
+
+
+def test_optimised_proposal_reaches_the_maximum_likelihood_of_its_tree(data_dir):
+    """hello has three taxa: a proposal's neighbourhood is its whole tree, all four of whose branches
+    (central, sister, two children; nothing is optimised above a rootsplit) are optimised, so the score
+    must approach the maximum likelihood of that rooted topology -- found here by scipy on the per-tree
+    checker, which shares no code with the GP route."""
+    from scipy.optimize import minimize
+
+    from oracle import gp as ogp
+    from oracle import oracle
+
+    sp, dag = _load(data_dir, "hello.fasta", "hello_rooted_diff_branches.nwk")
+    bl = np.full(dag.gpcsp_count, 0.1)
+    plain = NNIEvalEngineViaGP(dag, ogp.OracleGPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count))
+    plain.engine.set_branch_lengths(bl)
+    plain.engine.set_sbn_parameters(np.ones(dag.gpcsp_count))
+    plain.prep()
+    unoptimised = plain.score_adjacent_nnis()
+    scores, lengths, ev, _ = _optimised_scores(ogp.OracleGPEngine, sp, dag, bl, 0, 10)
+    cpu = oracle.OracleEngine("JC69", "constant", "none", sp.patterns, sp.weights, 1)
+    for prop in ev.proposals:
+        assert scores[prop.nni] >= unoptimised[prop.nni] - 1e-12
+        truth = dag.with_node_pair(prop.nni.parent, prop.nni.child)
+        e = truth.edge(truth.node_id[prop.nni.parent], truth.node_id[prop.nni.child])
+        (pid, edges), = [(pid, edges) for pid, edges in truth.all_trees() if e in edges]
+
+        def negative_ll(x):
+            return -cpu.log_likelihoods(pid[None, :], np.append(np.exp(x), 0.0)[None, :])[0]
+
+        best = minimize(negative_ll, np.log(np.full(4, 0.1)), method="Nelder-Mead",
+                        options={"xatol": 1e-10, "fatol": 1e-12, "maxiter": 4000})
+        # Brent brackets to 10 bits (significant_digits_for_optimization_ = 10): measured 1.1e-5 below the maximum
+        assert abs(scores[prop.nni] + best.fun) < 1e-4, (scores[prop.nni], -best.fun)
+        assert scores[prop.nni] <= -best.fun + 1e-9  # never above the maximum
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [0, 4])
+@pytest.mark.parametrize("fasta,newick", CASES[:2])
+def test_optimised_proposals_batched_gpu_equals_cpu(data_dir, fasta, newick, method):
+    """One workgroup per proposal interpreting PLV ops and optimiser ops alike = the same lists through
+    ProcessOperations one proposal at a time (bit for bit) = the CPU checker (Newton: 1e-7; Brent
+    brackets to 10 bits and its accept/reject decisions flip on the last bit of exp/log, so on these
+    8-site alignments single proposals end up to 0.1 apart -- as in test_gp.py, only loosely compared)."""
+    from bito_amd import gp
+    from oracle import gp as ogp
+
+    sp, dag = _load(data_dir, fasta, newick)
+    bl = np.random.default_rng(3).uniform(0.05, 0.3, dag.gpcsp_count)
+    g_scores, g_len, ev, eng = _optimised_scores(gp.GPEngine, sp, dag, bl, method, 4)
+    c_scores, c_len, _, _ = _optimised_scores(ogp.OracleGPEngine, sp, dag, bl, method, 4)
+    assert g_scores.keys() == c_scores.keys() and len(g_scores) > 0
+    diffs = np.array([abs(g_scores[k] - c_scores[k]) for k in g_scores])
+    if method == 4:
+        assert diffs.max() < 1e-7
+        assert np.allclose(g_len, c_len, rtol=5e-6, atol=1e-7)
+    else:
+        assert diffs.max() < 0.2 and np.median(diffs) < 1e-3
+    src = [x for p in ev.proposals for x in p.copy_src]
+    assert not np.allclose(g_len, bl[src])  # lengths did move
+    assert np.array_equal(eng.get_branch_lengths(), bl)  # the DAG's own branch lengths are not touched
+    # the sequential route on the same slots, from the same starting lengths
+    eng.copy_gpcsp_data(src, [x for p in ev.proposals for x in p.copy_dst])
+    for prop in ev.proposals:
+        eng.process_operations(prop.stream)
+    first = dag.gpcsp_count
+    again = eng.get_per_gpcsp_log_likelihoods_range(first, len(src))
+    for prop in ev.proposals:
+        assert again[prop.central_edge - first] == g_scores[prop.nni]
+    assert np.array_equal(eng.get_branch_lengths_range(first, len(src)), g_len)
