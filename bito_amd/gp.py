@@ -174,15 +174,17 @@ class SingleTreeDAG:
 BRENT, BRENT_WITH_GRADIENTS, GRADIENT_ASCENT, LOGSPACE_GRADIENT_ASCENT, NEWTON = range(5)
 
 
-def estimate_branch_lengths(engine, dag: "SingleTreeDAG", tol: float, max_iter: int, method=None) -> int:
+def estimate_branch_lengths(engine, dag, tol: float, max_iter: int, method=None, **schedule_options) -> int:
     """``GPInstance::EstimateBranchLengths`` (reference src/gp_instance.cpp:241-300): sweeps of
     BranchLengthOptimization + PopulatePLVs + MarginalLikelihood until the mean absolute change
     of the branch lengths drops below ``tol``.  Works with any engine exposing the GPEngine
-    mirror's methods; returns the number of sweeps."""
+    mirror's methods and with either DAG (``SingleTreeDAG`` or ``gp_dag.SubsplitDAG``;
+    ``schedule_options`` go to its ``branch_length_optimization``); returns the number of sweeps."""
     if method is not None:
         engine.set_optimization_method(method)
     engine.reset_optimization_count()
-    optimize, populate, marginal = dag.branch_length_optimization(), dag.populate_plvs(), dag.marginal_likelihood()
+    optimize = dag.branch_length_optimization(**schedule_options)
+    populate, marginal = dag.populate_plvs(), dag.marginal_likelihood()
     engine.process_operations(populate)
     engine.process_operations(marginal)
     sweeps = 0

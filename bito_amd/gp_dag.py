@@ -21,8 +21,8 @@ from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 
-from .gp import (INCREMENT_MARGINAL_LIKELIHOOD, INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, LIKELIHOOD, MULTIPLY, P, PHAT_LEFT,
-                 PHAT_RIGHT, RESET_MARGINAL_LIKELIHOOD, RHAT, R_LEFT, R_RIGHT, SET_TO_STATIONARY,
+from .gp import (INCREMENT_MARGINAL_LIKELIHOOD, INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, LIKELIHOOD, MULTIPLY,
+                 OPTIMIZE_BRANCH_LENGTH, P, PHAT_LEFT, PHAT_RIGHT, RESET_MARGINAL_LIKELIHOOD, RHAT, R_LEFT, R_RIGHT, SET_TO_STATIONARY,
                  UPDATE_SBN_PROBABILITIES, ZERO_PLV, OpStream)
 
 
@@ -233,6 +233,151 @@ class SubsplitDAG:
             if stop - start > 1:
                 s.add(UPDATE_SBN_PROBABILITIES, start, stop)
         s.add(UPDATE_SBN_PROBABILITIES, 0, len(self.rootsplits))
+        return s
+
+    # -- GPDAG::BranchLengthOptimization (src/gp_dag.cpp:126-175) over the tidy depth-first traversal
+    #    (TidySubsplitDAG, src/tidy_subsplit_dag.hpp:66-173, src/tidy_subsplit_dag.cpp:49-99) ---------
+    def _tidy_state(self):
+        """below[side][v]: v and every node under its ``side`` clade (the columns of the reference's
+        above_rotated_ / above_sorted_ matrices); dirty[side]: node-clades whose p-hat is stale.  Like the
+        reference's, the dirty flags live as long as the DAG object."""
+        if not hasattr(self, "_below"):
+            below = [[{v} for v in range(self.node_count)] for _ in (0, 1)]
+            for v in range(self.node_count):  # children have smaller ids: their sets are complete
+                for side in (0, 1):
+                    for c in self.children[v][side]:
+                        below[side][v] |= below[0][c] | below[1][c]
+            self._below = below
+            self._above = [[set() for _ in range(self.node_count)] for _ in (0, 1)]  # (side, v) -> ancestors via side
+            for side in (0, 1):
+                for a in range(self.node_count):
+                    for v in below[side][a]:
+                        self._above[side][v].add(a)
+            self._dirty = [set(), set()]
+        return self._below, self._above, self._dirty
+
+    def set_clean(self):
+        """TidySubsplitDAG::SetClean."""
+        self._tidy_state()
+        self._dirty = [set(), set()]
+
+    def above_node(self, side: int, node: int):
+        """TidySubsplitDAG::AboveNode(is_edge_on_left, node) without the DAG root: the nodes whose ``side``
+        clade holds ``node``, and ``node`` itself."""
+        return set(self._tidy_state()[1][side][node])
+
+    def below_node(self, side: int, node: int):
+        return set(self._tidy_state()[0][side][node])
+
+    def set_dirty_strictly_above(self, node: int):
+        below, above, dirty = self._tidy_state()
+        for side in (0, 1):
+            dirty[side] |= above[side][node] - {node}
+
+    def dirty_vector(self, side: int):
+        return set(self._tidy_state()[2][side])
+
+    def _update_rhat(self, s: OpStream, node: int):
+        """GPDAG::UpdateRHat (src/gp_dag.cpp:349-363): parents through their right clade first."""
+        s.add(ZERO_PLV, self.pv(RHAT, node))
+        srcs = [(self.pv(R_LEFT if side else R_RIGHT, p), self.edge(p, node))
+                for want in (0, 1) for p, side in self.parents[node] if side == want]
+        s.prep_for_marginalization(self.pv(RHAT, node), [src for src, _ in srcs])
+        for src, e in srcs:
+            s.add(INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, self.pv(RHAT, node), e, src)
+
+    def branch_length_optimization(self, edges_to_optimize=None, record=None, zero_before_update: bool = False) -> OpStream:
+        """One sweep of branch-length optimisation over the whole DAG.  An edge is optimised when the
+        traversal first comes down its parent's clade ("modify"); before a node's clade is entered, a
+        sister clade made stale by modifications further down (possible when a node has several
+        parents) is brought up to date without optimising ("update").  ``record`` collects the
+        traversal as (kind, node, child, side) tuples, like TidySubsplitDAG::RecordTraversal.
+
+        The reference's update step adds the refreshed children onto the p-hat without clearing it
+        first (UpdateEdge = UpdatePHatComputeLikelihood, no ZeroPLV; its own comments point at #321), so
+        while the sister clade is optimised that p-hat holds old + new.  That is what the default
+        emits.  ``zero_before_update=True`` clears the p-hat first; only then is the fixed point of the
+        sweeps a stationary point of every edge's likelihood (tests/test_gp.py)."""
+        below, above, dirty = self._tidy_state()
+        n = self.taxon_count
+        s = OpStream()
+        visited = set()
+        updating = [None]
+
+        def is_dirty_below(node, side):
+            return bool(below[side][node] & dirty[side])
+
+        def note(*event):
+            if record is not None:
+                record.append(event)
+
+        def phat(node, side):
+            return self.pv(PHAT_LEFT if side else PHAT_RIGHT, node)
+
+        def increment_phat(node, child, side, with_likelihood):
+            e = self.edge(node, child)
+            s.prep_for_marginalization(phat(node, side), [self.pv(P, child)])
+            s.add(INCREMENT_WITH_WEIGHTED_EVOLVED_PLV, phat(node, side), e, self.pv(P, child))
+            if with_likelihood:  # UpdatePHatComputeLikelihood (src/gp_dag.cpp:365-384)
+                s.add(LIKELIHOOD, e, self.pv(R_LEFT if side else R_RIGHT, node), self.pv(P, child))
+
+        def after_node(node):
+            s.add(MULTIPLY, self.pv(P, node), self.pv(PHAT_RIGHT, node), self.pv(PHAT_LEFT, node))
+
+        def for_node(node):
+            if node not in self.rootsplits:  # BeforeNode
+                self._update_rhat(s, node)
+            for_node_clade(node, 1)
+            for_node_clade(node, 0)
+            after_node(node)
+
+        def for_node_clade(node, side):
+            if updating[0] is not None:
+                update_clade(node, side)
+            else:
+                modify_clade(node, side)
+
+        def update_clade(node, side):
+            if is_dirty_below(node, side):
+                if zero_before_update:
+                    s.add(ZERO_PLV, phat(node, side))
+                for child in self.children[node][side]:
+                    if child >= n:
+                        for_node_clade(child, 1)
+                        for_node_clade(child, 0)
+                        after_node(child)
+                    note("update", node, child, side)
+                    increment_phat(node, child, side, True)
+                    dirty[side].discard(node)
+            if updating[0] == (node, side):
+                updating[0] = None
+
+        def modify_clade(node, side):
+            if is_dirty_below(node, 1 - side):
+                updating[0] = (node, 1 - side)
+                update_clade(node, 1 - side)
+            # BeforeNodeClade: RUpdateOfRotated, then the p-hat of this clade is rebuilt edge by edge
+            note("descend", node, -1, side)
+            if side:
+                s.add(MULTIPLY, self.pv(R_LEFT, node), self.pv(RHAT, node), self.pv(PHAT_RIGHT, node))
+            else:
+                s.add(MULTIPLY, self.pv(R_RIGHT, node), self.pv(RHAT, node), self.pv(PHAT_LEFT, node))
+            s.add(ZERO_PLV, phat(node, side))
+            for child in self.children[node][side]:
+                if child not in visited:
+                    visited.add(child)
+                    if child >= n:
+                        for_node(child)
+                note("modify", node, child, side)
+                e = self.edge(node, child)
+                if edges_to_optimize is None or e in edges_to_optimize:  # OptimizeBranchLengthUpdatePHat
+                    s.add(OPTIMIZE_BRANCH_LENGTH, self.pv(P, child), self.pv(R_LEFT if side else R_RIGHT, node), e)
+                increment_phat(node, child, side, False)
+                self.set_dirty_strictly_above(node)
+                dirty[side].discard(node)
+
+        for r in self.rootsplits:
+            for_node(r)
         return s
 
     # -- every tree the DAG spans (SubsplitDAG::GenerateAllTopologies, src/subsplit_dag.cpp:666-715) --

@@ -322,3 +322,151 @@ def test_gp_executor_composite_marginal(data_dir, fasta, newick):
         eng.process_operations(dag.compute_likelihoods())
         eng.process_operations(dag.optimize_sbn_parameters())
     assert np.abs(gpu.get_sbn_parameters() - cpu.get_sbn_parameters()).max() < 1e-10
+
+
+# -- f1 on multi-tree DAGs: GPDAG::BranchLengthOptimization over the tidy traversal ------------------
+
+def _motivating_dag():
+    """TidySubsplitDAG::MotivatingExample (src/tidy_subsplit_dag.cpp:149-153): (0,(1,(2,3))) and ((0,(2,3)),1)."""
+    tc = treeio.parse_newick_strings(["(x0,(x1,(x2,x3)));", "((x0,(x2,x3)),x1);"])
+    return gp_dag.SubsplitDAG(4, [t.parent_ids for t in tc.trees])
+
+
+def test_tidy_dag_slicing():
+    """"TidySubsplitDAG: slicing" (src/tidy_subsplit_dag.hpp:204-240) restated by subsplit: the reference's
+    node ids are 4 = 2|3, 5/6/7 = the nodes holding 2|3 in their right clade, 8 = 023|1, 9 = the DAG root
+    (which has no id here)."""
+    dag = _motivating_dag()
+    name = lambda ids: sorted(dag.subsplits[i] for i in ids)
+    n23, n0_23 = dag.node_id[(4, 8)], dag.node_id[(1, 12)]
+    assert name(dag.above_node(0, n23)) == sorted([(4, 8), (1, 12), (2, 12), (1, 14)])  # [0,0,0,0,1,1,1,1,0,0]
+    assert name(dag.above_node(1, n23)) == sorted([(4, 8), (13, 2)])  # [0,0,0,0,1,0,0,0,1,1] less the root
+    assert name(dag.above_node(0, n0_23)) == [(1, 12)]
+    assert name(dag.above_node(1, n0_23)) == sorted([(1, 12), (13, 2)])
+    assert name(dag.below_node(0, n0_23)) == sorted([(0, 4), (0, 8), (4, 8), (1, 12)])  # taxa 2, 3, node 2|3, itself
+    assert name(dag.below_node(1, n0_23)) == sorted([(0, 1), (1, 12)])
+    dag.set_dirty_strictly_above(n23)
+    assert name(dag.dirty_vector(1)) == [(13, 2)]
+    assert name(dag.dirty_vector(0)) == sorted([(1, 12), (2, 12), (1, 14)])
+    dag.set_clean()
+    assert not dag.dirty_vector(0) and not dag.dirty_vector(1)
+
+
+def test_tidy_traversal_modifies_every_edge_once_and_updates_where_needed():
+    """The motivating example is the one where a clade goes stale: 2|3 hangs under two parents, so by the
+    time the traversal reaches 0|23 its right p-hat was dirtied by the optimisation of 2|3's edges under
+    1|23 -- the traversal must bring it up to date before it descends (src/tidy_subsplit_dag.hpp:93-96)."""
+    dag = _motivating_dag()
+    record = []
+    stream = dag.branch_length_optimization(record=record)
+    modified = [(r[1], r[2]) for r in record if r[0] == "modify"]
+    non_root_edges = [k for k in dag.edge_id if k[0] >= 0]
+    assert sorted(modified) == sorted(non_root_edges) and len(set(modified)) == len(modified)
+    updates = [r for r in record if r[0] == "update"]
+    assert [(dag.subsplits[r[1]], dag.subsplits[r[2]], r[3]) for r in updates] == [((1, 12), (4, 8), 0)]
+    # the update comes before 0|23's first descent
+    first_descent = next(i for i, r in enumerate(record) if r[0] == "descend" and dag.subsplits[r[1]] == (1, 12))
+    assert record.index(updates[0]) < first_descent
+    ops = stream.arrays()[0]
+    assert (ops["opcode"] == gp.OPTIMIZE_BRANCH_LENGTH).sum() == len(non_root_edges)
+    # one tree: never an update
+    single = gp_dag.SubsplitDAG(4, [treeio.parse_newick_strings(["(x0,(x1,(x2,x3)));"]).trees[0].parent_ids])
+    record = []
+    single.branch_length_optimization(record=record)
+    assert not [r for r in record if r[0] == "update"]
+
+
+def _edge_key(dag, e):
+    (p, c), = [k for k, v in dag.edge_id.items() if v == e]
+    return (None if p < 0 else dag.subsplits[p], dag.subsplits[c])
+
+
+def test_multi_tree_schedule_equals_the_single_tree_schedule_on_one_tree(data_dir):
+    """The general traversal run on the DAG of ONE tree optimises to the same lengths as the single-tree
+    schedule (ids differ; edges are matched by the clade below them)."""
+    tc = treeio.read_newick_file(os.path.join(data_dir, "five_taxon_rooted.nwk"))
+    sp = SitePattern(treeio.read_fasta(os.path.join(data_dir, "five_taxon.fasta")), tc.taxon_names)
+    pid = tc.trees[0].parent_ids
+    general = gp_dag.SubsplitDAG(sp.taxon_count, [pid])
+    single = gp.single_tree_dag(pid)
+    clade = [1 << i for i in range(sp.taxon_count)] + [0] * (len(pid) + 1 - sp.taxon_count)
+    for c, p in enumerate(pid):
+        clade[p] |= clade[c]
+    results = []
+    for dag in (general, single):
+        eng = ogp.OracleGPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+        eng.set_branch_lengths(np.full(dag.gpcsp_count, 0.1))
+        eng.set_optimization_method(gp.NEWTON)
+        sweeps = gp.estimate_branch_lengths(eng, dag, 1e-8, 50)
+        results.append((eng.get_branch_lengths(), eng.get_log_marginal_likelihood(), sweeps))
+    (gb, gl, gs), (sb, sl, ss) = results
+    assert gs == ss and abs(gl - sl) < 1e-10
+    for e in range(general.gpcsp_count):
+        parent, child = _edge_key(general, e)
+        if parent is None:
+            continue
+        node = clade.index(child[0] | child[1])
+        assert abs(gb[e] - sb[single.edge(node)]) < 1e-10
+
+
+def _worst_edge_gradient(eng, dag):
+    """max over edges (away from the optimiser's bounds) of |d logL_e / d log t_e| with current PLVs."""
+    bl, worst = eng.get_branch_lengths(), 0.0
+    for (p, c), e in dag.edge_id.items():
+        if p < 0 or not 2e-6 < bl[e] < 2.9:
+            continue
+        side = 1 if c in dag.children[p][1] else 0
+        _, d1, _ = eng.log_likelihood_and_first_two_derivatives(e, dag.pv(gp.R_LEFT if side else gp.R_RIGHT, p), dag.pv(gp.P, c))
+        worst = max(worst, abs(d1 * bl[e]))
+    return worst
+
+
+@pytest.mark.parametrize("zero_before_update", [False, True])
+@pytest.mark.parametrize("fasta,newick", COMPOSITE_CASES)
+def test_estimate_branch_lengths_on_multi_tree_dags(data_dir, fasta, newick, zero_before_update):
+    """TestCompositeMarginal as the reference runs it (src/gp_doctest.cpp:210-232): EstimateBranchLengths
+    first, then the composite-marginal identity with the optimised lengths.  On top: the marginal went up
+    and the sweeps reach a fixed point.  With the p-hat cleared before an update (see
+    SubsplitDAG.branch_length_optimization) that fixed point is a stationary point of every edge's own
+    likelihood; with the reference's schedule it is not on ds1-reduced-5 (measured 2e-2 in d logL / d log t),
+    the one fixture where an update step fires on a clade with several parents' worth of mass."""
+    sp, dag, _ = _composite_case(data_dir, fasta, newick)
+    eng = ogp.OracleGPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+    eng.set_branch_lengths(np.full(dag.gpcsp_count, 0.1))  # init_default_branch_length_
+    eng.set_sbn_parameters(dag.uniform_on_topological_support_prior())
+    eng.process_operations(dag.populate_plvs())
+    eng.process_operations(dag.marginal_likelihood())
+    before = eng.get_log_marginal_likelihood()
+    eng.set_optimization_method(gp.NEWTON)
+    sweeps = gp.estimate_branch_lengths(eng, dag, 1e-9, 200, zero_before_update=zero_before_update)
+    assert sweeps < 200
+    assert eng.get_log_marginal_likelihood() > before
+    bl = eng.get_branch_lengths()
+    eng.reset_optimization_count()  # one more sweep, no edge skipped as converged: nothing moves
+    eng.process_operations(dag.branch_length_optimization(zero_before_update=zero_before_update))
+    assert np.abs(eng.get_branch_lengths() - bl).max() < 1e-7
+    eng.process_operations(dag.populate_plvs())
+    if zero_before_update:
+        assert _worst_edge_gradient(eng, dag) < 1e-5
+    bl = eng.get_branch_lengths()
+    bl[:len(dag.rootsplits)] = 0.0
+    _check_composite(eng, sp, dag, bl)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fasta,newick", COMPOSITE_CASES)
+def test_estimate_branch_lengths_on_multi_tree_dags_gpu(data_dir, fasta, newick):
+    """The executor runs the multi-tree optimisation schedule to the same lengths as the CPU route."""
+    sp, dag, _ = _composite_case(data_dir, fasta, newick)
+    out = []
+    for make in (gp.GPEngine, ogp.OracleGPEngine):
+        dag.set_clean()
+        eng = make(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+        eng.set_branch_lengths(np.full(dag.gpcsp_count, 0.1))
+        eng.set_sbn_parameters(dag.uniform_on_topological_support_prior())
+        eng.set_optimization_method(gp.NEWTON)
+        sweeps = gp.estimate_branch_lengths(eng, dag, 1e-7, 60)
+        out.append((eng.get_branch_lengths(), eng.get_log_marginal_likelihood(), sweeps))
+    (gb, gl, gs), (cb, cl, cs) = out
+    assert gs == cs
+    assert np.abs(gb - cb).max() < 1e-7 and abs(gl - cl) < 1e-8
