@@ -13,6 +13,11 @@ parent-id vectors and evaluated as ONE batch by the per-tree likelihood engine o
 kernels as ``Engine.log_likelihoods``); edges whose top trees coincide share the evaluation.  What
 the reference's own test checks -- the score of an edge equals BEAGLE's likelihood of the edge's top
 tree (src/gp_doctest.cpp:2909-2931) -- holds by construction.  No arithmetic happens in this module.
+
+Proposed NNIs (src/tp_engine.cpp:955-1135,1460-1468): the top tree through an NNI that is not in the
+DAG yet is the top tree of its best neighbour inside the DAG with the two clades exchanged; its
+branches keep the lengths of the edges they came from unless the DAG already holds the new PCSP.
+All proposals of a DAG are scored as one batch of trees, like the DAG's own edges.
 """
 from __future__ import annotations
 
@@ -21,6 +26,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from .gp_dag import SubsplitDAG
+from .nni import NNI, adjacent_nnis, contains_nni
 
 NO_EDGE = -1
 
@@ -196,3 +202,142 @@ class TPEngine:
             which.append(idx)
         ll = engine.log_likelihoods(np.stack(pids), np.stack(bls), params)
         return ll[np.asarray(which)]
+
+    # -- TPEngine::SetBranchLengthsByTakingFirst (src/tp_engine.cpp:1398-1421) ---------------------------
+    def branch_lengths_by_taking_first(self, parent_id_vectors, tree_branch_lengths, default: float = 0.1) -> np.ndarray:
+        """Per DAG edge the length of that branch in the first input tree that has it (branch lengths are
+        indexed by child node id, as everywhere at the boundary); rootsplit edges keep ``default``."""
+        dag, n = self.dag, self.dag.taxon_count
+        out = np.full(dag.gpcsp_count, float(default))
+        seen = np.zeros(dag.gpcsp_count, dtype=bool)
+        for parents, lengths in zip(parent_id_vectors, tree_branch_lengths):
+            parents = [int(x) for x in parents]
+            node_count = len(parents) + 1
+            clade = [1 << i for i in range(n)] + [0] * (node_count - n)
+            kids: Dict[int, List[int]] = {}
+            for child, p in enumerate(parents):
+                clade[p] |= clade[child]
+                kids.setdefault(p, []).append(child)
+            node = list(range(n)) + [0] * (node_count - n)
+            for v in range(n, node_count):
+                ca, cb = (clade[k] for k in kids[v])
+                node[v] = dag.node_id[(ca, cb) if (ca & -ca) < (cb & -cb) else (cb, ca)]
+            for child, p in enumerate(parents):
+                e = dag.edge(node[p], node[child])
+                if not seen[e]:
+                    seen[e], out[e] = True, float(lengths[child])
+        return out
+
+    # -- proposed NNIs ---------------------------------------------------------------------------------
+    def find_highest_priority_neighbor_nni(self, nni: NNI) -> NNI:
+        """TPEngine::FindHighestPriorityNeighborNNIInDAG: of the NNI's neighbours inside the DAG, the one whose
+        central edge has the best (lowest) tree source; the first wins ties."""
+        best, best_source = None, None
+        for nb in nni.neighbors():
+            if contains_nni(self.dag, nb):
+                source = self.tree_source[self.dag.edge(self.dag.node_id[nb.parent], self.dag.node_id[nb.child])]
+                if best is None or source < best_source:
+                    best, best_source = nb, source
+        if best is None:
+            raise ValueError("NNIOperation has no neighbors found in the DAG.")
+        return best
+
+    def proposed_nni_top_tree(self, nni: NNI, pre_nni: Optional[NNI] = None) -> Tuple[np.ndarray, List[int]]:
+        """(parent_ids, edge_of_node) of the top tree through a proposed NNI: the top tree of ``pre_nni``'s
+        central edge with the sister clade and one child clade exchanged (the choice-map re-mapping of
+        GetRemappedEdgeChoiceFromPreNNIToPostNNI, src/tp_engine.cpp:963-989).  ``edge_of_node`` names, for
+        every tree node, the DAG edge whose branch length the branch above it takes: the DAG's own edge
+        where the new PCSP exists already, else the pre-NNI's edge it came from
+        (BuildMapOfProposedNNIPCSPsToBestPreNNIEdges, src/tp_engine.cpp:1064-1132)."""
+        dag, n = self.dag, self.dag.taxon_count
+        pre = pre_nni or self.find_highest_priority_neighbor_nni(nni)
+        e0 = dag.edge(dag.node_id[pre.parent], dag.node_id[pre.child])
+        pid, edge_of = self.top_tree(e0)
+        count = 2 * n - 1
+        kids: Dict[int, List[int]] = {}
+        clade = [1 << i for i in range(n)] + [0] * (count - n)
+        for c, p in enumerate(pid):
+            kids.setdefault(int(p), []).append(c)
+            clade[int(p)] |= clade[c]
+        child_node = edge_of.index(e0)
+        parent_node = int(pid[child_node])
+        sister_node, = [k for k in kids[parent_node] if k != child_node]
+        swap_node, = [k for k in kids[child_node] if clade[k] == nni.sister_clade]
+        keep_node, = [k for k in kids[child_node] if k != swap_node]
+        # exchange the clades
+        new_parent_of = [int(x) for x in pid] + [-1]
+        new_parent_of[swap_node], new_parent_of[sister_node] = parent_node, child_node
+
+        def own_or(parent_subsplit, node, fallback):
+            """The DAG's own edge for (parent_subsplit -> subsplit of ``node``) if it exists."""
+            a, b = sorted_children[node] if node >= n else (0, clade[node])
+            key = (a, b)
+            if dag.contains_edge(parent_subsplit, key):
+                return dag.edge(dag.node_id[parent_subsplit], dag.node_id[key])
+            return fallback
+
+        sorted_children = {}
+        for v, ks in kids.items():
+            ca, cb = clade[ks[0]], clade[ks[1]]
+            sorted_children[v] = (ca, cb) if (ca & -ca) < (cb & -cb) else (cb, ca)
+        edges = list(edge_of)
+        edges[sister_node] = own_or(nni.child, sister_node, edge_of[sister_node])
+        edges[keep_node] = own_or(nni.child, keep_node, edge_of[keep_node])
+        edges[swap_node] = own_or(nni.parent, swap_node, edge_of[swap_node])
+        if parent_node != count - 1:  # the branch above the parent: (grandparent -> new parent) may exist already
+            grand = int(pid[parent_node])
+            if dag.contains_edge(sorted_children[grand], nni.parent):
+                edges[parent_node] = dag.edge(dag.node_id[sorted_children[grand]], dag.node_id[nni.parent])
+        # bito ids: internal nodes in post-order, root last
+        new_kids: Dict[int, List[int]] = {}
+        for c, p in enumerate(new_parent_of[:-1]):
+            new_kids.setdefault(p, []).append(c)
+        low = list(range(n)) + [0] * (count - n)
+        order: List[int] = []
+
+        def visit(v):
+            if v >= n:
+                ks = new_kids[v]
+                for k in ks:
+                    visit(k)
+                low[v] = min(low[k] for k in ks)
+                order.append(v)
+
+        # children in increasing order of their smallest taxon (left clade first), as top_tree emits them
+        def sort_kids(v):
+            if v >= n:
+                for k in new_kids[v]:
+                    sort_kids(k)
+                low[v] = min(low[k] for k in new_kids[v])
+                new_kids[v].sort(key=lambda k: low[k])
+
+        sort_kids(count - 1)
+        visit(count - 1)
+        new_id = {v: v for v in range(n)}
+        for i, v in enumerate(order):
+            new_id[v] = n + i
+        out = np.zeros(count - 1, dtype=np.int32)
+        out_edges = [0] * count
+        for v in range(count):
+            out_edges[new_id[v]] = edges[v]
+            if v != count - 1:
+                out[new_id[v]] = new_id[new_parent_of[v]]
+        return out, out_edges
+
+    def proposed_nni_likelihoods(self, engine, edge_branch_lengths: np.ndarray, nnis: Optional[Sequence[NNI]] = None,
+                                 params: Optional[np.ndarray] = None) -> Dict[NNI, float]:
+        """TPEngine::GetTopTreeScoreWithProposedNNI for every NNI adjacent to the DAG (or the given ones): the
+        log-likelihoods of the proposals' top trees, all in ONE batch of the per-tree engine."""
+        n = self.dag.taxon_count
+        nnis = list(adjacent_nnis(self.dag) if nnis is None else nnis)
+        if not nnis:
+            return {}
+        pids, bls = [], []
+        for x in nnis:
+            pid, edges = self.proposed_nni_top_tree(x)
+            bl = np.zeros(2 * n - 1)
+            bl[: 2 * n - 2] = [edge_branch_lengths[e] for e in edges[: 2 * n - 2]]
+            pids.append(pid)
+            bls.append(bl)
+        ll = engine.log_likelihoods(np.stack(pids), np.stack(bls), params)
+        return {x: float(v) for x, v in zip(nnis, ll)}

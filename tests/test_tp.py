@@ -122,3 +122,93 @@ def _renumber(parents):
     for c, p in enumerate(parents):
         out[new_id[c]] = new_id[p]
     return np.array(out, dtype=np.int32)
+
+
+# -- proposed NNIs: "TPEngine: Proposed NNI vs DAG NNI vs BEAGLE Likelihood" (src/gp_doctest.cpp:2973-3099) ----
+
+PROPOSED_CASES = [("hello.fasta", "hello_rooted_diff_branches.nwk"),
+                  ("five_taxon.fasta", "five_taxon_trees_3_4_diff_branches.nwk"),
+                  ("six_taxon.fasta", "six_taxon_rooted_simple.nwk")]
+
+
+def _subsplits_of(pid, n):
+    clade = [1 << i for i in range(n)] + [0] * (len(pid) + 1 - n)
+    kids = {}
+    for c, p in enumerate(pid):
+        clade[int(p)] |= clade[c]
+        kids.setdefault(int(p), []).append(c)
+    out = set()
+    for v, (a, b) in kids.items():
+        ca, cb = clade[a], clade[b]
+        out.add((ca, cb) if (ca & -ca) < (cb & -cb) else (cb, ca))
+    return out
+
+
+@pytest.mark.parametrize("fasta,newick", PROPOSED_CASES)
+def test_proposed_nni_top_tree_is_the_neighbours_top_tree_with_the_clades_exchanged(data_dir, fasta, newick):
+    from bito_amd.nni import adjacent_nnis
+
+    tc, sp, pids, dag = _load(data_dir, fasta, newick)
+    n = dag.taxon_count
+    tp = TPEngine(dag, pids)
+    nnis = adjacent_nnis(dag)
+    assert nnis
+    for x in nnis:
+        pre = tp.find_highest_priority_neighbor_nni(x)
+        pid, edges = tp.proposed_nni_top_tree(x)
+        before, _ = tp.top_tree(dag.edge(dag.node_id[pre.parent], dag.node_id[pre.child]))
+        a, b = _subsplits_of(before, n), _subsplits_of(pid, n)
+        assert a - b == {pre.parent, pre.child} - {x.parent} and b - a == {x.parent, x.child} - {pre.parent}
+        assert len(edges) == 2 * n - 1 and all(0 <= e < dag.gpcsp_count for e in edges)
+        # ids are bito's: every child below its parent, root last
+        assert all(pid[c] > c for c in range(2 * n - 2)) and pid.max() == 2 * n - 2
+        # "score_dag == score_proposed" in structure terms: once the proposed tree is part of the collection, the
+        # top tree through the NNI's edge in the grown DAG is that very tree
+        grown_pids = list(pids) + [pid]
+        grown = SubsplitDAG(n, grown_pids)
+        tp2 = TPEngine(grown, grown_pids)
+        again, _ = tp2.top_tree(grown.edge(grown.node_id[x.parent], grown.node_id[x.child]))
+        assert np.array_equal(again, pid)
+
+
+def test_branch_lengths_by_taking_first(data_dir):
+    """TPEngineSetBranchLengthsByTakingFirst: the two five-taxon trees carry lengths 1.x and 2.x."""
+    tc, sp, pids, dag = _load(data_dir, "five_taxon.fasta", "five_taxon_trees_3_4_diff_branches.nwk")
+    tp = TPEngine(dag, pids)
+    bl = tp.branch_lengths_by_taking_first(pids, [t.branch_lengths for t in tc.trees])
+    for e in range(dag.gpcsp_count):
+        if tp.edge_parent[e] < 0:
+            continue
+        assert int(bl[e]) == tp.tree_source[e], (e, bl[e], tp.tree_source[e])  # 1.x from tree 1, 2.x from tree 2
+    # the pendant branch of x0 is shared: tree 1 wins
+    x0 = [e for e in range(dag.gpcsp_count) if tp.edge_child[e] == 0]
+    assert all(abs(bl[e] - 1.1) < 1e-12 for e in x0 if tp.tree_source[e] == 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fasta,newick", PROPOSED_CASES)
+def test_proposed_nni_scores_equal_tree_likelihoods(data_dir, fasta, newick):
+    """score_proposed == BEAGLE's likelihood of the proposal's top tree (the reference asks 1e-5), here the
+    per-tree CPU oracle on the same tree and lengths, with the branch lengths taken from the first tree."""
+    from oracle import oracle
+
+    tc, sp, pids, dag = _load(data_dir, fasta, newick)
+    n = dag.taxon_count
+    tp = TPEngine(dag, pids)
+    bl = tp.branch_lengths_by_taking_first(pids, [t.branch_lengths for t in tc.trees])
+    if newick.startswith("six"):  # this fixture carries no branch lengths
+        bl = np.random.default_rng(2).uniform(0.02, 0.3, dag.gpcsp_count)
+    eng = bito_amd.Engine(bito_amd.PhyloModelSpecification("JC69", "constant", "none"), sp.patterns, sp.weights)
+    scores = tp.proposed_nni_likelihoods(eng, bl)
+    assert scores
+    cpu = oracle.OracleEngine("JC69", "constant", "none", sp.patterns, sp.weights, 2)
+    own = tp.top_tree_likelihoods(eng, bl)
+    for x, score in scores.items():
+        pid, edges = tp.proposed_nni_top_tree(x)
+        tree_bl = np.zeros(2 * n - 1)
+        tree_bl[: 2 * n - 2] = bl[edges[: 2 * n - 2]]
+        ref = cpu.log_likelihoods(pid[None, :], tree_bl[None, :])[0]
+        assert abs(score - ref) < 1e-10
+        # a proposal differs from its neighbour's top tree by one NNI: same taxa, same lengths, another topology
+        pre = tp.find_highest_priority_neighbor_nni(x)
+        assert score != own[dag.edge(dag.node_id[pre.parent], dag.node_id[pre.child])]
