@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 HBM arena, 2 LDS")
+    ap.add_argument("--sum-ll-reduce", choices=("auto", "on", "off"), default="auto",
+                    help="per step, all-reduce the summed log-likelihood over the ranks (RCCL); auto = when there "
+                         "is more than one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,10 +140,20 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 builds a one-rank RCCL group on a single GPU, to exercise the reduce path there
+    force_group = world == 1 and os.environ.get("BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_group:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if force_group:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    reduce_ll = dist is not None and args.sum_ll_reduce != "off"
+    if args.sum_ll_reduce == "on" and dist is None:
+        raise SystemExit("--sum-ll-reduce on needs a process group (launch with torch.distributed.run)")
 
     # every rank builds the same replicated workload and takes its own block of trees
     codon = args.workload == "codon"
@@ -157,20 +170,32 @@ def main():
         eng.set_kernel(args.kernel)
     eng.upload(w.parent_ids, w.branch_lengths, w.params)
 
+    ll_dev = torch.zeros(T, dtype=torch.float64, device="cuda") if reduce_ll else None
+    pending = []  # (work handle, tensor) of the summed-log-likelihood reductions in flight
+
     def step():
-        # trees are independent: each rank evaluates its own block, no data-path collective
+        # trees are independent: each rank evaluates its own block.  The only exchange the path has is
+        # the summed log-likelihood of the whole collection (the caller's objective): 8 bytes per step,
+        # all-reduced over RCCL without holding up the next pass.
         eng.run(w.want_gradient, w.rescaling)
+        if reduce_ll:
+            eng.download_to(ll_dev.data_ptr(), None)  # device-to-device, ordered behind this pass
+            total = ll_dev.sum().reshape(1)
+            pending.append((dist.all_reduce(total, async_op=True), total))
 
     def fence():
         eng.sync()
+        for work, _ in pending:
+            work.wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
+    pending.clear()
     eng.kernel_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -180,7 +205,7 @@ def main():
     kernel_ms, launches = eng.kernel_elapsed()
     eng.kernel_timing(False)
 
-    if world > 1:
+    if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -189,6 +214,17 @@ def main():
     ll_host, grad_host = eng.download(True)
     if not (np.all(np.isfinite(ll_host)) and np.all(np.isfinite(grad_host))):
         raise SystemExit("non-finite results in the timed batch")
+    summed_ll = None
+    if reduce_ll:
+        # the last reduction must be the sum over every rank's block: check it against a gather of the
+        # per-rank sums (outside the timed region)
+        summed_ll = float(pending[-1][1].item())
+        mine = torch.tensor([float(ll_host.sum())], dtype=torch.float64, device="cuda")
+        parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)
+        expect = float(sum(p.item() for p in parts))
+        if not abs(summed_ll - expect) <= 1e-9 * abs(expect):
+            raise SystemExit(f"summed log-likelihood {summed_ll} differs from the gathered sum {expect}")
 
     if rank == 0:
         total_trees = world * T
@@ -231,8 +267,11 @@ def main():
                 "trees_per_gpu": T,
                 "trees_total": total_trees,
                 "kernel": kernel,
-                "multi_gpu": "trees sharded by rank, no data-path collective (barrier + max-over-ranks timing "
-                             "only)" if world > 1 else "single GPU, no collective",
+                "multi_gpu": ("trees sharded by rank; per step one asynchronous RCCL all-reduce of the summed "
+                              "log-likelihood (8 bytes)" if reduce_ll else
+                              "trees sharded by rank, no data-path collective (barrier + max-over-ranks timing only)")
+                if dist is not None else "single GPU, no collective",
+                **({"summed_log_likelihood": summed_ll} if reduce_ll else {}),
             },
             "roofline": {
                 "bound": "hbm",
@@ -253,7 +292,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(full, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
