@@ -170,17 +170,36 @@ def main():
         eng.set_kernel(args.kernel)
     eng.upload(w.parent_ids, w.branch_lengths, w.params)
 
-    ll_dev = torch.zeros(T, dtype=torch.float64, device="cuda") if reduce_ll else None
-    pending = []  # (work handle, tensor) of the summed-log-likelihood reductions in flight
+    # Summed log-likelihood over the ranks, one asynchronous RCCL all-reduce per step.  Nothing waits on the
+    # host: the per-tree values are copied device-to-device on the engine's stream behind the pass, torch's
+    # stream waits for that copy through an event, sums, and hands the scalar to RCCL; the next pass (and its
+    # set-up, which overlaps this one) is submitted meanwhile.  A ring of result tensors, each guarded by the
+    # event of the sum that last read it.
+    kRing = 4
+    ll_ring = torch.zeros(kRing, T, dtype=torch.float64, device="cuda") if reduce_ll else None
+    engine_stream = torch.cuda.ExternalStream(eng.stream_handle()) if reduce_ll else None
+    sum_done = [None] * kRing
+    pending = []  # (work handle, tensor) of the reductions in flight
+    step_index = [0]
 
     def step():
-        # trees are independent: each rank evaluates its own block.  The only exchange the path has is
-        # the summed log-likelihood of the whole collection (the caller's objective): 8 bytes per step,
-        # all-reduced over RCCL without holding up the next pass.
+        # trees are independent: each rank evaluates its own block; the only exchange the path has is the
+        # summed log-likelihood of the whole collection (the caller's objective), 8 bytes per step
+        if reduce_ll:
+            slot = step_index[0] % kRing
+            step_index[0] += 1
+            if sum_done[slot] is not None:
+                engine_stream.wait_event(sum_done[slot])
         eng.run(w.want_gradient, w.rescaling)
         if reduce_ll:
-            eng.download_to(ll_dev.data_ptr(), None)  # device-to-device, ordered behind this pass
-            total = ll_dev.sum().reshape(1)
+            eng.download_async(ll_ring[slot].data_ptr(), None)
+            copied = torch.cuda.Event()
+            copied.record(engine_stream)
+            here = torch.cuda.current_stream()
+            here.wait_event(copied)
+            total = ll_ring[slot].sum().reshape(1)
+            sum_done[slot] = torch.cuda.Event()
+            sum_done[slot].record(here)
             pending.append((dist.all_reduce(total, async_op=True), total))
 
     def fence():

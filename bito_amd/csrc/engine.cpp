@@ -526,8 +526,16 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
   if ((hrc = hipSetDevice(e->device)) != hipSuccess) return dev_fail("hipSetDevice", hrc);
   if ((hrc = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
     return dev_fail("hipStreamCreate", hrc);
-  if ((hrc = hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking)) != hipSuccess)
-    return dev_fail("hipStreamCreate", hrc);
+  // The set-up stream gets its own priority level: the runtime keeps a separate pool of hardware queues per
+  // priority, so the two streams can never be folded onto ONE hardware queue (which serialises them) however
+  // many streams the process already holds.  Measured: with an RCCL process group created first, two
+  // normal-priority streams shared a queue and the set-up overlap was gone (2.24 ms per step against 2.17).
+  {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if ((hrc = hipStreamCreateWithPriority(&e->prep_stream, hipStreamNonBlocking, least)) != hipSuccess)
+      return dev_fail("hipStreamCreate", hrc);
+  }
   for (int i = 0; i < 2; i++) {
     if ((hrc = hipEventCreateWithFlags(&e->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess ||
         (hrc = hipEventCreateWithFlags(&e->ev_walk_done[i], hipEventDisableTiming)) != hipSuccess)
@@ -671,7 +679,7 @@ int bito_amd_engine_sync(bito_amd_engine* e) {
   return BITO_AMD_OK;
 }
 
-int bito_amd_engine_download(bito_amd_engine* e, double* out_ll, double* out_grad) {
+int bito_amd_engine_download_async(bito_amd_engine* e, double* out_ll, double* out_grad) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident");
   HIP_TRY(e, hipSetDevice(e->device));
@@ -680,9 +688,16 @@ int bito_amd_engine_download(bito_amd_engine* e, double* out_ll, double* out_gra
     HIP_TRY(e, hipMemcpyAsync(out_ll, e->out_ll.ptr, T * sizeof(double), hipMemcpyDefault, e->stream));
   if (out_grad)
     HIP_TRY(e, hipMemcpyAsync(out_grad, e->out_grad.ptr, T * e->dims.node_count * sizeof(double), hipMemcpyDefault, e->stream));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_download(bito_amd_engine* e, double* out_ll, double* out_grad) {
+  if (int rc = bito_amd_engine_download_async(e, out_ll, out_grad)) return rc;
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return BITO_AMD_OK;
 }
+
+void* bito_amd_engine_stream(bito_amd_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 int bito_amd_engine_log_likelihoods(bito_amd_engine* e, int32_t tree_count, int32_t rooted,
                                     int32_t node_count, const int32_t* parent_ids,

@@ -306,6 +306,14 @@ class Engine:
         """Copy results to raw (host or device) addresses, e.g. torch tensor data_ptr()."""
         self._check(_capi.lib().bito_amd_engine_download(self._h, ll_ptr, grad_ptr))
 
+    def download_async(self, ll_ptr: int, grad_ptr: Optional[int]):
+        """The same copies enqueued on the engine's stream without waiting (see ``stream_handle``)."""
+        self._check(_capi.lib().bito_amd_engine_download_async(self._h, ll_ptr, grad_ptr))
+
+    def stream_handle(self) -> int:
+        """The engine's hipStream_t as an integer, e.g. for ``torch.cuda.ExternalStream``."""
+        return int(_capi.lib().bito_amd_engine_stream(self._h) or 0)
+
     def set_kernel(self, kernel: int):
         self._check(_capi.lib().bito_amd_engine_set_kernel(self._h, kernel))
 

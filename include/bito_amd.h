@@ -233,6 +233,13 @@ int bito_amd_engine_sync(bito_amd_engine *e);
  * out_branch_gradients may be NULL. */
 int bito_amd_engine_download(bito_amd_engine *e, double *out_log_likelihoods,
                              double *out_branch_gradients);
+/* The same copies, enqueued on the engine's stream without waiting (destinations should be device or
+ * pinned host memory), and the stream itself (a hipStream_t) so that a caller can order its own work
+ * behind them -- record an event on it, or hand it to its framework as an external stream.  This is how a
+ * multi-GPU caller reduces the summed log-likelihood over RCCL without stalling the next pass (bench.py). */
+int bito_amd_engine_download_async(bito_amd_engine *e, double *out_log_likelihoods,
+                                   double *out_branch_gradients);
+void *bito_amd_engine_stream(bito_amd_engine *e);
 
 /* Diagnostics / benchmarking. */
 int bito_amd_engine_set_kernel(bito_amd_engine *e, int32_t kernel);
