@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <string>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/bito_amd.h"
 #include "../../include/bito_amd_gp.h"
@@ -31,12 +33,13 @@ struct bito_amd_gp_engine {
   bito_amd_gp_op* d_ops = nullptr;
   uint64_t* d_side = nullptr;
   int64_t* d_offsets = nullptr;
-  size_t ops_cap = 0, side_cap = 0, offsets_cap = 0, coef_blocks = 1;  // coef holds coef_blocks x [2][Ppad]
+  int64_t* d_levels = nullptr;  // level offsets of the levelled segments of the resident stream
+  size_t ops_cap = 0, side_cap = 0, offsets_cap = 0, levels_cap = 0, coef_blocks = 1;  // coef holds coef_blocks x [2][Ppad]
   std::string err;
   ~bito_amd_gp_engine() {
     (void)hipSetDevice(device);
     for (void* p : {(void*)plv, (void*)weights, (void*)bl, (void*)q, (void*)ll, (void*)marginal, (void*)scratch, (void*)diff, (void*)coef,
-                    (void*)counts, (void*)d_ops, (void*)d_side, (void*)d_offsets})
+                    (void*)counts, (void*)d_ops, (void*)d_side, (void*)d_offsets, (void*)d_levels})
       if (p) (void)hipFree(p);
   }
 };
@@ -171,6 +174,30 @@ gp_ops_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const in
   }
   for (int64_t o = 0; o < op_count; o++)
     PatternOp(ops[o], p, side, plv, counts, bl, q, ll, marginal, Ppad, threshold, log_threshold);
+}
+
+// A per-pattern segment whose operations have been sorted into dependency levels (LevelSegment below): one
+// workgroup per tile of 64 patterns, kLevelWaves waves; wave w takes operations w, w + kLevelWaves, ... of the
+// level, a workgroup barrier separates levels.  The dependent chain of a pass is then as long as the
+// schedule is DEEP (DS1 ten-tree DAG: 57 levels for 1082 PopulatePLVs operations), not as long as it has
+// operations, and nothing is launched per level.
+constexpr int kLevelWaves = 16;
+
+__global__ void __launch_bounds__(64 * kLevelWaves)
+gp_levels_kernel(const bito_amd_gp_op* __restrict__ ops, const int64_t* __restrict__ level_offsets, int level_count,
+                 const uint64_t* __restrict__ side, double* __restrict__ plv, int* __restrict__ counts,
+                 const double* __restrict__ bl, const double* __restrict__ q, double* __restrict__ ll,
+                 double* __restrict__ marginal, int P, int Ppad, double threshold, double log_threshold) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  const bool live = p < P;
+  for (int level = 0; level < level_count; level++) {
+    const int64_t first = level_offsets[level], last = level_offsets[level + 1];
+    if (live)
+      for (int64_t o = first + threadIdx.y; o < last; o += kLevelWaves)
+        PatternOp(ops[o], p, side, plv, counts, bl, q, ll, marginal, Ppad, threshold, log_threshold);
+    __threadfence_block();
+    __syncthreads();  // the level's results are visible to every wave of the tile
+  }
 }
 
 // block per row: out[row] = sum_p w_p * rows[row][p]
@@ -658,7 +685,7 @@ int bito_amd_gp_log_likelihood_matrix(bito_amd_gp_engine* e, double* out) {
 
 // ids are validated once on the host, then the stream and its side array go to the device
 static int ValidateAndUpload(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count, const uint64_t* side,
-                             int64_t side_count, bool batched) {
+                             int64_t side_count, bool batched, const bito_amd_gp_op* device_image = nullptr) {
   const uint64_t plv_limit = (uint64_t)e->plvs + (uint64_t)e->spare_plvs;
   const uint64_t gp_limit = (uint64_t)e->gpcsps + (uint64_t)e->spare_gpcsps;
   for (int64_t o = 0; o < op_count; o++) {
@@ -703,8 +730,74 @@ static int ValidateAndUpload(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, i
     GP_TRY(e, hipMalloc((void**)&e->d_ops, op_count * sizeof(bito_amd_gp_op)));
     e->ops_cap = op_count;
   }
-  if (op_count > 0) GP_TRY(e, hipMemcpy(e->d_ops, ops, op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
+  if (op_count > 0)
+    GP_TRY(e, hipMemcpy(e->d_ops, device_image ? device_image : ops, op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
   return BITO_AMD_OK;
+}
+
+// Dependency levels of a run of per-pattern operations.  An operation reads and writes whole PLVs (with
+// their rescaling counts), log-likelihood rows and the marginal row; its level is one more than the
+// latest earlier operation it must follow (read-after-write, write-after-read, write-after-write), so
+// operations of one level touch disjoint results and chains on one destination keep their order --
+// the arithmetic is the sequential one, bit for bit.  Returns the operations sorted by level (stable)
+// and appends the level boundaries (absolute indices into the stream) to `offsets`.
+constexpr int64_t kLevelMinOps = 48;  // shorter runs stay with the one-thread-per-pattern interpreter
+
+static void LevelSegment(const bito_amd_gp_op* ops, int64_t first, int64_t count, const uint64_t* side,
+                         bito_amd_gp_op* sorted, std::vector<int64_t>* offsets) {
+  struct Use { int write = -1, read = -1; };
+  std::unordered_map<uint64_t, Use> use;  // key: resource kind in the top bits
+  auto plv = [](uint64_t id) { return id; };
+  auto row = [](uint64_t id) { return id | (1ull << 62); };
+  const uint64_t marginal = 1ull << 63;
+  std::vector<int> level(count);
+  int deepest = -1;
+  for (int64_t k = 0; k < count; k++) {
+    const bito_amd_gp_op& op = ops[first + k];
+    uint64_t reads[2 + 64], writes[2];
+    int nr = 0, nw = 0;
+    std::vector<uint64_t> many;  // PrepForMarginalization with more than 64 sources
+    switch (op.opcode) {
+      case BITO_AMD_GP_ZERO_PLV:
+      case BITO_AMD_GP_SET_TO_STATIONARY_DISTRIBUTION: writes[nw++] = plv(op.a); break;
+      case BITO_AMD_GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV:
+        writes[nw++] = plv(op.a); reads[nr++] = plv(op.a); reads[nr++] = plv(op.c); break;
+      case BITO_AMD_GP_MULTIPLY: writes[nw++] = plv(op.a); reads[nr++] = plv(op.b); reads[nr++] = plv(op.c); break;
+      case BITO_AMD_GP_LIKELIHOOD: writes[nw++] = row(op.a); reads[nr++] = plv(op.b); reads[nr++] = plv(op.c); break;
+      case BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD: writes[nw++] = marginal; break;
+      case BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD:
+        writes[nw++] = marginal; writes[nw++] = row(op.b);
+        reads[nr++] = marginal; reads[nr++] = plv(op.a); reads[nr++] = plv(op.c); break;
+      case BITO_AMD_GP_PREP_FOR_MARGINALIZATION:
+        writes[nw++] = plv(op.a); reads[nr++] = plv(op.a);
+        for (uint32_t j = 0; j < op.count; j++) {
+          if (nr < 66) reads[nr++] = plv(side[op.b + j]);
+          else many.push_back(plv(side[op.b + j]));
+        }
+        break;
+      default: break;
+    }
+    int lv = 0;
+    auto after_write = [&](uint64_t r) { auto it = use.find(r); if (it != use.end()) lv = std::max(lv, it->second.write + 1); };
+    auto after_any = [&](uint64_t r) {
+      auto it = use.find(r);
+      if (it != use.end()) lv = std::max(lv, std::max(it->second.write, it->second.read) + 1);
+    };
+    for (int j = 0; j < nr; j++) after_write(reads[j]);
+    for (uint64_t r : many) after_write(r);
+    for (int j = 0; j < nw; j++) after_any(writes[j]);
+    for (int j = 0; j < nr; j++) { Use& u = use[reads[j]]; u.read = std::max(u.read, lv); }
+    for (uint64_t r : many) { Use& u = use[r]; u.read = std::max(u.read, lv); }
+    for (int j = 0; j < nw; j++) use[writes[j]].write = lv;
+    level[k] = lv;
+    deepest = std::max(deepest, lv);
+  }
+  std::vector<int64_t> start(deepest + 2, 0);
+  for (int64_t k = 0; k < count; k++) start[level[k] + 1]++;
+  for (int l = 0; l <= deepest; l++) start[l + 1] += start[l];
+  for (int l = 0; l <= deepest + 1; l++) offsets->push_back(first + start[l]);
+  std::vector<int64_t> cursor(start.begin(), start.end() - 1);
+  for (int64_t k = 0; k < count; k++) sorted[first + cursor[level[k]]++] = ops[first + k];
 }
 
 int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count,
@@ -712,15 +805,51 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
   if (!e || (op_count > 0 && !ops)) return BITO_AMD_ERR_BAD_ARG;
   GP_TRY(e, hipSetDevice(e->device));
   if (int rc = ValidateAndUpload(e, ops, op_count, side, side_count, false)) return rc;
-  // Segments: runs of per-pattern ops are one launch each; a run of OptimizeBranchLength ops is one
-  // single-workgroup launch (they couple the patterns through the reductions); UpdateSBNProbabilities
-  // is a host step.  Everything is issued in stream order, so the sequential semantics hold.
+  // Long runs of per-pattern operations are sorted into dependency levels and walked by gp_levels_kernel;
+  // the device image of the stream holds them in that order.
+  std::vector<bito_amd_gp_op> image;
+  std::vector<int64_t> level_offsets;                            // all levelled segments, back to back
+  std::unordered_map<int64_t, std::pair<int64_t, int>> levelled;  // segment start -> (first offset, level count)
+  {
+    int64_t seg = 0;
+    for (int64_t o = 0; o <= op_count; o++) {
+      const bool boundary = o == op_count || ops[o].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH ||
+                            ops[o].opcode == BITO_AMD_GP_UPDATE_SBN_PROBABILITIES;
+      if (!boundary) continue;
+      if (o - seg >= kLevelMinOps) {
+        if (image.empty()) image.assign(ops, ops + op_count);
+        const int64_t at = (int64_t)level_offsets.size();
+        LevelSegment(ops, seg, o - seg, side, image.data(), &level_offsets);
+        levelled[seg] = {at, (int)(level_offsets.size() - at - 1)};
+      }
+      seg = o + 1;
+    }
+  }
+  if (!levelled.empty()) {
+    GP_TRY(e, hipMemcpy(e->d_ops, image.data(), op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
+    if (level_offsets.size() > e->levels_cap) {
+      if (e->d_levels) (void)hipFree(e->d_levels);
+      e->levels_cap = 0;
+      GP_TRY(e, hipMalloc((void**)&e->d_levels, level_offsets.size() * sizeof(int64_t)));
+      e->levels_cap = level_offsets.size();
+    }
+    GP_TRY(e, hipMemcpy(e->d_levels, level_offsets.data(), level_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  }
+  auto run_segment = [&](int64_t first, int64_t count) -> int {
+    auto it = levelled.find(first);
+    if (it == levelled.end()) return RunSegment(e, first, count);
+    hipLaunchKernelGGL(gp_levels_kernel, dim3((e->P + 63) / 64), dim3(64, kLevelWaves), 0, 0, e->d_ops,
+                       (const int64_t*)(e->d_levels + it->second.first), it->second.second, e->d_side, e->plv,
+                       e->counts, e->bl, e->q, e->ll, e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
+    GP_TRY(e, hipGetLastError());
+    return BITO_AMD_OK;
+  };
   int64_t start = 0;
   for (int64_t o = 0; o <= op_count; o++) {
     const bool is_opt = o < op_count && ops[o].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH;
     const bool boundary = o == op_count || is_opt || ops[o].opcode == BITO_AMD_GP_UPDATE_SBN_PROBABILITIES;
     if (!boundary) continue;
-    int rc = RunSegment(e, start, o - start);
+    int rc = run_segment(start, o - start);
     if (rc) return rc;
     if (is_opt) {
       int64_t end = o;

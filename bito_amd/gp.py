@@ -37,6 +37,7 @@ class OpStream:
     def __init__(self):
         self.ops: List[Tuple[int, int, int, int, int]] = []
         self.side: List[int] = []
+        self._arrays = None  # (op count, side count, ops array, side array) of the last conversion
 
     def add(self, opcode, a=0, b=0, c=0):
         self.ops.append((opcode, 0, a, b, c))
@@ -46,9 +47,12 @@ class OpStream:
         self.side.extend(int(x) for x in sources)
 
     def arrays(self):
-        ops = np.array(self.ops, dtype=OP_DTYPE) if self.ops else np.zeros(0, dtype=OP_DTYPE)
-        side = np.array(self.side if self.side else [0], dtype=np.uint64)
-        return ops, side
+        """The POD image handed to the executor; cached, a schedule is usually replayed many times."""
+        if self._arrays is None or self._arrays[0] != len(self.ops) or self._arrays[1] != len(self.side):
+            ops = np.array(self.ops, dtype=OP_DTYPE) if self.ops else np.zeros(0, dtype=OP_DTYPE)
+            side = np.array(self.side if self.side else [0], dtype=np.uint64)
+            self._arrays = (len(self.ops), len(self.side), ops, side)
+        return self._arrays[2], self._arrays[3]
 
     def extend(self, other: "OpStream"):
         base = len(self.side)
