@@ -19,6 +19,9 @@
 // are bit-reproducible run to run.
 #include "kernels.hpp"
 
+#ifndef HBM_PRE_UNROLL
+#define HBM_PRE_UNROLL 1  // rate categories of a pre-order step whose loads are in flight together
+#endif
 #ifndef HBM_WAVES_EXPR
 #define HBM_WAVES_EXPR ((C <= 4) ? 4 : 1)  // waves per SIMD the register allocation is held to (measured: 3, 4, 5, 6)
 #endif
@@ -497,7 +500,7 @@ walk_hbm_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
       // (A forwarded partial takes LDS slot c after this node's own U, read from the same slot, is used.)
       const bool fwd0 = kForward && k0.kind == 1 && c0 == node - 1;
       const bool fwd1 = kForward && k1.kind == 1 && c1 == node - 1;
-#pragma unroll 1
+#pragma unroll HBM_PRE_UNROLL
       for (int c = 0; c < C; c++) {
         double q0[4], q1[4];
         category_step(c, q0, q1);
