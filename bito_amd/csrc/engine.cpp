@@ -704,6 +704,9 @@ int bito_amd_engine_log_likelihoods(bito_amd_engine* e, int32_t tree_count, int3
                                     const double* branch_lengths, const double* rates,
                                     const double* params, int32_t rescaling, double* out) {
   if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  // an empty collection is not an error: FatBeagleParallelize over no trees returns an empty vector
+  // (reference src/fat_beagle.hpp:160-181)
+  if (tree_count == 0) return BITO_AMD_OK;
   int rc = bito_amd_engine_upload(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params);
   if (rc) return rc;
   if ((rc = RunResident(e, 0, rescaling != 0))) return rc;
@@ -788,6 +791,7 @@ int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t ro
                               double fd_delta, double* out_ll, double* out_branch,
                               double* out_site, double* out_subst, double* out_clock) {
   if (!e || !out_ll || !out_branch) return BITO_AMD_ERR_BAD_ARG;
+  if (tree_count == 0) return BITO_AMD_OK;  // empty collection, empty result (as bito_amd_engine_log_likelihoods)
   int rc;
   // the finite-difference batch first: the main batch must be the resident one on return
   if ((flags & BITO_AMD_GRAD_SUBSTITUTION_MODEL) && out_subst && e->spec.rates_len > 0) {

@@ -116,7 +116,8 @@ int bito_amd_engine_block(const bito_amd_engine *e, int32_t idx, char *name,
  *   branch_lengths: [tree_count][node_count]    by child id (src/tree.cpp:16-30)
  *   params:         [tree_count][param_count]   one row per tree (fat_beagle.hpp:177)
  *   rescaling:      Engine's `rescaling` argument (BEAGLE manual scaling)
- * Host pointers.  out_log_likelihoods: [tree_count].
+ * Host pointers.  out_log_likelihoods: [tree_count].  tree_count == 0 (an empty collection) returns
+ * BITO_AMD_OK and writes nothing, as FatBeagleParallelize does over no trees; so does _gradients.
  */
 int bito_amd_engine_log_likelihoods(bito_amd_engine *e, int32_t tree_count, int32_t rooted,
                                     int32_t node_count, const int32_t *parent_ids,

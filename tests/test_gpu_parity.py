@@ -236,6 +236,11 @@ def test_edge_cases(data_dir):
     ref = cpu.gradients(pid, bl0)
     assert ll_close(out["log_likelihood"], ref["log_likelihood"])
     assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    # an empty collection gives empty results, not an error (FatBeagleParallelize over no trees)
+    assert gpu.log_likelihoods(pid[:0], bl[:0]).shape == (0,)
+    empty = gpu.gradients(pid[:0], bl[:0])
+    assert empty["log_likelihood"].shape == (0,) and empty["branch_lengths"].shape[0] == 0
+    assert ll_close(gpu.log_likelihoods(pid, bl0), ref["log_likelihood"])  # and the engine carries on
     # two-taxon rooted tree: the smallest bifurcating tree
     pats = sp.patterns[:2]
     gpu, cpu = engines("JC69", "constant", "none", pats, sp.weights, 1)
