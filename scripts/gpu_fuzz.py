@@ -1,0 +1,101 @@
+"""Randomised parity sweep on the GPU box: random tree shapes, sizes, pattern counts, models, category counts,
+kernels, rescaling, rooted/unrooted, against the CPU checker.  usage: python scripts/gpu_fuzz.py [cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import bito_amd
+from bito_amd import _capi, workloads
+from test_gpu_parity import _random_rooted_parent_ids, engines, spec
+from oracle import gs
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+rng = np.random.default_rng(seed)
+bad = 0
+t0 = time.time()
+for case in range(cases):
+    n = int(rng.choice([3, 4, 5, 6, 8, 11, 16, 23, 27, 40, 57, 90]))
+    P = int(rng.choice([1, 5, 16, 63, 64, 65, 130, 300]))
+    T = int(rng.choice([1, 2, 7, 33]))
+    sub = str(rng.choice(["JC69", "HKY", "GTR", "GY94"], p=[0.3, 0.3, 0.3, 0.1]))
+    site = str(rng.choice(["constant", "weibull+2", "weibull+3", "weibull+4", "weibull+6"]))
+    codon = sub == "GY94"
+    if codon:  # the 61-state checker is a scalar port: keep these small
+        n, P, T = min(n, 16), min(P, 65), min(T, 7)
+        site = str(rng.choice(["constant", "weibull+2"]))
+    kernel = int(rng.choice([_capi.KERNEL_AUTO, _capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE]))
+    rooted = bool(rng.integers(0, 2)) or n == 3 and False
+    rescaling = bool(rng.integers(0, 2))
+    gap_rate = float(rng.choice([0.0, 0.05, 0.5]))
+    states = 61 if codon else 4
+    patterns = rng.integers(0, states, (n, P)).astype(np.int32)
+    patterns[rng.random((n, P)) < gap_rate] = states
+    weights = rng.integers(1, 9, P).astype(np.float64)
+    if rooted:
+        pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(T)])
+        M = 2 * n - 1
+    else:
+        if n < 3:
+            continue
+        pid = np.stack([workloads.random_unrooted_tree(n, rng, 0.1).parent_ids for _ in range(T)]).astype(np.int32)
+        M = 2 * n - 2
+    scale = float(rng.choice([0.01, 0.1, 1.0]))
+    bl = rng.exponential(scale, (T, M))
+    bl[:, -1] = 0.0
+    if rng.random() < 0.2:
+        bl[rng.random((T, M)) < 0.1] = 0.0
+    desc = f"case {case}: n={n} P={P} T={T} {sub}+{site} kernel={kernel} rooted={rooted} rescaling={rescaling} gaps={gap_rate} scale={scale}"
+    try:
+        if codon:
+            gpu = bito_amd.Engine(spec("GY94", site), patterns, weights)
+            cpu = gs.GsOracleEngine("GY94", site, patterns, weights, 8)
+        else:
+            gpu, cpu = engines(sub, site, "none", patterns, weights, 8)
+            try:
+                gpu.set_kernel(kernel)
+            except bito_amd.BitoAmdError:
+                pass
+        params = gpu.default_params(T)
+        if codon:
+            params[:, :4] = rng.dirichlet([5, 5, 5, 5], T)
+            params[:, 4] = rng.uniform(1.0, 4.0, T)  # kappa
+            params[:, 5] = rng.uniform(0.1, 1.5, T)  # omega
+        elif sub != "JC69":
+            params[:, :4] = rng.dirichlet([5, 5, 5, 5], T)
+            k = 6 if sub == "GTR" else 1
+            params[:, 4:4 + k] = rng.dirichlet([3] * 6, T) if sub == "GTR" else rng.uniform(0.5, 4.0, (T, 1))
+        if site != "constant":
+            params[:, -1] = rng.uniform(0.3, 2.0, T)
+        try:
+            out = gpu.gradients(pid, bl, params, rescaling=rescaling)
+        except bito_amd.BitoAmdError as e:
+            if kernel in (_capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE):
+                continue  # a forced kernel that does not take this shape says so
+            raise
+        ref = cpu.gradients(pid, bl, params, rescaling=rescaling)
+        # degenerate inputs (zero-length branches between conflicting states) give -inf / nan / 1e17 on both sides:
+        # equal non-finite values count as equal, huge gradients are compared relatively
+        def close(a, b, atol):
+            a, b = np.asarray(a), np.asarray(b)
+            fa, fb = np.isfinite(a), np.isfinite(b)  # a likelihood of exactly zero is -inf or nan on either side
+            return np.array_equal(fa, fb) and np.allclose(a[fa], b[fa], rtol=1e-9, atol=atol)
+
+        ok = close(out["log_likelihood"], ref["log_likelihood"], 1e-10) and close(out["branch_lengths"], ref["branch_lengths"], 1e-6)
+        ll2 = gpu.log_likelihoods(pid, bl, params, rescaling=rescaling)
+        ok = ok and close(ll2, ref["log_likelihood"], 1e-10)
+        if not ok:
+            bad += 1
+            dl = np.nanmax(np.abs(out["log_likelihood"] - ref["log_likelihood"]))
+            dg = np.nanmax(np.abs(out["branch_lengths"] - ref["branch_lengths"]))
+            g, r = out["branch_lengths"], ref["branch_lengths"]
+            both = np.isfinite(g) & np.isfinite(r)
+            rel = np.max(np.abs(g[both] - r[both]) / (1e-6 + 1e-9 * np.abs(r[both]))) if both.any() else 0.0
+            print("MISMATCH", desc, f"kernel_used={gpu.kernel_name()} dLL={dl:.3e} dgrad={dg:.3e}; gradient entries: "
+                  f"gpu finite / ref not {int((np.isfinite(g) & ~np.isfinite(r)).sum())}, ref finite / gpu not "
+                  f"{int((~np.isfinite(g) & np.isfinite(r)).sum())}, worst both-finite error in tolerances {rel:.2f}; "
+                  f"zero branches {int((bl[:, :-1] == 0).sum())}, LL finite gpu/ref {int(np.isfinite(out['log_likelihood']).sum())}/{int(np.isfinite(ref['log_likelihood']).sum())}")
+    except Exception as e:  # noqa: BLE001
+        bad += 1
+        print("ERROR", desc, repr(e)[:300])
+print(f"{cases} cases, {bad} bad, {time.time() - t0:.0f} s")
