@@ -200,6 +200,16 @@ gp_levels_kernel(const bito_amd_gp_op* __restrict__ ops, const int64_t* __restri
   }
 }
 
+// dst[map[row]] = src[row] for rows of row_len elements (GrowPLVs / GrowGPCSPs with a reindexer)
+template <typename T>
+__global__ void __launch_bounds__(256)
+gp_permute_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, const int64_t* __restrict__ map, size_t row_len) {
+  const size_t row = blockIdx.y;
+  const T* from = src + row * row_len;
+  T* to = dst + (size_t)map[row] * row_len;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_len; i += (size_t)gridDim.x * blockDim.x) to[i] = from[i];
+}
+
 // block per row: out[row] = sum_p w_p * rows[row][p]
 __global__ void __launch_bounds__(256)
 gp_weighted_rows_kernel(const double* __restrict__ rows, const double* __restrict__ weights, int P, int Ppad,
@@ -962,6 +972,110 @@ int bito_amd_gp_grow_spare(bito_amd_gp_engine* e, int64_t spare_plv_count, int64
     GP_TRY(e, grow(e->scratch, have + 4, want + 4));
     e->spare_gpcsps = spare_gpcsp_count;
   }
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_grow(bito_amd_gp_engine* e, int32_t new_node_count, int32_t new_gpcsp_count,
+                     const int64_t* node_reindexer, const int64_t* gpcsp_reindexer) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  if (new_node_count < e->nodes || new_gpcsp_count < e->gpcsps)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "GrowPLVs / GrowGPCSPs: the engine only grows");
+  // a reindexer is a permutation of [0, new count): old index -> new index (Reindexer::GetNewIndexByOldIndex)
+  auto check = [&](const int64_t* map, int64_t count) {
+    if (!map) return true;
+    std::vector<char> seen(count, 0);
+    for (int64_t i = 0; i < count; i++) {
+      if (map[i] < 0 || map[i] >= count || seen[map[i]]) return false;
+      seen[map[i]] = 1;
+    }
+    return true;
+  };
+  if (!check(node_reindexer, new_node_count)) return Fail(e, BITO_AMD_ERR_BAD_ARG, "Node Reindexer is not valid.");
+  if (!check(gpcsp_reindexer, new_gpcsp_count))
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "GPCSP Reindexer is not valid for GPEngine size.");
+  GP_TRY(e, hipSetDevice(e->device));
+  GP_TRY(e, hipDeviceSynchronize());
+  const int old_nodes = e->nodes, old_gpcsps = e->gpcsps;
+  auto device_copy = [&](const std::vector<int64_t>& host, int64_t** out) -> hipError_t {
+    hipError_t rc = hipMalloc((void**)out, host.size() * sizeof(int64_t));
+    if (rc != hipSuccess) return rc;
+    return hipMemcpy(*out, host.data(), host.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+  };
+  if (new_node_count != old_nodes || node_reindexer) {
+    // PLV (type, node) moves to (type, reindexer[node]); new nodes and the spare slots start zeroed
+    const size_t new_plvs = (size_t)6 * new_node_count, total = new_plvs + e->spare_plvs;
+    std::vector<int64_t> map((size_t)6 * old_nodes);
+    for (int t = 0; t < 6; t++)
+      for (int v = 0; v < old_nodes; v++)
+        map[(size_t)t * old_nodes + v] = (int64_t)t * new_node_count + (node_reindexer ? node_reindexer[v] : v);
+    int64_t* d_map = nullptr;
+    double* plv = nullptr;
+    int* counts = nullptr;
+    GP_TRY(e, device_copy(map, &d_map));
+    GP_TRY(e, hipMalloc((void**)&plv, total * 4 * e->Ppad * sizeof(double)));
+    GP_TRY(e, hipMalloc((void**)&counts, total * e->Ppad * sizeof(int)));
+    GP_TRY(e, hipMemset(plv, 0, total * 4 * e->Ppad * sizeof(double)));
+    GP_TRY(e, hipMemset(counts, 0, total * e->Ppad * sizeof(int)));
+    hipLaunchKernelGGL(gp_permute_rows_kernel<double>, dim3(4, (unsigned)map.size()), dim3(256), 0, 0, e->plv, plv, d_map,
+                       (size_t)4 * e->Ppad);
+    hipLaunchKernelGGL(gp_permute_rows_kernel<int>, dim3(1, (unsigned)map.size()), dim3(256), 0, 0, e->counts, counts, d_map,
+                       (size_t)e->Ppad);
+    GP_TRY(e, hipDeviceSynchronize());
+    (void)hipFree(d_map);
+    (void)hipFree(e->plv);
+    (void)hipFree(e->counts);
+    e->plv = plv;
+    e->counts = counts;
+    e->nodes = new_node_count;
+    e->plvs = (int)new_plvs;
+  }
+  if (new_gpcsp_count != old_gpcsps || gpcsp_reindexer) {
+    const size_t total = (size_t)new_gpcsp_count + e->spare_gpcsps;
+    // per-GPCSP scalars on the host: new edges start with the default branch length, q = 1 and no difference
+    std::vector<double> bl(old_gpcsps), q(old_gpcsps), diff(old_gpcsps);
+    GP_TRY(e, hipMemcpy(bl.data(), e->bl, old_gpcsps * sizeof(double), hipMemcpyDeviceToHost));
+    GP_TRY(e, hipMemcpy(q.data(), e->q, old_gpcsps * sizeof(double), hipMemcpyDeviceToHost));
+    GP_TRY(e, hipMemcpy(diff.data(), e->diff, old_gpcsps * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> nbl(total, 0.0), nq(total, 0.0), ndiff(total, 0.0);
+    std::vector<int64_t> map(old_gpcsps);
+    for (int64_t i = 0; i < new_gpcsp_count; i++) {
+      const int64_t to = gpcsp_reindexer ? gpcsp_reindexer[i] : i;
+      if (i < old_gpcsps) {
+        nbl[to] = bl[i]; nq[to] = q[i]; ndiff[to] = diff[i];
+        map[i] = to;
+      } else {
+        nbl[to] = 0.1;  // DAGBranchHandler::init_default_branch_length_
+        nq[to] = 1.0;   // GPEngine::GrowGPCSPs: q_[i] = 1
+      }
+    }
+    double *dbl = nullptr, *dq = nullptr, *ddiff = nullptr, *ll = nullptr, *scratch = nullptr;
+    int64_t* d_map = nullptr;
+    GP_TRY(e, device_copy(map, &d_map));
+    GP_TRY(e, hipMalloc((void**)&dbl, total * sizeof(double)));
+    GP_TRY(e, hipMalloc((void**)&dq, total * sizeof(double)));
+    GP_TRY(e, hipMalloc((void**)&ddiff, total * sizeof(double)));
+    GP_TRY(e, hipMalloc((void**)&ll, total * e->Ppad * sizeof(double)));
+    GP_TRY(e, hipMalloc((void**)&scratch, (total + 4) * sizeof(double)));
+    GP_TRY(e, hipMemcpy(dbl, nbl.data(), total * sizeof(double), hipMemcpyHostToDevice));
+    GP_TRY(e, hipMemcpy(dq, nq.data(), total * sizeof(double), hipMemcpyHostToDevice));
+    GP_TRY(e, hipMemcpy(ddiff, ndiff.data(), total * sizeof(double), hipMemcpyHostToDevice));
+    GP_TRY(e, hipMemset(ll, 0, total * e->Ppad * sizeof(double)));
+    hipLaunchKernelGGL(gp_permute_rows_kernel<double>, dim3(1, (unsigned)old_gpcsps), dim3(256), 0, 0, e->ll, ll, d_map,
+                       (size_t)e->Ppad);
+    GP_TRY(e, hipDeviceSynchronize());
+    (void)hipFree(d_map);
+    for (double* p : {e->bl, e->q, e->diff, e->ll, e->scratch}) (void)hipFree(p);
+    e->bl = dbl; e->q = dq; e->diff = ddiff; e->ll = ll; e->scratch = scratch;
+    e->gpcsps = new_gpcsp_count;
+  }
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_get_plv(bito_amd_gp_engine* e, int64_t plv, double* out) {
+  if (!e || !out || plv < 0 || plv >= (int64_t)e->plvs + e->spare_plvs) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  GP_TRY(e, hipMemcpy2D(out, e->P * sizeof(double), e->plv + (size_t)plv * 4 * e->Ppad, e->Ppad * sizeof(double),
+                        e->P * sizeof(double), 4, hipMemcpyDeviceToHost));
   return BITO_AMD_OK;
 }
 

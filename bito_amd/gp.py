@@ -235,6 +235,7 @@ GP_SYMBOLS = [
     "bito_amd_gp_reset_optimization_count", "bito_amd_gp_increment_optimization_count",
     "bito_amd_gp_grow_spare", "bito_amd_gp_copy_gpcsp_data", "bito_amd_gp_process_operation_batches",
     "bito_amd_gp_per_gpcsp_log_likelihoods_range", "bito_amd_gp_branch_lengths_range",
+    "bito_amd_gp_grow", "bito_amd_gp_get_plv",
 ]
 
 
@@ -264,6 +265,8 @@ def _lib():
         L.bito_amd_gp_process_operation_batches.argtypes = [vp, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, ip, C.c_int64]
         L.bito_amd_gp_per_gpcsp_log_likelihoods_range.argtypes = [vp, C.c_int64, C.c_int64, dp]
         L.bito_amd_gp_branch_lengths_range.argtypes = [vp, C.c_int64, C.c_int64, dp]
+        L.bito_amd_gp_grow.argtypes = [vp, C.c_int32, C.c_int32, ip, ip]
+        L.bito_amd_gp_get_plv.argtypes = [vp, C.c_int64, dp]
         L._gp_ready = True
     return L
 
@@ -368,6 +371,23 @@ class GPEngine:
 
     def get_branch_lengths_range(self, first: int, count: int):
         return self._range(_lib().bito_amd_gp_branch_lengths_range, first, count)
+
+    def grow(self, new_node_count: int, new_gpcsp_count: int, node_reindexer=None, gpcsp_reindexer=None):
+        """GrowPLVs + GrowGPCSPs with reindexers (old index -> new index), after the DAG has grown."""
+        ip = C.POINTER(C.c_int64)
+        nr = None if node_reindexer is None else np.ascontiguousarray(node_reindexer, dtype=np.int64)
+        gr = None if gpcsp_reindexer is None else np.ascontiguousarray(gpcsp_reindexer, dtype=np.int64)
+        if nr is not None and nr.shape != (new_node_count,) or gr is not None and gr.shape != (new_gpcsp_count,):
+            raise BitoAmdError(_capi.ERR_BAD_ARG, "a reindexer has one entry per index of the grown engine")
+        self._check(_lib().bito_amd_gp_grow(self._h, int(new_node_count), int(new_gpcsp_count),
+                                            None if nr is None else nr.ctypes.data_as(ip),
+                                            None if gr is None else gr.ctypes.data_as(ip)))
+        self.node_count, self.gpcsp_count = int(new_node_count), int(new_gpcsp_count)
+
+    def get_plv(self, plv: int) -> np.ndarray:
+        out = np.zeros((4, self.pattern_count))
+        self._check(_lib().bito_amd_gp_get_plv(self._h, int(plv), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
 
     def get_log_marginal_likelihood(self) -> float:
         return float(self._vec(_lib().bito_amd_gp_log_marginal_likelihood, 1)[0])

@@ -135,6 +135,23 @@ class SubsplitDAG:
             pcsps |= self._compatible_pcsps(subsplits, only=fresh)
         return SubsplitDAG(self.taxon_count, subsplits=subsplits, pcsps=pcsps)
 
+    def reindexers_to(self, grown: "SubsplitDAG"):
+        """(node_reindexer, gpcsp_reindexer) from this DAG's ids to those of a DAG grown out of it: old index ->
+        new index for every node / edge both hold (matched by subsplit), the ids that are new taking the
+        remaining places in order -- the permutations GPEngine::GrowPLVs / GrowGPCSPs expect
+        (SubsplitDAG::ModificationResult::{node,edge}_reindexer, src/subsplit_dag.hpp)."""
+        def complete(known, new_count):
+            taken = set(known)
+            rest = iter(i for i in range(new_count) if i not in taken)
+            return np.array(list(known) + [next(rest) for _ in range(new_count - len(known))], dtype=np.int64)
+
+        nodes = [grown.node_id[s] for s in self.subsplits]
+        edges = [0] * self.gpcsp_count
+        for (p, c), e in self.edge_id.items():
+            gp_, gc = (-1 if p < 0 else grown.node_id[self.subsplits[p]]), grown.node_id[self.subsplits[c]]
+            edges[e] = grown.edge_id[(gp_, gc)]
+        return complete(nodes, grown.node_count), complete(edges, grown.gpcsp_count)
+
     # DAGBranchHandler::BuildBranchLengthMap / ApplyBranchLengthMap (src/dag_branch_handler.hpp:214-219):
     # branch lengths keyed by the edge's (parent subsplit, child subsplit), None = the DAG root
     def branch_length_map(self, branch_lengths) -> Dict:

@@ -88,6 +88,17 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine *e, const bito_amd_gp_op *
  * with bito_amd_gp_copy_gpcsp_data. */
 int bito_amd_gp_grow_spare(bito_amd_gp_engine *e, int64_t spare_plv_count, int64_t spare_gpcsp_count);
 
+/* GPEngine::GrowPLVs(node_count, node_reindexer) + GrowGPCSPs(gpcsp_count, gpcsp_reindexer)
+ * (src/gp_engine.hpp:44-51, src/gp_engine.cpp:64-193): the DAG has grown (AddNodePair).  A reindexer is a
+ * permutation of [0, new count) giving old index -> new index (Reindexer::GetNewIndexByOldIndex); NULL =
+ * identity.  PLV (type, node) moves to (type, reindexer[node]) with its rescaling counts, per-GPCSP data
+ * (branch length, q, difference, log-likelihood row) to reindexer[gpcsp]; new nodes start zeroed, new
+ * GPCSPs with the default branch length 0.1 and q = 1.  Spare slots are kept in number, not in content. */
+int bito_amd_gp_grow(bito_amd_gp_engine *e, int32_t new_node_count, int32_t new_gpcsp_count,
+                     const int64_t *node_reindexer, const int64_t *gpcsp_reindexer);
+/* GetPLV(plv_index) (src/gp_engine.hpp:145-150): out[4][pattern_count], one row per state. */
+int bito_amd_gp_get_plv(bito_amd_gp_engine *e, int64_t plv, double *out);
+
 /* GPEngine::CopyGPCSPData(src, dest) (src/gp_engine.cpp:401-409) for count pairs, applied in order:
  * branch length and q of src[i] are copied to dst[i]. */
 int bito_amd_gp_copy_gpcsp_data(bito_amd_gp_engine *e, const int64_t *src, const int64_t *dst, int64_t count);

@@ -39,6 +39,8 @@ def lib():
         L.gp_oracle_copy_gpcsp_data.argtypes = [vp, C.c_int, C.c_int]
         L.gp_oracle_per_gpcsp_log_likelihoods_range.argtypes = [vp, C.c_int, C.c_int, dp]
         L.gp_oracle_branch_lengths_range.argtypes = [vp, C.c_int, C.c_int, dp]
+        L.gp_oracle_grow.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.gp_oracle_get_plv.argtypes = [vp, C.c_int, dp]
         _lib = L
     return _lib
 
@@ -119,6 +121,19 @@ class OracleGPEngine:
     def get_branch_lengths_range(self, first, count):
         out = np.zeros(count)
         lib().gp_oracle_branch_lengths_range(self._h, int(first), int(count), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def grow(self, new_node_count, new_gpcsp_count, node_reindexer=None, gpcsp_reindexer=None):
+        ip = C.POINTER(C.c_int64)
+        nr = None if node_reindexer is None else np.ascontiguousarray(node_reindexer, dtype=np.int64)
+        gr = None if gpcsp_reindexer is None else np.ascontiguousarray(gpcsp_reindexer, dtype=np.int64)
+        lib().gp_oracle_grow(self._h, int(new_node_count), int(new_gpcsp_count),
+                             None if nr is None else nr.ctypes.data_as(ip), None if gr is None else gr.ctypes.data_as(ip))
+        self.gpcsp_count = int(new_gpcsp_count)
+
+    def get_plv(self, plv):
+        out = np.zeros((4, self.patterns.shape[1]))
+        lib().gp_oracle_get_plv(self._h, int(plv), out.ctypes.data_as(C.POINTER(C.c_double)))
         return out
 
     def get_log_marginal_likelihood(self):

@@ -318,6 +318,47 @@ void gp_oracle_grow_spare(gp_oracle *g, int spare_plvs, int spare_gpcsps) {
     g->spare_gpcsps = spare_gpcsps;
   }
 }
+/* GPEngine::GrowPLVs + GrowGPCSPs with reindexers (src/gp_engine.cpp:64-193): old index -> new index,
+ * NULL = identity; new nodes zeroed, new GPCSPs with branch length 0.1 and q = 1; spare slots emptied. */
+void gp_oracle_grow(gp_oracle *g, int new_nodes, int new_gpcsps, const int64_t *node_map, const int64_t *gpcsp_map) {
+  const int old_nodes = g->plv_count / 6, old_gpcsps = g->gpcsp_count;
+  const size_t cell = (size_t)g->P * 4;
+  {
+    const size_t total = (size_t)6 * new_nodes + g->spare_plvs;
+    double *plv = (double *)calloc(total * cell, sizeof(double));
+    int *counts = (int *)calloc(total, sizeof(int));
+    for (int t = 0; t < 6; t++)
+      for (int v = 0; v < old_nodes; v++) {
+        const size_t from = (size_t)t * old_nodes + v, to = (size_t)t * new_nodes + (node_map ? node_map[v] : v);
+        memcpy(plv + to * cell, g->plv + from * cell, cell * sizeof(double));
+        counts[to] = g->counts[from];
+      }
+    free(g->plv); free(g->counts);
+    g->plv = plv; g->counts = counts; g->plv_count = 6 * new_nodes;
+  }
+  {
+    const size_t total = (size_t)new_gpcsps + g->spare_gpcsps;
+    double *bl = (double *)calloc(total, sizeof(double)), *q = (double *)calloc(total, sizeof(double));
+    double *diff = (double *)calloc(total, sizeof(double)), *ll = (double *)calloc(total * g->P, sizeof(double));
+    for (int i = 0; i < new_gpcsps; i++) {
+      const size_t to = gpcsp_map ? (size_t)gpcsp_map[i] : (size_t)i;
+      if (i < old_gpcsps) {
+        bl[to] = g->bl[i]; q[to] = g->q[i]; diff[to] = g->diff[i];
+        memcpy(ll + to * g->P, g->ll + (size_t)i * g->P, sizeof(double) * g->P);
+      } else {
+        bl[to] = 0.1; q[to] = 1.0;
+      }
+    }
+    free(g->bl); free(g->q); free(g->diff); free(g->ll);
+    g->bl = bl; g->q = q; g->diff = diff; g->ll = ll; g->gpcsp_count = new_gpcsps;
+  }
+}
+/* GetPLV: out[4][P], one row per state (the arena is column-major 4 x P per PLV) */
+void gp_oracle_get_plv(const gp_oracle *g, int plv, double *out) {
+  for (int p = 0; p < g->P; p++)
+    for (int i = 0; i < 4; i++) out[(size_t)i * g->P + p] = g->plv[((size_t)plv * g->P + p) * 4 + i];
+}
+
 /* GPEngine::CopyGPCSPData (src/gp_engine.cpp:401-409) */
 void gp_oracle_copy_gpcsp_data(gp_oracle *g, int src, int dst) {
   g->bl[dst] = g->bl[src];

@@ -317,3 +317,72 @@ def test_optimised_proposals_batched_gpu_equals_cpu(data_dir, fasta, newick, met
     for prop in ev.proposals:
         assert again[prop.central_edge - first] == g_scores[prop.nni]
     assert np.array_equal(eng.get_branch_lengths_range(first, len(src)), g_len)
+
+
+# -- growing the engine with the DAG: "NNIEngine: Resize and Reindex GPEngine after AddNodePair" ---------------
+# (src/gp_doctest.cpp:1715-1935)
+
+def _grow_and_check(make_engine, data_dir, fasta, newick):
+    sp, dag = _load(data_dir, fasta, newick)
+    rng = np.random.default_rng(12)
+    bl = rng.uniform(0.02, 0.4, dag.gpcsp_count)
+    eng = make_engine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+    eng.set_branch_lengths(bl)
+    eng.set_sbn_parameters(np.ones(dag.gpcsp_count))
+    eng.process_operations(dag.populate_plvs())
+    eng.process_operations(dag.compute_likelihoods())
+    before_plvs = [eng.get_plv(k) for k in range(6 * dag.node_count)]
+    before_ll = eng.get_per_gpcsp_log_likelihoods()
+    grown = dag
+    for x in adjacent_nnis(dag)[:3]:
+        grown = grown.with_node_pair(x.parent, x.child)
+    node_map, edge_map = dag.reindexers_to(grown)
+    assert sorted(node_map) == list(range(grown.node_count)) and sorted(edge_map) == list(range(grown.gpcsp_count))
+    eng.grow(grown.node_count, grown.gpcsp_count, node_map, edge_map)
+    # every PLV and every per-edge quantity sits at its new index
+    for t in range(6):
+        for v in range(dag.node_count):
+            assert np.array_equal(eng.get_plv(t * grown.node_count + node_map[v]), before_plvs[t * dag.node_count + v])
+    lengths = eng.get_branch_lengths()
+    assert np.array_equal(lengths[edge_map[:dag.gpcsp_count]], bl)
+    fresh = np.setdiff1d(np.arange(grown.gpcsp_count), edge_map[:dag.gpcsp_count])
+    assert len(fresh) > 0 and np.all(lengths[fresh] == 0.1) and np.all(eng.get_sbn_parameters()[fresh] == 1.0)
+    assert np.array_equal(eng.get_per_gpcsp_log_likelihoods()[edge_map[:dag.gpcsp_count]], before_ll)
+    for v in range(dag.node_count, grown.node_count):  # nodes that are new start empty
+        assert not eng.get_plv(node_map[v]).any()
+    # and the grown engine runs the grown DAG like an engine created for it
+    eng.process_operations(grown.populate_plvs())
+    eng.process_operations(grown.compute_likelihoods())
+    other = make_engine(sp.patterns, sp.weights, grown.node_count, grown.gpcsp_count)
+    other.set_branch_lengths(lengths)
+    other.set_sbn_parameters(np.ones(grown.gpcsp_count))
+    other.process_operations(grown.populate_plvs())
+    other.process_operations(grown.compute_likelihoods())
+    assert np.array_equal(eng.get_per_gpcsp_log_likelihoods(), other.get_per_gpcsp_log_likelihoods())
+    assert eng.get_log_marginal_likelihood() == other.get_log_marginal_likelihood()
+    # proposals can be scored on the grown engine right away
+    scores = NNIEvalEngineViaGP(grown, eng).score_adjacent_nnis()
+    scores2 = NNIEvalEngineViaGP(grown, other).score_adjacent_nnis()
+    assert scores.keys() == scores2.keys() and all(scores[k] == scores2[k] for k in scores)
+    eng.grow(grown.node_count, grown.gpcsp_count)  # a no-op grow keeps everything
+    assert np.array_equal(eng.get_branch_lengths(), lengths)
+    return eng
+
+
+@pytest.mark.parametrize("fasta,newick", CASES[1:])
+def test_engine_grows_with_the_dag_cpu(data_dir, fasta, newick):
+    from oracle import gp as ogp
+
+    _grow_and_check(ogp.OracleGPEngine, data_dir, fasta, newick)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fasta,newick", CASES[1:])
+def test_engine_grows_with_the_dag_gpu(data_dir, fasta, newick):
+    from bito_amd import BitoAmdError, gp
+
+    eng = _grow_and_check(gp.GPEngine, data_dir, fasta, newick)
+    with pytest.raises(BitoAmdError):
+        eng.grow(eng.node_count - 1, eng.gpcsp_count)  # the engine only grows
+    with pytest.raises(BitoAmdError):
+        eng.grow(eng.node_count, eng.gpcsp_count, np.zeros(eng.node_count, dtype=np.int64))  # not a permutation
