@@ -386,3 +386,43 @@ def test_engine_grows_with_the_dag_gpu(data_dir, fasta, newick):
         eng.grow(eng.node_count - 1, eng.gpcsp_count)  # the engine only grows
     with pytest.raises(BitoAmdError):
         eng.grow(eng.node_count, eng.gpcsp_count, np.zeros(eng.node_count, dtype=np.int64))  # not a permutation
+
+
+@pytest.mark.parametrize("include_rootsplits", [True, False])
+@pytest.mark.parametrize("fasta,newick", [CASES[0], ("five_taxon.fasta", "five_taxon_trees_3_4_diff_branches.nwk")])
+def test_adding_every_adjacent_nni_builds_the_complete_dag(data_dir, fasta, newick, include_rootsplits):
+    """"NNIEngine: Build Complete DAG by Adding NNIs (include/exclude rootsplit)" (src/gp_doctest.cpp:1446-1568):
+    add all adjacent NNIs, re-sync, repeat until none is left -- every subsplit of the taxon set is then a
+    node ((3^n - 2^(n+1) + 1) / 2 of them); without rootsplit NNIs the rootsplits stay as they were and
+    exactly the subsplits below them appear."""
+    tc = treeio.read_newick_file(os.path.join(data_dir, newick))
+    n = len(tc.taxon_names)
+    dag = SubsplitDAG(n, [t.parent_ids for t in tc.trees])
+    rootsplits = {dag.subsplits[r] for r in dag.rootsplits}
+    rounds = 0
+    while True:
+        todo = adjacent_nnis(dag, include_rootsplits=include_rootsplits)
+        if not todo:
+            break
+        for x in todo:
+            dag = dag.with_node_pair(x.parent, x.child)
+        rounds += 1
+        assert rounds < 50
+    internal = set(dag.subsplits[n:])
+    every = set()
+    for assignment in np.ndindex(*([3] * n)):  # taxon -> left / right / absent
+        a = sum(1 << i for i, k in enumerate(assignment) if k == 0)
+        b = sum(1 << i for i, k in enumerate(assignment) if k == 1)
+        if a and b:
+            every.add(nni_mod.make_subsplit(a, b))
+    assert len(every) == (3 ** n - 2 ** (n + 1) + 1) // 2
+    if include_rootsplits:
+        assert internal == every
+    else:
+        assert {dag.subsplits[r] for r in dag.rootsplits} == rootsplits
+        below = set(rootsplits)
+        for s in every:
+            if any((s[0] | s[1]) & ~r[0] == 0 or (s[0] | s[1]) & ~r[1] == 0 for r in rootsplits):
+                below.add(s)
+        assert internal == below
+    assert dag.fully_connected().gpcsp_count == dag.gpcsp_count  # and every compatible pair is an edge
