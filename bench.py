@@ -69,14 +69,17 @@ def cpu_baseline(w, seconds: float):
     probe = max(4 * threads, 64)
     pid, bl, par = sample(probe)
     run(pid, bl, par, rescaling=w.rescaling)  # warm-up: first touch of every thread's buffers
-    t0 = time.perf_counter()
-    run(pid, bl, par, rescaling=w.rescaling)
-    rate = probe / (time.perf_counter() - t0)
-    count = int(max(probe, rate * seconds))
-    pid, bl, par = sample(count)
-    t0 = time.perf_counter()
-    run(pid, bl, par, rescaling=w.rescaling)
-    dt = time.perf_counter() - t0
+    # Timed in chunks until the budget is used: a short probe overestimates the sustained rate of a
+    # many-core host severalfold, so the sample size is not extrapolated from it.
+    count, dt, chunk = 0, 0.0, probe
+    while dt < seconds:
+        pid, bl, par = sample(chunk)
+        t0 = time.perf_counter()
+        run(pid, bl, par, rescaling=w.rescaling)
+        took = time.perf_counter() - t0
+        count += chunk
+        dt += took
+        chunk = int(min(max(probe, chunk / max(took, 1e-3) * seconds / 4), 64 * probe))  # about a quarter of the budget
     return {"value": count / dt, "unit": "trees/s", "cores": threads, "kind": "port",
             "sample": f"{count} trees of the same workload, {dt:.1f} s, {source} with {threads} threads "
                       "(FP64 restatement of the BEAGLE CPU path; the reference binary cannot be built here)"}
