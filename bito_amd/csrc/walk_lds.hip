@@ -577,8 +577,11 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
     // (SetRootPreorderPartialsToStateFrequencies, fat_beagle.cpp:327-336).  It stays in
     // registers when the next node is this node's second child (the usual case).
     double U[G];
+    // The weight of a (category, pattern) term, w_c w_p / L_p, is the same at every edge and every operation
+    // of this pass is linear in U lane by lane, so it rides along from the root instead of being
+    // multiplied into each edge's terms.
 #pragma unroll
-    for (int g = 0; g < G; g++) U[g] = pi_st;
+    for (int g = 0; g < G; g++) U[g] = pi_st * coef[g];
     // edge sums of the previous step, reduced one step late so that the reduction fills the
     // wait for this step's LDS operands: the two child edges, and the tip edges of cherry children
     double ps0 = 0.0, ps1 = 0.0, pa0 = 0.0, pb0 = 0.0, pa1 = 0.0, pb1 = 0.0;
@@ -666,8 +669,8 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
 #pragma unroll
           for (int g = 0; g < G; g++) {
             const double q = Mfma(cur.t0, ua1[g], 0.0);
-            sa = fma(coef[g], (q * mb0[g]) * Mfma(cur.da0, ta0[g], 0.0), sa);
-            sb = fma(coef[g], (q * ma0[g]) * Mfma(cur.db0, tb0[g], 0.0), sb);
+            sa = fma(q * mb0[g], Mfma(cur.da0, ta0[g], 0.0), sa);
+            sb = fma(q * ma0[g], Mfma(cur.db0, tb0[g], 0.0), sb);
           }
           pa0 = sa; pb0 = sb; pab0 = ds[kAb0];
         } else {
@@ -681,8 +684,8 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
 #pragma unroll
           for (int g = 0; g < G; g++) {
             const double q = Mfma(cur.t1, ua0[g], 0.0);
-            sa = fma(coef[g], (q * mb1[g]) * Mfma(cur.da1, ta1[g], 0.0), sa);
-            sb = fma(coef[g], (q * ma1[g]) * Mfma(cur.db1, tb1[g], 0.0), sb);
+            sa = fma(q * mb1[g], Mfma(cur.da1, ta1[g], 0.0), sa);
+            sb = fma(q * ma1[g], Mfma(cur.db1, tb1[g], 0.0), sb);
           }
           pa1 = sa; pb1 = sb; pab1 = ds[kAb1];
         } else {
@@ -698,8 +701,8 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        s0 = fma(coef[g], ua1[g] * dd0[g], s0);
-        s1 = fma(coef[g], ua0[g] * dd1[g], s1);
+        s0 = fma(ua1[g], dd0[g], s0);
+        s1 = fma(ua0[g], dd1[g], s1);
       }
       ps0 = s0; ps1 = s1; pc0 = DS_C0(ds); pc1 = DS_C1(ds);
     };
