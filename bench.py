@@ -180,7 +180,12 @@ def main():
     # event of the sum that last read it.
     kRing = 4
     ll_ring = torch.zeros(kRing, T, dtype=torch.float64, device="cuda") if reduce_ll else None
-    engine_stream = torch.cuda.ExternalStream(eng.stream_handle()) if reduce_ll else None
+    engine_stream = None
+    if reduce_ll:
+        try:
+            engine_stream = torch.cuda.ExternalStream(eng.stream_handle())
+        except Exception as exc:  # noqa: BLE001 -- then hand results over with a host wait per step instead
+            print(f"bench: no external-stream wrapper ({exc!r}); the reduction waits on the host each step", file=sys.stderr)
     sum_done = [None] * kRing
     pending = []  # (work handle, tensor) of the reductions in flight
     step_index = [0]
@@ -191,15 +196,19 @@ def main():
         if reduce_ll:
             slot = step_index[0] % kRing
             step_index[0] += 1
-            if sum_done[slot] is not None:
+            if engine_stream is not None and sum_done[slot] is not None:
                 engine_stream.wait_event(sum_done[slot])
         eng.run(w.want_gradient, w.rescaling)
         if reduce_ll:
-            eng.download_async(ll_ring[slot].data_ptr(), None)
-            copied = torch.cuda.Event()
-            copied.record(engine_stream)
             here = torch.cuda.current_stream()
-            here.wait_event(copied)
+            if engine_stream is not None:
+                eng.download_async(ll_ring[slot].data_ptr(), None)
+                copied = torch.cuda.Event()
+                copied.record(engine_stream)
+                here.wait_event(copied)
+            else:
+                torch.cuda.synchronize()  # earlier sums have read their slots
+                eng.download_to(ll_ring[slot].data_ptr(), None)  # waits for the pass
             total = ll_ring[slot].sum().reshape(1)
             sum_done[slot] = torch.cuda.Event()
             sum_done[slot].record(here)
