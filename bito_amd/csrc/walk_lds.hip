@@ -499,6 +499,13 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
       dispatch(D2, S2, D0, S0, D1, S1);
       if (++k >= steps) break;
     }
+    // The last steps fetched descriptors that nobody waits for.  A scalar load lands whenever it lands, and
+    // its destination registers are dead to the compiler from here on: nothing after the loop may be
+    // scheduled, or given those registers, before the load has landed.  (The wait names no register on
+    // purpose: an operand would make the compiler copy the in-flight tuple at every loop exit.)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---------------- root: site likelihoods ----------------------------------
@@ -717,6 +724,9 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
       dispatch(D2, S2, D0, S0, D1, S1);
       if (++j >= steps) break;
     }
+    __builtin_amdgcn_sched_barrier(0);  // (as after the post-order pass: no descriptor load is left in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     flush_edges();
   }
 #undef TIP_AT
