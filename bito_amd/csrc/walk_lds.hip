@@ -29,6 +29,7 @@
 // post-order pass; every edge derivative is then sum_p (w_p / L_p) sum_c w_c (...).
 // Not available here: rescaling (small trees do not need it; the engine routes
 // rescaling requests to the HBM-arena kernel).
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -89,6 +90,9 @@ void LaunchMatrixImages(const BatchDims& d, const DeviceBatch& b, int want_gradi
 #endif
 #ifndef LDS_COND_LOADS
 #define LDS_COND_LOADS 0
+#endif
+#ifndef LDS_TILE_RUN
+#define LDS_TILE_RUN 0  // 0: the launcher picks the run length; n: force runs of n tiles (experiments)
 #endif
 #ifndef LDS_NO_CHERRIES
 #define LDS_NO_CHERRIES 0  // 1: store every internal node (ablation of the cherry folding)
@@ -282,7 +286,7 @@ struct alignas(16) PdPair { double p, d; };  // one lane's P and dP entries of a
 
 template <int C, int G, bool GRAD>
 __global__ void __launch_bounds__(kLdsWaves * 64, LDS_WAVES_PER_EU)
-walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, const StepDesc* __restrict__ sched,
+walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, int tile_run, const StepDesc* __restrict__ sched,
                 const double* __restrict__ images, const TreeModel* __restrict__ models,
                 const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
                 const double* __restrict__ branch, double* __restrict__ part_ll, double* __restrict__ part_grad) {
@@ -298,7 +302,17 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
     const int per = units / 8, rem = units % 8, x = unit % 8, q = unit / 8;
     unit = x * per + (x < rem ? x : rem) + q;
   }
-  const int tree = unit / tiles, tile = unit % tiles;
+  // A workgroup walks a RUN of consecutive pattern tiles of one tree: everything that depends only on the
+  // tree (step tables in the scalar cache, the first steps' descriptors and images) is fetched once, and
+  // the next tile's tip states and weights are requested while this tile is walked, so only the first
+  // tile of a run pays the start-up latency that nothing else on the CU can hide.
+  // (Only the instantiation the headline workload uses takes runs: with the loop in every instantiation the
+  // compiler's AGPR-copy rewrite for -amdgpu-mfma-vgpr-form crashes on <1,8,true>.)
+  constexpr bool kRuns = C == 4 && G == 4;
+  const int run = kRuns ? tile_run : 1;
+  const int runs = (tiles + run - 1) / run;
+  const int tree = unit / runs, tile0 = (unit % runs) * run;
+  const int tile_count = min(run, tiles - tile0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int st = lane >> 4, blk = (lane >> 2) & 3, pj = lane & 3;
@@ -326,17 +340,20 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
   StepWords PD0 = StepFetch(post_tab), PD1 = StepFetch(post_tab + 1);
   constexpr int kTipBatch = 8;
   const int tip_total = n * PB;
-  int tip_sym[kTipBatch];
-#pragma unroll
-  for (int u = 0; u < kTipBatch; u++) {
-    const int q = tid + u * kLdsWaves * 64;
-    tip_sym[u] = q < tip_total ? tip_states[(size_t)(q / PB) * Ppad + tile * PB + (q % PB)] : 4;
-  }
   const int loc0 = wave * G * PG + sub * 4 + pj;  // pattern of group 0 inside the tile; group g: + g*PG
   const uint8_t* tip_b = tipbuf + loc0;
-  double wgt[G];     // pattern weight
+  auto load_tile_inputs = [&](int tile, int (&sym)[kTipBatch], double (&w)[G]) {
 #pragma unroll
-  for (int g = 0; g < G; g++) wgt[g] = weights[tile * PB + loc0 + g * PG];
+    for (int u = 0; u < kTipBatch; u++) {
+      const int q = tid + u * kLdsWaves * 64;
+      sym[u] = q < tip_total ? tip_states[(size_t)(q / PB) * Ppad + tile * PB + (q % PB)] : 4;
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) w[g] = weights[tile * PB + loc0 + g * PG];
+  };
+  int tip_sym[kTipBatch];
+  double wgt[G];     // pattern weight
+  load_tile_inputs(tile0, tip_sym, wgt);
   const double pi_st = tm->pi[st];
   const double w_cat = tm->cat_weight[cat];
   StepWait(PD0);
@@ -389,6 +406,9 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
   // (issued behind the image loads: its latency hides under theirs and the tip states')
   WarmWords warm = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 2 * SchedEntries(NI); i += 2) StepWarm(post_tab + i, warm);
+  StepWarmDone(warm);
+  for (int tile_index = 0; tile_index < tile_count; tile_index++) {
+  const int tile = tile0 + tile_index;
 #pragma unroll
   for (int u = 0; u < kTipBatch; u++) {
     const int q = tid + u * kLdsWaves * 64;
@@ -400,8 +420,11 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
   }
   if (GRAD)
     for (int q = tid; q < kLdsWaves * 4 * N; q += kLdsWaves * 64) grad_rows[q] = 0.0;
-  StepWarmDone(warm);
   __syncthreads();
+  // the next tile's inputs travel while this one is walked
+  int next_sym[kTipBatch];
+  double next_wgt[G];
+  if (kRuns && tile_index + 1 < tile_count) load_tile_inputs(tile + 1, next_sym, next_wgt);
 
 #define TIP_AT(off, g) tip_b[(off) + (g) * PG]
 #define CELL_AT(off, g) (*reinterpret_cast<double*>(arena_b + (off) + (g) * 512))
@@ -782,6 +805,14 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, con
       }
     }
   }
+  if (kRuns && tile_index + 1 < tile_count) {
+    __syncthreads();  // every wave is done with the tip buffer, the gradient rows and the sums
+#pragma unroll
+    for (int u = 0; u < kTipBatch; u++) tip_sym[u] = next_sym[u];
+#pragma unroll
+    for (int g = 0; g < G; g++) wgt[g] = next_wgt[g];
+  }
+  }  // tiles of the run
 }
 
 // cells per pattern group: the stored (non-cherry, non-root) internal nodes of the tree of the batch
@@ -823,13 +854,22 @@ LdsPlan PlanLds(const BatchDims& d) {
 template <int C, int G>
 static void LaunchWalkLdsCG(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient,
                             int want_site, hipStream_t stream) {
-  const int units = d.tree_count * plan.tiles;
+  // Run length: a divisor of the tile count (equal runs), as long as the launch still has about sixteen
+  // workgroups per CU to even out -- a run saves start-up latency, a short grid loses to quantisation.
+  int tile_run = 1;
+  if (C == 4 && G == 4) {
+    long long budget = LDS_TILE_RUN ? LDS_TILE_RUN : (long long)d.tree_count * plan.tiles / (16 * 256);
+    if (const char* forced = std::getenv("BITO_AMD_LDS_TILE_RUN")) budget = std::atoi(forced);  // tests: runs on small batches
+    for (int k = 1; k <= plan.tiles && k <= budget; k++)
+      if (plan.tiles % k == 0) tile_run = k;
+  }
+  const int units = d.tree_count * ((plan.tiles + tile_run - 1) / tile_run);  // a workgroup per run of tiles
   const dim3 grid(units), block(kLdsWaves * 64);
   const StepDesc* sched = reinterpret_cast<const StepDesc*>(b.sched);
   auto kern = want_gradient ? walk_lds_kernel<C, G, true> : walk_lds_kernel<C, G, false>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsBudget);
-  hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, LdsSlots(d), want_site, sched, b.images, b.model,
+  hipLaunchKernelGGL(kern, grid, block, plan.lds_bytes, stream, d, plan.tiles, units, LdsSlots(d), want_site, tile_run, sched, b.images, b.model,
                      b.tip_states, b.weights, b.branch, b.part_ll, b.part_grad);
 }
 

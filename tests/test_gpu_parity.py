@@ -534,3 +534,21 @@ def test_site_model_gradient_fused_equals_second_pass():
     assert grad_close(fused["site_model"], ref["site_model"])
     assert grad_close(twice["site_model"], ref["site_model"])
     assert grad_close(fused["branch_lengths"], ref["branch_lengths"])
+
+
+@pytest.mark.parametrize("run", [1, 3, 5, 15])
+def test_tile_runs_of_the_lds_walk(run, monkeypatch):
+    """A workgroup of the LDS walk takes a run of consecutive pattern tiles of its tree (the launcher picks the
+    run length from the batch size; here it is forced): same results whatever the run length, against the
+    oracle, with and without the fused site-model gradient."""
+    monkeypatch.setenv("BITO_AMD_LDS_TILE_RUN", str(run))
+    w = workloads.ds1_gtr_weibull4(1).subset(12)
+    gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
+    gpu.set_kernel(_capi.KERNEL_LDS)
+    out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, flags=_capi.GRAD_SITE_MODEL)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, flags=_capi.GRAD_SITE_MODEL)
+    assert gpu.kernel_name() == "walk_lds_kernel"
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+    assert grad_close(out["site_model"], ref["site_model"])
+    assert ll_close(gpu.log_likelihoods(w.parent_ids, w.branch_lengths, w.params), ref["log_likelihood"])
