@@ -306,9 +306,9 @@ walk_lds_kernel(BatchDims d, int tiles, int units, int slots, int want_site, int
   // tree (step tables in the scalar cache, the first steps' descriptors and images) is fetched once, and
   // the next tile's tip states and weights are requested while this tile is walked, so only the first
   // tile of a run pays the start-up latency that nothing else on the CU can hide.
-  // (Only the instantiation the headline workload uses takes runs: with the loop in every instantiation the
-  // compiler's AGPR-copy rewrite for -amdgpu-mfma-vgpr-form crashes on <1,8,true>.)
-  constexpr bool kRuns = C == 4 && G == 4;
+  // (Every instantiation but <1,8,.> takes runs: with the loop in that one the compiler's AGPR-copy rewrite
+  // for -amdgpu-mfma-vgpr-form crashes.)
+  constexpr bool kRuns = !(C == 1 && G == 8);
   const int run = kRuns ? tile_run : 1;
   const int runs = (tiles + run - 1) / run;
   const int tree = unit / runs, tile0 = (unit % runs) * run;
@@ -857,7 +857,7 @@ static void LaunchWalkLdsCG(const BatchDims& d, const DeviceBatch& b, const LdsP
   // Run length: a divisor of the tile count (equal runs), as long as the launch still has about sixteen
   // workgroups per CU to even out -- a run saves start-up latency, a short grid loses to quantisation.
   int tile_run = 1;
-  if (C == 4 && G == 4) {
+  if (!(C == 1 && G == 8)) {
     long long budget = LDS_TILE_RUN ? LDS_TILE_RUN : (long long)d.tree_count * plan.tiles / (16 * 256);
     if (const char* forced = std::getenv("BITO_AMD_LDS_TILE_RUN")) budget = std::atoi(forced);  // tests: runs on small batches
     for (int k = 1; k <= plan.tiles && k <= budget; k++)
