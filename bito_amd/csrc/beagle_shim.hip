@@ -35,8 +35,10 @@ struct Instance {
   double* d_out = nullptr;       // scratch for reductions
   int* d_idx = nullptr;          // scratch for index lists / ops
   size_t idx_cap = 0, out_cap = 0;
+  int device = 0;                // HIP device ordinal = this shim's BEAGLE resource number
   size_t plv() const { return (size_t)categories * patterns * S; }
   ~Instance() {
+    (void)hipSetDevice(device);
     for (void* p : {(void*)d_partials, (void*)d_states, (void*)d_mats, (void*)d_scale, (void*)d_weights,
                     (void*)d_catw, (void*)d_catr, (void*)d_freq, (void*)d_eigen, (void*)d_out, (void*)d_idx})
       if (p) (void)hipFree(p);
@@ -46,10 +48,17 @@ struct Instance {
 std::mutex g_mu;
 std::vector<std::unique_ptr<Instance>> g_instances;
 
+// The instance, with its device made current for the calling thread (instances may live on
+// different GPUs; BEAGLE's contract is one thread per instance at a time).
 Instance* Get(int id) {
-  std::lock_guard<std::mutex> lock(g_mu);
-  if (id < 0 || id >= (int)g_instances.size()) return nullptr;
-  return g_instances[id].get();
+  Instance* in = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (id < 0 || id >= (int)g_instances.size()) return nullptr;
+    in = g_instances[id].get();
+  }
+  if (in && hipSetDevice(in->device) != hipSuccess) return nullptr;
+  return in;
 }
 
 bool Ok(hipError_t rc) { return rc == hipSuccess; }
@@ -222,11 +231,24 @@ int RunOps(int instance, const BeagleOperation* ops, int count, int cumulative, 
   Instance* in = Get(instance);
   if (!in) return BEAGLE_ERROR_UNINITIALIZED_INSTANCE;
   const int blocks = (in->patterns + 255) / 256;
+  // every index of every operation is checked before the first launch: they go straight into device
+  // pointer arithmetic (and tip_is_compact on the host)
+  auto partial_ok = [&](int i) { return i >= 0 && i < in->partials; };
+  auto matrix_ok = [&](int i) { return i >= 0 && i < in->matrices; };
+  auto scale_ok = [&](int i) { return i == BEAGLE_OP_NONE || (i >= 0 && i < in->scales); };
+  if (count > 0 && !ops) return BEAGLE_ERROR_OUT_OF_RANGE;
+  if (!scale_ok(cumulative)) return BEAGLE_ERROR_OUT_OF_RANGE;
+  for (int o = 0; o < count; o++) {
+    const BeagleOperation& op = ops[o];
+    if (!partial_ok(op.destinationPartials) || !partial_ok(op.child1Partials) || !partial_ok(op.child2Partials) ||
+        !matrix_ok(op.child1TransitionMatrix) || !matrix_ok(op.child2TransitionMatrix) ||
+        !scale_ok(op.destinationScaleWrite) || !scale_ok(op.destinationScaleRead))
+      return BEAGLE_ERROR_OUT_OF_RANGE;
+  }
   for (int o = 0; o < count; o++) {
     const BeagleOperation& op = ops[o];
     const int c1c = !pre_order && op.child1Partials < in->tips && in->tip_is_compact[op.child1Partials];
     const int c2c = op.child2Partials < in->tips && in->tip_is_compact[op.child2Partials];
-    if (op.destinationPartials < 0 || op.destinationPartials >= in->partials) return BEAGLE_ERROR_OUT_OF_RANGE;
     hipLaunchKernelGGL(partials_kernel, dim3(blocks), dim3(256), 0, 0, in->d_partials, in->d_states, in->d_mats,
                        in->d_scale, in->patterns, in->categories, in->plv(), op.destinationPartials,
                        op.child1Partials, op.child1TransitionMatrix, c1c, op.child2Partials,
@@ -241,13 +263,30 @@ extern "C" {
 
 int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount,
                          int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount,
-                         int scaleBufferCount, int*, int, long, long requirementFlags,
+                         int scaleBufferCount, int* resourceList, int resourceCount, long, long requirementFlags,
                          BeagleInstanceDetails* returnInfo) {
   if (stateCount != S) return BEAGLE_ERROR_NO_IMPLEMENTATION;
   if (requirementFlags & BEAGLE_FLAG_PRECISION_SINGLE) return BEAGLE_ERROR_NO_IMPLEMENTATION;
+  if (tipCount < 0 || partialsBufferCount < 0 || compactBufferCount < 0 || patternCount <= 0 || categoryCount <= 0 ||
+      matrixBufferCount < 0 || scaleBufferCount < 0)
+    return BEAGLE_ERROR_OUT_OF_RANGE;
   int devices = 0;
   if (!Ok(hipGetDeviceCount(&devices)) || devices <= 0) return BEAGLE_ERROR_NO_RESOURCE;
+  // Resource numbers of this library are HIP device ordinals.  With a resource list the instance goes to the
+  // first listed device that exists; without one (bito passes NULL, fat_beagle.cpp:247-252) to the calling
+  // thread's current device.
+  int device = 0;
+  if (resourceList != nullptr && resourceCount > 0) {
+    device = -1;
+    for (int i = 0; i < resourceCount && device < 0; i++)
+      if (resourceList[i] >= 0 && resourceList[i] < devices) device = resourceList[i];
+    if (device < 0) return BEAGLE_ERROR_NO_RESOURCE;
+  } else if (!Ok(hipGetDevice(&device))) {
+    return BEAGLE_ERROR_NO_RESOURCE;
+  }
+  if (!Ok(hipSetDevice(device))) return BEAGLE_ERROR_NO_RESOURCE;
   auto in = std::make_unique<Instance>();
+  in->device = device;
   // BEAGLE's buffer index space covers partials AND compact buffers (tips first): with tip
   // states FatBeagle asks for 3n-2 partials + n compact and addresses buffers up to 4n-3.
   in->tips = tipCount; in->partials = partialsBufferCount + compactBufferCount; in->compact = compactBufferCount;
@@ -271,7 +310,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     static char name[] = "AMD Instinct MI355X (gfx950)";
     static char impl[] = "bito_amd-HIP-double";
     static char desc[] = "bito_amd BEAGLE-compatible shim, 4-state FP64, manual log scaling";
-    returnInfo->resourceNumber = 0;
+    returnInfo->resourceNumber = device;
     returnInfo->resourceName = name;
     returnInfo->implName = impl;
     returnInfo->implDescription = desc;
@@ -414,6 +453,10 @@ int beagleCalculateEdgeDerivatives(int instance, const int* postIdx, const int* 
   if (outPerSite != nullptr || outSumSq != nullptr) return BEAGLE_ERROR_NO_IMPLEMENTATION;  // bito passes nullptr (:158-160)
   if (catWeightsIdx && catWeightsIdx[0] != 0) return BEAGLE_ERROR_OUT_OF_RANGE;
   if (count <= 0 || !outSum) return BEAGLE_SUCCESS;
+  for (int i = 0; i < count; i++)
+    if (postIdx[i] < 0 || postIdx[i] >= in->partials || preIdx[i] < 0 || preIdx[i] >= in->partials ||
+        dmatIdx[i] < 0 || dmatIdx[i] >= in->matrices)
+      return BEAGLE_ERROR_OUT_OF_RANGE;
   std::vector<int> lists(3 * (size_t)count);
   std::memcpy(lists.data(), postIdx, count * sizeof(int));
   std::memcpy(lists.data() + count, preIdx, count * sizeof(int));
@@ -440,6 +483,7 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
   const int root = bufferIndices[0];
   if (root < 0 || root >= in->partials) return BEAGLE_ERROR_OUT_OF_RANGE;
   const int cum = cumulativeScaleIndices ? cumulativeScaleIndices[0] : BEAGLE_OP_NONE;
+  if (cum != BEAGLE_OP_NONE && (cum < 0 || cum >= in->scales)) return BEAGLE_ERROR_OUT_OF_RANGE;
   if (!ReserveOut(in, 1)) return BEAGLE_ERROR_OUT_OF_MEMORY;
   hipLaunchKernelGGL(root_kernel, dim3(1), dim3(256), 0, 0, in->d_partials + (size_t)root * in->plv(), in->d_weights,
                      in->d_catw, in->d_freq, cum >= 0 ? in->d_scale + (size_t)cum * in->patterns : nullptr,

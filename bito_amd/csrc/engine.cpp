@@ -83,6 +83,7 @@ struct bito_amd_engine {
   DeviceBuffer<TreeModel> model, model2;
   DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
   DeviceBuffer<int32_t> gs_model_index;  // [T] first tree with the same parameter row
+  bool gs_index_valid = false;           // the index was built from the parameter rows that are resident now
   // time-tree transforms (row f2): staging for host inputs, scratch and results
   DeviceBuffer<int32_t> tt_parents;
   DeviceBuffer<double> tt_heights, tt_bounds, tt_ratios, tt_in, tt_work, tt_out, tt_aux;
@@ -287,6 +288,7 @@ int UploadModelIndex(bito_amd_engine* e, int tree_count, const double* params) {
   HIP_TRY(e, e->gs_model_index.Reserve(tree_count));
   HIP_TRY(e, hipMemcpyAsync(e->gs_model_index.ptr, index.data(), tree_count * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->gs_index_valid = true;
   return BITO_AMD_OK;
 }
 
@@ -331,8 +333,18 @@ int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int
   e->site_ready = false;
   const BatchDims& d = e->dims;
   const int T = d.tree_count, S = e->spec.state_count;
-  if (e->gs_model_index.capacity < (size_t)T)
-    return Fail(e, BITO_AMD_ERR_STATE, "select the general-state kernels before uploading the batch");
+  if (!e->gs_index_valid) {
+    // The batch (or its parameter rows) arrived while another kernel family was selected, so no index was
+    // built for it: rebuild from the resident rows rather than reuse one that belongs to an earlier batch.
+    const int pc = e->spec.param_count;
+    std::vector<double> rows((size_t)T * std::max(pc, 1), 0.0);
+    if (pc > 0) {
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      HIP_TRY(e, hipMemcpy(rows.data(), e->params.ptr, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    static const double none = 0.0;
+    if (int rc = UploadModelIndex(e, T, pc > 0 ? rows.data() : &none)) return rc;
+  }
   const int tiles = GsTiles(d.pattern_count);
   const size_t img_per_tree = GsImageDoublesPerTree(d), arena_per_tree = GsArenaDoublesPerTree(d, tiles, want_gradient);
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
@@ -625,6 +637,7 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * M * sizeof(double), hipMemcpyHostToDevice, e->stream));
   if (e->spec.param_count > 0)
     HIP_TRY(e, hipMemcpyAsync(e->params.ptr, params, T * e->spec.param_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  e->gs_index_valid = false;
   if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL) {
     static const double none = 0.0;
     if ((rc = UploadModelIndex(e, tree_count, e->spec.param_count > 0 ? params : &none))) return rc;
@@ -658,6 +671,7 @@ int bito_amd_engine_update(bito_amd_engine* e, const double* branch_lengths, con
     int rc = ValidateParams(e, (int)T, params);
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(e->params.ptr, params, T * e->spec.param_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    e->gs_index_valid = false;
     if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL)
       if ((rc = UploadModelIndex(e, (int)T, params))) return rc;
   }

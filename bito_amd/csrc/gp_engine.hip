@@ -168,9 +168,16 @@ gp_ops_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const in
               double* __restrict__ marginal, int P, int Ppad, double threshold, double log_threshold) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  if (offsets) {  // independent sub-streams side by side: blockIdx.y owns [offsets[y], offsets[y + 1])
-    ops += offsets[blockIdx.y];
-    op_count = offsets[blockIdx.y + 1] - offsets[blockIdx.y];
+  if (offsets) {
+    // independent sub-streams side by side: sub-stream y owns [offsets[y], offsets[y + 1]); op_count is the
+    // number of sub-streams, grid.y (capped at 65535 by the launcher) strides over them
+    for (int64_t y = blockIdx.y; y < op_count; y += gridDim.y) {
+      const bito_amd_gp_op* mine = ops + offsets[y];
+      const int64_t n = offsets[y + 1] - offsets[y];
+      for (int64_t o = 0; o < n; o++)
+        PatternOp(mine[o], p, side, plv, counts, bl, q, ll, marginal, Ppad, threshold, log_threshold);
+    }
+    return;
   }
   for (int64_t o = 0; o < op_count; o++)
     PatternOp(ops[o], p, side, plv, counts, bl, q, ll, marginal, Ppad, threshold, log_threshold);
@@ -204,10 +211,21 @@ gp_levels_kernel(const bito_amd_gp_op* __restrict__ ops, const int64_t* __restri
 template <typename T>
 __global__ void __launch_bounds__(256)
 gp_permute_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, const int64_t* __restrict__ map, size_t row_len) {
-  const size_t row = blockIdx.y;
+  // rows on grid.x (up to 2^31 - 1 of them), column chunks on grid.y
+  const size_t row = blockIdx.x;
   const T* from = src + row * row_len;
   T* to = dst + (size_t)map[row] * row_len;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_len; i += (size_t)gridDim.x * blockDim.x) to[i] = from[i];
+  for (size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x; i < row_len; i += (size_t)gridDim.y * blockDim.x) to[i] = from[i];
+}
+
+// Launches the row permutation (nothing to do for zero rows) and reports a rejected launch: the
+// caller frees the source buffers afterwards, so a silent no-op would lose every row.
+template <typename T>
+static hipError_t PermuteRows(const T* src, T* dst, const int64_t* map, size_t rows, size_t row_len, unsigned chunks) {
+  if (rows == 0 || row_len == 0) return hipSuccess;
+  if (rows > 0x7fffffffu) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gp_permute_rows_kernel<T>, dim3((unsigned)rows, chunks), dim3(256), 0, 0, src, dst, map, row_len);
+  return hipGetLastError();
 }
 
 // block per row: out[row] = sum_p w_p * rows[row][p]
@@ -921,8 +939,9 @@ int bito_amd_gp_process_operation_batches(bito_amd_gp_engine* e, const bito_amd_
   bool has_optimiser = false;
   for (int64_t o = 0; o < op_count && !has_optimiser; o++) has_optimiser = ops[o].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH;
   if (!has_optimiser) {
-    hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64, (unsigned)batch_count), dim3(64), 0, 0, e->d_ops,
-                       (int64_t)0, (const int64_t*)e->d_offsets, e->d_side, e->plv, e->counts, e->bl, e->q, e->ll,
+    const unsigned rows = (unsigned)(batch_count < 65535 ? batch_count : 65535);  // grid.y limit
+    hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64, rows), dim3(64), 0, 0, e->d_ops,
+                       (int64_t)batch_count, (const int64_t*)e->d_offsets, e->d_side, e->plv, e->counts, e->bl, e->q, e->ll,
                        e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
   } else {
     // optimiser ops reduce over all patterns: one workgroup per sub-stream interprets everything
@@ -1016,10 +1035,8 @@ int bito_amd_gp_grow(bito_amd_gp_engine* e, int32_t new_node_count, int32_t new_
     GP_TRY(e, hipMalloc((void**)&counts, total * e->Ppad * sizeof(int)));
     GP_TRY(e, hipMemset(plv, 0, total * 4 * e->Ppad * sizeof(double)));
     GP_TRY(e, hipMemset(counts, 0, total * e->Ppad * sizeof(int)));
-    hipLaunchKernelGGL(gp_permute_rows_kernel<double>, dim3(4, (unsigned)map.size()), dim3(256), 0, 0, e->plv, plv, d_map,
-                       (size_t)4 * e->Ppad);
-    hipLaunchKernelGGL(gp_permute_rows_kernel<int>, dim3(1, (unsigned)map.size()), dim3(256), 0, 0, e->counts, counts, d_map,
-                       (size_t)e->Ppad);
+    GP_TRY(e, PermuteRows(e->plv, plv, d_map, map.size(), (size_t)4 * e->Ppad, 4));
+    GP_TRY(e, PermuteRows(e->counts, counts, d_map, map.size(), (size_t)e->Ppad, 1));
     GP_TRY(e, hipDeviceSynchronize());
     (void)hipFree(d_map);
     (void)hipFree(e->plv);
@@ -1060,8 +1077,7 @@ int bito_amd_gp_grow(bito_amd_gp_engine* e, int32_t new_node_count, int32_t new_
     GP_TRY(e, hipMemcpy(dq, nq.data(), total * sizeof(double), hipMemcpyHostToDevice));
     GP_TRY(e, hipMemcpy(ddiff, ndiff.data(), total * sizeof(double), hipMemcpyHostToDevice));
     GP_TRY(e, hipMemset(ll, 0, total * e->Ppad * sizeof(double)));
-    hipLaunchKernelGGL(gp_permute_rows_kernel<double>, dim3(1, (unsigned)old_gpcsps), dim3(256), 0, 0, e->ll, ll, d_map,
-                       (size_t)e->Ppad);
+    GP_TRY(e, PermuteRows(e->ll, ll, d_map, (size_t)old_gpcsps, (size_t)e->Ppad, 1));
     GP_TRY(e, hipDeviceSynchronize());
     (void)hipFree(d_map);
     for (double* p : {e->bl, e->q, e->diff, e->ll, e->scratch}) (void)hipFree(p);

@@ -186,16 +186,33 @@ class Engine:
         return out
 
     # -- time trees (reference src/rooted_tree.cpp, src/rooted_gradient_transforms.cpp) --------
-    def _tt(self, parent_ids, *node_arrays):
+    def _node_array(self, a, shape, what: str) -> np.ndarray:
+        """A float64 array of exactly ``shape``: the C ABI takes bare pointers and reads T*(2n-1) (node
+        arrays), T*(n-1) (height ratios) or n (tip dates) doubles from it, so the shape is checked here."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != tuple(shape):
+            raise BitoAmdError(_capi.ERR_BAD_ARG, f"{what} must have shape {tuple(shape)}, got {a.shape}")
+        return a
+
+    def _tt(self, parent_ids, **arrays):
+        """parent ids of rooted trees + named arrays; the name's prefix selects the expected shape:
+        ``node_*`` / ``branch_*`` / ``height_gradient`` -> (T, 2n-1), ``height_ratios`` -> (T, n-1),
+        ``tip_dates`` -> (n,)."""
         pid = np.ascontiguousarray(parent_ids, dtype=np.int32)
-        if pid.ndim != 2:
-            raise BitoAmdError(_capi.ERR_BAD_ARG, "parent_ids must be [tree_count][2n-2]")
-        return (pid, pid.shape[0]) + tuple(np.ascontiguousarray(a, dtype=np.float64) for a in node_arrays)
+        n, N = self.taxon_count, 2 * self.taxon_count - 1
+        if pid.ndim != 2 or pid.shape[1] != N - 1:
+            raise BitoAmdError(_capi.ERR_BAD_ARG, f"parent_ids must be [tree_count][{N - 1}] (rooted trees)")
+        T = pid.shape[0]
+        out = []
+        for name, a in arrays.items():
+            shape = (n,) if name == "tip_dates" else (T, n - 1) if name == "height_ratios" else (T, N)
+            out.append(self._node_array(a, shape, name))
+        return (pid, T) + tuple(out)
 
     def time_trees_from_branch_lengths(self, parent_ids, branch_lengths, tip_dates):
         """-> (node_bounds, node_heights, height_ratios); RuntimeError for a tree that is not
         time-calibrated (RootedTree::InitializeTimeTreeUsingBranchLengths)."""
-        pid, T, bl, dates = self._tt(parent_ids, branch_lengths, tip_dates)
+        pid, T, bl, dates = self._tt(parent_ids, branch_lengths=branch_lengths, tip_dates=tip_dates)
         n, N = self.taxon_count, 2 * self.taxon_count - 1
         bounds, heights, ratios = np.zeros((T, N)), np.zeros((T, N)), np.zeros((T, n - 1))
         self._check(_capi.lib().bito_amd_engine_time_trees_from_branch_lengths(
@@ -204,7 +221,7 @@ class Engine:
 
     def time_trees_from_height_ratios(self, parent_ids, node_bounds, height_ratios):
         """-> (node_heights, branch_lengths) (RootedTree::InitializeTimeTreeUsingHeightRatios)."""
-        pid, T, bounds, ratios = self._tt(parent_ids, node_bounds, height_ratios)
+        pid, T, bounds, ratios = self._tt(parent_ids, node_bounds=node_bounds, height_ratios=height_ratios)
         N = 2 * self.taxon_count - 1
         heights, bl = np.zeros((T, N)), np.zeros((T, N))
         self._check(_capi.lib().bito_amd_engine_time_trees_from_height_ratios(
@@ -212,14 +229,14 @@ class Engine:
         return heights, bl
 
     def log_det_jacobian(self, parent_ids, node_heights, node_bounds) -> np.ndarray:
-        pid, T, heights, bounds = self._tt(parent_ids, node_heights, node_bounds)
+        pid, T, heights, bounds = self._tt(parent_ids, node_heights=node_heights, node_bounds=node_bounds)
         out = np.zeros(T)
         self._check(_capi.lib().bito_amd_engine_log_det_jacobian(self._h, T, _ip(pid), _dp(heights), _dp(bounds),
                                                                  _dp(out)))
         return out
 
     def gradient_log_det_jacobian(self, parent_ids, node_heights, node_bounds, height_ratios) -> np.ndarray:
-        pid, T, heights, bounds, ratios = self._tt(parent_ids, node_heights, node_bounds, height_ratios)
+        pid, T, heights, bounds, ratios = self._tt(parent_ids, node_heights=node_heights, node_bounds=node_bounds, height_ratios=height_ratios)
         out = np.zeros((T, self.taxon_count - 1))
         self._check(_capi.lib().bito_amd_engine_gradient_log_det_jacobian(
             self._h, T, _ip(pid), _dp(heights), _dp(bounds), _dp(ratios), _dp(out)))
@@ -227,8 +244,9 @@ class Engine:
 
     def ratio_gradient_of_height_gradient(self, parent_ids, node_heights, node_bounds, height_ratios,
                                           height_gradient) -> np.ndarray:
-        pid, T, heights, bounds, ratios, hg = self._tt(parent_ids, node_heights, node_bounds, height_ratios,
-                                                       height_gradient)
+        pid, T, heights, bounds, ratios, hg = self._tt(
+            parent_ids, node_heights=node_heights, node_bounds=node_bounds, height_ratios=height_ratios,
+            height_gradient=height_gradient)
         out = np.zeros((T, self.taxon_count - 1))
         self._check(_capi.lib().bito_amd_engine_ratio_gradient_of_height_gradient(
             self._h, T, _ip(pid), _dp(heights), _dp(bounds), _dp(ratios), _dp(hg), _dp(out)))
@@ -239,8 +257,9 @@ class Engine:
         parent_ids, branch_lengths, rates, params, T, M, rooted = self._prep(parent_ids, branch_lengths, rates, params)
         if not rooted:
             raise BitoAmdError(_capi.ERR_BAD_TREE, "time trees are rooted")
-        heights = np.ascontiguousarray(node_heights, dtype=np.float64)
-        bounds = np.ascontiguousarray(node_bounds, dtype=np.float64)
+        N = 2 * self.taxon_count - 1
+        heights = self._node_array(node_heights, (T, N), "node_heights")
+        bounds = self._node_array(node_bounds, (T, N), "node_bounds")
         out = np.zeros(T)
         self._check(_capi.lib().bito_amd_engine_time_tree_log_likelihoods(
             self._h, T, _ip(parent_ids), _dp(branch_lengths), _dp(rates), _dp(heights), _dp(bounds), _dp(params),
@@ -256,9 +275,9 @@ class Engine:
         if not rooted:
             raise BitoAmdError(_capi.ERR_BAD_TREE, "time trees are rooted")
         n, N = self.taxon_count, 2 * self.taxon_count - 1
-        heights = np.ascontiguousarray(node_heights, dtype=np.float64)
-        bounds = np.ascontiguousarray(node_bounds, dtype=np.float64)
-        ratios = np.ascontiguousarray(height_ratios, dtype=np.float64)
+        heights = self._node_array(node_heights, (T, N), "node_heights")
+        bounds = self._node_array(node_bounds, (T, N), "node_bounds")
+        ratios = self._node_array(height_ratios, (T, n - 1), "height_ratios")
         ll, branch = np.zeros(T), np.zeros((T, N))
         bm = self.block_map()
         sub_len = bm["entire_substitution"][1] if "entire_substitution" in bm else 0
@@ -283,10 +302,21 @@ class Engine:
                                                        _dp(rates), _dp(params)))
         self.tree_count = T
         self._node_count = 2 * self.taxon_count - 1
+        self._resident_shape = (T, M)
 
     def update(self, branch_lengths=None, params=None):
+        """New branch lengths and/or parameter rows for the resident batch; the C side copies
+        T*in_node_count and T*param_count doubles, so the shapes must be the uploaded ones."""
+        shape = getattr(self, "_resident_shape", None)
+        if shape is None:
+            raise BitoAmdError(_capi.ERR_STATE, "no batch is resident: call upload first")
         bl = None if branch_lengths is None else np.ascontiguousarray(branch_lengths, dtype=np.float64)
         pr = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
+        if bl is not None and bl.shape != shape:
+            raise BitoAmdError(_capi.ERR_BAD_ARG, f"branch_lengths must have the uploaded shape {shape}, got {bl.shape}")
+        if pr is not None and pr.shape != (shape[0], self.param_count):
+            raise BitoAmdError(_capi.ERR_BAD_ARG,
+                               f"param matrix needs shape ({shape[0]}, {self.param_count}), got {pr.shape}")
         self._check(_capi.lib().bito_amd_engine_update(self._h, _dp(bl), _dp(pr)))
 
     def run(self, want_gradient: bool, rescaling: bool = False):

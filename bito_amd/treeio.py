@@ -179,23 +179,33 @@ def _leaf_names(root: _Node) -> List[str]:
 
 
 def _polish(root: _Node, taxa: Dict[str, int]) -> ParsedTree:
+    """Leaf ids from the taxon map, children ordered by the largest leaf id beneath them (the
+    ``Node`` constructor, reference src/node.cpp:33-46: ids must not depend on how the Newick string
+    happens to order siblings), then internal ids in post-order (``Node::Polish``, :383-402)."""
     n = len(taxa)
-    order: List[_Node] = []
-    stack: List[Tuple[_Node, bool]] = [(root, False)]
-    while stack:
-        nd, visited = stack.pop()
-        if visited or not nd.children:
-            order.append(nd)
-        else:
-            stack.append((nd, True))
-            for ch in reversed(nd.children):
-                stack.append((ch, False))
-    next_id = n
+
+    def postorder() -> List[_Node]:
+        order: List[_Node] = []
+        stack: List[Tuple[_Node, bool]] = [(root, False)]
+        while stack:
+            nd, visited = stack.pop()
+            if visited or not nd.children:
+                order.append(nd)
+            else:
+                stack.append((nd, True))
+                for ch in reversed(nd.children):
+                    stack.append((ch, False))
+        return order
+
     seen = set()
-    for nd in order:
+    max_leaf: Dict[int, int] = {}  # id(node) -> largest leaf id in its subtree
+    for nd in postorder():  # (children before parents in any sibling order)
         if nd.children:
-            nd.id = next_id
-            next_id += 1
+            keys = [max_leaf[id(ch)] for ch in nd.children]
+            if len(set(keys)) != len(keys):
+                raise RuntimeError("Tie observed between sibling subtrees.\nDo you have a taxon name repeated?")
+            nd.children = [ch for _, ch in sorted(zip(keys, nd.children), key=lambda kc: kc[0])]
+            max_leaf[id(nd)] = max(keys)
         else:
             if nd.name not in taxa:
                 raise RuntimeError(
@@ -206,8 +216,15 @@ def _polish(root: _Node, taxa: Dict[str, int]) -> ParsedTree:
             if nd.id in seen:
                 raise RuntimeError(f"Taxon '{nd.name}' appears twice in a tree")
             seen.add(nd.id)
+            max_leaf[id(nd)] = nd.id
     if len(seen) != n:
         raise RuntimeError("Tree does not contain every taxon of the collection")
+    order = postorder()  # now in the canonical sibling order
+    next_id = n
+    for nd in order:
+        if nd.children:
+            nd.id = next_id
+            next_id += 1
     node_count = next_id
     parents = np.zeros(node_count - 1, dtype=np.int32)
     lengths = np.zeros(node_count, dtype=np.float64)

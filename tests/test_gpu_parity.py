@@ -552,3 +552,109 @@ def test_tile_runs_of_the_lds_walk(run, monkeypatch):
     assert grad_close(out["branch_lengths"], ref["branch_lengths"])
     assert grad_close(out["site_model"], ref["site_model"])
     assert ll_close(gpu.log_likelihoods(w.parent_ids, w.branch_lengths, w.params), ref["log_likelihood"])
+
+
+def test_general_kernel_model_index_follows_the_resident_batch():
+    """Selecting the general-state kernels AFTER a batch was uploaded under another kernel choice must not
+    reuse the model index of an earlier batch: set_kernel(GENERAL), upload A, set_kernel(AUTO), upload B (same
+    tree count, other parameter rows), set_kernel(GENERAL), run."""
+    w = workloads.ds1_gtr_weibull4(1).subset(6)
+    gpu = bito_amd.Engine(spec(w.substitution, w.site, w.clock), w.patterns, w.weights)
+    rng = np.random.default_rng(5)
+    pa = w.params.copy()  # batch A: all rows equal -> every tree shares record 0
+    pb = w.params.copy()  # batch B: every tree its own Weibull shape
+    pb[:, 10] = 0.3 + rng.random(6)
+    gpu.set_kernel(_capi.KERNEL_GENERAL)
+    gpu.upload(w.parent_ids, w.branch_lengths, pa)
+    gpu.run(True)
+    gpu.set_kernel(_capi.KERNEL_AUTO)
+    gpu.upload(w.parent_ids, w.branch_lengths, pb)
+    gpu.set_kernel(_capi.KERNEL_GENERAL)
+    gpu.run(True)
+    ll, grad = gpu.download()
+    assert gpu.kernel_name().startswith("gs_walk")
+    cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 4)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, pb)
+    assert ll_close(ll, ref["log_likelihood"]), ll_close(ll, ref["log_likelihood"])
+    assert grad_close(grad, ref["branch_lengths"]), grad_close(grad, ref["branch_lengths"])
+    # and update() of the rows alone, again under another selection
+    gpu.set_kernel(_capi.KERNEL_AUTO)
+    gpu.update(None, pa)
+    gpu.set_kernel(_capi.KERNEL_GENERAL)
+    gpu.run(False)
+    ll, _ = gpu.download(False)
+    assert ll_close(ll, cpu.log_likelihoods(w.parent_ids, w.branch_lengths, pa))
+
+
+def test_resident_update_and_time_tree_shapes_are_checked():
+    """The C ABI reads T*M / T*param_count / T*(2n-1) doubles from bare pointers; the host mirror rejects
+    arrays of any other shape before they cross the boundary."""
+    w = workloads.ds1_gtr_weibull4(1).subset(4)
+    gpu = bito_amd.Engine(spec(w.substitution, w.site, w.clock), w.patterns, w.weights)
+    with pytest.raises(bito_amd.BitoAmdError, match="no batch is resident"):
+        gpu.update(w.branch_lengths)
+    gpu.upload(w.parent_ids, w.branch_lengths, w.params)
+    with pytest.raises(bito_amd.BitoAmdError, match="uploaded shape"):
+        gpu.update(w.branch_lengths[:2])
+    with pytest.raises(bito_amd.BitoAmdError, match="uploaded shape"):
+        gpu.update(w.branch_lengths[:, :-1])
+    with pytest.raises(bito_amd.BitoAmdError, match="param matrix"):
+        gpu.update(None, w.params[:, :-1])
+    gpu.update(w.branch_lengths, w.params)  # the right shapes still pass
+    n = gpu.taxon_count
+    pid = np.zeros((2, 2 * n - 2), dtype=np.int32)
+    with pytest.raises(bito_amd.BitoAmdError, match="node_heights must have shape"):
+        gpu.log_det_jacobian(pid, np.zeros((2, n)), np.zeros((2, 2 * n - 1)))
+    with pytest.raises(bito_amd.BitoAmdError, match="height_ratios must have shape"):
+        gpu.time_trees_from_height_ratios(pid, np.zeros((2, 2 * n - 1)), np.zeros((2, n)))
+    with pytest.raises(bito_amd.BitoAmdError, match="tip_dates must have shape"):
+        gpu.time_trees_from_branch_lengths(pid, np.zeros((2, 2 * n - 1)), np.zeros(n + 1))
+    with pytest.raises(bito_amd.BitoAmdError, match="rooted trees"):
+        gpu.log_det_jacobian(pid[:, :-1], np.zeros((2, 2 * n - 1)), np.zeros((2, 2 * n - 1)))
+
+
+def test_beagle_shim_rejects_out_of_range_indices(data_dir):
+    """Every buffer, matrix and scale index of an operation list is range-checked before anything is
+    launched (BEAGLE_ERROR_OUT_OF_RANGE = -5), negative child indices included; a resource list selects the
+    device."""
+    import ctypes as C
+
+    from beagle_driver import BEAGLE_OP_NONE, FLAG_SCALING_MANUAL, FatBeagleDriver, InstanceDetails, Operation
+
+    tc, sp = load(data_dir, "hello.fasta", "hello.nwk")
+    V, Vinv = np.eye(4), np.eye(4)
+    drv = FatBeagleDriver(sp.patterns, sp.weights, V, Vinv, np.zeros(4), np.full(4, 0.25), np.zeros((4, 4)), [1.0], [1.0])
+    n, N = drv.n, drv.N
+    good = (n, BEAGLE_OP_NONE, BEAGLE_OP_NONE, 0, 0, 1, 1)
+    out_of_range = -5
+    for field, value in [(0, -1), (0, 10**6), (3, -1), (3, 10**6), (5, -7), (5, 10**6), (4, -1), (4, 2 * N),
+                         (6, 2 * N), (1, 10**6), (1, -2), (2, -3)]:
+        row = list(good)
+        row[field] = value
+        ops = (Operation * 1)(Operation(*row))
+        assert drv.lib.beagleUpdatePartials(drv.inst, ops, 1, BEAGLE_OP_NONE) == out_of_range, (field, value)
+        assert drv.lib.beagleUpdatePrePartials(drv.inst, ops, 1, BEAGLE_OP_NONE) == out_of_range, (field, value)
+    ops = (Operation * 1)(Operation(*good))
+    assert drv.lib.beagleUpdatePartials(drv.inst, ops, 1, 10**6) == out_of_range  # cumulative scale index
+    assert drv.lib.beagleUpdatePartials(drv.inst, ops, 1, BEAGLE_OP_NONE) == 0
+    bad = np.array([10**6], dtype=np.int32)
+    ok = np.array([0], dtype=np.int32)
+    grad = np.zeros(1)
+    gp = grad.ctypes.data_as(C.POINTER(C.c_double))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    for post, pre, dm in [(bad, ok, ok), (ok, bad, ok), (ok, ok, bad), (-bad, ok, ok)]:
+        assert drv.lib.beagleCalculateEdgeDerivatives(drv.inst, ip(post), ip(pre), ip(dm), ip(ok), 1, None, gp,
+                                                      None) == out_of_range
+    ll = C.c_double()
+    assert drv.lib.beagleCalculateRootLogLikelihoods(drv.inst, ip(ok), ip(ok), ip(ok), ip(bad), 1,
+                                                     C.byref(ll)) == out_of_range
+    drv.close()
+    # resource list: device 0 is accepted and reported; a list without any existing device is refused
+    info = InstanceDetails()
+    lib = drv.lib
+    res = (C.c_int * 2)(99, 0)
+    inst = lib.beagleCreateInstance(3, 7, 3, 4, 15, 1, 10, 1, 8, res, 2, 0, FLAG_SCALING_MANUAL, C.byref(info))
+    assert inst >= 0 and info.resourceNumber == 0
+    assert lib.beagleFinalizeInstance(inst) == 0
+    res = (C.c_int * 1)(99)
+    assert lib.beagleCreateInstance(3, 7, 3, 4, 15, 1, 10, 1, 8, res, 1, 0, FLAG_SCALING_MANUAL, C.byref(info)) == -6  # BEAGLE_ERROR_NO_RESOURCE

@@ -128,6 +128,32 @@ def test_parse_inline_newick_features():
         treeio.parse_newick_strings(["(a:x,b,c);"])
 
 
+def test_internal_ids_do_not_depend_on_sibling_order():
+    """The reference's Node constructor sorts children by the largest leaf id beneath them before
+    Polish numbers the internal nodes in post-order (src/node.cpp:33-46,383-402), so one topology has
+    one parent-id vector however its Newick string orders siblings.  Expected vectors: the reference's
+    own examples (src/node.hpp:313-314,336-339,358)."""
+    def ids(newick, **kw):
+        return list(treeio.parse_newick_strings([newick], **kw).trees[0].parent_ids)
+
+    taxa = {str(i): i for i in range(7)}
+    assert ids("((((0,1),2),(3,4)),5,6);", taxa=taxa) == [7, 7, 8, 9, 9, 11, 11, 8, 10, 10, 11]
+    assert ids("(6,((4,3),(2,(1,0))),5);", taxa=taxa) == [7, 7, 8, 9, 9, 11, 11, 8, 10, 10, 11]
+    taxa4 = {str(i): i for i in range(4)}
+    assert ids("(0,1,(2,3));", taxa=taxa4) == [5, 5, 4, 4, 5]
+    assert ids("((3,2),1,0);", taxa=taxa4) == [5, 5, 4, 4, 5]
+    assert ids("(0,(1,(2,3)));", taxa=taxa4) == [6, 5, 4, 4, 5, 6]
+    assert ids("(((3,2),1),0);", taxa=taxa4) == [6, 5, 4, 4, 5, 6]
+    assert ids("(3,(2,(1,0)));", taxa=taxa4) == [4, 4, 5, 6, 5, 6]  # Node::Ladder(4)
+    # out-of-order siblings with alphabetical leaf ids: bito gives [5,5,6,6,7,7,7]
+    assert ids("((c,d),(a,b),e);", sort_taxa=True) == [5, 5, 6, 6, 7, 7, 7]
+    a = treeio.parse_newick_strings(["((a:1,b:2):3,(c:4,d:5):6,e:7);", "(e:7,(d:5,c:4):6,(b:2,a:1):3);"], sort_taxa=True)
+    assert np.array_equal(a.trees[0].parent_ids, a.trees[1].parent_ids)
+    assert np.array_equal(a.trees[0].branch_lengths, a.trees[1].branch_lengths)  # lengths travel with their child
+    with pytest.raises(RuntimeError, match="appears twice"):
+        treeio.parse_newick_strings(["((a,b),(a,c));"], taxa={"a": 0, "b": 1, "c": 2})
+
+
 def test_nexus_translate_order(data_dir):
     tc = treeio.read_nexus_file(os.path.join(data_dir, "DS1.subsampled_10.t"))
     assert len(tc.trees) == 10 and len(tc.taxon_names) == 27

@@ -426,3 +426,48 @@ def test_adding_every_adjacent_nni_builds_the_complete_dag(data_dir, fasta, newi
                 below.add(s)
         assert internal == below
     assert dag.fully_connected().gpcsp_count == dag.gpcsp_count  # and every compatible pair is an edge
+
+
+@pytest.mark.gpu
+def test_engine_grows_beyond_one_grid_dimension(data_dir):
+    """bito_amd_gp_grow re-lays 6 x nodes PLV rows and one row per GPCSP on the device.  With more than
+    65535 rows a launch that put rows on grid.y was rejected and the engine silently kept zeroed buffers;
+    rows now ride on grid.x.  Every PLV, rescaling count and branch length must arrive at its new index."""
+    from bito_amd import gp
+
+    sp = SitePattern(treeio.read_fasta(os.path.join(data_dir, "hello.fasta")), ["mars", "saturn", "jupiter"])
+    nodes, gpcsps = 11000, 66000  # 6 * 11000 = 66000 PLV rows > 65535, and > 65535 GPCSP rows
+    eng = gp.GPEngine(sp.patterns, sp.weights, nodes, gpcsps)
+    bl = np.linspace(0.01, 1.0, gpcsps)
+    eng.set_branch_lengths(bl)
+    q = np.linspace(0.5, 1.5, gpcsps)
+    eng.set_sbn_parameters(q)
+    s = gp.OpStream()
+    marked = [(gp.RHAT, nodes - 1, gpcsps - 1), (gp.R_LEFT, 5000, 40000), (gp.PHAT_LEFT, 3, 7)]
+    for t, node, edge in marked:
+        s.add(gp.SET_TO_STATIONARY, t * nodes + node, edge)  # the PLV becomes q[edge] * pi in every column
+    eng.process_operations(s)
+    leaf = eng.get_plv(gp.P * nodes + 1).copy()
+    assert leaf.sum() > 0
+    new_nodes, new_gpcsps = nodes + 1, gpcsps + 2
+    node_map = (np.arange(new_nodes) + 1) % new_nodes      # old node v -> v + 1 (the new node lands on 0)
+    edge_map = (np.arange(new_gpcsps) + 2) % new_gpcsps
+    eng.grow(new_nodes, new_gpcsps, node_map, edge_map)
+    for t, node, edge in marked:
+        got = eng.get_plv(t * new_nodes + node_map[node])
+        assert np.allclose(got, 0.25 * q[edge], rtol=0, atol=1e-15), (t, node)
+        assert not eng.get_plv(t * new_nodes + 0).any()  # the new node's PLVs start zeroed
+    assert np.array_equal(eng.get_plv(gp.P * new_nodes + node_map[1]), leaf)
+    out = eng.get_branch_lengths()
+    assert np.array_equal(out[edge_map[:gpcsps]], bl) and np.all(out[edge_map[gpcsps:]] == 0.1)
+    assert np.array_equal(eng.get_sbn_parameters()[edge_map[:gpcsps]], q)
+    # more independent sub-streams than grid.y can hold (65535): the launch strides over them
+    streams = []
+    for k in range(65600):
+        st = gp.OpStream()
+        st.add(gp.SET_TO_STATIONARY, k, k % 1000)
+        streams.append(st)
+    eng.process_operation_batches(streams)
+    qs = eng.get_sbn_parameters()
+    for k in (0, 65534, 65535, 65536, 65599):
+        assert np.allclose(eng.get_plv(k), 0.25 * qs[k % 1000], rtol=0, atol=1e-15), k
