@@ -922,7 +922,6 @@ int bito_amd_gp_process_operation_batches(bito_amd_gp_engine* e, const bito_amd_
                                           int64_t batch_count) {
   if (!e || (op_count > 0 && !ops) || !offsets || batch_count < 0) return BITO_AMD_ERR_BAD_ARG;
   if (batch_count == 0) return BITO_AMD_OK;
-  if (batch_count > 65535) return Fail(e, BITO_AMD_ERR_BAD_ARG, "at most 65535 sub-streams per call");
   if (offsets[0] != 0 || offsets[batch_count] != op_count)
     return Fail(e, BITO_AMD_ERR_BAD_ARG, "offsets must run from 0 to op_count");
   for (int64_t b = 0; b < batch_count; b++)

@@ -196,8 +196,8 @@ class Engine:
 
     def _tt(self, parent_ids, **arrays):
         """parent ids of rooted trees + named arrays; the name's prefix selects the expected shape:
-        ``node_*`` / ``branch_*`` / ``height_gradient`` -> (T, 2n-1), ``height_ratios`` -> (T, n-1),
-        ``tip_dates`` -> (n,)."""
+        ``node_*`` / ``branch_*`` -> (T, 2n-1), ``height_ratios`` / ``height_gradient`` -> (T, n-1) (one entry
+        per internal node), ``tip_dates`` -> (n,)."""
         pid = np.ascontiguousarray(parent_ids, dtype=np.int32)
         n, N = self.taxon_count, 2 * self.taxon_count - 1
         if pid.ndim != 2 or pid.shape[1] != N - 1:
@@ -205,7 +205,7 @@ class Engine:
         T = pid.shape[0]
         out = []
         for name, a in arrays.items():
-            shape = (n,) if name == "tip_dates" else (T, n - 1) if name == "height_ratios" else (T, N)
+            shape = (n,) if name == "tip_dates" else (T, n - 1) if name.startswith("height_") else (T, N)
             out.append(self._node_array(a, shape, name))
         return (pid, T) + tuple(out)
 

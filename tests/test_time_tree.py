@@ -25,7 +25,7 @@ def spec(sub, site, clock="strict"):
 def make_flu_instance(data_dir, initialize_time_trees, model=("JC69", "constant", "strict")):
     """MakeFluInstance (reference src/rooted_sbn_instance.hpp:262-275)."""
     inst = bito_amd.rooted_instance("charlie")
-    inst.read_newick_file(os.path.join(data_dir, "fluA.tree"))
+    inst.read_newick_file(os.path.join(data_dir, "fluA.tree"), False)  # as the reference: ReadNewickFile(..., false)
     inst.parse_dates_from_taxon_names(initialize_time_trees)
     inst.read_fasta_file(os.path.join(data_dir, "fluA.fa"))
     inst.prepare_for_phylo_likelihood(spec(*model), 1)
