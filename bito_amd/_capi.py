@@ -21,7 +21,7 @@ GRAD_STICKBREAKING = 8
 GRAD_RATIOS_ROOT_HEIGHT = 16
 GRAD_LOG_DET_JACOBIAN_GRADIENT = 32
 
-KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS, KERNEL_LDS_TREE, KERNEL_GENERAL = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS, KERNEL_LDS_TREE, KERNEL_GENERAL, KERNEL_LDS_PIPE = 0, 1, 2, 3, 4, 5
 
 # Every symbol include/bito_amd.h declares (tests check that the library exports them all).
 SYMBOLS = [

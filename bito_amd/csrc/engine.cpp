@@ -394,12 +394,19 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     return RunResidentGeneral(e, want_gradient, rescaling, deriv_mode);
   // Kernel choice: the LDS-resident MFMA walk when the tree fits in LDS and no rescaling
   // is requested, otherwise the HBM-arena walk.
-  const LdsPlan plan = PlanLds(d);
+  LdsPlan plan = PlanLds(d);
+  const LdsPlan pplan = PlanPipe(d);
   const TreePlan tplan = PlanTree(d);
   bool use_tree = tplan.waves > 0 && !rescaling;
   bool use_lds = plan.groups > 0 && !rescaling;
+  bool use_pipe = false;
   switch (e->kernel_choice) {
     case BITO_AMD_KERNEL_HBM_ARENA: use_tree = use_lds = false; break;
+    case BITO_AMD_KERNEL_LDS_PIPE:
+      use_tree = false;
+      use_pipe = pplan.groups > 0 && !rescaling;
+      if (!use_pipe) return Fail(e, BITO_AMD_ERR_STATE, "the pipelined LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, and a tree whose stored vectors fit in 160 KB of LDS)");
+      break;
     case BITO_AMD_KERNEL_LDS:
       use_tree = false;
       if (!use_lds) return Fail(e, BITO_AMD_ERR_STATE, "the LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, and a tree whose PLVs fit in 160 KB of LDS)");
@@ -414,6 +421,10 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   // tree-resident variant is only used when forced or when walk_lds cannot run.
   if (e->kernel_choice != BITO_AMD_KERNEL_LDS_TREE && use_lds) use_tree = false;
   if (use_tree) use_lds = false;
+  if (use_pipe) {  // same launch sequence as the LDS kernel, with its own images, tables and plan
+    use_lds = true;
+    plan = pplan;
+  }
   const int tiles = use_tree ? tplan.tiles : (use_lds ? plan.tiles : HbmTiles(d.pattern_count));
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
   const int grad_rows = (use_tree || use_lds) ? tiles : tiles * (kHbmBlock / 64);  // HBM kernel: a row per wave
@@ -426,8 +437,13 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     const DeviceBatch b = MakeBatch(e, set);
     HIP_TRY(e, hipStreamWaitEvent(e->prep_stream, e->ev_walk_done[set], 0));
     LaunchSetup(d, e->spec, b, want_gradient, e->prep_stream);
-    LaunchMatrixImages(d, b, want_gradient, deriv_mode, e->prep_stream);
-    if (use_lds) LaunchLdsSchedule(d, b, plan, e->prep_stream);
+    if (use_pipe) {
+      LaunchPipeImages(d, b, e->prep_stream);
+      LaunchPipeSchedule(d, b, plan, e->prep_stream);
+    } else {
+      LaunchMatrixImages(d, b, want_gradient, deriv_mode, e->prep_stream);
+      if (use_lds) LaunchLdsSchedule(d, b, plan, e->prep_stream);
+    }
     HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], e->prep_stream));
     HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_prep_done[set], 0));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -437,9 +453,10 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
       HIP_TRY(e, hipEventRecord(ev0, e->stream));
     }
     if (use_tree) LaunchWalkTree(d, b, tplan, want_gradient, e->stream);
+    else if (use_pipe) LaunchWalkPipe(d, b, plan, want_gradient, want_site && want_gradient && deriv_mode == 0, deriv_mode, e->stream);
     else LaunchWalkLds(d, b, plan, want_gradient, want_site && want_gradient && deriv_mode == 0, e->stream);
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
-    e->kernel_name = use_tree ? "walk_tree_kernel" : "walk_lds_kernel";
+    e->kernel_name = use_tree ? "walk_tree_kernel" : (use_pipe ? "walk_pipe_kernel" : "walk_lds_kernel");
     e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
     LaunchReduce(d, b, tiles, want_gradient, e->stream);
     HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));

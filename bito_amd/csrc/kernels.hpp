@@ -138,6 +138,17 @@ void LaunchLdsSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& 
 void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient, int want_site,
                    hipStream_t stream);
 
+// LDS-resident traversal with hand-scheduled loops (walk_pipe.hip): the mapping of walk_lds_kernel,
+// stored child MESSAGES instead of partials, both tree loops software-pipelined gfx950 assembly.
+// Images: [T][N-1][128] doubles ((P, P^T) per lane); step tables: [T][2][n+1][16] dwords in b.sched.
+LdsPlan PlanPipe(const BatchDims& d);
+size_t PipeScheduleInts(const BatchDims& d);
+void LaunchPipeImages(const BatchDims& d, const DeviceBatch& b, hipStream_t stream);
+void LaunchPipeSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream);
+// deriv_mode 1: the edge derivatives use d r_c / d shape in place of r_c (site-model pass)
+void LaunchWalkPipe(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient, int want_site,
+                    int deriv_mode, hipStream_t stream);
+
 // LDS-resident traversal, second generation (walk_tree.hip): 8 waves per workgroup (two per
 // SIMD), one group image per wave, the tree's P/dP images staged in LDS and shared.
 struct TreePlan {

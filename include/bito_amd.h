@@ -51,6 +51,8 @@ extern "C" {
 #define BITO_AMD_KERNEL_LDS_TREE 3 /* walk_tree_kernel: two waves per SIMD, images staged in LDS */
 #define BITO_AMD_KERNEL_GENERAL 4  /* gs_walk_kernel: the general-state-count kernels (any model; the only
                                       choice for the 61-state codon model) */
+#define BITO_AMD_KERNEL_LDS_PIPE 5 /* walk_pipe_kernel: walk_lds_kernel's mapping, child messages in LDS, both
+                                      tree loops hand-scheduled (software-pipelined) gfx950 assembly */
 
 typedef struct bito_amd_engine bito_amd_engine;
 

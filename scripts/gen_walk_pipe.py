@@ -1,0 +1,774 @@
+#!/usr/bin/env python3
+"""Generates bito_amd/csrc/walk_pipe_gen.inc: the two hand-scheduled gfx950 loops of
+walk_pipe_kernel (bito_amd/csrc/walk_pipe.hip) as inline-assembly text.
+
+Why generated assembly.  The traversal is bound by per-step latency and instruction issue, not by
+arithmetic: one wave per SIMD (LDS capacity) means nothing hides a dependent
+instruction's latency unless the instruction stream itself is software-pipelined across tree steps, and
+the compiler cannot do that across the dynamic dispatch on the kinds of a step's children.  Here every
+step body is straight-line code with
+
+  * the NEXT step's operands (child messages out of LDS, tip masks, matrix images out of L2, the step
+    descriptor) requested while THIS step's arithmetic runs,
+  * independent work placed in the shadow of every v_mfma_f64_4x4x4_4b (16 cycles of the matrix pipe),
+  * the wait states the hardware needs between a matrix instruction and a dependent read inserted by
+    this script (table below, measured from what hipcc itself inserts for gfx950).
+
+The arithmetic per step is documented in walk_pipe.hip.  Register numbers are fixed here; the C++ side
+passes a few operands by name and declares the rest clobbered.
+
+usage: python3 scripts/gen_walk_pipe.py   (rewrites bito_amd/csrc/walk_pipe_gen.inc)
+"""
+import os
+import sys
+
+GROUPS = (1, 2, 4)
+
+# ---- wait states (number of instruction issue slots between producer and consumer) -----------------
+# measured from hipcc output for gfx950 (v_mfma_f64_4x4x4_4b = "DGEMM 4x4", 4 passes):
+WS_MFMA_VALU = 6      # matrix result -> VALU read / VALU overwrite
+WS_MFMA_MFMA_AB = 6   # matrix result -> matrix A/B operand
+WS_MFMA_MFMA_C = 4    # matrix result -> matrix C operand
+WS_MFMA_MEM = 9       # matrix result -> store data / address of a memory or LDS instruction
+WS_VALU_MFMA = 2      # VALU result -> matrix operand
+
+VBASE = 32   # first VGPR the loops may use (v0..v31 and a224.. stay with the compiler)
+VLIMIT = 256
+SBASE, SLIMIT = 36, 96  # SGPRs
+
+
+class Emitter:
+    """Collects instructions, inserts s_nop for the hazards above, keeps a plain listing."""
+
+    def __init__(self):
+        self.lines = []
+        self.pos = 0
+        self.writer = {}  # vgpr index -> (pos, 'mfma' | 'valu')
+        self.last_mfma = -100
+        self.last_valu = -100
+        self.count = {}
+
+    def _raw(self, text):
+        self.lines.append(text)
+
+    def comment(self, text):
+        self._raw(f"; {text}")
+
+    def nop(self, states):
+        while states > 0:
+            n = min(states, 16)
+            self._raw(f"s_nop {n - 1}")
+            self.pos += n
+            states -= n
+
+    def _require(self, regs, need_of):
+        worst = 0
+        for r in regs:
+            w = self.writer.get(r)
+            if w is None:
+                continue
+            p, kind = w
+            need = need_of.get(kind, 0)
+            have = self.pos - p - 1
+            if need - have > worst:
+                worst = need - have
+        if worst > 0:
+            self.nop(worst)
+
+    def ins(self, text, kind, reads=(), writes=(), mem_reads=(), reads_c=()):
+        """kind: mfma | valu | salu | mem (memory/LDS/branch/misc).  reads: VGPRs read as ordinary operands;
+        mem_reads: VGPRs read by a memory instruction (address/data); reads_c: matrix C operand."""
+        if kind == "mfma":
+            self._require(reads, {"mfma": WS_MFMA_MFMA_AB, "valu": WS_VALU_MFMA})
+            self._require(reads_c, {"mfma": WS_MFMA_MFMA_C, "valu": WS_VALU_MFMA})
+            self._require(writes, {"mfma": WS_MFMA_VALU})
+        elif kind == "valu":
+            self._require(reads, {"mfma": WS_MFMA_VALU})
+            self._require(writes, {"mfma": WS_MFMA_VALU})
+        elif kind == "mem":
+            self._require(mem_reads, {"mfma": WS_MFMA_MEM})
+            self._require(writes, {"mfma": WS_MFMA_MEM})  # a load landing in a register a matrix op still owns
+        self._raw(text)
+        for r in writes:
+            if kind in ("mfma", "valu"):
+                self.writer[r] = (self.pos, kind)
+            else:
+                self.writer.pop(r, None)
+        if kind == "mfma":
+            self.last_mfma = self.pos
+        if kind == "valu":
+            self.last_valu = self.pos
+        self.count[kind] = self.count.get(kind, 0) + 1
+        self.pos += 1
+
+    def drain(self):
+        """Before control flow joins or leaves: no hazard may be pending."""
+        need = max(WS_MFMA_MEM - (self.pos - self.last_mfma - 1), WS_VALU_MFMA - (self.pos - self.last_valu - 1), 0)
+        if need > 0:
+            self.nop(need)
+        self.writer.clear()
+
+    # A forward skip over a section without matrix instructions: positions after the join are those of
+    # the path that skipped (the shorter one); registers written inside keep their distance to the join.
+    def begin_skip(self):
+        return self.pos
+
+    def end_skip(self, pos0):
+        shift = self.pos - (pos0)
+        for r, (p, kind) in list(self.writer.items()):
+            if p >= pos0:
+                self.writer[r] = (p - shift, kind)
+        if self.last_valu >= pos0:
+            self.last_valu -= shift
+        self.pos = pos0
+
+
+def vp(r):  # 64-bit VGPR pair
+    return f"v[{r}:{r + 1}]"
+
+
+def ap(r):
+    return f"a[{r}:{r + 1}]"
+
+
+class Alloc:
+    def __init__(self, base, limit, what):
+        self.next, self.limit, self.what = base, limit, what
+        self.names = []
+
+    def get(self, n, name, align=1):
+        self.next = (self.next + align - 1) // align * align
+        r = self.next
+        self.next += n
+        if self.next > self.limit:
+            raise RuntimeError(f"out of {self.what} registers at {name}")
+        self.names.append((name, r, n))
+        return r
+
+
+class Loops:
+    """One instance per group count G (1, 2 or 4).
+
+    What a lone wave pays per instruction on gfx950 (one wave per SIMD, measured with a microbenchmark of
+    1024 repetitions): SALU 4.5 cycles, 32-bit VALU 4.8, v_mul_f64 5.5, v_readlane_b32 9.2, the matrix
+    instruction 16.7 back to back -- and a VALU instruction does NOT overlap a matrix instruction of the
+    same wave (the pair costs 29 cycles), while SALU instructions disappear behind it (matrix + 2 SALU =
+    17.6).  A wait state (s_nop) is 4.5 cycles, a taken branch 21.  ds_read2st64_b64 / ds_write2st64_b64
+    move 1 KB per wave at 128 / 79 bytes per clock per CU, ds_read_b128 twice as fast.  Hence:
+
+      * everything that can be scalar is scalar and sits behind matrix instructions: a step's descriptor
+        arrives by ONE s_load_dwordx8 (requested a step ahead, its table kept in the scalar cache), its
+        fields are unpacked with SALU, bodies are branch-free (EXEC predicates for the optional reads and
+        hand-overs), and the jump to the next body goes through a table of code offsets;
+      * the (P, P^T) images of every branch of the tree live in the AGPR file (a[4b..4b+3], loaded once per
+        run of tiles) and the matrix instruction reads its A operand there through the VGPR index mode
+        (s_set_gpr_idx_on adds M0 to the register number of source 0, AGPR sources included): no image is
+        fetched, staged or copied inside the loops;
+      * the packed tip masks of all tips of the tile live in VGPRs (one per tip), read through the same
+        index mode on source 1: no tip traffic inside the loops either;
+      * stored cells are 16 bytes per lane (two pattern groups side by side): ds_read_b128 / ds_write_b128."""
+
+    MAX_BRANCHES = 56  # a[0:223]; a224.. and v0..v(VBASE-1) stay with the compiler
+    MAX_TIPS = 29
+
+    def __init__(self, G):
+        self.G = G
+        self.e = None
+        V = Alloc(VBASE, VLIMIT, "VGPR")
+        S = Alloc(SBASE, SLIMIT, "SGPR")
+        g2 = lambda name: [V.get(2, f"{name}{g}", 2) for g in range(G)]
+        # persistent
+        self.TMV = V.get(self.MAX_TIPS, "TMV")   # packed masks of tip t (byte g = mask of this lane's pattern in group g)
+        self.U = g2("U")                      # pre-order partial of the step's node
+        self.ONE = V.get(2, "ONE", 2)
+        self.SH = [V.get(1, f"SH{g}") for g in range(G)]   # 30 - state - 8 g
+        self.TP = [[V.get(2, f"TP{t}_{g}", 2) for g in range(G)] for t in range(4)]  # tip operands (lo word stays 0)
+        self.M = [g2("M0_"), g2("M1_")]       # child messages out of LDS (slot 0, slot 1)
+        self.ES = [V.get(2, "ES0", 2), V.get(2, "ES1", 2)]  # per-lane sums of the two child edges (flushed one step late)
+        # temporaries
+        self.MSG = [g2("MSG0_"), g2("MSG1_")]
+        self.MA = [g2("MA0_"), g2("MA1_")]
+        self.MB = [g2("MB0_"), g2("MB1_")]
+        self.X = [g2("X0_"), g2("X1_")]       # cherry partial ma.mb, later the cherry's pre-order partial
+        self.DQ = [g2("DQ0_"), g2("DQ1_")]
+        self.W = [g2("W0_"), g2("W1_")]
+        # pre-order: the children's partials; post-order: UC[1] = own message.  UC[1] shares X[1]'s registers:
+        # X[1] serves a cherry in slot 1, UC[1] a stored cell in slot 1 (post-order: after X[1]'s last use)
+        self.UC = [g2("UC0_"), self.X[1]]
+        self.R = [V.get(2, "R0", 2), V.get(2, "R1", 2)]
+        self.T = [V.get(2, "T0", 2), V.get(2, "T1", 2)]
+        # the tail of a cherry slot s (its two tip edges) runs after everything else of the step has been
+        # consumed, in registers that are dead by then: DQA = MSG[s], DQB = UC[0] (only a (C,C) step uses
+        # it), TA = W[s], TB = DQ[s], EA/EB = T0/T1 (the main pair's stores have been issued)
+        self.EA, self.EB = self.T[0], self.T[1]
+        self.AD = [V.get(1, f"AD{k}") for k in range(8)]
+        self.vnext = V.next
+        # scalars
+        self.CUR = S.get(8, "CUR", 4)   # this step's descriptor
+        self.FLY = S.get(8, "FLY", 4)   # the next step's (requested at the top of the body)
+        self.TAB = S.get(2, "TAB", 2)
+        self.CNT = S.get(1, "CNT")
+        self.EPREV = S.get(1, "EPREV")
+        self.WMASK = S.get(2, "WMASK", 2)
+        self.BASE = S.get(2, "BASE", 2)   # code address the body offsets are relative to
+        self.PC = S.get(2, "PC", 2)
+        self.OFFTAB = S.get(5, "OFFTAB")  # code offsets of the five bodies
+        self.F = [S.get(1, f"F{k}") for k in range(8)]  # unpacked fields of the current step
+        self.TMP = [S.get(1, f"TMP{k}") for k in range(6)]
+        self.IMGP = S.get(2, "IMGP", 2)
+        self.snext = S.next
+        self.V, self.S = V, S
+
+    # ---- descriptor words (see walk_pipe.hip) ----
+    FLAGS, OWN, OFFC01, TIPS, IMG, EDGE01, EDGEAB0, EDGEAB1 = range(8)
+    BIT_FORWARD, BIT_READ1, BIT_READU = 8, 9, 10
+
+    def cur(self, w):
+        return f"s{self.CUR + w}"
+
+    def fly(self, w):
+        return f"s{self.FLY + w}"
+
+    # ---- instruction helpers --------------------------------------------------------------------
+    idx_mode = None  # None | "SRC0" | "SRC1" while the VGPR index mode is on
+
+    def idx_on(self, sgpr, which):
+        self.salu(f"s_set_gpr_idx_on s{sgpr}, gpr_idx({which})")
+        self.idx_mode = which
+
+    def idx_set(self, sgpr):
+        assert self.idx_mode
+        self.salu(f"s_set_gpr_idx_idx s{sgpr}")
+
+    def idx_off(self):
+        self.salu("s_set_gpr_idx_off")
+        self.idx_mode = None
+
+    def mfma(self, dst, a, b):
+        """a: VGPR pair number, "Q" (the per-tree image operand), or ("A", k): AGPR pair a[k:k+1] offset by
+        the index mode (the image of the branch whose index is in M0)"""
+        if os.environ.get("PIPE_NO_MFMA"):  # timing experiment: results are wrong
+            self.e.ins(f"v_mov_b64 {vp(dst)}, {vp(b)}", "valu", reads=[b, b + 1], writes=[dst, dst + 1])
+            return
+        if isinstance(a, tuple):
+            assert self.idx_mode == "SRC0"
+            self.e.ins(f"v_mfma_f64_4x4x4_4b_f64 {vp(dst)}, {ap(a[1])}, {vp(b)}, 0", "mfma", reads=[b, b + 1], writes=[dst, dst + 1])
+            return
+        assert self.idx_mode is None, "a matrix instruction with a VGPR A operand inside an index-mode region"
+        if a == "Q":
+            self.e.ins(f"v_mfma_f64_4x4x4_4b_f64 {vp(dst)}, %[q], {vp(b)}, 0", "mfma", reads=[b, b + 1], writes=[dst, dst + 1])
+        else:
+            self.e.ins(f"v_mfma_f64_4x4x4_4b_f64 {vp(dst)}, {vp(a)}, {vp(b)}, 0", "mfma", reads=[a, a + 1, b, b + 1],
+                       writes=[dst, dst + 1])
+
+    def valu(self, text, reads, writes, indexed_ok=False):
+        assert self.idx_mode is None or indexed_ok, f"VALU inside an index-mode region: {text}"
+        self.e.ins(text, "valu", reads=list(reads), writes=list(writes))
+
+    def vmul(self, dst, a, b):
+        self.valu(f"v_mul_f64 {vp(dst)}, {vp(a)}, {vp(b)}", [a, a + 1, b, b + 1], [dst, dst + 1])
+
+    def vfma(self, dst, a, b, c):
+        self.valu(f"v_fma_f64 {vp(dst)}, {vp(a)}, {vp(b)}, {vp(c)}", [a, a + 1, b, b + 1, c, c + 1], [dst, dst + 1])
+
+    def vmov64(self, dst, src):
+        self.valu(f"v_mov_b64 {vp(dst)}, {vp(src)}", [src, src + 1], [dst, dst + 1])
+
+    def v32(self, text, reads, writes):
+        self.valu(text, reads, writes)
+
+    def salu(self, text):
+        self.e.ins(text, "salu")
+
+    def mem(self, text, mem_reads=(), writes=()):
+        if os.environ.get("PIPE_NO_LDS") and text.startswith("ds_"):  # timing experiment: results are wrong
+            return
+        self.e.ins(text, "mem", mem_reads=list(mem_reads), writes=list(writes))
+
+    def wait(self, vm=None, lgkm=None):
+        parts = []
+        if vm is not None:
+            parts.append(f"vmcnt({vm})")
+        if lgkm is not None:
+            parts.append(f"lgkmcnt({lgkm})")
+        self.salu("s_waitcnt " + " ".join(parts))
+
+    def label(self, name):
+        self.e.drain()
+        self.e._raw(f"{name}:")
+
+    def branch(self, cond, target):
+        self.e.drain()
+        self.e._raw(f"s_cbranch_{cond} {target}" if cond else f"s_branch {target}")
+        self.e.pos += 1
+
+    def L(self, name):
+        return f".Lwp_{self.tag}_{name}_%="
+
+    # EXEC = all lanes when bit `bit` of the next step's flags is set, else none
+    def predicate(self, bit):
+        self.salu(f"s_bitcmp1_b32 {self.fly(self.FLAGS)}, {bit}")
+        self.salu("s_cselect_b64 exec, -1, 0")
+
+    def unpredicate(self):
+        self.salu("s_mov_b64 exec, -1")
+
+    # cells: 16 bytes per lane = two pattern groups; pair p at + p * 1024
+    def cell_read(self, dst_list, addr_vgpr):
+        G = self.G
+        n = 0
+        for p in range((G + 1) // 2):
+            d = dst_list[2 * p]
+            if 2 * p + 1 < G:
+                if dst_list[2 * p + 1] != d + 2:
+                    raise RuntimeError("group registers must be consecutive")
+                self.mem(f"ds_read_b128 v[{d}:{d + 3}], v{addr_vgpr} offset:{1024 * p}", mem_reads=[addr_vgpr],
+                         writes=list(range(d, d + 4)))
+            else:
+                self.mem(f"ds_read_b64 {vp(d)}, v{addr_vgpr} offset:{1024 * p}", mem_reads=[addr_vgpr], writes=[d, d + 1])
+            n += 1
+        return n
+
+    def cell_write(self, src_list, addr_vgpr):
+        G = self.G
+        n = 0
+        for p in range((G + 1) // 2):
+            d = src_list[2 * p]
+            if 2 * p + 1 < G:
+                if src_list[2 * p + 1] != d + 2:
+                    raise RuntimeError("group registers must be consecutive")
+                self.mem(f"ds_write_b128 v{addr_vgpr}, v[{d}:{d + 3}] offset:{1024 * p}",
+                         mem_reads=[addr_vgpr] + list(range(d, d + 4)))
+            else:
+                self.mem(f"ds_write_b64 v{addr_vgpr}, {vp(d)} offset:{1024 * p}", mem_reads=[addr_vgpr, d, d + 1])
+            n += 1
+        return n
+
+    def cell_ops(self):  # LDS instructions per cell access
+        return (self.G + 1) // 2
+
+    # tip operands of all groups from the packed masks of the tip whose id is in `tip_sgpr`:
+    # 2.0 where the state is allowed (the hi word's bit 30), else 0
+    def tip_operands(self, slot_tip, tip_sgpr):
+        self.idx_on(tip_sgpr, "SRC1")
+        for g in range(self.G):
+            hi = self.TP[slot_tip][g] + 1
+            self.valu(f"v_lshlrev_b32 v{hi}, v{self.SH[g]}, v{self.TMV}", [self.SH[g]] + list(range(self.TMV, self.TMV + self.MAX_TIPS)), [hi],
+                      indexed_ok=True)
+        self.idx_off()
+        for g in range(self.G):
+            hi = self.TP[slot_tip][g] + 1
+            self.v32(f"v_and_b32 v{hi}, 2.0, v{hi}", [hi], [hi])
+
+    # ---- edge sums: 64 lanes -> one value per block (rate category), written by lanes 0,4,8,12 ----
+    def flush_stage1(self, ea, eb):
+        self.mfma(self.R[0], ea, self.ONE)
+        self.mfma(self.R[1], eb, self.ONE)
+
+    def flush_stage2(self, offsets):
+        t0, t1 = self.TMP[0], self.TMP[1]
+        self.mfma(self.T[0], self.ONE, self.R[0])
+        self.salu(f"s_and_b32 s{t0}, {offsets}, 0xffff")
+        self.salu(f"s_lshr_b32 s{t1}, {offsets}, 16")
+        self.mfma(self.T[1], self.ONE, self.R[1])
+        self.v32(f"v_add_u32 v{self.AD[6]}, s{t0}, %[grow]", [], [self.AD[6]])
+        self.v32(f"v_add_u32 v{self.AD[7]}, s{t1}, %[grow]", [], [self.AD[7]])
+
+    def flush_stage3(self):
+        self.salu(f"s_mov_b64 exec, s[{self.WMASK}:{self.WMASK + 1}]")
+        self.mem(f"ds_write_b64 v{self.AD[6]}, {vp(self.T[0])}", mem_reads=[self.AD[6], self.T[0], self.T[0] + 1])
+        self.mem(f"ds_write_b64 v{self.AD[7]}, {vp(self.T[1])}", mem_reads=[self.AD[7], self.T[1], self.T[1] + 1])
+        self.salu("s_mov_b64 exec, -1")
+        return 2
+
+    # ---- descriptor pipeline ----
+    def rotate_and_request(self):
+        """top of a body: the descriptor requested by the previous body becomes this step's, the next one is requested"""
+        for k in range(0, 8, 2):
+            self.salu(f"s_mov_b64 s[{self.CUR + k}:{self.CUR + k + 1}], s[{self.FLY + k}:{self.FLY + k + 1}]")
+        self.salu(f"s_add_u32 s{self.TAB}, s{self.TAB}, 32")
+        self.salu(f"s_addc_u32 s{self.TAB + 1}, s{self.TAB + 1}, 0")
+        self.mem(f"s_load_dwordx8 s[{self.FLY}:{self.FLY + 7}], s[{self.TAB}:{self.TAB + 1}], 0x0")
+
+    def request_cells(self, predicate_slot1):
+        """the next step's stored child messages into M[0], M[1] (a slot that is no stored cell has offset 0:
+        what lands is ignored).  Slot 1 under EXEC predicate "read it" when the message may be handed over."""
+        ad = self.AD
+        t = self.TMP[2]
+        self.salu(f"s_and_b32 s{t}, {self.fly(self.OFFC01)}, 0xffff")
+        self.v32(f"v_add_u32 v{ad[0]}, s{t}, %[arena]", [], [ad[0]])
+        self.salu(f"s_lshr_b32 s{t}, {self.fly(self.OFFC01)}, 16")
+        self.v32(f"v_add_u32 v{ad[1]}, s{t}, %[arena]", [], [ad[1]])
+        n = self.cell_read(self.M[0], ad[0])
+        if predicate_slot1:
+            self.predicate(self.BIT_READ1)
+        n += self.cell_read(self.M[1], ad[1])
+        if predicate_slot1:
+            self.unpredicate()
+        return n
+
+    def dispatch(self, done):
+        """leave the body: count the step, jump to the body of the next step (FLY's flags)"""
+        self.salu(f"s_sub_u32 s{self.CNT}, s{self.CNT}, 1")
+        self.salu(f"s_cmp_eq_u32 s{self.CNT}, 0")
+        self.branch("scc1", done)
+        self.jump()
+
+    def jump(self):
+        t = self.TMP[0]
+        self.salu(f"s_and_b32 m0, {self.fly(self.FLAGS)}, 7")
+        self.salu("s_nop 0")
+        self.salu(f"s_movrels_b32 s{t}, s{self.OFFTAB}")
+        self.salu(f"s_add_u32 s{self.PC}, s{self.BASE}, s{t}")
+        self.salu(f"s_addc_u32 s{self.PC + 1}, s{self.BASE + 1}, 0")
+        self.e.drain()
+        self.e._raw(f"s_setpc_b64 s[{self.PC}:{self.PC + 1}]")
+        self.e.pos += 1
+
+    def loop_entry(self, names):
+        """common prologue: first descriptor, constants, the tile's tip masks, the table of body offsets"""
+        G = self.G
+        self.salu(f"s_mov_b64 s[{self.TAB}:{self.TAB + 1}], %[tab]")
+        self.salu(f"s_mov_b32 s{self.CNT}, %[steps]")
+        self.mem(f"s_load_dwordx8 s[{self.FLY}:{self.FLY + 7}], s[{self.TAB}:{self.TAB + 1}], 0x0")
+        for g in range(G):
+            self.v32(f"v_subrev_u32 v{self.SH[g]}, {8 * g}, %[sh0]", [], [self.SH[g]])
+        for t in range(4):
+            for g in range(G):
+                self.v32(f"v_mov_b32 v{self.TP[t][g]}, 0", [], [self.TP[t][g]])
+        # packed masks of tip t into TMV[t]
+        a = self.AD[0]
+        self.v32(f"v_mov_b32 v{a}, %[tiprow]", [], [a])
+        for t in range(self.MAX_TIPS):
+            self.mem(f"ds_read_b32 v{self.TMV + t}, v{a}", mem_reads=[a], writes=[self.TMV + t])
+            if t + 1 < self.MAX_TIPS:
+                self.v32(f"v_add_u32 v{a}, %[tipstride], v{a}", [a], [a])
+        self.salu(f"s_getpc_b64 s[{self.BASE}:{self.BASE + 1}]")
+        self.e._raw(f"{self.L('base')}:")
+        for k, name in enumerate(names):
+            self.salu(f"s_mov_b32 s{self.OFFTAB + k}, {self.L(name)}-{self.L('base')}")
+
+    # ---- child messages of one slot (both passes) ---------------------------------------------------
+    def messages(self, kinds):
+        """leaves the message of a tip / cherry slot s in MSG[s] -- a stored cell's message is M[s] itself.
+        Cherry: MA, MB (tip messages) are kept for the pre-order pass.  Fields: F[0], F[1] image indices of
+        the slots, F[4..7] tip ids A0 B0 A1 B1."""
+        G = self.G
+        f = self.F
+        t = self.TMP
+        for s in (0, 1):
+            if kinds[s] == "T":
+                self.tip_operands(2 * s, f[4 + 2 * s])
+            elif kinds[s] == "H":
+                self.tip_operands(2 * s, f[4 + 2 * s])
+                self.tip_operands(2 * s + 1, f[5 + 2 * s])
+        for s in (0, 1):
+            if kinds[s] == "T":
+                self.idx_on(f[s], "SRC0")
+                for g in range(G):
+                    self.mfma(self.MSG[s][g], ("A", 0), self.TP[2 * s][g])
+                self.idx_off()
+            elif kinds[s] == "H":
+                # image index of a tip branch = 4 x tip id
+                self.salu(f"s_lshl_b32 s{t[2]}, s{f[4 + 2 * s]}, 2")
+                self.salu(f"s_lshl_b32 s{t[3]}, s{f[5 + 2 * s]}, 2")
+                self.idx_on(t[2], "SRC0")
+                for g in range(G):
+                    self.mfma(self.MA[s][g], ("A", 0), self.TP[2 * s][g])
+                self.idx_set(t[3])
+                for g in range(G):
+                    self.mfma(self.MB[s][g], ("A", 0), self.TP[2 * s + 1][g])
+                self.idx_off()
+        for s in (0, 1):
+            if kinds[s] == "H":
+                for g in range(G):
+                    self.vmul(self.X[s][g], self.MA[s][g], self.MB[s][g])
+        for s in (0, 1):
+            if kinds[s] == "H":
+                self.idx_on(f[s], "SRC0")
+                for g in range(G):
+                    self.mfma(self.MSG[s][g], ("A", 0), self.X[s][g])
+                self.idx_off()
+
+    def msg(self, s, kind):
+        return self.M[s] if kind == "C" else self.MSG[s]
+
+    def unpack(self, kinds, post):
+        f = self.F
+        self.salu(f"s_mov_b32 s{f[0]}, {self.cur(self.IMG)}")
+        self.salu(f"s_lshr_b32 s{f[1]}, {self.cur(self.IMG)}, 8")
+        if post:
+            self.salu(f"s_lshr_b32 s{f[2]}, {self.cur(self.IMG)}, 16")
+        if kinds[0] != "C":
+            self.salu(f"s_and_b32 s{f[4]}, {self.cur(self.TIPS)}, 0xff")
+        if kinds[0] == "H":
+            self.salu(f"s_bfe_u32 s{f[5]}, {self.cur(self.TIPS)}, 0x80008")
+        if kinds[1] != "C":
+            self.salu(f"s_bfe_u32 s{f[6]}, {self.cur(self.TIPS)}, 0x80010")
+        if kinds[1] == "H":
+            self.salu(f"s_lshr_b32 s{f[7]}, {self.cur(self.TIPS)}, 24")
+
+    # =============================== post-order loop ===============================================
+    VARIANTS = [("cc", "C", "C"), ("tc", "T", "C"), ("hc", "H", "C"), ("th", "T", "H"), ("hh", "H", "H")]
+
+    def post_body(self, name, K0, K1):
+        G = self.G
+        kinds = (K0, K1)
+        own = self.UC[1]
+        f = self.F
+        self.label(self.L(name))
+        self.e.comment(f"post-order step, children ({K0},{K1})")
+        self.rotate_and_request()
+        self.unpack(kinds, post=True)
+        self.messages(kinds)
+        # x = m0 . m1 (the node's partial); the root's leaves the loop in X[0]
+        m0, m1 = self.msg(0, K0), self.msg(1, K1)
+        for g in range(G):
+            self.vmul(self.X[0][g], m0[g], m1[g])
+        self.salu(f"s_cmp_eq_u32 s{self.CNT}, 1")
+        self.branch("scc1", self.L("root"))
+        # own message a = P_v x
+        self.idx_on(f[2], "SRC0")
+        for g in range(G):
+            self.mfma(own[g], ("A", 0), self.X[0][g])
+        self.idx_off()
+        self.wait(lgkm=0)  # the next step's descriptor (and long-issued stores)
+        self.request_cells(predicate_slot1=True)
+        self.v32(f"v_add_u32 v{self.AD[6]}, {self.cur(self.OWN)}, %[arena]", [], [self.AD[6]])
+        nst = self.cell_write(own, self.AD[6])
+        # the message is the next step's slot-1 operand when that step's node is this node's parent
+        self.predicate(self.BIT_FORWARD)
+        for g in range(G):
+            self.vmov64(self.M[1][g], own[g])
+        self.unpredicate()
+        self.wait(lgkm=nst)  # the requests have landed; the stores may still travel
+        self.dispatch(self.L("root"))
+
+    def post_loop(self):
+        self.e = Emitter()
+        self.tag = f"post{self.G}"
+        G = self.G
+        e = self.e
+        e.comment(f"post-order loop, G = {G}")
+        names = [v[0] for v in self.VARIANTS]
+        self.loop_entry(names)
+        self.wait(lgkm=0)
+        self.request_cells(predicate_slot1=False)
+        self.wait(lgkm=0)
+        self.jump()
+        for name, K0, K1 in self.VARIANTS:
+            self.post_body(name, K0, K1)
+        self.label(self.L("root"))
+        self.wait(vm=0, lgkm=0)
+        for g in range(G):
+            self.e.ins(f"v_mov_b64 %[r{g}], {vp(self.X[0][g])}", "valu", reads=[self.X[0][g], self.X[0][g] + 1])
+        return e
+
+    # =============================== pre-order loop ================================================
+    def pre_body(self, name, K0, K1):
+        G = self.G
+        kinds = (K0, K1)
+        f = self.F
+        self.label(self.L(name))
+        self.e.comment(f"pre-order step, children ({K0},{K1})")
+        self.rotate_and_request()
+        # the previous step's two edge sums, level 1; the scalar unpacking sits behind the matrix instructions
+        self.flush_stage1(self.ES[0], self.ES[1])
+        self.unpack(kinds, post=False)
+        self.messages(kinds)
+        # Q m of both children
+        for s in (0, 1):
+            for g in range(G):
+                self.mfma(self.DQ[s][g], "Q", self.msg(s, kinds[s])[g])
+        self.flush_stage2(f"s{self.EPREV}")
+        self.salu(f"s_mov_b32 s{self.EPREV}, {self.cur(self.EDGE01)}")
+        self.wait(lgkm=0)  # U when it came out of LDS; the next step's descriptor
+        nst = self.flush_stage3()
+        # w_s = U . (message of the other child)
+        m0, m1 = self.msg(0, K0), self.msg(1, K1)
+        for g in range(G):
+            self.vmul(self.W[0][g], self.U[g], m1[g])
+            self.vmul(self.W[1][g], self.U[g], m0[g])
+        # addresses of the next step's operands (VALU before the matrix block, the reads inside it)
+        ad = self.AD
+        t = self.TMP[2]
+        self.salu(f"s_and_b32 s{t}, {self.fly(self.OFFC01)}, 0xffff")
+        self.v32(f"v_add_u32 v{ad[0]}, s{t}, %[arena]", [], [ad[0]])
+        self.salu(f"s_lshr_b32 s{t}, {self.fly(self.OFFC01)}, 16")
+        self.v32(f"v_add_u32 v{ad[1]}, s{t}, %[arena]", [], [ad[1]])
+        self.v32(f"v_add_u32 v{ad[2]}, {self.fly(self.OWN)}, %[arena]", [], [ad[2]])
+        # P^T w: the children's pre-order partials, with the next step's reads issued underneath
+        # (the registers they land in -- M[0], M[1], U -- have had their last use)
+        first = True
+        nreq = 0
+        for s in (0, 1):
+            if kinds[s] == "T":
+                continue
+            dst = self.UC[s] if kinds[s] == "C" else self.X[s]
+            if first:
+                self.idx_on(f[s], "SRC0")
+            else:
+                self.idx_set(f[s])
+            for g in range(G):
+                self.mfma(dst[g], ("A", 2), self.W[s][g])
+            if first:
+                nreq += self.cell_read(self.M[0], ad[0])
+                nreq += self.cell_read(self.M[1], ad[1])
+                self.predicate(self.BIT_READU)
+                nreq += self.cell_read(self.U, ad[2])
+                self.unpredicate()
+            first = False
+        self.idx_off()
+        # edge sums of this step's two child edges (flushed by the next body)
+        for s in (0, 1):
+            for g in range(G):
+                if g == 0:
+                    self.vmul(self.ES[s], self.W[s][g], self.DQ[s][g])
+                else:
+                    self.vfma(self.ES[s], self.W[s][g], self.DQ[s][g], self.ES[s])
+        # cherry children: the two tip edges under each
+        nst = 0
+        for s in (0, 1):
+            if kinds[s] != "H":
+                continue
+            DQA, DQB, TA, TB = self.MSG[s], self.UC[0], self.W[s], self.DQ[s]
+            for g in range(G):
+                self.mfma(DQA[g], "Q", self.MA[s][g])
+            for g in range(G):
+                self.mfma(DQB[g], "Q", self.MB[s][g])
+            for g in range(G):
+                self.vmul(TA[g], self.X[s][g], self.MB[s][g])
+                self.vmul(TB[g], self.X[s][g], self.MA[s][g])
+            for g in range(G):
+                if g == 0:
+                    self.vmul(self.EA, TA[g], DQA[g])
+                    self.vmul(self.EB, TB[g], DQB[g])
+                else:
+                    self.vfma(self.EA, TA[g], DQA[g], self.EA)
+                    self.vfma(self.EB, TB[g], DQB[g], self.EB)
+            self.flush_stage1(self.EA, self.EB)
+            self.flush_stage2(self.cur(self.EDGEAB0 + s))
+            nst += self.flush_stage3()
+        # this step's stores
+        if K0 == "C":
+            self.salu(f"s_and_b32 s{self.TMP[3]}, {self.cur(self.OFFC01)}, 0xffff")
+            self.v32(f"v_add_u32 v{self.AD[3]}, s{self.TMP[3]}, %[arena]", [], [self.AD[3]])
+            nst += self.cell_write(self.UC[0], self.AD[3])
+        if K1 == "C":
+            self.salu(f"s_lshr_b32 s{self.TMP[3]}, {self.cur(self.OFFC01)}, 16")
+            self.v32(f"v_add_u32 v{self.AD[4]}, s{self.TMP[3]}, %[arena]", [], [self.AD[4]])
+            nst += self.cell_write(self.UC[1], self.AD[4])
+            # slot 1's partial is the next step's U when that step's node is this child
+            self.predicate(self.BIT_FORWARD)
+            for g in range(G):
+                self.vmov64(self.U[g], self.UC[1][g])
+            self.unpredicate()
+        self.wait(lgkm=nst)  # everything requested has landed; the stores may still travel
+        self.dispatch(self.L("done"))
+
+    def pre_loop(self):
+        self.e = Emitter()
+        self.tag = f"pre{self.G}"
+        G = self.G
+        e = self.e
+        e.comment(f"pre-order loop, G = {G}")
+        names = [v[0] for v in self.VARIANTS]
+        self.loop_entry(names)
+        self.e.ins(f"v_mov_b64 {vp(self.ONE)}, 1.0", "valu", writes=[self.ONE, self.ONE + 1])
+        for s in (0, 1):
+            self.e.ins(f"v_mov_b64 {vp(self.ES[s])}, 0", "valu", writes=[self.ES[s], self.ES[s] + 1])
+        for g in range(G):
+            self.e.ins(f"v_mov_b64 {vp(self.U[g])}, %[u{g}]", "valu", writes=[self.U[g], self.U[g] + 1])
+        self.salu(f"s_mov_b32 s{self.EPREV}, %[rootedge]")
+        self.salu(f"s_mov_b32 s{self.WMASK}, 0x1111")
+        self.salu(f"s_mov_b32 s{self.WMASK + 1}, 0")
+        self.wait(lgkm=0)
+        self.request_cells(predicate_slot1=False)
+        self.wait(lgkm=0)
+        self.jump()
+        for name, K0, K1 in self.VARIANTS:
+            self.pre_body(name, K0, K1)
+        self.label(self.L("done"))
+        # the last step's two edges
+        self.flush_stage1(self.ES[0], self.ES[1])
+        self.flush_stage2(f"s{self.EPREV}")
+        self.flush_stage3()
+        self.wait(vm=0, lgkm=0)
+        return e
+
+    # =============================== image loader ==================================================
+    def load_images(self):
+        """(P, P^T) of every branch of the tree into a[4b .. 4b+3]; %[nb] branches, at most MAX_BRANCHES"""
+        self.e = Emitter()
+        self.tag = "load"
+        e = self.e
+        e.comment("matrix images of the whole tree into the AGPR file")
+        ip = self.IMGP
+        self.salu(f"s_mov_b64 s[{ip}:{ip + 1}], %[img]")
+        done = self.L("done")
+        for b in range(self.MAX_BRANCHES):
+            if b % 4 == 0:
+                self.salu(f"s_cmp_le_u32 %[nb], {b}")
+                self.e._raw(f"s_cbranch_scc1 {done}")
+                self.e.pos += 1
+            self.mem(f"global_load_dwordx4 a[{4 * b}:{4 * b + 3}], %[lane16], s[{ip}:{ip + 1}] offset:{(b % 4) * 1024}")
+            if b % 4 == 3:
+                self.salu(f"s_add_u32 s{ip}, s{ip}, 4096")
+                self.salu(f"s_addc_u32 s{ip + 1}, s{ip + 1}, 0")
+        self.e._raw(f"{done}:")
+        self.wait(vm=0)
+        return e
+
+
+def fix_q(lines):
+    return [ln.replace("v[Q:Q1]", "%[q]") for ln in lines]
+
+
+def as_macro(name, lines):
+    out = [f"#define {name} \\"]
+    for ln in lines:
+        text = ln.replace("\\", "\\\\").replace('"', '\\"')
+        out.append(f'  "{text}\\n" \\')
+    out.append('  ""')
+    return "\n".join(out)
+
+
+def clobbers(loops):
+    regs = [f"v{r}" for r in range(VBASE, loops.vnext)] + [f"a{r}" for r in range(4 * Loops.MAX_BRANCHES)] + \
+           [f"s{r}" for r in range(SBASE, loops.snext)]
+    return ", ".join(f'"{r}"' for r in regs) + ', "vcc", "scc", "memory"  /* (and m0, which the compiler treats as reserved) */'
+
+
+def main():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = ["// GENERATED by scripts/gen_walk_pipe.py -- do not edit; see that script for what and why.",
+           "// clang-format off"]
+    listing = []
+    for G in GROUPS:
+        loops = Loops(G)
+        post = loops.post_loop()
+        pre = loops.pre_loop()
+        out.append(as_macro(f"WALK_PIPE_POST_ASM_G{G}", post.lines))
+        out.append(as_macro(f"WALK_PIPE_PRE_ASM_G{G}", pre.lines))
+        out.append(f"#define WALK_PIPE_CLOBBERS_G{G} {clobbers(loops)}")
+        listing.append(f"G={G}: VGPR v{VBASE}..v{loops.vnext - 1}, AGPR a0..a{4 * Loops.MAX_BRANCHES - 1}, SGPR s{SBASE}..s{loops.snext - 1}; "
+                       f"post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
+    loops = Loops(1)
+    out.append(as_macro("WALK_PIPE_LOAD_ASM", loops.load_images().lines))
+    out.append(f"#define WALK_PIPE_MAX_BRANCHES {Loops.MAX_BRANCHES}")
+    out.append(f"#define WALK_PIPE_MAX_TIPS {Loops.MAX_TIPS}")
+    out.append("// " + "\n// ".join(listing))
+    out.append("// clang-format on")
+    path = os.path.join(root, "bito_amd", "csrc", "walk_pipe_gen.inc")
+    with open(path, "w") as fh:
+        fh.write("\n".join(out) + "\n")
+    print("\n".join(listing))
+    if len(sys.argv) > 1:  # plain listing of one loop for reading: gen_walk_pipe.py pre4 > /tmp/pre4.s
+        want = sys.argv[1]
+        loops = Loops(int(want[-1]))
+        e = loops.post_loop() if want.startswith("post") else (loops.pre_loop() if want.startswith("pre") else loops.load_images())
+        sys.stderr.write("\n".join(e.lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
