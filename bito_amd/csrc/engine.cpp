@@ -427,13 +427,14 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   }
   const int tiles = use_tree ? tplan.tiles : (use_lds ? plan.tiles : HbmTiles(d.pattern_count));
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
-  const int grad_rows = (use_tree || use_lds) ? tiles : tiles * (kHbmBlock / 64);  // HBM kernel: a row per wave
+  // partial gradient rows per tree: one per tile (LDS kernels), per run of tiles (pipelined LDS kernel), per wave (HBM kernel)
+  const int grad_rows = (use_pipe && plan.grad_rows > 0) ? plan.grad_rows : (use_tree || use_lds) ? tiles : tiles * (kHbmBlock / 64);
   if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * grad_rows * d.node_count));
   if (use_tree || use_lds) {
     // pipelined: this pass's set-up goes to prep_stream and into buffer set (run_counter & 1)
     const int set = (int)(e->run_counter++ & 1u);
     HIP_TRY(e, (set ? e->images2 : e->images).Reserve((size_t)T * NB * kImgStride));
-    if (use_lds) HIP_TRY(e, (set ? e->sched2 : e->sched).Reserve(LdsScheduleInts(d)));
+    if (use_lds) HIP_TRY(e, (set ? e->sched2 : e->sched).Reserve(use_pipe ? PipeScheduleInts(d, plan) : LdsScheduleInts(d)));
     const DeviceBatch b = MakeBatch(e, set);
     HIP_TRY(e, hipStreamWaitEvent(e->prep_stream, e->ev_walk_done[set], 0));
     LaunchSetup(d, e->spec, b, want_gradient, e->prep_stream);
@@ -458,7 +459,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
     e->kernel_name = use_tree ? "walk_tree_kernel" : (use_pipe ? "walk_pipe_kernel" : "walk_lds_kernel");
     e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
-    LaunchReduce(d, b, tiles, want_gradient, e->stream);
+    LaunchReduce(d, b, tiles, want_gradient, e->stream, grad_rows);
     HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
     HIP_TRY(e, hipGetLastError());
     return BITO_AMD_OK;

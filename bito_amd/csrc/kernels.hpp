@@ -130,6 +130,8 @@ struct LdsPlan {
   int patterns_per_block;
   int tiles;           // workgroups per tree
   size_t lds_bytes;
+  int tile_run = 1;    // (walk_pipe_kernel) consecutive tiles of a tree walked by one workgroup
+  int grad_rows = 0;   // (walk_pipe_kernel) partial gradient rows per tree: one per run; 0 = one per tile
 };
 LdsPlan PlanLds(const BatchDims& d);
 size_t LdsScheduleInts(const BatchDims& d);
@@ -142,7 +144,7 @@ void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan
 // stored child MESSAGES instead of partials, both tree loops software-pipelined gfx950 assembly.
 // Images: [T][N-1][128] doubles ((P, P^T) per lane); step tables: [T][2][n+1][16] dwords in b.sched.
 LdsPlan PlanPipe(const BatchDims& d);
-size_t PipeScheduleInts(const BatchDims& d);
+size_t PipeScheduleInts(const BatchDims& d, const LdsPlan& plan);
 void LaunchPipeImages(const BatchDims& d, const DeviceBatch& b, hipStream_t stream);
 void LaunchPipeSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream);
 // deriv_mode 1: the edge derivatives use d r_c / d shape in place of r_c (site-model pass)

@@ -376,8 +376,9 @@ class Loops:
 
     def flush_stage3(self):
         self.salu(f"s_mov_b64 exec, s[{self.WMASK}:{self.WMASK + 1}]")
-        self.mem(f"ds_write_b64 v{self.AD[6]}, {vp(self.T[0])}", mem_reads=[self.AD[6], self.T[0], self.T[0] + 1])
-        self.mem(f"ds_write_b64 v{self.AD[7]}, {vp(self.T[1])}", mem_reads=[self.AD[7], self.T[1], self.T[1] + 1])
+        # (accumulate: the rows are summed over the tiles of a run)
+        self.mem(f"ds_add_f64 v{self.AD[6]}, {vp(self.T[0])}", mem_reads=[self.AD[6], self.T[0], self.T[0] + 1])
+        self.mem(f"ds_add_f64 v{self.AD[7]}, {vp(self.T[1])}", mem_reads=[self.AD[7], self.T[1], self.T[1] + 1])
         self.salu("s_mov_b64 exec, -1")
         return 2
 
