@@ -37,90 +37,203 @@ VLIMIT = 256
 SBASE, SLIMIT = 36, 96  # SGPRs
 
 
+import re
+
+_SREG = re.compile(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b|\b(exec|m0|vcc)\b|%\[(\w+)\]")
+
+
+def _scalar_operands(text):
+    """scalar resources named by an instruction, in operand order: SGPR numbers, 'exec', 'm0', 'vcc', and the
+    asm statement's named operands (inputs: never written by the loops)"""
+    body = text.split(None, 1)[1] if " " in text else ""
+    out = []
+    for m in _SREG.finditer(body):
+        if m.group(1):
+            out.append(set(range(int(m.group(1)), int(m.group(2)) + 1)))
+        elif m.group(3):
+            out.append({int(m.group(3))})
+        elif m.group(4):
+            out.append({m.group(4)})
+        else:
+            out.append({"%" + m.group(5)})
+    return out
+
+
+class Ins:
+    __slots__ = ("text", "kind", "reads", "writes", "mem_reads", "reads_c", "sreads", "swrites", "fence")
+
+    def __init__(self, text, kind, reads=(), writes=(), mem_reads=(), reads_c=()):
+        self.text, self.kind = text, kind
+        self.reads, self.writes, self.mem_reads, self.reads_c = list(reads), list(writes), list(mem_reads), list(reads_c)
+        self.fence = False
+        ops = _scalar_operands(text)
+        op = text.split()[0]
+        sr, sw = set(), set()
+        if kind == "salu":
+            no_dest = op.startswith(("s_cmp", "s_bitcmp", "s_waitcnt", "s_nop", "s_set_gpr_idx", "s_cbranch", "s_branch", "s_setpc"))
+            for k, o in enumerate(ops):
+                (sw if (k == 0 and not no_dest) else sr).update(o)
+            if op.startswith("s_set_gpr_idx"):
+                sw.update({"m0", "mode"})
+            if op == "s_movrels_b32":
+                sr.add("m0")
+                sr.update(range(0, 104))  # (relative source: any SGPR)
+            if op.startswith(("s_waitcnt", "s_cbranch", "s_branch", "s_setpc")):
+                self.fence = True
+            if op == "s_nop":  # (only the one between a write of M0 and s_movrels: it stays between them)
+                sr.add("m0")
+                sw.add("m0")
+        else:
+            for o in ops:
+                sr.update(o)
+            if op.startswith("s_load"):  # destination first
+                sw.update(ops[0])
+                sr.difference_update(ops[0])
+            if op.startswith("v_readlane"):
+                sw.update(ops[0])
+                sr.difference_update(ops[0])
+            sr.update({"exec", "mode", "m0"})  # every vector / memory instruction runs under EXEC and the index mode
+        self.sreads, self.swrites = sr, sw
+
+    def conflicts_with_delayed(self, s):
+        """may this instruction NOT be emitted before the delayed scalar instruction s (earlier in program order)?"""
+        return bool(self.sreads & s.swrites) or bool(self.swrites & (s.sreads | s.swrites))
+
+
 class Emitter:
-    """Collects instructions, inserts s_nop for the hazards above, keeps a plain listing."""
+    """Collects instructions; finish() sinks scalar instructions behind matrix instructions (a lone wave
+    hides about two SALU instructions behind one v_mfma_f64_4x4x4_4b, nothing else), then inserts the
+    s_nop wait states the hazards above need."""
+
+    SALU_PER_MFMA = 2
 
     def __init__(self):
-        self.lines = []
-        self.pos = 0
-        self.writer = {}  # vgpr index -> (pos, 'mfma' | 'valu')
-        self.last_mfma = -100
-        self.last_valu = -100
+        self.items = []   # Ins | ("label", name) | ("raw", text) | ("comment", text)
         self.count = {}
 
     def _raw(self, text):
-        self.lines.append(text)
+        self.items.append(("raw", text))
 
     def comment(self, text):
-        self._raw(f"; {text}")
+        self.items.append(("comment", text))
 
-    def nop(self, states):
-        while states > 0:
-            n = min(states, 16)
-            self._raw(f"s_nop {n - 1}")
-            self.pos += n
-            states -= n
+    def label(self, name):
+        self.items.append(("label", name))
 
-    def _require(self, regs, need_of):
-        worst = 0
-        for r in regs:
-            w = self.writer.get(r)
-            if w is None:
-                continue
-            p, kind = w
-            need = need_of.get(kind, 0)
-            have = self.pos - p - 1
-            if need - have > worst:
-                worst = need - have
-        if worst > 0:
-            self.nop(worst)
+    def control(self, text):
+        """branch / jump: nothing moves across it"""
+        self.items.append(("control", text))
 
     def ins(self, text, kind, reads=(), writes=(), mem_reads=(), reads_c=()):
-        """kind: mfma | valu | salu | mem (memory/LDS/branch/misc).  reads: VGPRs read as ordinary operands;
-        mem_reads: VGPRs read by a memory instruction (address/data); reads_c: matrix C operand."""
-        if kind == "mfma":
-            self._require(reads, {"mfma": WS_MFMA_MFMA_AB, "valu": WS_VALU_MFMA})
-            self._require(reads_c, {"mfma": WS_MFMA_MFMA_C, "valu": WS_VALU_MFMA})
-            self._require(writes, {"mfma": WS_MFMA_VALU})
-        elif kind == "valu":
-            self._require(reads, {"mfma": WS_MFMA_VALU})
-            self._require(writes, {"mfma": WS_MFMA_VALU})
-        elif kind == "mem":
-            self._require(mem_reads, {"mfma": WS_MFMA_MEM})
-            self._require(writes, {"mfma": WS_MFMA_MEM})  # a load landing in a register a matrix op still owns
-        self._raw(text)
-        for r in writes:
-            if kind in ("mfma", "valu"):
-                self.writer[r] = (self.pos, kind)
-            else:
-                self.writer.pop(r, None)
-        if kind == "mfma":
-            self.last_mfma = self.pos
-        if kind == "valu":
-            self.last_valu = self.pos
+        self.items.append(Ins(text, kind, reads, writes, mem_reads, reads_c))
         self.count[kind] = self.count.get(kind, 0) + 1
-        self.pos += 1
 
-    def drain(self):
-        """Before control flow joins or leaves: no hazard may be pending."""
-        need = max(WS_MFMA_MEM - (self.pos - self.last_mfma - 1), WS_VALU_MFMA - (self.pos - self.last_valu - 1), 0)
-        if need > 0:
-            self.nop(need)
-        self.writer.clear()
+    # ---- pass 1: scalar instructions into the shadow of matrix instructions ----
+    def _schedule(self):
+        out, queue = [], []
 
-    # A forward skip over a section without matrix instructions: positions after the join are those of
-    # the path that skipped (the shorter one); registers written inside keep their distance to the join.
-    def begin_skip(self):
-        return self.pos
+        def flush(upto=None):
+            n = len(queue) if upto is None else upto
+            out.extend(queue[:n])
+            del queue[:n]
 
-    def end_skip(self, pos0):
-        shift = self.pos - (pos0)
-        for r, (p, kind) in list(self.writer.items()):
-            if p >= pos0:
-                self.writer[r] = (p - shift, kind)
-        if self.last_valu >= pos0:
-            self.last_valu -= shift
-        self.pos = pos0
+        for it in self.items:
+            if not isinstance(it, Ins):
+                flush()
+                out.append(it)
+                continue
+            if it.kind == "salu":
+                if it.fence or os.environ.get("PIPE_NO_SINK"):
+                    flush()
+                    out.append(it)
+                else:
+                    queue.append(it)
+                continue
+            # vector / memory instruction: everything it depends on leaves the queue first (in order)
+            last = -1
+            for k, sq in enumerate(queue):
+                if it.conflicts_with_delayed(sq):
+                    last = k
+            if last >= 0:
+                flush(last + 1)
+            out.append(it)
+            if it.kind == "mfma":
+                flush(min(self.SALU_PER_MFMA, len(queue)))
+        flush()
+        return out
+
+    # ---- pass 2: hazards ----
+    def finish(self):
+        lines = []
+        pos = 0
+        writer = {}
+        last_mfma = last_valu = -100
+
+        def nop(states):
+            nonlocal pos
+            while states > 0:
+                n = min(states, 16)
+                lines.append(f"s_nop {n - 1}")
+                pos += n
+                states -= n
+
+        def require(regs, need_of):
+            worst = 0
+            for r in regs:
+                w = writer.get(r)
+                if w is None:
+                    continue
+                p, kind = w
+                need = need_of.get(kind, 0)
+                have = pos - p - 1
+                worst = max(worst, need - have)
+            if worst > 0:
+                nop(worst)
+
+        def drain():
+            need = max(WS_MFMA_MEM - (pos - last_mfma - 1), WS_VALU_MFMA - (pos - last_valu - 1), 0)
+            if need > 0:
+                nop(need)
+            writer.clear()
+
+        for it in self._schedule():
+            if not isinstance(it, Ins):
+                tag, text = it
+                if tag == "comment":
+                    lines.append(f"; {text}")
+                elif tag == "label":
+                    drain()
+                    lines.append(f"{text}:")
+                elif tag == "control":
+                    drain()
+                    lines.append(text)
+                    pos += 1
+                else:
+                    lines.append(text)
+                continue
+            if it.kind == "mfma":
+                require(it.reads, {"mfma": WS_MFMA_MFMA_AB, "valu": WS_VALU_MFMA})
+                require(it.reads_c, {"mfma": WS_MFMA_MFMA_C, "valu": WS_VALU_MFMA})
+                require(it.writes, {"mfma": WS_MFMA_VALU})
+            elif it.kind == "valu":
+                require(it.reads, {"mfma": WS_MFMA_VALU})
+                require(it.writes, {"mfma": WS_MFMA_VALU})
+            elif it.kind == "mem":
+                require(it.mem_reads, {"mfma": WS_MFMA_MEM})
+                require(it.writes, {"mfma": WS_MFMA_MEM})  # a load landing in a register a matrix op still owns
+            lines.append(it.text)
+            for r in it.writes:
+                if it.kind in ("mfma", "valu"):
+                    writer[r] = (pos, it.kind)
+                else:
+                    writer.pop(r, None)
+            if it.kind == "mfma":
+                last_mfma = pos
+            if it.kind == "valu":
+                last_valu = pos
+            pos += 1
+        self.lines = lines
+        return lines
 
 
 def vp(r):  # 64-bit VGPR pair
@@ -208,20 +321,21 @@ class Loops:
         self.FLY = S.get(8, "FLY", 4)   # the next step's (requested at the top of the body)
         self.TAB = S.get(2, "TAB", 2)
         self.CNT = S.get(1, "CNT")
-        self.EPREV = S.get(1, "EPREV")
+        self.EPREV = [S.get(1, "EPREV0"), S.get(1, "EPREV1")]  # gradient-row byte offsets of the previous step's two edges
         self.WMASK = S.get(2, "WMASK", 2)
         self.BASE = S.get(2, "BASE", 2)   # code address the body offsets are relative to
         self.PC = S.get(2, "PC", 2)
-        self.OFFTAB = S.get(5, "OFFTAB")  # code offsets of the five bodies
+        self.OFFTAB = S.get(6, "OFFTAB")  # code offsets of the five bodies and of the loop exit
         self.F = [S.get(1, f"F{k}") for k in range(8)]  # unpacked fields of the current step
         self.TMP = [S.get(1, f"TMP{k}") for k in range(6)]
+        self.TMPM = [S.get(1, f"TMPM{k}") for k in range(2)]  # scratch of messages() only
         self.IMGP = S.get(2, "IMGP", 2)
         self.snext = S.next
         self.V, self.S = V, S
 
     # ---- descriptor words (see walk_pipe.hip) ----
-    FLAGS, OWN, OFFC01, TIPS, IMG, EDGE01, EDGEAB0, EDGEAB1 = range(8)
-    BIT_FORWARD, BIT_READ1, BIT_READU = 8, 9, 10
+    FLAGS, OWNS, OFFC01, NOFFC01, TIPS, IMG = range(6)
+    BIT_FORWARD, BIT_READ1, BIT_READU = 8, 9, 10  # all three describe the NEXT step
 
     def cur(self, w):
         return f"s{self.CUR + w}"
@@ -294,20 +408,17 @@ class Loops:
         self.salu("s_waitcnt " + " ".join(parts))
 
     def label(self, name):
-        self.e.drain()
-        self.e._raw(f"{name}:")
+        self.e.label(name)
 
     def branch(self, cond, target):
-        self.e.drain()
-        self.e._raw(f"s_cbranch_{cond} {target}" if cond else f"s_branch {target}")
-        self.e.pos += 1
+        self.e.control(f"s_cbranch_{cond} {target}" if cond else f"s_branch {target}")
 
     def L(self, name):
         return f".Lwp_{self.tag}_{name}_%="
 
     # EXEC = all lanes when bit `bit` of the next step's flags is set, else none
     def predicate(self, bit):
-        self.salu(f"s_bitcmp1_b32 {self.fly(self.FLAGS)}, {bit}")
+        self.salu(f"s_bitcmp1_b32 {self.cur(self.FLAGS)}, {bit}")
         self.salu("s_cselect_b64 exec, -1, 0")
 
     def unpredicate(self):
@@ -365,14 +476,11 @@ class Loops:
         self.mfma(self.R[0], ea, self.ONE)
         self.mfma(self.R[1], eb, self.ONE)
 
-    def flush_stage2(self, offsets):
-        t0, t1 = self.TMP[0], self.TMP[1]
+    def flush_stage2(self, off0, off1):
         self.mfma(self.T[0], self.ONE, self.R[0])
-        self.salu(f"s_and_b32 s{t0}, {offsets}, 0xffff")
-        self.salu(f"s_lshr_b32 s{t1}, {offsets}, 16")
         self.mfma(self.T[1], self.ONE, self.R[1])
-        self.v32(f"v_add_u32 v{self.AD[6]}, s{t0}, %[grow]", [], [self.AD[6]])
-        self.v32(f"v_add_u32 v{self.AD[7]}, s{t1}, %[grow]", [], [self.AD[7]])
+        self.v32(f"v_add_u32 v{self.AD[6]}, s{off0}, %[grow]", [], [self.AD[6]])
+        self.v32(f"v_add_u32 v{self.AD[7]}, s{off1}, %[grow]", [], [self.AD[7]])
 
     def flush_stage3(self):
         self.salu(f"s_mov_b64 exec, s[{self.WMASK}:{self.WMASK + 1}]")
@@ -383,22 +491,57 @@ class Loops:
         return 2
 
     # ---- descriptor pipeline ----
-    def rotate_and_request(self):
-        """top of a body: the descriptor requested by the previous body becomes this step's, the next one is requested"""
+    def rotate(self):
+        """the descriptor requested by the previous body becomes this step's"""
         for k in range(0, 8, 2):
             self.salu(f"s_mov_b64 s[{self.CUR + k}:{self.CUR + k + 1}], s[{self.FLY + k}:{self.FLY + k + 1}]")
         self.salu(f"s_add_u32 s{self.TAB}, s{self.TAB}, 32")
         self.salu(f"s_addc_u32 s{self.TAB + 1}, s{self.TAB + 1}, 0")
+
+    def request_descriptor(self):
+        """the next step's descriptor (one scalar load; waited for in the middle of the body)"""
         self.mem(f"s_load_dwordx8 s[{self.FLY}:{self.FLY + 7}], s[{self.TAB}:{self.TAB + 1}], 0x0")
+
+    def next_pc(self):
+        """code address of the next step's body (this step's flags, bits 4..6) into PC; the jump itself comes last"""
+        t = self.TMP[0]
+        self.salu(f"s_bfe_u32 m0, {self.cur(self.FLAGS)}, 0x30004")
+        self.salu("s_nop 0")
+        self.salu(f"s_movrels_b32 s{t}, s{self.OFFTAB}")
+        self.salu(f"s_add_u32 s{self.PC}, s{self.BASE}, s{t}")
+        self.salu(f"s_addc_u32 s{self.PC + 1}, s{self.BASE + 1}, 0")
+
+    def go_first(self):
+        """from the loop prologue into the first step: its descriptor is FLY (the body hands it over), its
+        stored operands are requested here from that descriptor's own cell offsets"""
+        ad = self.AD
+        t = self.TMP
+        self.wait(lgkm=0)
+        self.salu(f"s_and_b32 s{t[2]}, {self.fly(self.OFFC01)}, 0xffff")
+        self.salu(f"s_lshr_b32 s{t[3]}, {self.fly(self.OFFC01)}, 16")
+        self.v32(f"v_add_u32 v{ad[0]}, s{t[2]}, %[arena]", [], [ad[0]])
+        self.v32(f"v_add_u32 v{ad[1]}, s{t[3]}, %[arena]", [], [ad[1]])
+        self.cell_read(self.M[0], ad[0])
+        self.cell_read(self.M[1], ad[1])
+        self.salu(f"s_and_b32 m0, {self.fly(self.FLAGS)}, 7")
+        self.salu("s_nop 0")
+        self.salu(f"s_movrels_b32 s{t[0]}, s{self.OFFTAB}")
+        self.salu(f"s_add_u32 s{self.PC}, s{self.BASE}, s{t[0]}")
+        self.salu(f"s_addc_u32 s{self.PC + 1}, s{self.BASE + 1}, 0")
+        self.wait(lgkm=0)
+        self.go()
+
+    def go(self):
+        self.e.control(f"s_setpc_b64 s[{self.PC}:{self.PC + 1}]")
 
     def request_cells(self, predicate_slot1):
         """the next step's stored child messages into M[0], M[1] (a slot that is no stored cell has offset 0:
         what lands is ignored).  Slot 1 under EXEC predicate "read it" when the message may be handed over."""
         ad = self.AD
         t = self.TMP[2]
-        self.salu(f"s_and_b32 s{t}, {self.fly(self.OFFC01)}, 0xffff")
+        self.salu(f"s_and_b32 s{t}, {self.cur(self.NOFFC01)}, 0xffff")
         self.v32(f"v_add_u32 v{ad[0]}, s{t}, %[arena]", [], [ad[0]])
-        self.salu(f"s_lshr_b32 s{t}, {self.fly(self.OFFC01)}, 16")
+        self.salu(f"s_lshr_b32 s{t}, {self.cur(self.NOFFC01)}, 16")
         self.v32(f"v_add_u32 v{ad[1]}, s{t}, %[arena]", [], [ad[1]])
         n = self.cell_read(self.M[0], ad[0])
         if predicate_slot1:
@@ -422,12 +565,11 @@ class Loops:
         self.salu(f"s_movrels_b32 s{t}, s{self.OFFTAB}")
         self.salu(f"s_add_u32 s{self.PC}, s{self.BASE}, s{t}")
         self.salu(f"s_addc_u32 s{self.PC + 1}, s{self.BASE + 1}, 0")
-        self.e.drain()
-        self.e._raw(f"s_setpc_b64 s[{self.PC}:{self.PC + 1}]")
-        self.e.pos += 1
+        self.e.control(f"s_setpc_b64 s[{self.PC}:{self.PC + 1}]")
 
-    def loop_entry(self, names):
-        """common prologue: first descriptor, constants, the tile's tip masks, the table of body offsets"""
+    def loop_entry(self, names, exit_label=None):
+        """common prologue: first descriptor, constants, the tile's tip masks, the table of body offsets
+        (entry 5: the loop exit, the "body" of the entries behind a table's last step)"""
         G = self.G
         self.salu(f"s_mov_b64 s[{self.TAB}:{self.TAB + 1}], %[tab]")
         self.salu(f"s_mov_b32 s{self.CNT}, %[steps]")
@@ -444,10 +586,12 @@ class Loops:
             self.mem(f"ds_read_b32 v{self.TMV + t}, v{a}", mem_reads=[a], writes=[self.TMV + t])
             if t + 1 < self.MAX_TIPS:
                 self.v32(f"v_add_u32 v{a}, %[tipstride], v{a}", [a], [a])
-        self.salu(f"s_getpc_b64 s[{self.BASE}:{self.BASE + 1}]")
-        self.e._raw(f"{self.L('base')}:")
+        self.e.control(f"s_getpc_b64 s[{self.BASE}:{self.BASE + 1}]")
+        self.e.label(self.L('base'))
         for k, name in enumerate(names):
             self.salu(f"s_mov_b32 s{self.OFFTAB + k}, {self.L(name)}-{self.L('base')}")
+        if exit_label:
+            self.salu(f"s_mov_b32 s{self.OFFTAB + 5}, {self.L(exit_label)}-{self.L('base')}")
 
     # ---- child messages of one slot (both passes) ---------------------------------------------------
     def messages(self, kinds):
@@ -456,7 +600,7 @@ class Loops:
         the slots, F[4..7] tip ids A0 B0 A1 B1."""
         G = self.G
         f = self.F
-        t = self.TMP
+        t = [None, None] + self.TMPM
         for s in (0, 1):
             if kinds[s] == "T":
                 self.tip_operands(2 * s, f[4 + 2 * s])
@@ -517,33 +661,46 @@ class Loops:
         kinds = (K0, K1)
         own = self.UC[1]
         f = self.F
+        t = self.TMP
         self.label(self.L(name))
         self.e.comment(f"post-order step, children ({K0},{K1})")
-        self.rotate_and_request()
+        self.rotate()
         self.unpack(kinds, post=True)
+        self.salu(f"s_sub_u32 s{self.CNT}, s{self.CNT}, 1")
+        self.next_pc()
+        # scalar halves of the addresses used below: next step's two cells, this node's own cell
+        self.salu(f"s_and_b32 s{t[2]}, {self.cur(self.NOFFC01)}, 0xffff")
+        self.salu(f"s_lshr_b32 s{t[3]}, {self.cur(self.NOFFC01)}, 16")
+        self.salu(f"s_and_b32 s{t[4]}, {self.cur(self.OWNS)}, 0xffff")
         self.messages(kinds)
+        self.request_descriptor()
         # x = m0 . m1 (the node's partial); the root's leaves the loop in X[0]
         m0, m1 = self.msg(0, K0), self.msg(1, K1)
         for g in range(G):
             self.vmul(self.X[0][g], m0[g], m1[g])
-        self.salu(f"s_cmp_eq_u32 s{self.CNT}, 1")
+        ad = self.AD
+        self.v32(f"v_add_u32 v{ad[0]}, s{t[2]}, %[arena]", [], [ad[0]])
+        self.v32(f"v_add_u32 v{ad[1]}, s{t[3]}, %[arena]", [], [ad[1]])
+        self.v32(f"v_add_u32 v{ad[6]}, s{t[4]}, %[arena]", [], [ad[6]])
+        self.salu(f"s_cmp_eq_u32 s{self.CNT}, 0")
         self.branch("scc1", self.L("root"))
-        # own message a = P_v x
+        # own message a = P_v x, the next step's operands requested underneath
         self.idx_on(f[2], "SRC0")
         for g in range(G):
             self.mfma(own[g], ("A", 0), self.X[0][g])
+        self.cell_read(self.M[0], ad[0])
+        self.predicate(self.BIT_READ1)
+        self.cell_read(self.M[1], ad[1])
+        self.unpredicate()
         self.idx_off()
-        self.wait(lgkm=0)  # the next step's descriptor (and long-issued stores)
-        self.request_cells(predicate_slot1=True)
-        self.v32(f"v_add_u32 v{self.AD[6]}, {self.cur(self.OWN)}, %[arena]", [], [self.AD[6]])
-        nst = self.cell_write(own, self.AD[6])
+        nst = self.cell_write(own, ad[6])
         # the message is the next step's slot-1 operand when that step's node is this node's parent
         self.predicate(self.BIT_FORWARD)
         for g in range(G):
             self.vmov64(self.M[1][g], own[g])
         self.unpredicate()
-        self.wait(lgkm=nst)  # the requests have landed; the stores may still travel
-        self.dispatch(self.L("root"))
+        self.wait(lgkm=0)  # the requests and the next descriptor have landed (the stores too: scalar loads and LDS share a counter)
+        self.go()
 
     def post_loop(self):
         self.e = Emitter()
@@ -553,10 +710,7 @@ class Loops:
         e.comment(f"post-order loop, G = {G}")
         names = [v[0] for v in self.VARIANTS]
         self.loop_entry(names)
-        self.wait(lgkm=0)
-        self.request_cells(predicate_slot1=False)
-        self.wait(lgkm=0)
-        self.jump()
+        self.go_first()
         for name, K0, K1 in self.VARIANTS:
             self.post_body(name, K0, K1)
         self.label(self.L("root"))
@@ -570,19 +724,39 @@ class Loops:
         G = self.G
         kinds = (K0, K1)
         f = self.F
+        t = self.TMP
+        ad = self.AD
         self.label(self.L(name))
         self.e.comment(f"pre-order step, children ({K0},{K1})")
-        self.rotate_and_request()
-        # the previous step's two edge sums, level 1; the scalar unpacking sits behind the matrix instructions
+        # the previous step's two edge sums, level 1; the scalar work of the step (descriptor hand-over,
+        # unpacking, scalar halves of every address, the next body's code address) sinks behind these and
+        # the next matrix instructions
         self.flush_stage1(self.ES[0], self.ES[1])
+        self.rotate()
         self.unpack(kinds, post=False)
-        self.messages(kinds)
-        # Q m of both children
+        self.next_pc()
+        self.salu(f"s_and_b32 s{t[1]}, {self.cur(self.OFFC01)}, 0xffff")   # this step's stores
+        self.salu(f"s_lshr_b32 s{t[2]}, {self.cur(self.OFFC01)}, 16")
+        self.salu(f"s_and_b32 s{t[3]}, {self.cur(self.NOFFC01)}, 0xffff")  # the next step's operands
+        self.salu(f"s_lshr_b32 s{t[4]}, {self.cur(self.NOFFC01)}, 16")
+        self.salu(f"s_lshr_b32 s{t[5]}, {self.cur(self.OWNS)}, 16")        # ... and its node's own cell
+        # Q m of the stored children: their messages are in registers already
         for s in (0, 1):
-            for g in range(G):
-                self.mfma(self.DQ[s][g], "Q", self.msg(s, kinds[s])[g])
-        self.flush_stage2(f"s{self.EPREV}")
-        self.salu(f"s_mov_b32 s{self.EPREV}, {self.cur(self.EDGE01)}")
+            if kinds[s] == "C":
+                for g in range(G):
+                    self.mfma(self.DQ[s][g], "Q", self.M[s][g])
+        self.request_descriptor()
+        self.messages(kinds)
+        for s in (0, 1):
+            if kinds[s] != "C":
+                for g in range(G):
+                    self.mfma(self.DQ[s][g], "Q", self.MSG[s][g])
+        self.flush_stage2(self.EPREV[0], self.EPREV[1])
+        # gradient-row offsets of this step's two edges (8 x child id = 2 x its image index), for the next body
+        self.salu(f"s_and_b32 s{self.EPREV[0]}, {self.cur(self.IMG)}, 0xff")
+        self.salu(f"s_lshl_b32 s{self.EPREV[0]}, s{self.EPREV[0]}, 1")
+        self.salu(f"s_bfe_u32 s{self.EPREV[1]}, {self.cur(self.IMG)}, 0x80008")
+        self.salu(f"s_lshl_b32 s{self.EPREV[1]}, s{self.EPREV[1]}, 1")
         self.wait(lgkm=0)  # U when it came out of LDS; the next step's descriptor
         nst = self.flush_stage3()
         # w_s = U . (message of the other child)
@@ -590,14 +764,13 @@ class Loops:
         for g in range(G):
             self.vmul(self.W[0][g], self.U[g], m1[g])
             self.vmul(self.W[1][g], self.U[g], m0[g])
-        # addresses of the next step's operands (VALU before the matrix block, the reads inside it)
-        ad = self.AD
-        t = self.TMP[2]
-        self.salu(f"s_and_b32 s{t}, {self.fly(self.OFFC01)}, 0xffff")
-        self.v32(f"v_add_u32 v{ad[0]}, s{t}, %[arena]", [], [ad[0]])
-        self.salu(f"s_lshr_b32 s{t}, {self.fly(self.OFFC01)}, 16")
-        self.v32(f"v_add_u32 v{ad[1]}, s{t}, %[arena]", [], [ad[1]])
-        self.v32(f"v_add_u32 v{ad[2]}, {self.fly(self.OWN)}, %[arena]", [], [ad[2]])
+        self.v32(f"v_add_u32 v{ad[0]}, s{t[3]}, %[arena]", [], [ad[0]])
+        self.v32(f"v_add_u32 v{ad[1]}, s{t[4]}, %[arena]", [], [ad[1]])
+        self.v32(f"v_add_u32 v{ad[2]}, s{t[5]}, %[arena]", [], [ad[2]])
+        if K0 == "C":
+            self.v32(f"v_add_u32 v{ad[3]}, s{t[1]}, %[arena]", [], [ad[3]])
+        if K1 == "C":
+            self.v32(f"v_add_u32 v{ad[4]}, s{t[2]}, %[arena]", [], [ad[4]])
         # P^T w: the children's pre-order partials, with the next step's reads issued underneath
         # (the registers they land in -- M[0], M[1], U -- have had their last use)
         first = True
@@ -627,7 +800,7 @@ class Loops:
                     self.vmul(self.ES[s], self.W[s][g], self.DQ[s][g])
                 else:
                     self.vfma(self.ES[s], self.W[s][g], self.DQ[s][g], self.ES[s])
-        # cherry children: the two tip edges under each
+        # cherry children: the two tip edges under each (gradient rows 8 x tip id)
         nst = 0
         for s in (0, 1):
             if kinds[s] != "H":
@@ -635,6 +808,8 @@ class Loops:
             DQA, DQB, TA, TB = self.MSG[s], self.UC[0], self.W[s], self.DQ[s]
             for g in range(G):
                 self.mfma(DQA[g], "Q", self.MA[s][g])
+            self.salu(f"s_lshl_b32 s{t[0]}, s{f[4 + 2 * s]}, 3")
+            self.salu(f"s_lshl_b32 s{t[1]}, s{f[5 + 2 * s]}, 3")
             for g in range(G):
                 self.mfma(DQB[g], "Q", self.MB[s][g])
             for g in range(G):
@@ -648,24 +823,20 @@ class Loops:
                     self.vfma(self.EA, TA[g], DQA[g], self.EA)
                     self.vfma(self.EB, TB[g], DQB[g], self.EB)
             self.flush_stage1(self.EA, self.EB)
-            self.flush_stage2(self.cur(self.EDGEAB0 + s))
+            self.flush_stage2(t[0], t[1])
             nst += self.flush_stage3()
         # this step's stores
         if K0 == "C":
-            self.salu(f"s_and_b32 s{self.TMP[3]}, {self.cur(self.OFFC01)}, 0xffff")
-            self.v32(f"v_add_u32 v{self.AD[3]}, s{self.TMP[3]}, %[arena]", [], [self.AD[3]])
-            nst += self.cell_write(self.UC[0], self.AD[3])
+            nst += self.cell_write(self.UC[0], ad[3])
         if K1 == "C":
-            self.salu(f"s_lshr_b32 s{self.TMP[3]}, {self.cur(self.OFFC01)}, 16")
-            self.v32(f"v_add_u32 v{self.AD[4]}, s{self.TMP[3]}, %[arena]", [], [self.AD[4]])
-            nst += self.cell_write(self.UC[1], self.AD[4])
+            nst += self.cell_write(self.UC[1], ad[4])
             # slot 1's partial is the next step's U when that step's node is this child
             self.predicate(self.BIT_FORWARD)
             for g in range(G):
                 self.vmov64(self.U[g], self.UC[1][g])
             self.unpredicate()
         self.wait(lgkm=nst)  # everything requested has landed; the stores may still travel
-        self.dispatch(self.L("done"))
+        self.go()
 
     def pre_loop(self):
         self.e = Emitter()
@@ -674,25 +845,23 @@ class Loops:
         e = self.e
         e.comment(f"pre-order loop, G = {G}")
         names = [v[0] for v in self.VARIANTS]
-        self.loop_entry(names)
+        self.loop_entry(names, exit_label="done")
         self.e.ins(f"v_mov_b64 {vp(self.ONE)}, 1.0", "valu", writes=[self.ONE, self.ONE + 1])
         for s in (0, 1):
             self.e.ins(f"v_mov_b64 {vp(self.ES[s])}, 0", "valu", writes=[self.ES[s], self.ES[s] + 1])
         for g in range(G):
             self.e.ins(f"v_mov_b64 {vp(self.U[g])}, %[u{g}]", "valu", writes=[self.U[g], self.U[g] + 1])
-        self.salu(f"s_mov_b32 s{self.EPREV}, %[rootedge]")
+        self.salu(f"s_mov_b32 s{self.EPREV[0]}, %[rootedge]")
+        self.salu(f"s_mov_b32 s{self.EPREV[1]}, %[rootedge]")
         self.salu(f"s_mov_b32 s{self.WMASK}, 0x1111")
         self.salu(f"s_mov_b32 s{self.WMASK + 1}, 0")
-        self.wait(lgkm=0)
-        self.request_cells(predicate_slot1=False)
-        self.wait(lgkm=0)
-        self.jump()
+        self.go_first()
         for name, K0, K1 in self.VARIANTS:
             self.pre_body(name, K0, K1)
         self.label(self.L("done"))
         # the last step's two edges
         self.flush_stage1(self.ES[0], self.ES[1])
-        self.flush_stage2(f"s{self.EPREV}")
+        self.flush_stage2(self.EPREV[0], self.EPREV[1])
         self.flush_stage3()
         self.wait(vm=0, lgkm=0)
         return e
@@ -710,13 +879,12 @@ class Loops:
         for b in range(self.MAX_BRANCHES):
             if b % 4 == 0:
                 self.salu(f"s_cmp_le_u32 %[nb], {b}")
-                self.e._raw(f"s_cbranch_scc1 {done}")
-                self.e.pos += 1
+                self.e.control(f"s_cbranch_scc1 {done}")
             self.mem(f"global_load_dwordx4 a[{4 * b}:{4 * b + 3}], %[lane16], s[{ip}:{ip + 1}] offset:{(b % 4) * 1024}")
             if b % 4 == 3:
                 self.salu(f"s_add_u32 s{ip}, s{ip}, 4096")
                 self.salu(f"s_addc_u32 s{ip + 1}, s{ip + 1}, 0")
-        self.e._raw(f"{done}:")
+        self.e.label(done)
         self.wait(vm=0)
         return e
 
@@ -749,13 +917,13 @@ def main():
         loops = Loops(G)
         post = loops.post_loop()
         pre = loops.pre_loop()
-        out.append(as_macro(f"WALK_PIPE_POST_ASM_G{G}", post.lines))
-        out.append(as_macro(f"WALK_PIPE_PRE_ASM_G{G}", pre.lines))
+        out.append(as_macro(f"WALK_PIPE_POST_ASM_G{G}", post.finish()))
+        out.append(as_macro(f"WALK_PIPE_PRE_ASM_G{G}", pre.finish()))
         out.append(f"#define WALK_PIPE_CLOBBERS_G{G} {clobbers(loops)}")
         listing.append(f"G={G}: VGPR v{VBASE}..v{loops.vnext - 1}, AGPR a0..a{4 * Loops.MAX_BRANCHES - 1}, SGPR s{SBASE}..s{loops.snext - 1}; "
                        f"post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
     loops = Loops(1)
-    out.append(as_macro("WALK_PIPE_LOAD_ASM", loops.load_images().lines))
+    out.append(as_macro("WALK_PIPE_LOAD_ASM", loops.load_images().finish()))
     out.append(f"#define WALK_PIPE_MAX_BRANCHES {Loops.MAX_BRANCHES}")
     out.append(f"#define WALK_PIPE_MAX_TIPS {Loops.MAX_TIPS}")
     out.append("// " + "\n// ".join(listing))
@@ -768,7 +936,7 @@ def main():
         want = sys.argv[1]
         loops = Loops(int(want[-1]))
         e = loops.post_loop() if want.startswith("post") else (loops.pre_loop() if want.startswith("pre") else loops.load_images())
-        sys.stderr.write("\n".join(e.lines) + "\n")
+        sys.stderr.write("\n".join(e.finish()) + "\n")
 
 
 if __name__ == "__main__":
