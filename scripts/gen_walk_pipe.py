@@ -325,7 +325,7 @@ class Loops:
         self.WMASK = S.get(2, "WMASK", 2)
         self.BASE = S.get(2, "BASE", 2)   # code address the body offsets are relative to
         self.PC = S.get(2, "PC", 2)
-        self.OFFTAB = S.get(6, "OFFTAB")  # code offsets of the five bodies and of the loop exit
+        self.OFFTAB = S.get(11, "OFFTAB")  # code offsets of the bodies (5 + 5 hand-over forms) and of the loop exit
         self.F = [S.get(1, f"F{k}") for k in range(8)]  # unpacked fields of the current step
         self.TMP = [S.get(1, f"TMP{k}") for k in range(6)]
         self.TMPM = [S.get(1, f"TMPM{k}") for k in range(2)]  # scratch of messages() only
@@ -505,7 +505,7 @@ class Loops:
     def next_pc(self):
         """code address of the next step's body (this step's flags, bits 4..6) into PC; the jump itself comes last"""
         t = self.TMP[0]
-        self.salu(f"s_bfe_u32 m0, {self.cur(self.FLAGS)}, 0x30004")
+        self.salu(f"s_bfe_u32 m0, {self.cur(self.FLAGS)}, 0x40004")
         self.salu("s_nop 0")
         self.salu(f"s_movrels_b32 s{t}, s{self.OFFTAB}")
         self.salu(f"s_add_u32 s{self.PC}, s{self.BASE}, s{t}")
@@ -523,7 +523,7 @@ class Loops:
         self.v32(f"v_add_u32 v{ad[1]}, s{t[3]}, %[arena]", [], [ad[1]])
         self.cell_read(self.M[0], ad[0])
         self.cell_read(self.M[1], ad[1])
-        self.salu(f"s_and_b32 m0, {self.fly(self.FLAGS)}, 7")
+        self.salu(f"s_and_b32 m0, {self.fly(self.FLAGS)}, 15")
         self.salu("s_nop 0")
         self.salu(f"s_movrels_b32 s{t[0]}, s{self.OFFTAB}")
         self.salu(f"s_add_u32 s{self.PC}, s{self.BASE}, s{t[0]}")
@@ -569,7 +569,7 @@ class Loops:
 
     def loop_entry(self, names, exit_label=None):
         """common prologue: first descriptor, constants, the tile's tip masks, the table of body offsets
-        (entry 5: the loop exit, the "body" of the entries behind a table's last step)"""
+        (entry 10: the loop exit, the "body" behind a table's last step)"""
         G = self.G
         self.salu(f"s_mov_b64 s[{self.TAB}:{self.TAB + 1}], %[tab]")
         self.salu(f"s_mov_b32 s{self.CNT}, %[steps]")
@@ -591,7 +591,7 @@ class Loops:
         for k, name in enumerate(names):
             self.salu(f"s_mov_b32 s{self.OFFTAB + k}, {self.L(name)}-{self.L('base')}")
         if exit_label:
-            self.salu(f"s_mov_b32 s{self.OFFTAB + 5}, {self.L(exit_label)}-{self.L('base')}")
+            self.salu(f"s_mov_b32 s{self.OFFTAB + 10}, {self.L(exit_label)}-{self.L('base')}")
 
     # ---- child messages of one slot (both passes) ---------------------------------------------------
     def messages(self, kinds):
@@ -654,16 +654,20 @@ class Loops:
             self.salu(f"s_lshr_b32 s{f[7]}, {self.cur(self.TIPS)}, 24")
 
     # =============================== post-order loop ===============================================
-    VARIANTS = [("cc", "C", "C"), ("tc", "T", "C"), ("hc", "H", "C"), ("th", "T", "H"), ("hh", "H", "H")]
+    # body index = position here; the second five hand a vector to the NEXT step in registers (post-order:
+    # this node's message is that step's slot-1 operand; pre-order: slot 1's partial is that step's U)
+    KINDS = [("cc", "C", "C"), ("tc", "T", "C"), ("hc", "H", "C"), ("th", "T", "H"), ("hh", "H", "H")]
+    POST_VARIANTS = [(n, a, b, False) for n, a, b in KINDS] + [(n + "f", a, b, True) for n, a, b in KINDS]
+    PRE_VARIANTS = [(n, a, b, False) for n, a, b in KINDS] + [(n + "f", a, b, True) for n, a, b in KINDS if b == "C"]
 
-    def post_body(self, name, K0, K1):
+    def post_body(self, name, K0, K1, hand_over):
         G = self.G
         kinds = (K0, K1)
-        own = self.UC[1]
+        own = self.M[1] if hand_over else self.UC[1]
         f = self.F
         t = self.TMP
         self.label(self.L(name))
-        self.e.comment(f"post-order step, children ({K0},{K1})")
+        self.e.comment(f"post-order step, children ({K0},{K1})" + (", message handed to the next step" if hand_over else ""))
         self.rotate()
         self.unpack(kinds, post=True)
         self.salu(f"s_sub_u32 s{self.CNT}, s{self.CNT}, 1")
@@ -680,26 +684,22 @@ class Loops:
             self.vmul(self.X[0][g], m0[g], m1[g])
         ad = self.AD
         self.v32(f"v_add_u32 v{ad[0]}, s{t[2]}, %[arena]", [], [ad[0]])
-        self.v32(f"v_add_u32 v{ad[1]}, s{t[3]}, %[arena]", [], [ad[1]])
+        if not hand_over:
+            self.v32(f"v_add_u32 v{ad[1]}, s{t[3]}, %[arena]", [], [ad[1]])
         self.v32(f"v_add_u32 v{ad[6]}, s{t[4]}, %[arena]", [], [ad[6]])
         self.salu(f"s_cmp_eq_u32 s{self.CNT}, 0")
         self.branch("scc1", self.L("root"))
-        # own message a = P_v x, the next step's operands requested underneath
+        # own message a = P_v x (straight into the next step's slot-1 registers when it is handed over), the
+        # next step's stored operands requested underneath
         self.idx_on(f[2], "SRC0")
         for g in range(G):
             self.mfma(own[g], ("A", 0), self.X[0][g])
         self.cell_read(self.M[0], ad[0])
-        self.predicate(self.BIT_READ1)
-        self.cell_read(self.M[1], ad[1])
-        self.unpredicate()
+        if not hand_over:
+            self.cell_read(self.M[1], ad[1])
         self.idx_off()
-        nst = self.cell_write(own, ad[6])
-        # the message is the next step's slot-1 operand when that step's node is this node's parent
-        self.predicate(self.BIT_FORWARD)
-        for g in range(G):
-            self.vmov64(self.M[1][g], own[g])
-        self.unpredicate()
-        self.wait(lgkm=0)  # the requests and the next descriptor have landed (the stores too: scalar loads and LDS share a counter)
+        self.cell_write(own, ad[6])
+        self.wait(lgkm=0)  # requests, next descriptor (and the stores: scalar loads and LDS share the counter)
         self.go()
 
     def post_loop(self):
@@ -708,11 +708,11 @@ class Loops:
         G = self.G
         e = self.e
         e.comment(f"post-order loop, G = {G}")
-        names = [v[0] for v in self.VARIANTS]
+        names = [v[0] for v in self.POST_VARIANTS]
         self.loop_entry(names)
         self.go_first()
-        for name, K0, K1 in self.VARIANTS:
-            self.post_body(name, K0, K1)
+        for name, K0, K1, hand_over in self.POST_VARIANTS:
+            self.post_body(name, K0, K1, hand_over)
         self.label(self.L("root"))
         self.wait(vm=0, lgkm=0)
         for g in range(G):
@@ -720,14 +720,14 @@ class Loops:
         return e
 
     # =============================== pre-order loop ================================================
-    def pre_body(self, name, K0, K1):
+    def pre_body(self, name, K0, K1, hand_over):
         G = self.G
         kinds = (K0, K1)
         f = self.F
         t = self.TMP
         ad = self.AD
         self.label(self.L(name))
-        self.e.comment(f"pre-order step, children ({K0},{K1})")
+        self.e.comment(f"pre-order step, children ({K0},{K1})" + (", slot 1's partial handed to the next step" if hand_over else ""))
         # the previous step's two edge sums, level 1; the scalar work of the step (descriptor hand-over,
         # unpacking, scalar halves of every address, the next body's code address) sinks behind these and
         # the next matrix instructions
@@ -766,7 +766,8 @@ class Loops:
             self.vmul(self.W[1][g], self.U[g], m0[g])
         self.v32(f"v_add_u32 v{ad[0]}, s{t[3]}, %[arena]", [], [ad[0]])
         self.v32(f"v_add_u32 v{ad[1]}, s{t[4]}, %[arena]", [], [ad[1]])
-        self.v32(f"v_add_u32 v{ad[2]}, s{t[5]}, %[arena]", [], [ad[2]])
+        if not hand_over:
+            self.v32(f"v_add_u32 v{ad[2]}, s{t[5]}, %[arena]", [], [ad[2]])
         if K0 == "C":
             self.v32(f"v_add_u32 v{ad[3]}, s{t[1]}, %[arena]", [], [ad[3]])
         if K1 == "C":
@@ -779,6 +780,8 @@ class Loops:
             if kinds[s] == "T":
                 continue
             dst = self.UC[s] if kinds[s] == "C" else self.X[s]
+            if s == 1 and hand_over:
+                dst = self.U  # (every use of this step's U has been issued)
             if first:
                 self.idx_on(f[s], "SRC0")
             else:
@@ -788,9 +791,8 @@ class Loops:
             if first:
                 nreq += self.cell_read(self.M[0], ad[0])
                 nreq += self.cell_read(self.M[1], ad[1])
-                self.predicate(self.BIT_READU)
-                nreq += self.cell_read(self.U, ad[2])
-                self.unpredicate()
+                if not hand_over:
+                    nreq += self.cell_read(self.U, ad[2])
             first = False
         self.idx_off()
         # edge sums of this step's two child edges (flushed by the next body)
@@ -829,12 +831,7 @@ class Loops:
         if K0 == "C":
             nst += self.cell_write(self.UC[0], ad[3])
         if K1 == "C":
-            nst += self.cell_write(self.UC[1], ad[4])
-            # slot 1's partial is the next step's U when that step's node is this child
-            self.predicate(self.BIT_FORWARD)
-            for g in range(G):
-                self.vmov64(self.U[g], self.UC[1][g])
-            self.unpredicate()
+            nst += self.cell_write(self.U if hand_over else self.UC[1], ad[4])
         self.wait(lgkm=nst)  # everything requested has landed; the stores may still travel
         self.go()
 
@@ -844,8 +841,8 @@ class Loops:
         G = self.G
         e = self.e
         e.comment(f"pre-order loop, G = {G}")
-        names = [v[0] for v in self.VARIANTS]
-        self.loop_entry(names, exit_label="done")
+        names = [v[0] for v in self.PRE_VARIANTS] + ["unused", "unused"]
+        self.loop_entry(names[:10], exit_label="done")
         self.e.ins(f"v_mov_b64 {vp(self.ONE)}, 1.0", "valu", writes=[self.ONE, self.ONE + 1])
         for s in (0, 1):
             self.e.ins(f"v_mov_b64 {vp(self.ES[s])}, 0", "valu", writes=[self.ES[s], self.ES[s] + 1])
@@ -856,8 +853,9 @@ class Loops:
         self.salu(f"s_mov_b32 s{self.WMASK}, 0x1111")
         self.salu(f"s_mov_b32 s{self.WMASK + 1}, 0")
         self.go_first()
-        for name, K0, K1 in self.VARIANTS:
-            self.pre_body(name, K0, K1)
+        self.label(self.L("unused"))
+        for name, K0, K1, hand_over in self.PRE_VARIANTS:
+            self.pre_body(name, K0, K1, hand_over)
         self.label(self.L("done"))
         # the last step's two edges
         self.flush_stage1(self.ES[0], self.ES[1])
