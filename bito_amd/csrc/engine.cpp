@@ -414,7 +414,11 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     case BITO_AMD_KERNEL_LDS_TREE:
       if (!use_tree) return Fail(e, BITO_AMD_ERR_STATE, "the LDS tree kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, and a tree whose images + PLVs fit in 160 KB of LDS)");
       break;
-    default: break;
+    default:
+      // AUTO: the hand-scheduled LDS walk where it applies (up to 29 taxa: every branch's images in the AGPR
+      // file), measured 1.44 ms against walk_lds_kernel's 2.00 ms per 1600 config-3 trees
+      use_pipe = pplan.groups > 0 && !rescaling;
+      break;
   }
   // Measured on config 3 (profiles/): walk_lds_kernel 2.1 ms, walk_tree_kernel 3.8 ms per 1600
   // trees -- the single-wave software pipeline beats two latency-bound waves per SIMD, so the

@@ -1,5 +1,6 @@
 """Randomised parity sweep on the GPU box: random tree shapes, sizes, pattern counts, models, category counts,
-kernels, rescaling, rooted/unrooted, against the CPU checker.  usage: python scripts/gpu_fuzz.py [cases] [seed]"""
+kernels, rescaling, rooted/unrooted, against the CPU checker.
+usage: python scripts/gpu_fuzz.py [cases] [seed] [kernel forced in every case, e.g. 5 = walk_pipe_kernel]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -11,6 +12,9 @@ from oracle import gs
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+forced_kernel = int(sys.argv[3]) if len(sys.argv) > 3 else None
+FORCED = (_capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE, _capi.KERNEL_LDS_PIPE)
+skipped = 0
 rng = np.random.default_rng(seed)
 bad = 0
 t0 = time.time()
@@ -24,7 +28,10 @@ for case in range(cases):
     if codon:  # the 61-state checker is a scalar port: keep these small
         n, P, T = min(n, 16), min(P, 65), min(T, 7)
         site = str(rng.choice(["constant", "weibull+2"]))
-    kernel = int(rng.choice([_capi.KERNEL_AUTO, _capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE]))
+    kernel = int(rng.choice([_capi.KERNEL_AUTO, _capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE,
+                             _capi.KERNEL_LDS_PIPE]))
+    if forced_kernel is not None:
+        kernel = forced_kernel
     rooted = bool(rng.integers(0, 2)) or n == 3 and False
     rescaling = bool(rng.integers(0, 2))
     gap_rate = float(rng.choice([0.0, 0.05, 0.5]))
@@ -70,7 +77,8 @@ for case in range(cases):
         try:
             out = gpu.gradients(pid, bl, params, rescaling=rescaling)
         except bito_amd.BitoAmdError as e:
-            if kernel in (_capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE):
+            if kernel in FORCED:
+                skipped += 1
                 continue  # a forced kernel that does not take this shape says so
             raise
         ref = cpu.gradients(pid, bl, params, rescaling=rescaling)
@@ -98,4 +106,4 @@ for case in range(cases):
     except Exception as e:  # noqa: BLE001
         bad += 1
         print("ERROR", desc, repr(e)[:300])
-print(f"{cases} cases, {bad} bad, {time.time() - t0:.0f} s")
+print(f"{cases} cases, {bad} bad, {skipped} declined by a forced kernel, {time.time() - t0:.0f} s")

@@ -146,11 +146,11 @@ def test_config3_ds1_gtr_weibull4_vs_oracle():
     assert grad_close(res["branch_lengths"], out["branch_lengths"])
 
 
-@pytest.mark.parametrize("kernel", [_capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE])
+@pytest.mark.parametrize("kernel", [_capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE, _capi.KERNEL_LDS_PIPE])
 @pytest.mark.parametrize("model", [("JC69", "constant"), ("HKY", "weibull+2"), ("GTR", "weibull+4")])
 def test_every_traversal_kernel_matches_oracle(kernel, model):
-    """The three traversal kernels (HBM arena, LDS one wave/SIMD, LDS tree-resident images)
-    are interchangeable: same inputs, same answers, for 1, 2 and 4 rate categories."""
+    """The four traversal kernels (HBM arena, LDS one wave/SIMD, LDS tree-resident images, LDS with
+    hand-scheduled loops) are interchangeable: same inputs, same answers, for 1, 2 and 4 rate categories."""
     sub, site = model
     w = workloads.ds1_gtr_weibull4(1).subset(12)
     gpu, cpu = engines(sub, site, "none", w.patterns, w.weights, 4)
@@ -167,7 +167,7 @@ def test_every_traversal_kernel_matches_oracle(kernel, model):
     assert grad_close(out["branch_lengths"], ref["branch_lengths"])
     assert ll_close(gpu.log_likelihoods(w.parent_ids, w.branch_lengths, params), ref["log_likelihood"])
     expect = {_capi.KERNEL_HBM_ARENA: "walk_hbm_kernel", _capi.KERNEL_LDS: "walk_lds_kernel",
-              _capi.KERNEL_LDS_TREE: "walk_tree_kernel"}[kernel]
+              _capi.KERNEL_LDS_TREE: "walk_tree_kernel", _capi.KERNEL_LDS_PIPE: "walk_pipe_kernel"}[kernel]
     assert gpu.kernel_name() == expect
 
 
@@ -482,8 +482,8 @@ def _random_rooted_parent_ids(n, rng):
     return np.array([parents[v] for v in range(2 * n - 2)], dtype=np.int32)
 
 
-@pytest.mark.parametrize("kernel", [_capi.KERNEL_LDS, _capi.KERNEL_HBM_ARENA])
-@pytest.mark.parametrize("n", [3, 4, 5, 7, 12, 33])
+@pytest.mark.parametrize("kernel", [_capi.KERNEL_LDS, _capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS_PIPE])
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 12, 29, 33])
 def test_random_shapes_rooted_and_unrooted(kernel, n):
     """Random topologies of many shapes -- caterpillars to balanced trees, cherries as first or second
     child, roots over a tip -- with gaps in the alignment, rooted and unrooted, 1, 2 and 4 categories:
@@ -509,6 +509,10 @@ def test_random_shapes_rooted_and_unrooted(kernel, n):
             params[:, 4:10] = rng.dirichlet([3] * 6, T)
             if C > 1:
                 params[:, 10] = rng.uniform(0.3, 2.0, T)
+            if kernel == _capi.KERNEL_LDS_PIPE and n > 29:  # its images live in the AGPR file: up to 29 taxa
+                with pytest.raises(bito_amd.BitoAmdError, match="pipelined LDS kernel was forced"):
+                    gpu.gradients(pid, bl, params)
+                continue
             out = gpu.gradients(pid, bl, params)
             ref = cpu.gradients(pid, bl, params)
             assert ll_close(out["log_likelihood"], ref["log_likelihood"]), (site, rooted)
@@ -526,28 +530,33 @@ def test_site_model_gradient_fused_equals_second_pass():
     params[:, 10] = np.linspace(0.3, 1.9, 9)
     flags = _capi.GRAD_SITE_MODEL
     fused = gpu.gradients(w.parent_ids, w.branch_lengths, params, flags=flags)
+    assert gpu.kernel_name() == "walk_pipe_kernel"
+    gpu.set_kernel(_capi.KERNEL_LDS)
+    fused_lds = gpu.gradients(w.parent_ids, w.branch_lengths, params, flags=flags)
     assert gpu.kernel_name() == "walk_lds_kernel"
     gpu.set_kernel(_capi.KERNEL_HBM_ARENA)
     twice = gpu.gradients(w.parent_ids, w.branch_lengths, params, flags=flags)
     assert gpu.kernel_name() == "walk_hbm_kernel"
     ref = cpu.gradients(w.parent_ids, w.branch_lengths, params, flags=oracle.GRAD_SITE_MODEL)
     assert grad_close(fused["site_model"], ref["site_model"])
+    assert grad_close(fused_lds["site_model"], ref["site_model"])
     assert grad_close(twice["site_model"], ref["site_model"])
     assert grad_close(fused["branch_lengths"], ref["branch_lengths"])
 
 
+@pytest.mark.parametrize("kernel", [_capi.KERNEL_LDS, _capi.KERNEL_LDS_PIPE])
 @pytest.mark.parametrize("run", [1, 3, 5, 15])
-def test_tile_runs_of_the_lds_walk(run, monkeypatch):
+def test_tile_runs_of_the_lds_walk(run, kernel, monkeypatch):
     """A workgroup of the LDS walk takes a run of consecutive pattern tiles of its tree (the launcher picks the
     run length from the batch size; here it is forced): same results whatever the run length, against the
     oracle, with and without the fused site-model gradient."""
     monkeypatch.setenv("BITO_AMD_LDS_TILE_RUN", str(run))
     w = workloads.ds1_gtr_weibull4(1).subset(12)
     gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
-    gpu.set_kernel(_capi.KERNEL_LDS)
+    gpu.set_kernel(kernel)
     out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, flags=_capi.GRAD_SITE_MODEL)
     ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, flags=_capi.GRAD_SITE_MODEL)
-    assert gpu.kernel_name() == "walk_lds_kernel"
+    assert gpu.kernel_name() == ("walk_lds_kernel" if kernel == _capi.KERNEL_LDS else "walk_pipe_kernel")
     assert ll_close(out["log_likelihood"], ref["log_likelihood"])
     assert grad_close(out["branch_lengths"], ref["branch_lengths"])
     assert grad_close(out["site_model"], ref["site_model"])
