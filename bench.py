@@ -85,17 +85,16 @@ def cpu_baseline(w, seconds: float):
                       "(FP64 restatement of the BEAGLE CPU path; the reference binary cannot be built here)"}
 
 
-def arithmetic_view(n, P, C, want_gradient, trees_per_launch, avg_kernel_s):
-    """FP64 flops of the 4x4 matrix-vector products per launch against the FP64 MFMA rate measured
-    on this part (profiles/r1_microbench.json: v_mfma_f64_4x4x4_4b, 68 TFLOP/s)."""
-    matvecs = 2 * (n - 1) + (4 * (n - 1) if want_gradient else 0)  # post: 2 per internal node; walk: dP.x and PT.y per child
-    flops = matvecs * 32.0 * C * P * trees_per_launch
+def arithmetic_view(n, P, C, S, trees_per_launch, avg_kernel_s):
+    """Algorithmic FP64 flops per launch (every child message a full matrix-vector
+    product, tips included) against the guide's dense FP64 matrix peak; the rate v_mfma_f64_4x4x4_4b sustains
+    from one wave per SIMD on the box (68 TFLOP/s, profiles/r1_microbench.json) is given beside it."""
+    flops = algorithmic_flops_per_tree(n, P, C, S) * trees_per_launch
     achieved = flops / avg_kernel_s / 1e12
-    # priced against the guide's dense FP64 matrix peak; the rate this instruction sustains from one wave per
-    # SIMD on the box (68 TFLOP/s) is given beside it
     return {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "sustained_peak": FP64_MFMA_PEAK_TFLOPS,
-            "frac_of_sustained": achieved / FP64_MFMA_PEAK_TFLOPS}
+            "frac_of_sustained": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "algorithmic_flops_per_tree": algorithmic_flops_per_tree(n, P, C, S)}
 
 
 def measured_traffic(kernel: str, trees_per_launch: int):
@@ -278,7 +277,7 @@ def main():
                         f"fluA.tree topology x {T} trees per GPU with seeded branch lengths, GY94 (kappa, omega, F1x4), "
                         "log-likelihood + branch-length gradient")
         else:
-            arithmetic = arithmetic_view(n, P, C, w.want_gradient, trees_per_launch, avg_kernel_s)
+            arithmetic = arithmetic_view(n, P, C, S, trees_per_launch, avg_kernel_s)
             workload = ("BASELINE config 3: DS1.fasta (27 taxa, 934 patterns) x 100 topologies x "
                         f"{args.replicas} replicas per GPU, GTR+weibull4 (4 categories), seeded Exp(0.1) branch "
                         "lengths, log-likelihood + branch-length gradient")
@@ -308,24 +307,26 @@ def main():
                 if dist is not None else "single GPU, no collective",
                 **({"summed_log_likelihood": summed_ll} if reduce_ll else {}),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                # the PMC-measured bytes over the same launch time: what the kernel really asks of HBM
-                "actual_hbm_GBps": (traffic / avg_kernel_s / 1e9) if traffic else None,
-                "kernel": kernel,
-                "avg_kernel_ms": avg_kernel_s * 1e3,
-                "trees_per_launch": trees_per_launch,
-                "algorithmic_bytes_per_tree": algorithmic_bytes_per_tree(n, P, C, w.want_gradient, S),
-                # the fused kernels keep the partials on chip, so the op-by-op byte model above can exceed
-                # the HBM peak; the arithmetic view of the same launch is reported beside it
-                "arithmetic": arithmetic,
-            },
+            "roofline": None,
         }
+        hbm_view = {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            # the PMC-measured bytes over the same launch time: what the kernel really asks of HBM
+            "actual_hbm_GBps": (traffic / avg_kernel_s / 1e9) if traffic else None,
+            "algorithmic_bytes_per_tree": algorithmic_bytes_per_tree(n, P, C, w.want_gradient, S),
+        }
+        common = {"traffic": traffic, "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3,
+                  "trees_per_launch": trees_per_launch}
+        if kernel in ("walk_pipe_kernel", "walk_lds_kernel", "walk_tree_kernel"):
+            # These kernels keep every partial in LDS: HBM sees 0.3 % of the op-by-op byte model (`traffic`), so
+            # the resource that bounds them is the FP64 matrix / vector pipe.  The byte view is kept beside it.
+            out["roofline"] = {**arithmetic, **common, "hbm_view": hbm_view}
+        else:
+            out["roofline"] = {**hbm_view, **common, "arithmetic": arithmetic}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(full, args.cpu_seconds)
         print(json.dumps(out))

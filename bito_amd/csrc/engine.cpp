@@ -77,6 +77,8 @@ struct bito_amd_engine {
   BatchDims dims{};
   bool has_rates = false;
   DeviceBuffer<int32_t> parent_ids, children, sched, children2, sched2;
+  DeviceBuffer<int32_t> pipe_masks;  // packed tip masks per pattern tile (walk_pipe_kernel): a function of the alignment and the plan
+  long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
   DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
       out_ll, out_grad, out_site, scale_arena, branch2, images2;
   bool site_ready = false;  // out_site holds the site-model gradient of the resident pass
@@ -102,7 +104,7 @@ struct bito_amd_engine {
     part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
     tt_out.Free(); tt_aux.Free();
-    children2.Free(); sched2.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
+    children2.Free(); sched2.Free(); pipe_masks.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
     for (int i = 0; i < 2; i++) {
       if (ev_prep_done[i]) (void)hipEventDestroy(ev_prep_done[i]);
       if (ev_walk_done[i]) (void)hipEventDestroy(ev_walk_done[i]);
@@ -306,6 +308,7 @@ DeviceBatch MakeBatch(bito_amd_engine* e, int set = 0) {
   b.mats = e->mats.ptr;
   b.images = set ? e->images2.ptr : e->images.ptr;
   b.sched = set ? e->sched2.ptr : e->sched.ptr;
+  b.pipe_masks = reinterpret_cast<const uint32_t*>(e->pipe_masks.ptr);
   b.arena = e->arena.ptr;
   b.scale_arena = e->scale_arena.ptr;
   b.part_ll = e->part_ll.ptr;
@@ -418,6 +421,10 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
       // AUTO: the hand-scheduled LDS walk where it applies (up to 29 taxa: every branch's images in the AGPR
       // file), measured 1.44 ms against walk_lds_kernel's 2.00 ms per 1600 config-3 trees
       use_pipe = pplan.groups > 0 && !rescaling;
+      // ... except a log-likelihood-only pass with one rate category: walk_hbm_kernel never stores a partial there
+      // (each node's is forwarded in registers to its parent) and runs 0.17 ms per 1600 DS1 JC69 trees
+      // against 0.32 ms (walk_pipe_kernel) and 0.37 ms (walk_lds_kernel); scripts/gpu_config2.py
+      if (!want_gradient && d.category_count == 1) use_pipe = use_lds = use_tree = false;
       break;
   }
   // Measured on config 3 (profiles/): walk_lds_kernel 2.1 ms, walk_tree_kernel 3.8 ms per 1600
@@ -438,13 +445,24 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     // pipelined: this pass's set-up goes to prep_stream and into buffer set (run_counter & 1)
     const int set = (int)(e->run_counter++ & 1u);
     HIP_TRY(e, (set ? e->images2 : e->images).Reserve((size_t)T * NB * kImgStride));
-    if (use_lds) HIP_TRY(e, (set ? e->sched2 : e->sched).Reserve(use_pipe ? PipeScheduleInts(d, plan) : LdsScheduleInts(d)));
+    if (use_lds) HIP_TRY(e, (set ? e->sched2 : e->sched).Reserve(use_pipe ? PipeScheduleInts(d) : LdsScheduleInts(d)));
+    bool build_masks = false;
+    if (use_pipe) {  // the tile masks depend on the alignment and the plan only: built once
+      const long long key = (long long)plan.groups | ((long long)plan.tiles << 8);
+      if (e->pipe_masks_key != key) {
+        HIP_TRY(e, hipStreamSynchronize(e->stream));  // (a traversal may still be reading the old ones)
+        HIP_TRY(e, e->pipe_masks.Reserve(PipeMaskInts(d, plan)));
+        e->pipe_masks_key = key;
+        build_masks = true;
+      }
+    }
     const DeviceBatch b = MakeBatch(e, set);
     HIP_TRY(e, hipStreamWaitEvent(e->prep_stream, e->ev_walk_done[set], 0));
     LaunchSetup(d, e->spec, b, want_gradient, e->prep_stream);
     if (use_pipe) {
       LaunchPipeImages(d, b, e->prep_stream);
       LaunchPipeSchedule(d, b, plan, e->prep_stream);
+      if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), e->prep_stream);
     } else {
       LaunchMatrixImages(d, b, want_gradient, deriv_mode, e->prep_stream);
       if (use_lds) LaunchLdsSchedule(d, b, plan, e->prep_stream);

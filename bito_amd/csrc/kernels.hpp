@@ -55,6 +55,7 @@ struct DeviceBatch {
   double* mats;               // [T][N-1][C][kMatStride]   (HBM-arena kernel)
   double* images;             // [T][N-1][kImgStride]      (LDS kernel)
   int32_t* sched;             // [T][2][n+1][16]           step descriptors (LDS kernel)
+  const uint32_t* pipe_masks; // [tiles][n][waves][16/C]   packed tip masks per pattern tile (walk_pipe_kernel)
   // traversal scratch + outputs
   double* arena;              // [chunk][n-1][C][4][Ppad]
   double* scale_arena;        // [chunk][n-1][Ppad]  post-order 1/scale factors (rescaled gradients)
@@ -142,9 +143,12 @@ void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan
 
 // LDS-resident traversal with hand-scheduled loops (walk_pipe.hip): the mapping of walk_lds_kernel,
 // stored child MESSAGES instead of partials, both tree loops software-pipelined gfx950 assembly.
-// Images: [T][N-1][128] doubles ((P, P^T) per lane); step tables: [T][2][n+1][16] dwords in b.sched.
+// Images: [T][N-1][128] doubles ((P, P^T) per lane); step tables: [T][2][n+1][8] dwords in b.sched; the
+// packed tip masks of every pattern tile (a function of the alignment and the plan) in b.pipe_masks.
 LdsPlan PlanPipe(const BatchDims& d);
-size_t PipeScheduleInts(const BatchDims& d, const LdsPlan& plan);
+size_t PipeScheduleInts(const BatchDims& d);
+size_t PipeMaskInts(const BatchDims& d, const LdsPlan& plan);
+void LaunchPipeMasks(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, uint32_t* masks, hipStream_t stream);
 void LaunchPipeImages(const BatchDims& d, const DeviceBatch& b, hipStream_t stream);
 void LaunchPipeSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream);
 // deriv_mode 1: the edge derivatives use d r_c / d shape in place of r_c (site-model pass)

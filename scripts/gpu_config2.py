@@ -1,0 +1,27 @@
+"""BASELINE config 2 (DS1, JC69, one rate category, log-likelihood only, 1600 trees resident): every kernel
+that takes it, against the CPU checker, with its time per pass."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import bito_amd
+from bito_amd import _capi, workloads
+from oracle import oracle
+
+w = workloads.ds1_jc69(16)
+eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights)
+small = w.subset(10)
+cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
+ref = cpu.log_likelihoods(small.parent_ids, small.branch_lengths, small.params)
+eng.upload(w.parent_ids, w.branch_lengths, w.params)
+for kern in (_capi.KERNEL_LDS_PIPE, _capi.KERNEL_LDS, _capi.KERNEL_HBM_ARENA):
+    eng.set_kernel(kern)
+    ll = eng.log_likelihoods(small.parent_ids, small.branch_lengths, small.params)
+    eng.upload(w.parent_ids, w.branch_lengths, w.params)
+    for g in (False, True):
+        eng.time_runs(g, False, 3)
+        total, k, launches = eng.time_runs(g, False, 20)
+        print(f"kernel={eng.kernel_name()} grad={g}: {total/20:.3f} ms per pass of {w.tree_count} trees "
+              f"({w.tree_count / (total / 20) / 1e3:.2f} M trees/s), walk kernel {k/launches:.3f} ms; max|dLL| {np.abs(ll - ref).max():.2e}")
