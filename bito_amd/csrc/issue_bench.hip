@@ -1,0 +1,91 @@
+// issue_bench.hip -- what ONE wave per SIMD pays per instruction on gfx950 (4 waves per CU, 150 KB of LDS
+// per workgroup so that no second workgroup shares the CU): the cost model behind walk_pipe.hip's loops
+// (scripts/gen_walk_pipe.py).  Every kernel repeats a short asm sequence 1024 times between two s_memtime
+// reads and reports cycles per repetition.  Output of the MI355X box: profiles/r2_issue_costs.txt.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define REP4(x) x x x x
+#define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
+#define REP64(x) REP16(x) REP16(x) REP16(x) REP16(x)
+#define BODY(name, text)                                                                          \
+  __global__ void __launch_bounds__(256) name(long long* out, double* sink) {                     \
+    extern __shared__ double lds[];                                                               \
+    double a = threadIdx.x * 0.5 + 1.0, b = 1.000001, c = 0.5, d = 2.0;                           \
+    unsigned la = threadIdx.x * 8;                                                                \
+    lds[threadIdx.x] = a;                                                                         \
+    __syncthreads();                                                                              \
+    long long t0 = clock64();                                                                     \
+    for (int it = 0; it < 16; it++) asm volatile(REP64(text) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(la) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "s40", "s41", "s42", "s43", "memory"); \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");                                                \
+    long long t1 = clock64();                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                    \
+    sink[blockIdx.x * 256 + threadIdx.x] = a + b + c + d;                                         \
+  }
+BODY(k_salu, "s_add_u32 s40, s40, 1\n")
+BODY(k_salu_indep, "s_add_u32 s40, s41, 1\n")
+BODY(k_valu32, "v_add_u32 v100, v101, v102\n")
+BODY(k_valu32_dep, "v_add_u32 v100, v100, v102\n")
+BODY(k_mul64, "v_mul_f64 v[100:101], %1, %2\n")
+BODY(k_mul64_dep, "v_mul_f64 %0, %0, %1\n")
+BODY(k_mov64, "v_mov_b64 v[100:101], %1\n")
+BODY(k_readlane, "v_readlane_b32 s40, v101, s41\n")
+BODY(k_mfma, "v_mfma_f64_4x4x4_4b_f64 v[100:101], %1, %2, 0\n")
+BODY(k_mfma_dep, "v_mfma_f64_4x4x4_4b_f64 %0, %0, %1, 0\n")
+BODY(k_mfma_valu, "v_mfma_f64_4x4x4_4b_f64 v[100:101], %1, %2, 0\n v_add_u32 v104, v105, v106\n")
+BODY(k_mfma_3valu, "v_mfma_f64_4x4x4_4b_f64 v[100:101], %1, %2, 0\n v_add_u32 v104, v105, v106\n v_add_u32 v105, v105, v106\n v_add_u32 v107, v105, v106\n")
+BODY(k_mfma_mul64, "v_mfma_f64_4x4x4_4b_f64 v[100:101], %1, %2, 0\n v_mul_f64 v[104:105], %1, %2\n")
+BODY(k_mfma_2salu, "v_mfma_f64_4x4x4_4b_f64 v[100:101], %1, %2, 0\n s_add_u32 s40, s41, 1\n s_add_u32 s42, s41, 1\n")
+BODY(k_mul64_salu, "v_mul_f64 v[100:101], %1, %2\n s_add_u32 s40, s41, 1\n")
+BODY(k_mul64_valu32, "v_mul_f64 v[100:101], %1, %2\n v_add_u32 v104, v105, v106\n")
+BODY(k_dsread, "ds_read_b64 v[100:101], %4\n")
+BODY(k_dsread2, "ds_read2st64_b64 v[100:103], %4 offset1:1\n")
+BODY(k_dswrite2, "ds_write2st64_b64 %4, %1, %2 offset1:1\n")
+BODY(k_gpridx, "s_set_gpr_idx_on s41, gpr_idx(SRC0)\n v_mov_b32 v100, v101\n s_set_gpr_idx_off\n")
+BODY(k_nop0, "s_nop 0\n")
+BODY(k_nop7, "s_nop 7\n")
+BODY(k_branch, "s_branch 1f\n s_nop 0\n 1:\n")
+BODY(k_cbranch_nt, "s_cmp_eq_u32 s41, s41\n s_cbranch_scc0 1f\n 1:\n")
+BODY(k_exec, "s_cselect_b64 exec, -1, -1\n")
+#define BODY2(name, text)                                                                          \
+  __global__ void __launch_bounds__(256) name(long long* out, const unsigned* tab, double* sink) {\
+    extern __shared__ double lds[];                                                               \
+    double a = threadIdx.x * 0.5 + 1.0, b = 1.000001;                                             \
+    unsigned la = threadIdx.x * 16;                                                               \
+    lds[threadIdx.x] = a;                                                                         \
+    __syncthreads();                                                                              \
+    const unsigned* p = tab + (blockIdx.x % 64) * 256;                                            \
+    long long t0 = clock64();                                                                     \
+    for (int it = 0; it < 16; it++) asm volatile(REP64(text) : "+v"(a), "+v"(b) : "s"(p), "v"(la) : "v100", "v101", "v102", "v103", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "memory"); \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");                                                \
+    long long t1 = clock64();                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                    \
+    sink[blockIdx.x * 256 + threadIdx.x] = a + b;                                                 \
+  }
+BODY2(k_sload_wait, "s_load_dwordx8 s[40:47], %2, 0x0\n s_waitcnt lgkmcnt(0)\n")
+BODY2(k_sload_wait_far, "s_load_dwordx8 s[40:47], %2, 0x40\n s_waitcnt lgkmcnt(0)\n s_load_dwordx8 s[40:47], %2, 0x100\n s_waitcnt lgkmcnt(0)\n")
+BODY2(k_dsread128_wait, "ds_read_b128 v[100:103], %3\n s_waitcnt lgkmcnt(0)\n")
+BODY2(k_dsread128, "ds_read_b128 v[100:103], %3\n")
+BODY2(k_dswrite128, "ds_write_b128 %3, v[100:103]\n")
+BODY2(k_dswrite128_wait, "ds_write_b128 %3, v[100:103]\n s_waitcnt lgkmcnt(0)\n")
+BODY2(k_setpc, "s_getpc_b64 s[40:41]\n s_add_u32 s40, s40, 16\n s_addc_u32 s41, s41, 0\n s_setpc_b64 s[40:41]\n")
+BODY2(k_mfma_agpr_idx, "s_set_gpr_idx_on s42, gpr_idx(SRC0)\n v_mfma_f64_4x4x4_4b_f64 v[100:101], a[0:1], %1, 0\n v_mfma_f64_4x4x4_4b_f64 v[102:103], a[0:1], %1, 0\n s_set_gpr_idx_off\n")
+BODY2(k_mfma_then_mul, "v_mfma_f64_4x4x4_4b_f64 v[100:101], %0, %1, 0\n s_nop 5\n v_mul_f64 v[102:103], v[100:101], %1\n")
+BODY2(k_4mfma_4mul, "v_mfma_f64_4x4x4_4b_f64 v[100:101], %0, %1, 0\n v_mfma_f64_4x4x4_4b_f64 v[102:103], %0, %1, 0\n v_mfma_f64_4x4x4_4b_f64 v[100:101], %0, %1, 0\n v_mfma_f64_4x4x4_4b_f64 v[102:103], %0, %1, 0\n v_mul_f64 v[100:101], %0, %1\n v_mul_f64 v[102:103], %0, %1\n v_mul_f64 v[100:101], %0, %1\n v_mul_f64 v[102:103], %0, %1\n")
+
+int main() {
+  long long* out; double* sink; hipMalloc(&out, 8); hipMalloc(&sink, 256 * 256 * 8);
+#define RUN(k, n) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(k, dim3(256), dim3(256), 150 * 1024, 0, out, sink); long long c; hipMemcpy(&c, out, 8, hipMemcpyDeviceToHost); \
+    printf("%-16s %7.2f cycles per repetition (%d instr)\n", #k, c / 1024.0, n); }
+  RUN(k_salu, 1) RUN(k_salu_indep, 1) RUN(k_valu32, 1) RUN(k_valu32_dep, 1) RUN(k_mul64, 1) RUN(k_mul64_dep, 1) RUN(k_mov64, 1)
+  RUN(k_readlane, 1) RUN(k_mfma, 1) RUN(k_mfma_dep, 1) RUN(k_mfma_valu, 2) RUN(k_mfma_3valu, 4) RUN(k_mfma_mul64, 2) RUN(k_mfma_2salu, 3)
+  RUN(k_mul64_salu, 2) RUN(k_mul64_valu32, 2) RUN(k_dsread, 1) RUN(k_dsread2, 1) RUN(k_dswrite2, 1) RUN(k_gpridx, 3) RUN(k_nop0, 1) RUN(k_nop7, 1)
+  RUN(k_branch, 1) RUN(k_cbranch_nt, 2) RUN(k_exec, 1)
+  unsigned* tab; hipMalloc(&tab, 1 << 20); hipMemset(tab, 0, 1 << 20);
+#define RUN2(k, n) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(k, dim3(256), dim3(256), 150 * 1024, 0, out, tab, sink); long long c; hipMemcpy(&c, out, 8, hipMemcpyDeviceToHost); \
+    printf("%-20s %7.2f cycles per repetition (%d instr)\n", #k, c / 1024.0, n); }
+  RUN2(k_sload_wait, 2) RUN2(k_sload_wait_far, 4) RUN2(k_dsread128_wait, 2) RUN2(k_dsread128, 1) RUN2(k_dswrite128, 1) RUN2(k_dswrite128_wait, 2) RUN2(k_setpc, 4)
+  RUN2(k_mfma_agpr_idx, 4) RUN2(k_mfma_then_mul, 3) RUN2(k_4mfma_4mul, 8)
+    return 0;
+}
