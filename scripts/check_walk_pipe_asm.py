@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Build-time check of walk_pipe.hip's compiled device code (hipcc -S --cuda-device-only output).
+
+walk_pipe_kernel keeps the matrix images of a whole tree in a[0 .. 4*WALK_PIPE_MAX_BRANCHES) across several asm
+statements.  Those AGPRs are on every statement's clobber list, which keeps the compiler from holding values in
+them ACROSS a statement; this script verifies the stronger property the kernel relies on: outside the asm
+statements the compiler never touches them at all (it has v0..v31 and the AGPRs above for its own values).
+Fails (exit 1) on the first stray use.  usage: check_walk_pipe_asm.py walk_pipe.gfx950.s"""
+import re
+import sys
+
+LIMIT = 224  # 4 * WALK_PIPE_MAX_BRANCHES
+
+
+def main(path):
+    inside = False
+    kernel = None
+    stray = 0
+    kernels = 0
+    for line in open(path):
+        m = re.match(r"^(_ZN8bito_amd16walk_pipe_kernel\w+):", line)
+        if m:
+            kernel = m.group(1)
+            kernels += 1
+        if "#ASMSTART" in line:
+            inside = True
+            continue
+        if "#ASMEND" in line:
+            inside = False
+            continue
+        text = line.strip()
+        if inside or not kernel or not text or text[0] in ";.":
+            continue
+        if text.startswith("s_endpgm"):
+            kernel = None
+            continue
+        for mm in re.finditer(r"\ba\[?(\d+)", text.split(";")[0]):
+            if int(mm.group(1)) < LIMIT:
+                stray += 1
+                if stray <= 5:
+                    print(f"stray AGPR use in {kernel}: {text}", file=sys.stderr)
+    if kernels == 0:
+        print("no walk_pipe_kernel instantiation found in " + path, file=sys.stderr)
+        return 1
+    if stray:
+        print(f"{stray} uses of a0..a{LIMIT - 1} outside the asm statements", file=sys.stderr)
+        return 1
+    print(f"{kernels} walk_pipe_kernel instantiations: a0..a{LIMIT - 1} untouched outside the asm statements")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

@@ -205,3 +205,29 @@ def test_workloads_are_deterministic():
     sh = [a.shard(r, 8) for r in range(8)]
     assert sum(x.tree_count for x in sh) == 100
     assert np.array_equal(np.concatenate([x.branch_lengths for x in sh]), a.branch_lengths)
+
+
+def test_generated_walk_loops_are_current_and_checked(tmp_path):
+    """bito_amd/csrc/walk_pipe_gen.inc is generated: the committed file must be what scripts/gen_walk_pipe.py
+    emits today, and the compiled kernel must leave the AGPRs that hold a tree's matrix images alone outside its
+    own asm statements (the Makefile runs the same check at build time)."""
+    import shutil
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    committed = os.path.join(root, "bito_amd", "csrc", "walk_pipe_gen.inc")
+    before = open(committed).read()
+    keep = tmp_path / "walk_pipe_gen.inc"
+    shutil.copy(committed, keep)
+    try:
+        subprocess.run([sys.executable, os.path.join(root, "scripts", "gen_walk_pipe.py")], check=True,
+                       stdout=subprocess.DEVNULL)
+        assert open(committed).read() == before, "walk_pipe_gen.inc is stale: run scripts/gen_walk_pipe.py"
+    finally:
+        shutil.copy(keep, committed)
+    listing = os.path.join(root, "bito_amd", "csrc", "walk_pipe.gfx950.s")
+    if os.path.exists(listing):  # (written by the build)
+        done = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_walk_pipe_asm.py"), listing],
+                              capture_output=True, text=True)
+        assert done.returncode == 0, done.stderr
