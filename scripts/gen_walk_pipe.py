@@ -62,7 +62,7 @@ def _scalar_operands(text):
 class Ins:
     __slots__ = ("text", "kind", "reads", "writes", "mem_reads", "reads_c", "sreads", "swrites", "fence")
 
-    def __init__(self, text, kind, reads=(), writes=(), mem_reads=(), reads_c=()):
+    def __init__(self, text, kind, reads=(), writes=(), mem_reads=(), reads_c=(), indexed=False):
         self.text, self.kind = text, kind
         self.reads, self.writes, self.mem_reads, self.reads_c = list(reads), list(writes), list(mem_reads), list(reads_c)
         self.fence = False
@@ -92,7 +92,9 @@ class Ins:
             if op.startswith("v_readlane"):
                 sw.update(ops[0])
                 sr.difference_update(ops[0])
-            sr.update({"exec", "mode", "m0"})  # every vector / memory instruction runs under EXEC and the index mode
+            sr.update({"exec", "mode"})  # every vector / memory instruction runs under EXEC and the index mode
+            if indexed:
+                sr.add("m0")  # ... and inside an index-mode region M0 is part of its operand
         self.sreads, self.swrites = sr, sw
 
     def conflicts_with_delayed(self, s):
@@ -124,8 +126,8 @@ class Emitter:
         """branch / jump: nothing moves across it"""
         self.items.append(("control", text))
 
-    def ins(self, text, kind, reads=(), writes=(), mem_reads=(), reads_c=()):
-        self.items.append(Ins(text, kind, reads, writes, mem_reads, reads_c))
+    def ins(self, text, kind, reads=(), writes=(), mem_reads=(), reads_c=(), indexed=False):
+        self.items.append(Ins(text, kind, reads, writes, mem_reads, reads_c, indexed))
         self.count[kind] = self.count.get(kind, 0) + 1
 
     # ---- pass 1: scalar instructions into the shadow of matrix instructions ----
@@ -366,7 +368,8 @@ class Loops:
             return
         if isinstance(a, tuple):
             assert self.idx_mode == "SRC0"
-            self.e.ins(f"v_mfma_f64_4x4x4_4b_f64 {vp(dst)}, {ap(a[1])}, {vp(b)}, 0", "mfma", reads=[b, b + 1], writes=[dst, dst + 1])
+            self.e.ins(f"v_mfma_f64_4x4x4_4b_f64 {vp(dst)}, {ap(a[1])}, {vp(b)}, 0", "mfma", reads=[b, b + 1], writes=[dst, dst + 1],
+                       indexed=True)
             return
         assert self.idx_mode is None, "a matrix instruction with a VGPR A operand inside an index-mode region"
         if a == "Q":
@@ -377,7 +380,7 @@ class Loops:
 
     def valu(self, text, reads, writes, indexed_ok=False):
         assert self.idx_mode is None or indexed_ok, f"VALU inside an index-mode region: {text}"
-        self.e.ins(text, "valu", reads=list(reads), writes=list(writes))
+        self.e.ins(text, "valu", reads=list(reads), writes=list(writes), indexed=self.idx_mode is not None)
 
     def vmul(self, dst, a, b):
         self.valu(f"v_mul_f64 {vp(dst)}, {vp(a)}, {vp(b)}", [a, a + 1, b, b + 1], [dst, dst + 1])
