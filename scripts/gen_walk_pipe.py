@@ -34,7 +34,7 @@ WS_VALU_MFMA = 2      # VALU result -> matrix operand
 
 VBASE = 32   # first VGPR the loops may use (v0..v31 and a224.. stay with the compiler)
 VLIMIT = 256
-SBASE, SLIMIT = 36, 96  # SGPRs
+SBASE, SLIMIT = 36, 100  # SGPRs
 
 
 import re
@@ -319,42 +319,42 @@ class Loops:
         self.AD = [V.get(1, f"AD{k}") for k in range(8)]
         self.vnext = V.next
         # scalars
-        self.CUR = S.get(8, "CUR", 4)   # this step's descriptor
-        self.FLY = S.get(8, "FLY", 4)   # the next step's (requested at the top of the body)
+        # two descriptor sets used alternately: a body of parity p reads its step's descriptor in DESC[p],
+        # finds the PREVIOUS step's in DESC[1-p] until it requests the NEXT step's into it
+        self.DESC = [S.get(16, "DESC0", 4), S.get(16, "DESC1", 4)]
+        self.p = 0
         self.TAB = S.get(2, "TAB", 2)
+        self.TABOFF = S.get(1, "TABOFF")
         self.CNT = S.get(1, "CNT")
-        self.EPREV = [S.get(1, "EPREV0"), S.get(1, "EPREV1")]  # gradient-row byte offsets of the previous step's two edges
         self.WMASK = S.get(2, "WMASK", 2)
-        self.BASE = S.get(2, "BASE", 2)   # code address the body offsets are relative to
+        self.BASE = [S.get(2, "BASE0", 2), S.get(2, "BASE1", 2)]  # code address of the bodies of parity 0 / 1
         self.PC = S.get(2, "PC", 2)
         self.OFFTAB = S.get(11, "OFFTAB")  # code offsets of the bodies (5 + 5 hand-over forms) and of the loop exit
-        self.F = [S.get(1, f"F{k}") for k in range(8)]  # unpacked fields of the current step
-        self.TMP = [S.get(1, f"TMP{k}") for k in range(6)]
+        self.IMGP = S.get(2, "IMGP", 2)   # (the image loader's pointer; the loops use the pair as scratch)
+        self.TMP = [self.IMGP, self.IMGP + 1, S.get(1, "TMP2")]
         self.TMPM = [S.get(1, f"TMPM{k}") for k in range(2)]  # scratch of messages() only
-        self.IMGP = S.get(2, "IMGP", 2)
         self.snext = S.next
         self.V, self.S = V, S
 
     # ---- descriptor words (see walk_pipe.hip) ----
-    FLAGS, OWNS, OFFC01, NOFFC01, TIPS, IMG = range(6)
-    BIT_FORWARD, BIT_READ1, BIT_READU = 8, 9, 10  # all three describe the NEXT step
+    (FLAGS, OWN, NOWN, OFFC0, OFFC1, NOFFC0, NOFFC1, IMG0, IMG1, IMGOWN, TIPA0, TIPB0, TIPA1, TIPB1, E0, E1) = range(16)
 
     def cur(self, w):
-        return f"s{self.CUR + w}"
+        return f"s{self.DESC[self.p] + w}"
 
-    def fly(self, w):
-        return f"s{self.FLY + w}"
+    def other(self, w):
+        return f"s{self.DESC[1 - self.p] + w}"
 
     # ---- instruction helpers --------------------------------------------------------------------
     idx_mode = None  # None | "SRC0" | "SRC1" while the VGPR index mode is on
 
     def idx_on(self, sgpr, which):
-        self.salu(f"s_set_gpr_idx_on s{sgpr}, gpr_idx({which})")
+        self.salu(f"s_set_gpr_idx_on {sgpr}, gpr_idx({which})")
         self.idx_mode = which
 
     def idx_set(self, sgpr):
         assert self.idx_mode
-        self.salu(f"s_set_gpr_idx_idx s{sgpr}")
+        self.salu(f"s_set_gpr_idx_idx {sgpr}")
 
     def idx_off(self):
         self.salu("s_set_gpr_idx_off")
@@ -479,11 +479,14 @@ class Loops:
         self.mfma(self.R[0], ea, self.ONE)
         self.mfma(self.R[1], eb, self.ONE)
 
-    def flush_stage2(self, off0, off1):
+    def flush_addresses(self, off0, off1):
+        """LDS addresses of the two gradient-row entries the next flush adds to (scalar byte offsets)"""
+        self.v32(f"v_add_u32 v{self.AD[6]}, {off0}, %[grow]", [], [self.AD[6]])
+        self.v32(f"v_add_u32 v{self.AD[7]}, {off1}, %[grow]", [], [self.AD[7]])
+
+    def flush_stage2(self):
         self.mfma(self.T[0], self.ONE, self.R[0])
         self.mfma(self.T[1], self.ONE, self.R[1])
-        self.v32(f"v_add_u32 v{self.AD[6]}, s{off0}, %[grow]", [], [self.AD[6]])
-        self.v32(f"v_add_u32 v{self.AD[7]}, s{off1}, %[grow]", [], [self.AD[7]])
 
     def flush_stage3(self):
         self.salu(f"s_mov_b64 exec, s[{self.WMASK}:{self.WMASK + 1}]")
@@ -494,89 +497,54 @@ class Loops:
         return 2
 
     # ---- descriptor pipeline ----
-    def rotate(self):
-        """the descriptor requested by the previous body becomes this step's"""
-        for k in range(0, 8, 2):
-            self.salu(f"s_mov_b64 s[{self.CUR + k}:{self.CUR + k + 1}], s[{self.FLY + k}:{self.FLY + k + 1}]")
-        self.salu(f"s_add_u32 s{self.TAB}, s{self.TAB}, 32")
-        self.salu(f"s_addc_u32 s{self.TAB + 1}, s{self.TAB + 1}, 0")
-
     def request_descriptor(self):
-        """the next step's descriptor (one scalar load; waited for in the middle of the body)"""
-        self.mem(f"s_load_dwordx8 s[{self.FLY}:{self.FLY + 7}], s[{self.TAB}:{self.TAB + 1}], 0x0")
+        """the next step's descriptor into the other set (one scalar load; nothing waits for it before the
+        end of the body -- the body finds what it must know about the next step in its own descriptor)"""
+        d = self.DESC[1 - self.p]
+        self.salu(f"s_add_u32 s{self.TABOFF}, s{self.TABOFF}, 64")
+        self.mem(f"s_load_dwordx16 s[{d}:{d + 15}], s[{self.TAB}:{self.TAB + 1}], s{self.TABOFF}")
 
     def next_pc(self):
-        """code address of the next step's body (this step's flags, bits 4..6) into PC; the jump itself comes last"""
+        """code address of the next step's body (this step's flags, bits 4..7; the body of the other parity)
+        into PC; the jump itself comes last"""
         t = self.TMP[0]
+        base = self.BASE[1 - self.p]
         self.salu(f"s_bfe_u32 m0, {self.cur(self.FLAGS)}, 0x40004")
         self.salu("s_nop 0")
         self.salu(f"s_movrels_b32 s{t}, s{self.OFFTAB}")
-        self.salu(f"s_add_u32 s{self.PC}, s{self.BASE}, s{t}")
-        self.salu(f"s_addc_u32 s{self.PC + 1}, s{self.BASE + 1}, 0")
+        self.salu(f"s_add_u32 s{self.PC}, s{base}, s{t}")
+        self.salu(f"s_addc_u32 s{self.PC + 1}, s{base + 1}, 0")
 
     def go_first(self):
-        """from the loop prologue into the first step: its descriptor is FLY (the body hands it over), its
-        stored operands are requested here from that descriptor's own cell offsets"""
+        """from the loop prologue into the first step (parity 0): its descriptor has landed in DESC[0], its
+        stored operands are requested here"""
         ad = self.AD
         t = self.TMP
+        self.p = 0
         self.wait(lgkm=0)
-        self.salu(f"s_and_b32 s{t[2]}, {self.fly(self.OFFC01)}, 0xffff")
-        self.salu(f"s_lshr_b32 s{t[3]}, {self.fly(self.OFFC01)}, 16")
-        self.v32(f"v_add_u32 v{ad[0]}, s{t[2]}, %[arena]", [], [ad[0]])
-        self.v32(f"v_add_u32 v{ad[1]}, s{t[3]}, %[arena]", [], [ad[1]])
+        self.v32(f"v_add_u32 v{ad[0]}, {self.cur(self.OFFC0)}, %[arena]", [], [ad[0]])
+        self.v32(f"v_add_u32 v{ad[1]}, {self.cur(self.OFFC1)}, %[arena]", [], [ad[1]])
         self.cell_read(self.M[0], ad[0])
         self.cell_read(self.M[1], ad[1])
-        self.salu(f"s_and_b32 m0, {self.fly(self.FLAGS)}, 15")
+        self.salu(f"s_and_b32 m0, {self.cur(self.FLAGS)}, 15")
         self.salu("s_nop 0")
         self.salu(f"s_movrels_b32 s{t[0]}, s{self.OFFTAB}")
-        self.salu(f"s_add_u32 s{self.PC}, s{self.BASE}, s{t[0]}")
-        self.salu(f"s_addc_u32 s{self.PC + 1}, s{self.BASE + 1}, 0")
+        self.salu(f"s_add_u32 s{self.PC}, s{self.BASE[0]}, s{t[0]}")
+        self.salu(f"s_addc_u32 s{self.PC + 1}, s{self.BASE[0] + 1}, 0")
         self.wait(lgkm=0)
         self.go()
 
     def go(self):
         self.e.control(f"s_setpc_b64 s[{self.PC}:{self.PC + 1}]")
 
-    def request_cells(self, predicate_slot1):
-        """the next step's stored child messages into M[0], M[1] (a slot that is no stored cell has offset 0:
-        what lands is ignored).  Slot 1 under EXEC predicate "read it" when the message may be handed over."""
-        ad = self.AD
-        t = self.TMP[2]
-        self.salu(f"s_and_b32 s{t}, {self.cur(self.NOFFC01)}, 0xffff")
-        self.v32(f"v_add_u32 v{ad[0]}, s{t}, %[arena]", [], [ad[0]])
-        self.salu(f"s_lshr_b32 s{t}, {self.cur(self.NOFFC01)}, 16")
-        self.v32(f"v_add_u32 v{ad[1]}, s{t}, %[arena]", [], [ad[1]])
-        n = self.cell_read(self.M[0], ad[0])
-        if predicate_slot1:
-            self.predicate(self.BIT_READ1)
-        n += self.cell_read(self.M[1], ad[1])
-        if predicate_slot1:
-            self.unpredicate()
-        return n
-
-    def dispatch(self, done):
-        """leave the body: count the step, jump to the body of the next step (FLY's flags)"""
-        self.salu(f"s_sub_u32 s{self.CNT}, s{self.CNT}, 1")
-        self.salu(f"s_cmp_eq_u32 s{self.CNT}, 0")
-        self.branch("scc1", done)
-        self.jump()
-
-    def jump(self):
-        t = self.TMP[0]
-        self.salu(f"s_and_b32 m0, {self.fly(self.FLAGS)}, 7")
-        self.salu("s_nop 0")
-        self.salu(f"s_movrels_b32 s{t}, s{self.OFFTAB}")
-        self.salu(f"s_add_u32 s{self.PC}, s{self.BASE}, s{t}")
-        self.salu(f"s_addc_u32 s{self.PC + 1}, s{self.BASE + 1}, 0")
-        self.e.control(f"s_setpc_b64 s[{self.PC}:{self.PC + 1}]")
-
-    def loop_entry(self, names, exit_label=None):
+    def loop_entry(self, names):
         """common prologue: first descriptor, constants, the tile's tip masks, the table of body offsets
-        (entry 10: the loop exit, the "body" behind a table's last step)"""
+        (relative to the start of a parity's block of bodies; entry 10: that block's way out of the loop)"""
         G = self.G
         self.salu(f"s_mov_b64 s[{self.TAB}:{self.TAB + 1}], %[tab]")
+        self.salu(f"s_mov_b32 s{self.TABOFF}, 0")
         self.salu(f"s_mov_b32 s{self.CNT}, %[steps]")
-        self.mem(f"s_load_dwordx8 s[{self.FLY}:{self.FLY + 7}], s[{self.TAB}:{self.TAB + 1}], 0x0")
+        self.mem(f"s_load_dwordx16 s[{self.DESC[0]}:{self.DESC[0] + 15}], s[{self.TAB}:{self.TAB + 1}], 0x0")
         for g in range(G):
             self.v32(f"v_subrev_u32 v{self.SH[g]}, {8 * g}, %[sh0]", [], [self.SH[g]])
         for t in range(4):
@@ -589,41 +557,45 @@ class Loops:
             self.mem(f"ds_read_b32 v{self.TMV + t}, v{a}", mem_reads=[a], writes=[self.TMV + t])
             if t + 1 < self.MAX_TIPS:
                 self.v32(f"v_add_u32 v{a}, %[tipstride], v{a}", [a], [a])
-        self.e.control(f"s_getpc_b64 s[{self.BASE}:{self.BASE + 1}]")
-        self.e.label(self.L('base'))
+        self.e.control(f"s_getpc_b64 s[{self.BASE[0]}:{self.BASE[0] + 1}]")
+        self.e.label(self.L("here"))
+        # BASE[p] = address of parity p's block of bodies
+        self.salu(f"s_add_u32 s{self.BASE[0]}, s{self.BASE[0]}, {self.L('block0')}-{self.L('here')}")
+        self.salu(f"s_addc_u32 s{self.BASE[0] + 1}, s{self.BASE[0] + 1}, 0")
+        self.salu(f"s_add_u32 s{self.BASE[1]}, s{self.BASE[0]}, {self.L('block1')}-{self.L('block0')}")
+        self.salu(f"s_addc_u32 s{self.BASE[1] + 1}, s{self.BASE[0] + 1}, 0")
         for k, name in enumerate(names):
-            self.salu(f"s_mov_b32 s{self.OFFTAB + k}, {self.L(name)}-{self.L('base')}")
-        if exit_label:
-            self.salu(f"s_mov_b32 s{self.OFFTAB + 10}, {self.L(exit_label)}-{self.L('base')}")
+            self.salu(f"s_mov_b32 s{self.OFFTAB + k}, {self.L(name + '_0')}-{self.L('block0')}")
+        self.salu(f"s_mov_b32 s{self.OFFTAB + 10}, {self.L('out_0')}-{self.L('block0')}")
 
     # ---- child messages of one slot (both passes) ---------------------------------------------------
     def messages(self, kinds):
         """leaves the message of a tip / cherry slot s in MSG[s] -- a stored cell's message is M[s] itself.
-        Cherry: MA, MB (tip messages) are kept for the pre-order pass.  Fields: F[0], F[1] image indices of
-        the slots, F[4..7] tip ids A0 B0 A1 B1."""
+        Cherry: MA, MB (tip messages) are kept for the pre-order pass."""
         G = self.G
-        f = self.F
-        t = [None, None] + self.TMPM
+        t = self.TMPM
+        tip = [[self.TIPA0, self.TIPB0], [self.TIPA1, self.TIPB1]]
+        img = [self.IMG0, self.IMG1]
         for s in (0, 1):
             if kinds[s] == "T":
-                self.tip_operands(2 * s, f[4 + 2 * s])
+                self.tip_operands(2 * s, self.cur(tip[s][0]))
             elif kinds[s] == "H":
-                self.tip_operands(2 * s, f[4 + 2 * s])
-                self.tip_operands(2 * s + 1, f[5 + 2 * s])
+                self.tip_operands(2 * s, self.cur(tip[s][0]))
+                self.tip_operands(2 * s + 1, self.cur(tip[s][1]))
         for s in (0, 1):
             if kinds[s] == "T":
-                self.idx_on(f[s], "SRC0")
+                self.idx_on(self.cur(img[s]), "SRC0")
                 for g in range(G):
                     self.mfma(self.MSG[s][g], ("A", 0), self.TP[2 * s][g])
                 self.idx_off()
             elif kinds[s] == "H":
                 # image index of a tip branch = 4 x tip id
-                self.salu(f"s_lshl_b32 s{t[2]}, s{f[4 + 2 * s]}, 2")
-                self.salu(f"s_lshl_b32 s{t[3]}, s{f[5 + 2 * s]}, 2")
-                self.idx_on(t[2], "SRC0")
+                self.salu(f"s_lshl_b32 s{t[0]}, {self.cur(tip[s][0])}, 2")
+                self.salu(f"s_lshl_b32 s{t[1]}, {self.cur(tip[s][1])}, 2")
+                self.idx_on(f"s{t[0]}", "SRC0")
                 for g in range(G):
                     self.mfma(self.MA[s][g], ("A", 0), self.TP[2 * s][g])
-                self.idx_set(t[3])
+                self.idx_set(f"s{t[1]}")
                 for g in range(G):
                     self.mfma(self.MB[s][g], ("A", 0), self.TP[2 * s + 1][g])
                 self.idx_off()
@@ -633,28 +605,13 @@ class Loops:
                     self.vmul(self.X[s][g], self.MA[s][g], self.MB[s][g])
         for s in (0, 1):
             if kinds[s] == "H":
-                self.idx_on(f[s], "SRC0")
+                self.idx_on(self.cur(img[s]), "SRC0")
                 for g in range(G):
                     self.mfma(self.MSG[s][g], ("A", 0), self.X[s][g])
                 self.idx_off()
 
     def msg(self, s, kind):
         return self.M[s] if kind == "C" else self.MSG[s]
-
-    def unpack(self, kinds, post):
-        f = self.F
-        self.salu(f"s_mov_b32 s{f[0]}, {self.cur(self.IMG)}")
-        self.salu(f"s_lshr_b32 s{f[1]}, {self.cur(self.IMG)}, 8")
-        if post:
-            self.salu(f"s_lshr_b32 s{f[2]}, {self.cur(self.IMG)}, 16")
-        if kinds[0] != "C":
-            self.salu(f"s_and_b32 s{f[4]}, {self.cur(self.TIPS)}, 0xff")
-        if kinds[0] == "H":
-            self.salu(f"s_bfe_u32 s{f[5]}, {self.cur(self.TIPS)}, 0x80008")
-        if kinds[1] != "C":
-            self.salu(f"s_bfe_u32 s{f[6]}, {self.cur(self.TIPS)}, 0x80010")
-        if kinds[1] == "H":
-            self.salu(f"s_lshr_b32 s{f[7]}, {self.cur(self.TIPS)}, 24")
 
     # =============================== post-order loop ===============================================
     # body index = position here; the second five hand a vector to the NEXT step in registers (post-order:
@@ -663,38 +620,32 @@ class Loops:
     POST_VARIANTS = [(n, a, b, False) for n, a, b in KINDS] + [(n + "f", a, b, True) for n, a, b in KINDS]
     PRE_VARIANTS = [(n, a, b, False) for n, a, b in KINDS] + [(n + "f", a, b, True) for n, a, b in KINDS if b == "C"]
 
-    def post_body(self, name, K0, K1, hand_over):
+    def post_body(self, name, K0, K1, hand_over, parity):
         G = self.G
+        self.p = parity
         kinds = (K0, K1)
         own = self.M[1] if hand_over else self.UC[1]
-        f = self.F
-        t = self.TMP
-        self.label(self.L(name))
-        self.e.comment(f"post-order step, children ({K0},{K1})" + (", message handed to the next step" if hand_over else ""))
-        self.rotate()
-        self.unpack(kinds, post=True)
+        ad = self.AD
+        self.label(self.L(f"{name}_{parity}"))
+        self.e.comment(f"post-order step, children ({K0},{K1})" + (", message handed to the next step" if hand_over else "")
+                       + f", descriptor set {parity}")
         self.salu(f"s_sub_u32 s{self.CNT}, s{self.CNT}, 1")
         self.next_pc()
-        # scalar halves of the addresses used below: next step's two cells, this node's own cell
-        self.salu(f"s_and_b32 s{t[2]}, {self.cur(self.NOFFC01)}, 0xffff")
-        self.salu(f"s_lshr_b32 s{t[3]}, {self.cur(self.NOFFC01)}, 16")
-        self.salu(f"s_and_b32 s{t[4]}, {self.cur(self.OWNS)}, 0xffff")
         self.messages(kinds)
         self.request_descriptor()
         # x = m0 . m1 (the node's partial); the root's leaves the loop in X[0]
         m0, m1 = self.msg(0, K0), self.msg(1, K1)
         for g in range(G):
             self.vmul(self.X[0][g], m0[g], m1[g])
-        ad = self.AD
-        self.v32(f"v_add_u32 v{ad[0]}, s{t[2]}, %[arena]", [], [ad[0]])
+        self.v32(f"v_add_u32 v{ad[0]}, {self.cur(self.NOFFC0)}, %[arena]", [], [ad[0]])
         if not hand_over:
-            self.v32(f"v_add_u32 v{ad[1]}, s{t[3]}, %[arena]", [], [ad[1]])
-        self.v32(f"v_add_u32 v{ad[6]}, s{t[4]}, %[arena]", [], [ad[6]])
+            self.v32(f"v_add_u32 v{ad[1]}, {self.cur(self.NOFFC1)}, %[arena]", [], [ad[1]])
+        self.v32(f"v_add_u32 v{ad[6]}, {self.cur(self.OWN)}, %[arena]", [], [ad[6]])
         self.salu(f"s_cmp_eq_u32 s{self.CNT}, 0")
         self.branch("scc1", self.L("root"))
         # own message a = P_v x (straight into the next step's slot-1 registers when it is handed over), the
         # next step's stored operands requested underneath
-        self.idx_on(f[2], "SRC0")
+        self.idx_on(self.cur(self.IMGOWN), "SRC0")
         for g in range(G):
             self.mfma(own[g], ("A", 0), self.X[0][g])
         self.cell_read(self.M[0], ad[0])
@@ -714,8 +665,12 @@ class Loops:
         names = [v[0] for v in self.POST_VARIANTS]
         self.loop_entry(names)
         self.go_first()
-        for name, K0, K1, hand_over in self.POST_VARIANTS:
-            self.post_body(name, K0, K1, hand_over)
+        for parity in (0, 1):
+            self.label(self.L(f"block{parity}"))
+            for name, K0, K1, hand_over in self.POST_VARIANTS:
+                self.post_body(name, K0, K1, hand_over, parity)
+            self.label(self.L(f"out_{parity}"))  # (never taken: the root's step leaves through the branch above)
+            self.branch(None, self.L("root"))
         self.label(self.L("root"))
         self.wait(vm=0, lgkm=0)
         for g in range(G):
@@ -723,26 +678,21 @@ class Loops:
         return e
 
     # =============================== pre-order loop ================================================
-    def pre_body(self, name, K0, K1, hand_over):
+    def pre_body(self, name, K0, K1, hand_over, parity):
         G = self.G
+        self.p = parity
         kinds = (K0, K1)
-        f = self.F
         t = self.TMP
         ad = self.AD
-        self.label(self.L(name))
+        img = [self.IMG0, self.IMG1]
+        tip = [[self.TIPA0, self.TIPB0], [self.TIPA1, self.TIPB1]]
+        self.label(self.L(f"{name}_{parity}"))
         self.e.comment(f"pre-order step, children ({K0},{K1})" + (", slot 1's partial handed to the next step" if hand_over else ""))
-        # the previous step's two edge sums, level 1; the scalar work of the step (descriptor hand-over,
-        # unpacking, scalar halves of every address, the next body's code address) sinks behind these and
-        # the next matrix instructions
+        # where the previous step's two edge sums go (its descriptor is still in the other set), then their
+        # reduction, level 1; the next body's code address sinks behind the matrix instructions
+        self.flush_addresses(self.other(self.E0), self.other(self.E1))
         self.flush_stage1(self.ES[0], self.ES[1])
-        self.rotate()
-        self.unpack(kinds, post=False)
         self.next_pc()
-        self.salu(f"s_and_b32 s{t[1]}, {self.cur(self.OFFC01)}, 0xffff")   # this step's stores
-        self.salu(f"s_lshr_b32 s{t[2]}, {self.cur(self.OFFC01)}, 16")
-        self.salu(f"s_and_b32 s{t[3]}, {self.cur(self.NOFFC01)}, 0xffff")  # the next step's operands
-        self.salu(f"s_lshr_b32 s{t[4]}, {self.cur(self.NOFFC01)}, 16")
-        self.salu(f"s_lshr_b32 s{t[5]}, {self.cur(self.OWNS)}, 16")        # ... and its node's own cell
         # Q m of the stored children: their messages are in registers already
         for s in (0, 1):
             if kinds[s] == "C":
@@ -754,27 +704,22 @@ class Loops:
             if kinds[s] != "C":
                 for g in range(G):
                     self.mfma(self.DQ[s][g], "Q", self.MSG[s][g])
-        self.flush_stage2(self.EPREV[0], self.EPREV[1])
-        # gradient-row offsets of this step's two edges (8 x child id = 2 x its image index), for the next body
-        self.salu(f"s_and_b32 s{self.EPREV[0]}, {self.cur(self.IMG)}, 0xff")
-        self.salu(f"s_lshl_b32 s{self.EPREV[0]}, s{self.EPREV[0]}, 1")
-        self.salu(f"s_bfe_u32 s{self.EPREV[1]}, {self.cur(self.IMG)}, 0x80008")
-        self.salu(f"s_lshl_b32 s{self.EPREV[1]}, s{self.EPREV[1]}, 1")
+        self.flush_stage2()
         self.wait(lgkm=0)  # U when it came out of LDS; the next step's descriptor
-        nst = self.flush_stage3()
         # w_s = U . (message of the other child)
         m0, m1 = self.msg(0, K0), self.msg(1, K1)
         for g in range(G):
             self.vmul(self.W[0][g], self.U[g], m1[g])
             self.vmul(self.W[1][g], self.U[g], m0[g])
-        self.v32(f"v_add_u32 v{ad[0]}, s{t[3]}, %[arena]", [], [ad[0]])
-        self.v32(f"v_add_u32 v{ad[1]}, s{t[4]}, %[arena]", [], [ad[1]])
+        nst = self.flush_stage3()
+        self.v32(f"v_add_u32 v{ad[0]}, {self.cur(self.NOFFC0)}, %[arena]", [], [ad[0]])
+        self.v32(f"v_add_u32 v{ad[1]}, {self.cur(self.NOFFC1)}, %[arena]", [], [ad[1]])
         if not hand_over:
-            self.v32(f"v_add_u32 v{ad[2]}, s{t[5]}, %[arena]", [], [ad[2]])
+            self.v32(f"v_add_u32 v{ad[2]}, {self.cur(self.NOWN)}, %[arena]", [], [ad[2]])
         if K0 == "C":
-            self.v32(f"v_add_u32 v{ad[3]}, s{t[1]}, %[arena]", [], [ad[3]])
+            self.v32(f"v_add_u32 v{ad[3]}, {self.cur(self.OFFC0)}, %[arena]", [], [ad[3]])
         if K1 == "C":
-            self.v32(f"v_add_u32 v{ad[4]}, s{t[2]}, %[arena]", [], [ad[4]])
+            self.v32(f"v_add_u32 v{ad[4]}, {self.cur(self.OFFC1)}, %[arena]", [], [ad[4]])
         # P^T w: the children's pre-order partials, with the next step's reads issued underneath
         # (the registers they land in -- M[0], M[1], U -- have had their last use)
         first = True
@@ -786,9 +731,9 @@ class Loops:
             if s == 1 and hand_over:
                 dst = self.U  # (every use of this step's U has been issued)
             if first:
-                self.idx_on(f[s], "SRC0")
+                self.idx_on(self.cur(img[s]), "SRC0")
             else:
-                self.idx_set(f[s])
+                self.idx_set(self.cur(img[s]))
             for g in range(G):
                 self.mfma(dst[g], ("A", 2), self.W[s][g])
             if first:
@@ -813,8 +758,8 @@ class Loops:
             DQA, DQB, TA, TB = self.MSG[s], self.UC[0], self.W[s], self.DQ[s]
             for g in range(G):
                 self.mfma(DQA[g], "Q", self.MA[s][g])
-            self.salu(f"s_lshl_b32 s{t[0]}, s{f[4 + 2 * s]}, 3")
-            self.salu(f"s_lshl_b32 s{t[1]}, s{f[5 + 2 * s]}, 3")
+            self.salu(f"s_lshl_b32 s{t[1]}, {self.cur(tip[s][0])}, 3")  # gradient rows of the two tip edges: 8 x tip id
+            self.salu(f"s_lshl_b32 s{t[2]}, {self.cur(tip[s][1])}, 3")
             for g in range(G):
                 self.mfma(DQB[g], "Q", self.MB[s][g])
             for g in range(G):
@@ -827,8 +772,9 @@ class Loops:
                 else:
                     self.vfma(self.EA, TA[g], DQA[g], self.EA)
                     self.vfma(self.EB, TB[g], DQB[g], self.EB)
+            self.flush_addresses(f"s{t[1]}", f"s{t[2]}")
             self.flush_stage1(self.EA, self.EB)
-            self.flush_stage2(t[0], t[1])
+            self.flush_stage2()
             nst += self.flush_stage3()
         # this step's stores
         if K0 == "C":
@@ -844,25 +790,31 @@ class Loops:
         G = self.G
         e = self.e
         e.comment(f"pre-order loop, G = {G}")
-        names = [v[0] for v in self.PRE_VARIANTS] + ["unused", "unused"]
-        self.loop_entry(names[:10], exit_label="done")
+        names = [v[0] for v in self.PRE_VARIANTS] + ["cc", "cc"]  # (body indices 8, 9 do not occur)
+        self.loop_entry(names[:10])
         self.e.ins(f"v_mov_b64 {vp(self.ONE)}, 1.0", "valu", writes=[self.ONE, self.ONE + 1])
         for s in (0, 1):
             self.e.ins(f"v_mov_b64 {vp(self.ES[s])}, 0", "valu", writes=[self.ES[s], self.ES[s] + 1])
         for g in range(G):
             self.e.ins(f"v_mov_b64 {vp(self.U[g])}, %[u{g}]", "valu", writes=[self.U[g], self.U[g] + 1])
-        self.salu(f"s_mov_b32 s{self.EPREV[0]}, %[rootedge]")
-        self.salu(f"s_mov_b32 s{self.EPREV[1]}, %[rootedge]")
+        # the first body flushes "the previous step's" edge sums: zeros, into the root's slot
+        self.salu(f"s_mov_b32 s{self.DESC[1] + self.E0}, %[rootedge]")
+        self.salu(f"s_mov_b32 s{self.DESC[1] + self.E1}, %[rootedge]")
         self.salu(f"s_mov_b32 s{self.WMASK}, 0x1111")
         self.salu(f"s_mov_b32 s{self.WMASK + 1}, 0")
         self.go_first()
-        self.label(self.L("unused"))
-        for name, K0, K1, hand_over in self.PRE_VARIANTS:
-            self.pre_body(name, K0, K1, hand_over)
+        for parity in (0, 1):
+            self.label(self.L(f"block{parity}"))
+            for name, K0, K1, hand_over in self.PRE_VARIANTS:
+                self.pre_body(name, K0, K1, hand_over, parity)
+            # the way out: behind the last step (its descriptor is in the other set) the last two edge sums
+            self.label(self.L(f"out_{parity}"))
+            self.p = parity
+            self.flush_addresses(self.other(self.E0), self.other(self.E1))
+            self.branch(None, self.L("done"))
         self.label(self.L("done"))
-        # the last step's two edges
         self.flush_stage1(self.ES[0], self.ES[1])
-        self.flush_stage2(self.EPREV[0], self.EPREV[1])
+        self.flush_stage2()
         self.flush_stage3()
         self.wait(vm=0, lgkm=0)
         return e
