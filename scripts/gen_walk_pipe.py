@@ -293,7 +293,7 @@ class Loops:
         S = Alloc(SBASE, SLIMIT, "SGPR")
         g2 = lambda name: [V.get(2, f"{name}{g}", 2) for g in range(G)]
         # persistent
-        self.TMV = V.get(self.MAX_TIPS, "TMV")   # packed masks of tip t (byte g = mask of this lane's pattern in group g)
+        self.TMV = V.get(32, "TMV", 4)   # packed masks of tip t (byte g = mask of this lane's pattern in group g); 32 slots
         self.U = g2("U")                      # pre-order partial of the step's node
         self.ONE = V.get(2, "ONE", 2)
         self.SH = [V.get(1, f"SH{g}") for g in range(G)]   # 30 - state - 8 g
@@ -467,7 +467,7 @@ class Loops:
         self.idx_on(tip_sgpr, "SRC1")
         for g in range(self.G):
             hi = self.TP[slot_tip][g] + 1
-            self.valu(f"v_lshlrev_b32 v{hi}, v{self.SH[g]}, v{self.TMV}", [self.SH[g]] + list(range(self.TMV, self.TMV + self.MAX_TIPS)), [hi],
+            self.valu(f"v_lshlrev_b32 v{hi}, v{self.SH[g]}, v{self.TMV}", [self.SH[g]] + list(range(self.TMV, self.TMV + 32)), [hi],
                       indexed_ok=True)
         self.idx_off()
         for g in range(self.G):
@@ -550,13 +550,10 @@ class Loops:
         for t in range(4):
             for g in range(G):
                 self.v32(f"v_mov_b32 v{self.TP[t][g]}, 0", [], [self.TP[t][g]])
-        # packed masks of tip t into TMV[t]
-        a = self.AD[0]
-        self.v32(f"v_mov_b32 v{a}, %[tiprow]", [], [a])
-        for t in range(self.MAX_TIPS):
-            self.mem(f"ds_read_b32 v{self.TMV + t}, v{a}", mem_reads=[a], writes=[self.TMV + t])
-            if t + 1 < self.MAX_TIPS:
-                self.v32(f"v_add_u32 v{a}, %[tipstride], v{a}", [a], [a])
+        # packed masks of tip t into TMV[t]: this lane's 32 tip slots are 128 consecutive bytes
+        for k in range(8):
+            self.mem(f"ds_read_b128 v[{self.TMV + 4 * k}:{self.TMV + 4 * k + 3}], %[tiprow] offset:{16 * k}",
+                     writes=list(range(self.TMV + 4 * k, self.TMV + 4 * k + 4)))
         self.e.control(f"s_getpc_b64 s[{self.BASE[0]}:{self.BASE[0] + 1}]")
         self.e.label(self.L("here"))
         # BASE[p] = address of parity p's block of bodies
