@@ -481,7 +481,8 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
     e->kernel_name = use_tree ? "walk_tree_kernel" : (use_pipe ? "walk_pipe_kernel" : "walk_lds_kernel");
     e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
-    LaunchReduce(d, b, tiles, want_gradient, e->stream, grad_rows);
+    // (walk_pipe_kernel's partial log-likelihoods are per run of tiles as well)
+    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, e->stream, grad_rows);
     HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
     HIP_TRY(e, hipGetLastError());
     return BITO_AMD_OK;
