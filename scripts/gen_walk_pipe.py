@@ -31,6 +31,7 @@ WS_MFMA_MFMA_AB = 6   # matrix result -> matrix A/B operand
 WS_MFMA_MFMA_C = 4    # matrix result -> matrix C operand
 WS_MFMA_MEM = 9       # matrix result -> store data / address of a memory or LDS instruction
 WS_VALU_MFMA = 2      # VALU result -> matrix operand
+SETPC_WAIT_STATES = 4 # what the 21 cycles of a taken s_setpc_b64 count for
 
 VBASE = 32   # first VGPR the loops may use (v0..v31 and a224.. stay with the compiler)
 VLIMIT = 256
@@ -122,9 +123,11 @@ class Emitter:
     def label(self, name):
         self.items.append(("label", name))
 
-    def control(self, text):
-        """branch / jump: nothing moves across it"""
-        self.items.append(("control", text))
+    def control(self, text, settled=False):
+        """branch / jump: nothing moves across it.  settled: the code at the target reads no matrix result and
+        feeds no matrix instruction before it has waited, so the hazard bookkeeping just carries on with the
+        fall-through path"""
+        self.items.append(("control_settled" if settled else "control", text))
 
     def ins(self, text, kind, reads=(), writes=(), mem_reads=(), reads_c=(), indexed=False):
         self.items.append(Ins(text, kind, reads, writes, mem_reads, reads_c, indexed))
@@ -192,8 +195,8 @@ class Emitter:
             if worst > 0:
                 nop(worst)
 
-        def drain():
-            need = max(WS_MFMA_MEM - (pos - last_mfma - 1), WS_VALU_MFMA - (pos - last_valu - 1), 0)
+        def drain(credit=0):
+            need = max(WS_MFMA_MEM - (pos - last_mfma - 1), WS_VALU_MFMA - (pos - last_valu - 1), 0) - credit
             if need > 0:
                 nop(need)
             writer.clear()
@@ -207,7 +210,11 @@ class Emitter:
                     drain()
                     lines.append(f"{text}:")
                 elif tag == "control":
-                    drain()
+                    # (a jump keeps the wave from issuing for 21 cycles, measured: worth four wait states)
+                    drain(credit=SETPC_WAIT_STATES if text.startswith("s_setpc") else 0)
+                    lines.append(text)
+                    pos += 1
+                elif tag == "control_settled":
                     lines.append(text)
                     pos += 1
                 else:
@@ -296,7 +303,6 @@ class Loops:
         self.TMV = V.get(32, "TMV", 4)   # packed masks of tip t (byte g = mask of this lane's pattern in group g); 32 slots
         self.U = g2("U")                      # pre-order partial of the step's node
         self.ONE = V.get(2, "ONE", 2)
-        self.SH = [V.get(1, f"SH{g}") for g in range(G)]   # 30 - state - 8 g
         self.TP = [[V.get(2, f"TP{t}_{g}", 2) for g in range(G)] for t in range(4)]  # tip operands (lo word stays 0)
         self.M = [g2("M0_"), g2("M1_")]       # child messages out of LDS (slot 0, slot 1)
         self.ES = [V.get(2, "ES0", 2), V.get(2, "ES1", 2)]  # per-lane sums of the two child edges (flushed one step late)
@@ -340,6 +346,8 @@ class Loops:
     (FLAGS, OWN, NOWN, OFFC0, OFFC1, NOFFC0, NOFFC1, IMG0, IMG1, IMGOWN, TIPA0, TIPB0, TIPA1, TIPB1, E0, E1) = range(16)
 
     def cur(self, w):
+        if self.own_set_requested:
+            raise RuntimeError("this step's descriptor set has been handed to the scalar load already")
         return f"s{self.DESC[self.p] + w}"
 
     def other(self, w):
@@ -347,6 +355,7 @@ class Loops:
 
     # ---- instruction helpers --------------------------------------------------------------------
     idx_mode = None  # None | "SRC0" | "SRC1" while the VGPR index mode is on
+    own_set_requested = False  # post-order: the step's own descriptor set already receives the step after next's
 
     def idx_on(self, sgpr, which):
         self.salu(f"s_set_gpr_idx_on {sgpr}, gpr_idx({which})")
@@ -413,8 +422,8 @@ class Loops:
     def label(self, name):
         self.e.label(name)
 
-    def branch(self, cond, target):
-        self.e.control(f"s_cbranch_{cond} {target}" if cond else f"s_branch {target}")
+    def branch(self, cond, target, settled=False):
+        self.e.control(f"s_cbranch_{cond} {target}" if cond else f"s_branch {target}", settled)
 
     def L(self, name):
         return f".Lwp_{self.tag}_{name}_%="
@@ -461,18 +470,26 @@ class Loops:
     def cell_ops(self):  # LDS instructions per cell access
         return (self.G + 1) // 2
 
-    # tip operands of all groups from the packed masks of the tip whose id is in `tip_sgpr`:
-    # 2.0 where the state is allowed (the hi word's bit 30), else 0
+    # tip operands of all groups from the packed masks of the tip whose id is in `tip_sgpr`: 2.0 where the
+    # state is allowed (the hi word's bit 30), else 0.  A lane's copy of a packed mask keeps only the bit of the
+    # lane's own state in every byte (specialise_masks), so byte g shifted by 30 - state is the hi word: one
+    # SDWA instruction per group
     def tip_operands(self, slot_tip, tip_sgpr):
         self.idx_on(tip_sgpr, "SRC1")
         for g in range(self.G):
             hi = self.TP[slot_tip][g] + 1
-            self.valu(f"v_lshlrev_b32 v{hi}, v{self.SH[g]}, v{self.TMV}", [self.SH[g]] + list(range(self.TMV, self.TMV + 32)), [hi],
-                      indexed_ok=True)
+            self.valu(f"v_lshlrev_b32_sdwa v{hi}, %[sh0], v{self.TMV} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "
+                      f"src1_sel:BYTE_{g}", list(range(self.TMV, self.TMV + 32)), [hi], indexed_ok=True)
         self.idx_off()
-        for g in range(self.G):
-            hi = self.TP[slot_tip][g] + 1
-            self.v32(f"v_and_b32 v{hi}, 2.0, v{hi}", [hi], [hi])
+
+    def specialise_masks(self):
+        """TMV[t] &= 0x01010101 << state: what is left of byte g is the bit tip_operands shifts to bit 30"""
+        k = self.AD[5]
+        self.v32(f"v_sub_u32 v{k}, 30, %[sh0]", [], [k])
+        self.v32(f"v_mov_b32 v{self.AD[4]}, 0x01010101", [], [self.AD[4]])
+        self.v32(f"v_lshlrev_b32 v{k}, v{k}, v{self.AD[4]}", [k, self.AD[4]], [k])
+        for t in range(32):
+            self.v32(f"v_and_b32 v{self.TMV + t}, v{k}, v{self.TMV + t}", [k, self.TMV + t], [self.TMV + t])
 
     # ---- edge sums: 64 lanes -> one value per block (rate category), written by lanes 0,4,8,12 ----
     def flush_stage1(self, ea, eb):
@@ -504,6 +521,15 @@ class Loops:
         self.salu(f"s_add_u32 s{self.TABOFF}, s{self.TABOFF}, 64")
         self.mem(f"s_load_dwordx16 s[{d}:{d + 15}], s[{self.TAB}:{self.TAB + 1}], s{self.TABOFF}")
 
+    def request_descriptor_after_next(self):
+        """post-order: the descriptor of the step AFTER the next one into this step's own set, once the body has
+        read the last of its own fields -- it is waited for half a step later, in the next body, together
+        with that body's operands, so that no body waits for a scalar load or a store it has just issued"""
+        d = self.DESC[self.p]
+        self.salu(f"s_add_u32 s{self.TABOFF}, s{self.TABOFF}, 64")
+        self.mem(f"s_load_dwordx16 s[{d}:{d + 15}], s[{self.TAB}:{self.TAB + 1}], s{self.TABOFF}")
+        self.own_set_requested = True
+
     def next_pc(self):
         """code address of the next step's body (this step's flags, bits 4..7; the body of the other parity)
         into PC; the jump itself comes last"""
@@ -515,15 +541,21 @@ class Loops:
         self.salu(f"s_add_u32 s{self.PC}, s{base}, s{t}")
         self.salu(f"s_addc_u32 s{self.PC + 1}, s{base + 1}, 0")
 
-    def go_first(self):
+    def go_first(self, delayed_store=False):
         """from the loop prologue into the first step (parity 0): its descriptor has landed in DESC[0], its
         stored operands are requested here"""
         ad = self.AD
         t = self.TMP
         self.p = 0
+        self.own_set_requested = False
         self.wait(lgkm=0)
+        self.specialise_masks()
         self.v32(f"v_add_u32 v{ad[0]}, {self.cur(self.OFFC0)}, %[arena]", [], [ad[0]])
         self.v32(f"v_add_u32 v{ad[1]}, {self.cur(self.OFFC1)}, %[arena]", [], [ad[1]])
+        if delayed_store:
+            # every post-order body first stores the PREVIOUS step's message; the first one stores whatever is
+            # in those registers into its own node's cell, which the real message overwrites a step later
+            self.v32(f"v_add_u32 v{ad[6]}, {self.cur(self.OWN)}, %[arena]", [], [ad[6]])
         self.cell_read(self.M[0], ad[0])
         self.cell_read(self.M[1], ad[1])
         self.salu(f"s_and_b32 m0, {self.cur(self.FLAGS)}, 15")
@@ -537,16 +569,17 @@ class Loops:
     def go(self):
         self.e.control(f"s_setpc_b64 s[{self.PC}:{self.PC + 1}]")
 
-    def loop_entry(self, names):
-        """common prologue: first descriptor, constants, the tile's tip masks, the table of body offsets
-        (relative to the start of a parity's block of bodies; entry 10: that block's way out of the loop)"""
+    def loop_entry(self, names, two_ahead=False):
+        """common prologue: first descriptor (post-order: the first two), constants, the tile's tip masks, the
+        table of body offsets (relative to the start of a parity's block of bodies; entry 10: that block's
+        way out of the loop)"""
         G = self.G
         self.salu(f"s_mov_b64 s[{self.TAB}:{self.TAB + 1}], %[tab]")
-        self.salu(f"s_mov_b32 s{self.TABOFF}, 0")
+        self.salu(f"s_mov_b32 s{self.TABOFF}, {64 if two_ahead else 0}")
         self.salu(f"s_mov_b32 s{self.CNT}, %[steps]")
         self.mem(f"s_load_dwordx16 s[{self.DESC[0]}:{self.DESC[0] + 15}], s[{self.TAB}:{self.TAB + 1}], 0x0")
-        for g in range(G):
-            self.v32(f"v_subrev_u32 v{self.SH[g]}, {8 * g}, %[sh0]", [], [self.SH[g]])
+        if two_ahead:
+            self.mem(f"s_load_dwordx16 s[{self.DESC[1]}:{self.DESC[1] + 15}], s[{self.TAB}:{self.TAB + 1}], 0x40")
         for t in range(4):
             for g in range(G):
                 self.v32(f"v_mov_b32 v{self.TP[t][g]}, 0", [], [self.TP[t][g]])
@@ -618,10 +651,17 @@ class Loops:
     PRE_VARIANTS = [(n, a, b, False) for n, a, b in KINDS] + [(n + "f", a, b, True) for n, a, b in KINDS if b == "C"]
 
     def post_body(self, name, K0, K1, hand_over, parity):
+        """What a body waits for is a step old: its stored operands were requested by the previous body under
+        that body's matrix instructions, its descriptor by the body before that, and its own message is stored
+        by the NEXT body (LDS executes a wave's instructions in order, so a parent's read, which is issued
+        later still, finds it).  The one s_waitcnt of a body therefore never sees a request younger than the
+        tip work in front of it."""
         G = self.G
         self.p = parity
+        self.own_set_requested = False
         kinds = (K0, K1)
-        own = self.M[1] if hand_over else self.UC[1]
+        held = self.DQ[0]  # the step's message until the next body stores it (registers the pre-order loop owns)
+        own = self.M[1] if hand_over else held
         ad = self.AD
         self.label(self.L(f"{name}_{parity}"))
         self.e.comment(f"post-order step, children ({K0},{K1})" + (", message handed to the next step" if hand_over else "")
@@ -629,7 +669,8 @@ class Loops:
         self.salu(f"s_sub_u32 s{self.CNT}, s{self.CNT}, 1")
         self.next_pc()
         self.messages(kinds)
-        self.request_descriptor()
+        self.wait(lgkm=0)  # stored operands, the next step's descriptor (and stores two steps old)
+        self.cell_write(held, ad[6])  # the previous step's message
         # x = m0 . m1 (the node's partial); the root's leaves the loop in X[0]
         m0, m1 = self.msg(0, K0), self.msg(1, K1)
         for g in range(G):
@@ -639,18 +680,20 @@ class Loops:
             self.v32(f"v_add_u32 v{ad[1]}, {self.cur(self.NOFFC1)}, %[arena]", [], [ad[1]])
         self.v32(f"v_add_u32 v{ad[6]}, {self.cur(self.OWN)}, %[arena]", [], [ad[6]])
         self.salu(f"s_cmp_eq_u32 s{self.CNT}, 0")
-        self.branch("scc1", self.L("root"))
+        self.branch("scc1", self.L("root"), settled=True)  # (root: s_waitcnt, then copies of X[0], which VALU wrote)
         # own message a = P_v x (straight into the next step's slot-1 registers when it is handed over), the
-        # next step's stored operands requested underneath
+        # next step's stored operands and the descriptor after it requested underneath
         self.idx_on(self.cur(self.IMGOWN), "SRC0")
+        self.request_descriptor_after_next()
         for g in range(G):
             self.mfma(own[g], ("A", 0), self.X[0][g])
         self.cell_read(self.M[0], ad[0])
         if not hand_over:
             self.cell_read(self.M[1], ad[1])
         self.idx_off()
-        self.cell_write(own, ad[6])
-        self.wait(lgkm=0)  # requests, next descriptor (and the stores: scalar loads and LDS share the counter)
+        if hand_over:
+            for g in range(G):
+                self.vmov64(held[g], own[g])
         self.go()
 
     def post_loop(self):
@@ -660,8 +703,8 @@ class Loops:
         e = self.e
         e.comment(f"post-order loop, G = {G}")
         names = [v[0] for v in self.POST_VARIANTS]
-        self.loop_entry(names)
-        self.go_first()
+        self.loop_entry(names, two_ahead=True)
+        self.go_first(delayed_store=True)
         for parity in (0, 1):
             self.label(self.L(f"block{parity}"))
             for name, K0, K1, hand_over in self.POST_VARIANTS:
@@ -824,6 +867,14 @@ class Loops:
         e = self.e
         e.comment("matrix images of the whole tree into the AGPR file")
         ip = self.IMGP
+        # the step tables into the scalar cache: %[lines] descriptors of 64 bytes behind %[tab]
+        warm = self.L("warm")
+        for k in range(2 * (self.MAX_TIPS + 1)):
+            if k % 4 == 0:
+                self.salu(f"s_cmp_le_u32 %[lines], {k}")
+                self.e.control(f"s_cbranch_scc1 {warm}")
+            self.mem(f"s_load_dword s{self.TMP[2]}, %[tab], {hex(64 * k)}")
+        self.e.label(warm)
         self.salu(f"s_mov_b64 s[{ip}:{ip + 1}], %[img]")
         done = self.L("done")
         for b in range(self.MAX_BRANCHES):
@@ -835,7 +886,7 @@ class Loops:
                 self.salu(f"s_add_u32 s{ip}, s{ip}, 4096")
                 self.salu(f"s_addc_u32 s{ip + 1}, s{ip + 1}, 0")
         self.e.label(done)
-        self.wait(vm=0)
+        self.wait(vm=0, lgkm=0)
         return e
 
 
