@@ -55,7 +55,7 @@ BODY(k_exec, "s_cselect_b64 exec, -1, -1\n")
     __syncthreads();                                                                              \
     const unsigned* p = tab + (blockIdx.x % 64) * 256;                                            \
     long long t0 = clock64();                                                                     \
-    for (int it = 0; it < 16; it++) asm volatile(REP64(text) : "+v"(a), "+v"(b) : "s"(p), "v"(la) : "v100", "v101", "v102", "v103", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "memory"); \
+    for (int it = 0; it < 16; it++) asm volatile(REP64(text) : "+v"(a), "+v"(b) : "s"(p), "v"(la) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "memory"); \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");                                                \
     long long t1 = clock64();                                                                     \
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                    \
@@ -71,6 +71,14 @@ BODY2(k_setpc, "s_getpc_b64 s[40:41]\n s_add_u32 s40, s40, 16\n s_addc_u32 s41, 
 BODY2(k_mfma_agpr_idx, "s_set_gpr_idx_on s42, gpr_idx(SRC0)\n v_mfma_f64_4x4x4_4b_f64 v[100:101], a[0:1], %1, 0\n v_mfma_f64_4x4x4_4b_f64 v[102:103], a[0:1], %1, 0\n s_set_gpr_idx_off\n")
 BODY2(k_mfma_then_mul, "v_mfma_f64_4x4x4_4b_f64 v[100:101], %0, %1, 0\n s_nop 5\n v_mul_f64 v[102:103], v[100:101], %1\n")
 BODY2(k_4mfma_4mul, "v_mfma_f64_4x4x4_4b_f64 v[100:101], %0, %1, 0\n v_mfma_f64_4x4x4_4b_f64 v[102:103], %0, %1, 0\n v_mfma_f64_4x4x4_4b_f64 v[100:101], %0, %1, 0\n v_mfma_f64_4x4x4_4b_f64 v[102:103], %0, %1, 0\n v_mul_f64 v[100:101], %0, %1\n v_mul_f64 v[102:103], %0, %1\n v_mul_f64 v[100:101], %0, %1\n v_mul_f64 v[102:103], %0, %1\n")
+#define MF "v_mfma_f64_4x4x4_4b_f64 v[100:101], %0, %1, 0\n"
+BODY2(k_mfma_dsread128, MF "ds_read_b128 v[104:107], %3\n")
+BODY2(k_4mfma_4dsread128, MF MF MF MF "ds_read_b128 v[104:107], %3\n ds_read_b128 v[104:107], %3\n ds_read_b128 v[104:107], %3\n ds_read_b128 v[104:107], %3\n")
+BODY2(k_mfma_dswrite128, MF "ds_write_b128 %3, v[104:107]\n")
+BODY2(k_4mfma_2dswrite128, MF MF MF MF "ds_write_b128 %3, v[104:107]\n ds_write_b128 %3, v[104:107]\n")
+BODY2(k_mfma_4salu, MF "s_add_u32 s40, s41, 1\n s_add_u32 s42, s41, 1\n s_add_u32 s43, s41, 1\n s_add_u32 s44, s41, 1\n")
+BODY2(k_mfma_salu_dsread, MF "s_add_u32 s40, s41, 1\n ds_read_b128 v[104:107], %3\n")
+BODY2(k_4mfma, MF MF MF MF)
 
 int main() {
   long long* out; double* sink; hipMalloc(&out, 8); hipMalloc(&sink, 256 * 256 * 8);
@@ -87,5 +95,7 @@ int main() {
     printf("%-20s %7.2f cycles per repetition (%d instr)\n", #k, c / 1024.0, n); }
   RUN2(k_sload_wait, 2) RUN2(k_sload_wait_far, 4) RUN2(k_dsread128_wait, 2) RUN2(k_dsread128, 1) RUN2(k_dswrite128, 1) RUN2(k_dswrite128_wait, 2) RUN2(k_setpc, 4)
   RUN2(k_mfma_agpr_idx, 4) RUN2(k_mfma_then_mul, 3) RUN2(k_4mfma_4mul, 8)
+  RUN2(k_mfma_dsread128, 2) RUN2(k_4mfma_4dsread128, 8) RUN2(k_mfma_dswrite128, 2) RUN2(k_4mfma_2dswrite128, 6) RUN2(k_mfma_4salu, 5)
+  RUN2(k_mfma_salu_dsread, 3) RUN2(k_4mfma, 4)
     return 0;
 }

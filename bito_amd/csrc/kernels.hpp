@@ -133,6 +133,7 @@ struct LdsPlan {
   size_t lds_bytes;
   int tile_run = 1;    // (walk_pipe_kernel) consecutive tiles of a tree walked by one workgroup
   int grad_rows = 0;   // (walk_pipe_kernel) partial gradient rows per tree: one per run; 0 = one per tile
+  int whole_trees = 0; // (walk_pipe_kernel) the first so many trees are walked by one workgroup each, all tiles
 };
 LdsPlan PlanLds(const BatchDims& d);
 size_t LdsScheduleInts(const BatchDims& d);
