@@ -63,6 +63,7 @@ struct bito_amd_engine {
   // other of two buffer sets.  Events order the two streams: a set is not rewritten before the
   // traversal that read it has finished, and a traversal does not start before its set is ready.
   hipStream_t prep_stream = nullptr;
+  bool serial_setup = false;  // BITO_AMD_SERIAL_SETUP=1 (measurements): the set-up kernels run on `stream`, in front of the traversal
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_walk_done[2] = {nullptr, nullptr};
   unsigned run_counter = 0;
   std::string err;
@@ -457,17 +458,18 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
       }
     }
     const DeviceBatch b = MakeBatch(e, set);
-    HIP_TRY(e, hipStreamWaitEvent(e->prep_stream, e->ev_walk_done[set], 0));
-    LaunchSetup(d, e->spec, b, want_gradient, e->prep_stream);
+    hipStream_t prep = e->serial_setup ? e->stream : e->prep_stream;
+    HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_walk_done[set], 0));
+    LaunchSetup(d, e->spec, b, want_gradient, prep);
     if (use_pipe) {
-      LaunchPipeImages(d, b, e->prep_stream);
-      LaunchPipeSchedule(d, b, plan, e->prep_stream);
-      if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), e->prep_stream);
+      LaunchPipeImages(d, b, prep);
+      LaunchPipeSchedule(d, b, plan, prep);
+      if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);
     } else {
-      LaunchMatrixImages(d, b, want_gradient, deriv_mode, e->prep_stream);
-      if (use_lds) LaunchLdsSchedule(d, b, plan, e->prep_stream);
+      LaunchMatrixImages(d, b, want_gradient, deriv_mode, prep);
+      if (use_lds) LaunchLdsSchedule(d, b, plan, prep);
     }
-    HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], e->prep_stream));
+    HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
     HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_prep_done[set], 0));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing) {
@@ -589,6 +591,7 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
     if ((hrc = hipStreamCreateWithPriority(&e->prep_stream, hipStreamNonBlocking, least)) != hipSuccess)
       return dev_fail("hipStreamCreate", hrc);
   }
+  if (const char* serial = std::getenv("BITO_AMD_SERIAL_SETUP")) e->serial_setup = std::atoi(serial) != 0;
   for (int i = 0; i < 2; i++) {
     if ((hrc = hipEventCreateWithFlags(&e->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess ||
         (hrc = hipEventCreateWithFlags(&e->ev_walk_done[i], hipEventDisableTiming)) != hipSuccess)

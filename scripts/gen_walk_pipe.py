@@ -491,8 +491,15 @@ class Loops:
         for t in range(32):
             self.v32(f"v_and_b32 v{self.TMV + t}, v{k}, v{self.TMV + t}", [k, self.TMV + t], [self.TMV + t])
 
-    # ---- edge sums: 64 lanes -> one value per block (rate category), written by lanes 0,4,8,12 ----
+    # ---- edge sums: 64 lanes -> the gradient row entries of the four blocks (rate categories) ----
+    # One matrix instruction sums over the states (R_b[i][j] = sum_k E[16k+4b+i], the same for every j); the lanes
+    # with j = 0 -- sixteen, four per block -- then add their values to the block's row entry in LDS (ds_add_f64:
+    # four lanes per address, which the LDS unit takes one after the other, in lane order).
     def flush_stage1(self, ea, eb):
+        if os.environ.get("PIPE_FLUSH_ALL_LANES"):  # experiment: every lane adds its own value (16 per address)
+            self.flush_src = (ea, eb)
+            return
+        self.flush_src = (self.R[0], self.R[1])
         self.mfma(self.R[0], ea, self.ONE)
         self.mfma(self.R[1], eb, self.ONE)
 
@@ -501,16 +508,16 @@ class Loops:
         self.v32(f"v_add_u32 v{self.AD[6]}, {off0}, %[grow]", [], [self.AD[6]])
         self.v32(f"v_add_u32 v{self.AD[7]}, {off1}, %[grow]", [], [self.AD[7]])
 
-    def flush_stage2(self):
-        self.mfma(self.T[0], self.ONE, self.R[0])
-        self.mfma(self.T[1], self.ONE, self.R[1])
-
     def flush_stage3(self):
-        self.salu(f"s_mov_b64 exec, s[{self.WMASK}:{self.WMASK + 1}]")
+        r0, r1 = self.flush_src
+        all_lanes = bool(os.environ.get("PIPE_FLUSH_ALL_LANES"))
+        if not all_lanes:
+            self.salu(f"s_mov_b64 exec, s[{self.WMASK}:{self.WMASK + 1}]")
         # (accumulate: the rows are summed over the tiles of a run)
-        self.mem(f"ds_add_f64 v{self.AD[6]}, {vp(self.T[0])}", mem_reads=[self.AD[6], self.T[0], self.T[0] + 1])
-        self.mem(f"ds_add_f64 v{self.AD[7]}, {vp(self.T[1])}", mem_reads=[self.AD[7], self.T[1], self.T[1] + 1])
-        self.salu("s_mov_b64 exec, -1")
+        self.mem(f"ds_add_f64 v{self.AD[6]}, {vp(r0)}", mem_reads=[self.AD[6], r0, r0 + 1])
+        self.mem(f"ds_add_f64 v{self.AD[7]}, {vp(r1)}", mem_reads=[self.AD[7], r1, r1 + 1])
+        if not all_lanes:
+            self.salu("s_mov_b64 exec, -1")
         return 2
 
     # ---- descriptor pipeline ----
@@ -744,7 +751,6 @@ class Loops:
             if kinds[s] != "C":
                 for g in range(G):
                     self.mfma(self.DQ[s][g], "Q", self.MSG[s][g])
-        self.flush_stage2()
         self.wait(lgkm=0)  # U when it came out of LDS; the next step's descriptor
         # w_s = U . (message of the other child)
         m0, m1 = self.msg(0, K0), self.msg(1, K1)
@@ -790,8 +796,11 @@ class Loops:
                     self.vmul(self.ES[s], self.W[s][g], self.DQ[s][g])
                 else:
                     self.vfma(self.ES[s], self.W[s][g], self.DQ[s][g], self.ES[s])
-        # cherry children: the two tip edges under each (gradient rows 8 x tip id)
+        # cherry children: the two tip edges under each (gradient rows 8 x tip id).  A cherry's sums leave for
+        # LDS behind the next block of work (the second cherry's matrix instructions, or this step's stores): a
+        # matrix result is not storable for nine wait states
         nst = 0
+        pending = False
         for s in (0, 1):
             if kinds[s] != "H":
                 continue
@@ -802,6 +811,9 @@ class Loops:
             self.salu(f"s_lshl_b32 s{t[2]}, {self.cur(tip[s][1])}, 3")
             for g in range(G):
                 self.mfma(DQB[g], "Q", self.MB[s][g])
+            if pending:
+                nst += self.flush_stage3()
+                pending = False
             for g in range(G):
                 self.vmul(TA[g], self.X[s][g], self.MB[s][g])
                 self.vmul(TB[g], self.X[s][g], self.MA[s][g])
@@ -814,13 +826,14 @@ class Loops:
                     self.vfma(self.EB, TB[g], DQB[g], self.EB)
             self.flush_addresses(f"s{t[1]}", f"s{t[2]}")
             self.flush_stage1(self.EA, self.EB)
-            self.flush_stage2()
-            nst += self.flush_stage3()
+            pending = True
         # this step's stores
         if K0 == "C":
             nst += self.cell_write(self.UC[0], ad[3])
         if K1 == "C":
             nst += self.cell_write(self.U if hand_over else self.UC[1], ad[4])
+        if pending:
+            nst += self.flush_stage3()
         self.wait(lgkm=nst)  # everything requested has landed; the stores may still travel
         self.go()
 
@@ -840,8 +853,8 @@ class Loops:
         # the first body flushes "the previous step's" edge sums: zeros, into the root's slot
         self.salu(f"s_mov_b32 s{self.DESC[1] + self.E0}, %[rootedge]")
         self.salu(f"s_mov_b32 s{self.DESC[1] + self.E1}, %[rootedge]")
-        self.salu(f"s_mov_b32 s{self.WMASK}, 0x1111")
-        self.salu(f"s_mov_b32 s{self.WMASK + 1}, 0")
+        self.salu(f"s_mov_b32 s{self.WMASK}, 0x11111111")  # lanes 16 i + 4 b: column 0 of every block's row sums
+        self.salu(f"s_mov_b32 s{self.WMASK + 1}, 0x11111111")
         self.go_first()
         for parity in (0, 1):
             self.label(self.L(f"block{parity}"))
@@ -854,7 +867,6 @@ class Loops:
             self.branch(None, self.L("done"))
         self.label(self.L("done"))
         self.flush_stage1(self.ES[0], self.ES[1])
-        self.flush_stage2()
         self.flush_stage3()
         self.wait(vm=0, lgkm=0)
         return e
