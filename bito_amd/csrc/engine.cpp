@@ -59,12 +59,17 @@ struct bito_amd_engine {
   uint64_t arena_limit = 0;
   hipStream_t stream = nullptr;
   // Set-up pipeline of the LDS kernels: the set-up kernels of pass k+1 (topology, model, matrix images,
-  // step tables) run on prep_stream while pass k's traversal is still on `stream`; they write into the
-  // other of two buffer sets.  Events order the two streams: a set is not rewritten before the
-  // traversal that read it has finished, and a traversal does not start before its set is ready.
+  // step tables) run on prep_stream while earlier passes' traversals are still on `stream`; they write into the
+  // next of kSets buffer sets.  Events order the two streams: a set is not rewritten before the traversal that
+  // read it has finished, and a traversal does not start before its set is ready.  Three sets: the set-up of
+  // pass k+1 may start when pass k-2 has finished, a whole pass before it is needed -- walk_pipe_kernel keeps
+  // every CU until its queue of work is empty, so the set-up kernels mostly run in the tail of a traversal,
+  // and with two sets the next traversal waited for them there.
   hipStream_t prep_stream = nullptr;
-  bool serial_setup = false;  // BITO_AMD_SERIAL_SETUP=1 (measurements): the set-up kernels run on `stream`, in front of the traversal
-  hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_walk_done[2] = {nullptr, nullptr};
+  int serial_setup = 0;  // BITO_AMD_SERIAL_SETUP (measurements): 1 = the set-up kernels run on `stream`, in front of the traversal;
+                         // 2 = no set-up and no events after the first kSets passes (the buffer sets keep what they hold)
+  static constexpr int kSets = 3;
+  hipEvent_t ev_prep_done[kSets] = {nullptr, nullptr, nullptr}, ev_walk_done[kSets] = {nullptr, nullptr, nullptr};
   unsigned run_counter = 0;
   std::string err;
   int kernel_choice = BITO_AMD_KERNEL_AUTO;
@@ -77,13 +82,14 @@ struct bito_amd_engine {
   bool resident = false;
   BatchDims dims{};
   bool has_rates = false;
-  DeviceBuffer<int32_t> parent_ids, children, sched, children2, sched2;
+  DeviceBuffer<int32_t> parent_ids, children, sched, children2, sched2, children3, sched3;
   DeviceBuffer<int32_t> pipe_masks;  // packed tip masks per pattern tile (walk_pipe_kernel): a function of the alignment and the plan
   long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
+  DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
   DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
-      out_ll, out_grad, out_site, scale_arena, branch2, images2;
+      out_ll, out_grad, out_site, scale_arena, branch2, images2, branch3, images3;
   bool site_ready = false;  // out_site holds the site-model gradient of the resident pass
-  DeviceBuffer<TreeModel> model, model2;
+  DeviceBuffer<TreeModel> model, model2, model3;
   DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
   DeviceBuffer<int32_t> gs_model_index;  // [T] first tree with the same parameter row
   bool gs_index_valid = false;           // the index was built from the parameter rows that are resident now
@@ -105,8 +111,9 @@ struct bito_amd_engine {
     part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
     tt_out.Free(); tt_aux.Free();
-    children2.Free(); sched2.Free(); pipe_masks.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
-    for (int i = 0; i < 2; i++) {
+    children2.Free(); sched2.Free(); pipe_masks.Free(); pipe_queue.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
+    children3.Free(); sched3.Free(); branch3.Free(); images3.Free(); model3.Free();
+    for (int i = 0; i < kSets; i++) {
       if (ev_prep_done[i]) (void)hipEventDestroy(ev_prep_done[i]);
       if (ev_walk_done[i]) (void)hipEventDestroy(ev_walk_done[i]);
     }
@@ -303,13 +310,14 @@ DeviceBatch MakeBatch(bito_amd_engine* e, int set = 0) {
   b.params = e->params.ptr;
   b.tip_states = e->tip_states.ptr;
   b.weights = e->weights.ptr;
-  b.children = set ? e->children2.ptr : e->children.ptr;
-  b.branch = set ? e->branch2.ptr : e->branch.ptr;
-  b.model = set ? e->model2.ptr : e->model.ptr;
+  b.children = (set == 0 ? e->children : set == 1 ? e->children2 : e->children3).ptr;
+  b.branch = (set == 0 ? e->branch : set == 1 ? e->branch2 : e->branch3).ptr;
+  b.model = (set == 0 ? e->model : set == 1 ? e->model2 : e->model3).ptr;
   b.mats = e->mats.ptr;
-  b.images = set ? e->images2.ptr : e->images.ptr;
-  b.sched = set ? e->sched2.ptr : e->sched.ptr;
+  b.images = (set == 0 ? e->images : set == 1 ? e->images2 : e->images3).ptr;
+  b.sched = (set == 0 ? e->sched : set == 1 ? e->sched2 : e->sched3).ptr;
   b.pipe_masks = reinterpret_cast<const uint32_t*>(e->pipe_masks.ptr);
+  b.pipe_queue = e->pipe_queue.ptr;
   b.arena = e->arena.ptr;
   b.scale_arena = e->scale_arena.ptr;
   b.part_ll = e->part_ll.ptr;
@@ -443,11 +451,16 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   const int grad_rows = (use_pipe && plan.grad_rows > 0) ? plan.grad_rows : (use_tree || use_lds) ? tiles : tiles * (kHbmBlock / 64);
   if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * grad_rows * d.node_count));
   if (use_tree || use_lds) {
-    // pipelined: this pass's set-up goes to prep_stream and into buffer set (run_counter & 1)
-    const int set = (int)(e->run_counter++ & 1u);
-    HIP_TRY(e, (set ? e->images2 : e->images).Reserve((size_t)T * NB * kImgStride));
-    if (use_lds) HIP_TRY(e, (set ? e->sched2 : e->sched).Reserve(use_pipe ? PipeScheduleInts(d) : LdsScheduleInts(d)));
+    // pipelined: this pass's set-up goes to prep_stream and into buffer set (run_counter mod kSets)
+    const int set = (int)(e->run_counter++ % (unsigned)bito_amd_engine::kSets);
+    HIP_TRY(e, (set == 0 ? e->images : set == 1 ? e->images2 : e->images3).Reserve((size_t)T * NB * kImgStride));
+    if (use_lds)
+      HIP_TRY(e, (set == 0 ? e->sched : set == 1 ? e->sched2 : e->sched3).Reserve(use_pipe ? PipeScheduleInts(d) : LdsScheduleInts(d)));
     bool build_masks = false;
+    if (use_pipe && e->pipe_queue.capacity == 0) {
+      HIP_TRY(e, e->pipe_queue.Reserve(2));
+      HIP_TRY(e, hipMemsetAsync(e->pipe_queue.ptr, 0, 2 * sizeof(int32_t), e->stream));
+    }
     if (use_pipe) {  // the tile masks depend on the alignment and the plan only: built once
       const long long key = (long long)plan.groups | ((long long)plan.tiles << 8);
       if (e->pipe_masks_key != key) {
@@ -459,18 +472,20 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     }
     const DeviceBatch b = MakeBatch(e, set);
     hipStream_t prep = e->serial_setup ? e->stream : e->prep_stream;
-    HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_walk_done[set], 0));
-    LaunchSetup(d, e->spec, b, want_gradient, prep);
-    if (use_pipe) {
-      LaunchPipeImages(d, b, prep);
-      LaunchPipeSchedule(d, b, plan, prep);
-      if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);
-    } else {
-      LaunchMatrixImages(d, b, want_gradient, deriv_mode, prep);
-      if (use_lds) LaunchLdsSchedule(d, b, plan, prep);
+    const bool bare = e->serial_setup == 2 && e->run_counter > (unsigned)bito_amd_engine::kSets;
+    if (!bare) {
+      HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_walk_done[set], 0));
+      LaunchSetup(d, e->spec, b, want_gradient, prep);
+      if (use_pipe) {
+        LaunchPipePrepare(d, b, plan, prep);
+        if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);
+      } else {
+        LaunchMatrixImages(d, b, want_gradient, deriv_mode, prep);
+        if (use_lds) LaunchLdsSchedule(d, b, plan, prep);
+      }
+      HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
+      HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_prep_done[set], 0));
     }
-    HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
-    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_prep_done[set], 0));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing) {
       ev0 = NextEvent(e);
@@ -485,7 +500,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
     // (walk_pipe_kernel's partial log-likelihoods are per run of tiles as well)
     LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, e->stream, grad_rows);
-    HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
+    if (!bare) HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
     HIP_TRY(e, hipGetLastError());
     return BITO_AMD_OK;
   }
@@ -591,8 +606,8 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
     if ((hrc = hipStreamCreateWithPriority(&e->prep_stream, hipStreamNonBlocking, least)) != hipSuccess)
       return dev_fail("hipStreamCreate", hrc);
   }
-  if (const char* serial = std::getenv("BITO_AMD_SERIAL_SETUP")) e->serial_setup = std::atoi(serial) != 0;
-  for (int i = 0; i < 2; i++) {
+  if (const char* serial = std::getenv("BITO_AMD_SERIAL_SETUP")) e->serial_setup = std::atoi(serial);
+  for (int i = 0; i < bito_amd_engine::kSets; i++) {
     if ((hrc = hipEventCreateWithFlags(&e->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess ||
         (hrc = hipEventCreateWithFlags(&e->ev_walk_done[i], hipEventDisableTiming)) != hipSuccess)
       return dev_fail("hipEventCreate", hrc);
@@ -674,6 +689,9 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   HIP_TRY(e, e->children2.Reserve(T * (n - 1) * 2));
   HIP_TRY(e, e->branch2.Reserve(T * N));
   HIP_TRY(e, e->model2.Reserve(T));
+  HIP_TRY(e, e->children3.Reserve(T * (n - 1) * 2));
+  HIP_TRY(e, e->branch3.Reserve(T * N));
+  HIP_TRY(e, e->model3.Reserve(T));
   HIP_TRY(e, e->out_ll.Reserve(T));
   HIP_TRY(e, e->out_grad.Reserve(T * N));
   HIP_TRY(e, e->out_site.Reserve(T));

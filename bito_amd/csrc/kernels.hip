@@ -31,10 +31,13 @@ namespace bito_amd {
 // --------------------------------------------------------------------------
 // Set-up: one thread per tree.  The per-tree recursions are serial, so what matters is that
 // their memory accesses do not queue up behind each other: a workgroup stages the wire-format
-// rows of its 16 trees in LDS with coalesced loads, each tree's thread works out of LDS, and the
-// results leave with coalesced stores (trees too large for that use the direct form).
+// rows of its trees in LDS with coalesced loads, each tree's thread works out of LDS, and the
+// results leave with coalesced stores (trees too large for that use the direct form).  As many trees per
+// workgroup as LDS holds, up to 128: the kernel runs beside the traversal of the previous pass, whose
+// workgroups need a whole CU each, so what it costs is the number of CUs it sits on (a thread takes the same
+// 50 us whether 15 or 127 others share its workgroup).
 
-constexpr int kSetupTrees = 16;  // trees per workgroup
+constexpr int kSetupTrees = 16;  // trees per workgroup of the staging-free forms
 
 __global__ void __launch_bounds__(64)
 setup_trees_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
@@ -88,37 +91,47 @@ setup_large_trees_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
   if (tid == 0) SetupTreeModel(spec, b.params + (size_t)t * spec.param_count, &b.model[t]);
 }
 
-static size_t SetupLdsBytes(const BatchDims& d) {
-  return (size_t)kSetupTrees * (d.node_count * sizeof(double) + (d.in_node_count - 1 + 2 * (d.taxon_count - 1)) * sizeof(int32_t));
+static size_t SetupLdsBytesPerTree(const BatchDims& d) {
+  return d.node_count * sizeof(double) + (d.in_node_count - 1 + 2 * (d.taxon_count - 1)) * sizeof(int32_t);
 }
 
-__global__ void __launch_bounds__(64)
-setup_trees_lds_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
+__global__ void __launch_bounds__(128)
+setup_trees_lds_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, int trees) {
   extern __shared__ double setup_lds[];
   const int n = d.taxon_count, N = d.node_count, M = d.in_node_count, NI = n - 1;
-  const int t0 = blockIdx.x * kSetupTrees, tid = threadIdx.x;
-  const int count = min(kSetupTrees, d.tree_count - t0);
-  double* bl = setup_lds;                                              // [trees][N]
-  int32_t* par = reinterpret_cast<int32_t*>(bl + kSetupTrees * N);     // [trees][M-1]
-  int32_t* ch = par + kSetupTrees * (M - 1);                           // [trees][2 NI]
-  for (int i = tid; i < count * (M - 1); i += 64) par[i] = b.parent_ids[(size_t)t0 * (M - 1) + i];
-  for (int i = tid; i < count * M; i += 64) bl[(i / M) * N + i % M] = b.branch_in[(size_t)t0 * M + i];
+  const int t0 = blockIdx.x * trees, tid = threadIdx.x, step = blockDim.x;
+  const int count = min(trees, d.tree_count - t0);
+  double* bl = setup_lds;                                        // [trees][N]
+  int32_t* par = reinterpret_cast<int32_t*>(bl + trees * N);     // [trees][M-1]
+  int32_t* ch = par + trees * (M - 1);                           // [trees][2 NI]
+  for (int i = tid; i < count * (M - 1); i += step) par[i] = b.parent_ids[(size_t)t0 * (M - 1) + i];
+  for (int i = tid; i < count * M; i += step) bl[(i / M) * N + i % M] = b.branch_in[(size_t)t0 * M + i];
   __syncthreads();
   if (tid < count)
     SetupTopologyCore(d, par + tid * (M - 1), ch + tid * 2 * NI, bl + tid * N,
                       b.rates != nullptr ? b.rates + (size_t)(t0 + tid) * (M - 1) : nullptr);
   __syncthreads();
-  for (int i = tid; i < count * 2 * NI; i += 64) b.children[(size_t)t0 * 2 * NI + i] = ch[i];
-  for (int i = tid; i < count * N; i += 64) b.branch[(size_t)t0 * N + i] = bl[i];
+  for (int i = tid; i < count * 2 * NI; i += step) b.children[(size_t)t0 * 2 * NI + i] = ch[i];
+  for (int i = tid; i < count * N; i += step) b.branch[(size_t)t0 * N + i] = bl[i];
   if (tid < count) SetupTreeModel(spec, b.params + (size_t)(t0 + tid) * spec.param_count, &b.model[t0 + tid]);
 }
 
 void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int,
                  hipStream_t stream) {
-  const size_t lds = SetupLdsBytes(d);
-  if (lds <= 48 * 1024) {
-    const int blocks = (d.tree_count + kSetupTrees - 1) / kSetupTrees;
-    hipLaunchKernelGGL(setup_trees_lds_kernel, dim3(blocks), dim3(64), lds, stream, d, spec, b);
+  const size_t per_tree = SetupLdsBytesPerTree(d);
+  for (int trees : {128, 64, 32, 16}) {
+    if (per_tree * 16 > 48 * 1024) break;  // (larger trees: a workgroup per tree, below)
+    if (per_tree * trees > 144 * 1024) continue;
+    if (trees > 16 && d.tree_count < 4 * trees) continue;  // (a small batch: spread it)
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(setup_trees_lds_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      raised = true;
+    }
+    const int blocks = (d.tree_count + trees - 1) / trees;
+    hipLaunchKernelGGL(setup_trees_lds_kernel, dim3(blocks), dim3(trees < 64 ? 64 : trees), per_tree * trees, stream, d,
+                       spec, b, trees);
     return;
   }
   const size_t large = ((size_t)2 * (d.taxon_count - 1) + 1) * sizeof(int);

@@ -56,6 +56,7 @@ struct DeviceBatch {
   double* images;             // [T][N-1][kImgStride]      (LDS kernel)
   int32_t* sched;             // [T][2][n+1][16]           step descriptors (LDS kernel)
   const uint32_t* pipe_masks; // [tiles][n][waves][16/C]   packed tip masks per pattern tile (walk_pipe_kernel)
+  int32_t* pipe_queue;        // [2] next unit of work, workgroups that have left (walk_pipe_kernel; zero between launches)
   // traversal scratch + outputs
   double* arena;              // [chunk][n-1][C][4][Ppad]
   double* scale_arena;        // [chunk][n-1][Ppad]  post-order 1/scale factors (rescaled gradients)
@@ -150,8 +151,7 @@ LdsPlan PlanPipe(const BatchDims& d);
 size_t PipeScheduleInts(const BatchDims& d);
 size_t PipeMaskInts(const BatchDims& d, const LdsPlan& plan);
 void LaunchPipeMasks(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, uint32_t* masks, hipStream_t stream);
-void LaunchPipeImages(const BatchDims& d, const DeviceBatch& b, hipStream_t stream);
-void LaunchPipeSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream);
+void LaunchPipePrepare(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream);
 // deriv_mode 1: the edge derivatives use d r_c / d shape in place of r_c (site-model pass)
 void LaunchWalkPipe(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient, int want_site,
                     int deriv_mode, hipStream_t stream);

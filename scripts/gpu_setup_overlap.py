@@ -9,7 +9,7 @@ import bito_amd
 from bito_amd import workloads
 
 big = workloads.ds1_gtr_weibull4(16)
-for serial in ("0", "1", "0", "1"):
+for serial in ("0", "1", "2", "0", "1", "2"):
     os.environ["BITO_AMD_SERIAL_SETUP"] = serial
     eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(big.substitution, big.site, big.clock), big.patterns, big.weights)
     eng.upload(big.parent_ids, big.branch_lengths, big.params)
