@@ -176,21 +176,28 @@ def main():
     eng.upload(w.parent_ids, w.branch_lengths, w.params)
 
     # Summed log-likelihood over the ranks, one asynchronous RCCL all-reduce per step.  Nothing waits on the
-    # host: the per-tree values are copied device-to-device on the engine's stream behind the pass, torch's
-    # stream waits for that copy through an event, sums, and hands the scalar to RCCL; the next pass (and its
-    # set-up, which overlaps this one) is submitted meanwhile.  A ring of result tensors, each guarded by the
-    # event of the sum that last read it.
+    # host and nothing is added to the engine's stream: torch's stream waits for the pass through the event the
+    # engine records behind it anyway, sums the per-tree values where the engine left them (a ring of four
+    # buffers, so the next passes do not touch them), and hands the scalar to RCCL; the next pass (and its
+    # set-up) is submitted meanwhile.  The engine's stream waits for the sum that last read a ring slot before
+    # the pass that rewrites it, four passes later.
     kRing = 4
-    ll_ring = torch.zeros(kRing, T, dtype=torch.float64, device="cuda") if reduce_ll else None
     engine_stream = None
     if reduce_ll:
         try:
             engine_stream = torch.cuda.ExternalStream(eng.stream_handle())
         except Exception as exc:  # noqa: BLE001 -- then hand results over with a host wait per step instead
             print(f"bench: no external-stream wrapper ({exc!r}); the reduction waits on the host each step", file=sys.stderr)
+    ll_host_ring = torch.zeros(T, dtype=torch.float64, device="cuda") if reduce_ll and engine_stream is None else None
     sum_done = [None] * kRing
     pending = []  # (work handle, tensor) of the reductions in flight
     step_index = [0]
+
+    class _DeviceVector:
+        """zero-copy view of `count` doubles at a device address, for torch.as_tensor"""
+
+        def __init__(self, address, count):
+            self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (address, False), "version": 2}
 
     def step():
         # trees are independent: each rank evaluates its own block; the only exchange the path has is the
@@ -204,14 +211,13 @@ def main():
         if reduce_ll:
             here = torch.cuda.current_stream()
             if engine_stream is not None:
-                eng.download_async(ll_ring[slot].data_ptr(), None)
-                copied = torch.cuda.Event()
-                copied.record(engine_stream)
-                here.wait_event(copied)
+                ll_address, _ = eng.results_async(here.cuda_stream)
+                values = torch.as_tensor(_DeviceVector(ll_address, T), device="cuda")
             else:
-                torch.cuda.synchronize()  # earlier sums have read their slots
-                eng.download_to(ll_ring[slot].data_ptr(), None)  # waits for the pass
-            total = ll_ring[slot].sum().reshape(1)
+                torch.cuda.synchronize()  # earlier sums have read the buffer
+                eng.download_to(ll_host_ring.data_ptr(), None)  # waits for the pass
+                values = ll_host_ring
+            total = values.sum().reshape(1)
             sum_done[slot] = torch.cuda.Event()
             sum_done[slot].record(here)
             pending.append((dist.all_reduce(total, async_op=True), total))

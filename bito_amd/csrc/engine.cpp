@@ -87,7 +87,14 @@ struct bito_amd_engine {
   long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
   DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
   DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
-      out_ll, out_grad, out_site, scale_arena, branch2, images2, branch3, images3;
+      out_grad, out_site, scale_arena, branch2, images2, branch3, images3;
+  // per-tree log-likelihoods: a ring, pass k writes slot k mod kOutRing, so that a consumer on another stream
+  // may still be reading a pass's values while the next passes run (bito_amd_engine_results_async)
+  static constexpr int kOutRing = 4;
+  DeviceBuffer<double> out_ll_ring[kOutRing];
+  unsigned out_slot = 0;
+  hipEvent_t last_pass_done = nullptr;  // recorded behind the last pass enqueued (one of ev_walk_done)
+  double* cur_ll() { return out_ll_ring[out_slot % kOutRing].ptr; }
   bool site_ready = false;  // out_site holds the site-model gradient of the resident pass
   DeviceBuffer<TreeModel> model, model2, model3;
   DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
@@ -108,7 +115,8 @@ struct bito_amd_engine {
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
     tip_states.Free(); weights.Free(); parent_ids.Free(); children.Free(); branch_in.Free();
     rates.Free(); params.Free(); branch.Free(); mats.Free(); images.Free(); arena.Free(); scale_arena.Free(); part_ll.Free();
-    part_grad.Free(); out_ll.Free(); out_grad.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
+    part_grad.Free(); out_grad.Free();
+    for (auto& r : out_ll_ring) r.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
     tt_out.Free(); tt_aux.Free();
     children2.Free(); sched2.Free(); pipe_masks.Free(); pipe_queue.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
@@ -322,7 +330,7 @@ DeviceBatch MakeBatch(bito_amd_engine* e, int set = 0) {
   b.scale_arena = e->scale_arena.ptr;
   b.part_ll = e->part_ll.ptr;
   b.part_grad = e->part_grad.ptr;
-  b.out_ll = e->out_ll.ptr;
+  b.out_ll = e->cur_ll();
   b.out_grad = e->out_grad.ptr;
   b.out_site = e->out_site.ptr;
   return b;
@@ -392,6 +400,7 @@ int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int
   e->kernel_name = "gs_walk_kernel";
   LaunchReduce(d, b, tiles, want_gradient, e->stream);
   HIP_TRY(e, hipEventRecord(e->ev_walk_done[0], e->stream));
+  e->last_pass_done = e->ev_walk_done[0];
   HIP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
 }
@@ -402,6 +411,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   const BatchDims& d = e->dims;
   const int T = d.tree_count;
   const size_t NB = (size_t)d.node_count - 1;
+  e->out_slot++;  // this pass's log-likelihoods go to the next buffer of the ring
   if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL)
     return RunResidentGeneral(e, want_gradient, rescaling, deriv_mode);
   // Kernel choice: the LDS-resident MFMA walk when the tree fits in LDS and no rescaling
@@ -501,6 +511,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     // (walk_pipe_kernel's partial log-likelihoods are per run of tiles as well)
     LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, e->stream, grad_rows);
     if (!bare) HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
+    e->last_pass_done = bare ? nullptr : e->ev_walk_done[set];
     HIP_TRY(e, hipGetLastError());
     return BITO_AMD_OK;
   }
@@ -533,6 +544,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   e->kernel_name = WalkHbmKernelName(d.category_count, want_gradient, rescaling);
   LaunchReduce(d, b, tiles, want_gradient, e->stream, grad_rows);
   HIP_TRY(e, hipEventRecord(e->ev_walk_done[0], e->stream));
+  e->last_pass_done = e->ev_walk_done[0];
   HIP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
 }
@@ -692,7 +704,7 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   HIP_TRY(e, e->children3.Reserve(T * (n - 1) * 2));
   HIP_TRY(e, e->branch3.Reserve(T * N));
   HIP_TRY(e, e->model3.Reserve(T));
-  HIP_TRY(e, e->out_ll.Reserve(T));
+  for (auto& r : e->out_ll_ring) HIP_TRY(e, r.Reserve(T));
   HIP_TRY(e, e->out_grad.Reserve(T * N));
   HIP_TRY(e, e->out_site.Reserve(T));
   HIP_TRY(e, hipMemcpyAsync(e->parent_ids.ptr, parent_ids, T * (M - 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
@@ -761,9 +773,27 @@ int bito_amd_engine_download_async(bito_amd_engine* e, double* out_ll, double* o
   HIP_TRY(e, hipSetDevice(e->device));
   const size_t T = e->dims.tree_count;
   if (out_ll)
-    HIP_TRY(e, hipMemcpyAsync(out_ll, e->out_ll.ptr, T * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(out_ll, e->cur_ll(), T * sizeof(double), hipMemcpyDefault, e->stream));
   if (out_grad)
     HIP_TRY(e, hipMemcpyAsync(out_grad, e->out_grad.ptr, T * e->dims.node_count * sizeof(double), hipMemcpyDefault, e->stream));
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_results_async(bito_amd_engine* e, void* consumer_stream, const double** out_ll,
+                                  const double** out_grad) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident");
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipStream_t consumer = static_cast<hipStream_t>(consumer_stream);
+  if (e->last_pass_done) {
+    HIP_TRY(e, hipStreamWaitEvent(consumer, e->last_pass_done, 0));
+  } else {  // (nothing recorded behind the last pass: an event of its own)
+    hipEvent_t ev = NextEvent(e);
+    HIP_TRY(e, hipEventRecord(ev, e->stream));
+    HIP_TRY(e, hipStreamWaitEvent(consumer, ev, 0));
+  }
+  if (out_ll) *out_ll = e->cur_ll();
+  if (out_grad) *out_grad = e->out_grad.ptr;
   return BITO_AMD_OK;
 }
 
@@ -1072,7 +1102,7 @@ int bito_amd_engine_time_tree_log_likelihoods(bito_amd_engine* e, int32_t tree_c
     if ((rc = ToDevice(e, e->tt_heights, node_heights, T * N))) return rc;
     if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
     LaunchLogDetJacobian(tree_count, n, e->parent_ids.ptr, e->tt_heights.ptr, e->tt_bounds.ptr, nullptr,
-                         e->out_ll.ptr, e->stream);
+                         e->cur_ll(), e->stream);
     HIP_TRY(e, hipGetLastError());
   }
   return bito_amd_engine_download(e, out, nullptr);

@@ -340,6 +340,14 @@ class Engine:
         """The same copies enqueued on the engine's stream without waiting (see ``stream_handle``)."""
         self._check(_capi.lib().bito_amd_engine_download_async(self._h, ll_ptr, grad_ptr))
 
+    def results_async(self, consumer_stream: int):
+        """Device addresses (log-likelihoods, gradients) of the last pass enqueued, after making the HIP stream
+        ``consumer_stream`` wait for it; nothing is copied and nothing enqueued on the engine's stream.  The
+        log-likelihood buffer is one of a ring of four (see ``bito_amd_engine_results_async``)."""
+        ll, grad = C.c_void_p(), C.c_void_p()
+        self._check(_capi.lib().bito_amd_engine_results_async(self._h, C.c_void_p(consumer_stream), C.byref(ll), C.byref(grad)))
+        return int(ll.value or 0), int(grad.value or 0)
+
     def stream_handle(self) -> int:
         """The engine's hipStream_t as an integer, e.g. for ``torch.cuda.ExternalStream``."""
         return int(_capi.lib().bito_amd_engine_stream(self._h) or 0)

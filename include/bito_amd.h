@@ -243,6 +243,14 @@ int bito_amd_engine_download(bito_amd_engine *e, double *out_log_likelihoods,
 int bito_amd_engine_download_async(bito_amd_engine *e, double *out_log_likelihoods,
                                    double *out_branch_gradients);
 void *bito_amd_engine_stream(bito_amd_engine *e);
+/* No copy at all: makes `consumer_stream` (a hipStream_t) wait for the passes enqueued so far and hands out the
+ * device addresses of the last pass's results.  Per-tree log-likelihoods live in a ring of four buffers (pass k
+ * writes buffer k mod 4): the address stays valid, and its contents untouched, until three more passes have
+ * been enqueued; the gradient buffer ([tree_count][2n-1]) is rewritten by the next pass that computes
+ * gradients.  Nothing is enqueued on the engine's own stream, so a consumer that sums the log-likelihoods and
+ * reduces them over RCCL costs the next pass nothing (bench.py with more than one rank). */
+int bito_amd_engine_results_async(bito_amd_engine *e, void *consumer_stream,
+                                  const double **log_likelihoods, const double **branch_gradients);
 
 /* Diagnostics / benchmarking. */
 int bito_amd_engine_set_kernel(bito_amd_engine *e, int32_t kernel);

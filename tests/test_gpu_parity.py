@@ -589,6 +589,58 @@ def test_whole_tree_units_of_the_pipe_walk(run, whole, monkeypatch):
     assert ll_close(gpu.log_likelihoods(w.parent_ids, w.branch_lengths, w.params), ref["log_likelihood"])
 
 
+_RESULTS_RING_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+torch.cuda.init()  # (torch's HIP runtime first: the engine's library brings its own)
+sys.path.insert(0, sys.argv[1])
+import bito_amd
+from bito_amd import workloads
+
+
+class DeviceVector:
+    def __init__(self, address, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (address, False), "version": 2}
+
+
+w = workloads.ds1_gtr_weibull4(1).subset(12)
+gpu = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights)
+gpu.upload(w.parent_ids, w.branch_lengths, w.params)
+stream = torch.cuda.Stream()
+views, expected = [], []
+for k in range(4):
+    gpu.update(w.branch_lengths * (1.0 + 0.1 * k), None)
+    gpu.run(True, False)
+    ll_address, grad_address = gpu.results_async(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        views.append(torch.as_tensor(DeviceVector(ll_address, 12), device="cuda"))
+        grad_now = torch.as_tensor(DeviceVector(grad_address, 12 * 53), device="cuda").clone()
+    ll, grad = gpu.download(True)
+    expected.append(ll.copy())
+    stream.synchronize()
+    assert np.array_equal(grad_now.cpu().numpy().reshape(12, 53), grad)
+assert len({v.data_ptr() for v in views}) == 4
+for k in range(4):  # passes 1..3 have not touched pass 0's buffer
+    assert np.array_equal(views[k].cpu().numpy(), expected[k])
+assert not np.array_equal(expected[0], expected[1])
+print("ring ok")
+"""
+
+
+def test_results_in_place_ring():
+    """bito_amd_engine_results_async hands out device addresses instead of copying: per-tree log-likelihoods of
+    pass k stay where they are until three more passes have been enqueued (a ring of four buffers), and the
+    consumer's stream is ordered behind the pass.  (In a process of its own: the consumer here is torch, whose
+    bundled HIP runtime has to be the first one the process initialises.)"""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, "-c", _RESULTS_RING_SCRIPT, os.path.dirname(HERE)], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "ring ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_general_kernel_model_index_follows_the_resident_batch():
     """Selecting the general-state kernels AFTER a batch was uploaded under another kernel choice must not
     reuse the model index of an earlier batch: set_kernel(GENERAL), upload A, set_kernel(AUTO), upload B (same
