@@ -485,7 +485,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     const bool bare = e->serial_setup == 2 && e->run_counter > (unsigned)bito_amd_engine::kSets;
     if (!bare) {
       HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_walk_done[set], 0));
-      LaunchSetup(d, e->spec, b, want_gradient, prep);
+      LaunchSetup(d, e->spec, b, want_gradient, prep, /*beside_traversal=*/!e->serial_setup);
       if (use_pipe) {
         LaunchPipePrepare(d, b, plan, prep);
         if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);

@@ -117,12 +117,12 @@ setup_trees_lds_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, int trees) {
 }
 
 void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int,
-                 hipStream_t stream) {
+                 hipStream_t stream, bool beside_traversal) {
   const size_t per_tree = SetupLdsBytesPerTree(d);
   for (int trees : {128, 64, 32, 16}) {
     if (per_tree * 16 > 48 * 1024) break;  // (larger trees: a workgroup per tree, below)
     if (per_tree * trees > 144 * 1024) continue;
-    if (trees > 16 && d.tree_count < 4 * trees) continue;  // (a small batch: spread it)
+    if (trees > 16 && (!beside_traversal || d.tree_count < 4 * trees)) continue;  // (alone, or a small batch: spread it)
     static bool raised = false;
     if (!raised) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(setup_trees_lds_kernel),

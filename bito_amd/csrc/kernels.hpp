@@ -116,8 +116,10 @@ __device__ inline void SetupTopology(const BatchDims& d, const DeviceBatch& b, i
                     b.rates != nullptr ? b.rates + (size_t)t * (M - 1) : nullptr);
 }
 
+// beside_traversal: the launch will run next to a traversal that needs whole CUs, so it should sit on as few
+// CUs as possible (up to 128 trees per workgroup) rather than finish as early as possible (16 per workgroup)
 void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int want_gradient,
-                 hipStream_t stream);
+                 hipStream_t stream, bool beside_traversal = false);
 // deriv_mode 0: dP = P (r_c Q); 1: dP = P ((d r_c / d shape) Q) for the site-model gradient pass.
 void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, int deriv_mode,
                     hipStream_t stream);
