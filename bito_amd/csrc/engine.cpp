@@ -86,7 +86,7 @@ struct bito_amd_engine {
   DeviceBuffer<int32_t> pipe_masks;  // packed tip masks per pattern tile (walk_pipe_kernel): a function of the alignment and the plan
   long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
   DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
-  DeviceBuffer<double> branch_in, rates, params, branch, mats, images, arena, part_ll, part_grad,
+  DeviceBuffer<double> branch_in, rates, params, branch, mats, mats2, mats3, images, arena, part_ll, part_grad,
       out_grad, out_site, scale_arena, branch2, images2, branch3, images3;
   // per-tree log-likelihoods: a ring, pass k writes slot k mod kOutRing, so that a consumer on another stream
   // may still be reading a pass's values while the next passes run (bito_amd_engine_results_async)
@@ -114,7 +114,7 @@ struct bito_amd_engine {
     (void)hipSetDevice(device);
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
     tip_states.Free(); weights.Free(); parent_ids.Free(); children.Free(); branch_in.Free();
-    rates.Free(); params.Free(); branch.Free(); mats.Free(); images.Free(); arena.Free(); scale_arena.Free(); part_ll.Free();
+    rates.Free(); params.Free(); branch.Free(); mats.Free(); mats2.Free(); mats3.Free(); images.Free(); arena.Free(); scale_arena.Free(); part_ll.Free();
     part_grad.Free(); out_grad.Free();
     for (auto& r : out_ll_ring) r.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
@@ -321,7 +321,7 @@ DeviceBatch MakeBatch(bito_amd_engine* e, int set = 0) {
   b.children = (set == 0 ? e->children : set == 1 ? e->children2 : e->children3).ptr;
   b.branch = (set == 0 ? e->branch : set == 1 ? e->branch2 : e->branch3).ptr;
   b.model = (set == 0 ? e->model : set == 1 ? e->model2 : e->model3).ptr;
-  b.mats = e->mats.ptr;
+  b.mats = (set == 0 ? e->mats : set == 1 ? e->mats2 : e->mats3).ptr;
   b.images = (set == 0 ? e->images : set == 1 ? e->images2 : e->images3).ptr;
   b.sched = (set == 0 ? e->sched : set == 1 ? e->sched2 : e->sched3).ptr;
   b.pipe_masks = reinterpret_cast<const uint32_t*>(e->pipe_masks.ptr);
@@ -515,11 +515,12 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     HIP_TRY(e, hipGetLastError());
     return BITO_AMD_OK;
   }
-  // the paths below are serial on `stream` and use buffer set 0: let the set-up stream drain first
-  HIP_TRY(e, hipStreamSynchronize(e->prep_stream));
+  // HBM-arena walk: the same set-up pipeline (tree set-up and transition matrices of this pass on prep_stream,
+  // into the next buffer set, while earlier passes' traversals run)
   e->site_ready = false;
+  const int set = (int)(e->run_counter++ % (unsigned)bito_amd_engine::kSets);
   // scratch sized for this run
-  HIP_TRY(e, e->mats.Reserve((size_t)T * NB * d.category_count * kMatStride));
+  HIP_TRY(e, (set == 0 ? e->mats : set == 1 ? e->mats2 : e->mats3).Reserve((size_t)T * NB * d.category_count * kMatStride));
   const size_t per_tree = HbmArenaBytesPerTree(d);
   size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
   // grid.y limit
@@ -527,9 +528,15 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   HIP_TRY(e, e->arena.Reserve(chunk * per_tree / sizeof(double)));
   if (want_gradient && rescaling)
     HIP_TRY(e, e->scale_arena.Reserve(chunk * (size_t)(d.taxon_count - 1) * d.pattern_stride));
-  const DeviceBatch b = MakeBatch(e);
-  LaunchSetup(d, e->spec, b, want_gradient, e->stream);
-  LaunchMatrices(d, b, want_gradient, deriv_mode, e->stream);
+  const DeviceBatch b = MakeBatch(e, set);
+  {
+    hipStream_t prep = e->serial_setup ? e->stream : e->prep_stream;
+    HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_walk_done[set], 0));
+    LaunchSetup(d, e->spec, b, want_gradient, prep);
+    LaunchMatrices(d, b, want_gradient, deriv_mode, prep);
+    HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_prep_done[set], 0));
+  }
   for (int t0 = 0; t0 < T; t0 += (int)chunk) {
     const int ct = std::min<int>((int)chunk, T - t0);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -543,8 +550,8 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   }
   e->kernel_name = WalkHbmKernelName(d.category_count, want_gradient, rescaling);
   LaunchReduce(d, b, tiles, want_gradient, e->stream, grad_rows);
-  HIP_TRY(e, hipEventRecord(e->ev_walk_done[0], e->stream));
-  e->last_pass_done = e->ev_walk_done[0];
+  HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
+  e->last_pass_done = e->ev_walk_done[set];
   HIP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
 }
