@@ -485,9 +485,12 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     const bool bare = e->serial_setup == 2 && e->run_counter > (unsigned)bito_amd_engine::kSets;
     if (!bare) {
       HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_walk_done[set], 0));
-      LaunchSetup(d, e->spec, b, want_gradient, prep, /*beside_traversal=*/!e->serial_setup);
+      // (packed into few workgroups when a traversal is still running beside it; spread out -- 30 us sooner --
+      // when the engine is idle, as it is for a caller that waits for every pass)
+      const bool busy = !e->serial_setup && e->last_pass_done != nullptr && hipEventQuery(e->last_pass_done) == hipErrorNotReady;
+      LaunchSetup(d, e->spec, b, want_gradient, prep, /*beside_traversal=*/busy);
       if (use_pipe) {
-        LaunchPipePrepare(d, b, plan, prep);
+        LaunchPipePrepare(d, b, plan, prep, busy);
         if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);
       } else {
         LaunchMatrixImages(d, b, want_gradient, deriv_mode, prep);

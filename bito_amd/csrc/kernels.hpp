@@ -153,7 +153,8 @@ LdsPlan PlanPipe(const BatchDims& d);
 size_t PipeScheduleInts(const BatchDims& d);
 size_t PipeMaskInts(const BatchDims& d, const LdsPlan& plan);
 void LaunchPipeMasks(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, uint32_t* masks, hipStream_t stream);
-void LaunchPipePrepare(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream);
+void LaunchPipePrepare(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream,
+                       bool beside_traversal);
 // deriv_mode 1: the edge derivatives use d r_c / d shape in place of r_c (site-model pass)
 void LaunchWalkPipe(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient, int want_site,
                     int deriv_mode, hipStream_t stream);
