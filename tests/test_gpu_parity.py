@@ -641,6 +641,100 @@ def test_results_in_place_ring():
     assert out.returncode == 0 and "ring ok" in out.stdout, out.stderr[-2000:]
 
 
+def _shaped_rooted_parent_ids(n, shape):
+    """Rooted bifurcating topologies of extreme shape with bito ids: 'caterpillar' (one cherry, every other
+    internal node has a tip child) or 'balanced' (as many cherries as a tree can have)."""
+    parents, next_id = {}, [n]
+
+    def join(a, b):
+        me = next_id[0]
+        next_id[0] += 1
+        parents[a] = parents[b] = me
+        return me
+
+    def balanced(leaves):
+        if len(leaves) == 1:
+            return leaves[0]
+        half = len(leaves) // 2
+        return join(balanced(leaves[:half]), balanced(leaves[half:]))
+
+    if shape == "caterpillar":
+        top = join(0, 1)
+        for leaf in range(2, n):
+            top = join(top, leaf)
+    else:
+        top = balanced(list(range(n)))
+    assert top == 2 * n - 2
+    return np.array([parents[v] for v in range(2 * n - 2)], dtype=np.int32)
+
+
+@pytest.mark.parametrize("site", ["constant", "weibull+2", "weibull+4"])
+@pytest.mark.parametrize("n", [5, 16, 27, 29])
+def test_pipe_walk_on_extreme_tree_shapes(n, site):
+    """walk_pipe_kernel keeps one LDS cell per internal node that is not a cherry, and sizes its cells by the
+    tree of the batch with the FEWEST cherries: a caterpillar (one cherry: the most cells, so fewer pattern
+    groups per wave at 27 and 29 taxa) and a balanced tree (the most cherries, the longest step bodies) in one
+    batch with a random tree, every category count, against the oracle."""
+    rng = np.random.default_rng(n)
+    P = 131
+    patterns = rng.integers(0, 4, (n, P)).astype(np.int32)
+    patterns[rng.random((n, P)) < 0.05] = 4
+    weights = rng.integers(1, 5, P).astype(np.float64)
+    pid = np.stack([_shaped_rooted_parent_ids(n, "caterpillar"), _shaped_rooted_parent_ids(n, "balanced"),
+                    _random_rooted_parent_ids(n, rng)])
+    bl = rng.exponential(0.1, (3, 2 * n - 1))
+    bl[:, -1] = 0.0
+    gpu, cpu = engines("GTR", site, "none", patterns, weights, 3)
+    gpu.set_kernel(_capi.KERNEL_LDS_PIPE)
+    params = gpu.default_params(3)
+    params[:, :4] = rng.dirichlet([5, 5, 5, 5], 3)
+    params[:, 4:10] = rng.dirichlet([3] * 6, 3)
+    for trees in (slice(0, 3), slice(0, 1), slice(1, 2)):  # mixed batch, caterpillars only, balanced only
+        out = gpu.gradients(pid[trees], bl[trees], params[trees])
+        ref = cpu.gradients(pid[trees], bl[trees], params[trees])
+        assert gpu.kernel_name() == "walk_pipe_kernel"
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+        assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+        assert ll_close(gpu.log_likelihoods(pid[trees], bl[trees], params[trees]), ref["log_likelihood"])
+
+
+def test_auto_kernel_choice_at_the_pipe_walk_limits():
+    """AUTO: 29 taxa is the last size whose branch images fit the AGPR file (walk_pipe_kernel), 30 taxa go to
+    walk_lds_kernel, rescaling to walk_hbm_kernel; each against the oracle."""
+    rng = np.random.default_rng(29)
+    for n, rescaling, expect in ((29, False, "walk_pipe_kernel"), (30, False, "walk_lds_kernel"), (29, True, "walk_hbm_kernel")):
+        patterns = rng.integers(0, 4, (n, 70)).astype(np.int32)
+        weights = np.ones(70)
+        pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(4)])
+        bl = rng.exponential(0.1, (4, 2 * n - 1))
+        bl[:, -1] = 0.0
+        gpu, cpu = engines("HKY", "weibull+4", "none", patterns, weights, 4)
+        out = gpu.gradients(pid, bl, rescaling=rescaling)
+        ref = cpu.gradients(pid, bl, rescaling=rescaling)
+        assert gpu.kernel_name() == expect
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+        assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+
+
+@pytest.mark.parametrize("trees", [1, 255, 257, 1030])
+def test_pipe_walk_unit_queue_sizes(trees):
+    """The resident workgroups of walk_pipe_kernel take units of work from a queue: fewer units than
+    workgroups, one more unit than workgroups, and a batch large enough for whole-tree units (first seven
+    eighths) followed by runs of tiles -- every tree against the oracle on a sample, and twice in a row (the
+    queue resets itself)."""
+    w = workloads.ds1_gtr_weibull4(11).subset(trees)
+    gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
+    first = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+    again = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert gpu.kernel_name() == "walk_pipe_kernel"
+    assert np.array_equal(first["log_likelihood"], again["log_likelihood"])
+    assert np.array_equal(first["branch_lengths"], again["branch_lengths"])
+    idx = np.unique(np.concatenate([np.arange(0, trees, 97), [trees - 1], np.arange(max(0, trees - 140), trees, 13)]))
+    ref = cpu.gradients(w.parent_ids[idx], w.branch_lengths[idx], w.params[idx])
+    assert ll_close(first["log_likelihood"][idx], ref["log_likelihood"])
+    assert grad_close(first["branch_lengths"][idx], ref["branch_lengths"])
+
+
 def test_general_kernel_model_index_follows_the_resident_batch():
     """Selecting the general-state kernels AFTER a batch was uploaded under another kernel choice must not
     reuse the model index of an earlier batch: set_kernel(GENERAL), upload A, set_kernel(AUTO), upload B (same
