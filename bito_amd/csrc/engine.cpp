@@ -437,7 +437,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
       if (!use_tree) return Fail(e, BITO_AMD_ERR_STATE, "the LDS tree kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, and a tree whose images + PLVs fit in 160 KB of LDS)");
       break;
     default:
-      // AUTO: the hand-scheduled LDS walk where it applies (up to 29 taxa: every branch's images in the AGPR
+      // AUTO: the hand-scheduled LDS walk where it applies (up to 38 taxa: every branch's images in the AGPR
       // file), measured 1.44 ms against walk_lds_kernel's 2.00 ms per 1600 config-3 trees
       use_pipe = pplan.groups > 0 && !rescaling;
       // ... except a log-likelihood-only pass with one rate category: walk_hbm_kernel never stores a partial there

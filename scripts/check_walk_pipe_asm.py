@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build-time check of walk_pipe.hip's compiled device code (hipcc -S --cuda-device-only output).
 
-walk_pipe_kernel keeps the matrix images of a whole tree in a[0 .. 4*WALK_PIPE_MAX_BRANCHES) across several asm
+walk_pipe_kernel keeps the matrix images of a whole tree in a[0 .. WALK_PIPE_IMAGE_REGS) across several asm
 statements.  Those AGPRs are on every statement's clobber list, which keeps the compiler from holding values in
 them ACROSS a statement; this script verifies the stronger property the kernel relies on: outside the asm
 statements the compiler never touches them at all (it has v0..v31 and the AGPRs above for its own values).
@@ -9,7 +9,7 @@ Fails (exit 1) on the first stray use.  usage: check_walk_pipe_asm.py walk_pipe.
 import re
 import sys
 
-LIMIT = 224  # 4 * WALK_PIPE_MAX_BRANCHES
+LIMIT = 224  # WALK_PIPE_IMAGE_REGS
 
 
 def main(path):

@@ -290,8 +290,13 @@ class Loops:
         index mode on source 1: no tip traffic inside the loops either;
       * stored cells are 16 bytes per lane (two pattern groups side by side): ds_read_b128 / ds_write_b128."""
 
-    MAX_BRANCHES = 56  # a[0:223]; a224.. and v0..v(VBASE-1) stay with the compiler
-    MAX_TIPS = 29
+    # Matrix images in the AGPR file, a0..a223 (a224.. and v0..v(VBASE-1) stay with the compiler): a tip's branch
+    # needs P only (nothing is propagated below a tip), two registers at a[2 tip]; the branch above internal node
+    # n + j needs (P, P^T), four registers at a[INNER_BASE + 4 j].
+    MAX_TIPS = 38
+    MAX_INNER = 37
+    INNER_BASE = 2 * MAX_TIPS
+    IMAGE_REGS = INNER_BASE + 4 * MAX_INNER
 
     def __init__(self, G):
         self.G = G
@@ -300,7 +305,10 @@ class Loops:
         S = Alloc(SBASE, SLIMIT, "SGPR")
         g2 = lambda name: [V.get(2, f"{name}{g}", 2) for g in range(G)]
         # persistent
-        self.TMV = V.get(32, "TMV", 4)   # packed masks of tip t (byte g = mask of this lane's pattern in group g); 32 slots
+        # packed masks of tip t (byte g = mask of this lane's pattern in group g): 32 slots beside four groups'
+        # registers, 48 (38 used) beside fewer
+        self.TIP_SLOTS = 32 if G == 4 else 48
+        self.TMV = V.get(self.TIP_SLOTS, "TMV", 4)
         self.U = g2("U")                      # pre-order partial of the step's node
         self.ONE = V.get(2, "ONE", 2)
         self.TP = [[V.get(2, f"TP{t}_{g}", 2) for g in range(G)] for t in range(4)]  # tip operands (lo word stays 0)
@@ -479,7 +487,7 @@ class Loops:
         for g in range(self.G):
             hi = self.TP[slot_tip][g] + 1
             self.valu(f"v_lshlrev_b32_sdwa v{hi}, %[sh0], v{self.TMV} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "
-                      f"src1_sel:BYTE_{g}", list(range(self.TMV, self.TMV + 32)), [hi], indexed_ok=True)
+                      f"src1_sel:BYTE_{g}", list(range(self.TMV, self.TMV + self.TIP_SLOTS)), [hi], indexed_ok=True)
         self.idx_off()
 
     def specialise_masks(self):
@@ -488,7 +496,7 @@ class Loops:
         self.v32(f"v_sub_u32 v{k}, 30, %[sh0]", [], [k])
         self.v32(f"v_mov_b32 v{self.AD[4]}, 0x01010101", [], [self.AD[4]])
         self.v32(f"v_lshlrev_b32 v{k}, v{k}, v{self.AD[4]}", [k, self.AD[4]], [k])
-        for t in range(32):
+        for t in range(min(self.TIP_SLOTS, self.MAX_TIPS)):
             self.v32(f"v_and_b32 v{self.TMV + t}, v{k}, v{self.TMV + t}", [k, self.TMV + t], [self.TMV + t])
 
     # ---- edge sums: 64 lanes -> the gradient row entries of the four blocks (rate categories) ----
@@ -590,8 +598,8 @@ class Loops:
         for t in range(4):
             for g in range(G):
                 self.v32(f"v_mov_b32 v{self.TP[t][g]}, 0", [], [self.TP[t][g]])
-        # packed masks of tip t into TMV[t]: this lane's 32 tip slots are 128 consecutive bytes
-        for k in range(8):
+        # packed masks of tip t into TMV[t]: this lane's tip slots are consecutive bytes
+        for k in range(self.TIP_SLOTS // 4):
             self.mem(f"ds_read_b128 v[{self.TMV + 4 * k}:{self.TMV + 4 * k + 3}], %[tiprow] offset:{16 * k}",
                      writes=list(range(self.TMV + 4 * k, self.TMV + 4 * k + 4)))
         self.e.control(f"s_getpc_b64 s[{self.BASE[0]}:{self.BASE[0] + 1}]")
@@ -626,9 +634,9 @@ class Loops:
                     self.mfma(self.MSG[s][g], ("A", 0), self.TP[2 * s][g])
                 self.idx_off()
             elif kinds[s] == "H":
-                # image index of a tip branch = 4 x tip id
-                self.salu(f"s_lshl_b32 s{t[0]}, {self.cur(tip[s][0])}, 2")
-                self.salu(f"s_lshl_b32 s{t[1]}, {self.cur(tip[s][1])}, 2")
+                # image index of a tip branch = 2 x tip id
+                self.salu(f"s_lshl_b32 s{t[0]}, {self.cur(tip[s][0])}, 1")
+                self.salu(f"s_lshl_b32 s{t[1]}, {self.cur(tip[s][1])}, 1")
                 self.idx_on(f"s{t[0]}", "SRC0")
                 for g in range(G):
                     self.mfma(self.MA[s][g], ("A", 0), self.TP[2 * s][g])
@@ -873,7 +881,8 @@ class Loops:
 
     # =============================== image loader ==================================================
     def load_images(self):
-        """(P, P^T) of every branch of the tree into a[4b .. 4b+3]; %[nb] branches, at most MAX_BRANCHES"""
+        """the tree's matrix images into the AGPR file: P of %[ntips] tip branches (8 of a lane's 16 bytes) from
+        %[img], (P, P^T) of %[ninner] internal branches from %[inner] (= %[img] + 1024 %[ntips])"""
         self.e = Emitter()
         self.tag = "load"
         e = self.e
@@ -888,13 +897,25 @@ class Loops:
             self.mem(f"s_load_dword s{self.TMP[2]}, %[tab], {hex(64 * k)}")
         self.e.label(warm)
         self.salu(f"s_mov_b64 s[{ip}:{ip + 1}], %[img]")
+        tips_done = self.L("tips")
+        for t in range(self.MAX_TIPS):
+            if t % 4 == 0:
+                self.salu(f"s_cmp_le_u32 %[ntips], {t}")
+                self.e.control(f"s_cbranch_scc1 {tips_done}")
+            self.mem(f"global_load_dwordx2 a[{2 * t}:{2 * t + 1}], %[lane16], s[{ip}:{ip + 1}] offset:{(t % 4) * 1024}")
+            if t % 4 == 3:
+                self.salu(f"s_add_u32 s{ip}, s{ip}, 4096")
+                self.salu(f"s_addc_u32 s{ip + 1}, s{ip + 1}, 0")
+        self.e.label(tips_done)
+        self.salu(f"s_mov_b64 s[{ip}:{ip + 1}], %[inner]")
         done = self.L("done")
-        for b in range(self.MAX_BRANCHES):
-            if b % 4 == 0:
-                self.salu(f"s_cmp_le_u32 %[nb], {b}")
+        for j in range(self.MAX_INNER):
+            if j % 4 == 0:
+                self.salu(f"s_cmp_le_u32 %[ninner], {j}")
                 self.e.control(f"s_cbranch_scc1 {done}")
-            self.mem(f"global_load_dwordx4 a[{4 * b}:{4 * b + 3}], %[lane16], s[{ip}:{ip + 1}] offset:{(b % 4) * 1024}")
-            if b % 4 == 3:
+            r = self.INNER_BASE + 4 * j
+            self.mem(f"global_load_dwordx4 a[{r}:{r + 3}], %[lane16], s[{ip}:{ip + 1}] offset:{(j % 4) * 1024}")
+            if j % 4 == 3:
                 self.salu(f"s_add_u32 s{ip}, s{ip}, 4096")
                 self.salu(f"s_addc_u32 s{ip + 1}, s{ip + 1}, 0")
         self.e.label(done)
@@ -916,7 +937,7 @@ def as_macro(name, lines):
 
 
 def clobbers(loops):
-    regs = [f"v{r}" for r in range(VBASE, loops.vnext)] + [f"a{r}" for r in range(4 * Loops.MAX_BRANCHES)] + \
+    regs = [f"v{r}" for r in range(VBASE, loops.vnext)] + [f"a{r}" for r in range(Loops.IMAGE_REGS)] + \
            [f"s{r}" for r in range(SBASE, loops.snext)]
     return ", ".join(f'"{r}"' for r in regs) + ', "vcc", "scc", "memory"  /* (and m0, which the compiler treats as reserved) */'
 
@@ -933,12 +954,15 @@ def main():
         out.append(as_macro(f"WALK_PIPE_POST_ASM_G{G}", post.finish()))
         out.append(as_macro(f"WALK_PIPE_PRE_ASM_G{G}", pre.finish()))
         out.append(f"#define WALK_PIPE_CLOBBERS_G{G} {clobbers(loops)}")
-        listing.append(f"G={G}: VGPR v{VBASE}..v{loops.vnext - 1}, AGPR a0..a{4 * Loops.MAX_BRANCHES - 1}, SGPR s{SBASE}..s{loops.snext - 1}; "
+        out.append(f"#define WALK_PIPE_TIP_SLOTS_G{G} {loops.TIP_SLOTS}")
+        listing.append(f"G={G}: VGPR v{VBASE}..v{loops.vnext - 1}, AGPR a0..a{Loops.IMAGE_REGS - 1}, SGPR s{SBASE}..s{loops.snext - 1}; "
                        f"post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
     loops = Loops(1)
     out.append(as_macro("WALK_PIPE_LOAD_ASM", loops.load_images().finish()))
-    out.append(f"#define WALK_PIPE_MAX_BRANCHES {Loops.MAX_BRANCHES}")
     out.append(f"#define WALK_PIPE_MAX_TIPS {Loops.MAX_TIPS}")
+    out.append(f"#define WALK_PIPE_MAX_INNER {Loops.MAX_INNER}")
+    out.append(f"#define WALK_PIPE_INNER_BASE {Loops.INNER_BASE}")
+    out.append(f"#define WALK_PIPE_IMAGE_REGS {Loops.IMAGE_REGS}")
     out.append("// " + "\n// ".join(listing))
     out.append("// clang-format on")
     path = os.path.join(root, "bito_amd", "csrc", "walk_pipe_gen.inc")

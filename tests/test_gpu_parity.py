@@ -488,7 +488,7 @@ def _random_rooted_parent_ids(n, rng):
 
 
 @pytest.mark.parametrize("kernel", [_capi.KERNEL_LDS, _capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS_PIPE])
-@pytest.mark.parametrize("n", [3, 4, 5, 7, 12, 29, 33])
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 12, 29, 33, 38, 41])
 def test_random_shapes_rooted_and_unrooted(kernel, n):
     """Random topologies of many shapes -- caterpillars to balanced trees, cherries as first or second
     child, roots over a tip -- with gaps in the alignment, rooted and unrooted, 1, 2 and 4 categories:
@@ -514,7 +514,7 @@ def test_random_shapes_rooted_and_unrooted(kernel, n):
             params[:, 4:10] = rng.dirichlet([3] * 6, T)
             if C > 1:
                 params[:, 10] = rng.uniform(0.3, 2.0, T)
-            if kernel == _capi.KERNEL_LDS_PIPE and n > 29:  # its images live in the AGPR file: up to 29 taxa
+            if kernel == _capi.KERNEL_LDS_PIPE and n > 38:  # its images live in the AGPR file: up to 38 taxa
                 with pytest.raises(bito_amd.BitoAmdError, match="pipelined LDS kernel was forced"):
                     gpu.gradients(pid, bl, params)
                 continue
@@ -669,11 +669,12 @@ def _shaped_rooted_parent_ids(n, shape):
 
 
 @pytest.mark.parametrize("site", ["constant", "weibull+2", "weibull+4"])
-@pytest.mark.parametrize("n", [5, 16, 27, 29])
+@pytest.mark.parametrize("n", [5, 16, 27, 29, 32, 33, 38])
 def test_pipe_walk_on_extreme_tree_shapes(n, site):
     """walk_pipe_kernel keeps one LDS cell per internal node that is not a cherry, and sizes its cells by the
     tree of the batch with the FEWEST cherries: a caterpillar (one cherry: the most cells, so fewer pattern
-    groups per wave at 27 and 29 taxa) and a balanced tree (the most cherries, the longest step bodies) in one
+    groups per wave from 27 taxa on; beyond 32 taxa the tip masks need the wider register file of the two-group
+    loops) and a balanced tree (the most cherries, the longest step bodies) in one
     batch with a random tree, every category count, against the oracle."""
     rng = np.random.default_rng(n)
     P = 131
@@ -690,7 +691,13 @@ def test_pipe_walk_on_extreme_tree_shapes(n, site):
     params[:, :4] = rng.dirichlet([5, 5, 5, 5], 3)
     params[:, 4:10] = rng.dirichlet([3] * 6, 3)
     for trees in (slice(0, 3), slice(0, 1), slice(1, 2)):  # mixed batch, caterpillars only, balanced only
-        out = gpu.gradients(pid[trees], bl[trees], params[trees])
+        try:
+            out = gpu.gradients(pid[trees], bl[trees], params[trees])
+        except bito_amd.BitoAmdError:
+            # a 38-taxon caterpillar keeps 35 vectors per wave: with one rate category (16 patterns per group)
+            # they do not fit beside the tip masks, and the forced kernel says so
+            assert n >= 33 and trees.start == 0
+            continue
         ref = cpu.gradients(pid[trees], bl[trees], params[trees])
         assert gpu.kernel_name() == "walk_pipe_kernel"
         assert ll_close(out["log_likelihood"], ref["log_likelihood"])
@@ -699,10 +706,10 @@ def test_pipe_walk_on_extreme_tree_shapes(n, site):
 
 
 def test_auto_kernel_choice_at_the_pipe_walk_limits():
-    """AUTO: 29 taxa is the last size whose branch images fit the AGPR file (walk_pipe_kernel), 30 taxa go to
+    """AUTO: 38 taxa is the last size whose branch images fit the AGPR file (walk_pipe_kernel), 39 taxa go to
     walk_lds_kernel, rescaling to walk_hbm_kernel; each against the oracle."""
     rng = np.random.default_rng(29)
-    for n, rescaling, expect in ((29, False, "walk_pipe_kernel"), (30, False, "walk_lds_kernel"), (29, True, "walk_hbm_kernel")):
+    for n, rescaling, expect in ((38, False, "walk_pipe_kernel"), (39, False, "walk_lds_kernel"), (29, True, "walk_hbm_kernel")):
         patterns = rng.integers(0, 4, (n, 70)).astype(np.int32)
         weights = np.ones(70)
         pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(4)])
