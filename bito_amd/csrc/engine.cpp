@@ -86,6 +86,19 @@ struct bito_amd_engine {
   DeviceBuffer<int32_t> pipe_masks;  // packed tip masks per pattern tile (walk_pipe_kernel): a function of the alignment and the plan
   long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
   DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
+  // walk_pipe_kernel in two launches: the trees of the resident batch that keep few enough vectors for four
+  // pattern groups per wave (class A), and the others (class B) -- one tree with few cherries would otherwise
+  // halve the groups of the whole batch
+  std::vector<int32_t> tree_cherries;  // per tree of the resident batch (counted while it is validated)
+  struct PipeSplit {
+    bool built = false, active = false;
+    int count_a = 0, count_b = 0, slots_a = 0;
+    LdsPlan plan_a{}, plan_b{};
+    std::vector<int32_t> order_host;
+  } pipe_split;
+  DeviceBuffer<int32_t> pipe_order;    // class A's tree ids, then class B's
+  DeviceBuffer<int32_t> pipe_masks_a;  // packed tip masks for class A's plan
+  long long pipe_masks_a_key = -1;
   DeviceBuffer<double> branch_in, rates, params, branch, mats, mats2, mats3, images, arena, part_ll, part_grad,
       out_grad, out_site, scale_arena, branch2, images2, branch3, images3;
   // per-tree log-likelihoods: a ring, pass k writes slot k mod kOutRing, so that a consumer on another stream
@@ -119,7 +132,7 @@ struct bito_amd_engine {
     for (auto& r : out_ll_ring) r.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
     tt_out.Free(); tt_aux.Free();
-    children2.Free(); sched2.Free(); pipe_masks.Free(); pipe_queue.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
+    children2.Free(); sched2.Free(); pipe_masks.Free(); pipe_queue.Free(); pipe_order.Free(); pipe_masks_a.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
     children3.Free(); sched3.Free(); branch3.Free(); images3.Free(); model3.Free();
     for (int i = 0; i < kSets; i++) {
       if (ev_prep_done[i]) (void)hipEventDestroy(ev_prep_done[i]);
@@ -247,7 +260,7 @@ int ValidateParams(bito_amd_engine* e, int tree_count, const double* params) {
 // the trifurcating root of an unrooted tree (reference src/node.cpp:383-402,511-551;
 // src/unrooted_tree.cpp:46-52).
 int ValidateTrees(bito_amd_engine* e, int tree_count, int rooted, int node_count,
-                  const int32_t* parent_ids, int* min_cherries = nullptr) {
+                  const int32_t* parent_ids, int* min_cherries = nullptr, std::vector<int32_t>* cherries_of = nullptr) {
   const int n = e->n, M = node_count;
   if (M != (rooted ? 2 * n - 1 : 2 * n - 2)) {
     char buf[200];
@@ -279,6 +292,7 @@ int ValidateTrees(bito_amd_engine* e, int tree_count, int rooted, int node_count
     for (int i = n; i < M - 1; i++) cherries += tip_children[i] == 2;
     if (!rooted) cherries += tip_children[M - 1] == 3;
     fewest = std::min(fewest, cherries);
+    if (cherries_of) (*cherries_of)[t] = cherries;
     for (int i = n; i < M; i++) {
       const int want = (!rooted && i == M - 1) ? 3 : 2;
       if (count[i] != want) {
@@ -455,10 +469,47 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     use_lds = true;
     plan = pplan;
   }
-  const int tiles = use_tree ? tplan.tiles : (use_lds ? plan.tiles : HbmTiles(d.pattern_count));
+  // walk_pipe_kernel: when the batch as a whole cannot have four pattern groups per wave (its tree with the
+  // fewest cherries keeps too many vectors) but many of its trees could, they are walked in a launch of their own
+  bito_amd_engine::PipeSplit& split = e->pipe_split;
+  if (use_pipe && !split.built) {
+    split.built = true;
+    split.active = false;
+    const int slots4 = PipeMaxSlots(d, 4);
+    static const bool no_split = std::getenv("BITO_AMD_PIPE_NO_SPLIT") != nullptr;
+    if (!no_split && T >= 32 && plan.groups < 4 && slots4 > 0 && (int)e->tree_cherries.size() == T) {
+      std::vector<int32_t> a, bb;
+      int need_a = 1, need_b = 1;
+      for (int t = 0; t < T; t++) {
+        const int need = PipeSlotsOfTree(d, e->tree_cherries[t]);
+        (need <= slots4 ? a : bb).push_back(t);
+        (need <= slots4 ? need_a : need_b) = std::max(need <= slots4 ? need_a : need_b, need);
+      }
+      if (!bb.empty() && (int)a.size() * 4 >= T) {
+        const LdsPlan pa = PlanPipeClass(d, (int)a.size(), need_a, 4), pb = PlanPipeClass(d, (int)bb.size(), need_b, 0);
+        if (pa.groups == 4 && pb.groups > 0) {
+          split.active = true;
+          split.count_a = (int)a.size();
+          split.count_b = (int)bb.size();
+          split.slots_a = slots4;
+          split.plan_a = pa;
+          split.plan_b = pb;
+          split.order_host = a;
+          split.order_host.insert(split.order_host.end(), bb.begin(), bb.end());
+          HIP_TRY(e, hipStreamSynchronize(e->stream));
+          HIP_TRY(e, e->pipe_order.Reserve((size_t)T));
+          HIP_TRY(e, hipMemcpy(e->pipe_order.ptr, split.order_host.data(), (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+      }
+    }
+  }
+  const bool two_classes = use_pipe && split.active;
+  if (two_classes) plan = split.plan_b;  // (class B's plan is the one the shared buffers and tables are sized by)
+  const int tiles = use_tree ? tplan.tiles : (use_lds ? std::max(plan.tiles, two_classes ? split.plan_a.tiles : 0) : HbmTiles(d.pattern_count));
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
   // partial gradient rows per tree: one per tile (LDS kernels), per run of tiles (pipelined LDS kernel), per wave (HBM kernel)
-  const int grad_rows = (use_pipe && plan.grad_rows > 0) ? plan.grad_rows : (use_tree || use_lds) ? tiles : tiles * (kHbmBlock / 64);
+  const int pipe_rows = two_classes ? std::max(split.plan_a.grad_rows, split.plan_b.grad_rows) : plan.grad_rows;
+  const int grad_rows = (use_pipe && pipe_rows > 0) ? pipe_rows : (use_tree || use_lds) ? tiles : tiles * (kHbmBlock / 64);
   if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * grad_rows * d.node_count));
   if (use_tree || use_lds) {
     // pipelined: this pass's set-up goes to prep_stream and into buffer set (run_counter mod kSets)
@@ -480,6 +531,16 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
         build_masks = true;
       }
     }
+    bool build_masks_a = false;
+    if (two_classes) {
+      const long long key = (long long)split.plan_a.groups | ((long long)split.plan_a.tiles << 8);
+      if (e->pipe_masks_a_key != key) {
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        HIP_TRY(e, e->pipe_masks_a.Reserve(PipeMaskInts(d, split.plan_a)));
+        e->pipe_masks_a_key = key;
+        build_masks_a = true;
+      }
+    }
     const DeviceBatch b = MakeBatch(e, set);
     hipStream_t prep = e->serial_setup ? e->stream : e->prep_stream;
     const bool bare = e->serial_setup == 2 && e->run_counter > (unsigned)bito_amd_engine::kSets;
@@ -490,8 +551,9 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
       const bool busy = !e->serial_setup && e->last_pass_done != nullptr && hipEventQuery(e->last_pass_done) == hipErrorNotReady;
       LaunchSetup(d, e->spec, b, want_gradient, prep, /*beside_traversal=*/busy);
       if (use_pipe) {
-        LaunchPipePrepare(d, b, plan, prep, busy);
+        LaunchPipePrepare(d, b, plan, prep, busy, two_classes ? split.slots_a : 0);
         if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);
+        if (build_masks_a) LaunchPipeMasks(d, b, split.plan_a, reinterpret_cast<uint32_t*>(e->pipe_masks_a.ptr), prep);
       } else {
         LaunchMatrixImages(d, b, want_gradient, deriv_mode, prep);
         if (use_lds) LaunchLdsSchedule(d, b, plan, prep);
@@ -506,7 +568,17 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
       HIP_TRY(e, hipEventRecord(ev0, e->stream));
     }
     if (use_tree) LaunchWalkTree(d, b, tplan, want_gradient, e->stream);
-    else if (use_pipe) LaunchWalkPipe(d, b, plan, want_gradient, want_site && want_gradient && deriv_mode == 0, deriv_mode, e->stream);
+    else if (use_pipe) {
+      const int site = want_site && want_gradient && deriv_mode == 0;
+      if (two_classes) {
+        LaunchWalkPipe(d, b, split.plan_a, want_gradient, site, deriv_mode, e->stream,
+                       PipeClass{split.count_a, e->pipe_order.ptr, reinterpret_cast<const uint32_t*>(e->pipe_masks_a.ptr), grad_rows});
+        LaunchWalkPipe(d, b, split.plan_b, want_gradient, site, deriv_mode, e->stream,
+                       PipeClass{split.count_b, e->pipe_order.ptr + split.count_a, b.pipe_masks, grad_rows});
+      } else {
+        LaunchWalkPipe(d, b, plan, want_gradient, site, deriv_mode, e->stream, PipeClass{T, nullptr, b.pipe_masks, grad_rows});
+      }
+    }
     else LaunchWalkLds(d, b, plan, want_gradient, want_site && want_gradient && deriv_mode == 0, e->stream);
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
     e->kernel_name = use_tree ? "walk_tree_kernel" : (use_pipe ? "walk_pipe_kernel" : "walk_lds_kernel");
@@ -692,7 +764,9 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   if (e->spec.param_count > 0 && !params)
     return Fail(e, BITO_AMD_ERR_BAD_ARG, "params is NULL but the model has parameters");
   int min_cherries = 0;
-  int rc = ValidateTrees(e, tree_count, rooted, node_count, parent_ids, &min_cherries);
+  e->tree_cherries.assign((size_t)tree_count, 0);
+  e->pipe_split = bito_amd_engine::PipeSplit{};
+  int rc = ValidateTrees(e, tree_count, rooted, node_count, parent_ids, &min_cherries, &e->tree_cherries);
   if (rc) return rc;
   if (params && (rc = ValidateParams(e, tree_count, params))) return rc;
   HIP_TRY(e, hipSetDevice(e->device));

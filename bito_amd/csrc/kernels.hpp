@@ -137,6 +137,7 @@ struct LdsPlan {
   int tile_run = 1;    // (walk_pipe_kernel) consecutive tiles of a tree walked by one workgroup
   int grad_rows = 0;   // (walk_pipe_kernel) partial gradient rows per tree: one per run; 0 = one per tile
   int whole_trees = 0; // (walk_pipe_kernel) the first so many trees are walked by one workgroup each, all tiles
+  int slots = 0;       // (walk_pipe_kernel) vectors a wave keeps in LDS
 };
 LdsPlan PlanLds(const BatchDims& d);
 size_t LdsScheduleInts(const BatchDims& d);
@@ -150,14 +151,26 @@ void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan
 // Images: [T][N-1][128] doubles ((P, P^T) per lane); step tables: [T][2][n+1][8] dwords in b.sched; the
 // packed tip masks of every pattern tile (a function of the alignment and the plan) in b.pipe_masks.
 LdsPlan PlanPipe(const BatchDims& d);
+// A batch may be walked as two classes of trees, each with its own plan (trees with few cherries keep more
+// vectors per wave and leave room for fewer pattern groups): the plan for `tree_count` trees that keep at most
+// `slots` vectors, the most vectors that fit beside G groups, and a tree's count from its cherries.
+LdsPlan PlanPipeClass(const BatchDims& d, int tree_count, int slots, int force_groups);
+int PipeMaxSlots(const BatchDims& d, int G);
+int PipeSlotsOfTree(const BatchDims& d, int cherries);
+struct PipeClass {
+  int tree_count;          // trees of this launch
+  const int32_t* order;    // their ids (device), or nullptr: trees 0 .. tree_count-1
+  const uint32_t* masks;   // packed tip masks built for this launch's plan
+  int row_stride;          // partial rows per tree the reduction adds up
+};
 size_t PipeScheduleInts(const BatchDims& d);
 size_t PipeMaskInts(const BatchDims& d, const LdsPlan& plan);
 void LaunchPipeMasks(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, uint32_t* masks, hipStream_t stream);
 void LaunchPipePrepare(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream,
-                       bool beside_traversal);
+                       bool beside_traversal, int split_slots);
 // deriv_mode 1: the edge derivatives use d r_c / d shape in place of r_c (site-model pass)
 void LaunchWalkPipe(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient, int want_site,
-                    int deriv_mode, hipStream_t stream);
+                    int deriv_mode, hipStream_t stream, const PipeClass& cls);
 
 // LDS-resident traversal, second generation (walk_tree.hip): 8 waves per workgroup (two per
 // SIMD), one group image per wave, the tree's P/dP images staged in LDS and shared.

@@ -742,6 +742,36 @@ def test_pipe_walk_unit_queue_sizes(trees):
     assert grad_close(first["branch_lengths"][idx], ref["branch_lengths"])
 
 
+def test_pipe_walk_in_two_classes():
+    """One tree with few cherries would halve the pattern groups per wave of a whole walk_pipe_kernel batch (the
+    LDS region of a wave is sized by the tree that keeps the most vectors): the engine walks such a batch in
+    two launches, the trees that fit four groups per wave and the others.  40 trees of 27 taxa -- caterpillars,
+    balanced and random ones, interleaved -- against the oracle, with the gradient and without, and again after
+    new branch lengths (the classes are a property of the topologies)."""
+    n, P = 27, 300
+    rng = np.random.default_rng(272)
+    patterns = rng.integers(0, 4, (n, P)).astype(np.int32)
+    patterns[rng.random((n, P)) < 0.03] = 4
+    weights = rng.integers(1, 4, P).astype(np.float64)
+    shapes = [_shaped_rooted_parent_ids(n, "caterpillar"), _shaped_rooted_parent_ids(n, "balanced")]
+    pid = np.stack([shapes[t % 2] if t % 3 else _random_rooted_parent_ids(n, rng) for t in range(40)])
+    bl = rng.exponential(0.1, (40, 2 * n - 1))
+    bl[:, -1] = 0.0
+    gpu, cpu = engines("GTR", "weibull+4", "none", patterns, weights, 8)
+    params = gpu.default_params(40)
+    params[:, :4] = rng.dirichlet([5, 5, 5, 5], 40)
+    params[:, 4:10] = rng.dirichlet([3] * 6, 40)
+    params[:, 10] = rng.uniform(0.3, 2.0, 40)
+    for scale in (1.0, 0.5):
+        out = gpu.gradients(pid, bl * scale, params, flags=_capi.GRAD_SITE_MODEL)
+        ref = cpu.gradients(pid, bl * scale, params, flags=_capi.GRAD_SITE_MODEL)
+        assert gpu.kernel_name() == "walk_pipe_kernel"
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+        assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+        assert grad_close(out["site_model"], ref["site_model"])
+        assert ll_close(gpu.log_likelihoods(pid, bl * scale, params), ref["log_likelihood"])
+
+
 def test_general_kernel_model_index_follows_the_resident_batch():
     """Selecting the general-state kernels AFTER a batch was uploaded under another kernel choice must not
     reuse the model index of an earlier batch: set_kernel(GENERAL), upload A, set_kernel(AUTO), upload B (same
