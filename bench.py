@@ -116,7 +116,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicas", type=int, default=16, help="x100 DS1 topologies per GPU")
+    ap.add_argument("--replicas", type=int, default=64,
+                    help="x100 DS1 topologies per GPU and pass (SURVEY 8d: replicated to fill the device; 6400 trees = 4 ms)")
     ap.add_argument("--workload", choices=["ds1", "codon"], default="ds1",
                     help="ds1 = BASELINE config 3 (the headline metric); codon = config 5 (fluA as codons, GY94)")
     ap.add_argument("--trees", type=int, default=4096, help="codon workload: trees per GPU")
@@ -162,8 +163,11 @@ def main():
 
     # every rank builds the same replicated workload and takes its own block of trees
     codon = args.workload == "codon"
-    full = workloads.flua_codon(args.trees * world) if codon else workloads.ds1_gtr_weibull4(args.replicas * world)
-    w = full.shard(rank, world)
+    if codon:
+        w = workloads.flua_codon(args.trees * world).shard(rank, world)
+    else:  # (a rank generates its own block of the 100 x replicas x world trees: same trees as the whole, sharded)
+        per_rank = 100 * args.replicas
+        w = workloads.ds1_gtr_weibull4(args.replicas * world, first_tree=rank * per_rank, tree_count=per_rank)
     T = w.tree_count
     n, P = w.patterns.shape
     C = 1 if codon else 4
@@ -334,7 +338,7 @@ def main():
         else:
             out["roofline"] = {**hbm_view, **common, "arithmetic": arithmetic}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(full, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

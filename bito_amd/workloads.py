@@ -122,22 +122,53 @@ def ds1_jc69(replicas: int = 1) -> Workload:
                     np.zeros((pid.shape[0], 0)), False, False)
 
 
-def ds1_gtr_weibull4(replicas: int = 1) -> Workload:
+def _xoshiro_exponentials(seeds: np.ndarray, count: int, mean: float) -> np.ndarray:
+    """Xoshiro256ss(seed).exponential(mean), `count` draws for every seed at once: [len(seeds)][count].  Same
+    integer arithmetic on uint64 arrays (wrapping), so the values are those of the scalar class bit for bit."""
+    u64 = np.uint64
+    x = seeds.astype(np.uint64)
+    state = []
+    with np.errstate(over="ignore"):
+        for _ in range(4):
+            x = x + u64(0x9E3779B97F4A7C15)
+            z = x.copy()
+            z = (z ^ (z >> u64(30))) * u64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> u64(27))) * u64(0x94D049BB133111EB)
+            state.append(z ^ (z >> u64(31)))
+        rotl = lambda v, k: (v << u64(k)) | (v >> u64(64 - k))  # noqa: E731
+        out = np.empty((len(seeds), count))
+        s0, s1, s2, s3 = state
+        for k in range(count):
+            result = rotl(s1 * u64(5), 7) * u64(9)
+            t = s1 << u64(17)
+            s2 = s2 ^ s0
+            s3 = s3 ^ s1
+            s1 = s1 ^ s2
+            s0 = s0 ^ s3
+            s2 = s2 ^ t
+            s3 = rotl(s3, 45)
+            uniform = (result >> u64(11)).astype(np.float64) * (1.0 / (1 << 53))
+            out[:, k] = -mean * np.log1p(-uniform)
+    return out
+
+
+def ds1_gtr_weibull4(replicas: int = 1, first_tree: int = 0, tree_count: Optional[int] = None) -> Workload:
     """BASELINE config 3 (headline): DS1, 100 topologies, GTR + weibull+4, shape 0.5,
     branch lengths Exp(mean 0.1) clamped to [1e-6, 1] from xoshiro256** seeded with
     20240601 + tree index; log-likelihood + branch-length gradient.  Replicas re-seed
-    with their own tree index so every tree of the batch is distinct work."""
+    with their own tree index so every tree of the batch is distinct work.  first_tree / tree_count:
+    only that block of the 100 x replicas trees (what one rank of a sharded run needs)."""
     tc, sp = load_ds1()
     base = tc.parent_id_matrix()
-    pid = np.tile(base, (replicas, 1))
-    T, M1 = pid.shape
-    bl = np.zeros((T, M1 + 1))
-    for t in range(T):
-        rng = Xoshiro256ss(20240601 + t)
-        for b in range(M1):
-            bl[t, b] = min(max(rng.exponential(0.1), 1e-6), 1.0)
+    total = base.shape[0] * replicas
+    count = total - first_tree if tree_count is None else tree_count
+    index = np.arange(first_tree, first_tree + count)
+    pid = base[index % base.shape[0]].copy()
+    M1 = pid.shape[1]
+    bl = np.zeros((count, M1 + 1))
+    bl[:, :M1] = np.clip(_xoshiro_exponentials(20240601 + index, M1, 0.1), 1e-6, 1.0)
     return Workload("DS1 x100 topologies GTR+weibull4 LL+grad", "GTR", "weibull+4", "none", sp.patterns, sp.weights,
-                    pid, bl, gtr_weibull_params(T), False, True)
+                    pid, bl, gtr_weibull_params(count), False, True)
 
 
 class _N:

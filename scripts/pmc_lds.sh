@@ -14,7 +14,8 @@ for f in ('$R/gpurun_out/pmc_${T}_a/a_counter_collection.csv','$R/gpurun_out/pmc
         if 'walk_tree' in r['Kernel_Name'] or 'walk_lds' in r['Kernel_Name'] or 'walk_pipe' in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in agg.items(): out[k]=sum(v)/len(v)
-waves=1600*15*4  # 1600 trees x 15 tiles of 64 patterns x 4 waves (G = 4 groups of 4 patterns per wave)
+trees=int('${TREES:-6400}')  # trees per launch of the bench default
+waves=trees*15*4  # trees x 15 tiles of 64 patterns x 4 waves (G = 4 groups of 4 patterns per wave)
 wc=out['SQ_WAVE_CYCLES']
 steps=2*17.6  # stored (non-cherry) internal nodes per pass, DS1 average
 print('per wave-step: instr VALU %.1f MFMA %.1f LDS %.1f SALU %.1f VMEM %.1f'%tuple(out[k]/waves/steps for k in ('SQ_INSTS_VALU','SQ_INSTS_MFMA','SQ_INSTS_LDS','SQ_INSTS_SALU','SQ_INSTS_VMEM_RD')))
@@ -23,6 +24,6 @@ for k in ('SQ_ACTIVE_INST_ANY','SQ_WAIT_ANY','SQ_WAIT_INST_ANY','SQ_ACTIVE_INST_
     if k in out: print(k, '%.3f'%(out[k]/wc))
 print('MFMA busy cycles per SIMD', out['SQ_VALU_MFMA_BUSY_CYCLES']/1024)
 import json
-out['_note']='mean per launch of the walk kernel over bench.py launches; 1600 trees x 15 tiles x 4 waves, about 35 tree steps per wave and tile (cherries folded)'
+out['_note']='mean per launch of the walk kernel over bench.py launches; %d trees x 15 tiles x 4 waves, about 35 tree steps per wave and tile (cherries folded)'%trees
 json.dump(out, open('$R/gpurun_out/pmc_${T}.json','w'), indent=1)
 PY
