@@ -123,12 +123,9 @@ void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b
     if (per_tree * 16 > 48 * 1024) break;  // (larger trees: a workgroup per tree, below)
     if (per_tree * trees > 144 * 1024) continue;
     if (trees > 16 && (!beside_traversal || d.tree_count < 4 * trees)) continue;  // (alone, or a small batch: spread it)
-    static bool raised = false;
-    if (!raised) {
+    if (per_tree * trees > 48 * 1024)  // (per device: a process may drive several)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(setup_trees_lds_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-      raised = true;
-    }
     const int blocks = (d.tree_count + trees - 1) / trees;
     hipLaunchKernelGGL(setup_trees_lds_kernel, dim3(blocks), dim3(trees < 64 ? 64 : trees), per_tree * trees, stream, d,
                        spec, b, trees);
