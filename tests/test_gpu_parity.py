@@ -341,6 +341,40 @@ def test_resident_batch_interface():
     assert total > 0 and kern > 0 and launches >= 3 and kern <= total * 1.05
 
 
+@pytest.mark.parametrize("kernel", [_capi.KERNEL_AUTO, _capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS])
+def test_passes_in_flight_with_updates_between_them(kernel):
+    """Passes enqueued back to back with new inputs in between: the set-up of a pass runs on its own stream into
+    one of three buffer sets, beside the traversals of earlier passes, and `update` rewrites the inputs it reads
+    -- every pass must see the inputs of its own moment.  Eight passes without a wait (results copied out by
+    copies enqueued behind each pass), log-likelihood-only passes mixed in, each against a fresh engine."""
+    w = workloads.ds1_gtr_weibull4(3).subset(300)
+    gpu = bito_amd.Engine(spec(w.substitution, w.site, w.clock), w.patterns, w.weights)
+    gpu.set_kernel(kernel)
+    gpu.upload(w.parent_ids, w.branch_lengths, w.params)
+    outs, inputs = [], []
+    for k in range(8):
+        bl = w.branch_lengths * (1.0 + 0.07 * k)
+        par = w.params.copy()
+        par[:, 10] = 0.4 + 0.1 * k
+        gpu.update(bl, par)
+        grad = k % 3 != 2
+        gpu.run(grad, False)
+        ll_out, grad_out = np.zeros(300), np.zeros((300, 53))
+        gpu.download_async(ll_out.ctypes.data, grad_out.ctypes.data if grad else None)
+        outs.append((ll_out, grad_out, grad))
+        inputs.append((bl, par))
+    gpu.sync()
+    fresh = bito_amd.Engine(spec(w.substitution, w.site, w.clock), w.patterns, w.weights)
+    fresh.set_kernel(kernel)
+    for (ll_out, grad_out, grad), (bl, par) in zip(outs, inputs):
+        if grad:
+            ref = fresh.gradients(w.parent_ids, bl, par)
+            assert np.array_equal(ll_out, ref["log_likelihood"])
+            assert np.array_equal(grad_out, ref["branch_lengths"])
+        else:
+            assert np.array_equal(ll_out, fresh.log_likelihoods(w.parent_ids, bl, par))
+
+
 def test_full_size_batch_properties():
     """BASELINE config 3 at bench size: results are bit-reproducible from run to run, a tree's results depend
     on the rest of the batch only through the order of the pattern-tile sums (the launcher splits a batch into
