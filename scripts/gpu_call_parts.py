@@ -1,3 +1,4 @@
+"""Where a blocking call spends its time on config 3 (100 and 1600 trees): upload, pass + wait, download."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
