@@ -1237,6 +1237,24 @@ int bito_amd_engine_time_tree_gradients(bito_amd_engine* e, int32_t tree_count, 
   return BITO_AMD_OK;
 }
 
+int bito_amd_plan_pipe_walk(int32_t taxon_count, int32_t pattern_count, int32_t category_count, int32_t tree_count,
+                            int32_t min_cherries, int32_t plan[7]) {
+  if (!plan || taxon_count < 3 || pattern_count < 1 || tree_count < 1) return BITO_AMD_ERR_BAD_ARG;
+  BatchDims d{};
+  d.taxon_count = taxon_count;
+  d.node_count = 2 * taxon_count - 1;
+  d.in_node_count = 2 * taxon_count - 2;
+  d.pattern_count = pattern_count;
+  d.pattern_stride = (pattern_count + 512 + kHbmBlock - 1) / kHbmBlock * kHbmBlock;
+  d.category_count = category_count;
+  d.tree_count = tree_count;
+  d.min_cherries = min_cherries;
+  const LdsPlan p = PlanPipe(d);
+  const int32_t out[7] = {p.groups, p.patterns_per_block, p.tiles, (int32_t)p.lds_bytes, p.tile_run, p.whole_trees, p.slots};
+  for (int k = 0; k < 7; k++) plan[k] = out[k];
+  return BITO_AMD_OK;
+}
+
 int bito_amd_engine_set_kernel(bito_amd_engine* e, int32_t kernel) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   e->kernel_choice = kernel;

@@ -254,6 +254,13 @@ int bito_amd_engine_results_async(bito_amd_engine *e, void *consumer_stream,
 
 /* Diagnostics / benchmarking. */
 int bito_amd_engine_set_kernel(bito_amd_engine *e, int32_t kernel);
+/* How walk_pipe_kernel would walk a batch of that shape (host arithmetic only: no device is touched, so the
+ * planner can be checked on a machine without a GPU).  min_cherries: fewest cherries of any tree of the batch.
+ * plan[0..6] = pattern groups per wave (0: the kernel does not take this shape), patterns per workgroup, pattern
+ * tiles, LDS bytes per workgroup, tiles per run-of-tiles unit, trees walked as whole-tree units, vectors a wave
+ * keeps in LDS. */
+int bito_amd_plan_pipe_walk(int32_t taxon_count, int32_t pattern_count, int32_t category_count,
+                            int32_t tree_count, int32_t min_cherries, int32_t plan[7]);
 /* Runs `steps` passes back to back with HIP events on the engine's stream.
  * total_ms: wall time of all steps; kernel_ms: summed duration of the dominant
  * (traversal) kernel only; kernel_launches: how many such launches that was. */

@@ -231,3 +231,48 @@ def test_generated_walk_loops_are_current_and_checked(tmp_path):
         done = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_walk_pipe_asm.py"), listing],
                               capture_output=True, text=True)
         assert done.returncode == 0, done.stderr
+
+
+def _pipe_plan(n, patterns, categories, trees, min_cherries):
+    import ctypes as C
+
+    from bito_amd import _capi
+
+    out = (C.c_int32 * 7)()
+    assert _capi.lib().bito_amd_plan_pipe_walk(n, patterns, categories, trees, min_cherries, out) == 0
+    keys = ("groups", "patterns_per_workgroup", "tiles", "lds_bytes", "tile_run", "whole_trees", "slots")
+    return dict(zip(keys, out))
+
+
+def test_pipe_walk_planner():
+    """Host arithmetic of walk_pipe_kernel's launch plan (no device involved): pattern groups per wave from what
+    a wave must keep in LDS, the taxon limits of the register files, and the units of work by batch size."""
+    ds1 = _pipe_plan(27, 934, 4, 1600, 7)  # BASELINE config 3: DS1's topologies have seven cherries or more
+    assert ds1["groups"] == 4 and ds1["patterns_per_workgroup"] == 64 and ds1["tiles"] == 15 and ds1["slots"] == 18
+    assert ds1["lds_bytes"] <= 160 * 1024
+    # a thousand trees and more: whole-tree units for seven eighths, runs of a third of a tree behind them
+    assert ds1["tile_run"] == 5 and ds1["whole_trees"] == 1400
+    big = _pipe_plan(27, 934, 4, 6400, 7)  # the short units stay a third of a tree, about 400 trees of them
+    assert big["tile_run"] == 5 and big["whole_trees"] == 6000
+    small = _pipe_plan(27, 934, 4, 400, 7)  # fewer: runs only, about four units per workgroup
+    assert small["whole_trees"] == 0 and small["tile_run"] == 5
+    assert _pipe_plan(27, 934, 4, 100, 7)["tile_run"] == 1
+    # one more vector per wave than LDS holds beside four groups: two groups
+    assert _pipe_plan(27, 934, 4, 1600, 6)["groups"] == 2
+    # tip masks: 32 registers beside four groups, 48 beside two; images: 38 taxa fill the AGPR file
+    assert _pipe_plan(32, 934, 4, 1600, 14)["groups"] == 4
+    assert _pipe_plan(33, 934, 4, 1600, 14)["groups"] == 2
+    assert _pipe_plan(38, 934, 4, 1600, 10)["groups"] == 2
+    assert _pipe_plan(39, 934, 4, 1600, 10)["groups"] == 0
+    # one rate category: sixteen patterns per group, 256 per workgroup
+    jc = _pipe_plan(27, 934, 1, 1600, 7)
+    assert jc["groups"] == 4 and jc["patterns_per_workgroup"] == 256 and jc["tiles"] == 4 and jc["lds_bytes"] <= 160 * 1024
+    assert _pipe_plan(27, 934, 3, 1600, 7)["groups"] == 0  # 1, 2 or 4 categories
+    # every plan fits LDS and keeps at least the vectors the batch's worst tree needs
+    for n in range(3, 39):
+        for cherries in (1, n // 3, n // 2):
+            for categories in (1, 2, 4):
+                p = _pipe_plan(n, 500, categories, 1000, cherries)
+                if p["groups"]:
+                    assert p["lds_bytes"] <= 160 * 1024 and p["slots"] >= max(1, n - 2 - cherries)
+                    assert p["tiles"] * p["patterns_per_workgroup"] >= 500 and p["tiles"] % p["tile_run"] == 0
