@@ -339,7 +339,6 @@ class Loops:
         self.p = 0
         self.TAB = S.get(2, "TAB", 2)
         self.TABOFF = S.get(1, "TABOFF")
-        self.CNT = S.get(1, "CNT")
         self.WMASK = S.get(2, "WMASK", 2)
         self.BASE = [S.get(2, "BASE0", 2), S.get(2, "BASE1", 2)]  # code address of the bodies of parity 0 / 1
         self.PC = S.get(2, "PC", 2)
@@ -591,7 +590,6 @@ class Loops:
         G = self.G
         self.salu(f"s_mov_b64 s[{self.TAB}:{self.TAB + 1}], %[tab]")
         self.salu(f"s_mov_b32 s{self.TABOFF}, {64 if two_ahead else 0}")
-        self.salu(f"s_mov_b32 s{self.CNT}, %[steps]")
         self.mem(f"s_load_dwordx16 s[{self.DESC[0]}:{self.DESC[0] + 15}], s[{self.TAB}:{self.TAB + 1}], 0x0")
         if two_ahead:
             self.mem(f"s_load_dwordx16 s[{self.DESC[1]}:{self.DESC[1] + 15}], s[{self.TAB}:{self.TAB + 1}], 0x40")
@@ -681,7 +679,6 @@ class Loops:
         self.label(self.L(f"{name}_{parity}"))
         self.e.comment(f"post-order step, children ({K0},{K1})" + (", message handed to the next step" if hand_over else "")
                        + f", descriptor set {parity}")
-        self.salu(f"s_sub_u32 s{self.CNT}, s{self.CNT}, 1")
         self.next_pc()
         self.messages(kinds)
         self.wait(lgkm=0)  # stored operands, the next step's descriptor (and stores two steps old)
@@ -694,8 +691,9 @@ class Loops:
         if not hand_over:
             self.v32(f"v_add_u32 v{ad[1]}, {self.cur(self.NOFFC1)}, %[arena]", [], [ad[1]])
         self.v32(f"v_add_u32 v{ad[6]}, {self.cur(self.OWN)}, %[arena]", [], [ad[6]])
-        self.salu(f"s_cmp_eq_u32 s{self.CNT}, 0")
-        self.branch("scc1", self.L("root"), settled=True)  # (root: s_waitcnt, then copies of X[0], which VALU wrote)
+        # (No test for the last step: the root's body runs to its end like any other -- a message nobody reads, from
+        # image 0 and cell 0 -- and its jump, body index 10, leaves the loop; a compare and an untaken branch per
+        # step cost more than that, 16 cycles each.)
         # own message a = P_v x (straight into the next step's slot-1 registers when it is handed over), the
         # next step's stored operands and the descriptor after it requested underneath
         self.idx_on(self.cur(self.IMGOWN), "SRC0")
@@ -724,7 +722,7 @@ class Loops:
             self.label(self.L(f"block{parity}"))
             for name, K0, K1, hand_over in self.POST_VARIANTS:
                 self.post_body(name, K0, K1, hand_over, parity)
-            self.label(self.L(f"out_{parity}"))  # (never taken: the root's step leaves through the branch above)
+            self.label(self.L(f"out_{parity}"))  # (where the root's step jumps to)
             self.branch(None, self.L("root"))
         self.label(self.L("root"))
         self.wait(vm=0, lgkm=0)
