@@ -481,13 +481,19 @@ class Loops:
     # state is allowed (the hi word's bit 30), else 0.  A lane's copy of a packed mask keeps only the bit of the
     # lane's own state in every byte (specialise_masks), so byte g shifted by 30 - state is the hi word: one
     # SDWA instruction per group
-    def tip_operands(self, slot_tip, tip_sgpr):
-        self.idx_on(tip_sgpr, "SRC1")
-        for g in range(self.G):
-            hi = self.TP[slot_tip][g] + 1
-            self.valu(f"v_lshlrev_b32_sdwa v{hi}, %[sh0], v{self.TMV} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "
-                      f"src1_sel:BYTE_{g}", list(range(self.TMV, self.TMV + self.TIP_SLOTS)), [hi], indexed_ok=True)
-        self.idx_off()
+    def tip_operands(self, requests):
+        """requests: [(tip operand slot, SGPR with the tip id)] -- one index-mode region for all of them"""
+        for k, (slot_tip, tip_sgpr) in enumerate(requests):
+            if k == 0:
+                self.idx_on(tip_sgpr, "SRC1")
+            else:
+                self.idx_set(tip_sgpr)
+            for g in range(self.G):
+                hi = self.TP[slot_tip][g] + 1
+                self.valu(f"v_lshlrev_b32_sdwa v{hi}, %[sh0], v{self.TMV} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "
+                          f"src1_sel:BYTE_{g}", list(range(self.TMV, self.TMV + self.TIP_SLOTS)), [hi], indexed_ok=True)
+        if requests:
+            self.idx_off()
 
     def specialise_masks(self):
         """TMV[t] &= 0x01010101 << state: what is left of byte g is the bit tip_operands shifts to bit 30"""
@@ -619,12 +625,14 @@ class Loops:
         t = self.TMPM
         tip = [[self.TIPA0, self.TIPB0], [self.TIPA1, self.TIPB1]]
         img = [self.IMG0, self.IMG1]
+        wanted = []
         for s in (0, 1):
             if kinds[s] == "T":
-                self.tip_operands(2 * s, self.cur(tip[s][0]))
+                wanted.append((2 * s, self.cur(tip[s][0])))
             elif kinds[s] == "H":
-                self.tip_operands(2 * s, self.cur(tip[s][0]))
-                self.tip_operands(2 * s + 1, self.cur(tip[s][1]))
+                wanted.append((2 * s, self.cur(tip[s][0])))
+                wanted.append((2 * s + 1, self.cur(tip[s][1])))
+        self.tip_operands(wanted)
         for s in (0, 1):
             if kinds[s] == "T":
                 self.idx_on(self.cur(img[s]), "SRC0")
@@ -746,13 +754,22 @@ class Loops:
         self.flush_addresses(self.other(self.E0), self.other(self.E1))
         self.flush_stage1(self.ES[0], self.ES[1])
         self.next_pc()
-        # Q m of the stored children: their messages are in registers already
+        # Q m of the stored children: their messages are in registers already.  The previous step's edge sums
+        # leave for LDS in the middle of the matrix instructions (behind the first group that follows their own
+        # reduction): there the two EXEC moves and the two LDS instructions cost nothing, and the wait below --
+        # for the next descriptor, which must be lgkmcnt(0) -- finds them long done
+        flushed = False
         for s in (0, 1):
             if kinds[s] == "C":
                 for g in range(G):
                     self.mfma(self.DQ[s][g], "Q", self.M[s][g])
+                if not flushed:
+                    self.flush_stage3()
+                    flushed = True
         self.request_descriptor()
         self.messages(kinds)
+        if not flushed:
+            self.flush_stage3()
         for s in (0, 1):
             if kinds[s] != "C":
                 for g in range(G):
@@ -763,7 +780,6 @@ class Loops:
         for g in range(G):
             self.vmul(self.W[0][g], self.U[g], m1[g])
             self.vmul(self.W[1][g], self.U[g], m0[g])
-        nst = self.flush_stage3()
         self.v32(f"v_add_u32 v{ad[0]}, {self.cur(self.NOFFC0)}, %[arena]", [], [ad[0]])
         self.v32(f"v_add_u32 v{ad[1]}, {self.cur(self.NOFFC1)}, %[arena]", [], [ad[1]])
         if not hand_over:
