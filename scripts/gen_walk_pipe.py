@@ -481,8 +481,9 @@ class Loops:
     # state is allowed (the hi word's bit 30), else 0.  A lane's copy of a packed mask keeps only the bit of the
     # lane's own state in every byte (specialise_masks), so byte g shifted by 30 - state is the hi word: one
     # SDWA instruction per group
-    def tip_operands(self, requests):
-        """requests: [(tip operand slot, SGPR with the tip id)] -- one index-mode region for all of them"""
+    def tip_operands(self, requests, leave_on=False):
+        """requests: [(tip operand slot, SGPR with the tip id)] -- one index-mode region for all of them;
+        leave_on: the caller switches the region to its own mode"""
         for k, (slot_tip, tip_sgpr) in enumerate(requests):
             if k == 0:
                 self.idx_on(tip_sgpr, "SRC1")
@@ -492,7 +493,7 @@ class Loops:
                 hi = self.TP[slot_tip][g] + 1
                 self.valu(f"v_lshlrev_b32_sdwa v{hi}, %[sh0], v{self.TMV} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "
                           f"src1_sel:BYTE_{g}", list(range(self.TMV, self.TMV + self.TIP_SLOTS)), [hi], indexed_ok=True)
-        if requests:
+        if requests and not leave_on:
             self.idx_off()
 
     def specialise_masks(self):
@@ -632,34 +633,48 @@ class Loops:
             elif kinds[s] == "H":
                 wanted.append((2 * s, self.cur(tip[s][0])))
                 wanted.append((2 * s + 1, self.cur(tip[s][1])))
-        self.tip_operands(wanted)
+        self.tip_operands(wanted, leave_on=bool(wanted))
+        # one index-mode region for all the tip products (s_set_gpr_idx_on switches the mode from source 1 to
+        # source 0 as it sets the index; further indices by s_set_gpr_idx_idx)
+        first = True
+
+        def index(sgpr):
+            nonlocal first
+            if first:
+                self.idx_on(sgpr, "SRC0")
+            else:
+                self.idx_set(sgpr)
+            first = False
+
         for s in (0, 1):
             if kinds[s] == "T":
-                self.idx_on(self.cur(img[s]), "SRC0")
+                index(self.cur(img[s]))
                 for g in range(G):
                     self.mfma(self.MSG[s][g], ("A", 0), self.TP[2 * s][g])
-                self.idx_off()
             elif kinds[s] == "H":
                 # image index of a tip branch = 2 x tip id
                 self.salu(f"s_lshl_b32 s{t[0]}, {self.cur(tip[s][0])}, 1")
                 self.salu(f"s_lshl_b32 s{t[1]}, {self.cur(tip[s][1])}, 1")
-                self.idx_on(f"s{t[0]}", "SRC0")
+                index(f"s{t[0]}")
                 for g in range(G):
                     self.mfma(self.MA[s][g], ("A", 0), self.TP[2 * s][g])
-                self.idx_set(f"s{t[1]}")
+                index(f"s{t[1]}")
                 for g in range(G):
                     self.mfma(self.MB[s][g], ("A", 0), self.TP[2 * s + 1][g])
-                self.idx_off()
+        if not first:
+            self.idx_off()
         for s in (0, 1):
             if kinds[s] == "H":
                 for g in range(G):
                     self.vmul(self.X[s][g], self.MA[s][g], self.MB[s][g])
+        first = True
         for s in (0, 1):
             if kinds[s] == "H":
-                self.idx_on(self.cur(img[s]), "SRC0")
+                index(self.cur(img[s]))
                 for g in range(G):
                     self.mfma(self.MSG[s][g], ("A", 0), self.X[s][g])
-                self.idx_off()
+        if not first:
+            self.idx_off()
 
     def msg(self, s, kind):
         return self.M[s] if kind == "C" else self.MSG[s]
