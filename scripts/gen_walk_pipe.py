@@ -551,14 +551,21 @@ class Loops:
         self.mem(f"s_load_dwordx16 s[{d}:{d + 15}], s[{self.TAB}:{self.TAB + 1}], s{self.TABOFF}")
         self.own_set_requested = True
 
-    def next_pc(self):
+    def next_pc(self, finish=True):
         """code address of the next step's body (this step's flags, bits 4..7; the body of the other parity)
-        into PC; the jump itself comes last"""
+        into PC; the jump itself comes last.  finish=False: the table look-up only (it needs M0 and so must
+        stand in front of an index-mode region); next_pc_finish() then adds the block's address where the two
+        additions can hide behind matrix instructions"""
         t = self.TMP[0]
-        base = self.BASE[1 - self.p]
         self.salu(f"s_bfe_u32 m0, {self.cur(self.FLAGS)}, 0x40004")
         self.salu("s_nop 0")
         self.salu(f"s_movrels_b32 s{t}, s{self.OFFTAB}")
+        if finish:
+            self.next_pc_finish()
+
+    def next_pc_finish(self):
+        t = self.TMP[0]
+        base = self.BASE[1 - self.p]
         self.salu(f"s_add_u32 s{self.PC}, s{base}, s{t}")
         self.salu(f"s_addc_u32 s{self.PC + 1}, s{base + 1}, 0")
 
@@ -702,7 +709,7 @@ class Loops:
         self.label(self.L(f"{name}_{parity}"))
         self.e.comment(f"post-order step, children ({K0},{K1})" + (", message handed to the next step" if hand_over else "")
                        + f", descriptor set {parity}")
-        self.next_pc()
+        self.next_pc(finish=False)
         self.messages(kinds)
         self.wait(lgkm=0)  # stored operands, the next step's descriptor (and stores two steps old)
         self.cell_write(held, ad[6])  # the previous step's message
@@ -721,6 +728,7 @@ class Loops:
         # next step's stored operands and the descriptor after it requested underneath
         self.idx_on(self.cur(self.IMGOWN), "SRC0")
         self.request_descriptor_after_next()
+        self.next_pc_finish()  # (behind the matrix instructions that follow)
         for g in range(G):
             self.mfma(own[g], ("A", 0), self.X[0][g])
         self.cell_read(self.M[0], ad[0])
