@@ -539,16 +539,18 @@ class Loops:
         """the next step's descriptor into the other set (one scalar load; nothing waits for it before the
         end of the body -- the body finds what it must know about the next step in its own descriptor)"""
         d = self.DESC[1 - self.p]
-        self.salu(f"s_add_u32 s{self.TABOFF}, s{self.TABOFF}, 64")
+        # (the offset is advanced BEHIND the load: that addition can hide behind a matrix instruction)
         self.mem(f"s_load_dwordx16 s[{d}:{d + 15}], s[{self.TAB}:{self.TAB + 1}], s{self.TABOFF}")
+        self.salu(f"s_add_u32 s{self.TABOFF}, s{self.TABOFF}, 64")
 
     def request_descriptor_after_next(self):
         """post-order: the descriptor of the step AFTER the next one into this step's own set, once the body has
         read the last of its own fields -- it is waited for half a step later, in the next body, together
         with that body's operands, so that no body waits for a scalar load or a store it has just issued"""
         d = self.DESC[self.p]
-        self.salu(f"s_add_u32 s{self.TABOFF}, s{self.TABOFF}, 64")
+        # (the offset is advanced BEHIND the load: that addition can hide behind a matrix instruction)
         self.mem(f"s_load_dwordx16 s[{d}:{d + 15}], s[{self.TAB}:{self.TAB + 1}], s{self.TABOFF}")
+        self.salu(f"s_add_u32 s{self.TABOFF}, s{self.TABOFF}, 64")
         self.own_set_requested = True
 
     def next_pc(self, finish=True):
@@ -603,7 +605,7 @@ class Loops:
         way out of the loop)"""
         G = self.G
         self.salu(f"s_mov_b64 s[{self.TAB}:{self.TAB + 1}], %[tab]")
-        self.salu(f"s_mov_b32 s{self.TABOFF}, {64 if two_ahead else 0}")
+        self.salu(f"s_mov_b32 s{self.TABOFF}, {128 if two_ahead else 64}")  # (offset of the next descriptor to request)
         self.mem(f"s_load_dwordx16 s[{self.DESC[0]}:{self.DESC[0] + 15}], s[{self.TAB}:{self.TAB + 1}], 0x0")
         if two_ahead:
             self.mem(f"s_load_dwordx16 s[{self.DESC[1]}:{self.DESC[1] + 15}], s[{self.TAB}:{self.TAB + 1}], 0x40")
@@ -709,8 +711,8 @@ class Loops:
         self.label(self.L(f"{name}_{parity}"))
         self.e.comment(f"post-order step, children ({K0},{K1})" + (", message handed to the next step" if hand_over else "")
                        + f", descriptor set {parity}")
-        self.next_pc(finish=False)
         self.messages(kinds)
+        self.next_pc(finish=False)  # (behind the tip products, where there are any)
         self.wait(lgkm=0)  # stored operands, the next step's descriptor (and stores two steps old)
         self.cell_write(held, ad[6])  # the previous step's message
         # x = m0 . m1 (the node's partial); the root's leaves the loop in X[0]
@@ -731,10 +733,10 @@ class Loops:
         self.next_pc_finish()  # (behind the matrix instructions that follow)
         for g in range(G):
             self.mfma(own[g], ("A", 0), self.X[0][g])
+        self.idx_off()
         self.cell_read(self.M[0], ad[0])
         if not hand_over:
             self.cell_read(self.M[1], ad[1])
-        self.idx_off()
         if hand_over:
             for g in range(G):
                 self.vmov64(held[g], own[g])
