@@ -778,11 +778,15 @@ class Loops:
         # reduction, level 1; the next body's code address sinks behind the matrix instructions
         self.flush_addresses(self.other(self.E0), self.other(self.E1))
         self.flush_stage1(self.ES[0], self.ES[1])
-        self.next_pc()
-        # Q m of the stored children: their messages are in registers already.  The previous step's edge sums
-        # leave for LDS in the middle of the matrix instructions (behind the first group that follows their own
-        # reduction): there the two EXEC moves and the two LDS instructions cost nothing, and the wait below --
-        # for the next descriptor, which must be lgkmcnt(0) -- finds them long done
+        # Tip and cherry messages first, then Q m of the stored children (their messages are in registers
+        # already), then Q m of the others: a matrix result is not a matrix operand for six wait states, and this
+        # order puts other matrix instructions in between.  The previous step's edge sums leave for LDS in the
+        # middle of the matrix instructions (behind the first group that follows their own reduction): there the
+        # two EXEC moves and the two LDS instructions cost nothing, and the wait below -- for the next descriptor,
+        # which must be lgkmcnt(0) -- finds them long done
+        self.request_descriptor()
+        self.messages(kinds)
+        self.next_pc()  # (sinks behind the matrix instructions that follow; M0 is free here)
         flushed = False
         for s in (0, 1):
             if kinds[s] == "C":
@@ -791,8 +795,6 @@ class Loops:
                 if not flushed:
                     self.flush_stage3()
                     flushed = True
-        self.request_descriptor()
-        self.messages(kinds)
         if not flushed:
             self.flush_stage3()
         for s in (0, 1):
@@ -816,7 +818,14 @@ class Loops:
         # P^T w: the children's pre-order partials, with the next step's reads issued underneath
         # (the registers they land in -- M[0], M[1], U -- have had their last use)
         first = True
-        nreq = 0
+        regions = sum(1 for k in kinds if k != "T")
+
+        def next_reads():
+            self.cell_read(self.M[0], ad[0])
+            self.cell_read(self.M[1], ad[1])
+            if not hand_over:
+                self.cell_read(self.U, ad[2])
+
         for s in (0, 1):
             if kinds[s] == "T":
                 continue
@@ -829,13 +838,12 @@ class Loops:
                 self.idx_set(self.cur(img[s]))
             for g in range(G):
                 self.mfma(dst[g], ("A", 2), self.W[s][g])
-            if first:
-                nreq += self.cell_read(self.M[0], ad[0])
-                nreq += self.cell_read(self.M[1], ad[1])
-                if not hand_over:
-                    nreq += self.cell_read(self.U, ad[2])
+            if first and regions > 1:
+                next_reads()
             first = False
-        self.idx_off()
+        self.idx_off()  # (right behind the last matrix instruction)
+        if regions <= 1:
+            next_reads()
         # edge sums of this step's two child edges (flushed by the next body)
         for s in (0, 1):
             for g in range(G):
