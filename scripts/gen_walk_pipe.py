@@ -628,9 +628,11 @@ class Loops:
         self.salu(f"s_mov_b32 s{self.OFFTAB + 10}, {self.L('out_0')}-{self.L('block0')}")
 
     # ---- child messages of one slot (both passes) ---------------------------------------------------
-    def messages(self, kinds):
+    def messages(self, kinds, scalar_work=None):
         """leaves the message of a tip / cherry slot s in MSG[s] -- a stored cell's message is M[s] itself.
-        Cherry: MA, MB (tip messages) are kept for the pre-order pass."""
+        Cherry: MA, MB (tip messages) are kept for the pre-order pass.  scalar_work: emits scalar instructions
+        the body needs anyway (they may use M0); they are placed where they fill wait states -- between a
+        cherry's tip products and their product -- or, without a cherry, at the end"""
         G = self.G
         t = self.TMPM
         tip = [[self.TIPA0, self.TIPB0], [self.TIPA1, self.TIPB1]]
@@ -672,6 +674,10 @@ class Loops:
                     self.mfma(self.MB[s][g], ("A", 0), self.TP[2 * s + 1][g])
         if not first:
             self.idx_off()
+        if scalar_work is not None and "H" in kinds:
+            scalar_work()
+            scalar_work = None
+            self.e.comment("(scalar work in the wait states between the tip products and their product)")  # (a comment pins them here)
         for s in (0, 1):
             if kinds[s] == "H":
                 for g in range(G):
@@ -684,6 +690,8 @@ class Loops:
                     self.mfma(self.MSG[s][g], ("A", 0), self.X[s][g])
         if not first:
             self.idx_off()
+        if scalar_work is not None:
+            scalar_work()
 
     def msg(self, s, kind):
         return self.M[s] if kind == "C" else self.MSG[s]
@@ -711,8 +719,7 @@ class Loops:
         self.label(self.L(f"{name}_{parity}"))
         self.e.comment(f"post-order step, children ({K0},{K1})" + (", message handed to the next step" if hand_over else "")
                        + f", descriptor set {parity}")
-        self.messages(kinds)
-        self.next_pc(finish=False)  # (behind the tip products, where there are any)
+        self.messages(kinds, lambda: self.next_pc(finish=False))  # (the table look-up behind the tip products)
         self.wait(lgkm=0)  # stored operands, the next step's descriptor (and stores two steps old)
         self.cell_write(held, ad[6])  # the previous step's message
         # x = m0 . m1 (the node's partial); the root's leaves the loop in X[0]
@@ -785,8 +792,7 @@ class Loops:
         # two EXEC moves and the two LDS instructions cost nothing, and the wait below -- for the next descriptor,
         # which must be lgkmcnt(0) -- finds them long done
         self.request_descriptor()
-        self.messages(kinds)
-        self.next_pc()  # (sinks behind the matrix instructions that follow; M0 is free here)
+        self.messages(kinds, self.next_pc)  # (the jump address: M0 is free there, and matrix instructions follow)
         flushed = False
         for s in (0, 1):
             if kinds[s] == "C":
