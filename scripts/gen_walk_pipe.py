@@ -94,6 +94,8 @@ class Ins:
                 sw.update(ops[0])
                 sr.difference_update(ops[0])
             sr.update({"exec", "mode"})  # every vector / memory instruction runs under EXEC and the index mode
+            if op.startswith("global_load_lds"):
+                sr.add("m0")  # (the LDS address of a load that goes straight to LDS)
             if indexed:
                 sr.add("m0")  # ... and inside an index-mode region M0 is part of its operand
         self.sreads, self.swrites = sr, sw
@@ -934,13 +936,18 @@ class Loops:
 
     # =============================== image loader ==================================================
     def load_images(self):
-        """the tree's matrix images into the AGPR file: P of %[ntips] tip branches (8 of a lane's 16 bytes) from
-        %[img], (P, P^T) of %[ninner] internal branches from %[inner] (= %[img] + 1024 %[ntips])"""
+        """the tree's matrix images into the AGPR file of every wave: the four waves of the workgroup fetch a
+        quarter of the branches each, straight into LDS (global_load_lds_dwordx4; the arena is idle between two
+        units), and after a barrier every wave reads all of them from there -- P of %[ntips] tip branches (8 of
+        a lane's 16 bytes) into a[2 tip], (P, P^T) of %[ninner] internal branches into a[INNER_BASE + 4 j].
+        Four waves fetching the same 40 to 75 KB through one L1 was 7 k cycles per unit."""
         self.e = Emitter()
         self.tag = "load"
         e = self.e
         e.comment("matrix images of the whole tree into the AGPR file")
         ip = self.IMGP
+        scratch = self.DESC[1]  # (the loops' descriptor registers are idle here)
+        s_branch, s_m0, s_nb = scratch, scratch + 1, scratch + 2
         # the step tables into the scalar cache: %[lines] descriptors of 64 bytes behind %[tab]
         warm = self.L("warm")
         for k in range(2 * (self.MAX_TIPS + 1)):
@@ -949,30 +956,46 @@ class Loops:
                 self.e.control(f"s_cbranch_scc1 {warm}")
             self.mem(f"s_load_dword s{self.TMP[2]}, %[tab], {hex(64 * k)}")
         self.e.label(warm)
+        # global -> LDS: this wave's branches are wave, wave + 4, ...
+        self.salu(f"s_add_u32 s{s_nb}, %[ntips], %[ninner]")
+        self.salu(f"s_lshl_b32 s{s_m0}, %[wave], 10")
         self.salu(f"s_mov_b64 s[{ip}:{ip + 1}], %[img]")
+        self.salu(f"s_add_u32 s{ip}, s{ip}, s{s_m0}")
+        self.salu(f"s_addc_u32 s{ip + 1}, s{ip + 1}, 0")
+        self.salu(f"s_add_u32 s{s_m0}, s{s_m0}, %[stage_s]")
+        self.salu(f"s_mov_b32 s{s_branch}, %[wave]")
+        staged = self.L("staged")
+        for k in range((self.MAX_TIPS + self.MAX_INNER + 3) // 4):
+            self.salu(f"s_cmp_ge_u32 s{s_branch}, s{s_nb}")
+            self.e.control(f"s_cbranch_scc1 {staged}")
+            self.salu(f"s_mov_b32 m0, s{s_m0}")
+            self.salu("s_nop 0")
+            self.mem(f"global_load_lds_dwordx4 %[lane16], s[{ip}:{ip + 1}]")
+            self.salu(f"s_add_u32 s{s_branch}, s{s_branch}, 4")
+            self.salu(f"s_add_u32 s{s_m0}, s{s_m0}, 4096")
+            self.salu(f"s_add_u32 s{ip}, s{ip}, 4096")
+            self.salu(f"s_addc_u32 s{ip + 1}, s{ip + 1}, 0")
+        self.e.label(staged)
+        self.wait(vm=0)
+        self.e.control("s_barrier")
+        # LDS -> AGPRs, every wave all branches
         tips_done = self.L("tips")
         for t in range(self.MAX_TIPS):
             if t % 4 == 0:
                 self.salu(f"s_cmp_le_u32 %[ntips], {t}")
                 self.e.control(f"s_cbranch_scc1 {tips_done}")
-            self.mem(f"global_load_dwordx2 a[{2 * t}:{2 * t + 1}], %[lane16], s[{ip}:{ip + 1}] offset:{(t % 4) * 1024}")
-            if t % 4 == 3:
-                self.salu(f"s_add_u32 s{ip}, s{ip}, 4096")
-                self.salu(f"s_addc_u32 s{ip + 1}, s{ip + 1}, 0")
+            self.mem(f"ds_read_b64 a[{2 * t}:{2 * t + 1}], %[stage_tips] offset:{t * 1024}")
         self.e.label(tips_done)
-        self.salu(f"s_mov_b64 s[{ip}:{ip + 1}], %[inner]")
         done = self.L("done")
         for j in range(self.MAX_INNER):
             if j % 4 == 0:
                 self.salu(f"s_cmp_le_u32 %[ninner], {j}")
                 self.e.control(f"s_cbranch_scc1 {done}")
             r = self.INNER_BASE + 4 * j
-            self.mem(f"global_load_dwordx4 a[{r}:{r + 3}], %[lane16], s[{ip}:{ip + 1}] offset:{(j % 4) * 1024}")
-            if j % 4 == 3:
-                self.salu(f"s_add_u32 s{ip}, s{ip}, 4096")
-                self.salu(f"s_addc_u32 s{ip + 1}, s{ip + 1}, 0")
+            self.mem(f"ds_read_b128 a[{r}:{r + 3}], %[stage_inner] offset:{j * 1024}")
         self.e.label(done)
         self.wait(vm=0, lgkm=0)
+        self.e.control("s_barrier")  # (the staging area is the arena: nobody writes a cell before everybody has read)
         return e
 
 
