@@ -1,5 +1,6 @@
 """BASELINE config 2 (DS1, JC69, one rate category, log-likelihood only, 1600 trees resident): every kernel
-that takes it, against the CPU checker, with its time per pass."""
+that takes it, against the CPU checker, with its time per pass.
+usage: python scripts/gpu_config2.py [replicas of the 100 topologies per pass, default 16]"""
 import os
 import sys
 
@@ -10,7 +11,8 @@ import bito_amd
 from bito_amd import _capi, workloads
 from oracle import oracle
 
-w = workloads.ds1_jc69(16)
+replicas = int(sys.argv[1]) if len(sys.argv) > 1 else 16  # x100 topologies per pass
+w = workloads.ds1_jc69(replicas)
 eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights)
 small = w.subset(10)
 cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
