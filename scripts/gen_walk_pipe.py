@@ -852,22 +852,17 @@ class Loops:
         self.idx_off()  # (right behind the last matrix instruction)
         if regions <= 1:
             next_reads()
-        # edge sums of this step's two child edges (flushed by the next body)
-        for s in (0, 1):
-            for g in range(G):
-                if g == 0:
-                    self.vmul(self.ES[s], self.W[s][g], self.DQ[s][g])
-                else:
-                    self.vfma(self.ES[s], self.W[s][g], self.DQ[s][g], self.ES[s])
-        # cherry children: the two tip edges under each (gradient rows 8 x tip id).  A cherry's sums leave for
-        # LDS behind the next block of work (the second cherry's matrix instructions, or this step's stores): a
-        # matrix result is not storable for nine wait states
+        # cherry children: the two tip edges under each (gradient rows 8 x tip id).  The tip messages are spent by
+        # then, so the products u . m_other of the two tips overwrite them in place (TA in MB, TB in MA).  A
+        # cherry's sums leave for LDS behind the next block of work: a matrix result is not storable for nine
+        # wait states -- the second cherry's matrix instructions, or the step's own edge sums, which therefore
+        # come last
         nst = 0
         pending = False
         for s in (0, 1):
             if kinds[s] != "H":
                 continue
-            DQA, DQB, TA, TB = self.MSG[s], self.UC[0], self.W[s], self.DQ[s]
+            DQA, DQB, TA, TB = self.MSG[s], self.UC[0], self.MB[s], self.MA[s]
             for g in range(G):
                 self.mfma(DQA[g], "Q", self.MA[s][g])
             self.salu(f"s_lshl_b32 s{t[1]}, {self.cur(tip[s][0])}, 3")  # gradient rows of the two tip edges: 8 x tip id
@@ -890,6 +885,13 @@ class Loops:
             self.flush_addresses(f"s{t[1]}", f"s{t[2]}")
             self.flush_stage1(self.EA, self.EB)
             pending = True
+        # edge sums of this step's two child edges (flushed by the next body)
+        for s in (0, 1):
+            for g in range(G):
+                if g == 0:
+                    self.vmul(self.ES[s], self.W[s][g], self.DQ[s][g])
+                else:
+                    self.vfma(self.ES[s], self.W[s][g], self.DQ[s][g], self.ES[s])
         # this step's stores
         if K0 == "C":
             nst += self.cell_write(self.UC[0], ad[3])
