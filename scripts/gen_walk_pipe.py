@@ -815,22 +815,23 @@ class Loops:
         for g in range(G):
             self.vmul(self.W[0][g], self.U[g], m1[g])
             self.vmul(self.W[1][g], self.U[g], m0[g])
-        self.v32(f"v_add_u32 v{ad[0]}, {self.cur(self.NOFFC0)}, %[arena]", [], [ad[0]])
-        self.v32(f"v_add_u32 v{ad[1]}, {self.cur(self.NOFFC1)}, %[arena]", [], [ad[1]])
+        # Cell addresses: the cells this step's children's partials go to are the cells their messages came from,
+        # i.e. the addresses the previous body computed for its requests -- two register pairs used alternately
+        # (bodies come once per parity), so a step computes the next step's addresses only
+        mine = [ad[0], ad[1]] if parity == 0 else [ad[3], ad[4]]
+        nxt = [ad[3], ad[4]] if parity == 0 else [ad[0], ad[1]]
+        self.v32(f"v_add_u32 v{nxt[0]}, {self.cur(self.NOFFC0)}, %[arena]", [], [nxt[0]])
+        self.v32(f"v_add_u32 v{nxt[1]}, {self.cur(self.NOFFC1)}, %[arena]", [], [nxt[1]])
         if not hand_over:
             self.v32(f"v_add_u32 v{ad[2]}, {self.cur(self.NOWN)}, %[arena]", [], [ad[2]])
-        if K0 == "C":
-            self.v32(f"v_add_u32 v{ad[3]}, {self.cur(self.OFFC0)}, %[arena]", [], [ad[3]])
-        if K1 == "C":
-            self.v32(f"v_add_u32 v{ad[4]}, {self.cur(self.OFFC1)}, %[arena]", [], [ad[4]])
         # P^T w: the children's pre-order partials, with the next step's reads issued underneath
         # (the registers they land in -- M[0], M[1], U -- have had their last use)
         first = True
         regions = sum(1 for k in kinds if k != "T")
 
         def next_reads():
-            self.cell_read(self.M[0], ad[0])
-            self.cell_read(self.M[1], ad[1])
+            self.cell_read(self.M[0], nxt[0])
+            self.cell_read(self.M[1], nxt[1])
             if not hand_over:
                 self.cell_read(self.U, ad[2])
 
@@ -894,9 +895,9 @@ class Loops:
                     self.vfma(self.ES[s], self.W[s][g], self.DQ[s][g], self.ES[s])
         # this step's stores
         if K0 == "C":
-            nst += self.cell_write(self.UC[0], ad[3])
+            nst += self.cell_write(self.UC[0], mine[0])
         if K1 == "C":
-            nst += self.cell_write(self.U if hand_over else self.UC[1], ad[4])
+            nst += self.cell_write(self.U if hand_over else self.UC[1], mine[1])
         if pending:
             nst += self.flush_stage3()
         self.wait(lgkm=nst)  # everything requested has landed; the stores may still travel
