@@ -555,14 +555,17 @@ class Loops:
         self.salu(f"s_add_u32 s{self.TABOFF}, s{self.TABOFF}, 64")
         self.own_set_requested = True
 
-    def next_pc(self, finish=True):
+    def next_pc(self, finish=True, between=None):
         """code address of the next step's body (this step's flags, bits 4..7; the body of the other parity)
         into PC; the jump itself comes last.  finish=False: the table look-up only (it needs M0 and so must
         stand in front of an index-mode region); next_pc_finish() then adds the block's address where the two
         additions can hide behind matrix instructions"""
         t = self.TMP[0]
         self.salu(f"s_bfe_u32 m0, {self.cur(self.FLAGS)}, 0x40004")
-        self.salu("s_nop 0")
+        if between is not None:
+            between()  # (an instruction the body needs anyway stands in for the wait state behind the M0 write)
+        else:
+            self.salu("s_nop 0")
         self.salu(f"s_movrels_b32 s{t}, s{self.OFFTAB}")
         if finish:
             self.next_pc_finish()
@@ -721,8 +724,16 @@ class Loops:
         self.label(self.L(f"{name}_{parity}"))
         self.e.comment(f"post-order step, children ({K0},{K1})" + (", message handed to the next step" if hand_over else "")
                        + f", descriptor set {parity}")
-        self.messages(kinds, lambda: self.next_pc(finish=False))  # (the table look-up behind the tip products)
-        self.wait(lgkm=0)  # stored operands, the next step's descriptor (and stores two steps old)
+        # (the table look-up behind the tip products; without a cherry the step's one wait sits in its middle)
+        waited = [False]
+
+        def wait_here():
+            self.wait(lgkm=0)
+            waited[0] = True
+
+        self.messages(kinds, lambda: self.next_pc(finish=False, between=None if "H" in kinds else wait_here))
+        if not waited[0]:
+            self.wait(lgkm=0)  # stored operands, the next step's descriptor (and stores two steps old)
         self.cell_write(held, ad[6])  # the previous step's message
         # x = m0 . m1 (the node's partial); the root's leaves the loop in X[0]
         m0, m1 = self.msg(0, K0), self.msg(1, K1)
