@@ -281,15 +281,23 @@ class Loops:
     move 1 KB per wave at 128 / 79 bytes per clock per CU, ds_read_b128 twice as fast.  Hence:
 
       * everything that can be scalar is scalar and sits behind matrix instructions: a step's descriptor
-        arrives by ONE s_load_dwordx8 (requested a step ahead, its table kept in the scalar cache), its
-        fields are unpacked with SALU, bodies are branch-free (EXEC predicates for the optional reads and
-        hand-overs), and the jump to the next body goes through a table of code offsets;
-      * the (P, P^T) images of every branch of the tree live in the AGPR file (a[4b..4b+3], loaded once per
-        run of tiles) and the matrix instruction reads its A operand there through the VGPR index mode
-        (s_set_gpr_idx_on adds M0 to the register number of source 0, AGPR sources included): no image is
-        fetched, staged or copied inside the loops;
+        arrives by ONE s_load_dwordx16, already unpacked, into one of two register sets (every body exists once
+        per set), requested a step ahead (pre-order) or two (post-order) from a table the unit has warmed into
+        the scalar cache; bodies are branch-free and specialised on the kinds of the two children and on
+        whether a vector is handed to the next step in registers; the jump to the next body goes through a
+        table of code offsets;
+      * the images of every branch of the tree live in the AGPR file (P of a tip's branch at a[2 tip], (P, P^T)
+        of an internal branch at a[INNER_BASE + 4 j], loaded once per unit of work) and the matrix instruction
+        reads its A operand there through the VGPR index mode (s_set_gpr_idx_on adds M0 to the register number
+        of source 0, AGPR sources included): no image is fetched, staged or copied inside the loops;
       * the packed tip masks of all tips of the tile live in VGPRs (one per tip), read through the same
-        index mode on source 1: no tip traffic inside the loops either;
+        index mode on source 1 by an SDWA shift -- one vector instruction per tip operand: no tip traffic
+        inside the loops either;
+      * nothing a body waits for is younger than a step: stores are issued a step late (post-order) or not
+        waited for at all, and the edge sums leave for LDS in the middle of matrix instructions;
+      * scalar instructions are placed where they are free (pass 1 below sinks them behind matrix instructions;
+        the bodies order their own work so that M0, EXEC and index-mode changes fall behind one as well), and the
+        wait states the hardware needs are filled with work the body has to do anyway;
       * stored cells are 16 bytes per lane (two pattern groups side by side): ds_read_b128 / ds_write_b128."""
 
     # Matrix images in the AGPR file, a0..a223 (a224.. and v0..v(VBASE-1) stay with the compiler): a tip's branch
