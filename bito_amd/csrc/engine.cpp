@@ -505,11 +505,11 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   }
   const bool two_classes = use_pipe && split.active;
   if (two_classes) plan = split.plan_b;  // (class B's plan is the one the shared buffers and tables are sized by)
-  const int tiles = use_tree ? tplan.tiles : (use_lds ? std::max(plan.tiles, two_classes ? split.plan_a.tiles : 0) : HbmTiles(d.pattern_count));
+  const int tiles = use_tree ? tplan.tiles : (use_lds ? std::max(plan.tiles, two_classes ? split.plan_a.tiles : 0) : HbmWalkTiles(d));
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
   // partial gradient rows per tree: one per tile (LDS kernels), per run of tiles (pipelined LDS kernel), per wave (HBM kernel)
   const int pipe_rows = two_classes ? std::max(split.plan_a.grad_rows, split.plan_b.grad_rows) : plan.grad_rows;
-  const int grad_rows = (use_pipe && pipe_rows > 0) ? pipe_rows : (use_tree || use_lds) ? tiles : tiles * (kHbmBlock / 64);
+  const int grad_rows = (use_pipe && pipe_rows > 0) ? pipe_rows : (use_tree || use_lds) ? tiles : HbmWalkGradRows(d);
   if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * grad_rows * d.node_count));
   if (use_tree || use_lds) {
     // pipelined: this pass's set-up goes to prep_stream and into buffer set (run_counter mod kSets)
@@ -620,7 +620,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
       ev1 = NextEvent(e);
       HIP_TRY(e, hipEventRecord(ev0, e->stream));
     }
-    LaunchWalkHbm(d, b, t0, ct, want_gradient, rescaling, e->stream);
+    LaunchWalkHbm(d, b, t0, ct, want_gradient, rescaling, e->stream, deriv_mode);
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
   }
   e->kernel_name = WalkHbmKernelName(d.category_count, want_gradient, rescaling);

@@ -80,8 +80,46 @@ BODY2(k_mfma_4salu, MF "s_add_u32 s40, s41, 1\n s_add_u32 s42, s41, 1\n s_add_u3
 BODY2(k_mfma_salu_dsread, MF "s_add_u32 s40, s41, 1\n ds_read_b128 v[104:107], %3\n")
 BODY2(k_4mfma, MF MF MF MF)
 
+// Two waves per SIMD (512-thread workgroups: wave w runs on SIMD w % 4): waves 0-3 repeat textA, waves 4-7
+// textB; each half reports its own time.  Answers whether one wave's vector / scalar / LDS work overlaps the
+// other wave's matrix instructions.
+#define PAIR(name, textA, textB)                                                                  \
+  __global__ void __launch_bounds__(512) name(long long* out, double* sink) {                     \
+    extern __shared__ double lds[];                                                               \
+    double a = threadIdx.x * 0.5 + 1.0, b = 1.000001, c = 0.5, d = 2.0;                           \
+    unsigned la = threadIdx.x * 16;                                                               \
+    lds[threadIdx.x] = a;                                                                         \
+    __syncthreads();                                                                              \
+    long long t0 = clock64();                                                                     \
+    if (threadIdx.x < 256) {                                                                      \
+      for (int it = 0; it < 16; it++) asm volatile(REP64(textA) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(la) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "s40", "s41", "s42", "s43", "memory"); \
+    } else {                                                                                      \
+      for (int it = 0; it < 16; it++) asm volatile(REP64(textB) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(la) : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "s40", "s41", "s42", "s43", "memory"); \
+    }                                                                                             \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");                                                \
+    long long t1 = clock64();                                                                     \
+    if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) out[threadIdx.x / 256] = t1 - t0; \
+    sink[blockIdx.x * 512 + threadIdx.x] = a + b + c + d;                                         \
+  }
+#define MFV "v_mfma_f64_4x4x4_4b_f64 v[100:101], %1, %2, 0\n"
+PAIR(p_mfma_mfma, MFV, MFV)
+PAIR(p_mfma_valu32, MFV, "v_add_u32 v100, v101, v102\n")
+PAIR(p_mfma_mul64, MFV, "v_mul_f64 v[100:101], %1, %2\n")
+PAIR(p_mfma_salu, MFV, "s_add_u32 s40, s41, 1\n")
+PAIR(p_mfma_dsread128, MFV, "ds_read_b128 v[104:107], %4\n")
+PAIR(p_mfma_dswrite128, MFV, "ds_write_b128 %4, v[104:107]\n")
+PAIR(p_valu32_valu32, "v_add_u32 v100, v101, v102\n", "v_add_u32 v100, v101, v102\n")
+PAIR(p_mul64_mul64, "v_mul_f64 v[100:101], %1, %2\n", "v_mul_f64 v[100:101], %1, %2\n")
+PAIR(p_mul64_valu32, "v_mul_f64 v[100:101], %1, %2\n", "v_add_u32 v100, v101, v102\n")
+PAIR(p_branch_branch, "s_branch 1f\n s_nop 0\n 1:\n", "s_branch 1f\n s_nop 0\n 1:\n")
+PAIR(p_mfma_branch, MFV, "s_branch 1f\n s_nop 0\n 1:\n")
+// the mix of a loop body (per matrix instruction: 1.7 vector, 0.9 scalar, 0.4 LDS), both waves the same
+#define MIX MFV "v_mul_f64 v[104:105], %1, %2\n s_add_u32 s40, s41, 1\n" MFV "v_add_u32 v106, v107, v106\n ds_read_b128 v[100:103], %4\n" MFV "v_mul_f64 v[104:105], %1, %2\n v_add_u32 v106, v107, v106\n s_add_u32 s42, s41, 1\n"
+PAIR(p_mix_mix, MIX, MIX)
+PAIR(p_mix_idle, MIX, "s_nop 0\n")
+
 int main() {
-  long long* out; double* sink; hipMalloc(&out, 8); hipMalloc(&sink, 256 * 256 * 8);
+  long long* out; double* sink; hipMalloc(&out, 16); hipMalloc(&sink, 256 * 512 * 8);
 #define RUN(k, n) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     hipLaunchKernelGGL(k, dim3(256), dim3(256), 150 * 1024, 0, out, sink); long long c; hipMemcpy(&c, out, 8, hipMemcpyDeviceToHost); \
     printf("%-16s %7.2f cycles per repetition (%d instr)\n", #k, c / 1024.0, n); }
@@ -97,5 +135,10 @@ int main() {
   RUN2(k_mfma_agpr_idx, 4) RUN2(k_mfma_then_mul, 3) RUN2(k_4mfma_4mul, 8)
   RUN2(k_mfma_dsread128, 2) RUN2(k_4mfma_4dsread128, 8) RUN2(k_mfma_dswrite128, 2) RUN2(k_4mfma_2dswrite128, 6) RUN2(k_mfma_4salu, 5)
   RUN2(k_mfma_salu_dsread, 3) RUN2(k_4mfma, 4)
+#define RUNP(k) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(k, dim3(256), dim3(512), 150 * 1024, 0, out, sink); long long c[2]; hipMemcpy(c, out, 16, hipMemcpyDeviceToHost); \
+    printf("%-20s %7.2f | %7.2f cycles per repetition (two waves per SIMD: first text | second text)\n", #k, c[0] / 1024.0, c[1] / 1024.0); }
+  RUNP(p_mfma_mfma) RUNP(p_mfma_valu32) RUNP(p_mfma_mul64) RUNP(p_mfma_salu) RUNP(p_mfma_dsread128) RUNP(p_mfma_dswrite128)
+  RUNP(p_valu32_valu32) RUNP(p_mul64_mul64) RUNP(p_mul64_valu32) RUNP(p_branch_branch) RUNP(p_mfma_branch) RUNP(p_mix_mix) RUNP(p_mix_idle)
     return 0;
 }

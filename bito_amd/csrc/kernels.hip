@@ -18,6 +18,7 @@
 // FP64 throughout.  No atomics anywhere: every sum has a fixed order, so results
 // are bit-reproducible run to run.
 #include "kernels.hpp"
+#include <cstdlib>
 
 #ifndef HBM_PRE_UNROLL
 #define HBM_PRE_UNROLL 1  // rate categories of a pre-order step whose loads are in flight together
@@ -597,7 +598,11 @@ static void LaunchWalkHbmC(const BatchDims& d, const DeviceBatch& b, int tree0, 
 }
 
 void LaunchWalkHbm(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk, int want_gradient,
-                   int rescaling, hipStream_t stream) {
+                   int rescaling, hipStream_t stream, int deriv_mode) {
+  if (HbmCatKernelApplies(d)) {
+    LaunchWalkHbmCat(d, b, tree0, chunk, want_gradient, rescaling, deriv_mode, stream);  // walk_hbm_cat.hip
+    return;
+  }
   switch (d.category_count) {
     case 1: LaunchWalkHbmC<1>(d, b, tree0, chunk, want_gradient, rescaling, stream); break;
     case 2: LaunchWalkHbmC<2>(d, b, tree0, chunk, want_gradient, rescaling, stream); break;
@@ -611,7 +616,11 @@ void LaunchWalkHbm(const BatchDims& d, const DeviceBatch& b, int tree0, int chun
   }
 }
 
-const char* WalkHbmKernelName(int, int, int) { return "walk_hbm_kernel"; }
+const char* WalkHbmKernelName(int category_count, int, int) {
+  BatchDims d{};
+  d.category_count = category_count;
+  return HbmCatKernelApplies(d) ? "walk_hbm_cat_kernel" : "walk_hbm_kernel";
+}
 
 // --------------------------------------------------------------------------
 // Final per-tree sums over pattern tiles, fixed order.

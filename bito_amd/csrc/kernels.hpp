@@ -190,9 +190,17 @@ void LaunchWalkTree(const BatchDims& d, const DeviceBatch& b, const TreePlan& pl
 constexpr int kHbmBlock = 256;
 inline int HbmTiles(int pattern_count) { return (pattern_count + kHbmBlock - 1) / kHbmBlock; }
 size_t HbmArenaBytesPerTree(const BatchDims& d);
+// deriv_mode as in LaunchMatrices (1: the site-model pass, rates replaced by d r_c / d shape)
 void LaunchWalkHbm(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk_trees,
-                   int want_gradient, int rescaling, hipStream_t stream);
+                   int want_gradient, int rescaling, hipStream_t stream, int deriv_mode = 0);
 const char* WalkHbmKernelName(int category_count, int want_gradient, int rescaling);
+// pattern tiles and partial gradient rows per tree of the HBM-arena kernel that LaunchWalkHbm picks for d
+// (walk_hbm_cat_kernel, one wave per rate category, for 2 to 4 categories; walk_hbm_kernel otherwise)
+int HbmWalkTiles(const BatchDims& d);
+int HbmWalkGradRows(const BatchDims& d);
+bool HbmCatKernelApplies(const BatchDims& d);
+void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk_trees, int want_gradient,
+                      int rescaling, int deriv_mode, hipStream_t stream);
 
 // grad_rows: partial gradient rows per tree (default: one per tile; the HBM-arena kernel writes one per wave)
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,

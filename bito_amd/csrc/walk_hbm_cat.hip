@@ -1,0 +1,381 @@
+// walk_hbm_cat.hip -- the HBM-arena traversal with one wave per (64 patterns, rate category).
+// Reference path: FatBeagle::LogLikelihoodInternals / Gradient (src/fat_beagle.cpp:253-373), the arithmetic of
+// kernels.hip (walk_hbm_kernel) re-dealt over threads.  FP64, no atomics, fixed summation order.
+#include "kernels.hpp"
+#include <cstdlib>
+
+namespace bito_amd {
+
+// Sum over the 64 lanes by DPP moves (no LDS round trips, no address registers): after the six steps lane 63
+// holds the total -- the caller writes from lane 63.  Fixed order.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double DppAdd(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double WaveSumLast(double v) {
+  v = DppAdd<0x111, 0xf>(v);  // row_shr:1
+  v = DppAdd<0x112, 0xf>(v);  // row_shr:2
+  v = DppAdd<0x114, 0xf>(v);  // row_shr:4
+  v = DppAdd<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row's sum
+  v = DppAdd<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = DppAdd<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return v;
+}
+constexpr int kSumLane = 63;
+
+__device__ __forceinline__ double WaveSum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ void MatVec(const double* __restrict__ M, const double x[4], double out[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    out[i] = M[i * 4 + 0] * x[0] + M[i * 4 + 1] * x[1] + M[i * 4 + 2] * x[2] + M[i * 4 + 3] * x[3];
+}
+
+__device__ __forceinline__ void MatVecT(const double* __restrict__ M, const double x[4], double out[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    out[j] = M[0 * 4 + j] * x[0] + M[1 * 4 + j] * x[1] + M[2 * 4 + j] * x[2] + M[3 * 4 + j] * x[3];
+}
+
+// --------------------------------------------------------------------------
+// The same traversal with one WAVE per (64 patterns, rate category): walk_hbm_cat_kernel, 2 to 4 categories.
+//
+// walk_hbm_kernel above is bound by memory latency at the occupancy its registers allow (a thread carries all
+// categories of its pattern: 128 registers, four waves per SIMD, a load-wait round per category and step).
+// Here a thread owns ONE category of one pattern: a workgroup is C waves over the same 64 patterns, wave c
+// walks the tree in category c.  The matrices stay wave-uniform (scalar loads), a thread needs a third of the
+// registers, and twice as many waves per SIMD have their loads in flight.  Categories meet only twice:
+//   * after the post-order pass, through LDS: site likelihood L_p = sum_c w_c s_c, and each thread's share
+//     sigma_c = w_c s_c / L_p of it;
+//   * never in the pre-order pass: d log L_p / dt_e = sum_c sigma_c num_c / den_c, where num_c and den_c are the
+//     step's two sums IN category c (den_c is category c's site likelihood seen from that node; the ratio does
+//     not depend on how the vectors of category c are scaled) -- so each wave sums w_p sigma_c num_c / den_c over
+//     its lanes into its OWN gradient row and the final reduction adds the categories' rows.
+// Rescaling is per (pattern, category) and by powers of two (exponent of the largest entry; exact, no
+// logarithm, nothing stored): the log-likelihood takes the exponent sums of the C categories through
+// max / ldexp, the pre-order partials are scaled the same way on the fly, and the ratio num_c / den_c never sees
+// a factor.  BEAGLE's manual scaling divides by the maximum over ALL categories of a pattern
+// (SURVEY A9); the log-likelihood and derivatives are the same numbers up to rounding.
+// Arena: [tree][tile][node][category][state][64 patterns] -- a wave moves 512 contiguous bytes per access.
+constexpr int kCatTile = 64;
+inline int HbmCatTiles(int pattern_count) { return (pattern_count + kCatTile - 1) / kCatTile; }
+
+#ifndef HBM_CAT_WAVES
+#define HBM_CAT_WAVES 8
+#endif
+
+// Buffer accesses: a wave-uniform 128-bit descriptor (base in scalar registers), a wave-uniform byte offset, and
+// ONE 32-bit lane offset in a vector register -- no 64-bit per-lane pointers (the compiler otherwise keeps one
+// per stream, registers this kernel does not have at eight waves per SIMD).
+using BufferRsrc = __amdgpu_buffer_rsrc_t;
+typedef unsigned UInt2 __attribute__((ext_vector_type(2)));
+typedef unsigned UInt4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ BufferRsrc MakeRsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ double BufLoad(BufferRsrc r, unsigned lane_bytes, unsigned uniform_bytes) {
+  const UInt2 v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, 0);
+  return __hiloint2double(v.y, v.x);
+}
+__device__ __forceinline__ void BufStore(BufferRsrc r, unsigned lane_bytes, unsigned uniform_bytes, double x) {
+  UInt2 v;
+  v.x = __double2loint(x);
+  v.y = __double2hiint(x);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_bytes, uniform_bytes, 0);
+}
+// four consecutive doubles (a row of a transposed matrix, picked per lane)
+__device__ __forceinline__ void BufLoadRow(BufferRsrc r, unsigned lane_bytes, unsigned uniform_bytes, double out[4]) {
+  const UInt4 a = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, uniform_bytes, 0);
+  const UInt4 b = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes + 16, uniform_bytes, 0);
+  out[0] = __hiloint2double(a.y, a.x);
+  out[1] = __hiloint2double(a.w, a.z);
+  out[2] = __hiloint2double(b.y, b.x);
+  out[3] = __hiloint2double(b.w, b.z);
+}
+
+__device__ __forceinline__ void ScalePow2(double v[4], int& exponent_sum) {
+  const double mx = fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
+  const int ex = __builtin_amdgcn_frexp_exp(mx);  // 0 for mx == 0
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = __builtin_amdgcn_ldexp(v[i], -ex);
+  exponent_sum += ex;
+}
+
+template <bool GRAD, bool RESCALE>
+__global__ void __launch_bounds__(256, HBM_CAT_WAVES)
+walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
+                    const double* __restrict__ all_mats, const TreeModel* __restrict__ models,
+                    const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
+                    double* __restrict__ arena_base, double* __restrict__ part_ll, double* __restrict__ part_grad,
+                    int deriv_mode) {
+  extern __shared__ double lds[];  // [4][threads] hand-over column | [threads] terms | [threads] exponents
+  const int n = d.taxon_count, N = d.node_count, NI = n - 1, Ppad = d.pattern_stride, C = d.category_count;
+  const int tree = tree0 + blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, threads = blockDim.x;
+  const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = blockIdx.x * kCatTile + lane;
+  const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
+  const double* __restrict__ mats = all_mats + ((size_t)tree * (N - 1) * C + c) * kMatStride;  // + node * C * kMatStride
+  const size_t node_mat = (size_t)C * kMatStride;
+  const TreeModel* __restrict__ tm = models + tree;
+  // every per-lane access: descriptor (wave-uniform base) + wave-uniform byte offset + this lane's 32-bit offset
+  const BufferRsrc tips = MakeRsrc(tip_states + (size_t)blockIdx.x * kCatTile);  // [taxon * Ppad][lane]
+  const int tile_count = gridDim.x;
+  // [(node - n) * C * 2 KB][state * 512 + lane * 8]
+  const BufferRsrc arena = MakeRsrc(arena_base + (((size_t)blockIdx.y * tile_count + blockIdx.x) * NI * C + c) * 4 * kCatTile);
+  const BufferRsrc matrows = MakeRsrc(mats);  // [node * C * kMatStride * 8][(kMatPT + state * 4) * 8]
+  const unsigned node_bytes = (unsigned)C * 4 * kCatTile * 8, mat_bytes = (unsigned)C * kMatStride * 8;
+  const unsigned ulane = lane;
+  const unsigned lane8 = ulane * 8;  // (constant offsets go to the scalar offset: added to this they would be hoisted into registers of their own)
+  const double weight = weights[p];
+  struct Child {
+    int kind;  // 0 tip, 1 stored internal node, 2 cherry
+    int a, b;
+    int s, sb;
+  };
+  auto classify = [&](int cc) {
+    Child ci{0, 0, 0, 0, 0};
+    if (cc < n) {
+      ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)cc * Ppad, 0);
+    } else {
+      ci.a = __builtin_amdgcn_readfirstlane(ch[(cc - n) * 2]);
+      ci.b = __builtin_amdgcn_readfirstlane(ch[(cc - n) * 2 + 1]);
+      if (ci.a < n && ci.b < n) {
+        ci.kind = 2;
+        ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)ci.a * Ppad, 0);
+        ci.sb = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)ci.b * Ppad, 0);
+      } else {
+        ci.kind = 1;
+      }
+    }
+    return ci;
+  };
+  // row `state` of the transposed transition matrix of the branch above `node` (a tip's message)
+  auto tip_row = [&](int node, int state, double out[4]) {
+    BufLoadRow(matrows, (unsigned)(kMatPT * 8) + (unsigned)state * 32, (unsigned)node * mat_bytes, out);
+  };
+  auto fetch = [&](const Child& ci, int cc, double x[4]) {
+    if (ci.kind == 2) {
+      double ra[4], rb[4];
+      tip_row(ci.a, ci.s, ra);
+      tip_row(ci.b, ci.sb, rb);
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = ra[i] * rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = BufLoad(arena, lane8, (unsigned)(cc - n) * node_bytes + i * 512);
+    }
+  };
+
+  // ---- post-order ------------------------------------------------------------
+  int exponent_sum = 0;
+  double site = 0.0;
+  double dd[4];
+  int last = -1;
+  bool unsaved = false;
+  for (int node = n; node < N; ++node) {
+    const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
+    const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
+    if (c0 < n && c1 < n && node != N - 1) continue;  // a cherry: rebuilt where it is used
+    const Child k0 = classify(c0), k1 = classify(c1);
+    if (!GRAD && unsaved && c0 != last && c1 != last) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(last - n) * node_bytes + i * 512, dd[i]);
+    }
+    double A[4], B[4];
+    const double* m0 = mats + c0 * node_mat;
+    const double* m1 = mats + c1 * node_mat;
+    if (k0.kind == 0) {
+      tip_row(c0, k0.s, A);
+    } else {
+      double x[4];
+      if (c0 == last) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = dd[i];
+      } else {
+        fetch(k0, c0, x);
+      }
+      MatVec(m0 + kMatP, x, A);
+    }
+    if (k1.kind == 0) {
+      tip_row(c1, k1.s, B);
+    } else {
+      double x[4];
+      if (c1 == last) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = dd[i];
+      } else {
+        fetch(k1, c1, x);
+      }
+      MatVec(m1 + kMatP, x, B);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) dd[i] = A[i] * B[i];
+    last = node;
+    if (RESCALE) ScalePow2(dd, exponent_sum);
+    if (node == N - 1) {
+      site = tm->cat_weight[c] * (tm->pi[0] * dd[0] + tm->pi[1] * dd[1] + tm->pi[2] * dd[2] + tm->pi[3] * dd[3]);
+    } else if (GRAD) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(node - n) * node_bytes + i * 512, dd[i]);
+    } else {
+      unsaved = true;
+    }
+  }
+  // ---- the categories of a pattern meet: L_p and this category's share of it ---
+  double* __restrict__ fwd = lds + 4 * tid;                              // [threads][4]
+  double* __restrict__ terms = lds + 4 * threads;                        // [C][64]
+  int* __restrict__ exps = reinterpret_cast<int*>(lds + 5 * threads);    // [C][64]
+  terms[tid] = site;
+  exps[tid] = exponent_sum;
+  __syncthreads();
+  int emax = exps[lane];
+  for (int k = 1; k < C; k++) emax = max(emax, exps[k * 64 + lane]);
+  double total = 0.0;
+  for (int k = 0; k < C; k++) total += RESCALE ? __builtin_amdgcn_ldexp(terms[k * 64 + lane], exps[k * 64 + lane] - emax) : terms[k * 64 + lane];
+  const double mine = RESCALE ? __builtin_amdgcn_ldexp(site, exponent_sum - emax) : site;
+  const double ll = weight * (log(total) + (RESCALE ? emax * 0.693147180559945309417232121458 : 0.0));
+
+  if (c == 0) {
+    const double wll = WaveSum(ll);
+    if (lane == 0) part_ll[(size_t)tree * gridDim.x + blockIdx.x] = wll;
+  }
+  // ---- pre-order + edge derivatives -----------------------------------------
+  // Messages: a_k = P_k x_k.  With u the pre-order partial of the node,
+  //     den = sum_i u_i a0_i a1_i,   num_0 = sum_i u_i a1_i (Q a0)_i   (dP x = r_c Q P x: Q and P commute; the
+  //     factor r_c, or d r_c / d shape for the site-model pass, multiplies the wave's weight once),
+  //     pre(child 0) = P_0^T (u . a1).
+  // The step is written child by child so that few vectors are live at a time (eight waves per SIMD).
+  if (GRAD) {
+    const double gw = weight * (mine / total) * (deriv_mode ? tm->cat_rate_deriv[c] : tm->cat_rate[c]);  // w_p sigma_c r_c
+    double* __restrict__ my_row = part_grad + (((size_t)tree * gridDim.x + blockIdx.x) * C + c) * N;
+    const double* __restrict__ Q = tm->Q;
+    bool u_forwarded = false;
+    // message of a child: tip -> its row of P^T; stored -> P x; cherry -> P (a_a . a_b)
+    auto message = [&](const Child& ci, int cc, double A[4]) {
+      const double* m = mats + cc * node_mat;
+      if (ci.kind == 0) {
+        tip_row(cc, ci.s, A);
+      } else {
+        double x[4];
+        fetch(ci, cc, x);
+        MatVec(m + kMatP, x, A);
+      }
+    };
+    // the two tip edges of a cherry child whose pre-order partial is q
+    auto cherry_edges = [&](const Child& ci, const double q[4], double rden) {
+      double aa[4], ab[4], qa[4];
+      tip_row(ci.a, ci.s, aa);
+      tip_row(ci.b, ci.sb, ab);
+      MatVec(Q, aa, qa);
+      double sa = 0.0, sb = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) sa += q[i] * (ab[i] * qa[i]);
+      MatVec(Q, ab, qa);
+#pragma unroll
+      for (int i = 0; i < 4; i++) sb += q[i] * (aa[i] * qa[i]);
+      const double ga = WaveSumLast(sa * rden), gb = WaveSumLast(sb * rden);
+      if (lane == kSumLane) {
+        my_row[ci.a] = ga;
+        my_row[ci.b] = gb;
+      }
+    };
+    // the sum of a child's edge: sum_i (u . a_sibling)_i (Q a)_i, times w_p sigma_c r_c / den, over the wave's lanes
+    auto edge_sum = [&](int cc, const double A[4], const double UAs[4], double rden) {
+      double qa[4];
+      MatVec(Q, A, qa);
+      const double num = UAs[0] * qa[0] + UAs[1] * qa[1] + UAs[2] * qa[2] + UAs[3] * qa[3];
+      const double g = WaveSumLast(num * rden);
+      if (lane == kSumLane) my_row[cc] = g;
+    };
+    // an internal child's pre-order partial P^T (u . a_sibling): stored in place (the child's cell held its
+    // post-order partial, read for this step's message), handed to the next step through the thread's LDS
+    // column when the child is processed next (node - 1), or consumed here by a cherry's two tip edges
+    auto pre_part = [&](const Child& ci, int cc, const double UAs[4], double rden, bool forward) {
+      if (ci.kind == 0) return;
+      double q[4];
+      MatVecT(mats + cc * node_mat + kMatP, UAs, q);
+      if (ci.kind == 2) {
+        cherry_edges(ci, q, rden);
+        return;
+      }
+      if (RESCALE) { int unused = 0; ScalePow2(q, unused); }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (forward) fwd[i] = q[i];
+        else BufStore(arena, lane8, (unsigned)(cc - n) * node_bytes + i * 512, q[i]);
+      }
+    };
+    for (int node = N - 1; node >= n; --node) {
+      const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
+      const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
+      if (c0 < n && c1 < n && node != N - 1) continue;  // a cherry: handled inside its parent's step
+      const Child k0 = classify(c0), k1 = classify(c1);
+      double U[4], A0[4], A1[4];
+      if (node == N - 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) U[i] = tm->pi[i];
+      } else if (u_forwarded) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) U[i] = fwd[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) U[i] = BufLoad(arena, lane8, (unsigned)(node - n) * node_bytes + i * 512);
+      }
+      message(k0, c0, A0);
+      message(k1, c1, A1);
+      const bool fwd0 = k0.kind == 1 && c0 == node - 1;
+      const bool fwd1 = k1.kind == 1 && c1 == node - 1;
+      double UA1[4], UA0[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) UA1[i] = U[i] * A1[i];
+      const double den = UA1[0] * A0[0] + UA1[1] * A0[1] + UA1[2] * A0[2] + UA1[3] * A0[3];
+      // gw / den by reciprocal and two Newton steps (relative error ~1e-16; the full division's special-case
+      // handling costs a dozen registers the step does not have at eight waves per SIMD)
+      double r = __builtin_amdgcn_rcp(den);
+      r = fma(fma(-den, r, 1.0), r, r);
+      r = fma(fma(-den, r, 1.0), r, r);
+      const double rden = gw * r;
+      // both edge sums first: after them only u . a1 and u . a0 are live
+      edge_sum(c0, A0, UA1, rden);
+#pragma unroll
+      for (int i = 0; i < 4; i++) UA0[i] = U[i] * A0[i];
+      edge_sum(c1, A1, UA0, rden);
+      __builtin_amdgcn_sched_barrier(0);
+      pre_part(k0, c0, UA1, rden, fwd0);
+      __builtin_amdgcn_sched_barrier(0);
+      pre_part(k1, c1, UA0, rden, fwd1);
+      __builtin_amdgcn_sched_barrier(0);
+      u_forwarded = fwd0 || fwd1;
+    }
+  }
+}
+
+bool HbmCatKernelApplies(const BatchDims& d) {
+  static const bool classic = [] { const char* v = getenv("BITO_AMD_HBM_CLASSIC"); return v && v[0] == '1'; }();
+  return !classic && d.category_count >= 2 && d.category_count <= 4;
+}
+int HbmWalkTiles(const BatchDims& d) { return HbmCatKernelApplies(d) ? HbmCatTiles(d.pattern_count) : HbmTiles(d.pattern_count); }
+int HbmWalkGradRows(const BatchDims& d) {
+  return HbmCatKernelApplies(d) ? HbmCatTiles(d.pattern_count) * d.category_count : HbmTiles(d.pattern_count) * (kHbmBlock / 64);
+}
+
+void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk, int want_gradient,
+                      int rescaling, int deriv_mode, hipStream_t stream) {
+  const int threads = 64 * d.category_count;
+  const dim3 grid(HbmCatTiles(d.pattern_count), chunk), block(threads);
+  const size_t lds = (size_t)threads * (4 * sizeof(double) + sizeof(double) + sizeof(int));
+#define BITO_CAT(G, R) hipLaunchKernelGGL((walk_hbm_cat_kernel<G, R>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model, \
+                                          b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad, deriv_mode)
+  if (want_gradient) { if (rescaling) BITO_CAT(true, true); else BITO_CAT(true, false); }
+  else { if (rescaling) BITO_CAT(false, true); else BITO_CAT(false, false); }
+#undef BITO_CAT
+}
+
+}  // namespace bito_amd

@@ -166,7 +166,8 @@ def test_every_traversal_kernel_matches_oracle(kernel, model):
     assert ll_close(out["log_likelihood"], ref["log_likelihood"])
     assert grad_close(out["branch_lengths"], ref["branch_lengths"])
     assert ll_close(gpu.log_likelihoods(w.parent_ids, w.branch_lengths, params), ref["log_likelihood"])
-    expect = {_capi.KERNEL_HBM_ARENA: "walk_hbm_kernel", _capi.KERNEL_LDS: "walk_lds_kernel",
+    # (the HBM-arena walk has a form of its own for 2 to 4 rate categories: one wave per category)
+    expect = {_capi.KERNEL_HBM_ARENA: "walk_hbm_kernel" if site == "constant" else "walk_hbm_cat_kernel", _capi.KERNEL_LDS: "walk_lds_kernel",
               _capi.KERNEL_LDS_TREE: "walk_tree_kernel", _capi.KERNEL_LDS_PIPE: "walk_pipe_kernel"}[kernel]
     assert gpu.kernel_name() == expect
 
@@ -575,7 +576,7 @@ def test_site_model_gradient_fused_equals_second_pass():
     assert gpu.kernel_name() == "walk_lds_kernel"
     gpu.set_kernel(_capi.KERNEL_HBM_ARENA)
     twice = gpu.gradients(w.parent_ids, w.branch_lengths, params, flags=flags)
-    assert gpu.kernel_name() == "walk_hbm_kernel"
+    assert gpu.kernel_name() == "walk_hbm_cat_kernel"
     ref = cpu.gradients(w.parent_ids, w.branch_lengths, params, flags=oracle.GRAD_SITE_MODEL)
     assert grad_close(fused["site_model"], ref["site_model"])
     assert grad_close(fused_lds["site_model"], ref["site_model"])
@@ -741,9 +742,9 @@ def test_pipe_walk_on_extreme_tree_shapes(n, site):
 
 def test_auto_kernel_choice_at_the_pipe_walk_limits():
     """AUTO: 38 taxa is the last size whose branch images fit the AGPR file (walk_pipe_kernel), 39 taxa go to
-    walk_lds_kernel, rescaling to walk_hbm_kernel; each against the oracle."""
+    walk_lds_kernel, rescaling to the HBM-arena walk (walk_hbm_cat_kernel with four categories); each against the oracle."""
     rng = np.random.default_rng(29)
-    for n, rescaling, expect in ((38, False, "walk_pipe_kernel"), (39, False, "walk_lds_kernel"), (29, True, "walk_hbm_kernel")):
+    for n, rescaling, expect in ((38, False, "walk_pipe_kernel"), (39, False, "walk_lds_kernel"), (29, True, "walk_hbm_cat_kernel")):
         patterns = rng.integers(0, 4, (n, 70)).astype(np.int32)
         weights = np.ones(70)
         pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(4)])
