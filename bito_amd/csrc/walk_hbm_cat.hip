@@ -6,24 +6,27 @@
 
 namespace bito_amd {
 
-// Sum over the 64 lanes by DPP moves (no LDS round trips, no address registers): after the six steps lane 63
-// holds the total -- the caller writes from lane 63.  Fixed order.
+// Two sums over the 64 lanes at once, without LDS round trips or address registers: v_permlane32_swap puts
+// a's upper half beside its lower half in lanes 0-31 and b's likewise in lanes 32-63 (one addition halves
+// both), then five DPP steps reduce each half: lane 31 ends up with the sum of a, lane 63 with the sum of b.
+// Fixed order.
 template <int kCtrl, int kRowMask>
 __device__ __forceinline__ double DppAdd(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, false);
   return v + __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double WaveSumLast(double v) {
+__device__ __forceinline__ double PairSum(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  double v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
   v = DppAdd<0x111, 0xf>(v);  // row_shr:1
   v = DppAdd<0x112, 0xf>(v);  // row_shr:2
   v = DppAdd<0x114, 0xf>(v);  // row_shr:4
   v = DppAdd<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row's sum
-  v = DppAdd<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-  v = DppAdd<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  v = DppAdd<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3 -> lanes 31 and 63 hold the halves' sums
   return v;
 }
-constexpr int kSumLane = 63;
 
 __device__ __forceinline__ double WaveSum(double v) {
 #pragma unroll
@@ -280,19 +283,14 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       MatVec(Q, ab, qa);
 #pragma unroll
       for (int i = 0; i < 4; i++) sb += q[i] * (aa[i] * qa[i]);
-      const double ga = WaveSumLast(sa * rden), gb = WaveSumLast(sb * rden);
-      if (lane == kSumLane) {
-        my_row[ci.a] = ga;
-        my_row[ci.b] = gb;
-      }
+      const double g = PairSum(sa * rden, sb * rden);
+      if ((lane & 31) == 31) my_row[lane < 32 ? ci.a : ci.b] = g;
     };
-    // the sum of a child's edge: sum_i (u . a_sibling)_i (Q a)_i, times w_p sigma_c r_c / den, over the wave's lanes
-    auto edge_sum = [&](int cc, const double A[4], const double UAs[4], double rden) {
+    // a child's edge term: sum_i (u . a_sibling)_i (Q a)_i, times w_p sigma_c r_c / den
+    auto edge_term = [&](const double A[4], const double UAs[4], double rden) {
       double qa[4];
       MatVec(Q, A, qa);
-      const double num = UAs[0] * qa[0] + UAs[1] * qa[1] + UAs[2] * qa[2] + UAs[3] * qa[3];
-      const double g = WaveSumLast(num * rden);
-      if (lane == kSumLane) my_row[cc] = g;
+      return (UAs[0] * qa[0] + UAs[1] * qa[1] + UAs[2] * qa[2] + UAs[3] * qa[3]) * rden;
     };
     // an internal child's pre-order partial P^T (u . a_sibling): stored in place (the child's cell held its
     // post-order partial, read for this step's message), handed to the next step through the thread's LDS
@@ -343,10 +341,12 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       r = fma(fma(-den, r, 1.0), r, r);
       const double rden = gw * r;
       // both edge sums first: after them only u . a1 and u . a0 are live
-      edge_sum(c0, A0, UA1, rden);
+      const double e0 = edge_term(A0, UA1, rden);
 #pragma unroll
       for (int i = 0; i < 4; i++) UA0[i] = U[i] * A0[i];
-      edge_sum(c1, A1, UA0, rden);
+      const double e1 = edge_term(A1, UA0, rden);
+      const double g = PairSum(e0, e1);
+      if ((lane & 31) == 31) my_row[lane < 32 ? c0 : c1] = g;
       __builtin_amdgcn_sched_barrier(0);
       pre_part(k0, c0, UA1, rden, fwd0);
       __builtin_amdgcn_sched_barrier(0);
