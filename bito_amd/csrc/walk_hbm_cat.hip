@@ -117,7 +117,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
                     const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
                     double* __restrict__ arena_base, double* __restrict__ part_ll, double* __restrict__ part_grad,
                     int deriv_mode) {
-  extern __shared__ double lds[];  // [4][threads] hand-over column | [threads] terms | [threads] exponents
+  extern __shared__ double lds[];  // [threads][4] hand-over column | [threads][4] pending column | [threads] terms | [threads] exponents
   const int n = d.taxon_count, N = d.node_count, NI = n - 1, Ppad = d.pattern_stride, C = d.category_count;
   const int tree = tree0 + blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, threads = blockDim.x;
@@ -159,6 +159,15 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     }
     return ci;
   };
+  // Two thread-private LDS columns of four doubles.  `fwd` hands a vector to the step that follows immediately
+  // (pre-order: the partial of child node - 1).  `pend` keeps ONE vector that is needed later -- post-order: the
+  // partial of a node whose parent is not the next step (also stored in the arena: the pre-order pass reads it
+  // there); pre-order: the partial of the child that is NOT processed next -- until its reader comes, unless a
+  // younger such vector takes the column first (the walk is depth-first, so the youngest is needed soonest; the
+  // older one moves to the arena then).  Hits save the arena round trip of about half of those vectors.
+  double* __restrict__ fwd = lds + 4 * tid;
+  double* __restrict__ pend = lds + 4 * threads + 4 * tid;
+  int pend_owner = -1;  // node whose vector `pend` holds (wave-uniform)
   // row `state` of the transposed transition matrix of the branch above `node` (a tip's message)
   auto tip_row = [&](int node, int state, double out[4]) {
     BufLoadRow(matrows, (unsigned)(kMatPT * 8) + (unsigned)state * 32, (unsigned)node * mat_bytes, out);
@@ -170,6 +179,10 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       tip_row(ci.b, ci.sb, rb);
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = ra[i] * rb[i];
+    } else if (cc == pend_owner) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = pend[i];
+      pend_owner = -1;
     } else {
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = BufLoad(arena, lane8, (unsigned)(cc - n) * node_bytes + i * 512);
@@ -187,6 +200,11 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
     if (c0 < n && c1 < n && node != N - 1) continue;  // a cherry: rebuilt where it is used
     const Child k0 = classify(c0), k1 = classify(c1);
+    if (GRAD && last >= 0 && c0 != last && c1 != last) {  // its parent comes later: keep a copy at hand
+#pragma unroll
+      for (int i = 0; i < 4; i++) pend[i] = dd[i];
+      pend_owner = last;
+    }
     if (!GRAD && unsaved && c0 != last && c1 != last) {
 #pragma unroll
       for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(last - n) * node_bytes + i * 512, dd[i]);
@@ -232,9 +250,8 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     }
   }
   // ---- the categories of a pattern meet: L_p and this category's share of it ---
-  double* __restrict__ fwd = lds + 4 * tid;                              // [threads][4]
-  double* __restrict__ terms = lds + 4 * threads;                        // [C][64]
-  int* __restrict__ exps = reinterpret_cast<int*>(lds + 5 * threads);    // [C][64]
+  double* __restrict__ terms = lds + 8 * threads;                        // [C][64]
+  int* __restrict__ exps = reinterpret_cast<int*>(lds + 9 * threads);    // [C][64]
   terms[tid] = site;
   exps[tid] = exponent_sum;
   __syncthreads();
@@ -260,6 +277,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     double* __restrict__ my_row = part_grad + (((size_t)tree * gridDim.x + blockIdx.x) * C + c) * N;
     const double* __restrict__ Q = tm->Q;
     bool u_forwarded = false;
+    pend_owner = -1;  // (what the post-order pass left there is in the arena as well)
     // message of a child: tip -> its row of P^T; stored -> P x; cherry -> P (a_a . a_b)
     auto message = [&](const Child& ci, int cc, double A[4]) {
       const double* m = mats + cc * node_mat;
@@ -304,11 +322,18 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
         return;
       }
       if (RESCALE) { int unused = 0; ScalePow2(q, unused); }
+      if (forward) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if (forward) fwd[i] = q[i];
-        else BufStore(arena, lane8, (unsigned)(cc - n) * node_bytes + i * 512, q[i]);
+        for (int i = 0; i < 4; i++) fwd[i] = q[i];
+        return;
       }
+      if (pend_owner >= 0) {  // an older vector waits in the column: it moves to its cell in the arena
+#pragma unroll
+        for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(pend_owner - n) * node_bytes + i * 512, pend[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) pend[i] = q[i];
+      pend_owner = cc;
     };
     for (int node = N - 1; node >= n; --node) {
       const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
@@ -322,6 +347,10 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       } else if (u_forwarded) {
 #pragma unroll
         for (int i = 0; i < 4; i++) U[i] = fwd[i];
+      } else if (node == pend_owner) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) U[i] = pend[i];
+        pend_owner = -1;
       } else {
 #pragma unroll
         for (int i = 0; i < 4; i++) U[i] = BufLoad(arena, lane8, (unsigned)(node - n) * node_bytes + i * 512);
@@ -370,7 +399,7 @@ void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int c
                       int rescaling, int deriv_mode, hipStream_t stream) {
   const int threads = 64 * d.category_count;
   const dim3 grid(HbmCatTiles(d.pattern_count), chunk), block(threads);
-  const size_t lds = (size_t)threads * (4 * sizeof(double) + sizeof(double) + sizeof(int));
+  const size_t lds = (size_t)threads * (8 * sizeof(double) + sizeof(double) + sizeof(int));
 #define BITO_CAT(G, R) hipLaunchKernelGGL((walk_hbm_cat_kernel<G, R>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model, \
                                           b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad, deriv_mode)
   if (want_gradient) { if (rescaling) BITO_CAT(true, true); else BITO_CAT(true, false); }
