@@ -206,8 +206,14 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       pend_owner = last;
     }
     if (!GRAD && unsaved && c0 != last && c1 != last) {
+      // log-likelihood only: the column is the partial's only home until a younger one needs it
+      if (pend_owner >= 0) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(last - n) * node_bytes + i * 512, dd[i]);
+        for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(pend_owner - n) * node_bytes + i * 512, pend[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) pend[i] = dd[i];
+      pend_owner = last;
     }
     double A[4], B[4];
     const double* m0 = mats + c0 * node_mat;
