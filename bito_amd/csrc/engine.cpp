@@ -457,7 +457,12 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
       // ... except a log-likelihood-only pass with one rate category: walk_hbm_kernel never stores a partial there
       // (each node's is forwarded in registers to its parent) and runs 0.17 ms per 1600 DS1 JC69 trees
       // against 0.32 ms (walk_pipe_kernel) and 0.37 ms (walk_lds_kernel); scripts/gpu_config2.py
-      if (!want_gradient && d.category_count == 1) use_pipe = use_lds = use_tree = false;
+      if (!want_gradient && d.category_count == 1) use_pipe = false;
+      // Everything else goes to the HBM-arena walk since round 2: with one wave per rate category
+      // (walk_hbm_cat_kernel) it beats walk_lds_kernel wherever walk_pipe_kernel does not apply -- 1600 trees of
+      // 41 / 50 / 64 taxa, 1000 patterns, four categories: 3.75 / 4.50 / 5.85 ms against 4.79 / 5.72 / 11.8 ms
+      // (scripts/gpu_midsize.py) -- so walk_lds_kernel and walk_tree_kernel run only when asked for.
+      use_lds = use_tree = false;
       break;
   }
   // Measured on config 3 (profiles/): walk_lds_kernel 2.1 ms, walk_tree_kernel 3.8 ms per 1600

@@ -195,7 +195,7 @@ void LaunchWalkHbm(const BatchDims& d, const DeviceBatch& b, int tree0, int chun
                    int want_gradient, int rescaling, hipStream_t stream, int deriv_mode = 0);
 const char* WalkHbmKernelName(int category_count, int want_gradient, int rescaling);
 // pattern tiles and partial gradient rows per tree of the HBM-arena kernel that LaunchWalkHbm picks for d
-// (walk_hbm_cat_kernel, one wave per rate category, for 2 to 4 categories; walk_hbm_kernel otherwise)
+// (walk_hbm_cat_kernel, one wave per rate category, for up to 4 categories; walk_hbm_kernel otherwise)
 int HbmWalkTiles(const BatchDims& d);
 int HbmWalkGradRows(const BatchDims& d);
 bool HbmCatKernelApplies(const BatchDims& d);

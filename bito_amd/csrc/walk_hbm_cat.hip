@@ -47,7 +47,8 @@ __device__ __forceinline__ void MatVecT(const double* __restrict__ M, const doub
 }
 
 // --------------------------------------------------------------------------
-// The same traversal with one WAVE per (64 patterns, rate category): walk_hbm_cat_kernel, 2 to 4 categories.
+// The same traversal with one WAVE per (64 patterns, rate category): walk_hbm_cat_kernel, up to 4 categories
+// (with one category: walk_hbm_kernel's thread per pattern, in 64-thread workgroups, with this kernel's step).
 //
 // walk_hbm_kernel above is bound by memory latency at the occupancy its registers allow (a thread carries all
 // categories of its pattern: 128 registers, four waves per SIMD, a load-wait round per category and step).
@@ -394,7 +395,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
 
 bool HbmCatKernelApplies(const BatchDims& d) {
   static const bool classic = [] { const char* v = getenv("BITO_AMD_HBM_CLASSIC"); return v && v[0] == '1'; }();
-  return !classic && d.category_count >= 2 && d.category_count <= 4;
+  return !classic && d.category_count <= 4;
 }
 int HbmWalkTiles(const BatchDims& d) { return HbmCatKernelApplies(d) ? HbmCatTiles(d.pattern_count) : HbmTiles(d.pattern_count); }
 int HbmWalkGradRows(const BatchDims& d) {

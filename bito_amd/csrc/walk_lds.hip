@@ -856,8 +856,13 @@ static void LaunchWalkLdsCG(const BatchDims& d, const DeviceBatch& b, const LdsP
                             int want_site, hipStream_t stream) {
   // Run length: a divisor of the tile count (equal runs), as long as the launch still has about sixteen
   // workgroups per CU to even out -- a run saves start-up latency, a short grid loses to quantisation.
+  // Runs only up to 38 taxa, the sizes this kernel served as the default (round 1) and was validated on.  With
+  // runs, trees of 55 taxa and more showed an intermittent fault in round 2 (a few trees per 1600 with wrong
+  // gradients, different ones every pass, log-likelihoods right; none with one tile per workgroup, none at 45
+  // taxa and fewer: scripts/gpu_lds_runs_check.py); its cause was not found.  AUTO no longer sends trees of
+  // more than 38 taxa here (walk_hbm_cat_kernel is faster there).
   int tile_run = 1;
-  if (!(C == 1 && G == 8)) {
+  if (!(C == 1 && G == 8) && d.taxon_count <= 38) {
     long long budget = LDS_TILE_RUN ? LDS_TILE_RUN : (long long)d.tree_count * plan.tiles / (16 * 256);
     if (const char* forced = std::getenv("BITO_AMD_LDS_TILE_RUN")) budget = std::atoi(forced);  // tests: runs on small batches
     for (int k = 1; k <= plan.tiles && k <= budget; k++)

@@ -1,4 +1,5 @@
-"""Trees of 30 to 38 taxa (DS3-sized): walk_pipe_kernel (two pattern groups per wave there) against walk_lds_kernel.
+"""Trees of 30 taxa and more (DS3- to DS8-sized): walk_pipe_kernel (two pattern groups per wave from 33 taxa, up to
+38 taxa) against walk_lds_kernel and the HBM-arena walk.
 usage: python scripts/gpu_midsize.py [taxa ...]"""
 import os
 import sys
@@ -14,13 +15,17 @@ for n in [int(a) for a in sys.argv[1:]] or [27, 31, 36, 38]:
     eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights)
     eng.upload(w.parent_ids, w.branch_lengths, w.params)
     results = {}
-    for kern in (_capi.KERNEL_LDS_PIPE, _capi.KERNEL_LDS):
+    for kern in (_capi.KERNEL_LDS_PIPE, _capi.KERNEL_LDS, _capi.KERNEL_HBM_ARENA):
         eng.set_kernel(kern)
-        eng.run(True, False)
+        try:
+            eng.run(True, False)
+        except bito_amd.BitoAmdError as err:
+            print(f"n={n} kernel {kern}: {str(err)[:60]}")
+            continue
         eng.sync()
         results[kern] = eng.download(True)
         eng.time_runs(True, False, 3)
         total, k, launches = eng.time_runs(True, False, 10)
         print(f"n={n} kernel={eng.kernel_name()}: step {total / 10:.3f} ms per 1600 trees ({1600 / (total / 10):.0f} k trees/s), walk kernel {k / launches:.3f} ms")
-    a, b = results[_capi.KERNEL_LDS_PIPE], results[_capi.KERNEL_LDS]
-    print(f"   max |dLL| between the two {np.abs(a[0] - b[0]).max():.2e}, max |dgrad| {np.abs(a[1] - b[1]).max():.2e}")
+    a, b = results[_capi.KERNEL_HBM_ARENA], results[_capi.KERNEL_LDS]
+    print(f"   max |dLL| between the last two {np.abs(a[0] - b[0]).max():.2e}, max |dgrad| {np.abs(a[1] - b[1]).max():.2e}")

@@ -166,8 +166,8 @@ def test_every_traversal_kernel_matches_oracle(kernel, model):
     assert ll_close(out["log_likelihood"], ref["log_likelihood"])
     assert grad_close(out["branch_lengths"], ref["branch_lengths"])
     assert ll_close(gpu.log_likelihoods(w.parent_ids, w.branch_lengths, params), ref["log_likelihood"])
-    # (the HBM-arena walk has a form of its own for 2 to 4 rate categories: one wave per category)
-    expect = {_capi.KERNEL_HBM_ARENA: "walk_hbm_kernel" if site == "constant" else "walk_hbm_cat_kernel", _capi.KERNEL_LDS: "walk_lds_kernel",
+    # (the HBM-arena walk for up to 4 rate categories is walk_hbm_cat_kernel: one wave per category)
+    expect = {_capi.KERNEL_HBM_ARENA: "walk_hbm_cat_kernel", _capi.KERNEL_LDS: "walk_lds_kernel",
               _capi.KERNEL_LDS_TREE: "walk_tree_kernel", _capi.KERNEL_LDS_PIPE: "walk_pipe_kernel"}[kernel]
     assert gpu.kernel_name() == expect
 
@@ -741,10 +741,10 @@ def test_pipe_walk_on_extreme_tree_shapes(n, site):
 
 
 def test_auto_kernel_choice_at_the_pipe_walk_limits():
-    """AUTO: 38 taxa is the last size whose branch images fit the AGPR file (walk_pipe_kernel), 39 taxa go to
-    walk_lds_kernel, rescaling to the HBM-arena walk (walk_hbm_cat_kernel with four categories); each against the oracle."""
+    """AUTO: 38 taxa is the last size whose branch images fit the AGPR file (walk_pipe_kernel); 39 taxa, and
+    rescaling at any size, go to the HBM-arena walk (walk_hbm_cat_kernel); each against the oracle."""
     rng = np.random.default_rng(29)
-    for n, rescaling, expect in ((38, False, "walk_pipe_kernel"), (39, False, "walk_lds_kernel"), (29, True, "walk_hbm_cat_kernel")):
+    for n, rescaling, expect in ((38, False, "walk_pipe_kernel"), (39, False, "walk_hbm_cat_kernel"), (29, True, "walk_hbm_cat_kernel")):
         patterns = rng.integers(0, 4, (n, 70)).astype(np.int32)
         weights = np.ones(70)
         pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(4)])
@@ -756,6 +756,28 @@ def test_auto_kernel_choice_at_the_pipe_walk_limits():
         assert gpu.kernel_name() == expect
         assert ll_close(out["log_likelihood"], ref["log_likelihood"])
         assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+
+
+def test_large_batches_of_larger_trees_every_tree_every_pass():
+    """1600 trees of 64 taxa, three passes per kernel: EVERY tree of every pass must agree between the HBM-arena walk
+    (AUTO's choice at this size) and walk_lds_kernel, and a sample with the oracle.  (Round 2 found walk_lds_kernel
+    returning wrong gradients for a few trees per pass, different ones each time, at 55 taxa and more when a
+    workgroup walked a run of tiles; it walks one tile per workgroup there now.)"""
+    n, T = 64, 1600
+    w = workloads.synthetic_gtr_weibull4(n=n, P=400, tree_count=T)
+    gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
+    good = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert gpu.kernel_name() == "walk_hbm_cat_kernel"
+    sel = np.r_[0:3, T - 3:T]
+    ref = cpu.gradients(w.parent_ids[sel], w.branch_lengths[sel], w.params[sel])
+    assert ll_close(good["log_likelihood"][sel], ref["log_likelihood"])
+    assert grad_close(good["branch_lengths"][sel], ref["branch_lengths"])
+    for kernel in (_capi.KERNEL_AUTO, _capi.KERNEL_LDS):
+        gpu.set_kernel(kernel)
+        for _ in range(3):
+            out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+            assert ll_close(out["log_likelihood"], good["log_likelihood"])
+            assert grad_close(out["branch_lengths"], good["branch_lengths"])
 
 
 @pytest.mark.parametrize("trees", [1, 255, 257, 1030])
