@@ -13,6 +13,8 @@ w = workloads.synthetic_gtr_weibull4(n=n, P=1000, tree_count=T)
 gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
 gpu.set_kernel(_capi.KERNEL_HBM_ARENA)
 good = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+again = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+print("HBM-arena walk, two passes bitwise equal:", np.array_equal(good["branch_lengths"], again["branch_lengths"]) and np.array_equal(good["log_likelihood"], again["log_likelihood"]))
 gpu.set_kernel(int(sys.argv[2]) if len(sys.argv) > 2 else _capi.KERNEL_LDS)
 for rep in range(int(sys.argv[3]) if len(sys.argv) > 3 else 4):
     o = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
