@@ -70,6 +70,11 @@ __device__ __forceinline__ void MatVecT(const double* __restrict__ M, const doub
 constexpr int kCatTile = 64;
 inline int HbmCatTiles(int pattern_count) { return (pattern_count + kCatTile - 1) / kCatTile; }
 
+// Tried on top of this kernel and dropped: PITCHFORKS (a cherry and a tip under one node -- a sixth of the internal
+// nodes of a random tree) rebuilt and folded into the parent's step like cherries.  The nested step needs 75
+// registers: held to 64 it spills (config 4, 125 trees, same box: 84.8 ms against 69.9), at six waves per SIMD it
+// gains 2.5-4 % (66.7 / 69.4 ms against 69.9 / 71.2; 41 taxa: 3.54 against 3.78 ms) -- the arena traffic it saves is
+// paid for in vector and scalar work at lower occupancy.
 #ifndef HBM_CAT_WAVES
 #define HBM_CAT_WAVES 8
 #endif
@@ -280,7 +285,9 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   //     pre(child 0) = P_0^T (u . a1).
   // The step is written child by child so that few vectors are live at a time (eight waves per SIMD).
   if (GRAD) {
-    const double gw = weight * (mine / total) * (deriv_mode ? tm->cat_rate_deriv[c] : tm->cat_rate[c]);  // w_p sigma_c r_c
+    const double rate = deriv_mode ? tm->cat_rate_deriv[c] : tm->cat_rate[c];
+    // rescaled: w_p sigma_c r_c (then times num_c / den_c per edge); plain: w_p w_c r_c / L_p (then times num_c)
+    const double gw = RESCALE ? weight * (mine / total) * rate : weight * (tm->cat_weight[c] / total) * rate;
     double* __restrict__ my_row = part_grad + (((size_t)tree * gridDim.x + blockIdx.x) * C + c) * N;
     const double* __restrict__ Q = tm->Q;
     bool u_forwarded = false;
@@ -369,13 +376,21 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       double UA1[4], UA0[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) UA1[i] = U[i] * A1[i];
-      const double den = UA1[0] * A0[0] + UA1[1] * A0[1] + UA1[2] * A0[2] + UA1[3] * A0[3];
-      // gw / den by reciprocal and two Newton steps (relative error ~1e-16; the full division's special-case
-      // handling costs a dozen registers the step does not have at eight waves per SIMD)
-      double r = __builtin_amdgcn_rcp(den);
-      r = fma(fma(-den, r, 1.0), r, r);
-      r = fma(fma(-den, r, 1.0), r, r);
-      const double rden = gw * r;
+      // Rescaled vectors carry unknown powers of two, the same in num_c and den_c: the ratio form, gw / den by
+      // reciprocal and two Newton steps (relative error ~1e-16; the full division's special-case handling costs
+      // a dozen registers the step does not have at eight waves per SIMD).  Without rescaling the numerator is
+      // the reference's own term and w_p w_c r_c / L_p multiplies it directly: no division, and a category that
+      // has underflowed (large tree, short branches: the slow categories go first) contributes its zero instead
+      // of 0/0, while a pattern whose likelihood is zero still turns the tree's derivatives non-finite as the
+      // reference's do.
+      double rden = gw;
+      if (RESCALE) {
+        const double den = UA1[0] * A0[0] + UA1[1] * A0[1] + UA1[2] * A0[2] + UA1[3] * A0[3];
+        double r = __builtin_amdgcn_rcp(den);
+        r = fma(fma(-den, r, 1.0), r, r);
+        r = fma(fma(-den, r, 1.0), r, r);
+        rden = gw * r;
+      }
       // both edge sums first: after them only u . a1 and u . a0 are live
       const double e0 = edge_term(A0, UA1, rden);
 #pragma unroll
