@@ -103,6 +103,9 @@ for case in range(cases):
                   f"gpu finite / ref not {int((np.isfinite(g) & ~np.isfinite(r)).sum())}, ref finite / gpu not "
                   f"{int((~np.isfinite(g) & np.isfinite(r)).sum())}, worst both-finite error in tolerances {rel:.2f}; "
                   f"zero branches {int((bl[:, :-1] == 0).sum())}, LL finite gpu/ref {int(np.isfinite(out['log_likelihood']).sum())}/{int(np.isfinite(ref['log_likelihood']).sum())}")
+            odd = np.unique(np.where(np.isfinite(g) != np.isfinite(r))[0])
+            if len(odd):
+                print("   trees whose gradients are finite on one side only:", odd[:8], "their log-likelihoods (gpu, ref):", out["log_likelihood"][odd[:8]], ref["log_likelihood"][odd[:8]])
     except Exception as e:  # noqa: BLE001
         bad += 1
         print("ERROR", desc, repr(e)[:300])
