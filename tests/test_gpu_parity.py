@@ -560,6 +560,65 @@ def test_random_shapes_rooted_and_unrooted(kernel, n):
             assert ll_close(gpu.log_likelihoods(pid, bl, params), ref["log_likelihood"]), (site, rooted)
 
 
+@pytest.mark.parametrize("site", ["constant", "weibull+2", "weibull+3", "weibull+4"])
+@pytest.mark.parametrize("rescaling", [False, True])
+def test_hbm_arena_walk_one_wave_per_category(site, rescaling):
+    """walk_hbm_cat_kernel (one wave per rate category, per-category power-of-two rescaling, one pending vector per
+    thread in LDS) on trees with many nodes over two internal children, pattern counts that leave a tile one
+    pattern full, gaps, rooted and unrooted; log-likelihood-only passes and the site-model pass included."""
+    rng = np.random.default_rng(4242)
+    n, T = 60, 6
+    for P, rooted in ((65, False), (130, True)):
+        patterns = rng.integers(0, 5, (n, P)).astype(np.int32)
+        weights = rng.integers(1, 5, P).astype(np.float64)
+        if rooted:
+            pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(T)])
+            M = 2 * n - 1
+        else:
+            pid = np.stack([workloads.random_unrooted_tree(n, rng, 0.1).parent_ids for _ in range(T)]).astype(np.int32)
+            M = 2 * n - 2
+        bl = rng.exponential(0.1, (T, M))
+        bl[:, -1] = 0.0
+        gpu, cpu = engines("HKY", site, "none", patterns, weights, 4)
+        gpu.set_kernel(_capi.KERNEL_HBM_ARENA)
+        params = gpu.default_params(T)
+        params[:, :4] = rng.dirichlet([5, 5, 5, 5], T)
+        if site != "constant":
+            params[:, -1] = rng.uniform(0.3, 2.0, T)
+        flags = _capi.GRAD_SITE_MODEL if site != "constant" else 0
+        out = gpu.gradients(pid, bl, params, rescaling=rescaling, flags=flags)
+        assert gpu.kernel_name() == "walk_hbm_cat_kernel"
+        ref = cpu.gradients(pid, bl, params, rescaling=rescaling, flags=oracle.GRAD_SITE_MODEL if flags else 0)
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"]), (P, rooted)
+        assert grad_close(out["branch_lengths"], ref["branch_lengths"]), (P, rooted)
+        if flags:
+            assert grad_close(out["site_model"], ref["site_model"]), (P, rooted)
+        assert ll_close(gpu.log_likelihoods(pid, bl, params, rescaling=rescaling), ref["log_likelihood"]), (P, rooted)
+
+
+def test_one_rate_category_underflows_without_rescaling():
+    """90 taxa, short branches, no rescaling: the slowest rate category's site likelihoods underflow for some
+    patterns while the patterns' likelihoods (the sum over categories) stay normal numbers.  The derivatives must
+    stay finite and right (a per-category ratio num_c / den_c would be 0/0 there: found by scripts/gpu_fuzz.py)."""
+    rng = np.random.default_rng(90)
+    n, P, T = 90, 65, 8
+    patterns = rng.integers(0, 4, (n, P)).astype(np.int32)
+    weights = rng.integers(1, 9, P).astype(np.float64)
+    pid = np.stack([workloads.random_unrooted_tree(n, rng, 0.1).parent_ids for _ in range(T)]).astype(np.int32)
+    bl = rng.exponential(0.01, (T, 2 * n - 2))
+    bl[:, -1] = 0.0
+    gpu, cpu = engines("HKY", "weibull+4", "none", patterns, weights, 4)
+    params = gpu.default_params(T)
+    params[:, :4] = rng.dirichlet([5, 5, 5, 5], T)
+    params[:, -1] = 0.3  # a heavy-tailed rate distribution: the slowest category is very slow
+    out = gpu.gradients(pid, bl, params)
+    assert gpu.kernel_name() == "walk_hbm_cat_kernel"
+    ref = cpu.gradients(pid, bl, params)
+    assert np.all(np.isfinite(ref["branch_lengths"])) and np.all(np.isfinite(out["branch_lengths"]))
+    assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+    assert np.allclose(out["branch_lengths"], ref["branch_lengths"], rtol=1e-9, atol=GRAD_ATOL)
+
+
 def test_site_model_gradient_fused_equals_second_pass():
     """The LDS traversal yields the site-model gradient in the same pass (per-category edge sums weighted by
     (d r_c / d shape) / r_c); the other kernels run FatBeagle's second traversal with the rate derivatives
