@@ -34,6 +34,10 @@
 
 #include "kernels.hpp"
 
+#ifndef LDS_SYNC_FETCH
+#define LDS_SYNC_FETCH 1  // 0: descriptors in flight across compiler-visible code (the fault of round 2, see StepFetch)
+#endif
+
 namespace bito_amd {
 
 // --------------------------------------------------------------------------
@@ -181,8 +185,14 @@ struct alignas(32) StepDesc {
   unsigned ab0, ab1;    // cherry child 0 / 1: its tips' ids, a | b << 16 (0xffffffff: no cherry)
 };
 // A descriptor is fetched with an explicit scalar load: the compiler only selects s_load for
-// memory it can prove unclobbered, which it does not here.  The caller waits (lgkmcnt) before
-// the first use: StepFetch two steps ahead, StepWait one step ahead (mid-step, where it is free).
+// memory it can prove unclobbered, which it does not here.  StepFetch two steps ahead, StepWait one step ahead.
+// The load and its wait are ONE asm statement since round 2: a tuple whose load is still in flight must not be
+// visible to the compiler, which treats the asm's output as written -- it copied such a tuple (s_mov) ahead of
+// the wait and used registers of it as temporaries (the image offsets of cherry tips) while the data was still
+// on its way.  With the step tables in the scalar cache the data always beat those instructions; in later tiles
+// of a run of tiles, lines that other CUs had evicted meanwhile did not, and a few trees per pass came back with
+// wrong gradients on cherry tip edges (55 taxa and more, one pattern group per wave, where bodies are shortest;
+// scripts/gpu_lds_runs_check.py).  The wait costs 4 % (2.47 -> 2.57 ms per 1600 trees of 27 taxa).
 typedef unsigned StepWords __attribute__((ext_vector_type(8)));
 // Pull 64 bytes (two descriptors) into the scalar cache; the data itself is discarded.
 typedef unsigned WarmWords __attribute__((ext_vector_type(16)));
@@ -194,7 +204,11 @@ __device__ __forceinline__ void StepWarm(const StepDesc* p, WarmWords& w) {
 __device__ __forceinline__ void StepWarmDone(WarmWords& w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w)::"memory"); }
 __device__ __forceinline__ StepWords StepFetch(const StepDesc* p) {
   StepWords w;
+#if LDS_SYNC_FETCH
+  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(p) : "memory");
+#else
   asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(w) : "s"(p));
+#endif
   return w;
 }
 // the wait "produces" the descriptor, so no use of it can be scheduled above the wait
@@ -856,13 +870,8 @@ static void LaunchWalkLdsCG(const BatchDims& d, const DeviceBatch& b, const LdsP
                             int want_site, hipStream_t stream) {
   // Run length: a divisor of the tile count (equal runs), as long as the launch still has about sixteen
   // workgroups per CU to even out -- a run saves start-up latency, a short grid loses to quantisation.
-  // Runs only up to 38 taxa, the sizes this kernel served as the default (round 1) and was validated on.  With
-  // runs, trees of 55 taxa and more showed an intermittent fault in round 2 (a few trees per 1600 with wrong
-  // gradients, different ones every pass, log-likelihoods right; none with one tile per workgroup, none at 45
-  // taxa and fewer: scripts/gpu_lds_runs_check.py); its cause was not found.  AUTO no longer sends trees of
-  // more than 38 taxa here (walk_hbm_cat_kernel is faster there).
   int tile_run = 1;
-  if (!(C == 1 && G == 8) && d.taxon_count <= 38) {
+  if (!(C == 1 && G == 8)) {
     long long budget = LDS_TILE_RUN ? LDS_TILE_RUN : (long long)d.tree_count * plan.tiles / (16 * 256);
     if (const char* forced = std::getenv("BITO_AMD_LDS_TILE_RUN")) budget = std::atoi(forced);  // tests: runs on small batches
     for (int k = 1; k <= plan.tiles && k <= budget; k++)

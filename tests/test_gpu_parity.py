@@ -821,7 +821,8 @@ def test_large_batches_of_larger_trees_every_tree_every_pass():
     """1600 trees of 64 taxa, three passes per kernel: EVERY tree of every pass must agree between the HBM-arena walk
     (AUTO's choice at this size) and walk_lds_kernel, and a sample with the oracle.  (Round 2 found walk_lds_kernel
     returning wrong gradients for a few trees per pass, different ones each time, at 55 taxa and more when a
-    workgroup walked a run of tiles; it walks one tile per workgroup there now.)"""
+    workgroup walked a run of tiles: step descriptors whose scalar loads were still in flight were visible to the
+    compiler, which reused their registers)"""
     n, T = 64, 1600
     w = workloads.synthetic_gtr_weibull4(n=n, P=400, tree_count=T)
     gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
