@@ -630,6 +630,11 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   }
   e->kernel_name = WalkHbmKernelName(d.category_count, want_gradient, rescaling);
   LaunchReduce(d, b, tiles, want_gradient, e->stream, grad_rows);
+  if (want_site && want_gradient && deriv_mode == 0 && d.category_count > 1 && HbmCatKernelApplies(d)) {
+    // (walk_hbm_cat_kernel's gradient rows are per rate category: the site-model gradient needs no second pass)
+    LaunchSiteFromCategoryRows(d, b, grad_rows, e->stream);
+    e->site_ready = true;
+  }
   HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
   e->last_pass_done = e->ev_walk_done[set];
   HIP_TRY(e, hipGetLastError());
@@ -1002,7 +1007,8 @@ int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t ro
   if ((rc = bito_amd_engine_download(e, out_ll, out_branch))) return rc;
   const int N = 2 * e->n - 1;
   if ((flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && e->spec.category_count > 1 && e->site_ready) {
-    // the LDS traversal produced it in the same pass (per-category edge sums, see walk_lds_kernel)
+    // the traversal produced it in the same pass (per-category edge sums: walk_lds_kernel, walk_pipe_kernel,
+    // walk_hbm_cat_kernel)
     HIP_TRY(e, hipMemcpyAsync(out_site, e->out_site.ptr, (size_t)tree_count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   } else if ((flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && e->spec.category_count > 1) {

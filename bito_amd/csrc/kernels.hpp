@@ -199,6 +199,8 @@ const char* WalkHbmKernelName(int category_count, int want_gradient, int rescali
 int HbmWalkTiles(const BatchDims& d);
 int HbmWalkGradRows(const BatchDims& d);
 bool HbmCatKernelApplies(const BatchDims& d);
+// out_site from walk_hbm_cat_kernel's per-category gradient rows (after the walk of every chunk), no second traversal
+void LaunchSiteFromCategoryRows(const BatchDims& d, const DeviceBatch& b, int rows, hipStream_t stream);
 void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk_trees, int want_gradient,
                       int rescaling, int deriv_mode, hipStream_t stream);
 

@@ -408,6 +408,39 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   }
 }
 
+// The site-model gradient without a second traversal (DiscreteSiteModelGradient, fat_beagle.cpp:401-410,538-550:
+// the edge sums with r_c replaced by d r_c / d shape, times the branch lengths).  walk_hbm_cat_kernel's partial
+// gradient rows are per rate category -- row (tile, c) holds sum_p w_p sigma_c r_c num_c / den_c per edge -- so it is
+// sum over rows and edges of (d r_c / d shape) / r_c * row[e] * t_e.  One workgroup per tree, fixed order.
+__global__ void __launch_bounds__(256)
+site_from_category_rows_kernel(BatchDims d, DeviceBatch b, int rows) {
+  __shared__ double partial[256];
+  const int N = d.node_count, C = d.category_count, tree = blockIdx.x, tid = threadIdx.x;
+  const TreeModel* __restrict__ tm = b.model + tree;
+  const double* __restrict__ mine = b.part_grad + (size_t)tree * rows * N;
+  const double* __restrict__ t_e = b.branch + (size_t)tree * N;
+  const int edges = d.rooted ? N - 1 : N - 2;  // (the root has no branch; unrooted: nor has the node that took its id)
+  double acc = 0.0;
+  for (int row = 0; row < rows; row++) {
+    const int c = row % C;
+    const double ratio = tm->cat_rate_deriv[c] / tm->cat_rate[c];
+    double s = 0.0;
+    for (int e = tid; e < edges; e += 256) s += mine[(size_t)row * N + e] * t_e[e];
+    acc += ratio * s;
+  }
+  partial[tid] = acc;
+  __syncthreads();
+  for (int half = 128; half > 0; half >>= 1) {
+    if (tid < half) partial[tid] += partial[tid + half];
+    __syncthreads();
+  }
+  if (tid == 0) b.out_site[tree] = partial[0];
+}
+
+void LaunchSiteFromCategoryRows(const BatchDims& d, const DeviceBatch& b, int rows, hipStream_t stream) {
+  hipLaunchKernelGGL(site_from_category_rows_kernel, dim3(d.tree_count), dim3(256), 0, stream, d, b, rows);
+}
+
 bool HbmCatKernelApplies(const BatchDims& d) {
   static const bool classic = [] { const char* v = getenv("BITO_AMD_HBM_CLASSIC"); return v && v[0] == '1'; }();
   return !classic && d.category_count <= 4;
