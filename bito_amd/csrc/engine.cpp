@@ -11,7 +11,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -109,6 +111,7 @@ struct bito_amd_engine {
   hipEvent_t last_pass_done = nullptr;  // recorded behind the last pass enqueued (one of ev_walk_done)
   double* cur_ll() { return out_ll_ring[out_slot % kOutRing].ptr; }
   bool site_ready = false;  // out_site holds the site-model gradient of the resident pass
+  double min_branch = 0.0;  // smallest branch length of the resident batch (known for 39 taxa and more only, else 0)
   DeviceBuffer<TreeModel> model, model2, model3;
   DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
   DeviceBuffer<int32_t> gs_model_index;  // [T] first tree with the same parameter row
@@ -324,6 +327,17 @@ int UploadModelIndex(bito_amd_engine* e, int tree_count, const double* params) {
   return BITO_AMD_OK;
 }
 
+// smallest effective branch length of a batch in wire format ([T][M], the last column is the root's)
+double MinBranchLength(const double* branch_lengths, const double* rates, size_t T, size_t M) {
+  double m = std::numeric_limits<double>::infinity();
+  for (size_t t = 0; t < T; t++)
+    for (size_t i = 0; i + 1 < M; i++) {
+      const double bl = branch_lengths[t * M + i] * (rates ? rates[t * (M - 1) + i] : 1.0);
+      m = bl < m ? bl : m;
+    }
+  return m;
+}
+
 DeviceBatch MakeBatch(bito_amd_engine* e, int set = 0) {
   DeviceBatch b{};
   b.parent_ids = e->parent_ids.ptr;
@@ -436,12 +450,19 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   bool use_tree = tplan.waves > 0 && !rescaling;
   bool use_lds = plan.groups > 0 && !rescaling;
   bool use_pipe = false;
+  // (39 to 48 taxa: walk_pipe_kernel's one-image-per-branch form holds to rounding only while no transition
+  // matrix entry is all rounding error, i.e. no branch is shorter than 1e-6; see walk_pipe.hip)
+  static const double min_branch_needed = [] {  // (BITO_AMD_PIPE_MIN_BRANCH: measurements of that bound)
+    const char* v = std::getenv("BITO_AMD_PIPE_MIN_BRANCH");
+    return v ? std::atof(v) : kPipeReversibleMinBranch;
+  }();
+  const bool pipe_branches_ok = d.taxon_count <= kPipeExactTaxa || e->min_branch >= min_branch_needed;
   switch (e->kernel_choice) {
     case BITO_AMD_KERNEL_HBM_ARENA: use_tree = use_lds = false; break;
     case BITO_AMD_KERNEL_LDS_PIPE:
       use_tree = false;
-      use_pipe = pplan.groups > 0 && !rescaling;
-      if (!use_pipe) return Fail(e, BITO_AMD_ERR_STATE, "the pipelined LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, and a tree whose stored vectors fit in 160 KB of LDS)");
+      use_pipe = pplan.groups > 0 && !rescaling && pipe_branches_ok;
+      if (!use_pipe) return Fail(e, BITO_AMD_ERR_STATE, "the pipelined LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, a tree whose stored vectors fit in 160 KB of LDS, and from 39 taxa on branch lengths of 1e-6 and more)");
       break;
     case BITO_AMD_KERNEL_LDS:
       use_tree = false;
@@ -453,7 +474,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     default:
       // AUTO: the hand-scheduled LDS walk where it applies (up to 38 taxa: every branch's images in the AGPR
       // file), measured 1.44 ms against walk_lds_kernel's 2.00 ms per 1600 config-3 trees
-      use_pipe = pplan.groups > 0 && !rescaling;
+      use_pipe = pplan.groups > 0 && !rescaling && pipe_branches_ok;
       // ... except a log-likelihood-only pass with one rate category: walk_hbm_kernel never stores a partial there
       // (each node's is forwarded in registers to its parent) and runs 0.17 ms per 1600 DS1 JC69 trees
       // against 0.32 ms (walk_pipe_kernel) and 0.37 ms (walk_lds_kernel); scripts/gpu_config2.py
@@ -803,6 +824,7 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   HIP_TRY(e, e->out_site.Reserve(T));
   HIP_TRY(e, hipMemcpyAsync(e->parent_ids.ptr, parent_ids, T * (M - 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * M * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  e->min_branch = e->n > kPipeExactTaxa ? MinBranchLength(branch_lengths, rooted ? rates : nullptr, T, M) : 0.0;
   if (e->spec.param_count > 0)
     HIP_TRY(e, hipMemcpyAsync(e->params.ptr, params, T * e->spec.param_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
   e->gs_index_valid = false;
@@ -843,8 +865,11 @@ int bito_amd_engine_update(bito_amd_engine* e, const double* branch_lengths, con
     if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL)
       if ((rc = UploadModelIndex(e, (int)T, params))) return rc;
   }
-  if (branch_lengths)
+  if (branch_lengths) {
     HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * e->dims.in_node_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    // (rates, when a batch has them, stay on the device: unknown here, so no claim about the effective lengths)
+    e->min_branch = (e->n > kPipeExactTaxa && !e->has_rates) ? MinBranchLength(branch_lengths, nullptr, T, (size_t)e->dims.in_node_count) : 0.0;
+  }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return BITO_AMD_OK;
 }

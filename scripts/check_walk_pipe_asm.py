@@ -9,7 +9,11 @@ Fails (exit 1) on the first stray use.  usage: check_walk_pipe_asm.py walk_pipe.
 import re
 import sys
 
-LIMIT = 224  # WALK_PIPE_IMAGE_REGS
+import os
+
+# WALK_PIPE_IMAGE_REGS of the generated loops this build includes
+_INC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bito_amd", "csrc", "walk_pipe_gen.inc")
+LIMIT = int(re.search(r"#define WALK_PIPE_IMAGE_REGS (\d+)", open(_INC).read()).group(1))
 
 
 def main(path):

@@ -286,8 +286,8 @@ class Loops:
         the scalar cache; bodies are branch-free and specialised on the kinds of the two children and on
         whether a vector is handed to the next step in registers; the jump to the next body goes through a
         table of code offsets;
-      * the images of every branch of the tree live in the AGPR file (P of a tip's branch at a[2 tip], (P, P^T)
-        of an internal branch at a[INNER_BASE + 4 j], loaded once per unit of work) and the matrix instruction
+      * the images of every branch of the tree live in the AGPR file (P of a tip's branch at a[2 tip], of an
+        internal branch behind them, in one of the two layouts below -- loaded once per unit of work) and the matrix instruction
         reads its A operand there through the VGPR index mode (s_set_gpr_idx_on adds M0 to the register number
         of source 0, AGPR sources included): no image is fetched, staged or copied inside the loops;
       * the packed tip masks of all tips of the tile live in VGPRs (one per tip), read through the same
@@ -300,23 +300,41 @@ class Loops:
         wait states the hardware needs are filled with work the body has to do anyway;
       * stored cells are 16 bytes per lane (two pattern groups side by side): ds_read_b128 / ds_write_b128."""
 
-    # Matrix images in the AGPR file, a0..a223 (a224.. and v0..v(VBASE-1) stay with the compiler): a tip's branch
-    # needs P only (nothing is propagated below a tip), two registers at a[2 tip]; the branch above internal node
-    # n + j needs (P, P^T), four registers at a[INNER_BASE + 4 j].
-    MAX_TIPS = 38
-    MAX_INNER = 37
-    INNER_BASE = 2 * MAX_TIPS
-    IMAGE_REGS = INNER_BASE + 4 * MAX_INNER
+    # Matrix images in the AGPR file, a0..a223 (a224.. and v0..v(VBASE-1) stay with the compiler), in one of two
+    # layouts (a step's descriptor names the registers of the images it uses; the post-order loop is the same for
+    # both, the pre-order loop exists once per layout):
+    #   * up to 38 taxa, EXACT: P of a tip's branch at a[2 tip] (nothing is propagated below a tip, so no P^T),
+    #     (P, P^T) of the branch above internal node n + j at a[EXACT_BASE + 4 j]; the pre-order loop multiplies
+    #     by the second half where the reference's recursion has P^T (and by the first where it rebuilds a
+    #     cherry's message).
+    #   * 39 to 48 taxa, ONE image per branch (P at a[2 tip], at a[REV_BASE + 2 j]): the models are reversible,
+    #     pi_i P_ij = pi_j P_ji, i.e. P^T = Pi P Pi^-1, so with the pre-order partials kept as v = u / pi the
+    #     recursion pre(child) = P^T (u . m) reads v(child) = P (v . m) -- the image of the post-order pass, no
+    #     extra multiplication; the root starts from 1 instead of pi and the Q image carries the factor (rows of
+    #     r_c Q scaled by pi_i).  The computed P is reversible to rounding only, relative to ITS OWN entries'
+    #     rounding error: an entry that is all rounding error -- a zero-length branch -- breaks the identity, and a
+    #     pattern that needs a substitution on such a branch then gets derivatives that differ from the
+    #     reference's (which are noise there too, but the same noise as the checker's).  The engine therefore uses
+    #     this layout only for batches whose branch lengths are all 1e-6 or more (relative error of an
+    #     off-diagonal entry <= 1e-10) and keeps the exact one wherever it fits.
+    MAX_TIPS = 48      # a VGPR per tip for its packed masks beside one or two pattern groups (64: 5.5 % slower at 36 taxa)
+    EXACT_TAXA = 38
+    EXACT_BASE = 2 * EXACT_TAXA
+    REV_BASE = 2 * MAX_TIPS
+    MAX_INNER = MAX_TIPS - 2
+    IMAGE_REGS = 224
+    assert EXACT_BASE + 4 * (EXACT_TAXA - 2) <= IMAGE_REGS and REV_BASE + 2 * MAX_INNER <= IMAGE_REGS
 
-    def __init__(self, G):
+    def __init__(self, G, exact=True):
         self.G = G
+        self.exact = exact  # image layout the pre-order loop is generated for (the only place the loops differ)
         self.e = None
         V = Alloc(VBASE, VLIMIT, "VGPR")
         S = Alloc(SBASE, SLIMIT, "SGPR")
         g2 = lambda name: [V.get(2, f"{name}{g}", 2) for g in range(G)]
         # persistent
         # packed masks of tip t (byte g = mask of this lane's pattern in group g): 32 slots beside four groups'
-        # registers, 48 (38 used) beside fewer
+        # registers, 48 beside fewer
         self.TIP_SLOTS = 32 if G == 4 else 48
         self.TMV = V.get(self.TIP_SLOTS, "TMV", 4)
         self.U = g2("U")                      # pre-order partial of the step's node
@@ -843,7 +861,8 @@ class Loops:
         self.v32(f"v_add_u32 v{nxt[1]}, {self.cur(self.NOFFC1)}, %[arena]", [], [nxt[1]])
         if not hand_over:
             self.v32(f"v_add_u32 v{ad[2]}, {self.cur(self.NOWN)}, %[arena]", [], [ad[2]])
-        # P^T w: the children's pre-order partials, with the next step's reads issued underneath
+        # P w (= P^T of the reference's recursion, in the u / pi variables): the children's pre-order partials, with
+        # the next step's reads issued underneath
         # (the registers they land in -- M[0], M[1], U -- have had their last use)
         first = True
         regions = sum(1 for k in kinds if k != "T")
@@ -865,7 +884,7 @@ class Loops:
             else:
                 self.idx_set(self.cur(img[s]))
             for g in range(G):
-                self.mfma(dst[g], ("A", 2), self.W[s][g])
+                self.mfma(dst[g], ("A", 2 if self.exact else 0), self.W[s][g])
             if first and regions > 1:
                 next_reads()
             first = False
@@ -957,11 +976,12 @@ class Loops:
         return e
 
     # =============================== image loader ==================================================
-    def load_images(self):
+    def load_images(self, exact):
         """the tree's matrix images into the AGPR file of every wave: the four waves of the workgroup fetch a
         quarter of the branches each, straight into LDS (global_load_lds_dwordx4; the arena is idle between two
         units), and after a barrier every wave reads all of them from there -- P of %[ntips] tip branches (8 of
-        a lane's 16 bytes) into a[2 tip], (P, P^T) of %[ninner] internal branches into a[INNER_BASE + 4 j].
+        a lane's 16 bytes) into a[2 tip], and of %[ninner] internal branches (P, P^T) into a[EXACT_BASE + 4 j] (exact
+        layout) or P into a[REV_BASE + 2 j].
         Four waves fetching the same 40 to 75 KB through one L1 was 7 k cycles per unit."""
         self.e = Emitter()
         self.tag = "load"
@@ -1009,12 +1029,16 @@ class Loops:
             self.mem(f"ds_read_b64 a[{2 * t}:{2 * t + 1}], %[stage_tips] offset:{t * 1024}")
         self.e.label(tips_done)
         done = self.L("done")
-        for j in range(self.MAX_INNER):
+        for j in range(self.EXACT_TAXA - 2 if exact else self.MAX_INNER):
             if j % 4 == 0:
                 self.salu(f"s_cmp_le_u32 %[ninner], {j}")
                 self.e.control(f"s_cbranch_scc1 {done}")
-            r = self.INNER_BASE + 4 * j
-            self.mem(f"ds_read_b128 a[{r}:{r + 3}], %[stage_inner] offset:{j * 1024}")
+            if exact:
+                r = self.EXACT_BASE + 4 * j
+                self.mem(f"ds_read_b128 a[{r}:{r + 3}], %[stage_inner] offset:{j * 1024}")
+            else:
+                r = self.REV_BASE + 2 * j
+                self.mem(f"ds_read_b64 a[{r}:{r + 1}], %[stage_inner] offset:{j * 1024}")
         self.e.label(done)
         self.wait(vm=0, lgkm=0)
         self.e.control("s_barrier")  # (the staging area is the arena: nobody writes a cell before everybody has read)
@@ -1051,15 +1075,21 @@ def main():
         pre = loops.pre_loop()
         out.append(as_macro(f"WALK_PIPE_POST_ASM_G{G}", post.finish()))
         out.append(as_macro(f"WALK_PIPE_PRE_ASM_G{G}", pre.finish()))
+        if G < 4:  # (39 taxa and more never run with four pattern groups per wave: 32 tip-mask registers there)
+            out.append(as_macro(f"WALK_PIPE_PRE_REV_ASM_G{G}", Loops(G, exact=False).pre_loop().finish()))
         out.append(f"#define WALK_PIPE_CLOBBERS_G{G} {clobbers(loops)}")
         out.append(f"#define WALK_PIPE_TIP_SLOTS_G{G} {loops.TIP_SLOTS}")
         listing.append(f"G={G}: VGPR v{VBASE}..v{loops.vnext - 1}, AGPR a0..a{Loops.IMAGE_REGS - 1}, SGPR s{SBASE}..s{loops.snext - 1}; "
                        f"post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
     loops = Loops(1)
-    out.append(as_macro("WALK_PIPE_LOAD_ASM", loops.load_images().finish()))
+    out.append(as_macro("WALK_PIPE_LOAD_EXACT_ASM", loops.load_images(True).finish()))
+    loops = Loops(1)
+    out.append(as_macro("WALK_PIPE_LOAD_REV_ASM", loops.load_images(False).finish()))
     out.append(f"#define WALK_PIPE_MAX_TIPS {Loops.MAX_TIPS}")
     out.append(f"#define WALK_PIPE_MAX_INNER {Loops.MAX_INNER}")
-    out.append(f"#define WALK_PIPE_INNER_BASE {Loops.INNER_BASE}")
+    out.append(f"#define WALK_PIPE_EXACT_TAXA {Loops.EXACT_TAXA}")
+    out.append(f"#define WALK_PIPE_EXACT_BASE {Loops.EXACT_BASE}")
+    out.append(f"#define WALK_PIPE_REV_BASE {Loops.REV_BASE}")
     out.append(f"#define WALK_PIPE_IMAGE_REGS {Loops.IMAGE_REGS}")
     out.append("// " + "\n// ".join(listing))
     out.append("// clang-format on")
@@ -1070,7 +1100,7 @@ def main():
     if len(sys.argv) > 1:  # plain listing of one loop for reading: gen_walk_pipe.py pre4 > /tmp/pre4.s
         want = sys.argv[1]
         loops = Loops(int(want[-1]))
-        e = loops.post_loop() if want.startswith("post") else (loops.pre_loop() if want.startswith("pre") else loops.load_images())
+        e = loops.post_loop() if want.startswith("post") else (loops.pre_loop() if want.startswith("pre") else loops.load_images(True))
         sys.stderr.write("\n".join(e.finish()) + "\n")
 
 

@@ -259,17 +259,21 @@ def test_pipe_walk_planner():
     assert _pipe_plan(27, 934, 4, 100, 7)["tile_run"] == 1
     # one more vector per wave than LDS holds beside four groups: two groups
     assert _pipe_plan(27, 934, 4, 1600, 6)["groups"] == 2
-    # tip masks: 32 registers beside four groups, 48 beside two; images: 38 taxa fill the AGPR file
+    # tip masks: 32 registers beside four groups, 48 beside two (one image per branch: the AGPR file would hold 57
+    # taxa); beyond that, or when the stored vectors of the tree with the fewest cherries do not fit LDS: not taken
     assert _pipe_plan(32, 934, 4, 1600, 14)["groups"] == 4
     assert _pipe_plan(33, 934, 4, 1600, 14)["groups"] == 2
     assert _pipe_plan(38, 934, 4, 1600, 10)["groups"] == 2
-    assert _pipe_plan(39, 934, 4, 1600, 10)["groups"] == 0
+    assert _pipe_plan(41, 934, 4, 1600, 9)["groups"] == 2
+    assert _pipe_plan(48, 934, 4, 1600, 14)["groups"] == 2
+    assert _pipe_plan(48, 934, 4, 1600, 8)["groups"] == 0  # 38 vectors per wave: 160 KB do not hold them
+    assert _pipe_plan(49, 934, 4, 1600, 20)["groups"] == 0
     # one rate category: sixteen patterns per group, 256 per workgroup
     jc = _pipe_plan(27, 934, 1, 1600, 7)
     assert jc["groups"] == 4 and jc["patterns_per_workgroup"] == 256 and jc["tiles"] == 4 and jc["lds_bytes"] <= 160 * 1024
     assert _pipe_plan(27, 934, 3, 1600, 7)["groups"] == 0  # 1, 2 or 4 categories
     # every plan fits LDS and keeps at least the vectors the batch's worst tree needs
-    for n in range(3, 39):
+    for n in range(3, 49):
         for cherries in (1, n // 3, n // 2):
             for categories in (1, 2, 4):
                 p = _pipe_plan(n, 500, categories, 1000, cherries)
