@@ -451,7 +451,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
   bool use_lds = plan.groups > 0 && !rescaling;
   bool use_pipe = false;
   // (39 to 48 taxa: walk_pipe_kernel's one-image-per-branch form holds to rounding only while no transition
-  // matrix entry is all rounding error, i.e. no branch is shorter than 1e-6; see walk_pipe.hip)
+  // matrix entry is all rounding error, i.e. no branch is shorter than 9e-7; see walk_pipe.hip)
   static const double min_branch_needed = [] {  // (BITO_AMD_PIPE_MIN_BRANCH: measurements of that bound)
     const char* v = std::getenv("BITO_AMD_PIPE_MIN_BRANCH");
     return v ? std::atof(v) : kPipeReversibleMinBranch;
@@ -462,7 +462,7 @@ int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_
     case BITO_AMD_KERNEL_LDS_PIPE:
       use_tree = false;
       use_pipe = pplan.groups > 0 && !rescaling && pipe_branches_ok;
-      if (!use_pipe) return Fail(e, BITO_AMD_ERR_STATE, "the pipelined LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, a tree whose stored vectors fit in 160 KB of LDS, and from 39 taxa on branch lengths of 1e-6 and more)");
+      if (!use_pipe) return Fail(e, BITO_AMD_ERR_STATE, "the pipelined LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, a tree whose stored vectors fit in 160 KB of LDS, and from 39 taxa on branch lengths of 9e-7 and more)");
       break;
     case BITO_AMD_KERNEL_LDS:
       use_tree = false;

@@ -200,9 +200,9 @@ int HbmWalkTiles(const BatchDims& d);
 int HbmWalkGradRows(const BatchDims& d);
 // walk_pipe_kernel: up to this many taxa it keeps (P, P^T) pairs; beyond, one image per branch and the reversible
 // form of the pre-order recursion, which the engine uses only when every branch length is at least
-// kPipeReversibleMinBranch (walk_pipe.hip, scripts/gen_walk_pipe.py)
+// kPipeReversibleMinBranch (about 1e-6) (walk_pipe.hip, scripts/gen_walk_pipe.py)
 constexpr int kPipeExactTaxa = 38;
-constexpr double kPipeReversibleMinBranch = 1e-6;
+constexpr double kPipeReversibleMinBranch = 9e-7;  // (just below exp(-13.9), the reference optimiser's own floor: src/dag_branch_handler.hpp:272)
 bool HbmCatKernelApplies(const BatchDims& d);
 // out_site from walk_hbm_cat_kernel's per-category gradient rows (after the walk of every chunk), no second traversal
 void LaunchSiteFromCategoryRows(const BatchDims& d, const DeviceBatch& b, int rows, hipStream_t stream);

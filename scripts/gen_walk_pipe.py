@@ -315,7 +315,7 @@ class Loops:
     #     rounding error: an entry that is all rounding error -- a zero-length branch -- breaks the identity, and a
     #     pattern that needs a substitution on such a branch then gets derivatives that differ from the
     #     reference's (which are noise there too, but the same noise as the checker's).  The engine therefore uses
-    #     this layout only for batches whose branch lengths are all 1e-6 or more (relative error of an
+    #     this layout only for batches whose branch lengths are all 9e-7 or more (relative error of an
     #     off-diagonal entry <= 1e-10) and keeps the exact one wherever it fits.
     MAX_TIPS = 48      # a VGPR per tip for its packed masks beside one or two pattern groups (64: 5.5 % slower at 36 taxa)
     EXACT_TAXA = 38

@@ -810,7 +810,7 @@ def test_auto_kernel_choice_at_the_pipe_walk_limits():
     branch is shorter than 1e-6; everything else, and rescaling at any size, goes to the HBM-arena walk
     (walk_hbm_cat_kernel); each against the oracle."""
     rng = np.random.default_rng(29)
-    for n, rescaling, shortest, expect in ((38, False, 0.0, "walk_pipe_kernel"), (41, False, 1e-6, "walk_pipe_kernel"),
+    for n, rescaling, shortest, expect in ((38, False, 0.0, "walk_pipe_kernel"), (41, False, 9.2e-7, "walk_pipe_kernel"),
                                            (41, False, 1e-7, "walk_hbm_cat_kernel"), (41, False, 0.0, "walk_hbm_cat_kernel"),
                                            (58, False, 1e-3, "walk_hbm_cat_kernel"), (29, True, 0.0, "walk_hbm_cat_kernel")):
         patterns = rng.integers(0, 4, (n, 70)).astype(np.int32)
@@ -829,7 +829,7 @@ def test_auto_kernel_choice_at_the_pipe_walk_limits():
         assert np.allclose(out["branch_lengths"][fin], ref["branch_lengths"][fin], rtol=1e-9, atol=GRAD_ATOL), (n, shortest)
         if n == 41 and shortest == 0.0:  # the kernel itself, when asked for, says why it does not take the batch
             gpu.set_kernel(_capi.KERNEL_LDS_PIPE)
-            with pytest.raises(bito_amd.BitoAmdError, match="branch lengths of 1e-6 and more"):
+            with pytest.raises(bito_amd.BitoAmdError, match="branch lengths of 9e-7 and more"):
                 gpu.gradients(pid, bl)
 
 
