@@ -601,6 +601,32 @@ def test_hbm_arena_walk_one_wave_per_category(site, rescaling):
         assert ll_close(gpu.log_likelihoods(pid, bl, params, rescaling=rescaling), ref["log_likelihood"]), (P, rooted)
 
 
+def test_hbm_arena_walk_in_chunks():
+    """A PLV arena too small for the batch: the HBM-arena walk runs it in several launches (chunks of trees), with
+    gradients, rescaling and the site-model gradient, against the oracle."""
+    rng = np.random.default_rng(77)
+    n, P, T = 50, 150, 11
+    patterns = rng.integers(0, 5, (n, P)).astype(np.int32)
+    weights = rng.integers(1, 4, P).astype(np.float64)
+    pid = np.stack([workloads.random_unrooted_tree(n, rng, 0.1).parent_ids for _ in range(T)]).astype(np.int32)
+    bl = rng.exponential(0.1, (T, 2 * n - 2))
+    bl[:, -1] = 0.0
+    per_tree = (n - 1) * 4 * 4 * 256 * 8  # (n - 1) vectors of 4 categories x 4 states x the padded patterns, doubles
+    gpu = bito_amd.Engine(spec("HKY", "weibull+4"), patterns, weights, arena_bytes=3 * per_tree)  # three trees at a time
+    cpu = oracle.OracleEngine("HKY", "weibull+4", "none", patterns, weights, 4)
+    params = gpu.default_params(T)
+    params[:, :4] = rng.dirichlet([5, 5, 5, 5], T)
+    params[:, -1] = rng.uniform(0.3, 2.0, T)
+    for rescaling in (False, True):
+        out = gpu.gradients(pid, bl, params, rescaling=rescaling, flags=_capi.GRAD_SITE_MODEL)
+        assert gpu.kernel_name() == "walk_hbm_cat_kernel"
+        ref = cpu.gradients(pid, bl, params, rescaling=rescaling, flags=oracle.GRAD_SITE_MODEL)
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+        assert grad_close(out["branch_lengths"], ref["branch_lengths"])
+        assert grad_close(out["site_model"], ref["site_model"])
+        assert ll_close(gpu.log_likelihoods(pid, bl, params, rescaling=rescaling), ref["log_likelihood"])
+
+
 def test_one_rate_category_underflows_without_rescaling():
     """90 taxa, short branches, no rescaling: the slowest rate category's site likelihoods underflow for some
     patterns while the patterns' likelihoods (the sum over categories) stay normal numbers.  The derivatives must
