@@ -43,10 +43,11 @@ extern "C" {
 #define BITO_AMD_GRAD_RATIOS_ROOT_HEIGHT 16        /* ratios_root_height (time trees only) */
 #define BITO_AMD_GRAD_LOG_DET_JACOBIAN_GRADIENT 32 /* include_log_det_jacobian_gradient */
 
-/* Kernel selection (diagnostics / benchmarking).  AUTO picks the LDS-resident
- * kernel when the tree fits, the HBM-arena kernel otherwise. */
+/* Kernel selection (diagnostics / benchmarking).  AUTO picks walk_pipe_kernel (partial-likelihood messages in
+ * LDS, matrix images in registers) for trees of up to 38 taxa -- up to 48 when no branch of the batch is shorter
+ * than 9e-7 -- with 1, 2 or 4 rate categories and no rescaling, the HBM-arena walk otherwise. */
 #define BITO_AMD_KERNEL_AUTO 0
-#define BITO_AMD_KERNEL_HBM_ARENA 1
+#define BITO_AMD_KERNEL_HBM_ARENA 1 /* walk_hbm_cat_kernel (up to 4 rate categories: one wave per category), walk_hbm_kernel */
 #define BITO_AMD_KERNEL_LDS 2      /* walk_lds_kernel: one wave per SIMD, images from L2 */
 #define BITO_AMD_KERNEL_LDS_TREE 3 /* walk_tree_kernel: two waves per SIMD, images staged in LDS */
 #define BITO_AMD_KERNEL_GENERAL 4  /* gs_walk_kernel: the general-state-count kernels (any model; the only
