@@ -70,7 +70,9 @@ __device__ __forceinline__ void MatVecT(const double* __restrict__ M, const doub
 constexpr int kCatTile = 64;
 inline int HbmCatTiles(int pattern_count) { return (pattern_count + kCatTile - 1) / kCatTile; }
 
-// Tried on top of this kernel and dropped: PITCHFORKS (a cherry and a tip under one node -- a sixth of the internal
+// Tried on top of this kernel and dropped: a node's child pair requested one node ahead (the scalar load off the
+// step's dependent chain: config 2 0.585 against 0.51-0.53 ms per 6400 trees, config 4 72.5 against 70.1 ms -- the
+// request in flight turns the step's first wait for LDS into a wait for everything); and PITCHFORKS (a cherry and a tip under one node -- a sixth of the internal
 // nodes of a random tree) rebuilt and folded into the parent's step like cherries.  The nested step needs 75
 // registers: held to 64 it spills (config 4, 125 trees, same box: 84.8 ms against 69.9), at six waves per SIMD it
 // gains 2.5-4 % (66.7 / 69.4 ms against 69.9 / 71.2; 41 taxa: 3.54 against 3.78 ms) -- the arena traffic it saves is
