@@ -4,16 +4,24 @@
 Workload (config 3): DS1.fasta (27 taxa, 934 site patterns), the 100 topologies of
 DS1.100_topologies.nwk replicated R times per GPU with per-tree seeded branch lengths,
 GTR + weibull+4 (4 rate categories), FP64, log-likelihood + branch-length gradient.
-A "step" is one pass of the hot path over the resident batch: per-tree model set-up +
+
+A "step" is ONE blocking call of the engine's gradients entry point -- the span of the
+reference's Engine::Gradients (src/fat_beagle.hpp:173-181, SURVEY.md 8d): host arrays in
+(parent-id vectors, FRESH branch lengths -- two sets alternate, so no step sees the values the
+device already holds -- and parameter rows), then on the device per-tree model set-up +
 eigendecomposition, transition matrices, post-order partials, pre-order partials + edge
-derivatives, per-tree reductions.  Inputs (parent-id vectors, branch lengths, parameter
-rows, compressed alignment) are resident in HBM before the timed region.
+derivatives, per-tree reductions, and host arrays out (log-likelihoods and gradients).  That
+rate is `value`.  The compressed alignment is resident in HBM (engine creation is outside the
+span, as in the reference).  `resident` reports, beside it, the rate of the same passes over a
+batch that stays in HBM (bito_amd_engine_run back to back: no host arrays cross PCIe), which
+is what round 1 and 2 reported as `value`.
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); every rank owns
-R x 100 trees (weak scaling); each step ends with an all-gather of the per-tree results
-and an all-reduce of the summed log-likelihood, the only exchange the path has.
+R x 100 trees (weak scaling) and calls its own engine; each step ends with an all-reduce of
+the summed log-likelihood, the only exchange the path has.
 
-Prints ONE JSON line on rank 0.
+Other workloads: --workload config4 (synthetic 1000 taxa x 10 000 patterns, rescaling on,
+1000 trees / ranks), --workload codon (config 5).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -29,9 +37,7 @@ import numpy as np  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 68.0  # measured, scripts: bito_amd/csrc/microbench.hip
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-
-
-FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (MI355X_MICROARCH.md); codon workload
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes_per_tree(n: int, P: int, C: int, gradient: bool, S: int = 4) -> float:
@@ -45,44 +51,112 @@ def algorithmic_flops_per_tree(n: int, P: int, C: int, S: int) -> float:
     return C * P * ((3 * n - 3) * (4 * S * S - S) + (2 * n - 2) * (2 * S * S + 3 * S - 1))
 
 
+def usable_cpus():
+    """(logical CPUs this process may run on, CPU quota of its cgroup or None): os.cpu_count() ignores both."""
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, period = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, period = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    return affinity, quota
+
+
+def physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def cpu_baseline(w, seconds: float):
-    """The CPU oracle driven like the reference Engine (one instance per thread, dynamic
-    queue over trees) on a bounded sample of the same workload."""
-    threads = os.cpu_count() or 1
+    """The CPU oracle driven like the reference Engine (one instance per thread, dynamic queue over trees,
+    src/fat_beagle.hpp:160-181) on a bounded sample of the same workload.  Thread counts are swept -- 1, powers
+    of four, the physical cores, every usable logical CPU (affinity mask and cgroup quota, not os.cpu_count()) --
+    with calls long enough that the per-call thread start-up does not show; the best sustained rate is `value`,
+    the one-thread rate is reported beside it."""
+    affinity, quota = usable_cpus()
+    limit = max(1, min(affinity, int(quota + 0.5)) if quota else affinity)
+    phys = physical_cores()
     if w.substitution == "GY94":
         from oracle import gs
 
-        eng = gs.GsOracleEngine(w.substitution, w.site, w.patterns, w.weights, threads)
+        make = lambda threads: gs.GsOracleEngine(w.substitution, w.site, w.patterns, w.weights, threads)  # noqa: E731
         source = "oracle/gs_oracle.c"
     else:
         from oracle import oracle
 
-        eng = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, threads)
+        make = lambda threads: oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, threads)  # noqa: E731
         source = "oracle/bito_oracle.c"
-    run = eng.gradients if w.want_gradient else eng.log_likelihoods
 
     def sample(count):
         reps = -(-count // w.tree_count)
         return (np.tile(w.parent_ids, (reps, 1))[:count], np.tile(w.branch_lengths, (reps, 1))[:count],
                 np.tile(w.params, (reps, 1))[:count])
 
-    probe = max(4 * threads, 64)
-    pid, bl, par = sample(probe)
-    run(pid, bl, par, rescaling=w.rescaling)  # warm-up: first touch of every thread's buffers
-    # Timed in chunks until the budget is used: a short probe overestimates the sustained rate of a
-    # many-core host severalfold, so the sample size is not extrapolated from it.
-    count, dt, chunk = 0, 0.0, probe
-    while dt < seconds:
+    def rate(threads, budget):
+        """sustained trees/s of `threads` threads over about `budget` seconds (after a warm-up call that makes
+        every thread touch its own buffers); calls of at least a quarter of the budget each"""
+        eng = make(threads)
+        run = eng.gradients if w.want_gradient else eng.log_likelihoods
+        chunk = max(8 * threads, 32)  # (every thread gets trees: first touch of its own buffers)
         pid, bl, par = sample(chunk)
         t0 = time.perf_counter()
         run(pid, bl, par, rescaling=w.rescaling)
-        took = time.perf_counter() - t0
-        count += chunk
-        dt += took
-        chunk = int(min(max(probe, chunk / max(took, 1e-3) * seconds / 4), 64 * probe))  # about a quarter of the budget
-    return {"value": count / dt, "unit": "trees/s", "cores": threads, "kind": "port",
-            "sample": f"{count} trees of the same workload, {dt:.1f} s, {source} with {threads} threads "
-                      "(FP64 restatement of the BEAGLE CPU path; the reference binary cannot be built here)"}
+        per_tree = (time.perf_counter() - t0) / chunk  # (an overestimate: first touch included)
+        chunk = int(min(max(chunk, budget / 4 / max(per_tree, 1e-9)), 1 << 16))
+        count, dt = 0, 0.0
+        while dt < budget:
+            pid, bl, par = sample(chunk)
+            t0 = time.perf_counter()
+            run(pid, bl, par, rescaling=w.rescaling)
+            took = time.perf_counter() - t0
+            count += chunk
+            dt += took
+            chunk = int(min(max(2 * threads, chunk * budget / 3 / max(took, 1e-3)), 1 << 17))
+        return count / dt, count, dt
+
+    candidates = sorted({c for c in (1, 4, 16, 64, phys or 0, limit) if 1 <= c <= limit})
+    sweep_budget = seconds * 0.4 / max(len(candidates), 1)
+    sweep = {}
+    for c in candidates:
+        sweep[c] = rate(c, sweep_budget)[0]
+    best = max(sweep, key=sweep.get)
+    value, count, dt = rate(best, seconds * 0.6)
+    value = max(value, sweep[best])
+    return {"value": value, "unit": "trees/s", "cores": best, "kind": "port",
+            "one_thread": sweep.get(1), "per_thread_at_cores": value / best,
+            "sweep_trees_per_s": {str(k): v for k, v in sweep.items()},
+            "host": {"logical_cpus": os.cpu_count(), "affinity": affinity, "cgroup_quota": quota,
+                     "physical_cores": phys},
+            "sample": f"{count} trees of the same workload, {dt:.1f} s, {source} with {best} threads, the best of "
+                      f"the thread counts {candidates} (one engine instance per thread, dynamic queue over trees, "
+                      "as the reference's Engine; FP64 restatement of the BEAGLE CPU path -- the reference binary "
+                      "cannot be built here)"}
 
 
 def arithmetic_view(n, P, C, S, trees_per_launch, avg_kernel_s):
@@ -97,18 +171,47 @@ def arithmetic_view(n, P, C, S, trees_per_launch, avg_kernel_s):
             "algorithmic_flops_per_tree": algorithmic_flops_per_tree(n, P, C, S)}
 
 
-def measured_traffic(kernel: str, trees_per_launch: int):
-    """HBM bytes per launch of the traversal kernel from the committed rocprofv3 PMC pass
-    (profiles/*_traffic.json), if one matches this launch shape."""
+def measured_traffic(kernel: str, trees_per_launch: float, workload: str):
+    """HBM bytes per launch of the traversal kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json), scaled per tree to this launch size when the pass was taken at another one."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
-            for row in json.load(fh):
-                if row["kernel"] == kernel and row["trees_per_launch"] == trees_per_launch:
-                    return row["hbm_bytes_per_launch"]
+            rows = [r for r in json.load(fh) if r["kernel"] == kernel and r.get("workload", "ds1") == workload]
     except (OSError, ValueError, KeyError):
-        pass
-    return None
+        return None
+    if not rows:
+        return None
+    row = min(rows, key=lambda r: abs(r["trees_per_launch"] - trees_per_launch))
+    return row["hbm_bytes_per_launch"] / row["trees_per_launch"] * trees_per_launch
+
+
+def roofline_object(kernel, n, P, C, S, want_gradient, trees_per_launch, avg_kernel_s, workload_key):
+    alg_bytes = algorithmic_bytes_per_tree(n, P, C, want_gradient, S) * trees_per_launch
+    achieved = alg_bytes / avg_kernel_s / 1e9
+    traffic = measured_traffic(kernel, trees_per_launch, workload_key)
+    hbm_view = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        # the PMC-measured bytes over the same launch time: what the kernel really asks of HBM
+        "actual_hbm_GBps": (traffic / avg_kernel_s / 1e9) if traffic else None,
+        "actual_frac_of_peak": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "algorithmic_bytes_per_tree": algorithmic_bytes_per_tree(n, P, C, want_gradient, S),
+    }
+    if S == 61:
+        flops = algorithmic_flops_per_tree(n, P, C, S) * trees_per_launch
+        arithmetic = {"bound": "mfma", "achieved": flops / avg_kernel_s / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                      "unit": "TFLOP/s", "frac": flops / avg_kernel_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                      "note": "algorithmic flops of SURVEY 8d (tip children counted as full products); "
+                              "v_mfma_f64_16x16x4 sustains 47.6 TFLOP/s on this part (profiles/r1_microbench.json)"}
+    else:
+        arithmetic = arithmetic_view(n, P, C, S, trees_per_launch, avg_kernel_s)
+    common = {"traffic": traffic, "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3,
+              "trees_per_launch": trees_per_launch}
+    if kernel in ("walk_pipe_kernel", "walk_lds_kernel", "walk_tree_kernel"):
+        # These kernels keep every partial in LDS: HBM sees 0.3 % of the op-by-op byte model (`traffic`), so
+        # the resource that bounds them is the FP64 matrix / vector pipe.  The byte view is kept beside it.
+        return {**arithmetic, **common, "hbm_view": hbm_view}
+    return {**hbm_view, **common, "arithmetic": arithmetic}
 
 
 def main():
@@ -117,12 +220,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=64,
-                    help="x100 DS1 topologies per GPU and pass (SURVEY 8d: replicated to fill the device; 6400 trees = 4 ms)")
-    ap.add_argument("--workload", choices=["ds1", "codon"], default="ds1",
-                    help="ds1 = BASELINE config 3 (the headline metric); codon = config 5 (fluA as codons, GY94)")
-    ap.add_argument("--trees", type=int, default=4096, help="codon workload: trees per GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+                    help="x100 DS1 topologies per GPU and call (SURVEY 8d: replicated to fill the device; 6400 trees = 4 ms)")
+    ap.add_argument("--workload", choices=["ds1", "config4", "codon"], default="ds1",
+                    help="ds1 = BASELINE config 3 (the headline metric); config4 = synthetic 1000 taxa x 10 000 patterns, "
+                         "1000 trees over the ranks, rescaling on; codon = config 5 (fluA as codons, GY94)")
+    ap.add_argument("--trees", type=int, default=0,
+                    help="codon workload: trees per GPU (default 4096); config4: trees in all (default 1000, "
+                         "125 per GPU at 8 GPUs; one GPU alone takes 125)")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-resident", action="store_true", help="skip the second timed region (resident batch)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 HBM arena, 2 LDS")
     ap.add_argument("--sum-ll-reduce", choices=("auto", "on", "off"), default="auto",
                     help="per step, all-reduce the summed log-likelihood over the ranks (RCCL); auto = when there "
@@ -161,10 +268,20 @@ def main():
     if args.sum_ll_reduce == "on" and dist is None:
         raise SystemExit("--sum-ll-reduce on needs a process group (launch with torch.distributed.run)")
 
-    # every rank builds the same replicated workload and takes its own block of trees
+    # every rank builds its own block of the same replicated workload
     codon = args.workload == "codon"
+    config4 = args.workload == "config4"
+    scaling = "weak"
     if codon:
-        w = workloads.flua_codon(args.trees * world).shard(rank, world)
+        per_rank = args.trees or 4096
+        w = workloads.flua_codon(per_rank * world).shard(rank, world)
+    elif config4:
+        # BASELINE config 4: 1000 sampled trees sharded across the ranks (strong scaling: the collection is fixed);
+        # one GPU alone takes one GPU's share of the 8-GPU run, 125 trees
+        total = args.trees or (1000 if world > 1 else 125)
+        lo, hi = total * rank // world, total * (rank + 1) // world
+        w = workloads.synthetic_gtr_weibull4(1000, 10000, tree_count=hi - lo, first_tree=lo)
+        scaling = "strong" if world > 1 else "weak"
     else:  # (a rank generates its own block of the 100 x replicas x world trees: same trees as the whole, sharded)
         per_rank = 100 * args.replicas
         w = workloads.ds1_gtr_weibull4(args.replicas * world, first_tree=rank * per_rank, tree_count=per_rank)
@@ -172,58 +289,35 @@ def main():
     n, P = w.patterns.shape
     C = 1 if codon else 4
     S = 61 if codon else 4
+    N = 2 * n - 1
 
     eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights,
                           device_id=local_rank)
     if not codon:
         eng.set_kernel(args.kernel)
-    eng.upload(w.parent_ids, w.branch_lengths, w.params)
 
-    # Summed log-likelihood over the ranks, one asynchronous RCCL all-reduce per step.  Nothing waits on the
-    # host and nothing is added to the engine's stream: torch's stream waits for the pass through the event the
-    # engine records behind it anyway, sums the per-tree values where the engine left them (a ring of four
-    # buffers, so the next passes do not touch them), and hands the scalar to RCCL; the next pass (and its
-    # set-up) is submitted meanwhile.  The engine's stream waits for the sum that last read a ring slot before
-    # the pass that rewrites it, four passes later.
-    kRing = 4
-    engine_stream = None
-    if reduce_ll:
-        try:
-            engine_stream = torch.cuda.ExternalStream(eng.stream_handle())
-        except Exception as exc:  # noqa: BLE001 -- then hand results over with a host wait per step instead
-            print(f"bench: no external-stream wrapper ({exc!r}); the reduction waits on the host each step", file=sys.stderr)
-    ll_host_ring = torch.zeros(T, dtype=torch.float64, device="cuda") if reduce_ll and engine_stream is None else None
-    sum_done = [None] * kRing
+    # fresh host inputs per step: two sets of branch lengths take turns
+    pid = np.ascontiguousarray(w.parent_ids, dtype=np.int32)
+    params = np.ascontiguousarray(w.params, dtype=np.float64)
+    bl_sets = [np.ascontiguousarray(w.branch_lengths, dtype=np.float64),
+               np.ascontiguousarray(w.branch_lengths * 1.03125, dtype=np.float64)]
+    out_ll = np.zeros(T)
+    out_grad = np.zeros((T, N))
     pending = []  # (work handle, tensor) of the reductions in flight
-    step_index = [0]
-
-    class _DeviceVector:
-        """zero-copy view of `count` doubles at a device address, for torch.as_tensor"""
-
-        def __init__(self, address, count):
-            self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (address, False), "version": 2}
+    counter = [0]
 
     def step():
-        # trees are independent: each rank evaluates its own block; the only exchange the path has is the
-        # summed log-likelihood of the whole collection (the caller's objective), 8 bytes per step
+        # the call the reference's Engine::Gradients is: host trees + parameter rows in, host results out
+        bl = bl_sets[counter[0] & 1]
+        counter[0] += 1
+        if w.want_gradient:
+            eng.gradients_into(pid, bl, params, out_ll, out_grad, rescaling=w.rescaling)
+        else:
+            eng.log_likelihoods_into(pid, bl, params, out_ll, rescaling=w.rescaling)
         if reduce_ll:
-            slot = step_index[0] % kRing
-            step_index[0] += 1
-            if engine_stream is not None and sum_done[slot] is not None:
-                engine_stream.wait_event(sum_done[slot])
-        eng.run(w.want_gradient, w.rescaling)
-        if reduce_ll:
-            here = torch.cuda.current_stream()
-            if engine_stream is not None:
-                ll_address, _ = eng.results_async(here.cuda_stream)
-                values = torch.as_tensor(_DeviceVector(ll_address, T), device="cuda")
-            else:
-                torch.cuda.synchronize()  # earlier sums have read the buffer
-                eng.download_to(ll_host_ring.data_ptr(), None)  # waits for the pass
-                values = ll_host_ring
-            total = values.sum().reshape(1)
-            sum_done[slot] = torch.cuda.Event()
-            sum_done[slot].record(here)
+            # trees are independent: the only exchange the path has is the summed log-likelihood of the whole
+            # collection (the caller's objective), 8 bytes per step
+            total = torch.tensor([float(out_ll.sum())], dtype=torch.float64).cuda(non_blocking=True)
             pending.append((dist.all_reduce(total, async_op=True), total))
 
     def fence():
@@ -247,54 +341,75 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = eng.kernel_elapsed()
     eng.kernel_timing(False)
+    kernel = eng.kernel_name()
 
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # sanity: results of the timed batch are finite
-    ll_host, grad_host = eng.download(True)
-    if not (np.all(np.isfinite(ll_host)) and np.all(np.isfinite(grad_host))):
+    # sanity: results of the timed calls are finite
+    if not (np.all(np.isfinite(out_ll)) and (not w.want_gradient or np.all(np.isfinite(out_grad)))):
         raise SystemExit("non-finite results in the timed batch")
     summed_ll = None
     if reduce_ll:
         # the last reduction must be the sum over every rank's block: check it against a gather of the
         # per-rank sums (outside the timed region)
         summed_ll = float(pending[-1][1].item())
-        mine = torch.tensor([float(ll_host.sum())], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([float(out_ll.sum())], dtype=torch.float64, device="cuda")
         parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, mine)
         expect = float(sum(p.item() for p in parts))
         if not abs(summed_ll - expect) <= 1e-9 * abs(expect):
             raise SystemExit(f"summed log-likelihood {summed_ll} differs from the gathered sum {expect}")
 
+    # second timed region: the same passes over a batch that stays in HBM (no host arrays cross PCIe)
+    resident = None
+    if not args.no_resident:
+        eng.upload(pid, bl_sets[0], params)
+        for _ in range(args.warmup):
+            eng.run(w.want_gradient, w.rescaling)
+        eng.sync()
+        eng.kernel_timing(True)
+        r0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.run(w.want_gradient, w.rescaling)
+        eng.sync()
+        r_elapsed = time.perf_counter() - r0
+        r_kernel_ms, r_launches = eng.kernel_elapsed()
+        eng.kernel_timing(False)
+        r_kernel = eng.kernel_name()
+        if dist is not None:
+            tmax = torch.tensor([r_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            r_elapsed = float(tmax.item())
+        resident = {"trees_per_s": world * T * args.steps / r_elapsed, "ms_per_step": r_elapsed / args.steps * 1e3,
+                    "note": "bito_amd_engine_run back to back over a batch resident in HBM, no sum reduction",
+                    "roofline": roofline_object(r_kernel, n, P, C, S, w.want_gradient, T * args.steps / max(r_launches, 1),
+                                                r_kernel_ms * 1e-3 / max(r_launches, 1), args.workload)}
+
     if rank == 0:
         total_trees = world * T
         value = total_trees * args.steps / elapsed
         trees_per_launch = T * args.steps / max(launches, 1)
         avg_kernel_s = kernel_ms * 1e-3 / max(launches, 1)
-        alg_bytes = algorithmic_bytes_per_tree(n, P, C, w.want_gradient, S) * trees_per_launch
-        achieved = alg_bytes / avg_kernel_s / 1e9
-        kernel = eng.kernel_name()
         if codon:
-            flops = algorithmic_flops_per_tree(n, P, C, S) * trees_per_launch
-            arithmetic = {"bound": "mfma", "achieved": flops / avg_kernel_s / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                          "unit": "TFLOP/s", "frac": flops / avg_kernel_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
-                          "note": "algorithmic flops of SURVEY 8d (tip children counted as full products); "
-                                  "v_mfma_f64_16x16x4 sustains 47.6 TFLOP/s on this part (profiles/r1_microbench.json)"}
+            metric = "tree log-likelihoods+gradients/sec (fluA codon GY94, 61 states)"
             workload = (f"BASELINE config 5: fluA.fa as codons (69 taxa, 329 codon columns = {P} patterns, 61 states), "
                         f"fluA.tree topology x {T} trees per GPU with seeded branch lengths, GY94 (kappa, omega, F1x4), "
                         "log-likelihood + branch-length gradient")
+        elif config4:
+            metric = "tree log-likelihoods+gradients/sec (synthetic 1000 taxa x 10000 patterns, GTR+Gamma4, rescaling)"
+            workload = (f"BASELINE config 4: synthetic alignment, 1000 taxa x 10 000 distinct patterns (JC69 down a seeded "
+                        f"tree), {total_trees} seeded random topologies with Exp(0.1) branch lengths sharded over "
+                        f"{world} GPU(s) ({T} per GPU), GTR+weibull4, rescaling on, log-likelihood + branch-length gradient")
         else:
-            arithmetic = arithmetic_view(n, P, C, S, trees_per_launch, avg_kernel_s)
+            metric = "tree log-likelihoods+gradients/sec (DS1 GTR+Gamma4)"
             workload = ("BASELINE config 3: DS1.fasta (27 taxa, 934 patterns) x 100 topologies x "
                         f"{args.replicas} replicas per GPU, GTR+weibull4 (4 categories), seeded Exp(0.1) branch "
                         "lengths, log-likelihood + branch-length gradient")
-        traffic = measured_traffic(kernel, int(trees_per_launch))
         out = {
-            "metric": ("tree log-likelihoods+gradients/sec (fluA codon GY94, 61 states)" if codon
-                       else "tree log-likelihoods+gradients/sec (DS1 GTR+Gamma4)"),
+            "metric": metric,
             "value": value,
             "unit": "trees/s",
             "n_gpus": world,
@@ -302,12 +417,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": workload,
+                "span": ("one blocking Engine::Gradients-shaped call per step: host parent ids, fresh host branch "
+                         "lengths and parameter rows in, host log-likelihoods and gradients out (PCIe inclusive)"),
                 "trees_per_gpu": T,
                 "trees_total": total_trees,
                 "kernel": kernel,
@@ -317,26 +434,12 @@ def main():
                 if dist is not None else "single GPU, no collective",
                 **({"summed_log_likelihood": summed_ll} if reduce_ll else {}),
             },
-            "roofline": None,
+            "roofline": roofline_object(kernel, n, P, C, S, w.want_gradient, trees_per_launch, avg_kernel_s,
+                                        args.workload),
         }
-        hbm_view = {
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            # the PMC-measured bytes over the same launch time: what the kernel really asks of HBM
-            "actual_hbm_GBps": (traffic / avg_kernel_s / 1e9) if traffic else None,
-            "algorithmic_bytes_per_tree": algorithmic_bytes_per_tree(n, P, C, w.want_gradient, S),
-        }
-        common = {"traffic": traffic, "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3,
-                  "trees_per_launch": trees_per_launch}
-        if kernel in ("walk_pipe_kernel", "walk_lds_kernel", "walk_tree_kernel"):
-            # These kernels keep every partial in LDS: HBM sees 0.3 % of the op-by-op byte model (`traffic`), so
-            # the resource that bounds them is the FP64 matrix / vector pipe.  The byte view is kept beside it.
-            out["roofline"] = {**arithmetic, **common, "hbm_view": hbm_view}
-        else:
-            out["roofline"] = {**hbm_view, **common, "arithmetic": arithmetic}
+        out["roofline"]["launches_per_step"] = launches / args.steps
+        if resident is not None:
+            out["resident"] = resident
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         print(json.dumps(out))

@@ -26,7 +26,7 @@ KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS, KERNEL_LDS_TREE, KERNEL_GENERAL, KERN
 # Every symbol include/bito_amd.h declares (tests check that the library exports them all).
 SYMBOLS = [
     "bito_amd_engine_create", "bito_amd_engine_destroy", "bito_amd_engine_last_error",
-    "bito_amd_engine_param_count", "bito_amd_engine_category_count", "bito_amd_engine_state_count", "bito_amd_engine_block_count",
+    "bito_amd_engine_param_count", "bito_amd_engine_device_count", "bito_amd_engine_category_count", "bito_amd_engine_state_count", "bito_amd_engine_block_count",
     "bito_amd_engine_block", "bito_amd_engine_log_likelihoods", "bito_amd_engine_gradients",
     "bito_amd_engine_upload", "bito_amd_engine_update", "bito_amd_engine_run", "bito_amd_engine_sync",
     "bito_amd_engine_download", "bito_amd_engine_download_async", "bito_amd_engine_results_async", "bito_amd_engine_stream", "bito_amd_engine_set_kernel", "bito_amd_plan_pipe_walk", "bito_amd_engine_time_runs",
@@ -40,7 +40,8 @@ SYMBOLS = [
 
 
 class EngineSpec(C.Structure):
-    _fields_ = [("device_id", C.c_int32), ("use_tip_states", C.c_int32), ("arena_bytes", C.c_uint64)]
+    _fields_ = [("device_id", C.c_int32), ("use_tip_states", C.c_int32), ("arena_bytes", C.c_uint64),
+                ("device_count", C.c_int32), ("reserved", C.c_int32), ("devices", C.POINTER(C.c_int32))]
 
 
 _lib = None
@@ -65,7 +66,7 @@ def lib():
     L.bito_amd_engine_destroy.argtypes = [vp]
     L.bito_amd_engine_last_error.restype = C.c_char_p
     L.bito_amd_engine_last_error.argtypes = [vp]
-    for name in ("param_count", "category_count", "state_count", "block_count"):
+    for name in ("param_count", "category_count", "state_count", "block_count", "device_count"):
         fn = getattr(L, f"bito_amd_engine_{name}")
         fn.restype = C.c_int32
         fn.argtypes = [vp]

@@ -1,149 +1,57 @@
-// engine.cpp -- host side of the C ABI declared in include/bito_amd.h.
+// engine.cpp -- the C ABI declared in include/bito_amd.h.
 //
-// The engine owns one GPU, the compressed alignment in HBM, and one resident
-// batch of trees.  It mirrors what Engine + FatBeagleParallelize do in the
-// reference (src/engine.cpp:10-110, src/fat_beagle.hpp:151-184) but hands the
-// whole tree collection to the device at once instead of farming trees to
-// threads: the per-tree work (model set-up, transition matrices, traversal) is
-// done by kernels, the host only validates inputs and moves buffers.
-#include <hip/hip_runtime.h>
-
+// One engine drives one or more GPUs from one host thread, as the reference's Engine drives
+// thread_count FatBeagle instances (src/engine.cpp:10-31, src/fat_beagle.hpp:151-184): a tree
+// collection is cut into contiguous blocks, one per device, and every block into a few chunks
+// that travel through the device one behind the other -- each chunk on a worker of its own
+// (worker.cpp: streams, pinned staging, resident buffers), so that while chunk k is being
+// traversed the host validates and stages chunk k+1 and the results of chunk k-1 come back.
+// Results land in the caller's arrays at the trees' own positions; nothing depends on which
+// chunk or device a tree went to except the order of the pattern-tile sums (rounding level,
+// see INTEGRATION.md).
 #include <algorithm>
-#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <limits>
+#include <memory>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
-#include "../../include/bito_amd.h"
-#include "kernels.hpp"
-#include "model.hpp"
+#include "worker.hpp"
 
 using namespace bito_amd;
 
 namespace {
 
-struct Block {
-  std::string name;
-  int32_t start, len;
+// a block of the resident batch: trees [t0, t0 + count) of the caller's collection live on worker (slot, lane)
+struct Shard {
+  int slot, lane;
+  int t0, count;
 };
 
-template <typename T>
-struct DeviceBuffer {
-  T* ptr = nullptr;
-  size_t capacity = 0;  // elements
-  hipError_t Reserve(size_t count) {
-    if (count <= capacity) return hipSuccess;
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    capacity = 0;
-    hipError_t rc = hipMalloc(reinterpret_cast<void**>(&ptr), count * sizeof(T));
-    if (rc == hipSuccess) capacity = count;
-    return rc;
-  }
-  void Free() {
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    capacity = 0;
-  }
-};
+constexpr int kMaxLanes = 8;
 
 }  // namespace
 
 struct bito_amd_engine {
-  ModelSpec spec{};
-  std::vector<Block> blocks;
-  int device = 0;
-  int n = 0, P = 0, Ppad = 0;
-  uint64_t arena_limit = 0;
-  hipStream_t stream = nullptr;
-  // Set-up pipeline of the LDS kernels: the set-up kernels of pass k+1 (topology, model, matrix images,
-  // step tables) run on prep_stream while earlier passes' traversals are still on `stream`; they write into the
-  // next of kSets buffer sets.  Events order the two streams: a set is not rewritten before the traversal that
-  // read it has finished, and a traversal does not start before its set is ready.  Three sets: the set-up of
-  // pass k+1 may start when pass k-2 has finished, a whole pass before it is needed -- walk_pipe_kernel keeps
-  // every CU until its queue of work is empty, so the set-up kernels mostly run in the tail of a traversal,
-  // and with two sets the next traversal waited for them there.
-  hipStream_t prep_stream = nullptr;
-  int serial_setup = 0;  // BITO_AMD_SERIAL_SETUP (measurements): 1 = the set-up kernels run on `stream`, in front of the traversal;
-                         // 2 = no set-up and no events after the first kSets passes (the buffer sets keep what they hold)
-  static constexpr int kSets = 3;
-  hipEvent_t ev_prep_done[kSets] = {nullptr, nullptr, nullptr}, ev_walk_done[kSets] = {nullptr, nullptr, nullptr};
-  unsigned run_counter = 0;
-  std::string err;
+  std::vector<int> devices;  // HIP ordinal per device slot (a list may name a device twice: two slots on one GPU)
+  std::vector<std::vector<std::unique_ptr<Worker>>> workers;  // [slot][lane]; lanes beyond 0 are created on first use
+  // what a worker is created from
+  std::string substitution, site, clock;
+  int n = 0, P = 0;
+  std::vector<int32_t> patterns;
+  std::vector<double> weights;
+  uint64_t arena_bytes = 0;
   int kernel_choice = BITO_AMD_KERNEL_AUTO;
-  std::string kernel_name = "none";
-
-  // alignment
-  DeviceBuffer<uint8_t> tip_states;
-  DeviceBuffer<double> weights;
-  // resident batch
-  bool resident = false;
-  BatchDims dims{};
-  bool has_rates = false;
-  DeviceBuffer<int32_t> parent_ids, children, sched, children2, sched2, children3, sched3;
-  DeviceBuffer<int32_t> pipe_masks;  // packed tip masks per pattern tile (walk_pipe_kernel): a function of the alignment and the plan
-  long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
-  DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
-  // walk_pipe_kernel in two launches: the trees of the resident batch that keep few enough vectors for four
-  // pattern groups per wave (class A), and the others (class B) -- one tree with few cherries would otherwise
-  // halve the groups of the whole batch
-  std::vector<int32_t> tree_cherries;  // per tree of the resident batch (counted while it is validated)
-  struct PipeSplit {
-    bool built = false, active = false;
-    int count_a = 0, count_b = 0, slots_a = 0;
-    LdsPlan plan_a{}, plan_b{};
-    std::vector<int32_t> order_host;
-  } pipe_split;
-  DeviceBuffer<int32_t> pipe_order;    // class A's tree ids, then class B's
-  DeviceBuffer<int32_t> pipe_masks_a;  // packed tip masks for class A's plan
-  long long pipe_masks_a_key = -1;
-  DeviceBuffer<double> branch_in, rates, params, branch, mats, mats2, mats3, images, arena, part_ll, part_grad,
-      out_grad, out_site, scale_arena, branch2, images2, branch3, images3;
-  // per-tree log-likelihoods: a ring, pass k writes slot k mod kOutRing, so that a consumer on another stream
-  // may still be reading a pass's values while the next passes run (bito_amd_engine_results_async)
-  static constexpr int kOutRing = 4;
-  DeviceBuffer<double> out_ll_ring[kOutRing];
-  unsigned out_slot = 0;
-  hipEvent_t last_pass_done = nullptr;  // recorded behind the last pass enqueued (one of ev_walk_done)
-  double* cur_ll() { return out_ll_ring[out_slot % kOutRing].ptr; }
-  bool site_ready = false;  // out_site holds the site-model gradient of the resident pass
-  double min_branch = 0.0;  // smallest branch length of the resident batch (known for 39 taxa and more only, else 0)
-  DeviceBuffer<TreeModel> model, model2, model3;
-  DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
-  DeviceBuffer<int32_t> gs_model_index;  // [T] first tree with the same parameter row
-  bool gs_index_valid = false;           // the index was built from the parameter rows that are resident now
-  // time-tree transforms (row f2): staging for host inputs, scratch and results
-  DeviceBuffer<int32_t> tt_parents;
-  DeviceBuffer<double> tt_heights, tt_bounds, tt_ratios, tt_in, tt_work, tt_out, tt_aux;
-  // host mirrors for the composed gradients
-  std::vector<double> h_params;
-  // timing
   bool timing = false;
-  std::vector<hipEvent_t> ev_pool;
-  size_t ev_used = 0;
-
-  ~bito_amd_engine() {
-    (void)hipSetDevice(device);
-    for (auto ev : ev_pool) (void)hipEventDestroy(ev);
-    tip_states.Free(); weights.Free(); parent_ids.Free(); children.Free(); branch_in.Free();
-    rates.Free(); params.Free(); branch.Free(); mats.Free(); mats2.Free(); mats3.Free(); images.Free(); arena.Free(); scale_arena.Free(); part_ll.Free();
-    part_grad.Free(); out_grad.Free();
-    for (auto& r : out_ll_ring) r.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
-    tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
-    tt_out.Free(); tt_aux.Free();
-    children2.Free(); sched2.Free(); pipe_masks.Free(); pipe_queue.Free(); pipe_order.Free(); pipe_masks_a.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
-    children3.Free(); sched3.Free(); branch3.Free(); images3.Free(); model3.Free();
-    for (int i = 0; i < kSets; i++) {
-      if (ev_prep_done[i]) (void)hipEventDestroy(ev_prep_done[i]);
-      if (ev_walk_done[i]) (void)hipEventDestroy(ev_walk_done[i]);
-    }
-    if (prep_stream) (void)hipStreamDestroy(prep_stream);
-    if (stream) (void)hipStreamDestroy(stream);
-  }
+  // the resident batch
+  bool resident = false;
+  int rooted = 0, node_count = 0, tree_count = 0;
+  std::vector<Shard> shards;
+  std::string err;
+  // chunking of blocking calls (BITO_AMD_CHUNK_FIRST / _GROWTH / _CAP / _LANES: measurements)
+  int chunk_first = 256, chunk_cap = 2048, max_lanes = 6;
+  double chunk_growth = 2.0;
 };
 
 namespace {
@@ -153,616 +61,229 @@ int Fail(bito_amd_engine* e, int code, const std::string& msg) {
   return code;
 }
 
-#define HIP_TRY(e, call)                                                              \
-  do {                                                                                \
-    hipError_t rc_ = (call);                                                          \
-    if (rc_ != hipSuccess)                                                            \
-      return Fail(e, BITO_AMD_ERR_DEVICE,                                             \
-                  std::string(#call) + " failed: " + hipGetErrorString(rc_));         \
-  } while (0)
+Worker* Primary(const bito_amd_engine* e) { return e->workers[0][0].get(); }
 
-// PhyloModel::OfSpecification + BlockSpecification layout
-// (reference src/phylo_model.cpp:6-24, src/block_specification.cpp:14-53).
-int ParseSpec(const char* sub, const char* site, const char* clock, ModelSpec* m,
-              std::vector<Block>* blocks, std::string* err) {
-  std::memset(m, 0, sizeof(*m));
-  const std::string s(sub ? sub : ""), si(site ? site : ""), cl(clock ? clock : "");
-  if (s == "JC69") m->substitution = kJC69;
-  else if (s == "HKY") m->substitution = kHKY;
-  else if (s == "GTR") m->substitution = kGTR;
-  else if (s == "GY94") m->substitution = kGY94;  // 61-state codon model: defined by this build (bito_amd.h)
-  else { *err = "Substitution model not known: " + s; return BITO_AMD_ERR_BAD_MODEL; }
-  if (si == "constant") {
-    m->weibull = 0;
-    m->category_count = 1;
-  } else if (si.rfind("weibull", 0) == 0) {
-    m->weibull = 1;
-    m->category_count = 4;
-    const auto plus = si.find('+');
-    if (plus != std::string::npos) m->category_count = std::atoi(si.c_str() + plus + 1);
-    if (m->category_count < 1 || m->category_count > 8) {
-      *err = "Site model '" + si + "': the GPU engine supports 1..8 rate categories.";
-      return BITO_AMD_ERR_BAD_MODEL;
-    }
-  } else { *err = "Site model not known: " + si; return BITO_AMD_ERR_BAD_MODEL; }
-  if (cl == "none") m->strict_clock = 0;
-  else if (cl == "strict") m->strict_clock = 1;
-  else { *err = "Clock model not known: " + cl; return BITO_AMD_ERR_BAD_MODEL; }
-  int at = 0;
-  m->freq_start = m->rates_start = m->shape_start = m->clock_start = -1;
-  blocks->clear();
-  if (m->substitution != kJC69) {
-    m->freq_start = at;
-    at += 4;
-    m->rates_start = at;
-    m->rates_len = (m->substitution == kGTR) ? 6 : (m->substitution == kGY94 ? 2 : 1);
-    at += m->rates_len;
-    blocks->push_back({"substitution_model_frequencies", m->freq_start, 4});
-    blocks->push_back({"substitution_model_rates", m->rates_start, m->rates_len});
-    blocks->push_back({"entire_substitution", m->freq_start, 4 + m->rates_len});
+// worker (slot, lane), created on first use
+int GetWorker(bito_amd_engine* e, int slot, int lane, Worker** out) {
+  auto& lanes = e->workers[slot];
+  if ((int)lanes.size() <= lane) lanes.resize(lane + 1);
+  if (!lanes[lane]) {
+    Worker* w = nullptr;
+    std::string msg;
+    const int rc = WorkerCreate(e->devices[slot], e->arena_bytes, e->substitution.c_str(), e->site.c_str(),
+                                e->clock.c_str(), e->n, e->P, e->patterns.data(), e->weights.data(), &w, &msg);
+    if (rc) return Fail(e, rc, msg);
+    WorkerSetKernel(w, e->kernel_choice);
+    if (e->timing) WorkerKernelTiming(w, 1);
+    lanes[lane].reset(w);
   }
-  if (m->weibull) {
-    m->shape_start = at++;
-    blocks->push_back({"Weibull_shape", m->shape_start, 1});
-    blocks->push_back({"entire_site", m->shape_start, 1});
-  }
-  if (m->strict_clock) {
-    m->clock_start = at++;
-    blocks->push_back({"clock_rate", m->clock_start, 1});
-    blocks->push_back({"entire_clock", m->clock_start, 1});
-  }
-  m->param_count = at;
-  m->state_count = (m->substitution == kGY94) ? 61 : 4;
-  for (int i = 0; i < m->category_count && i < 16; i++)
-    m->weibull_log_l[i] = std::log(-std::log(1.0 - (2.0 * i + 1.0) / (2.0 * m->category_count)));
-  blocks->push_back({"entire", 0, at});
+  *out = lanes[lane].get();
   return BITO_AMD_OK;
 }
 
-// GTRModel/HKYModel::SetParameters checks (reference src/substitution_model.cpp:33-47,120-139).
-int ValidateParams(bito_amd_engine* e, int tree_count, const double* params) {
-  const ModelSpec& m = e->spec;
-  if (m.substitution == kJC69) return BITO_AMD_OK;
-  const char* name = m.substitution == kGTR ? "GTR" : (m.substitution == kGY94 ? "GY94" : "HKY");
-  for (int t = 0; t < tree_count; t++) {
-    const double* row = params + (size_t)t * m.param_count;
-    const double* f = row + m.freq_start;
-    if (std::fabs(f[0] + f[1] + f[2] + f[3] - 1.) >= 0.001) {
-      char buf[256];
-      std::snprintf(buf, sizeof(buf),
-                    "%s frequencies do not sum to 1 +/- 0.001! frequency vector: (%g,%g,%g,%g) [tree %d]",
-                    name, f[0], f[1], f[2], f[3], t);
-      return Fail(e, BITO_AMD_ERR_BAD_PARAMS, buf);
+Worker* ShardWorker(const bito_amd_engine* e, const Shard& s) { return e->workers[s.slot][s.lane].get(); }
+
+int Propagate(bito_amd_engine* e, Worker* w, int rc) {
+  if (rc) e->err = WorkerLastError(w);
+  return rc;
+}
+
+// Chunk sizes for `count` trees on one device.  The first chunk is small, so that the device starts early; the
+// following ones grow, so that the host -- which validates and stages about five times faster than the device
+// traverses -- stays a chunk ahead and the set-up kernels of chunk k+1 are in the queue before the traversal of
+// chunk k needs every CU.  Heavy trees (large n x P x C, or the 61-state model) go as one chunk: their traversal
+// takes so long per tree that there is nothing to hide, and one launch fills the PLV arena best.
+std::vector<int> PlanChunks(const bito_amd_engine* e, int count, bool single) {
+  std::vector<int> sizes;
+  const Worker* w = Primary(e);
+  const size_t work = (size_t)e->n * e->P * w->spec.category_count;
+  if (single || w->spec.state_count != 4 || work > ((size_t)1 << 20) || count < 2 * e->chunk_first) {
+    sizes.push_back(count);
+    return sizes;
+  }
+  int remaining = count;
+  double c = e->chunk_first;
+  while (remaining > 0) {
+    int take = std::min<int>((int)c, remaining);
+    if ((int)sizes.size() == e->max_lanes - 1 || remaining - take < take / 2) take = remaining;
+    sizes.push_back(take);
+    remaining -= take;
+    c = std::min<double>(c * e->chunk_growth, e->chunk_cap);
+  }
+  return sizes;
+}
+
+// The blocks of a collection: contiguous per device slot, then chunks per slot; listed in the order they are
+// issued (chunk 0 of every slot, then chunk 1 of every slot, ...), so that every device starts early.
+int PlanShards(bito_amd_engine* e, int tree_count, bool single, std::vector<Shard>* out) {
+  out->clear();
+  const int D = single ? 1 : (int)e->devices.size();
+  std::vector<std::vector<Shard>> per_slot(D);
+  size_t most = 0;
+  for (int s = 0; s < D; s++) {
+    const int t0 = (int)((long long)tree_count * s / D), t1 = (int)((long long)tree_count * (s + 1) / D);
+    if (t1 == t0) continue;
+    int at = t0, lane = 0;
+    for (int size : PlanChunks(e, t1 - t0, single)) {
+      per_slot[s].push_back({s, lane++, at, size});
+      at += size;
     }
-    if (m.substitution == kGY94) {
-      const double* r = row + m.rates_start;
-      if (!(r[0] > 0.) || !(r[1] > 0.)) {
-        char buf[256];
-        std::snprintf(buf, sizeof(buf), "GY94 kappa and omega must be positive: (%g,%g) [tree %d]", r[0], r[1], t);
-        return Fail(e, BITO_AMD_ERR_BAD_PARAMS, buf);
-      }
-    }
-    if (m.substitution == kGTR) {
-      const double* r = row + m.rates_start;
-      double sum = 0;
-      for (int i = 0; i < 6; i++) sum += r[i];
-      if (std::fabs(sum - 1.) >= 0.001) {
-        char buf[256];
-        std::snprintf(buf, sizeof(buf),
-                      "GTR rates do not sum to 1 +/- 0.001! rate vector: (%g,%g,%g,%g,%g,%g) [tree %d]",
-                      r[0], r[1], r[2], r[3], r[4], r[5], t);
-        return Fail(e, BITO_AMD_ERR_BAD_PARAMS, buf);
-      }
-    }
+    most = std::max(most, per_slot[s].size());
+  }
+  for (size_t k = 0; k < most; k++)
+    for (int s = 0; s < D; s++)
+      if (k < per_slot[s].size()) out->push_back(per_slot[s][k]);
+  for (const Shard& s : *out) {
+    Worker* w = nullptr;
+    if (int rc = GetWorker(e, s.slot, s.lane, &w)) return rc;
   }
   return BITO_AMD_OK;
 }
 
-// The parent-id vector must describe a bito topology: leaves 0..n-1, internal ids
-// in post-order (every parent id larger than its children), bifurcating except for
-// the trifurcating root of an unrooted tree (reference src/node.cpp:383-402,511-551;
-// src/unrooted_tree.cpp:46-52).
-int ValidateTrees(bito_amd_engine* e, int tree_count, int rooted, int node_count,
-                  const int32_t* parent_ids, int* min_cherries = nullptr, std::vector<int32_t>* cherries_of = nullptr) {
-  const int n = e->n, M = node_count;
-  if (M != (rooted ? 2 * n - 1 : 2 * n - 2)) {
-    char buf[200];
-    std::snprintf(buf, sizeof(buf), "node_count %d does not match %d taxa for a%s tree (expected %d)",
-                  M, n, rooted ? " rooted" : "n unrooted", rooted ? 2 * n - 1 : 2 * n - 2);
-    return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
-  }
-  if (M < 3) return Fail(e, BITO_AMD_ERR_BAD_TREE, "tree too small");
-  std::vector<int> count(M), tip_children(M);
-  int fewest = M;
-  for (int t = 0; t < tree_count; t++) {
-    const int32_t* par = parent_ids + (size_t)t * (M - 1);
-    std::fill(count.begin(), count.end(), 0);
-    std::fill(tip_children.begin(), tip_children.end(), 0);
-    for (int child = 0; child < M - 1; child++) {
-      const int p = par[child];
-      if (p < n || p >= M || p <= child) {
-        char buf[200];
-        std::snprintf(buf, sizeof(buf), "tree %d: parent id %d of node %d is not a valid internal id",
-                      t, p, child);
-        return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
-      }
-      count[p]++;
-      if (child < n) tip_children[p]++;
-    }
-    // cherries of the (detrifurcated) tree: non-root internal nodes over two tips; the node that
-    // re-uses an unrooted tree's old root id joins children 1 and 2 of the trifurcation
-    int cherries = 0;
-    for (int i = n; i < M - 1; i++) cherries += tip_children[i] == 2;
-    if (!rooted) cherries += tip_children[M - 1] == 3;
-    fewest = std::min(fewest, cherries);
-    if (cherries_of) (*cherries_of)[t] = cherries;
-    for (int i = n; i < M; i++) {
-      const int want = (!rooted && i == M - 1) ? 3 : 2;
-      if (count[i] != want) {
-        char buf[200];
-        std::snprintf(buf, sizeof(buf), "tree %d: node %d has %d children, expected %d", t, i,
-                      count[i], want);
-        return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
-      }
-    }
-  }
-  if (min_cherries) *min_cherries = fewest;
-  return BITO_AMD_OK;
+void SyncShards(bito_amd_engine* e, size_t issued) {
+  for (size_t k = 0; k < issued && k < e->shards.size(); k++) (void)WorkerSync(ShardWorker(e, e->shards[k]));
 }
 
-// General-state path: trees whose parameter rows are bit-identical share one model record (rate
-// matrix, eigensystem); index[t] = first tree carrying t's row.
-int UploadModelIndex(bito_amd_engine* e, int tree_count, const double* params) {
-  const int pc = e->spec.param_count;
-  std::vector<int32_t> index(tree_count);
-  std::unordered_map<std::string, int32_t> first;
-  for (int t = 0; t < tree_count; t++) {
-    std::string key(reinterpret_cast<const char*>(params + (size_t)t * pc), pc * sizeof(double));
-    index[t] = first.emplace(std::move(key), t).first->second;
-  }
-  HIP_TRY(e, e->gs_model_index.Reserve(tree_count));
-  HIP_TRY(e, hipMemcpyAsync(e->gs_model_index.ptr, index.data(), tree_count * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  e->gs_index_valid = true;
-  return BITO_AMD_OK;
-}
-
-// smallest effective branch length of a batch in wire format ([T][M], the last column is the root's)
-double MinBranchLength(const double* branch_lengths, const double* rates, size_t T, size_t M) {
-  double m = std::numeric_limits<double>::infinity();
-  for (size_t t = 0; t < T; t++)
-    for (size_t i = 0; i + 1 < M; i++) {
-      const double bl = branch_lengths[t * M + i] * (rates ? rates[t * (M - 1) + i] : 1.0);
-      m = bl < m ? bl : m;
-    }
-  return m;
-}
-
-DeviceBatch MakeBatch(bito_amd_engine* e, int set = 0) {
-  DeviceBatch b{};
-  b.parent_ids = e->parent_ids.ptr;
-  b.branch_in = e->branch_in.ptr;
-  b.rates = e->has_rates ? e->rates.ptr : nullptr;
-  b.params = e->params.ptr;
-  b.tip_states = e->tip_states.ptr;
-  b.weights = e->weights.ptr;
-  b.children = (set == 0 ? e->children : set == 1 ? e->children2 : e->children3).ptr;
-  b.branch = (set == 0 ? e->branch : set == 1 ? e->branch2 : e->branch3).ptr;
-  b.model = (set == 0 ? e->model : set == 1 ? e->model2 : e->model3).ptr;
-  b.mats = (set == 0 ? e->mats : set == 1 ? e->mats2 : e->mats3).ptr;
-  b.images = (set == 0 ? e->images : set == 1 ? e->images2 : e->images3).ptr;
-  b.sched = (set == 0 ? e->sched : set == 1 ? e->sched2 : e->sched3).ptr;
-  b.pipe_masks = reinterpret_cast<const uint32_t*>(e->pipe_masks.ptr);
-  b.pipe_queue = e->pipe_queue.ptr;
-  b.arena = e->arena.ptr;
-  b.scale_arena = e->scale_arena.ptr;
-  b.part_ll = e->part_ll.ptr;
-  b.part_grad = e->part_grad.ptr;
-  b.out_ll = e->cur_ll();
-  b.out_grad = e->out_grad.ptr;
-  b.out_site = e->out_site.ptr;
-  return b;
-}
-
-hipEvent_t NextEvent(bito_amd_engine* e) {
-  if (e->ev_used == e->ev_pool.size()) {
-    hipEvent_t ev;
-    (void)hipEventCreate(&ev);
-    e->ev_pool.push_back(ev);
-  }
-  return e->ev_pool[e->ev_used++];
-}
-
-// General-state-count path (gs_kernels.hip): the codon model, or a 4-state model when the
-// general kernels are selected explicitly.  Trees are processed in chunks sized so that a chunk's
-// matrix records and PLV arena fit the arena budget.
-int RunResidentGeneral(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_mode) {
-  HIP_TRY(e, hipSetDevice(e->device));
-  e->site_ready = false;
-  const BatchDims& d = e->dims;
-  const int T = d.tree_count, S = e->spec.state_count;
-  if (!e->gs_index_valid) {
-    // The batch (or its parameter rows) arrived while another kernel family was selected, so no index was
-    // built for it: rebuild from the resident rows rather than reuse one that belongs to an earlier batch.
-    const int pc = e->spec.param_count;
-    std::vector<double> rows((size_t)T * std::max(pc, 1), 0.0);
-    if (pc > 0) {
-      HIP_TRY(e, hipStreamSynchronize(e->stream));
-      HIP_TRY(e, hipMemcpy(rows.data(), e->params.ptr, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
-    }
-    static const double none = 0.0;
-    if (int rc = UploadModelIndex(e, T, pc > 0 ? rows.data() : &none)) return rc;
-  }
-  const int tiles = GsTiles(d.pattern_count);
-  const size_t img_per_tree = GsImageDoublesPerTree(d), arena_per_tree = GsArenaDoublesPerTree(d, tiles, want_gradient);
-  HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
-  if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * tiles * d.node_count));
-  // (Not pipelined like the LDS path: the traversal fills the register file -- two 256-VGPR waves per
-  // SIMD -- so set-up kernels of the next pass cannot co-reside with it; measured +2 % for twice the
-  // matrix records.)
-  // serial on `stream`, buffer set 0, trees in chunks sized to the budget
-  HIP_TRY(e, hipStreamSynchronize(e->prep_stream));
-  const size_t per_tree = (img_per_tree + arena_per_tree) * sizeof(double);
-  size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
-  chunk = std::min<size_t>(chunk, 65535);
-  HIP_TRY(e, e->gs_model.Reserve((size_t)T * kGsModelStride));
-  HIP_TRY(e, e->images.Reserve(chunk * img_per_tree));
-  HIP_TRY(e, e->arena.Reserve(chunk * arena_per_tree));
-  if (want_gradient && rescaling) HIP_TRY(e, e->scale_arena.Reserve(chunk * (size_t)(d.taxon_count - 1) * tiles * 16));
-  HIP_TRY(e, e->sched.Reserve((size_t)T * GsScheduleStride(d)));
-  const DeviceBatch b = MakeBatch(e);
-  LaunchGsSetup(d, e->spec, b, e->gs_model_index.ptr, e->gs_model.ptr, e->stream);
-  LaunchGsSchedule(d, b, e->stream);
-  for (int t0 = 0; t0 < T; t0 += (int)chunk) {
-    const int ct = std::min<int>((int)chunk, T - t0);
-    LaunchGsMatrices(d, S, t0, ct, e->branch.ptr, e->gs_model_index.ptr, e->gs_model.ptr, e->images.ptr, want_gradient, deriv_mode, e->stream);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (e->timing) {
-      ev0 = NextEvent(e);
-      ev1 = NextEvent(e);
-      HIP_TRY(e, hipEventRecord(ev0, e->stream));
-    }
-    LaunchGsWalk(d, S, b, e->gs_model_index.ptr, e->gs_model.ptr, t0, ct, tiles, want_gradient, rescaling, deriv_mode, e->stream);
-    if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
-  }
-  e->kernel_name = "gs_walk_kernel";
-  LaunchReduce(d, b, tiles, want_gradient, e->stream);
-  HIP_TRY(e, hipEventRecord(e->ev_walk_done[0], e->stream));
-  e->last_pass_done = e->ev_walk_done[0];
-  HIP_TRY(e, hipGetLastError());
-  return BITO_AMD_OK;
-}
-
-int RunResident(bito_amd_engine* e, int want_gradient, int rescaling, int deriv_mode = 0, int want_site = 0) {
-  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
-  HIP_TRY(e, hipSetDevice(e->device));
-  const BatchDims& d = e->dims;
-  const int T = d.tree_count;
-  const size_t NB = (size_t)d.node_count - 1;
-  e->out_slot++;  // this pass's log-likelihoods go to the next buffer of the ring
-  if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL)
-    return RunResidentGeneral(e, want_gradient, rescaling, deriv_mode);
-  // Kernel choice: the LDS-resident MFMA walk when the tree fits in LDS and no rescaling
-  // is requested, otherwise the HBM-arena walk.
-  LdsPlan plan = PlanLds(d);
-  const LdsPlan pplan = PlanPipe(d);
-  const TreePlan tplan = PlanTree(d);
-  bool use_tree = tplan.waves > 0 && !rescaling;
-  bool use_lds = plan.groups > 0 && !rescaling;
-  bool use_pipe = false;
-  // (39 to 48 taxa: walk_pipe_kernel's one-image-per-branch form holds to rounding only while no transition
-  // matrix entry is all rounding error, i.e. no branch is shorter than 9e-7; see walk_pipe.hip)
-  static const double min_branch_needed = [] {  // (BITO_AMD_PIPE_MIN_BRANCH: measurements of that bound)
-    const char* v = std::getenv("BITO_AMD_PIPE_MIN_BRANCH");
-    return v ? std::atof(v) : kPipeReversibleMinBranch;
-  }();
-  const bool pipe_branches_ok = d.taxon_count <= kPipeExactTaxa || e->min_branch >= min_branch_needed;
-  switch (e->kernel_choice) {
-    case BITO_AMD_KERNEL_HBM_ARENA: use_tree = use_lds = false; break;
-    case BITO_AMD_KERNEL_LDS_PIPE:
-      use_tree = false;
-      use_pipe = pplan.groups > 0 && !rescaling && pipe_branches_ok;
-      if (!use_pipe) return Fail(e, BITO_AMD_ERR_STATE, "the pipelined LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, a tree whose stored vectors fit in 160 KB of LDS, and from 39 taxa on branch lengths of 9e-7 and more)");
-      break;
-    case BITO_AMD_KERNEL_LDS:
-      use_tree = false;
-      if (!use_lds) return Fail(e, BITO_AMD_ERR_STATE, "the LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, and a tree whose PLVs fit in 160 KB of LDS)");
-      break;
-    case BITO_AMD_KERNEL_LDS_TREE:
-      if (!use_tree) return Fail(e, BITO_AMD_ERR_STATE, "the LDS tree kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, and a tree whose images + PLVs fit in 160 KB of LDS)");
-      break;
-    default:
-      // AUTO: the hand-scheduled LDS walk where it applies (up to 38 taxa: every branch's images in the AGPR
-      // file), measured 1.44 ms against walk_lds_kernel's 2.00 ms per 1600 config-3 trees
-      use_pipe = pplan.groups > 0 && !rescaling && pipe_branches_ok;
-      // ... except a log-likelihood-only pass with one rate category: walk_hbm_kernel never stores a partial there
-      // (each node's is forwarded in registers to its parent) and runs 0.17 ms per 1600 DS1 JC69 trees
-      // against 0.32 ms (walk_pipe_kernel) and 0.37 ms (walk_lds_kernel); scripts/gpu_config2.py
-      if (!want_gradient && d.category_count == 1) use_pipe = false;
-      // Everything else goes to the HBM-arena walk since round 2: with one wave per rate category
-      // (walk_hbm_cat_kernel) it beats walk_lds_kernel wherever walk_pipe_kernel does not apply -- 1600 trees of
-      // 41 / 50 / 64 taxa, 1000 patterns, four categories: 3.75 / 4.50 / 5.85 ms against 4.79 / 5.72 / 11.8 ms
-      // (scripts/gpu_midsize.py) -- so walk_lds_kernel and walk_tree_kernel run only when asked for.
-      use_lds = use_tree = false;
-      break;
-  }
-  // Measured on config 3 (profiles/): walk_lds_kernel 2.1 ms, walk_tree_kernel 3.8 ms per 1600
-  // trees -- the single-wave software pipeline beats two latency-bound waves per SIMD, so the
-  // tree-resident variant is only used when forced or when walk_lds cannot run.
-  if (e->kernel_choice != BITO_AMD_KERNEL_LDS_TREE && use_lds) use_tree = false;
-  if (use_tree) use_lds = false;
-  if (use_pipe) {  // same launch sequence as the LDS kernel, with its own images, tables and plan
-    use_lds = true;
-    plan = pplan;
-  }
-  // walk_pipe_kernel: when the batch as a whole cannot have four pattern groups per wave (its tree with the
-  // fewest cherries keeps too many vectors) but many of its trees could, they are walked in a launch of their own
-  bito_amd_engine::PipeSplit& split = e->pipe_split;
-  if (use_pipe && !split.built) {
-    split.built = true;
-    split.active = false;
-    const int slots4 = PipeMaxSlots(d, 4);
-    static const bool no_split = std::getenv("BITO_AMD_PIPE_NO_SPLIT") != nullptr;
-    if (!no_split && T >= 32 && plan.groups < 4 && slots4 > 0 && (int)e->tree_cherries.size() == T) {
-      std::vector<int32_t> a, bb;
-      int need_a = 1, need_b = 1;
-      for (int t = 0; t < T; t++) {
-        const int need = PipeSlotsOfTree(d, e->tree_cherries[t]);
-        (need <= slots4 ? a : bb).push_back(t);
-        (need <= slots4 ? need_a : need_b) = std::max(need <= slots4 ? need_a : need_b, need);
-      }
-      if (!bb.empty() && (int)a.size() * 4 >= T) {
-        const LdsPlan pa = PlanPipeClass(d, (int)a.size(), need_a, 4), pb = PlanPipeClass(d, (int)bb.size(), need_b, 0);
-        if (pa.groups == 4 && pb.groups > 0) {
-          split.active = true;
-          split.count_a = (int)a.size();
-          split.count_b = (int)bb.size();
-          split.slots_a = slots4;
-          split.plan_a = pa;
-          split.plan_b = pb;
-          split.order_host = a;
-          split.order_host.insert(split.order_host.end(), bb.begin(), bb.end());
-          HIP_TRY(e, hipStreamSynchronize(e->stream));
-          HIP_TRY(e, e->pipe_order.Reserve((size_t)T));
-          HIP_TRY(e, hipMemcpy(e->pipe_order.ptr, split.order_host.data(), (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
-        }
-      }
-    }
-  }
-  const bool two_classes = use_pipe && split.active;
-  if (two_classes) plan = split.plan_b;  // (class B's plan is the one the shared buffers and tables are sized by)
-  const int tiles = use_tree ? tplan.tiles : (use_lds ? std::max(plan.tiles, two_classes ? split.plan_a.tiles : 0) : HbmWalkTiles(d));
-  HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
-  // partial gradient rows per tree: one per tile (LDS kernels), per run of tiles (pipelined LDS kernel), per wave (HBM kernel)
-  const int pipe_rows = two_classes ? std::max(split.plan_a.grad_rows, split.plan_b.grad_rows) : plan.grad_rows;
-  const int grad_rows = (use_pipe && pipe_rows > 0) ? pipe_rows : (use_tree || use_lds) ? tiles : HbmWalkGradRows(d);
-  if (want_gradient) HIP_TRY(e, e->part_grad.Reserve((size_t)T * grad_rows * d.node_count));
-  if (use_tree || use_lds) {
-    // pipelined: this pass's set-up goes to prep_stream and into buffer set (run_counter mod kSets)
-    const int set = (int)(e->run_counter++ % (unsigned)bito_amd_engine::kSets);
-    HIP_TRY(e, (set == 0 ? e->images : set == 1 ? e->images2 : e->images3).Reserve((size_t)T * NB * kImgStride));
-    if (use_lds)
-      HIP_TRY(e, (set == 0 ? e->sched : set == 1 ? e->sched2 : e->sched3).Reserve(use_pipe ? PipeScheduleInts(d) : LdsScheduleInts(d)));
-    bool build_masks = false;
-    if (use_pipe && e->pipe_queue.capacity == 0) {
-      HIP_TRY(e, e->pipe_queue.Reserve(2));
-      HIP_TRY(e, hipMemsetAsync(e->pipe_queue.ptr, 0, 2 * sizeof(int32_t), e->stream));
-    }
-    if (use_pipe) {  // the tile masks depend on the alignment and the plan only: built once
-      const long long key = (long long)plan.groups | ((long long)plan.tiles << 8);
-      if (e->pipe_masks_key != key) {
-        HIP_TRY(e, hipStreamSynchronize(e->stream));  // (a traversal may still be reading the old ones)
-        HIP_TRY(e, e->pipe_masks.Reserve(PipeMaskInts(d, plan)));
-        e->pipe_masks_key = key;
-        build_masks = true;
-      }
-    }
-    bool build_masks_a = false;
-    if (two_classes) {
-      const long long key = (long long)split.plan_a.groups | ((long long)split.plan_a.tiles << 8);
-      if (e->pipe_masks_a_key != key) {
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        HIP_TRY(e, e->pipe_masks_a.Reserve(PipeMaskInts(d, split.plan_a)));
-        e->pipe_masks_a_key = key;
-        build_masks_a = true;
-      }
-    }
-    const DeviceBatch b = MakeBatch(e, set);
-    hipStream_t prep = e->serial_setup ? e->stream : e->prep_stream;
-    const bool bare = e->serial_setup == 2 && e->run_counter > (unsigned)bito_amd_engine::kSets;
-    if (!bare) {
-      HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_walk_done[set], 0));
-      // (packed into few workgroups when a traversal is still running beside it; spread out -- 30 us sooner --
-      // when the engine is idle, as it is for a caller that waits for every pass)
-      const bool busy = !e->serial_setup && e->last_pass_done != nullptr && hipEventQuery(e->last_pass_done) == hipErrorNotReady;
-      LaunchSetup(d, e->spec, b, want_gradient, prep, /*beside_traversal=*/busy);
-      if (use_pipe) {
-        LaunchPipePrepare(d, b, plan, prep, busy, two_classes ? split.slots_a : 0);
-        if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);
-        if (build_masks_a) LaunchPipeMasks(d, b, split.plan_a, reinterpret_cast<uint32_t*>(e->pipe_masks_a.ptr), prep);
-      } else {
-        LaunchMatrixImages(d, b, want_gradient, deriv_mode, prep);
-        if (use_lds) LaunchLdsSchedule(d, b, plan, prep);
-      }
-      HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
-      HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_prep_done[set], 0));
-    }
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (e->timing) {
-      ev0 = NextEvent(e);
-      ev1 = NextEvent(e);
-      HIP_TRY(e, hipEventRecord(ev0, e->stream));
-    }
-    if (use_tree) LaunchWalkTree(d, b, tplan, want_gradient, e->stream);
-    else if (use_pipe) {
-      const int site = want_site && want_gradient && deriv_mode == 0;
-      if (two_classes) {
-        LaunchWalkPipe(d, b, split.plan_a, want_gradient, site, deriv_mode, e->stream,
-                       PipeClass{split.count_a, e->pipe_order.ptr, reinterpret_cast<const uint32_t*>(e->pipe_masks_a.ptr), grad_rows});
-        LaunchWalkPipe(d, b, split.plan_b, want_gradient, site, deriv_mode, e->stream,
-                       PipeClass{split.count_b, e->pipe_order.ptr + split.count_a, b.pipe_masks, grad_rows});
-      } else {
-        LaunchWalkPipe(d, b, plan, want_gradient, site, deriv_mode, e->stream, PipeClass{T, nullptr, b.pipe_masks, grad_rows});
-      }
-    }
-    else LaunchWalkLds(d, b, plan, want_gradient, want_site && want_gradient && deriv_mode == 0, e->stream);
-    if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
-    e->kernel_name = use_tree ? "walk_tree_kernel" : (use_pipe ? "walk_pipe_kernel" : "walk_lds_kernel");
-    e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
-    // (walk_pipe_kernel's partial log-likelihoods are per run of tiles as well)
-    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, e->stream, grad_rows);
-    if (!bare) HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
-    e->last_pass_done = bare ? nullptr : e->ev_walk_done[set];
-    HIP_TRY(e, hipGetLastError());
+// The blocking evaluation behind bito_amd_engine_log_likelihoods / _gradients: stage, run and fetch every chunk
+// without waiting, copy results out as they arrive.
+int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
+             const double* branch_lengths, const double* rates, const double* params, int rescaling,
+             int want_gradient, int want_site, double* out_ll, double* out_grad, double* out_site, bool single) {
+  e->resident = false;
+  if (tree_count < 1 || !parent_ids || !branch_lengths)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "need at least one tree and non-NULL parent_ids / branch_lengths");
+  const Worker* w0 = Primary(e);
+  const size_t pc = (size_t)w0->spec.param_count, M = (size_t)node_count, N = 2 * (size_t)e->n - 1;
+  if (pc > 0 && !params) return Fail(e, BITO_AMD_ERR_BAD_ARG, "params is NULL but the model has parameters");
+  if (int rc = PlanShards(e, tree_count, single, &e->shards)) return rc;
+  const bool has_rates = rooted && rates != nullptr;
+  size_t drained = 0;
+  auto drain = [&](size_t k) -> int {
+    const Shard& s = e->shards[k];
+    Worker* w = ShardWorker(e, s);
+    const double *ll = nullptr, *grad = nullptr, *site = nullptr;
+    if (int rc = Propagate(e, w, WorkerResults(w, &ll, &grad, &site))) return rc;
+    std::memcpy(out_ll + s.t0, ll, (size_t)s.count * sizeof(double));
+    if (want_gradient && out_grad) std::memcpy(out_grad + (size_t)s.t0 * N, grad, (size_t)s.count * N * sizeof(double));
+    if (want_site && out_site && w->site_ready) std::memcpy(out_site + s.t0, site, (size_t)s.count * sizeof(double));
     return BITO_AMD_OK;
-  }
-  // HBM-arena walk: the same set-up pipeline (tree set-up and transition matrices of this pass on prep_stream,
-  // into the next buffer set, while earlier passes' traversals run)
-  e->site_ready = false;
-  const int set = (int)(e->run_counter++ % (unsigned)bito_amd_engine::kSets);
-  // scratch sized for this run
-  HIP_TRY(e, (set == 0 ? e->mats : set == 1 ? e->mats2 : e->mats3).Reserve((size_t)T * NB * d.category_count * kMatStride));
-  const size_t per_tree = HbmArenaBytesPerTree(d);
-  size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
-  // grid.y limit
-  chunk = std::min<size_t>(chunk, 65535);
-  HIP_TRY(e, e->arena.Reserve(chunk * per_tree / sizeof(double)));
-  if (want_gradient && rescaling)
-    HIP_TRY(e, e->scale_arena.Reserve(chunk * (size_t)(d.taxon_count - 1) * d.pattern_stride));
-  const DeviceBatch b = MakeBatch(e, set);
-  {
-    hipStream_t prep = e->serial_setup ? e->stream : e->prep_stream;
-    HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_walk_done[set], 0));
-    LaunchSetup(d, e->spec, b, want_gradient, prep);
-    LaunchMatrices(d, b, want_gradient, deriv_mode, prep);
-    HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
-    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_prep_done[set], 0));
-  }
-  for (int t0 = 0; t0 < T; t0 += (int)chunk) {
-    const int ct = std::min<int>((int)chunk, T - t0);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (e->timing) {
-      ev0 = NextEvent(e);
-      ev1 = NextEvent(e);
-      HIP_TRY(e, hipEventRecord(ev0, e->stream));
+  };
+  std::vector<char> slot_busy(e->devices.size(), 0);
+  for (size_t k = 0; k < e->shards.size(); k++) {
+    const Shard& s = e->shards[k];
+    Worker* w = ShardWorker(e, s);
+    w->one_shot = slot_busy[s.slot] ? 2 : 1;
+    w->id_offset = s.t0;
+    slot_busy[s.slot] = 1;
+    int rc = WorkerStage(w, s.count, rooted, node_count, parent_ids + (size_t)s.t0 * (M - 1),
+                         branch_lengths + (size_t)s.t0 * M, has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr,
+                         pc > 0 ? params + (size_t)s.t0 * pc : nullptr, /*wait=*/0);
+    if (!rc) rc = WorkerRunPass(w, want_gradient, rescaling, 0, want_site);
+    if (!rc) rc = WorkerFetchResults(w, want_gradient, want_site);
+    if (rc) {
+      Propagate(e, w, rc);
+      SyncShards(e, k + 1);
+      return rc;
     }
-    LaunchWalkHbm(d, b, t0, ct, want_gradient, rescaling, e->stream, deriv_mode);
-    if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
+    // results that have arrived meanwhile (in order: the chunks finish in the order they were issued, near enough)
+    while (drained < k && hipEventQuery(ShardWorker(e, e->shards[drained])->ev_results) == hipSuccess)
+      if (int rc2 = drain(drained++)) {
+        SyncShards(e, k + 1);
+        return rc2;
+      }
   }
-  e->kernel_name = WalkHbmKernelName(d.category_count, want_gradient, rescaling);
-  LaunchReduce(d, b, tiles, want_gradient, e->stream, grad_rows);
-  if (want_site && want_gradient && deriv_mode == 0 && d.category_count > 1 && HbmCatKernelApplies(d)) {
-    // (walk_hbm_cat_kernel's gradient rows are per rate category: the site-model gradient needs no second pass)
-    LaunchSiteFromCategoryRows(d, b, grad_rows, e->stream);
-    e->site_ready = true;
+  for (; drained < e->shards.size(); drained++)
+    if (int rc = drain(drained)) {
+      SyncShards(e, e->shards.size());
+      return rc;
+    }
+  e->resident = true;
+  e->rooted = rooted;
+  e->node_count = node_count;
+  e->tree_count = tree_count;
+  if (want_site && out_site) {
+    // kernels that do not produce the site-model gradient in the main pass: a second traversal per block
+    for (const Shard& s : e->shards) {
+      Worker* w = ShardWorker(e, s);
+      if (w->site_ready) continue;
+      const int rc = WorkerSiteGradientSecondPass(w, rooted, node_count, branch_lengths + (size_t)s.t0 * M,
+                                                  has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr, rescaling,
+                                                  out_site + s.t0);
+      if (rc) return Propagate(e, w, rc);
+    }
   }
-  HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
-  e->last_pass_done = e->ev_walk_done[set];
-  HIP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
+}
+
+int LogLikelihoods(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t node_count,
+                   const int32_t* parent_ids, const double* branch_lengths, const double* rates, const double* params,
+                   int32_t rescaling, double* out, bool single) {
+  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
+  // an empty collection is not an error: FatBeagleParallelize over no trees returns an empty vector
+  // (reference src/fat_beagle.hpp:160-181)
+  if (tree_count == 0) return BITO_AMD_OK;
+  return Evaluate(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, rescaling != 0, 0, 0,
+                  out, nullptr, nullptr, single);
+}
+
+// the calls that work on ONE worker's resident batch (time trees, stream hand-off, event timing)
+int SingleShard(bito_amd_engine* e, Worker** w) {
+  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
+  if (e->shards.size() != 1)
+    return Fail(e, BITO_AMD_ERR_STATE, "the resident batch is spread over several devices or chunks: this call needs it on one (a single-device engine and bito_amd_engine_upload)");
+  *w = ShardWorker(e, e->shards[0]);
+  return BITO_AMD_OK;
+}
+
+void SetSingleResident(bito_amd_engine* e, int rooted, int node_count, int tree_count) {
+  e->shards.assign(1, Shard{0, 0, 0, tree_count});
+  e->resident = true;
+  e->rooted = rooted;
+  e->node_count = node_count;
+  e->tree_count = tree_count;
 }
 
 }  // namespace
 
 extern "C" {
 
-const char* bito_amd_version(void) {
-  static std::string v;
-  if (v.empty()) {
-    v = "bito_amd 0.1 (gfx950)";
-    int count = 0;
-    if (hipGetDeviceCount(&count) == hipSuccess && count > 0) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, 0) == hipSuccess) {
-        char buf[256];
-        std::snprintf(buf, sizeof(buf), "bito_amd 0.1 %s %dCU %.0fGB", prop.gcnArchName,
-                      prop.multiProcessorCount, prop.totalGlobalMem / 1e9);
-        v = buf;
-      }
-    }
-  }
-  return v.c_str();
-}
-
-int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substitution,
-                           const char* site, const char* clock, int32_t taxon_count,
-                           int32_t pattern_count, const int32_t* patterns, const double* weights,
-                           bito_amd_engine** out, char* err, size_t err_len) {
+int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substitution, const char* site,
+                           const char* clock, int32_t taxon_count, int32_t pattern_count, const int32_t* patterns,
+                           const double* weights, bito_amd_engine** out, char* err, size_t err_len) {
   auto report = [&](int code, const std::string& msg) {
     if (err && err_len) std::snprintf(err, err_len, "%s", msg.c_str());
     return code;
   };
   if (!out) return report(BITO_AMD_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
-  auto e = new bito_amd_engine();
-  std::string msg;
-  int rc = ParseSpec(substitution, site, clock, &e->spec, &e->blocks, &msg);
-  if (rc) { delete e; return report(rc, msg); }
-  if (taxon_count < 2 || pattern_count < 1 || !patterns || !weights) {
-    delete e;
+  if (taxon_count < 2 || pattern_count < 1 || !patterns || !weights)
     return report(BITO_AMD_ERR_BAD_ARG, "need at least 2 taxa, 1 site pattern and non-NULL arrays");
-  }
-  e->device = spec ? spec->device_id : 0;
-  int count = 0;
-  hipError_t hrc = hipGetDeviceCount(&count);
-  if (hrc != hipSuccess || count <= 0) {
-    delete e;
-    return report(BITO_AMD_ERR_DEVICE, "no HIP device available: the bito_amd engine needs an MI355X (gfx950); there is no CPU fallback");
-  }
-  if (e->device < 0 || e->device >= count) {
-    delete e;
-    return report(BITO_AMD_ERR_DEVICE, "device_id out of range");
-  }
-  auto dev_fail = [&](const char* what, hipError_t c) {
-    std::string m = std::string(what) + " failed: " + hipGetErrorString(c);
-    delete e;
-    return report(BITO_AMD_ERR_DEVICE, m);
-  };
-  if ((hrc = hipSetDevice(e->device)) != hipSuccess) return dev_fail("hipSetDevice", hrc);
-  if ((hrc = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
-    return dev_fail("hipStreamCreate", hrc);
-  // The set-up stream gets its own priority level: the runtime keeps a separate pool of hardware queues per
-  // priority, so the two streams can never be folded onto ONE hardware queue (which serialises them) however
-  // many streams the process already holds.  Measured: with an RCCL process group created first, two
-  // normal-priority streams shared a queue and the set-up overlap was gone (2.24 ms per step against 2.17).
-  {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if ((hrc = hipStreamCreateWithPriority(&e->prep_stream, hipStreamNonBlocking, least)) != hipSuccess)
-      return dev_fail("hipStreamCreate", hrc);
-  }
-  if (const char* serial = std::getenv("BITO_AMD_SERIAL_SETUP")) e->serial_setup = std::atoi(serial);
-  for (int i = 0; i < bito_amd_engine::kSets; i++) {
-    if ((hrc = hipEventCreateWithFlags(&e->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess ||
-        (hrc = hipEventCreateWithFlags(&e->ev_walk_done[i], hipEventDisableTiming)) != hipSuccess)
-      return dev_fail("hipEventCreate", hrc);
-  }
+  // "Thread count needs to be strictly positive." (reference src/engine.cpp:14-16): here, devices
+  const int device_count = spec ? spec->device_count : 1;
+  if (device_count < 1) return report(BITO_AMD_ERR_BAD_ARG, "Device count needs to be strictly positive.");
+  auto e = std::make_unique<bito_amd_engine>();
+  for (int k = 0; k < device_count; k++)
+    e->devices.push_back(spec && spec->devices ? spec->devices[k] : (spec ? spec->device_id : 0) + k);
+  e->workers.resize(device_count);
+  e->substitution = substitution ? substitution : "";
+  e->site = site ? site : "";
+  e->clock = clock ? clock : "";
   e->n = taxon_count;
   e->P = pattern_count;
-  // padded so that every kernel's last tile (at most 512 patterns wide) stays in bounds
-  e->Ppad = (pattern_count + 512 + kHbmBlock - 1) / kHbmBlock * kHbmBlock;
-  size_t free_b = 0, total_b = 0;
-  (void)hipMemGetInfo(&free_b, &total_b);
-  e->arena_limit = (spec && spec->arena_bytes) ? spec->arena_bytes : std::max<size_t>(free_b / 4 * 3, (size_t)1 << 28);
-  // Compact tip states, gap for every symbol >= 4 and for the padding columns
-  // (SitePattern symbol table, reference src/site_pattern.cpp:16-46).
-  const int S = e->spec.state_count;
-  std::vector<uint8_t> tips((size_t)e->n * e->Ppad, (uint8_t)S);
-  for (int t = 0; t < e->n; t++)
-    for (int p = 0; p < e->P; p++) {
-      const int32_t s = patterns[(size_t)t * e->P + p];
-      if (s < 0) { delete e; return report(BITO_AMD_ERR_BAD_ARG, "negative pattern symbol"); }
-      tips[(size_t)t * e->Ppad + p] = (uint8_t)(s >= S ? S : s);
-    }
-  std::vector<double> w(e->Ppad, 0.0);
-  std::copy(weights, weights + e->P, w.begin());
-  if ((hrc = e->tip_states.Reserve(tips.size())) != hipSuccess) return dev_fail("hipMalloc", hrc);
-  if ((hrc = e->weights.Reserve(w.size())) != hipSuccess) return dev_fail("hipMalloc", hrc);
-  if ((hrc = hipMemcpy(e->tip_states.ptr, tips.data(), tips.size(), hipMemcpyHostToDevice)) != hipSuccess)
-    return dev_fail("hipMemcpy", hrc);
-  if ((hrc = hipMemcpy(e->weights.ptr, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
-    return dev_fail("hipMemcpy", hrc);
-  *out = e;
+  e->patterns.assign(patterns, patterns + (size_t)taxon_count * pattern_count);
+  e->weights.assign(weights, weights + pattern_count);
+  e->arena_bytes = spec ? spec->arena_bytes : 0;
+  if (const char* v = std::getenv("BITO_AMD_CHUNK_FIRST")) e->chunk_first = std::max(1, std::atoi(v));
+  if (const char* v = std::getenv("BITO_AMD_CHUNK_CAP")) e->chunk_cap = std::max(1, std::atoi(v));
+  if (const char* v = std::getenv("BITO_AMD_CHUNK_GROWTH")) e->chunk_growth = std::max(1.0, std::atof(v));
+  if (const char* v = std::getenv("BITO_AMD_CHUNK_LANES")) e->max_lanes = std::min(kMaxLanes, std::max(1, std::atoi(v)));
+  // the first worker of every device now (model strings, device ordinals and the alignment are checked here);
+  // further lanes when a call first needs them
+  for (int s = 0; s < device_count; s++) {
+    Worker* w = nullptr;
+    if (int rc = GetWorker(e.get(), s, 0, &w)) return report(rc, e->err);
+  }
+  *out = e.release();
   return BITO_AMD_OK;
 }
 
@@ -770,294 +291,51 @@ void bito_amd_engine_destroy(bito_amd_engine* e) { delete e; }
 
 const char* bito_amd_engine_last_error(const bito_amd_engine* e) { return e ? e->err.c_str() : ""; }
 
-int32_t bito_amd_engine_param_count(const bito_amd_engine* e) { return e->spec.param_count; }
-int32_t bito_amd_engine_category_count(const bito_amd_engine* e) { return e->spec.category_count; }
-int32_t bito_amd_engine_state_count(const bito_amd_engine* e) { return e->spec.state_count; }
-int32_t bito_amd_engine_block_count(const bito_amd_engine* e) { return (int32_t)e->blocks.size(); }
+int32_t bito_amd_engine_param_count(const bito_amd_engine* e) { return WorkerParamCount(Primary(e)); }
+int32_t bito_amd_engine_category_count(const bito_amd_engine* e) { return WorkerCategoryCount(Primary(e)); }
+int32_t bito_amd_engine_state_count(const bito_amd_engine* e) { return WorkerStateCount(Primary(e)); }
+int32_t bito_amd_engine_block_count(const bito_amd_engine* e) { return WorkerBlockCount(Primary(e)); }
+int32_t bito_amd_engine_device_count(const bito_amd_engine* e) { return e ? (int32_t)e->devices.size() : 0; }
 
-int bito_amd_engine_block(const bito_amd_engine* e, int32_t idx, char* name, size_t name_len,
-                          int32_t* start, int32_t* len) {
-  if (idx < 0 || idx >= (int32_t)e->blocks.size()) return BITO_AMD_ERR_BAD_ARG;
-  const Block& b = e->blocks[idx];
-  if (name && name_len) std::snprintf(name, name_len, "%s", b.name.c_str());
-  if (start) *start = b.start;
-  if (len) *len = b.len;
-  return BITO_AMD_OK;
+int bito_amd_engine_block(const bito_amd_engine* e, int32_t idx, char* name, size_t name_len, int32_t* start,
+                          int32_t* len) {
+  return WorkerBlock(Primary(e), idx, name, name_len, start, len);
 }
 
-int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t rooted,
-                           int32_t node_count, const int32_t* parent_ids,
-                           const double* branch_lengths, const double* rates, const double* params) {
-  if (!e) return BITO_AMD_ERR_BAD_ARG;
-  e->resident = false;
-  if (tree_count < 1 || !parent_ids || !branch_lengths)
-    return Fail(e, BITO_AMD_ERR_BAD_ARG, "need at least one tree and non-NULL parent_ids / branch_lengths");
-  if (e->spec.param_count > 0 && !params)
-    return Fail(e, BITO_AMD_ERR_BAD_ARG, "params is NULL but the model has parameters");
-  int min_cherries = 0;
-  e->tree_cherries.assign((size_t)tree_count, 0);
-  e->pipe_split = bito_amd_engine::PipeSplit{};
-  int rc = ValidateTrees(e, tree_count, rooted, node_count, parent_ids, &min_cherries, &e->tree_cherries);
-  if (rc) return rc;
-  if (params && (rc = ValidateParams(e, tree_count, params))) return rc;
-  HIP_TRY(e, hipSetDevice(e->device));
-  // a set-up kernel of an earlier, still running pass may be reading the input buffers
-  HIP_TRY(e, hipStreamSynchronize(e->prep_stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  const int n = e->n, N = 2 * n - 1, M = node_count, C = e->spec.category_count;
-  const size_t T = tree_count;
-  const int pc = std::max(e->spec.param_count, 1);
-  HIP_TRY(e, e->parent_ids.Reserve(T * (M - 1)));
-  HIP_TRY(e, e->branch_in.Reserve(T * M));
-  HIP_TRY(e, e->params.Reserve(T * pc));
-  HIP_TRY(e, e->children.Reserve(T * (n - 1) * 2));
-  HIP_TRY(e, e->branch.Reserve(T * N));
-  HIP_TRY(e, e->model.Reserve(T));
-  HIP_TRY(e, e->children2.Reserve(T * (n - 1) * 2));
-  HIP_TRY(e, e->branch2.Reserve(T * N));
-  HIP_TRY(e, e->model2.Reserve(T));
-  HIP_TRY(e, e->children3.Reserve(T * (n - 1) * 2));
-  HIP_TRY(e, e->branch3.Reserve(T * N));
-  HIP_TRY(e, e->model3.Reserve(T));
-  for (auto& r : e->out_ll_ring) HIP_TRY(e, r.Reserve(T));
-  HIP_TRY(e, e->out_grad.Reserve(T * N));
-  HIP_TRY(e, e->out_site.Reserve(T));
-  HIP_TRY(e, hipMemcpyAsync(e->parent_ids.ptr, parent_ids, T * (M - 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * M * sizeof(double), hipMemcpyHostToDevice, e->stream));
-  e->min_branch = e->n > kPipeExactTaxa ? MinBranchLength(branch_lengths, rooted ? rates : nullptr, T, M) : 0.0;
-  if (e->spec.param_count > 0)
-    HIP_TRY(e, hipMemcpyAsync(e->params.ptr, params, T * e->spec.param_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
-  e->gs_index_valid = false;
-  if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL) {
-    static const double none = 0.0;
-    if ((rc = UploadModelIndex(e, tree_count, e->spec.param_count > 0 ? params : &none))) return rc;
-  }
-  e->has_rates = rooted && rates != nullptr;
-  if (e->has_rates) {
-    HIP_TRY(e, e->rates.Reserve(T * (M - 1)));
-    HIP_TRY(e, hipMemcpyAsync(e->rates.ptr, rates, T * (M - 1) * sizeof(double), hipMemcpyHostToDevice, e->stream));
-  }
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  e->dims.taxon_count = n;
-  e->dims.node_count = N;
-  e->dims.in_node_count = M;
-  e->dims.rooted = rooted;
-  e->dims.pattern_count = e->P;
-  e->dims.pattern_stride = e->Ppad;
-  e->dims.category_count = C;
-  e->dims.tree_count = tree_count;
-  e->dims.min_cherries = min_cherries;
-  e->resident = true;
-  return BITO_AMD_OK;
-}
-
-int bito_amd_engine_update(bito_amd_engine* e, const double* branch_lengths, const double* params) {
-  if (!e) return BITO_AMD_ERR_BAD_ARG;
-  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
-  HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipStreamSynchronize(e->prep_stream));  // (see bito_amd_engine_upload)
-  const size_t T = e->dims.tree_count;
-  if (params && e->spec.param_count > 0) {
-    int rc = ValidateParams(e, (int)T, params);
-    if (rc) return rc;
-    HIP_TRY(e, hipMemcpyAsync(e->params.ptr, params, T * e->spec.param_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    e->gs_index_valid = false;
-    if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL)
-      if ((rc = UploadModelIndex(e, (int)T, params))) return rc;
-  }
-  if (branch_lengths) {
-    HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * e->dims.in_node_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    // (rates, when a batch has them, stay on the device: unknown here, so no claim about the effective lengths)
-    e->min_branch = (e->n > kPipeExactTaxa && !e->has_rates) ? MinBranchLength(branch_lengths, nullptr, T, (size_t)e->dims.in_node_count) : 0.0;
-  }
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  return BITO_AMD_OK;
-}
-
-int bito_amd_engine_run(bito_amd_engine* e, int32_t want_gradient, int32_t rescaling) {
-  if (!e) return BITO_AMD_ERR_BAD_ARG;
-  return RunResident(e, want_gradient != 0, rescaling != 0);
-}
-
-int bito_amd_engine_sync(bito_amd_engine* e) {
-  if (!e) return BITO_AMD_ERR_BAD_ARG;
-  HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  return BITO_AMD_OK;
-}
-
-int bito_amd_engine_download_async(bito_amd_engine* e, double* out_ll, double* out_grad) {
-  if (!e) return BITO_AMD_ERR_BAD_ARG;
-  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident");
-  HIP_TRY(e, hipSetDevice(e->device));
-  const size_t T = e->dims.tree_count;
-  if (out_ll)
-    HIP_TRY(e, hipMemcpyAsync(out_ll, e->cur_ll(), T * sizeof(double), hipMemcpyDefault, e->stream));
-  if (out_grad)
-    HIP_TRY(e, hipMemcpyAsync(out_grad, e->out_grad.ptr, T * e->dims.node_count * sizeof(double), hipMemcpyDefault, e->stream));
-  return BITO_AMD_OK;
-}
-
-int bito_amd_engine_results_async(bito_amd_engine* e, void* consumer_stream, const double** out_ll,
-                                  const double** out_grad) {
-  if (!e) return BITO_AMD_ERR_BAD_ARG;
-  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident");
-  HIP_TRY(e, hipSetDevice(e->device));
-  hipStream_t consumer = static_cast<hipStream_t>(consumer_stream);
-  if (e->last_pass_done) {
-    HIP_TRY(e, hipStreamWaitEvent(consumer, e->last_pass_done, 0));
-  } else {  // (nothing recorded behind the last pass: an event of its own)
-    hipEvent_t ev = NextEvent(e);
-    HIP_TRY(e, hipEventRecord(ev, e->stream));
-    HIP_TRY(e, hipStreamWaitEvent(consumer, ev, 0));
-  }
-  if (out_ll) *out_ll = e->cur_ll();
-  if (out_grad) *out_grad = e->out_grad.ptr;
-  return BITO_AMD_OK;
-}
-
-int bito_amd_engine_download(bito_amd_engine* e, double* out_ll, double* out_grad) {
-  if (int rc = bito_amd_engine_download_async(e, out_ll, out_grad)) return rc;
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  return BITO_AMD_OK;
-}
-
-void* bito_amd_engine_stream(bito_amd_engine* e) { return e ? (void*)e->stream : nullptr; }
-
-int bito_amd_engine_log_likelihoods(bito_amd_engine* e, int32_t tree_count, int32_t rooted,
-                                    int32_t node_count, const int32_t* parent_ids,
-                                    const double* branch_lengths, const double* rates,
+int bito_amd_engine_log_likelihoods(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t node_count,
+                                    const int32_t* parent_ids, const double* branch_lengths, const double* rates,
                                     const double* params, int32_t rescaling, double* out) {
-  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
-  // an empty collection is not an error: FatBeagleParallelize over no trees returns an empty vector
-  // (reference src/fat_beagle.hpp:160-181)
-  if (tree_count == 0) return BITO_AMD_OK;
-  int rc = bito_amd_engine_upload(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params);
-  if (rc) return rc;
-  if ((rc = RunResident(e, 0, rescaling != 0))) return rc;
-  return bito_amd_engine_download(e, out, nullptr);
+  return LogLikelihoods(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, rescaling, out,
+                        /*single=*/false);
 }
 
-// StickBreakingTransform (reference src/stick_breaking_transform.cpp:10-44): the Stan
-// simplex transform; x = T(y) has K entries, y has K-1.
-static void StickForward(const double* y, int K, double* x) {
-  double stick = 1.0;
-  for (int k = 0; k < K - 1; k++) {
-    const double z = 1.0 / (1 + std::exp(-(y[k] - std::log((double)(K - k - 1)))));
-    x[k] = stick * z;
-    stick -= x[k];
-  }
-  x[K - 1] = stick;
-}
-static void StickInverse(const double* x, int K, double* y) {
-  double sum = 0;
-  for (int k = 0; k < K - 1; k++) {
-    const double z = x[k] / (1.0 - sum);
-    y[k] = std::log(z / (1.0 - z)) + std::log((double)(K - k - 1));
-    sum += x[k];
-  }
-}
-
-// FatBeagle::SubstitutionModelGradient (reference src/fat_beagle.cpp:412-508): central finite
-// differences of the tree log-likelihood in every free substitution-model parameter, rates
-// first then frequencies, in stick-breaking coordinates when requested (frequencies always,
-// rates only for GTR's six).  The 2 x (#parameters) perturbed evaluations of every tree are
-// run as ONE batch of log-likelihood-only passes on the device.
-static int SubstitutionGradients(bito_amd_engine* e, int T, int rooted, int node_count,
-                                 const int32_t* parent_ids, const double* branch_lengths,
-                                 const double* rates, const double* params, int rescaling, bool stick,
-                                 double delta, double* out_subst) {
-  const ModelSpec& m = e->spec;
-  const int pc = m.param_count;
-  struct Dir { int start, len, index; bool stick; };
-  std::vector<Dir> dirs;
-  const bool rates_stick = stick && m.rates_len == 6;
-  for (int i = 0; i < (rates_stick ? 5 : m.rates_len); i++) dirs.push_back({m.rates_start, m.rates_len, i, rates_stick});
-  for (int i = 0; i < (stick ? 3 : 4); i++) dirs.push_back({m.freq_start, 4, i, stick});
-  const int K = (int)dirs.size(), M = node_count;
-  const size_t big = (size_t)T * 2 * K;
-  std::vector<int32_t> pid(big * (M - 1));
-  std::vector<double> bl(big * M), par(big * pc), rt;
-  if (rooted && rates) rt.resize(big * (M - 1));
-  for (int t = 0; t < T; t++)
-    for (int j = 0; j < 2 * K; j++) {
-      const size_t r = (size_t)t * 2 * K + j;
-      std::copy(parent_ids + (size_t)t * (M - 1), parent_ids + (size_t)(t + 1) * (M - 1), pid.begin() + r * (M - 1));
-      std::copy(branch_lengths + (size_t)t * M, branch_lengths + (size_t)(t + 1) * M, bl.begin() + r * M);
-      if (!rt.empty()) std::copy(rates + (size_t)t * (M - 1), rates + (size_t)(t + 1) * (M - 1), rt.begin() + r * (M - 1));
-      double* row = par.data() + r * pc;
-      std::copy(params + (size_t)t * pc, params + (size_t)(t + 1) * pc, row);
-      const Dir& dr = dirs[j / 2];
-      const double sign = (j % 2 == 0) ? 1.0 : -1.0;
-      double y[8];
-      if (dr.stick) {
-        StickInverse(row + dr.start, dr.len, y);
-        y[dr.index] += sign * delta;
-        StickForward(y, dr.len, row + dr.start);
-      } else {
-        row[dr.start + dr.index] += sign * delta;
-      }
-    }
-  std::vector<double> ll(big);
-  int rc = bito_amd_engine_log_likelihoods(e, (int32_t)big, rooted, node_count, pid.data(), bl.data(),
-                                           rt.empty() ? nullptr : rt.data(), par.data(), rescaling, ll.data());
-  if (rc) return rc;
-  const int stride = m.rates_len + 4;
-  for (int t = 0; t < T; t++)
-    for (int k = 0; k < K; k++)
-      out_subst[(size_t)t * stride + k] = (ll[((size_t)t * K + k) * 2] - ll[((size_t)t * K + k) * 2 + 1]) / (2. * delta);
-  return BITO_AMD_OK;
-}
-
-int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t rooted,
-                              int32_t node_count, const int32_t* parent_ids,
-                              const double* branch_lengths, const double* rates,
-                              const double* params, int32_t rescaling, int32_t flags,
-                              double fd_delta, double* out_ll, double* out_branch,
-                              double* out_site, double* out_subst, double* out_clock) {
+int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t node_count,
+                              const int32_t* parent_ids, const double* branch_lengths, const double* rates,
+                              const double* params, int32_t rescaling, int32_t flags, double fd_delta,
+                              double* out_ll, double* out_branch, double* out_site, double* out_subst,
+                              double* out_clock) {
   if (!e || !out_ll || !out_branch) return BITO_AMD_ERR_BAD_ARG;
   if (tree_count == 0) return BITO_AMD_OK;  // empty collection, empty result (as bito_amd_engine_log_likelihoods)
-  int rc;
+  const ModelSpec& m = Primary(e)->spec;
   // the finite-difference batch first: the main batch must be the resident one on return
-  if ((flags & BITO_AMD_GRAD_SUBSTITUTION_MODEL) && out_subst && e->spec.rates_len > 0) {
-    rc = SubstitutionGradients(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params,
-                               rescaling, (flags & BITO_AMD_GRAD_STICKBREAKING) != 0,
-                               fd_delta > 0 ? fd_delta : 1e-6, out_subst);
+  if ((flags & BITO_AMD_GRAD_SUBSTITUTION_MODEL) && out_subst && m.rates_len > 0) {
+    if (!parent_ids || !branch_lengths || !params) return Fail(e, BITO_AMD_ERR_BAD_ARG, "NULL argument");
+    const int rc = SubstitutionGradientsVia(
+        m, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params,
+        (flags & BITO_AMD_GRAD_STICKBREAKING) != 0, fd_delta > 0 ? fd_delta : 1e-6, out_subst,
+        [&](int32_t big, const int32_t* pid, const double* bl, const double* rt, const double* par, double* ll) {
+          return LogLikelihoods(e, big, rooted, node_count, pid, bl, rt, par, rescaling, ll, false);
+        });
     if (rc) return rc;
   }
-  rc = bito_amd_engine_upload(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params);
+  const int want_site = (flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && m.category_count > 1;
+  int rc = Evaluate(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, rescaling != 0, 1,
+                    want_site, out_ll, out_branch, out_site, /*single=*/false);
   if (rc) return rc;
-  const int want_site = (flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && e->spec.category_count > 1;
-  if ((rc = RunResident(e, 1, rescaling != 0, /*deriv_mode=*/0, want_site))) return rc;
-  if ((rc = bito_amd_engine_download(e, out_ll, out_branch))) return rc;
-  const int N = 2 * e->n - 1;
-  if ((flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && e->spec.category_count > 1 && e->site_ready) {
-    // the traversal produced it in the same pass (per-category edge sums: walk_lds_kernel, walk_pipe_kernel,
-    // walk_hbm_cat_kernel)
-    HIP_TRY(e, hipMemcpyAsync(out_site, e->out_site.ptr, (size_t)tree_count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-  } else if ((flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && e->spec.category_count > 1) {
-    // second gradient pass with dQ = Q * d r_c / d shape, then sum_b g_b t_b over the
-    // effective branch lengths (DiscreteSiteModelGradient, reference src/fat_beagle.cpp:401-410,538-550)
-    if ((rc = RunResident(e, 1, rescaling != 0, /*deriv_mode=*/1))) return rc;
-    std::vector<double> g2((size_t)tree_count * N);
-    if ((rc = bito_amd_engine_download(e, nullptr, g2.data()))) return rc;
-    for (int t = 0; t < tree_count; t++) {
-      double s = 0;
-      for (int i = 0; i < node_count - 1; i++) {
-        double bl = branch_lengths[(size_t)t * node_count + i];
-        if (rooted && rates) bl *= rates[(size_t)t * (node_count - 1) + i];
-        s += g2[(size_t)t * N + i] * bl;
-      }
-      out_site[t] = s;  // unrooted: the two extra nodes of the detrifurcated tree have branch length 0
-    }
-    // leave the device results of the main pass in place for bito_amd_engine_download
-    if ((rc = RunResident(e, 1, rescaling != 0))) return rc;
-    if ((rc = bito_amd_engine_sync(e))) return rc;
-  }
   if (rooted && (flags & BITO_AMD_GRAD_CLOCK_MODEL) && out_clock) {
     // ClockGradient, strict clock (reference src/fat_beagle.cpp:379-399): sum of
     // branch gradient times the tree's own (time) branch length.
+    const int N = 2 * e->n - 1;
     for (int t = 0; t < tree_count; t++) {
       double s = 0;
       for (int i = 0; i < N - 1; i++) s += out_branch[(size_t)t * N + i] * branch_lengths[(size_t)t * node_count + i];
@@ -1067,142 +345,51 @@ int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t ro
   return BITO_AMD_OK;
 }
 
-// ---- time trees -------------------------------------------------------------
-extern "C++" {
-namespace {
+// ---- time trees: one worker (the transforms are O(n) per tree and keep their inputs on that worker) ----
 
-template <typename T>
-int ToDevice(bito_amd_engine* e, DeviceBuffer<T>& buf, const T* host, size_t count) {
-  HIP_TRY(e, buf.Reserve(count));
-  HIP_TRY(e, hipMemcpyAsync(buf.ptr, host, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
-  return BITO_AMD_OK;
-}
-
-int ToHost(bito_amd_engine* e, double* host, const double* dev, size_t count) {
-  HIP_TRY(e, hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  return BITO_AMD_OK;
-}
-
-// common front end of the stand-alone transforms: validate, stage the topologies
-int StageTimeTrees(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids) {
+int bito_amd_engine_time_trees_from_branch_lengths(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
+                                                   const double* branch_lengths, const double* tip_dates,
+                                                   double* out_node_bounds, double* out_node_heights,
+                                                   double* out_height_ratios) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
-  if (tree_count < 1 || !parent_ids) return Fail(e, BITO_AMD_ERR_BAD_ARG, "need at least one tree and parent_ids");
-  const int N = 2 * e->n - 1;
-  int rc = ValidateTrees(e, tree_count, 1, N, parent_ids);
-  if (rc) return rc;
-  HIP_TRY(e, hipSetDevice(e->device));
-  return ToDevice(e, e->tt_parents, parent_ids, (size_t)tree_count * (N - 1));
+  Worker* w = Primary(e);
+  return Propagate(e, w, WorkerTimeTreesFromBranchLengths(w, tree_count, parent_ids, branch_lengths, tip_dates,
+                                                          out_node_bounds, out_node_heights, out_height_ratios));
 }
 
-}  // namespace
-}  // extern "C++"
-
-int bito_amd_engine_time_trees_from_branch_lengths(bito_amd_engine* e, int32_t tree_count,
-                                                   const int32_t* parent_ids, const double* branch_lengths,
-                                                   const double* tip_dates, double* out_node_bounds,
-                                                   double* out_node_heights, double* out_height_ratios) {
-  int rc = StageTimeTrees(e, tree_count, parent_ids);
-  if (rc) return rc;
-  if (!branch_lengths || !tip_dates || !out_node_bounds || !out_node_heights || !out_height_ratios)
-    return Fail(e, BITO_AMD_ERR_BAD_ARG, "NULL argument");
-  const int n = e->n, N = 2 * n - 1;
-  const size_t T = tree_count;
-  if ((rc = ToDevice(e, e->tt_in, branch_lengths, T * N))) return rc;
-  if ((rc = ToDevice(e, e->tt_aux, tip_dates, (size_t)n))) return rc;
-  HIP_TRY(e, e->tt_bounds.Reserve(T * N));
-  HIP_TRY(e, e->tt_heights.Reserve(T * N));
-  HIP_TRY(e, e->tt_ratios.Reserve(T * (n - 1)));
-  HIP_TRY(e, e->tt_out.Reserve(T));
-  LaunchTimeTreeFromBranchLengths(tree_count, n, e->tt_parents.ptr, e->tt_in.ptr, e->tt_aux.ptr, e->tt_bounds.ptr,
-                                  e->tt_heights.ptr, e->tt_ratios.ptr, e->tt_out.ptr, e->stream);
-  HIP_TRY(e, hipGetLastError());
-  std::vector<double> diff(T);
-  if ((rc = ToHost(e, diff.data(), e->tt_out.ptr, T))) return rc;
-  for (size_t t = 0; t < T; t++)
-    if (!(diff[t] <= 1e-4)) {  // BRANCH_LENGTH_TOLERANCE, rooted_tree.cpp:7
-      char buf[200];
-      std::snprintf(buf, sizeof(buf),
-                    "Tree isn't time-calibrated in RootedTree::InitializeTimeTreeUsingBranchLengths. "
-                    "Height difference: %f (tree %zu)", diff[t], t);
-      return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
-    }
-  if ((rc = ToHost(e, out_node_bounds, e->tt_bounds.ptr, T * N))) return rc;
-  if ((rc = ToHost(e, out_node_heights, e->tt_heights.ptr, T * N))) return rc;
-  return ToHost(e, out_height_ratios, e->tt_ratios.ptr, T * (n - 1));
-}
-
-int bito_amd_engine_time_trees_from_height_ratios(bito_amd_engine* e, int32_t tree_count,
-                                                  const int32_t* parent_ids, const double* node_bounds,
-                                                  const double* height_ratios, double* out_node_heights,
-                                                  double* out_branch_lengths) {
-  int rc = StageTimeTrees(e, tree_count, parent_ids);
-  if (rc) return rc;
-  if (!node_bounds || !height_ratios || !out_node_heights || !out_branch_lengths)
-    return Fail(e, BITO_AMD_ERR_BAD_ARG, "NULL argument");
-  const int n = e->n, N = 2 * n - 1;
-  const size_t T = tree_count;
-  if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
-  if ((rc = ToDevice(e, e->tt_ratios, height_ratios, T * (n - 1)))) return rc;
-  HIP_TRY(e, e->tt_heights.Reserve(T * N));
-  HIP_TRY(e, e->tt_in.Reserve(T * N));
-  LaunchTimeTreeFromRatios(tree_count, n, e->tt_parents.ptr, e->tt_bounds.ptr, e->tt_ratios.ptr, e->tt_heights.ptr,
-                           e->tt_in.ptr, e->stream);
-  HIP_TRY(e, hipGetLastError());
-  if ((rc = ToHost(e, out_node_heights, e->tt_heights.ptr, T * N))) return rc;
-  return ToHost(e, out_branch_lengths, e->tt_in.ptr, T * N);
+int bito_amd_engine_time_trees_from_height_ratios(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
+                                                  const double* node_bounds, const double* height_ratios,
+                                                  double* out_node_heights, double* out_branch_lengths) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  Worker* w = Primary(e);
+  return Propagate(e, w, WorkerTimeTreesFromHeightRatios(w, tree_count, parent_ids, node_bounds, height_ratios,
+                                                         out_node_heights, out_branch_lengths));
 }
 
 int bito_amd_engine_log_det_jacobian(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
                                      const double* node_heights, const double* node_bounds, double* out) {
-  int rc = StageTimeTrees(e, tree_count, parent_ids);
-  if (rc) return rc;
-  if (!node_heights || !node_bounds || !out) return Fail(e, BITO_AMD_ERR_BAD_ARG, "NULL argument");
-  const int n = e->n, N = 2 * n - 1;
-  const size_t T = tree_count;
-  if ((rc = ToDevice(e, e->tt_heights, node_heights, T * N))) return rc;
-  if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
-  HIP_TRY(e, e->tt_out.Reserve(T));
-  LaunchLogDetJacobian(tree_count, n, e->tt_parents.ptr, e->tt_heights.ptr, e->tt_bounds.ptr, e->tt_out.ptr, nullptr,
-                       e->stream);
-  HIP_TRY(e, hipGetLastError());
-  return ToHost(e, out, e->tt_out.ptr, T);
-}
-
-// shared by the two stand-alone ratio-space transforms (mode 0 / 1 of ratio_gradient_kernel)
-static int RatioTransform(bito_amd_engine* e, int mode, int32_t tree_count, const int32_t* parent_ids,
-                          const double* node_heights, const double* node_bounds, const double* height_ratios,
-                          const double* height_gradient, double* out) {
-  int rc = StageTimeTrees(e, tree_count, parent_ids);
-  if (rc) return rc;
-  if (!node_heights || !node_bounds || !height_ratios || !out || (mode == 0 && !height_gradient))
-    return Fail(e, BITO_AMD_ERR_BAD_ARG, "NULL argument");
-  const int n = e->n, N = 2 * n - 1;
-  const size_t T = tree_count;
-  if ((rc = ToDevice(e, e->tt_heights, node_heights, T * N))) return rc;
-  if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
-  if ((rc = ToDevice(e, e->tt_ratios, height_ratios, T * (n - 1)))) return rc;
-  if (mode == 0 && (rc = ToDevice(e, e->tt_in, height_gradient, T * (n - 1)))) return rc;
-  HIP_TRY(e, e->tt_work.Reserve(T * 3 * (n - 1)));
-  HIP_TRY(e, e->tt_out.Reserve(T * (n - 1)));
-  LaunchRatioGradient(tree_count, n, mode, e->tt_parents.ptr, e->tt_heights.ptr, e->tt_bounds.ptr, e->tt_ratios.ptr,
-                      e->tt_in.ptr, n - 1, nullptr, e->tt_work.ptr, e->tt_out.ptr, e->stream);
-  HIP_TRY(e, hipGetLastError());
-  return ToHost(e, out, e->tt_out.ptr, T * (n - 1));
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  Worker* w = Primary(e);
+  return Propagate(e, w, WorkerLogDetJacobian(w, tree_count, parent_ids, node_heights, node_bounds, out));
 }
 
 int bito_amd_engine_gradient_log_det_jacobian(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
                                               const double* node_heights, const double* node_bounds,
                                               const double* height_ratios, double* out) {
-  return RatioTransform(e, 1, tree_count, parent_ids, node_heights, node_bounds, height_ratios, nullptr, out);
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  Worker* w = Primary(e);
+  return Propagate(e, w, WorkerGradientLogDetJacobian(w, tree_count, parent_ids, node_heights, node_bounds,
+                                                      height_ratios, out));
 }
 
 int bito_amd_engine_ratio_gradient_of_height_gradient(bito_amd_engine* e, int32_t tree_count,
                                                       const int32_t* parent_ids, const double* node_heights,
                                                       const double* node_bounds, const double* height_ratios,
                                                       const double* height_gradient, double* out) {
-  return RatioTransform(e, 0, tree_count, parent_ids, node_heights, node_bounds, height_ratios, height_gradient,
-                        out);
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  Worker* w = Primary(e);
+  return Propagate(e, w, WorkerRatioGradientOfHeightGradient(w, tree_count, parent_ids, node_heights, node_bounds,
+                                                             height_ratios, height_gradient, out));
 }
 
 int bito_amd_engine_time_tree_log_likelihoods(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
@@ -1210,22 +397,16 @@ int bito_amd_engine_time_tree_log_likelihoods(bito_amd_engine* e, int32_t tree_c
                                               const double* node_heights, const double* node_bounds,
                                               const double* params, int32_t rescaling,
                                               int32_t include_log_det_jacobian, double* out) {
-  if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
-  const int n = e->n, N = 2 * n - 1;
-  if (include_log_det_jacobian && (!node_heights || !node_bounds))
-    return Fail(e, BITO_AMD_ERR_BAD_ARG, "node_heights / node_bounds are needed for the log-det-Jacobian");
-  int rc = bito_amd_engine_upload(e, tree_count, 1, N, parent_ids, branch_lengths, rates, params);
-  if (rc) return rc;
-  if ((rc = RunResident(e, 0, rescaling != 0))) return rc;
-  if (include_log_det_jacobian) {
-    const size_t T = tree_count;
-    if ((rc = ToDevice(e, e->tt_heights, node_heights, T * N))) return rc;
-    if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
-    LaunchLogDetJacobian(tree_count, n, e->parent_ids.ptr, e->tt_heights.ptr, e->tt_bounds.ptr, nullptr,
-                         e->cur_ll(), e->stream);
-    HIP_TRY(e, hipGetLastError());
-  }
-  return bito_amd_engine_download(e, out, nullptr);
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  Worker* w = Primary(e);
+  e->resident = false;
+  w->one_shot = 0;
+  w->id_offset = 0;
+  const int rc = WorkerTimeTreeLogLikelihoods(w, tree_count, parent_ids, branch_lengths, rates, node_heights,
+                                              node_bounds, params, rescaling, include_log_det_jacobian, out);
+  if (rc) return Propagate(e, w, rc);
+  SetSingleResident(e, 1, 2 * e->n - 1, tree_count);
+  return BITO_AMD_OK;
 }
 
 int bito_amd_engine_time_tree_gradients(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
@@ -1233,142 +414,180 @@ int bito_amd_engine_time_tree_gradients(bito_amd_engine* e, int32_t tree_count, 
                                         const double* node_heights, const double* node_bounds,
                                         const double* height_ratios, const double* params, int32_t rescaling,
                                         int32_t flags, double fd_delta, double* out_ll, double* out_branch,
-                                        double* out_site, double* out_subst, double* out_clock,
-                                        double* out_ratios) {
+                                        double* out_site, double* out_subst, double* out_clock, double* out_ratios) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
-  const int n = e->n, N = 2 * n - 1;
-  const size_t T = tree_count;
-  const bool want_clock = (flags & BITO_AMD_GRAD_CLOCK_MODEL) && out_clock;
-  const bool want_ratios = (flags & BITO_AMD_GRAD_RATIOS_ROOT_HEIGHT) && out_ratios;
-  if (want_clock && rate_count != 1 && rate_count != N - 1)
-    return Fail(e, BITO_AMD_ERR_BAD_ARG,
-                "The number of rates should be equal to 1 (i.e. strict clock) or equal to the number of branches.");
-  if (want_ratios && (!node_heights || !node_bounds || !height_ratios))
-    return Fail(e, BITO_AMD_ERR_BAD_ARG, "time trees are not initialised: node_heights / node_bounds / height_ratios");
-  // everything except the clock and ratio outputs; leaves the main pass resident on the device
-  int rc = bito_amd_engine_gradients(e, tree_count, 1, N, parent_ids, branch_lengths, rates, params, rescaling,
-                                     flags & ~BITO_AMD_GRAD_CLOCK_MODEL, fd_delta, out_ll, out_branch, out_site,
-                                     out_subst, nullptr);
-  if (rc) return rc;
-  if (want_clock) {
-    const size_t count = T * (rate_count == 1 ? 1 : N - 1);
-    HIP_TRY(e, e->tt_out.Reserve(count));
-    LaunchClockGradient(tree_count, N, rate_count, e->out_grad.ptr, e->branch_in.ptr, N, e->tt_out.ptr, e->stream);
-    HIP_TRY(e, hipGetLastError());
-    if ((rc = ToHost(e, out_clock, e->tt_out.ptr, count))) return rc;
+  Worker* w = Primary(e);
+  e->resident = false;
+  w->one_shot = 0;
+  w->id_offset = 0;
+  const int rc = WorkerTimeTreeGradients(w, tree_count, parent_ids, branch_lengths, rates, rate_count, node_heights,
+                                         node_bounds, height_ratios, params, rescaling, flags, fd_delta, out_ll,
+                                         out_branch, out_site, out_subst, out_clock, out_ratios);
+  if (rc) return Propagate(e, w, rc);
+  SetSingleResident(e, 1, 2 * e->n - 1, tree_count);
+  return BITO_AMD_OK;
+}
+
+// ---- HBM-resident batch interface: one block per device, passes pipelined on each device's first worker ----
+
+int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t node_count,
+                           const int32_t* parent_ids, const double* branch_lengths, const double* rates,
+                           const double* params) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  e->resident = false;
+  if (tree_count < 1 || !parent_ids || !branch_lengths)
+    return Fail(e, BITO_AMD_ERR_BAD_ARG, "need at least one tree and non-NULL parent_ids / branch_lengths");
+  const size_t pc = (size_t)Primary(e)->spec.param_count, M = (size_t)node_count;
+  if (pc > 0 && !params) return Fail(e, BITO_AMD_ERR_BAD_ARG, "params is NULL but the model has parameters");
+  const int D = (int)e->devices.size();
+  e->shards.clear();
+  for (int s = 0; s < D; s++) {
+    const int t0 = (int)((long long)tree_count * s / D), t1 = (int)((long long)tree_count * (s + 1) / D);
+    if (t1 > t0) e->shards.push_back({s, 0, t0, t1 - t0});
   }
-  if (want_ratios) {
-    if ((rc = ToDevice(e, e->tt_heights, node_heights, T * N))) return rc;
-    if ((rc = ToDevice(e, e->tt_bounds, node_bounds, T * N))) return rc;
-    if ((rc = ToDevice(e, e->tt_ratios, height_ratios, T * (n - 1)))) return rc;
-    HIP_TRY(e, e->tt_work.Reserve(T * 3 * (n - 1)));
-    HIP_TRY(e, e->tt_out.Reserve(T * (n - 1)));
-    const int mode = 2 | ((flags & BITO_AMD_GRAD_LOG_DET_JACOBIAN_GRADIENT) ? 4 : 0);
-    LaunchRatioGradient(tree_count, n, mode, e->parent_ids.ptr, e->tt_heights.ptr, e->tt_bounds.ptr, e->tt_ratios.ptr,
-                        e->out_grad.ptr, N, e->has_rates ? e->rates.ptr : nullptr, e->tt_work.ptr, e->tt_out.ptr,
-                        e->stream);
-    HIP_TRY(e, hipGetLastError());
-    if ((rc = ToHost(e, out_ratios, e->tt_out.ptr, T * (n - 1)))) return rc;
+  const bool has_rates = rooted && rates != nullptr;
+  for (const Shard& s : e->shards) {
+    Worker* w = ShardWorker(e, s);
+    w->one_shot = 0;
+    w->id_offset = s.t0;
+    const int rc = WorkerStage(w, s.count, rooted, node_count, parent_ids + (size_t)s.t0 * (M - 1),
+                               branch_lengths + (size_t)s.t0 * M, has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr,
+                               pc > 0 ? params + (size_t)s.t0 * pc : nullptr, /*wait=*/0);
+    if (rc) return Propagate(e, w, rc);
+  }
+  for (const Shard& s : e->shards)
+    if (int rc = WorkerSync(ShardWorker(e, s))) return Propagate(e, ShardWorker(e, s), rc);
+  e->resident = true;
+  e->rooted = rooted;
+  e->node_count = node_count;
+  e->tree_count = tree_count;
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_update(bito_amd_engine* e, const double* branch_lengths, const double* params) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
+  const size_t pc = (size_t)Primary(e)->spec.param_count, M = (size_t)e->node_count;
+  for (const Shard& s : e->shards) {
+    Worker* w = ShardWorker(e, s);
+    w->id_offset = s.t0;
+    const int rc = WorkerUpdate(w, branch_lengths ? branch_lengths + (size_t)s.t0 * M : nullptr,
+                                (params && pc > 0) ? params + (size_t)s.t0 * pc : nullptr);
+    if (rc) return Propagate(e, w, rc);
   }
   return BITO_AMD_OK;
 }
 
-int bito_amd_plan_pipe_walk(int32_t taxon_count, int32_t pattern_count, int32_t category_count, int32_t tree_count,
-                            int32_t min_cherries, int32_t plan[7]) {
-  if (!plan || taxon_count < 3 || pattern_count < 1 || tree_count < 1) return BITO_AMD_ERR_BAD_ARG;
-  BatchDims d{};
-  d.taxon_count = taxon_count;
-  d.node_count = 2 * taxon_count - 1;
-  d.in_node_count = 2 * taxon_count - 2;
-  d.pattern_count = pattern_count;
-  d.pattern_stride = (pattern_count + 512 + kHbmBlock - 1) / kHbmBlock * kHbmBlock;
-  d.category_count = category_count;
-  d.tree_count = tree_count;
-  d.min_cherries = min_cherries;
-  const LdsPlan p = PlanPipe(d);
-  const int32_t out[7] = {p.groups, p.patterns_per_block, p.tiles, (int32_t)p.lds_bytes, p.tile_run, p.whole_trees, p.slots};
-  for (int k = 0; k < 7; k++) plan[k] = out[k];
+int bito_amd_engine_run(bito_amd_engine* e, int32_t want_gradient, int32_t rescaling) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call bito_amd_engine_upload first");
+  for (const Shard& s : e->shards) {
+    Worker* w = ShardWorker(e, s);
+    w->one_shot = 0;  // passes over a resident batch are pipelined: the set-up of pass k+1 beside the traversal of pass k
+    if (int rc = WorkerRun(w, want_gradient, rescaling)) return Propagate(e, w, rc);
+  }
   return BITO_AMD_OK;
 }
+
+int bito_amd_engine_sync(bito_amd_engine* e) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  for (auto& lanes : e->workers)
+    for (auto& w : lanes)
+      if (w)
+        if (int rc = WorkerSync(w.get())) return Propagate(e, w.get(), rc);
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_download_async(bito_amd_engine* e, double* out_ll, double* out_grad) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident");
+  const size_t N = 2 * (size_t)e->n - 1;
+  for (const Shard& s : e->shards) {
+    Worker* w = ShardWorker(e, s);
+    const int rc = WorkerDownloadAsync(w, out_ll ? out_ll + s.t0 : nullptr, out_grad ? out_grad + (size_t)s.t0 * N : nullptr);
+    if (rc) return Propagate(e, w, rc);
+  }
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_download(bito_amd_engine* e, double* out_ll, double* out_grad) {
+  if (int rc = bito_amd_engine_download_async(e, out_ll, out_grad)) return rc;
+  for (const Shard& s : e->shards)
+    if (int rc = WorkerSync(ShardWorker(e, s))) return Propagate(e, ShardWorker(e, s), rc);
+  return BITO_AMD_OK;
+}
+
+int bito_amd_engine_results_async(bito_amd_engine* e, void* consumer_stream, const double** out_ll,
+                                  const double** out_grad) {
+  if (!e) return BITO_AMD_ERR_BAD_ARG;
+  Worker* w = nullptr;
+  if (int rc = SingleShard(e, &w)) return rc;
+  return Propagate(e, w, WorkerResultsAsync(w, consumer_stream, out_ll, out_grad));
+}
+
+void* bito_amd_engine_stream(bito_amd_engine* e) { return e ? WorkerStream(Primary(e)) : nullptr; }
+
+// ---- diagnostics / benchmarking ----
 
 int bito_amd_engine_set_kernel(bito_amd_engine* e, int32_t kernel) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   e->kernel_choice = kernel;
+  for (auto& lanes : e->workers)
+    for (auto& w : lanes)
+      if (w) WorkerSetKernel(w.get(), kernel);
   return BITO_AMD_OK;
 }
 
 int bito_amd_engine_kernel_timing(bito_amd_engine* e, int32_t enable) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   e->timing = enable != 0;
-  e->ev_used = 0;
+  for (auto& lanes : e->workers)
+    for (auto& w : lanes)
+      if (w) WorkerKernelTiming(w.get(), enable);
   return BITO_AMD_OK;
 }
 
 int bito_amd_engine_kernel_elapsed(bito_amd_engine* e, double* kernel_ms, int32_t* kernel_launches) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
-  HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  double k = 0;
+  double total = 0;
   int launches = 0;
-  for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
-    float kms = 0;
-    HIP_TRY(e, hipEventElapsedTime(&kms, e->ev_pool[i], e->ev_pool[i + 1]));
-    k += kms;
-    launches++;
-  }
-  e->ev_used = 0;
-  if (kernel_ms) *kernel_ms = k;
+  for (auto& lanes : e->workers)
+    for (auto& w : lanes)
+      if (w) {
+        double ms = 0;
+        int32_t count = 0;
+        if (int rc = WorkerKernelElapsed(w.get(), &ms, &count)) return Propagate(e, w.get(), rc);
+        total += ms;
+        launches += count;
+      }
+  if (kernel_ms) *kernel_ms = total;
   if (kernel_launches) *kernel_launches = launches;
   return BITO_AMD_OK;
 }
 
 int bito_amd_engine_read_general_model(bito_amd_engine* e, int32_t tree, double* out, size_t capacity) {
   if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
-  const double* gs_model = e->gs_model.ptr;
-  if (!e->resident || tree < 0 || tree >= e->dims.tree_count || !gs_model || !e->gs_model_index.ptr)
-    return Fail(e, BITO_AMD_ERR_STATE, "no general-state model is resident for that tree");
-  HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  const size_t count = std::min<size_t>(capacity, (size_t)kGsModelStride);
-  int32_t slot = tree;
-  HIP_TRY(e, hipMemcpy(&slot, e->gs_model_index.ptr + tree, sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(e, hipMemcpy(out, gs_model + (size_t)slot * kGsModelStride, count * sizeof(double), hipMemcpyDeviceToHost));
-  return BITO_AMD_OK;
+  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no general-state model is resident for that tree");
+  for (const Shard& s : e->shards)
+    if (tree >= s.t0 && tree < s.t0 + s.count) {
+      Worker* w = ShardWorker(e, s);
+      return Propagate(e, w, WorkerReadGeneralModel(w, tree - s.t0, out, capacity));
+    }
+  return Fail(e, BITO_AMD_ERR_STATE, "no general-state model is resident for that tree");
 }
 
-const char* bito_amd_engine_kernel_name(const bito_amd_engine* e) { return e ? e->kernel_name.c_str() : ""; }
+const char* bito_amd_engine_kernel_name(const bito_amd_engine* e) {
+  if (!e) return "";
+  return WorkerKernelName(e->resident && !e->shards.empty() ? ShardWorker(e, e->shards[0]) : Primary(e));
+}
 
-int bito_amd_engine_time_runs(bito_amd_engine* e, int32_t want_gradient, int32_t rescaling,
-                              int32_t steps, double* total_ms, double* kernel_ms,
-                              int32_t* kernel_launches) {
+int bito_amd_engine_time_runs(bito_amd_engine* e, int32_t want_gradient, int32_t rescaling, int32_t steps,
+                              double* total_ms, double* kernel_ms, int32_t* kernel_launches) {
   if (!e || steps < 1) return BITO_AMD_ERR_BAD_ARG;
-  if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident");
-  HIP_TRY(e, hipSetDevice(e->device));
-  e->timing = true;
-  e->ev_used = 0;
-  hipEvent_t t0 = NextEvent(e), t1 = NextEvent(e);
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  HIP_TRY(e, hipEventRecord(t0, e->stream));
-  int rc = BITO_AMD_OK;
-  for (int s = 0; s < steps && !rc; s++) rc = RunResident(e, want_gradient != 0, rescaling != 0);
-  e->timing = false;
-  if (rc) return rc;
-  HIP_TRY(e, hipEventRecord(t1, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  float ms = 0;
-  HIP_TRY(e, hipEventElapsedTime(&ms, t0, t1));
-  if (total_ms) *total_ms = ms;
-  double k = 0;
-  int launches = 0;
-  for (size_t i = 2; i + 1 < e->ev_used; i += 2) {
-    float kms = 0;
-    HIP_TRY(e, hipEventElapsedTime(&kms, e->ev_pool[i], e->ev_pool[i + 1]));
-    k += kms;
-    launches++;
-  }
-  if (kernel_ms) *kernel_ms = k;
-  if (kernel_launches) *kernel_launches = launches;
-  return BITO_AMD_OK;
+  Worker* w = nullptr;
+  if (int rc = SingleShard(e, &w)) return rc;
+  w->one_shot = 0;
+  return Propagate(e, w, WorkerTimeRuns(w, want_gradient, rescaling, steps, total_ms, kernel_ms, kernel_launches));
 }
 
 }  // extern "C"

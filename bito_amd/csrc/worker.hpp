@@ -1,0 +1,263 @@
+// worker.hpp -- one GPU worker of the engine: a HIP device, its streams, the compressed alignment in HBM and one
+// resident batch of trees with everything the kernels derive from it.  The public C ABI (engine.cpp) owns one or
+// more workers per device: a blocking call cuts its tree collection into chunks, one per worker, so that the host
+// side of chunk k+1 (validation, staging) and the copies of chunk k-1 overlap the traversal of chunk k; an engine
+// over several devices shards the collection across them first (reference src/engine.cpp:10-31,
+// src/fat_beagle.hpp:151-184: N FatBeagle instances behind one Engine).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/bito_amd.h"
+#include "kernels.hpp"
+#include "model.hpp"
+
+namespace bito_amd {
+
+struct Block {
+  std::string name;
+  int32_t start, len;
+};
+
+template <typename T>
+struct DeviceBuffer {
+  T* ptr = nullptr;
+  size_t capacity = 0;  // elements
+  hipError_t Reserve(size_t count) {
+    if (count <= capacity) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    capacity = 0;
+    hipError_t rc = hipMalloc(reinterpret_cast<void**>(&ptr), count * sizeof(T));
+    if (rc == hipSuccess) capacity = count;
+    return rc;
+  }
+  void Free() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    capacity = 0;
+  }
+};
+
+// a typed window into another allocation (the input block)
+template <typename T>
+struct DeviceView {
+  T* ptr = nullptr;
+};
+
+// page-locked host memory (hipHostMalloc): copies to and from it are asynchronous and run at PCIe speed
+struct PinnedBuffer {
+  void* ptr = nullptr;
+  size_t capacity = 0;  // bytes
+  hipError_t Reserve(size_t bytes) {
+    if (bytes <= capacity) return hipSuccess;
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    capacity = 0;
+    bytes += bytes / 2;  // (grown with room to spare: allocating pinned memory takes milliseconds)
+    hipError_t rc = hipHostMalloc(&ptr, bytes, hipHostMallocDefault);
+    if (rc == hipSuccess) capacity = bytes;
+    return rc;
+  }
+  void Free() {
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    capacity = 0;
+  }
+};
+
+struct Worker {
+  ModelSpec spec{};
+  std::vector<Block> blocks;
+  int device = 0;
+  int n = 0, P = 0, Ppad = 0;
+  uint64_t arena_limit = 0;
+  hipStream_t stream = nullptr;
+  // Set-up pipeline of the LDS kernels: the set-up kernels of pass k+1 (topology, model, matrix images,
+  // step tables) run on prep_stream while earlier passes' traversals are still on `stream`; they write into the
+  // next of kSets buffer sets.  Events order the two streams: a set is not rewritten before the traversal that
+  // read it has finished, and a traversal does not start before its set is ready.  Three sets: the set-up of
+  // pass k+1 may start when pass k-2 has finished, a whole pass before it is needed -- walk_pipe_kernel keeps
+  // every CU until its queue of work is empty, so the set-up kernels mostly run in the tail of a traversal,
+  // and with two sets the next traversal waited for them there.
+  hipStream_t prep_stream = nullptr;
+  int serial_setup = 0;  // BITO_AMD_SERIAL_SETUP (measurements): 1 = the set-up kernels run on `stream`, in front of the traversal;
+                         // 2 = no set-up and no events after the first kSets passes (the buffer sets keep what they hold)
+  static constexpr int kSets = 3;
+  hipEvent_t ev_prep_done[kSets] = {nullptr, nullptr, nullptr}, ev_walk_done[kSets] = {nullptr, nullptr, nullptr};
+  unsigned run_counter = 0;
+  std::string err;
+  int kernel_choice = BITO_AMD_KERNEL_AUTO;
+  std::string kernel_name = "none";
+
+  // alignment
+  DeviceBuffer<uint8_t> tip_states;
+  DeviceBuffer<double> weights;
+  // resident batch
+  bool resident = false;
+  BatchDims dims{};
+  bool has_rates = false;
+  // the wire-format inputs of the resident batch are ONE device allocation, filled by one copy from the pinned
+  // staging buffer that has the same layout: branch lengths [T][M], parameter rows [T][pc], rates [T][M-1]
+  // (rooted trees with rates only), then the parent ids [T][M-1] as int32
+  DeviceBuffer<double> in_block;
+  DeviceView<int32_t> parent_ids;
+  DeviceView<double> branch_in, rates, params;
+  PinnedBuffer pin_order;  // staging of the two-class tree order (walk_pipe_kernel)
+  PinnedBuffer pin_in, pin_out;  // host staging: inputs as laid out above; results [ll T][gradient T*N][site T]
+  hipEvent_t ev_inputs = nullptr;   // recorded behind the copy of a batch's inputs (the set-up stream waits for it)
+  hipEvent_t ev_results = nullptr;  // recorded behind the copies of a pass's results into pin_out
+  bool inputs_pending = false;      // the copy of the resident batch's inputs may still be in flight
+  // Blocking calls (engine.cpp): this worker walks ONE chunk of the call, so its set-up kernels have no earlier
+  // traversal of its own to hide behind and run on `stream`, in front of the traversal -- no cross-stream events.
+  // 1: the GPU is otherwise idle (set-up kernels spread out); 2: another worker's traversal is running (packed).
+  int one_shot = 0;
+  int id_offset = 0;  // index of the resident block's first tree in the caller's collection (error messages)
+  DeviceBuffer<int32_t> children, sched, children2, sched2, children3, sched3;
+  DeviceBuffer<int32_t> pipe_masks;  // packed tip masks per pattern tile (walk_pipe_kernel): a function of the alignment and the plan
+  long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
+  DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
+  // walk_pipe_kernel in two launches: the trees of the resident batch that keep few enough vectors for four
+  // pattern groups per wave (class A), and the others (class B) -- one tree with few cherries would otherwise
+  // halve the groups of the whole batch
+  std::vector<int32_t> tree_cherries;  // per tree of the resident batch (counted while it is validated)
+  struct PipeSplit {
+    bool built = false, active = false;
+    int count_a = 0, count_b = 0, slots_a = 0;
+    LdsPlan plan_a{}, plan_b{};
+    std::vector<int32_t> order_host;
+  } pipe_split;
+  DeviceBuffer<int32_t> pipe_order;    // class A's tree ids, then class B's
+  DeviceBuffer<int32_t> pipe_masks_a;  // packed tip masks for class A's plan
+  long long pipe_masks_a_key = -1;
+  DeviceBuffer<double> branch, mats, mats2, mats3, images, arena, part_ll, part_grad,
+      out_grad, out_site, scale_arena, branch2, images2, branch3, images3;
+  // per-tree log-likelihoods: a ring, pass k writes slot k mod kOutRing, so that a consumer on another stream
+  // may still be reading a pass's values while the next passes run (WorkerResultsAsync)
+  static constexpr int kOutRing = 4;
+  DeviceBuffer<double> out_ll_ring[kOutRing];
+  unsigned out_slot = 0;
+  hipEvent_t last_pass_done = nullptr;  // recorded behind the last pass enqueued (one of ev_walk_done)
+  double* cur_ll() { return out_ll_ring[out_slot % kOutRing].ptr; }
+  bool site_ready = false;  // out_site holds the site-model gradient of the resident pass
+  double min_branch = 0.0;  // smallest branch length of the resident batch (known for 39 taxa and more only, else 0)
+  DeviceBuffer<TreeModel> model, model2, model3;
+  DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
+  DeviceBuffer<int32_t> gs_model_index;  // [T] first tree with the same parameter row
+  bool gs_index_valid = false;           // the index was built from the parameter rows that are resident now
+  // time-tree transforms (row f2): staging for host inputs, scratch and results
+  DeviceBuffer<int32_t> tt_parents;
+  DeviceBuffer<double> tt_heights, tt_bounds, tt_ratios, tt_in, tt_work, tt_out, tt_aux;
+  // host mirrors for the composed gradients
+  std::vector<double> h_params;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+
+  ~Worker() {
+    (void)hipSetDevice(device);
+    for (auto ev : ev_pool) (void)hipEventDestroy(ev);
+    tip_states.Free(); weights.Free(); in_block.Free(); children.Free(); pin_in.Free(); pin_out.Free(); pin_order.Free();
+    if (ev_inputs) (void)hipEventDestroy(ev_inputs);
+    if (ev_results) (void)hipEventDestroy(ev_results);
+    branch.Free(); mats.Free(); mats2.Free(); mats3.Free(); images.Free(); arena.Free(); scale_arena.Free(); part_ll.Free();
+    part_grad.Free(); out_grad.Free();
+    for (auto& r : out_ll_ring) r.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
+    tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
+    tt_out.Free(); tt_aux.Free();
+    children2.Free(); sched2.Free(); pipe_masks.Free(); pipe_queue.Free(); pipe_order.Free(); pipe_masks_a.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
+    children3.Free(); sched3.Free(); branch3.Free(); images3.Free(); model3.Free();
+    for (int i = 0; i < kSets; i++) {
+      if (ev_prep_done[i]) (void)hipEventDestroy(ev_prep_done[i]);
+      if (ev_walk_done[i]) (void)hipEventDestroy(ev_walk_done[i]);
+    }
+    if (prep_stream) (void)hipStreamDestroy(prep_stream);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+
+// ---- worker.cpp ----------------------------------------------------------------------------------------
+int WorkerCreate(int32_t device_id, uint64_t arena_bytes, const char* substitution, const char* site,
+                 const char* clock, int32_t taxon_count, int32_t pattern_count, const int32_t* patterns,
+                 const double* weights, Worker** out, std::string* err);
+void WorkerDestroy(Worker* e);
+const char* WorkerLastError(const Worker* e);
+int32_t WorkerParamCount(const Worker* e);
+int32_t WorkerCategoryCount(const Worker* e);
+int32_t WorkerStateCount(const Worker* e);
+int32_t WorkerBlockCount(const Worker* e);
+int WorkerBlock(const Worker* e, int32_t idx, char* name, size_t name_len, int32_t* start, int32_t* len);
+int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
+                const double* branch_lengths, const double* rates, const double* params, int wait);
+int WorkerUpload(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
+                 const double* branch_lengths, const double* rates, const double* params);
+int WorkerUpdate(Worker* e, const double* branch_lengths, const double* params);
+int WorkerRun(Worker* e, int32_t want_gradient, int32_t rescaling);
+// the pass with everything RunResident takes: deriv_mode 1 = the site-model pass (d r_c / d shape in place of r_c),
+// want_site = also produce the site-model gradient when the traversal kernel can (Worker::site_ready says so)
+int WorkerRunPass(Worker* e, int want_gradient, int rescaling, int deriv_mode, int want_site);
+int WorkerSync(Worker* e);
+int WorkerFetchResults(Worker* e, int want_gradient, int want_site);
+int WorkerResults(Worker* e, const double** ll, const double** grad, const double** site);
+int WorkerDownloadAsync(Worker* e, double* out_ll, double* out_grad);
+int WorkerResultsAsync(Worker* e, void* consumer_stream, const double** out_ll, const double** out_grad);
+int WorkerDownload(Worker* e, double* out_ll, double* out_grad);
+void* WorkerStream(Worker* e);
+int WorkerLogLikelihoods(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count,
+                         const int32_t* parent_ids, const double* branch_lengths, const double* rates,
+                         const double* params, int32_t rescaling, double* out);
+int WorkerGradients(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
+                    const double* branch_lengths, const double* rates, const double* params, int32_t rescaling,
+                    int32_t flags, double fd_delta, double* out_ll, double* out_branch, double* out_site,
+                    double* out_subst, double* out_clock);
+// the site-model gradient by a second traversal with dQ = Q d r_c / d shape (kernels that do not produce it in
+// the main pass); leaves the main pass's results resident again
+int WorkerSiteGradientSecondPass(Worker* e, int32_t rooted, int32_t node_count, const double* branch_lengths,
+                                 const double* rates, int32_t rescaling, double* out_site);
+int WorkerTimeTreesFromBranchLengths(Worker* e, int32_t tree_count, const int32_t* parent_ids,
+                                     const double* branch_lengths, const double* tip_dates, double* out_node_bounds,
+                                     double* out_node_heights, double* out_height_ratios);
+int WorkerTimeTreesFromHeightRatios(Worker* e, int32_t tree_count, const int32_t* parent_ids,
+                                    const double* node_bounds, const double* height_ratios, double* out_node_heights,
+                                    double* out_branch_lengths);
+int WorkerLogDetJacobian(Worker* e, int32_t tree_count, const int32_t* parent_ids, const double* node_heights,
+                         const double* node_bounds, double* out);
+int WorkerGradientLogDetJacobian(Worker* e, int32_t tree_count, const int32_t* parent_ids, const double* node_heights,
+                                 const double* node_bounds, const double* height_ratios, double* out);
+int WorkerRatioGradientOfHeightGradient(Worker* e, int32_t tree_count, const int32_t* parent_ids,
+                                        const double* node_heights, const double* node_bounds,
+                                        const double* height_ratios, const double* height_gradient, double* out);
+int WorkerTimeTreeLogLikelihoods(Worker* e, int32_t tree_count, const int32_t* parent_ids,
+                                 const double* branch_lengths, const double* rates, const double* node_heights,
+                                 const double* node_bounds, const double* params, int32_t rescaling,
+                                 int32_t include_log_det_jacobian, double* out);
+int WorkerTimeTreeGradients(Worker* e, int32_t tree_count, const int32_t* parent_ids, const double* branch_lengths,
+                            const double* rates, int32_t rate_count, const double* node_heights,
+                            const double* node_bounds, const double* height_ratios, const double* params,
+                            int32_t rescaling, int32_t flags, double fd_delta, double* out_ll, double* out_branch,
+                            double* out_site, double* out_subst, double* out_clock, double* out_ratios);
+int WorkerSetKernel(Worker* e, int32_t kernel);
+int WorkerKernelTiming(Worker* e, int32_t enable);
+int WorkerKernelElapsed(Worker* e, double* kernel_ms, int32_t* kernel_launches);
+int WorkerReadGeneralModel(Worker* e, int32_t tree, double* out, size_t capacity);
+const char* WorkerKernelName(const Worker* e);
+int WorkerTimeRuns(Worker* e, int32_t want_gradient, int32_t rescaling, int32_t steps, double* total_ms,
+                   double* kernel_ms, int32_t* kernel_launches);
+// FatBeagle::SubstitutionModelGradient (reference src/fat_beagle.cpp:412-508) as one batch of 2 x (#parameters)
+// perturbed copies of every tree, evaluated by `log_likelihoods(tree_count, parent_ids, branch_lengths, rates,
+// params, out)` -- one worker's blocking call, or the engine's over all of its workers.
+using LogLikelihoodFn = std::function<int(int32_t, const int32_t*, const double*, const double*, const double*, double*)>;
+int SubstitutionGradientsVia(const ModelSpec& m, int T, int rooted, int node_count, const int32_t* parent_ids,
+                             const double* branch_lengths, const double* rates, const double* params, bool stick,
+                             double delta, double* out_subst, const LogLikelihoodFn& log_likelihoods);
+// host-only pieces the engine level shares with the worker level
+void StickForward(const double* y, int K, double* x);
+void StickInverse(const double* x, int K, double* y);
+
+}  // namespace bito_amd

@@ -51,7 +51,9 @@ def _ip(a: np.ndarray):
 
 class Engine:
     def __init__(self, model: PhyloModelSpecification, patterns: np.ndarray, weights: np.ndarray,
-                 device_id: int = 0, use_tip_states: bool = True, arena_bytes: int = 0):
+                 device_id: int = 0, use_tip_states: bool = True, arena_bytes: int = 0, devices=None):
+        """``devices``: HIP ordinals of the GPUs this engine drives (default: ``[device_id]``); the counterpart of
+        the reference's ``thread_count`` (src/engine.cpp:10-31).  Blocking calls shard their trees over them."""
         self._h = None
         L = _capi.lib()
         self.patterns = np.ascontiguousarray(patterns, dtype=np.int32)
@@ -59,7 +61,11 @@ class Engine:
         if self.patterns.ndim != 2 or self.patterns.shape[1] != self.weights.shape[0]:
             raise BitoAmdError(_capi.ERR_BAD_ARG, "patterns must be [taxon_count][pattern_count] and match weights")
         n, P = self.patterns.shape
-        spec = _capi.EngineSpec(device_id, int(use_tip_states), arena_bytes)
+        devs = [int(device_id)] if devices is None else [int(d) for d in devices]
+        if not devs:
+            raise BitoAmdError(_capi.ERR_BAD_ARG, "Device count needs to be strictly positive.")
+        dev_array = (C.c_int32 * len(devs))(*devs)
+        spec = _capi.EngineSpec(devs[0], int(use_tip_states), arena_bytes, len(devs), 0, dev_array)
         h = C.c_void_p()
         err = C.create_string_buffer(512)
         rc = L.bito_amd_engine_create(C.byref(spec), model.substitution.encode(), model.site.encode(),
@@ -76,6 +82,8 @@ class Engine:
         self.state_count = L.bito_amd_engine_state_count(h)
         self.tree_count = 0
         self._node_count = 2 * n - 1
+        self._resident_shape = None
+        self.device_count = L.bito_amd_engine_device_count(h)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -146,8 +154,55 @@ class Engine:
         self._check(_capi.lib().bito_amd_engine_log_likelihoods(
             self._h, T, rooted, M, _ip(parent_ids), _dp(branch_lengths), _dp(rates), _dp(params), int(rescaling),
             _dp(out)))
-        self.tree_count = T
+        self._set_resident(T, M)
         return out
+
+    def log_likelihoods_into(self, parent_ids: np.ndarray, branch_lengths: np.ndarray, params: np.ndarray,
+                             out: np.ndarray, rescaling: bool = False):
+        """``log_likelihoods`` without per-call allocations or conversions, for callers that evaluate in a loop:
+        C-contiguous arrays of the exact dtypes (int32 parent ids, float64 elsewhere), unrooted or rooted by shape,
+        results written into ``out`` [T]."""
+        T, M = self._lean_check(parent_ids, branch_lengths, params, out)
+        self._check(_capi.lib().bito_amd_engine_log_likelihoods(
+            self._h, T, int(M == 2 * self.taxon_count - 1), M, _ip(parent_ids), _dp(branch_lengths), None,
+            _dp(params) if self.param_count else None, int(rescaling), _dp(out)))
+        self._set_resident(T, M)
+
+    def gradients_into(self, parent_ids: np.ndarray, branch_lengths: np.ndarray, params: np.ndarray,
+                       out_ll: np.ndarray, out_branch: np.ndarray, rescaling: bool = False):
+        """``gradients`` (log-likelihoods + branch-length gradients) into caller-owned arrays ``out_ll`` [T] and
+        ``out_branch`` [T][2n-1]; the span of the reference's ``Engine::Gradients`` call -- host trees and
+        parameter rows in, host results out (src/fat_beagle.hpp:173-181) -- with nothing else around it."""
+        T, M = self._lean_check(parent_ids, branch_lengths, params, out_ll)
+        if out_branch.dtype != np.float64 or not out_branch.flags.c_contiguous or \
+                out_branch.shape != (T, 2 * self.taxon_count - 1):
+            raise BitoAmdError(_capi.ERR_BAD_ARG, "out_branch must be a C-contiguous float64 [T][2n-1] array")
+        self._check(_capi.lib().bito_amd_engine_gradients(
+            self._h, T, int(M == 2 * self.taxon_count - 1), M, _ip(parent_ids), _dp(branch_lengths), None,
+            _dp(params) if self.param_count else None, int(rescaling), 0, 0.0, _dp(out_ll), _dp(out_branch), None,
+            None, None))
+        self._set_resident(T, M)
+
+    def _lean_check(self, parent_ids, branch_lengths, params, out_ll):
+        ok = (parent_ids.dtype == np.int32 and branch_lengths.dtype == np.float64 and out_ll.dtype == np.float64 and
+              parent_ids.flags.c_contiguous and branch_lengths.flags.c_contiguous and out_ll.flags.c_contiguous and
+              branch_lengths.ndim == 2 and parent_ids.ndim == 2)
+        if not ok:
+            raise BitoAmdError(_capi.ERR_BAD_ARG, "the *_into calls take C-contiguous int32 / float64 arrays as they are")
+        T, M = branch_lengths.shape
+        if parent_ids.shape != (T, M - 1) or out_ll.shape != (T,):
+            raise BitoAmdError(_capi.ERR_BAD_ARG, "parent_ids must be [T][M-1], branch_lengths [T][M], out [T]")
+        if self.param_count and (params is None or params.dtype != np.float64 or not params.flags.c_contiguous or
+                                 params.shape != (T, self.param_count)):
+            raise BitoAmdError(_capi.ERR_BAD_ARG, f"param matrix needs shape ({T}, {self.param_count}), float64")
+        return T, M
+
+    def _set_resident(self, T: int, M: int):
+        """Every call that takes a tree collection leaves it resident on the device(s): ``update`` / ``run`` /
+        ``download`` then refer to it (the C side keeps the same record)."""
+        self.tree_count = T
+        self._node_count = 2 * self.taxon_count - 1
+        self._resident_shape = (T, M)
 
     def gradients(self, parent_ids, branch_lengths, params=None, rates=None, rescaling=False, flags=0,
                   fd_delta=1e-6) -> Dict[str, np.ndarray]:
@@ -163,7 +218,7 @@ class Engine:
         self._check(_capi.lib().bito_amd_engine_gradients(
             self._h, T, rooted, M, _ip(parent_ids), _dp(branch_lengths), _dp(rates), _dp(params), int(rescaling),
             flags, fd_delta, _dp(ll), _dp(branch), _dp(site), _dp(subst), _dp(clock)))
-        self.tree_count = T
+        self._set_resident(T, M)
         return self._package(flags, rooted, ll, branch, site, subst, clock)
 
     def _package(self, flags, rooted, ll, branch, site, subst, clock) -> Dict[str, np.ndarray]:
@@ -264,7 +319,7 @@ class Engine:
         self._check(_capi.lib().bito_amd_engine_time_tree_log_likelihoods(
             self._h, T, _ip(parent_ids), _dp(branch_lengths), _dp(rates), _dp(heights), _dp(bounds), _dp(params),
             int(rescaling), int(include_log_det_jacobian), _dp(out)))
-        self.tree_count = T
+        self._set_resident(T, M)
         return out
 
     def time_tree_gradients(self, parent_ids, branch_lengths, node_heights, node_bounds, height_ratios, params=None,
@@ -289,7 +344,7 @@ class Engine:
             self._h, T, _ip(parent_ids), _dp(branch_lengths), _dp(rates), int(rate_count), _dp(heights), _dp(bounds),
             _dp(ratios), _dp(params), int(rescaling), flags, fd_delta, _dp(ll), _dp(branch), _dp(site), _dp(subst),
             _dp(clock), _dp(ratio_grad)))
-        self.tree_count = T
+        self._set_resident(T, M)
         out = self._package(flags, rooted, ll, branch, site, subst, clock)
         if ratio_grad is not None:
             out["ratios_root_height"] = ratio_grad
@@ -300,9 +355,7 @@ class Engine:
         parent_ids, branch_lengths, rates, params, T, M, rooted = self._prep(parent_ids, branch_lengths, rates, params)
         self._check(_capi.lib().bito_amd_engine_upload(self._h, T, rooted, M, _ip(parent_ids), _dp(branch_lengths),
                                                        _dp(rates), _dp(params)))
-        self.tree_count = T
-        self._node_count = 2 * self.taxon_count - 1
-        self._resident_shape = (T, M)
+        self._set_resident(T, M)
 
     def update(self, branch_lengths=None, params=None):
         """New branch lengths and/or parameter rows for the resident batch; the C side copies

@@ -36,8 +36,11 @@ struct PhyloGradient {             // src/phylo_gradient.hpp:10-35
 class Engine {
  public:
   Engine(const PhyloModelSpecification& spec, int32_t taxon_count, int32_t pattern_count,
-         const std::vector<int32_t>& patterns, const std::vector<double>& weights, int32_t device_id = 0) {
-    bito_amd_engine_spec es{device_id, 1, 0};
+         const std::vector<int32_t>& patterns, const std::vector<double>& weights, int32_t device_id = 0,
+         int32_t device_count = 1, const std::vector<int32_t>& devices = {}) {
+    // device_count stands where the reference has thread_count (src/engine.hpp:20-24): how many FatBeagle
+    // instances -- here GPUs -- serve one call
+    bito_amd_engine_spec es{device_id, 1, 0, device_count, 0, devices.empty() ? nullptr : devices.data()};
     char err[512] = {0};
     const int rc = bito_amd_engine_create(&es, spec.substitution_.c_str(), spec.site_.c_str(), spec.clock_.c_str(),
                                           taxon_count, pattern_count, patterns.data(), weights.data(), &e_, err,

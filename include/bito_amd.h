@@ -2,8 +2,9 @@
  * bito_amd.h -- C ABI of the MI355X-native likelihood engine that replaces
  * bito's FatBeagle/Engine path (seam 2).
  *
- * Plain C: opaque handle, pointers and sizes only.  One engine = one GPU
- * (one process per GPU).  Every entry point below names the reference
+ * Plain C: opaque handle, pointers and sizes only.  One engine = one or more GPUs of
+ * one node driven from the calling thread (bito_amd_engine_spec.device_count); one process
+ * per GPU with one single-device engine each works as well (bench.py).  Every entry point below names the reference
  * interface it stands in for; bito's own host code above this line (tree
  * collections, SBN instances, pybind11 module) stays as it is -- see
  * INTEGRATION.md for the binding a bito maintainer would add.
@@ -57,14 +58,23 @@ extern "C" {
 
 typedef struct bito_amd_engine bito_amd_engine;
 
-/* Replaces EngineSpecification (reference src/engine.hpp:20-24).  thread_count
- * has no meaning on a GPU; what remains is which device this engine owns. */
+/* Replaces EngineSpecification (reference src/engine.hpp:20-24).  The reference's one parallel axis lives inside
+ * Engine -- thread_count FatBeagle instances behind one queue of trees (src/engine.cpp:10-31,
+ * src/fat_beagle.hpp:151-184); here it is device_count GPUs behind one engine: every blocking call shards its
+ * tree collection contiguously over the devices, drives all of them from the calling thread (streams, no extra
+ * process) and gathers the results into the caller's arrays. */
 typedef struct {
-  int32_t device_id;      /* HIP device ordinal */
+  int32_t device_id;      /* HIP ordinal of the first device */
   int32_t use_tip_states; /* accepted for API parity (engine.hpp:23); tips are always
                              held as compact states, which is what BEAGLE's
                              tip-state path computes (fat_beagle.cpp:269-275) */
-  uint64_t arena_bytes;   /* cap on the HBM PLV arena; 0 = default (3/4 of free HBM: one engine owns its GPU) */
+  uint64_t arena_bytes;   /* cap on the HBM PLV arena per device; 0 = default (3/4 of free HBM: the engine owns its GPUs) */
+  int32_t device_count;   /* GPUs this engine drives, >= 1 ("Thread count needs to be strictly positive.",
+                             src/engine.cpp:14-16) */
+  int32_t reserved;       /* 0 */
+  const int32_t *devices; /* device_count HIP ordinals, or NULL: device_id, device_id + 1, ...  A device may be named
+                             more than once (each entry is served like a device of its own): that is how the
+                             multi-device path is exercised on a one-GPU machine. */
 } bito_amd_engine_spec;
 
 /*
@@ -104,6 +114,7 @@ int32_t bito_amd_engine_param_count(const bito_amd_engine *e);
 int32_t bito_amd_engine_category_count(const bito_amd_engine *e);
 int32_t bito_amd_engine_state_count(const bito_amd_engine *e); /* 4, or 61 for "GY94" */
 int32_t bito_amd_engine_block_count(const bito_amd_engine *e);
+int32_t bito_amd_engine_device_count(const bito_amd_engine *e); /* device slots of this engine */
 int bito_amd_engine_block(const bito_amd_engine *e, int32_t idx, char *name,
                           size_t name_len, int32_t *start, int32_t *len);
 

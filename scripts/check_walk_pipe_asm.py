@@ -21,6 +21,8 @@ def main(path):
     kernel = None
     stray = 0
     kernels = 0
+    meta = ""
+    spilled = []
     for line in open(path):
         m = re.match(r"^(_ZN8bito_amd16walk_pipe_kernel\w+):", line)
         if m:
@@ -33,10 +35,20 @@ def main(path):
             inside = False
             continue
         text = line.strip()
-        if inside or not kernel or not text or text[0] in ";.":
-            continue
-        if text.startswith("s_endpgm"):
+        # a kernel's code ends at its .Lfunc_end label / .size directive, not at the first s_endpgm: LLVM may emit
+        # several exits and place blocks behind the first one
+        if kernel and (text.startswith(".Lfunc_end") or text.startswith(".size")):
             kernel = None
+            continue
+        # the kernels' metadata records (end of the file).  Spilled VGPRs are parked in AGPRs (above the images:
+        # the scan below covers every instruction of the function, spill code included) or in scratch; reported only.
+        m = re.match(r"^\.name:\s+(\S+)", text)
+        if m:
+            meta = m.group(1)
+        m = re.match(r"^\.vgpr_spill_count:\s+(\d+)", text)
+        if m and "walk_pipe_kernel" in meta and int(m.group(1)) > 0:
+            spilled.append((meta, int(m.group(1))))
+        if inside or not kernel or not text or text[0] in ";.":
             continue
         for mm in re.finditer(r"\ba\[?(\d+)", text.split(";")[0]):
             if int(mm.group(1)) < LIMIT:
@@ -49,7 +61,8 @@ def main(path):
     if stray:
         print(f"{stray} uses of a0..a{LIMIT - 1} outside the asm statements", file=sys.stderr)
         return 1
-    print(f"{kernels} walk_pipe_kernel instantiations: a0..a{LIMIT - 1} untouched outside the asm statements")
+    print(f"{kernels} walk_pipe_kernel instantiations: a0..a{LIMIT - 1} untouched outside the asm statements"
+          + (f" ({len(spilled)} instantiations spill VGPRs, at most {max(c for _, c in spilled)}: none into the image registers)" if spilled else ""))
     return 0
 
 

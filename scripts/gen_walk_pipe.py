@@ -1061,7 +1061,7 @@ def as_macro(name, lines):
 def clobbers(loops):
     regs = [f"v{r}" for r in range(VBASE, loops.vnext)] + [f"a{r}" for r in range(Loops.IMAGE_REGS)] + \
            [f"s{r}" for r in range(SBASE, loops.snext)]
-    return ", ".join(f'"{r}"' for r in regs) + ', "vcc", "scc", "memory"  /* (and m0, which the compiler treats as reserved) */'
+    return ", ".join(f'"{r}"' for r in regs) + ', "vcc", "scc", "memory"  /* (not m0: clang rejects it on a clobber list as a reserved register; it keeps no value there across a statement) */'
 
 
 def main():
