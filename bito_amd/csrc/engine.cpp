@@ -49,9 +49,11 @@ struct bito_amd_engine {
   int rooted = 0, node_count = 0, tree_count = 0;
   std::vector<Shard> shards;
   std::string err;
-  // chunking of blocking calls (BITO_AMD_CHUNK_FIRST / _GROWTH / _CAP / _LANES: measurements)
-  int chunk_first = 256, chunk_cap = 2048, max_lanes = 6;
-  double chunk_growth = 2.0;
+  // chunking of blocking calls (BITO_AMD_CHUNK_FIRST / _GROWTH / _CAP / _LANES / _RESERVE: measurements;
+  // scripts/gpu_chunk_sweep.sh: 4.24 ms per 6400 config-3 trees with these, 4.9 with first = 128, growth = 1.5)
+  int chunk_first = 512, chunk_cap = 2048, max_lanes = 8, reserve_cus = 0;
+  double chunk_growth = 3.0;
+  int walk_streams = 2;
 };
 
 namespace {
@@ -173,8 +175,24 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
     const Shard& s = e->shards[k];
     Worker* w = ShardWorker(e, s);
     w->one_shot = slot_busy[s.slot] ? 2 : 1;
+    // The slot's stream pair: every chunk's traversal, final sums and completion flag on the first worker's
+    // stream, in order; the copies and set-up kernels of the later chunks on its (low-priority) set-up stream,
+    // beside the traversal of the chunk before.  Two streams per device, whatever the number of chunks: the
+    // runtime multiplexes streams onto four hardware queues, and with a stream per chunk the chunks' commands
+    // queued up behind one another's traversals (measured: copies waiting a millisecond).
+    // (walk_streams == 2: the chunks' traversals alternate between the first two workers' streams, so that chunk
+    // k+1's resident workgroups move in as chunk k's leave -- the ragged end of one launch filled by the next)
+    Worker* first = e->workers[s.slot][0].get();
+    Worker* second = (e->walk_streams > 1 && e->workers[s.slot].size() > 1) ? e->workers[s.slot][1].get() : first;
+    w->lent_walk = s.lane > 0 ? ((s.lane & 1) ? second->stream : first->stream) : nullptr;
+    w->lent_setup = s.lane > 0 ? first->prep_stream : nullptr;
     w->id_offset = s.t0;
     slot_busy[s.slot] = 1;
+    // a traversal holds every CU it is given until its queue of work is empty: while a later chunk of this device
+    // still has its set-up kernels to run, it leaves them one CU per XCD
+    w->reserve_cus = 0;
+    for (size_t later = k + 1; later < e->shards.size(); later++)
+      if (e->shards[later].slot == s.slot) w->reserve_cus = e->reserve_cus;
     int rc = WorkerStage(w, s.count, rooted, node_count, parent_ids + (size_t)s.t0 * (M - 1),
                          branch_lengths + (size_t)s.t0 * M, has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr,
                          pc > 0 ? params + (size_t)s.t0 * pc : nullptr, /*wait=*/0);
@@ -186,7 +204,7 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
       return rc;
     }
     // results that have arrived meanwhile (in order: the chunks finish in the order they were issued, near enough)
-    while (drained < k && hipEventQuery(ShardWorker(e, e->shards[drained])->ev_results) == hipSuccess)
+    while (drained < k && WorkerResultsReady(ShardWorker(e, e->shards[drained])))
       if (int rc2 = drain(drained++)) {
         SyncShards(e, k + 1);
         return rc2;
@@ -276,6 +294,8 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
   if (const char* v = std::getenv("BITO_AMD_CHUNK_FIRST")) e->chunk_first = std::max(1, std::atoi(v));
   if (const char* v = std::getenv("BITO_AMD_CHUNK_CAP")) e->chunk_cap = std::max(1, std::atoi(v));
   if (const char* v = std::getenv("BITO_AMD_CHUNK_GROWTH")) e->chunk_growth = std::max(1.0, std::atof(v));
+  if (const char* v = std::getenv("BITO_AMD_CHUNK_WALK_STREAMS")) e->walk_streams = std::atoi(v);
+  if (const char* v = std::getenv("BITO_AMD_CHUNK_RESERVE")) e->reserve_cus = std::max(0, std::atoi(v));
   if (const char* v = std::getenv("BITO_AMD_CHUNK_LANES")) e->max_lanes = std::min(kMaxLanes, std::max(1, std::atoi(v)));
   // the first worker of every device now (model strings, device ordinals and the alignment are checked here);
   // further lanes when a call first needs them
@@ -401,6 +421,7 @@ int bito_amd_engine_time_tree_log_likelihoods(bito_amd_engine* e, int32_t tree_c
   Worker* w = Primary(e);
   e->resident = false;
   w->one_shot = 0;
+  w->reserve_cus = 0;
   w->id_offset = 0;
   const int rc = WorkerTimeTreeLogLikelihoods(w, tree_count, parent_ids, branch_lengths, rates, node_heights,
                                               node_bounds, params, rescaling, include_log_det_jacobian, out);
@@ -419,6 +440,7 @@ int bito_amd_engine_time_tree_gradients(bito_amd_engine* e, int32_t tree_count, 
   Worker* w = Primary(e);
   e->resident = false;
   w->one_shot = 0;
+  w->reserve_cus = 0;
   w->id_offset = 0;
   const int rc = WorkerTimeTreeGradients(w, tree_count, parent_ids, branch_lengths, rates, rate_count, node_heights,
                                          node_bounds, height_ratios, params, rescaling, flags, fd_delta, out_ll,
@@ -449,6 +471,7 @@ int bito_amd_engine_upload(bito_amd_engine* e, int32_t tree_count, int32_t roote
   for (const Shard& s : e->shards) {
     Worker* w = ShardWorker(e, s);
     w->one_shot = 0;
+  w->reserve_cus = 0;
     w->id_offset = s.t0;
     const int rc = WorkerStage(w, s.count, rooted, node_count, parent_ids + (size_t)s.t0 * (M - 1),
                                branch_lengths + (size_t)s.t0 * M, has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr,
@@ -484,6 +507,7 @@ int bito_amd_engine_run(bito_amd_engine* e, int32_t want_gradient, int32_t resca
   for (const Shard& s : e->shards) {
     Worker* w = ShardWorker(e, s);
     w->one_shot = 0;  // passes over a resident batch are pipelined: the set-up of pass k+1 beside the traversal of pass k
+    w->reserve_cus = 0;
     if (int rc = WorkerRun(w, want_gradient, rescaling)) return Propagate(e, w, rc);
   }
   return BITO_AMD_OK;
@@ -587,6 +611,7 @@ int bito_amd_engine_time_runs(bito_amd_engine* e, int32_t want_gradient, int32_t
   Worker* w = nullptr;
   if (int rc = SingleShard(e, &w)) return rc;
   w->one_shot = 0;
+  w->reserve_cus = 0;
   return Propagate(e, w, WorkerTimeRuns(w, want_gradient, rescaling, steps, total_ms, kernel_ms, kernel_launches));
 }
 

@@ -18,6 +18,7 @@
 // FP64 throughout.  No atomics anywhere: every sum has a fixed order, so results
 // are bit-reproducible run to run.
 #include "kernels.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 #ifndef HBM_PRE_UNROLL
@@ -92,44 +93,95 @@ setup_large_trees_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
   if (tid == 0) SetupTreeModel(spec, b.params + (size_t)t * spec.param_count, &b.model[t]);
 }
 
-static size_t SetupLdsBytesPerTree(const BatchDims& d) {
-  return d.node_count * sizeof(double) + (d.in_node_count - 1 + 2 * (d.taxon_count - 1)) * sizeof(int32_t);
+static size_t SetupLdsBytesPerTree(const BatchDims& d, const ModelSpec& spec) {
+  // effective branch lengths [N], parameter row, rates [M-1] (rooted trees only: 0 doubles when there are none is
+  // decided at launch; sized for them here), parent ids [M-1], child lists [2 NI]
+  return ((size_t)d.node_count + std::max(spec.param_count, 1) + (d.rooted ? d.in_node_count - 1 : 0)) * sizeof(double) +
+         (d.in_node_count - 1 + 2 * (d.taxon_count - 1)) * sizeof(int32_t);
 }
 
-__global__ void __launch_bounds__(128)
+// The wire-format rows of the workgroup's trees go through LDS: coalesced loads (from HBM, or straight from the
+// caller's pinned staging buffer over PCIe -- a blocking call's chunk, which then also leaves the device copies for
+// later passes, DeviceBatch::copy_*), one thread per tree out of LDS, coalesced stores.
+// (element i of a workgroup's slice of a wire-format array: loaded by thread i mod 256, four elements per thread in
+// flight at once -- over PCIe a load takes two microseconds, and a loop that waits for each one before it issues the
+// next costs a workgroup of sixteen trees thirty)
+template <typename T, typename Store>
+__device__ __forceinline__ void StageSlice(const T* __restrict__ src, T* __restrict__ copy, int total, int tid,
+                                           const Store& store) {
+  constexpr int kStep = 256, kInFlight = 4;
+  for (int i0 = tid; i0 < total; i0 += kStep * kInFlight) {
+    T v[kInFlight];
+#pragma unroll
+    for (int u = 0; u < kInFlight; u++) {
+      const int i = i0 + u * kStep;
+      v[u] = i < total ? src[i] : T();
+    }
+#pragma unroll
+    for (int u = 0; u < kInFlight; u++) {
+      const int i = i0 + u * kStep;
+      if (i < total) {
+        store(i, v[u]);
+        if (copy != nullptr) copy[i] = v[u];
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
 setup_trees_lds_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, int trees) {
   extern __shared__ double setup_lds[];
   const int n = d.taxon_count, N = d.node_count, M = d.in_node_count, NI = n - 1;
+  const int pc = spec.param_count > 0 ? spec.param_count : 1, RW = (d.rooted && b.rates != nullptr) ? M - 1 : 0;
   const int t0 = blockIdx.x * trees, tid = threadIdx.x, step = blockDim.x;
   const int count = min(trees, d.tree_count - t0);
   double* bl = setup_lds;                                        // [trees][N]
-  int32_t* par = reinterpret_cast<int32_t*>(bl + trees * N);     // [trees][M-1]
+  double* prm = bl + trees * N;                                  // [trees][pc]
+  double* rts = prm + trees * pc;                                // [trees][M-1] (rooted trees with rates)
+  int32_t* par = reinterpret_cast<int32_t*>(rts + trees * (d.rooted ? M - 1 : 0));  // [trees][M-1]
   int32_t* ch = par + trees * (M - 1);                           // [trees][2 NI]
-  for (int i = tid; i < count * (M - 1); i += step) par[i] = b.parent_ids[(size_t)t0 * (M - 1) + i];
-  for (int i = tid; i < count * M; i += step) bl[(i / M) * N + i % M] = b.branch_in[(size_t)t0 * M + i];
+  StageSlice(b.parent_ids + (size_t)t0 * (M - 1), b.copy_parent_ids ? b.copy_parent_ids + (size_t)t0 * (M - 1) : nullptr,
+             count * (M - 1), tid, [&](int i, int32_t v) { par[i] = v; });
+  StageSlice(b.branch_in + (size_t)t0 * M, b.copy_branch_in ? b.copy_branch_in + (size_t)t0 * M : nullptr, count * M, tid,
+             [&](int i, double v) { bl[(i / M) * N + i % M] = v; });
+  if (spec.param_count > 0)
+    StageSlice(b.params + (size_t)t0 * pc, b.copy_params ? b.copy_params + (size_t)t0 * pc : nullptr, count * pc, tid,
+               [&](int i, double v) { prm[i] = v; });
+  if (RW)
+    StageSlice(b.rates + (size_t)t0 * RW, b.copy_rates ? b.copy_rates + (size_t)t0 * RW : nullptr, count * RW, tid,
+               [&](int i, double v) { rts[i] = v; });
   __syncthreads();
   if (tid < count)
-    SetupTopologyCore(d, par + tid * (M - 1), ch + tid * 2 * NI, bl + tid * N,
-                      b.rates != nullptr ? b.rates + (size_t)(t0 + tid) * (M - 1) : nullptr);
+    SetupTopologyCore(d, par + tid * (M - 1), ch + tid * 2 * NI, bl + tid * N, RW ? rts + tid * RW : nullptr);
   __syncthreads();
   for (int i = tid; i < count * 2 * NI; i += step) b.children[(size_t)t0 * 2 * NI + i] = ch[i];
   for (int i = tid; i < count * N; i += step) b.branch[(size_t)t0 * N + i] = bl[i];
-  if (tid < count) SetupTreeModel(spec, b.params + (size_t)(t0 + tid) * spec.param_count, &b.model[t0 + tid]);
+  if (tid < count) SetupTreeModel(spec, prm + tid * pc, &b.model[t0 + tid]);
 }
+
+// trees per workgroup of setup_trees_lds_kernel for this batch, 0: another kernel
+static int SetupLdsTrees(const BatchDims& d, const ModelSpec& spec, bool beside_traversal) {
+  const size_t per_tree = SetupLdsBytesPerTree(d, spec);
+  for (int trees : {128, 64, 32, 16}) {
+    if (per_tree * 16 > 48 * 1024) break;  // (larger trees: a workgroup per tree)
+    if (per_tree * trees > 144 * 1024) continue;
+    if (trees > 16 && (!beside_traversal || d.tree_count < 4 * trees)) continue;  // (alone, or a small batch: spread it)
+    return trees;
+  }
+  return 0;
+}
+
+bool SetupReadsHostInputs(const BatchDims& d, const ModelSpec& spec) { return SetupLdsTrees(d, spec, false) > 0; }
 
 void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int,
                  hipStream_t stream, bool beside_traversal) {
-  const size_t per_tree = SetupLdsBytesPerTree(d);
-  for (int trees : {128, 64, 32, 16}) {
-    if (per_tree * 16 > 48 * 1024) break;  // (larger trees: a workgroup per tree, below)
-    if (per_tree * trees > 144 * 1024) continue;
-    if (trees > 16 && (!beside_traversal || d.tree_count < 4 * trees)) continue;  // (alone, or a small batch: spread it)
+  const size_t per_tree = SetupLdsBytesPerTree(d, spec);
+  if (const int trees = SetupLdsTrees(d, spec, beside_traversal)) {
     if (per_tree * trees > 48 * 1024)  // (per device: a process may drive several)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(setup_trees_lds_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     const int blocks = (d.tree_count + trees - 1) / trees;
-    hipLaunchKernelGGL(setup_trees_lds_kernel, dim3(blocks), dim3(trees < 64 ? 64 : trees), per_tree * trees, stream, d,
-                       spec, b, trees);
+    hipLaunchKernelGGL(setup_trees_lds_kernel, dim3(blocks), dim3(256), per_tree * trees, stream, d, spec, b, trees);
     return;
   }
   const size_t large = ((size_t)2 * (d.taxon_count - 1) + 1) * sizeof(int);
@@ -656,6 +708,17 @@ void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_
   const int blocks = (int)((total + 255) / 256);
   hipLaunchKernelGGL(reduce_tiles_kernel, dim3(blocks), dim3(256), 0, stream, d, b, tiles, grad_rows,
                      want_gradient);
+}
+
+// Completion flag of a blocking call's chunk: stored behind the kernels that wrote the chunk's results into pinned
+// host memory (a kernel boundary on one stream orders it behind their stores), polled by the host.
+__global__ void signal_kernel(unsigned long long* flag, unsigned long long value) {
+  __threadfence_system();
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void LaunchSignal(unsigned long long* flag, unsigned long long value, hipStream_t stream) {
+  hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, stream, flag, value);
 }
 
 }  // namespace bito_amd

@@ -45,6 +45,11 @@ struct DeviceBatch {
   const double* branch_in;    // [T][M]
   const double* rates;        // [T][M-1] or nullptr
   const double* params;       // [T][param_count]
+  // A blocking call's chunk hands the set-up kernel its inputs in pinned HOST memory (the four pointers above;
+  // device-readable) instead of copying them first; the kernel then also leaves the device copies later passes
+  // over the batch read (null otherwise).  setup_trees_lds_kernel only: SetupReadsHostInputs(d).
+  int32_t* copy_parent_ids;
+  double *copy_branch_in, *copy_rates, *copy_params;
   // alignment
   const uint8_t* tip_states;  // [n][Ppad], 4 = gap (padding = gap)
   const double* weights;      // [Ppad], padding = 0
@@ -120,6 +125,9 @@ __device__ inline void SetupTopology(const BatchDims& d, const DeviceBatch& b, i
 // CUs as possible (up to 128 trees per workgroup) rather than finish as early as possible (16 per workgroup)
 void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, int want_gradient,
                  hipStream_t stream, bool beside_traversal = false);
+// does LaunchSetup pick the kernel that stages a workgroup's wire-format rows through LDS -- the one that can read
+// them from pinned host memory and leave the device copies (DeviceBatch::copy_*)?
+bool SetupReadsHostInputs(const BatchDims& d, const ModelSpec& spec);
 // deriv_mode 0: dP = P (r_c Q); 1: dP = P ((d r_c / d shape) Q) for the site-model gradient pass.
 void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, int deriv_mode,
                     hipStream_t stream);
@@ -162,6 +170,8 @@ struct PipeClass {
   const int32_t* order;    // their ids (device), or nullptr: trees 0 .. tree_count-1
   const uint32_t* masks;   // packed tip masks built for this launch's plan
   int row_stride;          // partial rows per tree the reduction adds up
+  int reserve_cus = 0;     // CUs this launch leaves free: a blocking call's next chunk has its set-up kernels to run
+                           // while this traversal holds every other CU (engine.cpp)
 };
 size_t PipeScheduleInts(const BatchDims& d);
 size_t PipeMaskInts(const BatchDims& d, const LdsPlan& plan);
@@ -212,6 +222,8 @@ void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int c
 // grad_rows: partial gradient rows per tree (default: one per tile; the HBM-arena kernel writes one per wave)
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
                   hipStream_t stream, int grad_rows = 0);
+// one thread stores `value` to `flag` (pinned host memory) behind everything enqueued on the stream so far
+void LaunchSignal(unsigned long long* flag, unsigned long long value, hipStream_t stream);
 
 // ---- general-state-count path (gs_kernels.hip): the 61-state codon model, states padded to 64 ----
 // Per-model record, doubles: V [64][64], V^-1 [64][64], Q [64][64], lambda [64], pi [64] (padding 0),

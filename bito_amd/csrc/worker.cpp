@@ -36,6 +36,16 @@ int Fail(Worker* e, int code, const std::string& msg) {
                   std::string(#call) + " failed: " + hipGetErrorString(rc_));         \
   } while (0)
 
+// The two streams of a pass.  Passes over a resident batch: the worker's own pair (set-up of pass k+1 on
+// prep_stream beside the traversal of pass k on stream).  A blocking call's chunk (one_shot): the pair its
+// device slot lends it (engine.cpp) -- every chunk's traversal on ONE stream, in order, every later chunk's copy and
+// set-up kernels on ONE other stream -- or, for the slot's first chunk, everything in line on the worker's stream.
+hipStream_t SetupStream(const Worker* e) {
+  if (e->one_shot) return e->lent_setup ? e->lent_setup : e->stream;
+  return e->serial_setup ? e->stream : e->prep_stream;
+}
+hipStream_t WalkStream(const Worker* e) { return (e->one_shot && e->lent_walk) ? e->lent_walk : e->stream; }
+
 // PhyloModel::OfSpecification + BlockSpecification layout
 // (reference src/phylo_model.cpp:6-24, src/block_specification.cpp:14-53).
 int ParseSpec(const char* sub, const char* site, const char* clock, ModelSpec* m,
@@ -219,6 +229,20 @@ DeviceBatch MakeBatch(Worker* e, int set = 0) {
   b.branch_in = e->branch_in.ptr;
   b.rates = e->has_rates ? e->rates.ptr : nullptr;
   b.params = e->params.ptr;
+  if (e->inputs_on_host) {
+    // a blocking call's chunk, first pass: the set-up kernel reads the pinned staging buffer (same layout as the
+    // device block) and leaves the device copies
+    const char* stage = static_cast<const char*>(e->pin_in.ptr);
+    const char* block = reinterpret_cast<const char*>(e->in_block.ptr);
+    b.copy_parent_ids = e->parent_ids.ptr;
+    b.copy_branch_in = e->branch_in.ptr;
+    b.copy_rates = e->has_rates ? e->rates.ptr : nullptr;
+    b.copy_params = e->params.ptr;
+    b.parent_ids = reinterpret_cast<const int32_t*>(stage + (reinterpret_cast<const char*>(e->parent_ids.ptr) - block));
+    b.branch_in = reinterpret_cast<const double*>(stage);
+    b.rates = e->has_rates ? reinterpret_cast<const double*>(stage + (reinterpret_cast<const char*>(e->rates.ptr) - block)) : nullptr;
+    b.params = reinterpret_cast<const double*>(stage + (reinterpret_cast<const char*>(e->params.ptr) - block));
+  }
   b.tip_states = e->tip_states.ptr;
   b.weights = e->weights.ptr;
   b.children = (set == 0 ? e->children : set == 1 ? e->children2 : e->children3).ptr;
@@ -233,9 +257,18 @@ DeviceBatch MakeBatch(Worker* e, int set = 0) {
   b.scale_arena = e->scale_arena.ptr;
   b.part_ll = e->part_ll.ptr;
   b.part_grad = e->part_grad.ptr;
-  b.out_ll = e->cur_ll();
-  b.out_grad = e->out_grad.ptr;
-  b.out_site = e->out_site.ptr;
+  if (e->one_shot) {
+    // a blocking call's chunk: results straight into the pinned staging buffer, [ll T][gradient T*N][site T]
+    const size_t T = e->dims.tree_count, N = e->dims.node_count;
+    double* out = static_cast<double*>(e->pin_out.ptr);
+    b.out_ll = out;
+    b.out_grad = out + T;
+    b.out_site = out + T + T * N;
+  } else {
+    b.out_ll = e->cur_ll();
+    b.out_grad = e->out_grad.ptr;
+    b.out_site = e->out_site.ptr;
+  }
   return b;
 }
 
@@ -311,6 +344,8 @@ int RunResidentGeneral(Worker* e, int want_gradient, int rescaling, int deriv_mo
 int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0, int want_site = 0) {
   if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call WorkerUpload first");
   HIP_TRY(e, hipSetDevice(e->device));
+  e->busy = true;
+  e->results_on_host = e->one_shot != 0;
   const BatchDims& d = e->dims;
   const int T = d.tree_count;
   const size_t NB = (size_t)d.node_count - 1;
@@ -399,11 +434,11 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
           split.order_host.insert(split.order_host.end(), bb.begin(), bb.end());
           // (through pinned memory, in stream order: an earlier traversal that reads the list has finished by then,
           // and the staging copy is rewritten only by the next batch, which waits for the worker to be idle)
-          if ((size_t)T > e->pipe_order.capacity) HIP_TRY(e, hipStreamSynchronize(e->stream));
+          if ((size_t)T > e->pipe_order.capacity) HIP_TRY(e, hipStreamSynchronize(WalkStream(e)));
           HIP_TRY(e, e->pipe_order.Reserve((size_t)T));
           HIP_TRY(e, e->pin_order.Reserve((size_t)T * sizeof(int32_t)));
           std::memcpy(e->pin_order.ptr, split.order_host.data(), (size_t)T * sizeof(int32_t));
-          HIP_TRY(e, hipMemcpyAsync(e->pipe_order.ptr, e->pin_order.ptr, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+          HIP_TRY(e, hipMemcpyAsync(e->pipe_order.ptr, e->pin_order.ptr, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, SetupStream(e)));
         }
       }
     }
@@ -425,12 +460,12 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     bool build_masks = false;
     if (use_pipe && e->pipe_queue.capacity == 0) {
       HIP_TRY(e, e->pipe_queue.Reserve(2));
-      HIP_TRY(e, hipMemsetAsync(e->pipe_queue.ptr, 0, 2 * sizeof(int32_t), e->stream));
+      HIP_TRY(e, hipMemsetAsync(e->pipe_queue.ptr, 0, 2 * sizeof(int32_t), SetupStream(e)));
     }
     if (use_pipe) {  // the tile masks depend on the alignment and the plan only: built once
       const long long key = (long long)plan.groups | ((long long)plan.tiles << 8);
       if (e->pipe_masks_key != key) {
-        HIP_TRY(e, hipStreamSynchronize(e->stream));  // (a traversal may still be reading the old ones)
+        HIP_TRY(e, hipStreamSynchronize(WalkStream(e)));  // (a traversal may still be reading the old ones)
         HIP_TRY(e, e->pipe_masks.Reserve(PipeMaskInts(d, plan)));
         e->pipe_masks_key = key;
         build_masks = true;
@@ -440,26 +475,34 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     if (two_classes) {
       const long long key = (long long)split.plan_a.groups | ((long long)split.plan_a.tiles << 8);
       if (e->pipe_masks_a_key != key) {
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        HIP_TRY(e, hipStreamSynchronize(WalkStream(e)));
         HIP_TRY(e, e->pipe_masks_a.Reserve(PipeMaskInts(d, split.plan_a)));
         e->pipe_masks_a_key = key;
         build_masks_a = true;
       }
     }
     const DeviceBatch b = MakeBatch(e, set);
-    const bool in_line = e->serial_setup || e->one_shot;  // set-up on `stream`, in front of the traversal
-    hipStream_t prep = in_line ? e->stream : e->prep_stream;
+    hipStream_t prep = SetupStream(e);
+    const hipStream_t walk = WalkStream(e);
+    const bool in_line = prep == walk;  // set-up in front of the traversal, on its stream
+    e->last_walk = walk;
     const bool bare = e->serial_setup == 2 && e->run_counter > (unsigned)Worker::kSets;
     if (!bare) {
       if (!in_line) {
+        e->prep_used = e->prep_used || !e->one_shot;  // (a lent stream is not this worker's to wait for)
         HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_walk_done[set], 0));
-        if (e->inputs_pending) HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_inputs, 0));
+        if (e->inputs_pending && !e->one_shot) HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_inputs, 0));  // (one_shot: the copy is on `prep` itself)
       }
       // (packed into few workgroups when a traversal is still running beside it; spread out -- 30 us sooner --
       // when the engine is idle, as it is for a caller that waits for every pass)
       const bool busy = e->one_shot ? e->one_shot == 2
                                     : (!e->serial_setup && e->last_pass_done != nullptr && hipEventQuery(e->last_pass_done) == hipErrorNotReady);
       LaunchSetup(d, e->spec, b, want_gradient, prep, /*beside_traversal=*/busy);
+      if (e->inputs_on_host) {  // (that kernel made the device copies of the inputs: later passes wait for it)
+        HIP_TRY(e, hipEventRecord(e->ev_inputs, prep));
+        e->inputs_pending = true;
+        e->inputs_on_host = false;
+      }
       if (use_pipe) {
         LaunchPipePrepare(d, b, plan, prep, busy, two_classes ? split.slots_a : 0);
         if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);
@@ -470,34 +513,34 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
       }
       if (!in_line) {
         HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
-        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_prep_done[set], 0));
+        HIP_TRY(e, hipStreamWaitEvent(walk, e->ev_prep_done[set], 0));
       }
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing) {
       ev0 = NextEvent(e);
       ev1 = NextEvent(e);
-      HIP_TRY(e, hipEventRecord(ev0, e->stream));
+      HIP_TRY(e, hipEventRecord(ev0, walk));
     }
-    if (use_tree) LaunchWalkTree(d, b, tplan, want_gradient, e->stream);
+    if (use_tree) LaunchWalkTree(d, b, tplan, want_gradient, walk);
     else if (use_pipe) {
       const int site = want_site && want_gradient && deriv_mode == 0;
       if (two_classes) {
-        LaunchWalkPipe(d, b, split.plan_a, want_gradient, site, deriv_mode, e->stream,
-                       PipeClass{split.count_a, e->pipe_order.ptr, reinterpret_cast<const uint32_t*>(e->pipe_masks_a.ptr), grad_rows});
-        LaunchWalkPipe(d, b, split.plan_b, want_gradient, site, deriv_mode, e->stream,
-                       PipeClass{split.count_b, e->pipe_order.ptr + split.count_a, b.pipe_masks, grad_rows});
+        LaunchWalkPipe(d, b, split.plan_a, want_gradient, site, deriv_mode, walk,
+                       PipeClass{split.count_a, e->pipe_order.ptr, reinterpret_cast<const uint32_t*>(e->pipe_masks_a.ptr), grad_rows, e->reserve_cus});
+        LaunchWalkPipe(d, b, split.plan_b, want_gradient, site, deriv_mode, walk,
+                       PipeClass{split.count_b, e->pipe_order.ptr + split.count_a, b.pipe_masks, grad_rows, e->reserve_cus});
       } else {
-        LaunchWalkPipe(d, b, plan, want_gradient, site, deriv_mode, e->stream, PipeClass{T, nullptr, b.pipe_masks, grad_rows});
+        LaunchWalkPipe(d, b, plan, want_gradient, site, deriv_mode, walk, PipeClass{T, nullptr, b.pipe_masks, grad_rows, e->reserve_cus});
       }
     }
-    else LaunchWalkLds(d, b, plan, want_gradient, want_site && want_gradient && deriv_mode == 0, e->stream);
-    if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
+    else LaunchWalkLds(d, b, plan, want_gradient, want_site && want_gradient && deriv_mode == 0, walk);
+    if (e->timing) HIP_TRY(e, hipEventRecord(ev1, walk));
     e->kernel_name = use_tree ? "walk_tree_kernel" : (use_pipe ? "walk_pipe_kernel" : "walk_lds_kernel");
     e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
     // (walk_pipe_kernel's partial log-likelihoods are per run of tiles as well)
-    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, e->stream, grad_rows);
-    if (!bare) HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
+    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, walk, grad_rows);
+    if (!bare) HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], walk));
     e->last_pass_done = bare ? nullptr : e->ev_walk_done[set];
     HIP_TRY(e, hipGetLastError());
     return BITO_AMD_OK;
@@ -516,18 +559,26 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   if (want_gradient && rescaling)
     HIP_TRY(e, e->scale_arena.Reserve(chunk * (size_t)(d.taxon_count - 1) * d.pattern_stride));
   const DeviceBatch b = MakeBatch(e, set);
+  const hipStream_t walk = WalkStream(e);
+  e->last_walk = walk;
   {
-    const bool in_line = e->serial_setup || e->one_shot;
-    hipStream_t prep = in_line ? e->stream : e->prep_stream;
+    hipStream_t prep = SetupStream(e);
+    const bool in_line = prep == walk;
     if (!in_line) {
+      e->prep_used = e->prep_used || !e->one_shot;
       HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_walk_done[set], 0));
-      if (e->inputs_pending) HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_inputs, 0));
+      if (e->inputs_pending && !e->one_shot) HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_inputs, 0));
     }
     LaunchSetup(d, e->spec, b, want_gradient, prep);
+    if (e->inputs_on_host) {
+      HIP_TRY(e, hipEventRecord(e->ev_inputs, prep));
+      e->inputs_pending = true;
+      e->inputs_on_host = false;
+    }
     LaunchMatrices(d, b, want_gradient, deriv_mode, prep);
     if (!in_line) {
       HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
-      HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_prep_done[set], 0));
+      HIP_TRY(e, hipStreamWaitEvent(walk, e->ev_prep_done[set], 0));
     }
   }
   for (int t0 = 0; t0 < T; t0 += (int)chunk) {
@@ -536,19 +587,19 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     if (e->timing) {
       ev0 = NextEvent(e);
       ev1 = NextEvent(e);
-      HIP_TRY(e, hipEventRecord(ev0, e->stream));
+      HIP_TRY(e, hipEventRecord(ev0, walk));
     }
-    LaunchWalkHbm(d, b, t0, ct, want_gradient, rescaling, e->stream, deriv_mode);
-    if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
+    LaunchWalkHbm(d, b, t0, ct, want_gradient, rescaling, walk, deriv_mode);
+    if (e->timing) HIP_TRY(e, hipEventRecord(ev1, walk));
   }
   e->kernel_name = WalkHbmKernelName(d.category_count, want_gradient, rescaling);
-  LaunchReduce(d, b, tiles, want_gradient, e->stream, grad_rows);
+  LaunchReduce(d, b, tiles, want_gradient, walk, grad_rows);
   if (want_site && want_gradient && deriv_mode == 0 && d.category_count > 1 && HbmCatKernelApplies(d)) {
     // (walk_hbm_cat_kernel's gradient rows are per rate category: the site-model gradient needs no second pass)
-    LaunchSiteFromCategoryRows(d, b, grad_rows, e->stream);
+    LaunchSiteFromCategoryRows(d, b, grad_rows, walk);
     e->site_ready = true;
   }
-  HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], e->stream));
+  HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], walk));
   e->last_pass_done = e->ev_walk_done[set];
   HIP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
@@ -699,9 +750,17 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
   if (rc) return rc;
   if (params && (rc = ValidateParams(e, tree_count, params))) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
-  // a set-up kernel of an earlier, still running pass may be reading the input buffers, an earlier copy the staging buffer
-  HIP_TRY(e, hipStreamSynchronize(e->prep_stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  // A set-up kernel of an earlier, still running pass may be reading the input buffers, an earlier copy the staging
+  // buffer.  (Only when something may be in flight: a stream synchronisation is not free even on an idle stream --
+  // the runtime multiplexes streams onto a few hardware queues, and the marker it waits for can queue up behind
+  // ANOTHER worker's traversal: measured 0.77 ms in a five-chunk call.)
+  if (e->busy) {
+    HIP_TRY(e, hipStreamSynchronize(e->prep_stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->last_walk && e->last_walk != e->stream) HIP_TRY(e, hipStreamSynchronize(e->last_walk));
+    e->prep_used = false;
+  }
+  e->busy = true;
   const int n = e->n, N = 2 * n - 1, M = node_count, C = e->spec.category_count;
   const size_t T = tree_count;
   const size_t pc = (size_t)e->spec.param_count;
@@ -724,6 +783,11 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
   for (auto& r : e->out_ll_ring) HIP_TRY(e, r.Reserve(T));
   HIP_TRY(e, e->out_grad.Reserve(T * N));
   HIP_TRY(e, e->out_site.Reserve(T));
+  HIP_TRY(e, e->pin_out.Reserve(T * (N + 2) * sizeof(double)));
+  if (!e->pin_flag.ptr) {
+    HIP_TRY(e, e->pin_flag.Reserve(64));
+    std::memset(e->pin_flag.ptr, 0, 64);
+  }
   e->branch_in.ptr = e->in_block.ptr;
   e->params.ptr = e->in_block.ptr + off_params;
   e->rates.ptr = e->has_rates ? e->in_block.ptr + off_rates : nullptr;
@@ -733,9 +797,23 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
   if (pc > 0) std::memcpy(stage + off_params, params, T * pc * sizeof(double));
   if (e->has_rates) std::memcpy(stage + off_rates, rates, T * (M - 1) * sizeof(double));
   std::memcpy(stage + off_pid, parent_ids, T * (M - 1) * sizeof(int32_t));
-  HIP_TRY(e, hipMemcpyAsync(e->in_block.ptr, stage, bytes, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipEventRecord(e->ev_inputs, e->stream));
-  e->inputs_pending = true;
+  // A blocking call's chunk of trees small enough for the staging set-up kernel: no copy at all, that kernel reads
+  // the pinned buffer over PCIe (measured: the copy engine's start-up and the hand-over to the kernel behind it cost
+  // 30 us per call) and writes the device copies.  Otherwise one copy, on the stream the set-up kernels follow on
+  // (the worker's own: with ev_inputs behind it for the set-up stream).
+  BatchDims probe{};
+  probe.taxon_count = n;
+  probe.node_count = N;
+  probe.in_node_count = M;
+  probe.rooted = rooted;
+  probe.tree_count = tree_count;
+  e->inputs_on_host = e->one_shot && !wait && e->spec.state_count == 4 && e->kernel_choice != BITO_AMD_KERNEL_GENERAL &&
+                      SetupReadsHostInputs(probe, e->spec);
+  if (!e->inputs_on_host) {
+    HIP_TRY(e, hipMemcpyAsync(e->in_block.ptr, stage, bytes, hipMemcpyHostToDevice, SetupStream(e)));
+    HIP_TRY(e, hipEventRecord(e->ev_inputs, SetupStream(e)));
+    e->inputs_pending = true;
+  }
   e->min_branch = e->n > kPipeExactTaxa ? MinBranchLength(branch_lengths, rooted ? rates : nullptr, T, M) : 0.0;
   e->gs_index_valid = false;
   if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL) {
@@ -743,7 +821,7 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
     if ((rc = UploadModelIndex(e, tree_count, e->spec.param_count > 0 ? params : &none))) return rc;
   }
   if (wait) {
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipStreamSynchronize(SetupStream(e)));
     e->inputs_pending = false;
   }
   e->dims.taxon_count = n;
@@ -764,13 +842,19 @@ int WorkerUpload(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_cou
   return WorkerStage(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, /*wait=*/1);
 }
 
-// Enqueues the copies of the last pass's results into the pinned staging buffer -- [ll T][gradient T*N][site T] --
-// and records ev_results behind them; WorkerResults waits for that event and hands out the three host addresses.
+// Asks for the last pass's results in the pinned staging buffer -- [ll T][gradient T*N][site T].  A blocking
+// call's chunk (one_shot) already wrote them there: only the completion flag is enqueued.  Otherwise the copies,
+// with ev_results recorded behind them.  WorkerResults waits and hands out the three host addresses.
 int WorkerFetchResults(Worker* e, int want_gradient, int want_site) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident");
   HIP_TRY(e, hipSetDevice(e->device));
   const size_t T = e->dims.tree_count, N = e->dims.node_count;
+  if (e->results_on_host) {
+    LaunchSignal(static_cast<unsigned long long*>(e->pin_flag.ptr), ++e->ticket, e->last_walk ? e->last_walk : e->stream);
+    HIP_TRY(e, hipGetLastError());
+    return BITO_AMD_OK;
+  }
   HIP_TRY(e, e->pin_out.Reserve((T * (N + 2)) * sizeof(double)));
   double* out = static_cast<double*>(e->pin_out.ptr);
   HIP_TRY(e, hipMemcpyAsync(out, e->cur_ll(), T * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -782,11 +866,33 @@ int WorkerFetchResults(Worker* e, int want_gradient, int want_site) {
   return BITO_AMD_OK;
 }
 
+bool WorkerResultsReady(Worker* e) {
+  if (e->results_on_host)
+    return __atomic_load_n(static_cast<volatile uint64_t*>(e->pin_flag.ptr), __ATOMIC_ACQUIRE) == e->ticket;
+  return hipEventQuery(e->ev_results) == hipSuccess;
+}
+
 int WorkerResults(Worker* e, const double** ll, const double** grad, const double** site) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipEventSynchronize(e->ev_results));
+  if (e->results_on_host) {
+    // poll the flag the chunk's last kernel stores; now and then ask the stream whether it has failed
+    volatile uint64_t* flag = static_cast<volatile uint64_t*>(e->pin_flag.ptr);
+    for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != e->ticket; spins++) {
+      __builtin_ia32_pause();
+      if ((spins & 0xffff) == 0xffff) {
+        const hipError_t state = hipStreamQuery(e->last_walk ? e->last_walk : e->stream);
+        if (state != hipSuccess && state != hipErrorNotReady)
+          return Fail(e, BITO_AMD_ERR_DEVICE, std::string("the pass failed on the device: ") + hipGetErrorString(state));
+        if (state == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != e->ticket)
+          return Fail(e, BITO_AMD_ERR_DEVICE, "the stream is idle but the completion flag was never stored");
+      }
+    }
+  } else {
+    HIP_TRY(e, hipEventSynchronize(e->ev_results));
+  }
   e->inputs_pending = false;
+  e->busy = e->prep_used;  // (the flag / ev_results is the last thing on `stream`; the set-up stream is idle unless a pipelined pass used it)
   const size_t T = e->dims.tree_count, N = e->dims.node_count;
   const double* out = static_cast<const double*>(e->pin_out.ptr);
   if (ll) *ll = out;
@@ -832,6 +938,7 @@ int WorkerSync(Worker* e) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   HIP_TRY(e, hipSetDevice(e->device));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (e->last_walk && e->last_walk != e->stream) HIP_TRY(e, hipStreamSynchronize(e->last_walk));
   e->inputs_pending = false;
   return BITO_AMD_OK;
 }
@@ -841,10 +948,12 @@ int WorkerDownloadAsync(Worker* e, double* out_ll, double* out_grad) {
   if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident");
   HIP_TRY(e, hipSetDevice(e->device));
   const size_t T = e->dims.tree_count;
-  if (out_ll)
-    HIP_TRY(e, hipMemcpyAsync(out_ll, e->cur_ll(), T * sizeof(double), hipMemcpyDefault, e->stream));
+  // (a blocking call's chunk left its results in the pinned staging buffer, which a device reads as well)
+  const double* ll = e->results_on_host ? static_cast<const double*>(e->pin_out.ptr) : e->cur_ll();
+  const double* grad = e->results_on_host ? static_cast<const double*>(e->pin_out.ptr) + T : e->out_grad.ptr;
+  if (out_ll) HIP_TRY(e, hipMemcpyAsync(out_ll, ll, T * sizeof(double), hipMemcpyDefault, e->stream));
   if (out_grad)
-    HIP_TRY(e, hipMemcpyAsync(out_grad, e->out_grad.ptr, T * e->dims.node_count * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(out_grad, grad, T * e->dims.node_count * sizeof(double), hipMemcpyDefault, e->stream));
   return BITO_AMD_OK;
 }
 
@@ -861,8 +970,8 @@ int WorkerResultsAsync(Worker* e, void* consumer_stream, const double** out_ll,
     HIP_TRY(e, hipEventRecord(ev, e->stream));
     HIP_TRY(e, hipStreamWaitEvent(consumer, ev, 0));
   }
-  if (out_ll) *out_ll = e->cur_ll();
-  if (out_grad) *out_grad = e->out_grad.ptr;
+  if (out_ll) *out_ll = e->results_on_host ? static_cast<const double*>(e->pin_out.ptr) : e->cur_ll();
+  if (out_grad) *out_grad = e->results_on_host ? static_cast<const double*>(e->pin_out.ptr) + e->dims.tree_count : e->out_grad.ptr;
   return BITO_AMD_OK;
 }
 
@@ -1268,6 +1377,7 @@ int WorkerKernelElapsed(Worker* e, double* kernel_ms, int32_t* kernel_launches) 
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   HIP_TRY(e, hipSetDevice(e->device));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (e->last_walk && e->last_walk != e->stream) HIP_TRY(e, hipStreamSynchronize(e->last_walk));
   double k = 0;
   int launches = 0;
   for (size_t i = 0; i + 1 < e->ev_used; i += 2) {

@@ -59,6 +59,7 @@ class Engine {
   ~Engine() { bito_amd_engine_destroy(e_); }
 
   int32_t ParameterCount() const { return bito_amd_engine_param_count(e_); }
+  int32_t DeviceCount() const { return bito_amd_engine_device_count(e_); }
   const std::map<std::string, std::pair<int32_t, int32_t>>& BlockMap() const { return blocks_; }
 
   // Engine::LogLikelihoods (src/engine.cpp:58-74); params is [tree_count][ParameterCount()] row-major

@@ -7,7 +7,10 @@
 //   rooted T node_count   parent ids (T*(node_count-1))   branch lengths (T*node_count)
 //   param_count           params (T*param_count)
 // and prints "ll <value>" per tree followed by "grad <2n-1 values>" per tree with %.17g.
+// A second argument is the number of device slots the engine is created over (EngineSpecification's thread_count
+// in the reference, src/engine.hpp:20-24); every slot names GPU 0, so a one-GPU machine runs the multi-device path.
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 
@@ -43,7 +46,10 @@ int main(int argc, char** argv) {
     return 2;
   }
   try {
-    bito_amd_cpp::Engine engine(spec, n, P, patterns, weights);
+    const int device_count = argc > 2 ? std::atoi(argv[2]) : 1;
+    bito_amd_cpp::Engine engine(spec, n, P, patterns, weights, /*device_id=*/0, device_count,
+                                std::vector<int32_t>(device_count > 0 ? device_count : 0, 0));
+    std::printf("devices %d\n", engine.DeviceCount());
     if (engine.ParameterCount() != pc) throw std::runtime_error("parameter count mismatch");
     const auto ll = engine.LogLikelihoods(trees, params, false);
     const auto grads = engine.Gradients(trees, params, false);

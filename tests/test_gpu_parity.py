@@ -418,10 +418,16 @@ def test_large_tree_with_rescaling_vs_oracle():
     assert np.all(np.isfinite(out["branch_lengths"]))
 
 
-def test_config4_full_size_two_trees():
-    """BASELINE config 4 shape (1000 taxa x 10000 patterns): two trees against the oracle."""
-    w = workloads.synthetic_gtr_weibull4(n=1000, P=10000, tree_count=2)
-    gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 2)
+def test_config4_full_size_eight_trees():
+    """BASELINE config 4 shape (1000 taxa x 10000 patterns, rescaling on): eight of its trees against the oracle --
+    the first four and four from the last rank's block of the 8-GPU sharding (trees 875..878)."""
+    w = workloads.synthetic_gtr_weibull4(n=1000, P=10000, tree_count=4)
+    tail = workloads.synthetic_gtr_weibull4(n=1000, P=10000, tree_count=4, first_tree=875)
+    assert np.array_equal(w.patterns, tail.patterns)
+    w.parent_ids = np.concatenate([w.parent_ids, tail.parent_ids])
+    w.branch_lengths = np.concatenate([w.branch_lengths, tail.branch_lengths])
+    w.params = np.concatenate([w.params, tail.params])
+    gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
     out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
     ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
     assert np.all(np.isfinite(out["log_likelihood"]))
