@@ -366,15 +366,35 @@ def main():
     # second timed region: the same passes over a batch that stays in HBM (no host arrays cross PCIe)
     resident = None
     if not args.no_resident:
+        from bito_amd import dist as bdist
+
         eng.upload(pid, bl_sets[0], params)
+        # (more than one rank: every pass ends with the asynchronous all-reduce of the summed log-likelihood, taken
+        # from where the engine left the values -- bito_amd/dist.py)
+        reducer = bdist.ResidentSumReducer(eng) if reduce_ll else None
+
+        def resident_pass():
+            if reducer is not None:
+                reducer.run(w.want_gradient, w.rescaling)
+            else:
+                eng.run(w.want_gradient, w.rescaling)
+
+        def resident_fence():
+            if reducer is not None:
+                reducer.finish()
+            eng.sync()
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
+
         for _ in range(args.warmup):
-            eng.run(w.want_gradient, w.rescaling)
-        eng.sync()
+            resident_pass()
+        resident_fence()
         eng.kernel_timing(True)
         r0 = time.perf_counter()
         for _ in range(args.steps):
-            eng.run(w.want_gradient, w.rescaling)
-        eng.sync()
+            resident_pass()
+        resident_fence()
         r_elapsed = time.perf_counter() - r0
         r_kernel_ms, r_launches = eng.kernel_elapsed()
         eng.kernel_timing(False)
@@ -384,7 +404,8 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             r_elapsed = float(tmax.item())
         resident = {"trees_per_s": world * T * args.steps / r_elapsed, "ms_per_step": r_elapsed / args.steps * 1e3,
-                    "note": "bito_amd_engine_run back to back over a batch resident in HBM, no sum reduction",
+                    "note": "bito_amd_engine_run back to back over a batch resident in HBM" +
+                            ("; per pass one asynchronous RCCL all-reduce of the summed log-likelihood" if reduce_ll else ""),
                     "roofline": roofline_object(r_kernel, n, P, C, S, w.want_gradient, T * args.steps / max(r_launches, 1),
                                                 r_kernel_ms * 1e-3 / max(r_launches, 1), args.workload)}
 

@@ -53,7 +53,7 @@ struct bito_amd_engine {
   // scripts/gpu_chunk_sweep.sh: 4.24 ms per 6400 config-3 trees with these, 4.9 with first = 128, growth = 1.5)
   int chunk_first = 512, chunk_cap = 2048, max_lanes = 8, reserve_cus = 0;
   double chunk_growth = 3.0;
-  int walk_streams = 2;
+  int walk_streams = 2, chunk_taper = 1;
 };
 
 namespace {
@@ -111,6 +111,12 @@ std::vector<int> PlanChunks(const bito_amd_engine* e, int count, bool single) {
     sizes.push_back(take);
     remaining -= take;
     c = std::min<double>(c * e->chunk_growth, e->chunk_cap);
+  }
+  // ... and the last chunk small again: what the caller waits for at the very end -- the final sums of the last chunk
+  // written over PCIe, and the host's copy of them into the caller's arrays -- is in proportion to its size
+  if (e->chunk_taper && sizes.size() >= 2 && sizes.back() >= 3 * e->chunk_first && (int)sizes.size() < e->max_lanes) {
+    sizes.back() -= e->chunk_first;
+    sizes.push_back(e->chunk_first);
   }
   return sizes;
 }
@@ -294,6 +300,7 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
   if (const char* v = std::getenv("BITO_AMD_CHUNK_FIRST")) e->chunk_first = std::max(1, std::atoi(v));
   if (const char* v = std::getenv("BITO_AMD_CHUNK_CAP")) e->chunk_cap = std::max(1, std::atoi(v));
   if (const char* v = std::getenv("BITO_AMD_CHUNK_GROWTH")) e->chunk_growth = std::max(1.0, std::atof(v));
+  if (const char* v = std::getenv("BITO_AMD_CHUNK_TAPER")) e->chunk_taper = std::atoi(v);
   if (const char* v = std::getenv("BITO_AMD_CHUNK_WALK_STREAMS")) e->walk_streams = std::atoi(v);
   if (const char* v = std::getenv("BITO_AMD_CHUNK_RESERVE")) e->reserve_cus = std::max(0, std::atoi(v));
   if (const char* v = std::getenv("BITO_AMD_CHUNK_LANES")) e->max_lanes = std::min(kMaxLanes, std::max(1, std::atoi(v)));

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <string>
 #include <type_traits>
@@ -1091,6 +1092,56 @@ int bito_amd_gp_get_plv(bito_amd_gp_engine* e, int64_t plv, double* out) {
   GP_TRY(e, hipSetDevice(e->device));
   GP_TRY(e, hipMemcpy2D(out, e->P * sizeof(double), e->plv + (size_t)plv * 4 * e->Ppad, e->Ppad * sizeof(double),
                         e->P * sizeof(double), 4, hipMemcpyDeviceToHost));
+  return BITO_AMD_OK;
+}
+
+// The reference keeps ONE rescaling count per PLV, decided from the whole-PLV maximum (RescalePLVIfNeeded,
+// src/gp_engine.cpp:583-597); the executor keeps one per (PLV, pattern).  Both are the number of divisions by the
+// threshold that brought a value into [threshold, 1): a count never exceeds what the magnitude of its values asks
+// for, so the whole-PLV count -- decided by the LARGEST entry -- is the smallest of the per-pattern counts (over the
+// patterns that are not identically zero: a zero does not take part in a maximum), and the reference's stored value
+// of pattern p is the executor's times threshold^(count_p - count).  These two calls hand out that view.
+static int ReferenceView(bito_amd_gp_engine* e, int64_t plv, std::vector<double>* values, std::vector<int>* cnt, int* count) {
+  GP_TRY(e, hipSetDevice(e->device));
+  values->assign((size_t)4 * e->P, 0.0);
+  cnt->assign((size_t)e->P, 0);
+  GP_TRY(e, hipMemcpy2D(values->data(), e->P * sizeof(double), e->plv + (size_t)plv * 4 * e->Ppad, e->Ppad * sizeof(double),
+                        e->P * sizeof(double), 4, hipMemcpyDeviceToHost));
+  GP_TRY(e, hipMemcpy(cnt->data(), e->counts + (size_t)plv * e->Ppad, (size_t)e->P * sizeof(int), hipMemcpyDeviceToHost));
+  int lowest = std::numeric_limits<int>::max(), lowest_any = std::numeric_limits<int>::max();
+  for (int p = 0; p < e->P; p++) {
+    double mx = 0;
+    for (int i = 0; i < 4; i++) mx = std::max(mx, (*values)[(size_t)i * e->P + p]);
+    lowest_any = std::min(lowest_any, (*cnt)[p]);
+    if (mx > 0) lowest = std::min(lowest, (*cnt)[p]);
+  }
+  *count = lowest == std::numeric_limits<int>::max() ? lowest_any : lowest;
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_rescaling_counts(bito_amd_gp_engine* e, int64_t first, int64_t count, int32_t* out) {
+  if (!e || !out || first < 0 || count < 0 || first + count > (int64_t)e->plvs + e->spare_plvs) return BITO_AMD_ERR_BAD_ARG;
+  std::vector<double> values;
+  std::vector<int> cnt;
+  for (int64_t k = 0; k < count; k++) {
+    int c = 0;
+    if (int rc = ReferenceView(e, first + k, &values, &cnt, &c)) return rc;
+    out[k] = c;
+  }
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_get_plv_as_reference(bito_amd_gp_engine* e, int64_t plv, double* out, int32_t* out_count) {
+  if (!e || !out || plv < 0 || plv >= (int64_t)e->plvs + e->spare_plvs) return BITO_AMD_ERR_BAD_ARG;
+  std::vector<double> values;
+  std::vector<int> cnt;
+  int c = 0;
+  if (int rc = ReferenceView(e, plv, &values, &cnt, &c)) return rc;
+  for (int p = 0; p < e->P; p++) {
+    const double f = cnt[p] == c ? 1.0 : std::pow(e->threshold, (double)(cnt[p] - c));
+    for (int i = 0; i < 4; i++) out[(size_t)i * e->P + p] = values[(size_t)i * e->P + p] * f;
+  }
+  if (out_count) *out_count = c;
   return BITO_AMD_OK;
 }
 

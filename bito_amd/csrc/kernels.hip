@@ -151,12 +151,21 @@ setup_trees_lds_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, int trees) {
     StageSlice(b.rates + (size_t)t0 * RW, b.copy_rates ? b.copy_rates + (size_t)t0 * RW : nullptr, count * RW, tid,
                [&](int i, double v) { rts[i] = v; });
   __syncthreads();
-  if (tid < count)
-    SetupTopologyCore(d, par + tid * (M - 1), ch + tid * 2 * NI, bl + tid * N, RW ? rts + tid * RW : nullptr);
+  // Three serial jobs per tree that share nothing: the topology (child lists, effective branch lengths), the rate
+  // matrix + eigensystem, the category rates.  Up to 64 trees per workgroup each job has a wave of its own (wave 0 the
+  // eigensystems, the longest; wave 1 the topologies, wave 2 the category rates), so that a tree's set-up takes as long
+  // as its eigensystem instead of the sum of the three; with 128 trees waves 0-1 take the eigensystems and waves 2-3
+  // the other two jobs one after the other.
+  const int lanes = trees <= 64 ? 64 : 128;       // threads per job
+  const int job = tid / lanes, who = tid % lanes;  // job 0: eigensystem; 1: topology (+ rates when there is no job 2); 2: rates
+  if (who < count) {
+    if (job == 0) SetupSubstitution(spec, prm + who * pc, &b.model[t0 + who]);
+    if (job == 1) SetupTopologyCore(d, par + who * (M - 1), ch + who * 2 * NI, bl + who * N, RW ? rts + who * RW : nullptr);
+    if (job == (lanes == 64 ? 2 : 1)) SetupSiteRates(spec, prm + who * pc, &b.model[t0 + who]);
+  }
   __syncthreads();
   for (int i = tid; i < count * 2 * NI; i += step) b.children[(size_t)t0 * 2 * NI + i] = ch[i];
   for (int i = tid; i < count * N; i += step) b.branch[(size_t)t0 * N + i] = bl[i];
-  if (tid < count) SetupTreeModel(spec, prm + tid * pc, &b.model[t0 + tid]);
 }
 
 // trees per workgroup of setup_trees_lds_kernel for this batch, 0: another kernel
@@ -678,36 +687,50 @@ const char* WalkHbmKernelName(int category_count, int, int) {
 // Final per-tree sums over pattern tiles, fixed order.
 
 __global__ void __launch_bounds__(256)
-reduce_tiles_kernel(BatchDims d, DeviceBatch b, int tiles, int grad_rows, int want_gradient) {
+reduce_tiles_kernel(BatchDims d, DeviceBatch b, int tiles, int grad_rows, int want_gradient, ReduceDone done) {
   const int N = d.node_count;
   const int per_tree = want_gradient ? N + 1 : 1;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)d.tree_count * per_tree) return;
-  const int t = (int)(idx / per_tree), e = (int)(idx % per_tree);
-  if (e == per_tree - 1) {
-    double s = 0.0;
-    for (int k = 0; k < tiles; k++) s += b.part_ll[(size_t)t * tiles + k];
-    b.out_ll[t] = s;
-    return;
+  if (idx < (size_t)d.tree_count * per_tree) {
+    const int t = (int)(idx / per_tree), e = (int)(idx % per_tree);
+    if (e == per_tree - 1) {
+      double s = 0.0;
+      for (int k = 0; k < tiles; k++) s += b.part_ll[(size_t)t * tiles + k];
+      b.out_ll[t] = s;
+    } else {
+      double s = 0.0;
+      for (int k = 0; k < grad_rows; k++) s += b.part_grad[((size_t)t * grad_rows + k) * N + e];
+      // The root's slot carries the site-model gradient of kernels that produce it in the same pass
+      // (walk_lds_kernel); other kernels leave 0 there.
+      if (e == N - 1 && b.out_site != nullptr) b.out_site[t] = s;
+      // Root has no branch; for unrooted trees the node that re-uses the old root id
+      // is the fixed node whose gradient is pinned to 0 (reference fat_beagle.cpp:148,553).
+      if (e == N - 1 || (!d.rooted && e == N - 2)) s = 0.0;
+      b.out_grad[(size_t)t * N + e] = s;
+    }
   }
-  double s = 0.0;
-  for (int k = 0; k < grad_rows; k++) s += b.part_grad[((size_t)t * grad_rows + k) * N + e];
-  // The root's slot carries the site-model gradient of kernels that produce it in the same pass
-  // (walk_lds_kernel); other kernels leave 0 there.
-  if (e == N - 1 && b.out_site != nullptr) b.out_site[t] = s;
-  // Root has no branch; for unrooted trees the node that re-uses the old root id
-  // is the fixed node whose gradient is pinned to 0 (reference fat_beagle.cpp:148,553).
-  if (e == N - 1 || (!d.rooted && e == N - 2)) s = 0.0;
-  b.out_grad[(size_t)t * N + e] = s;
+  if (done.flag != nullptr) {
+    // every thread's results are on their way to host memory before its workgroup is counted; the workgroup that
+    // counts last stores the flag behind them (the pattern of a reduction's last block, at system scope)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (atomicAdd(done.counter, 1) == (int)gridDim.x - 1) {
+        *done.counter = 0;
+        __threadfence_system();
+        __hip_atomic_store(done.flag, done.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
-                  hipStream_t stream, int grad_rows) {
+                  hipStream_t stream, int grad_rows, ReduceDone done) {
   if (grad_rows <= 0) grad_rows = tiles;
   const size_t total = (size_t)d.tree_count * (want_gradient ? d.node_count + 1 : 1);
   const int blocks = (int)((total + 255) / 256);
   hipLaunchKernelGGL(reduce_tiles_kernel, dim3(blocks), dim3(256), 0, stream, d, b, tiles, grad_rows,
-                     want_gradient);
+                     want_gradient, done);
 }
 
 // Completion flag of a blocking call's chunk: stored behind the kernels that wrote the chunk's results into pinned

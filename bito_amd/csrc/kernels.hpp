@@ -212,6 +212,7 @@ int HbmWalkGradRows(const BatchDims& d);
 // form of the pre-order recursion, which the engine uses only when every branch length is at least
 // kPipeReversibleMinBranch (about 1e-6) (walk_pipe.hip, scripts/gen_walk_pipe.py)
 constexpr int kPipeExactTaxa = 38;
+constexpr double kPipeReversibleRateScale = 0.2;  // smallest off-diagonal rate of the matrices that bound was measured on
 constexpr double kPipeReversibleMinBranch = 9e-7;  // (just below exp(-13.9), the reference optimiser's own floor: src/dag_branch_handler.hpp:272)
 bool HbmCatKernelApplies(const BatchDims& d);
 // out_site from walk_hbm_cat_kernel's per-category gradient rows (after the walk of every chunk), no second traversal
@@ -220,8 +221,16 @@ void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int c
                       int rescaling, int deriv_mode, hipStream_t stream);
 
 // grad_rows: partial gradient rows per tree (default: one per tile; the HBM-arena kernel writes one per wave)
+// done: when the sums are the last kernel of a blocking call's chunk and go straight to pinned host memory, the
+// workgroup that finishes last stores `ticket` to `flag` (pinned, polled by the host) behind everybody's results;
+// `counter` is a zeroed int in device memory that the kernel leaves zeroed.
+struct ReduceDone {
+  unsigned long long* flag = nullptr;
+  unsigned long long ticket = 0;
+  int* counter = nullptr;
+};
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
-                  hipStream_t stream, int grad_rows = 0);
+                  hipStream_t stream, int grad_rows = 0, ReduceDone done = ReduceDone{});
 // one thread stores `value` to `flag` (pinned host memory) behind everything enqueued on the stream so far
 void LaunchSignal(unsigned long long* flag, unsigned long long value, hipStream_t stream);
 

@@ -46,6 +46,20 @@ hipStream_t SetupStream(const Worker* e) {
 }
 hipStream_t WalkStream(const Worker* e) { return (e->one_shot && e->lent_walk) ? e->lent_walk : e->stream; }
 
+// A blocking call's chunk whose final-sums kernel is the last kernel of the pass: that kernel stores the completion
+// flag itself.  (Otherwise WorkerFetchResults enqueues a one-thread kernel for it.)
+ReduceDone DoneByReduce(Worker* e) {
+  ReduceDone done{};
+  e->signalled = false;
+  if (e->results_on_host && e->done_counter.ptr != nullptr) {
+    done.flag = static_cast<unsigned long long*>(e->pin_flag.ptr);
+    done.ticket = ++e->ticket;
+    done.counter = e->done_counter.ptr;
+    e->signalled = true;
+  }
+  return done;
+}
+
 // PhyloModel::OfSpecification + BlockSpecification layout
 // (reference src/phylo_model.cpp:6-24, src/block_specification.cpp:14-53).
 int ParseSpec(const char* sub, const char* site, const char* clock, ModelSpec* m,
@@ -223,6 +237,28 @@ double MinBranchLength(const double* branch_lengths, const double* rates, size_t
   return m;
 }
 
+// Smallest off-diagonal entry of the normalised rate matrices of a batch's parameter rows (JC69: 1/3).  The
+// one-image-per-branch form of walk_pipe_kernel needs every off-diagonal entry of every P(t) ~ t Q_ij to stand well
+// above its own rounding error, so what it asks of a batch is a bound on t_min * Q_min, not on t_min alone (a large
+// kappa or a rare nucleotide makes some Q_ij a hundred times smaller than the matrices the bound was measured on).
+double MinOffDiagonalRate(const ModelSpec& m, const double* params, size_t T) {
+  if (m.substitution == kJC69 || m.state_count != 4 || params == nullptr) return 1.0 / 3.0;
+  double lowest = std::numeric_limits<double>::infinity();
+  for (size_t t = 0; t < T; t++) {
+    const double* row = params + t * m.param_count;
+    double r[6] = {1, 1, 1, 1, 1, 1}, Q[16];
+    if (m.substitution == kGTR)
+      for (int i = 0; i < 6; i++) r[i] = row[m.rates_start + i];
+    else
+      r[1] = r[4] = row[m.rates_start];  // HKY: kappa on the two transitions
+    BuildQ(r, row + m.freq_start, Q);
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++)
+        if (i != j) lowest = std::min(lowest, Q[i * 4 + j]);
+  }
+  return lowest;
+}
+
 DeviceBatch MakeBatch(Worker* e, int set = 0) {
   DeviceBatch b{};
   b.parent_ids = e->parent_ids.ptr;
@@ -334,7 +370,8 @@ int RunResidentGeneral(Worker* e, int want_gradient, int rescaling, int deriv_mo
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, e->stream));
   }
   e->kernel_name = "gs_walk_kernel";
-  LaunchReduce(d, b, tiles, want_gradient, e->stream);
+  e->last_walk = e->stream;
+  LaunchReduce(d, b, tiles, want_gradient, e->stream, 0, DoneByReduce(e));
   HIP_TRY(e, hipEventRecord(e->ev_walk_done[0], e->stream));
   e->last_pass_done = e->ev_walk_done[0];
   HIP_TRY(e, hipGetLastError());
@@ -366,7 +403,10 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     const char* v = std::getenv("BITO_AMD_PIPE_MIN_BRANCH");
     return v ? std::atof(v) : kPipeReversibleMinBranch;
   }();
-  const bool pipe_branches_ok = d.taxon_count <= kPipeExactTaxa || e->min_branch >= min_branch_needed;
+  // (kPipeReversibleMinBranch was measured on matrices whose smallest off-diagonal entry is about 0.2,
+  // scripts/gpu_pipe_reversible_bound.py: what is held is the product)
+  const bool pipe_branches_ok = d.taxon_count <= kPipeExactTaxa ||
+                                e->min_branch * std::min(e->min_rate / kPipeReversibleRateScale, 1.0) >= min_branch_needed;
   switch (e->kernel_choice) {
     case BITO_AMD_KERNEL_HBM_ARENA: use_tree = use_lds = false; break;
     case BITO_AMD_KERNEL_LDS_PIPE:
@@ -539,7 +579,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     e->kernel_name = use_tree ? "walk_tree_kernel" : (use_pipe ? "walk_pipe_kernel" : "walk_lds_kernel");
     e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
     // (walk_pipe_kernel's partial log-likelihoods are per run of tiles as well)
-    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, walk, grad_rows);
+    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, walk, grad_rows, DoneByReduce(e));
     if (!bare) HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], walk));
     e->last_pass_done = bare ? nullptr : e->ev_walk_done[set];
     HIP_TRY(e, hipGetLastError());
@@ -593,8 +633,10 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, walk));
   }
   e->kernel_name = WalkHbmKernelName(d.category_count, want_gradient, rescaling);
-  LaunchReduce(d, b, tiles, want_gradient, walk, grad_rows);
-  if (want_site && want_gradient && deriv_mode == 0 && d.category_count > 1 && HbmCatKernelApplies(d)) {
+  const bool site_kernel = want_site && want_gradient && deriv_mode == 0 && d.category_count > 1 && HbmCatKernelApplies(d);
+  e->signalled = false;
+  LaunchReduce(d, b, tiles, want_gradient, walk, grad_rows, site_kernel ? ReduceDone{} : DoneByReduce(e));
+  if (site_kernel) {
     // (walk_hbm_cat_kernel's gradient rows are per rate category: the site-model gradient needs no second pass)
     LaunchSiteFromCategoryRows(d, b, grad_rows, walk);
     e->site_ready = true;
@@ -787,6 +829,8 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
   if (!e->pin_flag.ptr) {
     HIP_TRY(e, e->pin_flag.Reserve(64));
     std::memset(e->pin_flag.ptr, 0, 64);
+    HIP_TRY(e, e->done_counter.Reserve(1));
+    HIP_TRY(e, hipMemset(e->done_counter.ptr, 0, sizeof(int32_t)));
   }
   e->branch_in.ptr = e->in_block.ptr;
   e->params.ptr = e->in_block.ptr + off_params;
@@ -815,6 +859,7 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
     e->inputs_pending = true;
   }
   e->min_branch = e->n > kPipeExactTaxa ? MinBranchLength(branch_lengths, rooted ? rates : nullptr, T, M) : 0.0;
+  e->min_rate = e->n > kPipeExactTaxa ? MinOffDiagonalRate(e->spec, params, T) : 1.0;
   e->gs_index_valid = false;
   if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL) {
     static const double none = 0.0;
@@ -851,8 +896,10 @@ int WorkerFetchResults(Worker* e, int want_gradient, int want_site) {
   HIP_TRY(e, hipSetDevice(e->device));
   const size_t T = e->dims.tree_count, N = e->dims.node_count;
   if (e->results_on_host) {
-    LaunchSignal(static_cast<unsigned long long*>(e->pin_flag.ptr), ++e->ticket, e->last_walk ? e->last_walk : e->stream);
-    HIP_TRY(e, hipGetLastError());
+    if (!e->signalled) {
+      LaunchSignal(static_cast<unsigned long long*>(e->pin_flag.ptr), ++e->ticket, e->last_walk ? e->last_walk : e->stream);
+      HIP_TRY(e, hipGetLastError());
+    }
     return BITO_AMD_OK;
   }
   HIP_TRY(e, e->pin_out.Reserve((T * (N + 2)) * sizeof(double)));
@@ -914,6 +961,7 @@ int WorkerUpdate(Worker* e, const double* branch_lengths, const double* params) 
     e->gs_index_valid = false;
     if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL)
       if ((rc = UploadModelIndex(e, (int)T, params))) return rc;
+    if (e->n > kPipeExactTaxa) e->min_rate = MinOffDiagonalRate(e->spec, params, T);
   }
   if (branch_lengths) {
     HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * e->dims.in_node_count * sizeof(double), hipMemcpyHostToDevice, e->stream));

@@ -116,6 +116,8 @@ struct Worker {
   // polls: no device-to-host copy commands and no event wake-up on the way back (measured: 45 us per call).
   PinnedBuffer pin_flag;
   uint64_t ticket = 0;           // of the last pass whose results go to pin_out
+  DeviceBuffer<int32_t> done_counter;  // workgroups of the final-sums kernel that have finished (it leaves 0)
+  bool signalled = false;        // the last pass's final-sums kernel stores the ticket itself (no kernel behind it)
   bool results_on_host = false;  // the resident pass's results are in pin_out, not in the device buffers
   bool inputs_pending = false;      // the copy of the resident batch's inputs may still be in flight
   bool inputs_on_host = false;      // ... or has not been made: the next pass's set-up kernel reads pin_in and makes it
@@ -157,6 +159,7 @@ struct Worker {
   hipEvent_t last_pass_done = nullptr;  // recorded behind the last pass enqueued (one of ev_walk_done)
   double* cur_ll() { return out_ll_ring[out_slot % kOutRing].ptr; }
   bool site_ready = false;  // out_site holds the site-model gradient of the resident pass
+  double min_rate = 1.0;    // smallest off-diagonal entry of the batch's normalised rate matrices (39 taxa and more only)
   double min_branch = 0.0;  // smallest branch length of the resident batch (known for 39 taxa and more only, else 0)
   DeviceBuffer<TreeModel> model, model2, model3;
   DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
@@ -175,7 +178,7 @@ struct Worker {
   ~Worker() {
     (void)hipSetDevice(device);
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
-    tip_states.Free(); weights.Free(); in_block.Free(); children.Free(); pin_in.Free(); pin_out.Free(); pin_order.Free(); pin_flag.Free();
+    tip_states.Free(); weights.Free(); in_block.Free(); children.Free(); pin_in.Free(); pin_out.Free(); pin_order.Free(); pin_flag.Free(); done_counter.Free();
     if (ev_inputs) (void)hipEventDestroy(ev_inputs);
     if (ev_results) (void)hipEventDestroy(ev_results);
     branch.Free(); mats.Free(); mats2.Free(); mats3.Free(); images.Free(); arena.Free(); scale_arena.Free(); part_ll.Free();

@@ -235,7 +235,7 @@ GP_SYMBOLS = [
     "bito_amd_gp_reset_optimization_count", "bito_amd_gp_increment_optimization_count",
     "bito_amd_gp_grow_spare", "bito_amd_gp_copy_gpcsp_data", "bito_amd_gp_process_operation_batches",
     "bito_amd_gp_per_gpcsp_log_likelihoods_range", "bito_amd_gp_branch_lengths_range",
-    "bito_amd_gp_grow", "bito_amd_gp_get_plv",
+    "bito_amd_gp_grow", "bito_amd_gp_get_plv", "bito_amd_gp_rescaling_counts", "bito_amd_gp_get_plv_as_reference",
 ]
 
 
@@ -267,6 +267,8 @@ def _lib():
         L.bito_amd_gp_branch_lengths_range.argtypes = [vp, C.c_int64, C.c_int64, dp]
         L.bito_amd_gp_grow.argtypes = [vp, C.c_int32, C.c_int32, ip, ip]
         L.bito_amd_gp_get_plv.argtypes = [vp, C.c_int64, dp]
+        L.bito_amd_gp_rescaling_counts.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
+        L.bito_amd_gp_get_plv_as_reference.argtypes = [vp, C.c_int64, dp, C.POINTER(C.c_int32)]
         L._gp_ready = True
     return L
 
@@ -388,6 +390,21 @@ class GPEngine:
         out = np.zeros((4, self.pattern_count))
         self._check(_lib().bito_amd_gp_get_plv(self._h, int(plv), out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
+
+    def get_rescaling_counts(self, first: int = 0, count=None) -> np.ndarray:
+        """The reference's ``rescaling_counts_`` (one per PLV) for PLVs ``first .. first + count - 1`` (default: the
+        6 * node_count PLVs of the DAG)."""
+        count = 6 * self.node_count - first if count is None else count
+        out = np.zeros(count, dtype=np.int32)
+        self._check(_lib().bito_amd_gp_rescaling_counts(self._h, int(first), int(count), out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def get_plv_as_reference(self, plv: int):
+        """-> (values [4][pattern_count] as the reference's GetPLV would hold them, its rescaling count)"""
+        out = np.zeros((4, self.pattern_count))
+        cnt = C.c_int32()
+        self._check(_lib().bito_amd_gp_get_plv_as_reference(self._h, int(plv), out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt)))
+        return out, int(cnt.value)
 
     def get_log_marginal_likelihood(self) -> float:
         return float(self._vec(_lib().bito_amd_gp_log_marginal_likelihood, 1)[0])

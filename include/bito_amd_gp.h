@@ -99,6 +99,18 @@ int bito_amd_gp_grow(bito_amd_gp_engine *e, int32_t new_node_count, int32_t new_
 /* GetPLV(plv_index) (src/gp_engine.hpp:145-150): out[4][pattern_count], one row per state. */
 int bito_amd_gp_get_plv(bito_amd_gp_engine *e, int64_t plv, double *out);
 
+/* The reference's view of a PLV's rescaling.  GPEngine keeps ONE count per PLV, decided from the whole-PLV maximum
+ * (rescaling_counts_, RescalePLVIfNeeded, src/gp_engine.cpp:564-601, src/gp_engine.hpp:300-330); this executor keeps
+ * one per (PLV, pattern).  A count is the number of divisions by the threshold that brought values into
+ * [threshold, 1), and the whole-PLV decision follows the PLV's largest entry, so the reference's count is the
+ * smallest per-pattern count (over patterns that are not identically zero) and its stored values are the
+ * executor's times threshold^(count_p - count).
+ *   _rescaling_counts:    out[count] = the reference's rescaling_counts_ for PLVs first .. first + count - 1
+ *   _get_plv_as_reference: GetPLV(plv) with the values the reference would hold, out[4][pattern_count], and its count
+ * (what code that copies PLVs together with their counts -- the NNI engine -- reads). */
+int bito_amd_gp_rescaling_counts(bito_amd_gp_engine *e, int64_t first, int64_t count, int32_t *out);
+int bito_amd_gp_get_plv_as_reference(bito_amd_gp_engine *e, int64_t plv, double *out, int32_t *out_count);
+
 /* GPEngine::CopyGPCSPData(src, dest) (src/gp_engine.cpp:401-409) for count pairs, applied in order:
  * branch length and q of src[i] are copied to dst[i]. */
 int bito_amd_gp_copy_gpcsp_data(bito_amd_gp_engine *e, const int64_t *src, const int64_t *dst, int64_t count);

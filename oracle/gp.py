@@ -41,6 +41,7 @@ def lib():
         L.gp_oracle_branch_lengths_range.argtypes = [vp, C.c_int, C.c_int, dp]
         L.gp_oracle_grow.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.gp_oracle_get_plv.argtypes = [vp, C.c_int, dp]
+        L.gp_oracle_rescaling_counts.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -134,6 +135,12 @@ class OracleGPEngine:
     def get_plv(self, plv):
         out = np.zeros((4, self.patterns.shape[1]))
         lib().gp_oracle_get_plv(self._h, int(plv), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def get_rescaling_counts(self, first, count):
+        """rescaling_counts_ of the reference (src/gp_engine.hpp:300-330): one count per PLV"""
+        out = np.zeros(count, dtype=np.int32)
+        lib().gp_oracle_rescaling_counts(self._h, int(first), int(count), out.ctypes.data_as(C.POINTER(C.c_int)))
         return out
 
     def get_log_marginal_likelihood(self):

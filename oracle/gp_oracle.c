@@ -359,6 +359,11 @@ void gp_oracle_get_plv(const gp_oracle *g, int plv, double *out) {
     for (int i = 0; i < 4; i++) out[(size_t)i * g->P + p] = g->plv[((size_t)plv * g->P + p) * 4 + i];
 }
 
+/* rescaling_counts_ (src/gp_engine.hpp:300-330): one count per PLV */
+void gp_oracle_rescaling_counts(const gp_oracle *g, int first, int count, int *out) {
+  for (int k = 0; k < count; k++) out[k] = g->counts[first + k];
+}
+
 /* GPEngine::CopyGPCSPData (src/gp_engine.cpp:401-409) */
 void gp_oracle_copy_gpcsp_data(gp_oracle *g, int src, int dst) {
   g->bl[dst] = g->bl[src];

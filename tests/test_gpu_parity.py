@@ -865,6 +865,44 @@ def test_auto_kernel_choice_at_the_pipe_walk_limits():
                 gpu.gradients(pid, bl)
 
 
+def test_reversible_form_guard_counts_the_rate_matrix_too():
+    """39 taxa and more: the one-image-per-branch form needs every off-diagonal entry of P(t) ~ t Q_ij well above its
+    own rounding error.  With a large kappa and rare nucleotides some Q_ij are a hundred times smaller than in the
+    matrices the branch-length bound was measured on, so the same branch lengths that go to walk_pipe_kernel under
+    mild parameters must go to the HBM-arena walk under extreme ones -- and parity must hold either way."""
+    rng = np.random.default_rng(31)
+    n, T = 41, 6
+    patterns = rng.integers(0, 4, (n, 90)).astype(np.int32)
+    weights = np.ones(90)
+    pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(T)])
+    bl = np.maximum(rng.exponential(0.1, (T, 2 * n - 1)), 1e-3)
+    bl[rng.random(bl.shape) < 0.2] = 2e-6  # a fifth of the branches just above the bound
+    bl[:, -1] = 0.0
+    gpu, cpu = engines("HKY", "weibull+4", "none", patterns, weights, 4)
+    for freqs, kappa, expect in (([0.25, 0.25, 0.25, 0.25], 2.0, "walk_pipe_kernel"),
+                                 ([0.03, 0.47, 0.47, 0.03], 60.0, "walk_hbm_cat_kernel")):
+        params = gpu.default_params(T)
+        params[:, :4] = freqs
+        params[:, 4] = kappa
+        params[:, 5] = 0.5
+        out = gpu.gradients(pid, bl, params)
+        ref = cpu.gradients(pid, bl, params)
+        assert gpu.kernel_name() == expect, (freqs, kappa)
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"])
+        assert np.allclose(out["branch_lengths"], ref["branch_lengths"], rtol=1e-9, atol=GRAD_ATOL), (freqs, kappa)
+    # new parameter rows for a resident batch move the choice as well
+    mild = gpu.default_params(T)
+    mild[:, 4] = 2.0
+    gpu.upload(pid, bl, mild)
+    gpu.run(True)
+    assert gpu.kernel_name() == "walk_pipe_kernel"
+    gpu.update(None, params)
+    gpu.run(True)
+    assert gpu.kernel_name() == "walk_hbm_cat_kernel"
+    ll, grad = gpu.download()
+    assert ll_close(ll, ref["log_likelihood"]) and np.allclose(grad, ref["branch_lengths"], rtol=1e-9, atol=GRAD_ATOL)
+
+
 def test_large_batches_of_larger_trees_every_tree_every_pass():
     """1600 trees of 64 taxa, three passes per kernel: EVERY tree of every pass must agree between the HBM-arena walk
     (AUTO's choice at this size) and walk_lds_kernel, and a sample with the oracle.  (Round 2 found walk_lds_kernel

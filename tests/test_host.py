@@ -256,7 +256,10 @@ def test_pipe_walk_planner():
     assert big["tile_run"] == 5 and big["whole_trees"] == 6000
     small = _pipe_plan(27, 934, 4, 400, 7)  # fewer: runs only, about four units per workgroup
     assert small["whole_trees"] == 0 and small["tile_run"] == 5
-    assert _pipe_plan(27, 934, 4, 100, 7)["tile_run"] == 1
+    # a hundred trees: the units go through the 256 resident workgroups in rounds -- 500 units of three tiles (two
+    # rounds) beat 1500 of one (six rounds, each paying the tree's images again); ten trees: one tile per unit
+    assert _pipe_plan(27, 934, 4, 100, 7)["tile_run"] == 3
+    assert _pipe_plan(27, 934, 4, 10, 7)["tile_run"] == 1
     # one more vector per wave than LDS holds beside four groups: two groups
     assert _pipe_plan(27, 934, 4, 1600, 6)["groups"] == 2
     # tip masks: 32 registers beside four groups, 48 beside two (one image per branch: the AGPR file would hold 57
