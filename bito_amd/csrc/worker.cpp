@@ -451,23 +451,38 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   if (use_pipe && !split.built) {
     split.built = true;
     split.active = false;
-    const int slots4 = PipeMaxSlots(d, 4);
     static const bool no_split = std::getenv("BITO_AMD_PIPE_NO_SPLIT") != nullptr;
-    if (!no_split && T >= 32 && plan.groups < 4 && slots4 > 0 && (int)e->tree_cherries.size() == T) {
+    // class A: the most pattern groups per wave -- 4, else 2 -- that at least a quarter of the trees leave room for
+    // and that the batch as a whole (its tree with the fewest cherries) does not
+    int groups_a = 0, slots_a = 0;
+    if (!no_split && T >= 32 && (int)e->tree_cherries.size() == T)
+      for (int g : {4, 2}) {
+        const int room = PipeMaxSlots(d, g);
+        if (g <= plan.groups || room <= 0) continue;
+        int fit = 0;
+        for (int t = 0; t < T; t++) fit += PipeSlotsOfTree(d, e->tree_cherries[t]) <= room;
+        if (fit * 4 >= T) {
+          groups_a = g;
+          slots_a = room;
+          break;
+        }
+      }
+    if (groups_a > 0) {
       std::vector<int32_t> a, bb;
       int need_a = 1, need_b = 1;
       for (int t = 0; t < T; t++) {
         const int need = PipeSlotsOfTree(d, e->tree_cherries[t]);
-        (need <= slots4 ? a : bb).push_back(t);
-        (need <= slots4 ? need_a : need_b) = std::max(need <= slots4 ? need_a : need_b, need);
+        (need <= slots_a ? a : bb).push_back(t);
+        (need <= slots_a ? need_a : need_b) = std::max(need <= slots_a ? need_a : need_b, need);
       }
       if (!bb.empty() && (int)a.size() * 4 >= T) {
-        const LdsPlan pa = PlanPipeClass(d, (int)a.size(), need_a, 4), pb = PlanPipeClass(d, (int)bb.size(), need_b, 0);
-        if (pa.groups == 4 && pb.groups > 0) {
+        const LdsPlan pa = PlanPipeClass(d, (int)a.size(), need_a, groups_a), pb = PlanPipeClass(d, (int)bb.size(), need_b, 0);
+        if (pa.groups == groups_a && pb.groups > 0 && pb.groups < groups_a) {
           split.active = true;
           split.count_a = (int)a.size();
           split.count_b = (int)bb.size();
-          split.slots_a = slots4;
+          split.slots_a = slots_a;
+          split.groups_a = groups_a;
           split.plan_a = pa;
           split.plan_b = pb;
           split.order_host = a;
@@ -544,7 +559,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
         e->inputs_on_host = false;
       }
       if (use_pipe) {
-        LaunchPipePrepare(d, b, plan, prep, busy, two_classes ? split.slots_a : 0);
+        LaunchPipePrepare(d, b, plan, prep, busy, two_classes ? split.slots_a : 0, two_classes ? split.groups_a : 4);
         if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);
         if (build_masks_a) LaunchPipeMasks(d, b, split.plan_a, reinterpret_cast<uint32_t*>(e->pipe_masks_a.ptr), prep);
       } else {

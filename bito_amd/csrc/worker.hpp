@@ -142,7 +142,7 @@ struct Worker {
   std::vector<int32_t> tree_cherries;  // per tree of the resident batch (counted while it is validated)
   struct PipeSplit {
     bool built = false, active = false;
-    int count_a = 0, count_b = 0, slots_a = 0;
+    int count_a = 0, count_b = 0, slots_a = 0, groups_a = 4;
     LdsPlan plan_a{}, plan_b{};
     std::vector<int32_t> order_host;
   } pipe_split;

@@ -325,9 +325,23 @@ class Loops:
     IMAGE_REGS = 224
     assert EXACT_BASE + 4 * (EXACT_TAXA - 2) <= IMAGE_REGS and REV_BASE + 2 * MAX_INNER <= IMAGE_REGS
 
-    def __init__(self, G, exact=True):
+    #   * 49 to 56 taxa, WIDE (round 3): the one-image layout with room for 56 tips -- 64 mask registers per lane
+    #     (5.5 % slower where 48 would do, hence a layout of its own), P of a tip's branch at a[2 tip], of an internal
+    #     branch at a[WIDE_REV_BASE + 2 j]: 4 n - 4 = 220 of the 224 image registers at 56 taxa.  One or two pattern
+    #     groups per wave only.
+    WIDE_MAX_TIPS = 56
+    WIDE_TIP_SLOTS = 64
+    WIDE_REV_BASE = 2 * WIDE_MAX_TIPS
+    WIDE_MAX_INNER = WIDE_MAX_TIPS - 2
+    assert WIDE_REV_BASE + 2 * WIDE_MAX_INNER <= IMAGE_REGS
+
+    def __init__(self, G, exact=True, wide=False):
         self.G = G
         self.exact = exact  # image layout the pre-order loop is generated for (the only place the loops differ)
+        self.wide = wide
+        if wide:  # (instance attributes shadow the class's: every use below goes through self)
+            assert G < 4 and not exact
+            self.MAX_TIPS, self.REV_BASE, self.MAX_INNER = self.WIDE_MAX_TIPS, self.WIDE_REV_BASE, self.WIDE_MAX_INNER
         self.e = None
         V = Alloc(VBASE, VLIMIT, "VGPR")
         S = Alloc(SBASE, SLIMIT, "SGPR")
@@ -335,7 +349,7 @@ class Loops:
         # persistent
         # packed masks of tip t (byte g = mask of this lane's pattern in group g): 32 slots beside four groups'
         # registers, 48 beside fewer
-        self.TIP_SLOTS = 32 if G == 4 else 48
+        self.TIP_SLOTS = self.WIDE_TIP_SLOTS if wide else (32 if G == 4 else 48)
         self.TMV = V.get(self.TIP_SLOTS, "TMV", 4)
         self.U = g2("U")                      # pre-order partial of the step's node
         self.ONE = V.get(2, "ONE", 2)
@@ -1081,6 +1095,19 @@ def main():
         out.append(f"#define WALK_PIPE_TIP_SLOTS_G{G} {loops.TIP_SLOTS}")
         listing.append(f"G={G}: VGPR v{VBASE}..v{loops.vnext - 1}, AGPR a0..a{Loops.IMAGE_REGS - 1}, SGPR s{SBASE}..s{loops.snext - 1}; "
                        f"post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
+    for G in (1, 2):  # the wide layout: 49 to 56 taxa
+        loops = Loops(G, exact=False, wide=True)
+        post = loops.post_loop()
+        pre = Loops(G, exact=False, wide=True).pre_loop()
+        out.append(as_macro(f"WALK_PIPE_POST_W_ASM_G{G}", post.finish()))
+        out.append(as_macro(f"WALK_PIPE_PRE_REV_W_ASM_G{G}", pre.finish()))
+        out.append(f"#define WALK_PIPE_CLOBBERS_W_G{G} {clobbers(loops)}")
+        listing.append(f"G={G} wide: VGPR v{VBASE}..v{loops.vnext - 1}; post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
+    out.append(as_macro("WALK_PIPE_LOAD_REV_W_ASM", Loops(1, exact=False, wide=True).load_images(False).finish()))
+    out.append(f"#define WALK_PIPE_W_TIP_SLOTS {Loops.WIDE_TIP_SLOTS}")
+    out.append(f"#define WALK_PIPE_W_MAX_TIPS {Loops.WIDE_MAX_TIPS}")
+    out.append(f"#define WALK_PIPE_W_MAX_INNER {Loops.WIDE_MAX_INNER}")
+    out.append(f"#define WALK_PIPE_W_REV_BASE {Loops.WIDE_REV_BASE}")
     loops = Loops(1)
     out.append(as_macro("WALK_PIPE_LOAD_EXACT_ASM", loops.load_images(True).finish()))
     loops = Loops(1)

@@ -27,5 +27,8 @@ for n in [int(a) for a in sys.argv[1:]] or [27, 31, 36, 38]:
         eng.time_runs(True, False, 3)
         total, k, launches = eng.time_runs(True, False, 10)
         print(f"n={n} kernel={eng.kernel_name()}: step {total / 10:.3f} ms per 1600 trees ({1600 / (total / 10):.0f} k trees/s), walk kernel {k / launches:.3f} ms")
-    a, b = results[_capi.KERNEL_HBM_ARENA], results[_capi.KERNEL_LDS]
-    print(f"   max |dLL| between the last two {np.abs(a[0] - b[0]).max():.2e}, max |dgrad| {np.abs(a[1] - b[1]).max():.2e}")
+    a = results[_capi.KERNEL_HBM_ARENA]
+    for kern, name in ((_capi.KERNEL_LDS, "walk_lds_kernel"), (_capi.KERNEL_LDS_PIPE, "walk_pipe_kernel")):
+        if kern in results:
+            b = results[kern]
+            print(f"   HBM-arena walk vs {name}: max |dLL| {np.abs(a[0] - b[0]).max():.2e}, max |dgrad| {np.abs(a[1] - b[1]).max():.2e}")

@@ -529,7 +529,7 @@ def _random_rooted_parent_ids(n, rng):
 
 
 @pytest.mark.parametrize("kernel", [_capi.KERNEL_LDS, _capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS_PIPE])
-@pytest.mark.parametrize("n", [3, 4, 5, 7, 12, 29, 33, 38, 41, 48, 49])
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 12, 29, 33, 38, 41, 48, 49, 52, 56, 57])
 def test_random_shapes_rooted_and_unrooted(kernel, n):
     """Random topologies of many shapes -- caterpillars to balanced trees, cherries as first or second
     child, roots over a tip -- with gaps in the alignment, rooted and unrooted, 1, 2 and 4 categories:
@@ -555,7 +555,7 @@ def test_random_shapes_rooted_and_unrooted(kernel, n):
             params[:, 4:10] = rng.dirichlet([3] * 6, T)
             if C > 1:
                 params[:, 10] = rng.uniform(0.3, 2.0, T)
-            if kernel == _capi.KERNEL_LDS_PIPE and n > 48:  # a register per tip for its packed masks: up to 48 taxa
+            if kernel == _capi.KERNEL_LDS_PIPE and n > 56:  # 4n - 4 image registers: up to 56 taxa (the wide layout from 49)
                 with pytest.raises(bito_amd.BitoAmdError, match="pipelined LDS kernel was forced"):
                     gpu.gradients(pid, bl, params)
                 continue
@@ -619,6 +619,7 @@ def test_hbm_arena_walk_in_chunks():
     bl[:, -1] = 0.0
     per_tree = (n - 1) * 4 * 4 * 256 * 8  # (n - 1) vectors of 4 categories x 4 states x the padded patterns, doubles
     gpu = bito_amd.Engine(spec("HKY", "weibull+4"), patterns, weights, arena_bytes=3 * per_tree)  # three trees at a time
+    gpu.set_kernel(_capi.KERNEL_HBM_ARENA)  # (50 taxa: AUTO takes walk_pipe_kernel's wide layout when rescaling is off)
     cpu = oracle.OracleEngine("HKY", "weibull+4", "none", patterns, weights, 4)
     params = gpu.default_params(T)
     params[:, :4] = rng.dirichlet([5, 5, 5, 5], T)
@@ -800,7 +801,7 @@ def _shaped_rooted_parent_ids(n, shape):
 
 
 @pytest.mark.parametrize("site", ["constant", "weibull+2", "weibull+4"])
-@pytest.mark.parametrize("n", [5, 16, 27, 29, 32, 33, 38, 45, 48])
+@pytest.mark.parametrize("n", [5, 16, 27, 29, 32, 33, 38, 45, 48, 49, 53, 56])
 def test_pipe_walk_on_extreme_tree_shapes(n, site):
     """walk_pipe_kernel keeps one LDS cell per internal node that is not a cherry, and sizes its cells by the
     tree of the batch with the FEWEST cherries: a caterpillar (one cherry: the most cells, so fewer pattern
@@ -815,6 +816,8 @@ def test_pipe_walk_on_extreme_tree_shapes(n, site):
     pid = np.stack([_shaped_rooted_parent_ids(n, "caterpillar"), _shaped_rooted_parent_ids(n, "balanced"),
                     _random_rooted_parent_ids(n, rng)])
     bl = rng.exponential(0.1, (3, 2 * n - 1))
+    if n > 38:
+        bl = np.maximum(bl, 1e-4)  # (39 taxa and more: the one-image form is used from 9e-7 on)
     bl[:, -1] = 0.0
     gpu, cpu = engines("GTR", site, "none", patterns, weights, 3)
     gpu.set_kernel(_capi.KERNEL_LDS_PIPE)
@@ -837,13 +840,15 @@ def test_pipe_walk_on_extreme_tree_shapes(n, site):
 
 
 def test_auto_kernel_choice_at_the_pipe_walk_limits():
-    """AUTO: walk_pipe_kernel up to 48 taxa while the trees' stored vectors fit LDS (random trees: some 45 taxa) --
-    from 39 taxa on (one matrix image per branch, the reversible form of the pre-order recursion) only when no
-    branch is shorter than 1e-6; everything else, and rescaling at any size, goes to the HBM-arena walk
-    (walk_hbm_cat_kernel); each against the oracle."""
+    """AUTO: walk_pipe_kernel up to 56 taxa (49 to 56: the wide register layout) while the trees' stored vectors fit
+    LDS (random trees: some 45 taxa; the ladder-free trees drawn here always do) -- from 39 taxa on (one matrix image
+    per branch, the reversible form of the pre-order recursion) only when no branch is shorter than 1e-6; everything
+    else, and rescaling at any size, goes to the HBM-arena walk (walk_hbm_cat_kernel); each against the oracle."""
     rng = np.random.default_rng(29)
     for n, rescaling, shortest, expect in ((38, False, 0.0, "walk_pipe_kernel"), (41, False, 9.2e-7, "walk_pipe_kernel"),
                                            (41, False, 1e-7, "walk_hbm_cat_kernel"), (41, False, 0.0, "walk_hbm_cat_kernel"),
+                                           (49, False, 1e-3, None), (52, False, 1e-3, None), (56, False, 1e-3, None),
+                                           (52, False, 1e-8, "walk_hbm_cat_kernel"),
                                            (58, False, 1e-3, "walk_hbm_cat_kernel"), (29, True, 0.0, "walk_hbm_cat_kernel")):
         patterns = rng.integers(0, 4, (n, 70)).astype(np.int32)
         weights = np.ones(70)
@@ -854,7 +859,10 @@ def test_auto_kernel_choice_at_the_pipe_walk_limits():
         gpu, cpu = engines("HKY", "weibull+4", "none", patterns, weights, 4)
         out = gpu.gradients(pid, bl, rescaling=rescaling)
         ref = cpu.gradients(pid, bl, rescaling=rescaling)
-        assert gpu.kernel_name() == expect, (n, shortest)
+        if expect is None:  # 49 to 56 taxa: walk_pipe_kernel when this draw's trees fit LDS (few cherries: they do not)
+            assert gpu.kernel_name() in ("walk_pipe_kernel", "walk_hbm_cat_kernel"), (n, shortest)
+        else:
+            assert gpu.kernel_name() == expect, (n, shortest)
         assert ll_close(out["log_likelihood"], ref["log_likelihood"]), (n, shortest)
         fin = np.isfinite(ref["branch_lengths"])
         assert np.array_equal(fin, np.isfinite(out["branch_lengths"]))
