@@ -397,7 +397,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   bool use_tree = tplan.waves > 0 && !rescaling;
   bool use_lds = plan.groups > 0 && !rescaling;
   bool use_pipe = false;
-  // (39 to 48 taxa: walk_pipe_kernel's one-image-per-branch form holds to rounding only while no transition
+  // (39 to 64 taxa: walk_pipe_kernel's one-image-per-branch form holds to rounding only while no transition
   // matrix entry is all rounding error, i.e. no branch is shorter than 9e-7; see walk_pipe.hip)
   static const double min_branch_needed = [] {  // (BITO_AMD_PIPE_MIN_BRANCH: measurements of that bound)
     const char* v = std::getenv("BITO_AMD_PIPE_MIN_BRANCH");

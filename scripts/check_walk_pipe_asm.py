@@ -14,6 +14,8 @@ import os
 # WALK_PIPE_IMAGE_REGS of the generated loops this build includes
 _INC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bito_amd", "csrc", "walk_pipe_gen.inc")
 LIMIT = int(re.search(r"#define WALK_PIPE_IMAGE_REGS (\d+)", open(_INC).read()).group(1))
+# ... and of the wide layout's kernels (fourth template argument true: ...ELb1EEE / ...ELb0ELb1EE in the mangled name)
+WIDE_LIMIT = int(re.search(r"#define WALK_PIPE_W_IMAGE_REGS (\d+)", open(_INC).read()).group(1))
 
 
 def main(path):
@@ -50,8 +52,9 @@ def main(path):
             spilled.append((meta, int(m.group(1))))
         if inside or not kernel or not text or text[0] in ";.":
             continue
+        limit = WIDE_LIMIT if re.search(r"walk_pipe_kernelILi\dELi\dELb[01]ELb1EE", kernel) else LIMIT
         for mm in re.finditer(r"\ba\[?(\d+)", text.split(";")[0]):
-            if int(mm.group(1)) < LIMIT:
+            if int(mm.group(1)) < limit:
                 stray += 1
                 if stray <= 5:
                     print(f"stray AGPR use in {kernel}: {text}", file=sys.stderr)
@@ -61,7 +64,7 @@ def main(path):
     if stray:
         print(f"{stray} uses of a0..a{LIMIT - 1} outside the asm statements", file=sys.stderr)
         return 1
-    print(f"{kernels} walk_pipe_kernel instantiations: a0..a{LIMIT - 1} untouched outside the asm statements"
+    print(f"{kernels} walk_pipe_kernel instantiations: a0..a{LIMIT - 1} (wide layout: a0..a{WIDE_LIMIT - 1}) untouched outside the asm statements"
           + (f" ({len(spilled)} instantiations spill VGPRs, at most {max(c for _, c in spilled)}: none into the image registers)" if spilled else ""))
     return 0
 

@@ -329,11 +329,12 @@ class Loops:
     #     (5.5 % slower where 48 would do, hence a layout of its own), P of a tip's branch at a[2 tip], of an internal
     #     branch at a[WIDE_REV_BASE + 2 j]: 4 n - 4 = 220 of the 224 image registers at 56 taxa.  One or two pattern
     #     groups per wave only.
-    WIDE_MAX_TIPS = 56
+    WIDE_MAX_TIPS = 64
     WIDE_TIP_SLOTS = 64
     WIDE_REV_BASE = 2 * WIDE_MAX_TIPS
     WIDE_MAX_INNER = WIDE_MAX_TIPS - 2
-    assert WIDE_REV_BASE + 2 * WIDE_MAX_INNER <= IMAGE_REGS
+    WIDE_IMAGE_REGS = 252  # (the wide kernels carry at most two pattern groups: the compiler needs no AGPR there, checked at build time)
+    assert WIDE_REV_BASE + 2 * WIDE_MAX_INNER <= WIDE_IMAGE_REGS
 
     def __init__(self, G, exact=True, wide=False):
         self.G = G
@@ -1073,7 +1074,8 @@ def as_macro(name, lines):
 
 
 def clobbers(loops):
-    regs = [f"v{r}" for r in range(VBASE, loops.vnext)] + [f"a{r}" for r in range(Loops.IMAGE_REGS)] + \
+    regs = [f"v{r}" for r in range(VBASE, loops.vnext)] + \
+           [f"a{r}" for r in range(Loops.WIDE_IMAGE_REGS if loops.wide else Loops.IMAGE_REGS)] + \
            [f"s{r}" for r in range(SBASE, loops.snext)]
     return ", ".join(f'"{r}"' for r in regs) + ', "vcc", "scc", "memory"  /* (not m0: clang rejects it on a clobber list as a reserved register; it keeps no value there across a statement) */'
 
@@ -1108,6 +1110,7 @@ def main():
     out.append(f"#define WALK_PIPE_W_MAX_TIPS {Loops.WIDE_MAX_TIPS}")
     out.append(f"#define WALK_PIPE_W_MAX_INNER {Loops.WIDE_MAX_INNER}")
     out.append(f"#define WALK_PIPE_W_REV_BASE {Loops.WIDE_REV_BASE}")
+    out.append(f"#define WALK_PIPE_W_IMAGE_REGS {Loops.WIDE_IMAGE_REGS}")
     loops = Loops(1)
     out.append(as_macro("WALK_PIPE_LOAD_EXACT_ASM", loops.load_images(True).finish()))
     loops = Loops(1)

@@ -19,7 +19,7 @@ rng = np.random.default_rng(seed)
 bad = 0
 t0 = time.time()
 for case in range(cases):
-    n = int(rng.choice([3, 4, 5, 6, 8, 11, 16, 23, 27, 31, 36, 38, 40, 44, 48, 49, 52, 56, 57, 90]))
+    n = int(rng.choice([3, 4, 5, 6, 8, 11, 16, 23, 27, 31, 36, 38, 40, 44, 48, 49, 52, 56, 57, 60, 64, 65, 90]))
     P = int(rng.choice([1, 5, 16, 63, 64, 65, 130, 300]))
     T = int(rng.choice([1, 2, 7, 33]))
     sub = str(rng.choice(["JC69", "HKY", "GTR", "GY94"], p=[0.3, 0.3, 0.3, 0.1]))

@@ -529,7 +529,7 @@ def _random_rooted_parent_ids(n, rng):
 
 
 @pytest.mark.parametrize("kernel", [_capi.KERNEL_LDS, _capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS_PIPE])
-@pytest.mark.parametrize("n", [3, 4, 5, 7, 12, 29, 33, 38, 41, 48, 49, 52, 56, 57])
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 12, 29, 33, 38, 41, 48, 49, 52, 56, 57, 64, 65])
 def test_random_shapes_rooted_and_unrooted(kernel, n):
     """Random topologies of many shapes -- caterpillars to balanced trees, cherries as first or second
     child, roots over a tip -- with gaps in the alignment, rooted and unrooted, 1, 2 and 4 categories:
@@ -555,7 +555,7 @@ def test_random_shapes_rooted_and_unrooted(kernel, n):
             params[:, 4:10] = rng.dirichlet([3] * 6, T)
             if C > 1:
                 params[:, 10] = rng.uniform(0.3, 2.0, T)
-            if kernel == _capi.KERNEL_LDS_PIPE and n > 56:  # 4n - 4 image registers: up to 56 taxa (the wide layout from 49)
+            if kernel == _capi.KERNEL_LDS_PIPE and n > 64:  # 4n - 4 image registers, a mask register per tip: up to 64 taxa
                 with pytest.raises(bito_amd.BitoAmdError, match="pipelined LDS kernel was forced"):
                     gpu.gradients(pid, bl, params)
                 continue
@@ -801,7 +801,7 @@ def _shaped_rooted_parent_ids(n, shape):
 
 
 @pytest.mark.parametrize("site", ["constant", "weibull+2", "weibull+4"])
-@pytest.mark.parametrize("n", [5, 16, 27, 29, 32, 33, 38, 45, 48, 49, 53, 56])
+@pytest.mark.parametrize("n", [5, 16, 27, 29, 32, 33, 38, 45, 48, 49, 53, 56, 60, 64])
 def test_pipe_walk_on_extreme_tree_shapes(n, site):
     """walk_pipe_kernel keeps one LDS cell per internal node that is not a cherry, and sizes its cells by the
     tree of the batch with the FEWEST cherries: a caterpillar (one cherry: the most cells, so fewer pattern
@@ -840,16 +840,18 @@ def test_pipe_walk_on_extreme_tree_shapes(n, site):
 
 
 def test_auto_kernel_choice_at_the_pipe_walk_limits():
-    """AUTO: walk_pipe_kernel up to 56 taxa (49 to 56: the wide register layout) while the trees' stored vectors fit
-    LDS (random trees: some 45 taxa; the ladder-free trees drawn here always do) -- from 39 taxa on (one matrix image
+    """AUTO: walk_pipe_kernel up to 64 taxa (from 49: the wide register layout; trees that keep too many vectors
+    for two pattern groups per wave run with one and half-size cells) -- from 39 taxa on (one matrix image
     per branch, the reversible form of the pre-order recursion) only when no branch is shorter than 1e-6; everything
     else, and rescaling at any size, goes to the HBM-arena walk (walk_hbm_cat_kernel); each against the oracle."""
     rng = np.random.default_rng(29)
     for n, rescaling, shortest, expect in ((38, False, 0.0, "walk_pipe_kernel"), (41, False, 9.2e-7, "walk_pipe_kernel"),
                                            (41, False, 1e-7, "walk_hbm_cat_kernel"), (41, False, 0.0, "walk_hbm_cat_kernel"),
-                                           (49, False, 1e-3, None), (52, False, 1e-3, None), (56, False, 1e-3, None),
-                                           (52, False, 1e-8, "walk_hbm_cat_kernel"),
-                                           (58, False, 1e-3, "walk_hbm_cat_kernel"), (29, True, 0.0, "walk_hbm_cat_kernel")):
+                                           (58, False, 1e-3, "walk_pipe_kernel"), (29, True, 0.0, "walk_hbm_cat_kernel"),
+                                           # (round 3's sizes behind the earlier cases, whose random draws stay as they were)
+                                           (49, False, 1e-3, "walk_pipe_kernel"), (52, False, 1e-3, "walk_pipe_kernel"),
+                                           (56, False, 1e-3, "walk_pipe_kernel"), (64, False, 1e-3, "walk_pipe_kernel"),
+                                           (52, False, 1e-8, "walk_hbm_cat_kernel"), (66, False, 1e-3, "walk_hbm_cat_kernel")):
         patterns = rng.integers(0, 4, (n, 70)).astype(np.int32)
         weights = np.ones(70)
         pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(4)])
@@ -859,10 +861,7 @@ def test_auto_kernel_choice_at_the_pipe_walk_limits():
         gpu, cpu = engines("HKY", "weibull+4", "none", patterns, weights, 4)
         out = gpu.gradients(pid, bl, rescaling=rescaling)
         ref = cpu.gradients(pid, bl, rescaling=rescaling)
-        if expect is None:  # 49 to 56 taxa: walk_pipe_kernel when this draw's trees fit LDS (few cherries: they do not)
-            assert gpu.kernel_name() in ("walk_pipe_kernel", "walk_hbm_cat_kernel"), (n, shortest)
-        else:
-            assert gpu.kernel_name() == expect, (n, shortest)
+        assert gpu.kernel_name() == expect, (n, shortest)
         assert ll_close(out["log_likelihood"], ref["log_likelihood"]), (n, shortest)
         fin = np.isfinite(ref["branch_lengths"])
         assert np.array_equal(fin, np.isfinite(out["branch_lengths"]))
@@ -920,14 +919,23 @@ def test_large_batches_of_larger_trees_every_tree_every_pass():
     n, T = 64, 1600
     w = workloads.synthetic_gtr_weibull4(n=n, P=400, tree_count=T)
     gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
+    gpu.set_kernel(_capi.KERNEL_HBM_ARENA)
     good = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
     assert gpu.kernel_name() == "walk_hbm_cat_kernel"
     sel = np.r_[0:3, T - 3:T]
     ref = cpu.gradients(w.parent_ids[sel], w.branch_lengths[sel], w.params[sel])
     assert ll_close(good["log_likelihood"][sel], ref["log_likelihood"])
     assert grad_close(good["branch_lengths"][sel], ref["branch_lengths"])
-    for kernel in (_capi.KERNEL_AUTO, _capi.KERNEL_LDS):
+    # (walk_pipe_kernel takes 39 taxa and more when t_min x Q_min / 0.2 >= 9e-7: this model's smallest rate is 0.026)
+    bl_floor = np.maximum(w.branch_lengths, 1e-4)
+    bl_floor[:, -1] = 0.0
+    for kernel in (_capi.KERNEL_AUTO, _capi.KERNEL_LDS, _capi.KERNEL_LDS_PIPE):
         gpu.set_kernel(kernel)
+        if kernel == _capi.KERNEL_LDS_PIPE:  # the wide layout, one group per wave: every tree of every pass as well
+            gpu.set_kernel(_capi.KERNEL_HBM_ARENA)
+            good = gpu.gradients(w.parent_ids, bl_floor, w.params)
+            gpu.set_kernel(kernel)
+            w.branch_lengths = bl_floor
         for _ in range(3):
             out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
             assert ll_close(out["log_likelihood"], good["log_likelihood"])

@@ -272,18 +272,21 @@ def test_pipe_walk_planner():
     # 38 vectors per wave: 160 KB do not hold them beside two groups (1 KB cells); one group per wave keeps 512-byte
     # cells, twice as many
     assert _pipe_plan(48, 934, 4, 1600, 8)["groups"] == 1
-    # 49 to 56 taxa: the wide layout (64 mask registers, 4n - 4 <= 224 image registers), two groups at most
+    # 49 to 64 taxa: the wide layout (64 mask registers, 4n - 4 <= 252 image registers), two groups at most
     assert _pipe_plan(49, 934, 4, 1600, 20)["groups"] == 2
     assert _pipe_plan(56, 934, 4, 1600, 22)["groups"] == 2
     assert _pipe_plan(56, 934, 4, 1600, 10)["groups"] == 1  # 44 vectors per wave: one group, half-size cells
     assert _pipe_plan(56, 934, 4, 1600, 1)["groups"] == 1  # a caterpillar: 53 vectors
-    assert _pipe_plan(57, 934, 4, 1600, 25)["groups"] == 0
+    assert _pipe_plan(57, 934, 4, 1600, 25)["groups"] == 2  # (the wide kernels own all but four AGPRs: up to 64 taxa)
+    assert _pipe_plan(64, 934, 4, 1600, 21)["groups"] == 1
+    assert _pipe_plan(64, 934, 4, 1600, 1)["groups"] == 1   # a caterpillar: 61 vectors of 512 bytes per wave
+    assert _pipe_plan(65, 934, 4, 1600, 30)["groups"] == 0
     # one rate category: sixteen patterns per group, 256 per workgroup
     jc = _pipe_plan(27, 934, 1, 1600, 7)
     assert jc["groups"] == 4 and jc["patterns_per_workgroup"] == 256 and jc["tiles"] == 4 and jc["lds_bytes"] <= 160 * 1024
     assert _pipe_plan(27, 934, 3, 1600, 7)["groups"] == 0  # 1, 2 or 4 categories
     # every plan fits LDS and keeps at least the vectors the batch's worst tree needs
-    for n in range(3, 58):
+    for n in range(3, 66):
         for cherries in (1, n // 3, n // 2):
             for categories in (1, 2, 4):
                 p = _pipe_plan(n, 500, categories, 1000, cherries)
