@@ -239,6 +239,65 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
   return BITO_AMD_OK;
 }
 
+// Trees of 39 to 64 taxa take walk_pipe_kernel only in its one-image-per-branch form, which needs every branch of a
+// block well above the rounding error of its transition matrix (worker.cpp) -- and a worker
+// decides for its whole block, so ONE tree with a near-zero branch would send a collection of thousands to the
+// HBM-arena walk at half the speed.  Collections that mix the two kinds are therefore evaluated as two: the trees that
+// fit, and the others; inputs gathered, results scattered back by position.  (Such a call leaves no batch resident.)
+int EvaluateByKind(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
+                   const double* branch_lengths, const double* rates, const double* params, int rescaling,
+                   int want_gradient, int want_site, double* out_ll, double* out_grad, double* out_site, bool single) {
+  const Worker* w0 = Primary(e);
+  const ModelSpec& m = w0->spec;
+  const int C = m.category_count;
+  const bool candidates = !single && !rescaling && m.state_count == 4 && (C == 1 || C == 2 || C == 4) &&
+                          e->n > kPipeExactTaxa && e->n <= 64 && tree_count >= 2 && e->kernel_choice == BITO_AMD_KERNEL_AUTO &&
+                          parent_ids && branch_lengths && (m.param_count == 0 || params) && !(want_gradient == 0 && C == 1);
+  if (!candidates)
+    return Evaluate(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, rescaling, want_gradient,
+                    want_site, out_ll, out_grad, out_site, single);
+  const size_t M = (size_t)node_count, pc = (size_t)m.param_count, N = 2 * (size_t)e->n - 1;
+  const bool has_rates = rooted && rates != nullptr;
+  std::vector<int32_t> kind[2];  // [0]: trees that fit the form, [1]: the others
+  for (int32_t t = 0; t < tree_count; t++)
+    kind[TreeFitsReversibleForm(m, rooted, node_count, branch_lengths + t * M, has_rates ? rates + t * (M - 1) : nullptr,
+                                pc ? params + t * pc : nullptr) ? 0 : 1].push_back(t);
+  if (kind[0].empty() || kind[1].empty())
+    return Evaluate(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, rescaling, want_gradient,
+                    want_site, out_ll, out_grad, out_site, single);
+  // (checked as one collection first, so that an error names a tree by its position in the caller's arrays)
+  {
+    Worker* w = e->workers[0][0].get();
+    if (int rc = WorkerValidate(w, tree_count, rooted, node_count, parent_ids, pc ? params : nullptr)) return Propagate(e, w, rc);
+  }
+  for (const auto& ids : kind) {
+    const size_t K = ids.size();
+    std::vector<int32_t> pid(K * (M - 1));
+    std::vector<double> bl(K * M), par(K * std::max<size_t>(pc, 1)), rt(has_rates ? K * (M - 1) : 0);
+    std::vector<double> ll(K), grad(want_gradient ? K * N : 0), site(want_site ? K : 0);
+    for (size_t k = 0; k < K; k++) {
+      const size_t t = (size_t)ids[k];
+      std::copy(parent_ids + t * (M - 1), parent_ids + (t + 1) * (M - 1), pid.begin() + k * (M - 1));
+      std::copy(branch_lengths + t * M, branch_lengths + (t + 1) * M, bl.begin() + k * M);
+      if (pc) std::copy(params + t * pc, params + (t + 1) * pc, par.begin() + k * pc);
+      if (has_rates) std::copy(rates + t * (M - 1), rates + (t + 1) * (M - 1), rt.begin() + k * (M - 1));
+    }
+    const int rc = Evaluate(e, (int32_t)K, rooted, node_count, pid.data(), bl.data(), has_rates ? rt.data() : nullptr,
+                            pc ? par.data() : nullptr, rescaling, want_gradient, want_site, ll.data(),
+                            want_gradient ? grad.data() : nullptr, want_site ? site.data() : nullptr, single);
+    if (rc) return rc;
+    for (size_t k = 0; k < K; k++) {
+      const size_t t = (size_t)ids[k];
+      out_ll[t] = ll[k];
+      if (want_gradient && out_grad) std::copy(grad.begin() + k * N, grad.begin() + (k + 1) * N, out_grad + t * N);
+      if (want_site && out_site) out_site[t] = site[k];
+    }
+  }
+  e->resident = false;
+  e->shards.clear();
+  return BITO_AMD_OK;
+}
+
 int LogLikelihoods(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t node_count,
                    const int32_t* parent_ids, const double* branch_lengths, const double* rates, const double* params,
                    int32_t rescaling, double* out, bool single) {
@@ -246,8 +305,8 @@ int LogLikelihoods(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32
   // an empty collection is not an error: FatBeagleParallelize over no trees returns an empty vector
   // (reference src/fat_beagle.hpp:160-181)
   if (tree_count == 0) return BITO_AMD_OK;
-  return Evaluate(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, rescaling != 0, 0, 0,
-                  out, nullptr, nullptr, single);
+  return EvaluateByKind(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, rescaling != 0, 0, 0,
+                        out, nullptr, nullptr, single);
 }
 
 // the calls that work on ONE worker's resident batch (time trees, stream hand-off, event timing)
@@ -356,8 +415,8 @@ int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t ro
     if (rc) return rc;
   }
   const int want_site = (flags & BITO_AMD_GRAD_SITE_MODEL) && out_site && m.category_count > 1;
-  int rc = Evaluate(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, rescaling != 0, 1,
-                    want_site, out_ll, out_branch, out_site, /*single=*/false);
+  int rc = EvaluateByKind(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, rescaling != 0, 1,
+                          want_site, out_ll, out_branch, out_site, /*single=*/false);
   if (rc) return rc;
   if (rooted && (flags & BITO_AMD_GRAD_CLOCK_MODEL) && out_clock) {
     // ClockGradient, strict clock (reference src/fat_beagle.cpp:379-399): sum of

@@ -259,6 +259,29 @@ double MinOffDiagonalRate(const ModelSpec& m, const double* params, size_t T) {
   return lowest;
 }
 
+double PipeReversibleMinBranch() {  // (BITO_AMD_PIPE_MIN_BRANCH: measurements of that bound)
+  static const double bound = [] {
+    const char* v = std::getenv("BITO_AMD_PIPE_MIN_BRANCH");
+    return v ? std::atof(v) : kPipeReversibleMinBranch;
+  }();
+  return bound;
+}
+
+}  // namespace
+
+namespace bito_amd {
+// May one tree of 39 taxa or more take walk_pipe_kernel's one-image-per-branch form?  (The engine level sorts a
+// collection's trees by this before it hands them to workers: a worker decides for its whole block.)
+bool TreeFitsReversibleForm(const ModelSpec& m, int32_t rooted, int32_t node_count, const double* branch_lengths,
+                            const double* rates, const double* params) {
+  const double t_min = MinBranchLength(branch_lengths, rooted ? rates : nullptr, 1, (size_t)node_count);
+  const double q_min = MinOffDiagonalRate(m, params, 1);
+  return t_min * std::min(q_min / kPipeReversibleRateScale, 1.0) >= PipeReversibleMinBranch();
+}
+}  // namespace bito_amd
+
+namespace {
+
 DeviceBatch MakeBatch(Worker* e, int set = 0) {
   DeviceBatch b{};
   b.parent_ids = e->parent_ids.ptr;
@@ -399,10 +422,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   bool use_pipe = false;
   // (39 to 64 taxa: walk_pipe_kernel's one-image-per-branch form holds to rounding only while no transition
   // matrix entry is all rounding error, i.e. no branch is shorter than 9e-7; see walk_pipe.hip)
-  static const double min_branch_needed = [] {  // (BITO_AMD_PIPE_MIN_BRANCH: measurements of that bound)
-    const char* v = std::getenv("BITO_AMD_PIPE_MIN_BRANCH");
-    return v ? std::atof(v) : kPipeReversibleMinBranch;
-  }();
+  const double min_branch_needed = PipeReversibleMinBranch();
   // (kPipeReversibleMinBranch was measured on matrices whose smallest off-diagonal entry is about 0.2,
   // scripts/gpu_pipe_reversible_bound.py: what is held is the product)
   const bool pipe_branches_ok = d.taxon_count <= kPipeExactTaxa ||
@@ -895,6 +915,16 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
   e->dims.min_cherries = min_cherries;
   e->resident = true;
   return BITO_AMD_OK;
+}
+
+// the host-side checks of WorkerStage alone (messages name trees by their position in the arrays given)
+int WorkerValidate(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
+                   const double* params) {
+  if (!e || !parent_ids) return BITO_AMD_ERR_BAD_ARG;
+  e->id_offset = 0;
+  int rc = ValidateTrees(e, tree_count, rooted, node_count, parent_ids);
+  if (!rc && params) rc = ValidateParams(e, tree_count, params);
+  return rc;
 }
 
 int WorkerUpload(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,

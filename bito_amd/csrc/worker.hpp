@@ -213,6 +213,8 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
                 const double* branch_lengths, const double* rates, const double* params, int wait);
 int WorkerUpload(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
                  const double* branch_lengths, const double* rates, const double* params);
+int WorkerValidate(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
+                   const double* params);
 int WorkerUpdate(Worker* e, const double* branch_lengths, const double* params);
 int WorkerRun(Worker* e, int32_t want_gradient, int32_t rescaling);
 // the pass with everything RunResident takes: deriv_mode 1 = the site-model pass (d r_c / d shape in place of r_c),
@@ -273,6 +275,8 @@ using LogLikelihoodFn = std::function<int(int32_t, const int32_t*, const double*
 int SubstitutionGradientsVia(const ModelSpec& m, int T, int rooted, int node_count, const int32_t* parent_ids,
                              const double* branch_lengths, const double* rates, const double* params, bool stick,
                              double delta, double* out_subst, const LogLikelihoodFn& log_likelihoods);
+bool TreeFitsReversibleForm(const ModelSpec& m, int32_t rooted, int32_t node_count, const double* branch_lengths,
+                            const double* rates, const double* params);
 // host-only pieces the engine level shares with the worker level
 void StickForward(const double* y, int K, double* x);
 void StickInverse(const double* x, int K, double* y);

@@ -6,7 +6,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 T=$1
-B="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+# (round 3: bench.py's timed region is the blocking call, five chunked launches of the walk kernel per step; the second
+# region -- passes over a resident batch -- is left out so that the per-kernel averages are those of `value`'s region)
+B="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-resident"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_stats -o s -- $B > $R/gpurun_out/${T}_stats.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${T}_fetch -o f -- $B > $R/gpurun_out/${T}_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${T}_write -o w -- $B > $R/gpurun_out/${T}_write.log 2>&1
@@ -14,7 +16,7 @@ python3 $R/bench.py --steps 50 --warmup 5 > $R/gpurun_out/${T}_bench.json 2> $R/
 python3 - <<PY
 import csv, collections, json
 R='$R'; T='$T'
-out={'command':'rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline','counters':{}}
+out={'command':'rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-resident','counters':{}}
 for name,f in (('FETCH_SIZE',f'{R}/gpurun_out/{T}_fetch/f_counter_collection.csv'),('WRITE_SIZE',f'{R}/gpurun_out/{T}_write/w_counter_collection.csv')):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):

@@ -185,3 +185,42 @@ def test_rooted_trees_with_rates_and_rescaling_through_chunks(data_dir):
         assert _close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
         assert _close(out["clock_model"], ref["clock_model"], GRAD_ATOL, 1e-8)
         assert _close(out["site_model"], ref["site_model"], GRAD_ATOL, 1e-8)
+
+
+@pytest.mark.gpu
+def test_collections_that_mix_short_and_ordinary_branches_are_evaluated_by_kind():
+    """39 to 64 taxa: walk_pipe_kernel's one-image-per-branch form needs every branch of a block well above the
+    rounding error of its transition matrix, and a worker decides for its whole block -- so the engine sorts a mixed
+    collection into the trees that fit (walk_pipe_kernel) and the others (HBM-arena walk) and scatters the results
+    back.  Against the oracle, with the positions of the odd trees scattered through the collection."""
+    from oracle import oracle
+
+    rng = np.random.default_rng(5)
+    n, T = 50, 40
+    w = workloads.synthetic_gtr_weibull4(n=n, P=200, tree_count=T)
+    bl = np.maximum(w.branch_lengths, 1e-3)
+    bl[:, -1] = 0.0
+    odd = [3, 4, 17, 39]
+    for t in odd:
+        bl[t, rng.integers(0, 2 * n - 3)] = 1e-9
+    gpu = bito_amd.Engine(_spec(w), w.patterns, w.weights)
+    cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
+    out = gpu.gradients(w.parent_ids, bl, w.params, flags=_capi.GRAD_SITE_MODEL)
+    ref = cpu.gradients(w.parent_ids, bl, w.params, flags=oracle.GRAD_SITE_MODEL)
+    assert _close(out["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL)
+    assert np.allclose(out["branch_lengths"], ref["branch_lengths"], rtol=GRAD_RTOL, atol=GRAD_ATOL)
+    assert _close(out["site_model"], ref["site_model"], GRAD_ATOL, 1e-8)
+    assert gpu.kernel_name() in ("walk_pipe_kernel", "walk_hbm_cat_kernel")
+    with pytest.raises(bito_amd.BitoAmdError, match="no batch is resident"):
+        gpu.run(True)  # (a call evaluated as two collections leaves none of them resident)
+    # the same trees without the short branches: one collection, walk_pipe_kernel
+    bl2 = np.maximum(bl, 1e-3)
+    bl2[:, -1] = 0.0
+    out2 = gpu.gradients(w.parent_ids, bl2, w.params)
+    assert gpu.kernel_name() == "walk_pipe_kernel"
+    assert _close(out2["log_likelihood"], cpu.log_likelihoods(w.parent_ids, bl2, w.params), LL_ATOL, LL_RTOL)
+    # errors name the caller's tree
+    pid = w.parent_ids.copy()
+    pid[30, 0] = 0
+    with pytest.raises(bito_amd.BitoAmdError, match="tree 30: parent id 0"):
+        gpu.gradients(pid, bl, w.params)
