@@ -409,6 +409,7 @@ def main():
                     "roofline": roofline_object(r_kernel, n, P, C, S, w.want_gradient, T * args.steps / max(r_launches, 1),
                                                 r_kernel_ms * 1e-3 / max(r_launches, 1), args.workload)}
 
+    out = None
     if rank == 0:
         total_trees = world * T
         value = total_trees * args.steps / elapsed
@@ -463,10 +464,13 @@ def main():
             out["resident"] = resident
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # (the one JSON line goes out last and flushed: RCCL writes its version banner straight to file descriptor 1)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
