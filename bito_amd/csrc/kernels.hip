@@ -93,41 +93,6 @@ setup_large_trees_kernel(BatchDims d, ModelSpec spec, DeviceBatch b) {
   if (tid == 0) SetupTreeModel(spec, b.params + (size_t)t * spec.param_count, &b.model[t]);
 }
 
-static size_t SetupLdsBytesPerTree(const BatchDims& d, const ModelSpec& spec) {
-  // effective branch lengths [N], parameter row, rates [M-1] (rooted trees only: 0 doubles when there are none is
-  // decided at launch; sized for them here), parent ids [M-1], child lists [2 NI]
-  return ((size_t)d.node_count + std::max(spec.param_count, 1) + (d.rooted ? d.in_node_count - 1 : 0)) * sizeof(double) +
-         (d.in_node_count - 1 + 2 * (d.taxon_count - 1)) * sizeof(int32_t);
-}
-
-// The wire-format rows of the workgroup's trees go through LDS: coalesced loads (from HBM, or straight from the
-// caller's pinned staging buffer over PCIe -- a blocking call's chunk, which then also leaves the device copies for
-// later passes, DeviceBatch::copy_*), one thread per tree out of LDS, coalesced stores.
-// (element i of a workgroup's slice of a wire-format array: loaded by thread i mod 256, four elements per thread in
-// flight at once -- over PCIe a load takes two microseconds, and a loop that waits for each one before it issues the
-// next costs a workgroup of sixteen trees thirty)
-template <typename T, typename Store>
-__device__ __forceinline__ void StageSlice(const T* __restrict__ src, T* __restrict__ copy, int total, int tid,
-                                           const Store& store) {
-  constexpr int kStep = 256, kInFlight = 4;
-  for (int i0 = tid; i0 < total; i0 += kStep * kInFlight) {
-    T v[kInFlight];
-#pragma unroll
-    for (int u = 0; u < kInFlight; u++) {
-      const int i = i0 + u * kStep;
-      v[u] = i < total ? src[i] : T();
-    }
-#pragma unroll
-    for (int u = 0; u < kInFlight; u++) {
-      const int i = i0 + u * kStep;
-      if (i < total) {
-        store(i, v[u]);
-        if (copy != nullptr) copy[i] = v[u];
-      }
-    }
-  }
-}
-
 __global__ void __launch_bounds__(256)
 setup_trees_lds_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, int trees) {
   extern __shared__ double setup_lds[];
@@ -140,15 +105,15 @@ setup_trees_lds_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, int trees) {
   double* rts = prm + trees * pc;                                // [trees][M-1] (rooted trees with rates)
   int32_t* par = reinterpret_cast<int32_t*>(rts + trees * (d.rooted ? M - 1 : 0));  // [trees][M-1]
   int32_t* ch = par + trees * (M - 1);                           // [trees][2 NI]
-  StageSlice(b.parent_ids + (size_t)t0 * (M - 1), b.copy_parent_ids ? b.copy_parent_ids + (size_t)t0 * (M - 1) : nullptr,
+  StageSlice<256>(b.parent_ids + (size_t)t0 * (M - 1), b.copy_parent_ids ? b.copy_parent_ids + (size_t)t0 * (M - 1) : nullptr,
              count * (M - 1), tid, [&](int i, int32_t v) { par[i] = v; });
-  StageSlice(b.branch_in + (size_t)t0 * M, b.copy_branch_in ? b.copy_branch_in + (size_t)t0 * M : nullptr, count * M, tid,
+  StageSlice<256>(b.branch_in + (size_t)t0 * M, b.copy_branch_in ? b.copy_branch_in + (size_t)t0 * M : nullptr, count * M, tid,
              [&](int i, double v) { bl[(i / M) * N + i % M] = v; });
   if (spec.param_count > 0)
-    StageSlice(b.params + (size_t)t0 * pc, b.copy_params ? b.copy_params + (size_t)t0 * pc : nullptr, count * pc, tid,
+    StageSlice<256>(b.params + (size_t)t0 * pc, b.copy_params ? b.copy_params + (size_t)t0 * pc : nullptr, count * pc, tid,
                [&](int i, double v) { prm[i] = v; });
   if (RW)
-    StageSlice(b.rates + (size_t)t0 * RW, b.copy_rates ? b.copy_rates + (size_t)t0 * RW : nullptr, count * RW, tid,
+    StageSlice<256>(b.rates + (size_t)t0 * RW, b.copy_rates ? b.copy_rates + (size_t)t0 * RW : nullptr, count * RW, tid,
                [&](int i, double v) { rts[i] = v; });
   __syncthreads();
   // Three serial jobs per tree that share nothing: the topology (child lists, effective branch lengths), the rate

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 
@@ -120,6 +121,43 @@ __device__ inline void SetupTopology(const BatchDims& d, const DeviceBatch& b, i
   SetupTopologyCore(d, b.parent_ids + (size_t)t * (M - 1), b.children + (size_t)t * (n - 1) * 2, bl,
                     b.rates != nullptr ? b.rates + (size_t)t * (M - 1) : nullptr);
 }
+
+// ---- the staging set-up kernels (kernels.hip: setup_trees_lds_kernel; walk_pipe.hip: pipe_setup_kernel) ----
+inline size_t SetupLdsBytesPerTree(const BatchDims& d, const ModelSpec& spec) {
+  // effective branch lengths [N], parameter row, rates [M-1] (rooted trees only: 0 doubles when there are none is
+  // decided at launch; sized for them here), parent ids [M-1], child lists [2 NI]
+  return ((size_t)d.node_count + std::max(spec.param_count, 1) + (d.rooted ? d.in_node_count - 1 : 0)) * sizeof(double) +
+         (d.in_node_count - 1 + 2 * (d.taxon_count - 1)) * sizeof(int32_t);
+}
+
+// The wire-format rows of the workgroup's trees go through LDS: coalesced loads (from HBM, or straight from the
+// caller's pinned staging buffer over PCIe -- a blocking call's chunk, which then also leaves the device copies for
+// later passes, DeviceBatch::copy_*), one thread per tree out of LDS, coalesced stores.
+// (element i of a workgroup's slice of a wire-format array: loaded by thread i mod kStep (the workgroup size), four elements per thread in
+// flight at once -- over PCIe a load takes two microseconds, and a loop that waits for each one before it issues the
+// next costs a workgroup of sixteen trees thirty)
+template <int kStep, typename T, typename Store>
+__device__ __forceinline__ void StageSlice(const T* __restrict__ src, T* __restrict__ copy, int total, int tid,
+                                           const Store& store) {
+  constexpr int kInFlight = 4;
+  for (int i0 = tid; i0 < total; i0 += kStep * kInFlight) {
+    T v[kInFlight];
+#pragma unroll
+    for (int u = 0; u < kInFlight; u++) {
+      const int i = i0 + u * kStep;
+      v[u] = i < total ? src[i] : T();
+    }
+#pragma unroll
+    for (int u = 0; u < kInFlight; u++) {
+      const int i = i0 + u * kStep;
+      if (i < total) {
+        store(i, v[u]);
+        if (copy != nullptr) copy[i] = v[u];
+      }
+    }
+  }
+}
+
 
 // beside_traversal: the launch will run next to a traversal that needs whole CUs, so it should sit on as few
 // CUs as possible (up to 128 trees per workgroup) rather than finish as early as possible (16 per workgroup)
