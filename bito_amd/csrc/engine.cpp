@@ -10,6 +10,7 @@
 // chunk or device a tree went to except the order of the pattern-tile sums (rounding level,
 // see INTEGRATION.md).
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -166,14 +167,26 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
   if (int rc = PlanShards(e, tree_count, single, &e->shards)) return rc;
   const bool has_rates = rooted && rates != nullptr;
   size_t drained = 0;
+  // (BITO_AMD_TRACE_CALL=1: host-side time line of the call on stderr -- when each chunk was issued and when its
+  // results had arrived)
+  static const bool trace = std::getenv("BITO_AMD_TRACE_CALL") != nullptr;
+  const auto call_start = std::chrono::steady_clock::now();
+  auto stamp = [&](const char* what, size_t k) {
+    if (trace)
+      std::fprintf(stderr, "  %8.1f us  %s chunk %zu (%d trees)\n",
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - call_start).count(), what, k,
+                   e->shards[k].count);
+  };
   auto drain = [&](size_t k) -> int {
     const Shard& s = e->shards[k];
     Worker* w = ShardWorker(e, s);
     const double *ll = nullptr, *grad = nullptr, *site = nullptr;
     if (int rc = Propagate(e, w, WorkerResults(w, &ll, &grad, &site))) return rc;
+    stamp("results of", k);
     std::memcpy(out_ll + s.t0, ll, (size_t)s.count * sizeof(double));
     if (want_gradient && out_grad) std::memcpy(out_grad + (size_t)s.t0 * N, grad, (size_t)s.count * N * sizeof(double));
     if (want_site && out_site && w->site_ready) std::memcpy(out_site + s.t0, site, (size_t)s.count * sizeof(double));
+    stamp("copied out", k);
     return BITO_AMD_OK;
   };
   std::vector<char> slot_busy(e->devices.size(), 0);
@@ -202,8 +215,10 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
     int rc = WorkerStage(w, s.count, rooted, node_count, parent_ids + (size_t)s.t0 * (M - 1),
                          branch_lengths + (size_t)s.t0 * M, has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr,
                          pc > 0 ? params + (size_t)s.t0 * pc : nullptr, /*wait=*/0);
+    stamp("staged", k);
     if (!rc) rc = WorkerRunPass(w, want_gradient, rescaling, 0, want_site);
     if (!rc) rc = WorkerFetchResults(w, want_gradient, want_site);
+    stamp("issued", k);
     if (rc) {
       Propagate(e, w, rc);
       SyncShards(e, k + 1);

@@ -98,6 +98,10 @@ class Engine:
 
     # -- BlockSpecification -------------------------------------------------
     def block_map(self) -> Dict[str, Tuple[int, int]]:
+        """BlockSpecification::GetMap; fixed for the engine's lifetime, so asked of the library once."""
+        cached = getattr(self, "_block_map", None)
+        if cached is not None:
+            return dict(cached)
         L = _capi.lib()
         out = {}
         name = C.create_string_buffer(64)
@@ -105,6 +109,7 @@ class Engine:
         for i in range(L.bito_amd_engine_block_count(self._h)):
             L.bito_amd_engine_block(self._h, i, name, 64, C.byref(s), C.byref(ln))
             out[name.value.decode()] = (s.value, ln.value)
+        self._block_map = dict(out)
         return out
 
     def default_params(self, tree_count: int) -> np.ndarray:
