@@ -363,6 +363,24 @@ def main():
         if not abs(summed_ll - expect) <= 1e-9 * abs(expect):
             raise SystemExit(f"summed log-likelihood {summed_ll} differs from the gathered sum {expect}")
 
+    # the same blocking call on small collections (BASELINE's literal "100 topologies", vip's particle loop): ms per call
+    small_calls = None
+    if args.workload == "ds1" and world == 1:
+        small_calls = {}
+        for count in (1, 100, 400, 1600):
+            if count > T:
+                continue
+            ll_s, grad_s = np.zeros(count), np.zeros((count, N))
+            pid_s, par_s = np.ascontiguousarray(pid[:count]), np.ascontiguousarray(params[:count])
+            bl_s = [np.ascontiguousarray(b[:count]) for b in bl_sets]
+            for k in range(5):
+                eng.gradients_into(pid_s, bl_s[k & 1], par_s, ll_s, grad_s)
+            reps = 40
+            s0 = time.perf_counter()
+            for k in range(reps):
+                eng.gradients_into(pid_s, bl_s[k & 1], par_s, ll_s, grad_s)
+            small_calls[str(count)] = (time.perf_counter() - s0) / reps * 1e3
+
     # second timed region: the same passes over a batch that stays in HBM (no host arrays cross PCIe)
     resident = None
     if not args.no_resident:
@@ -460,6 +478,9 @@ def main():
                                         args.workload),
         }
         out["roofline"]["launches_per_step"] = launches / args.steps
+        if small_calls:
+            out["blocking_call_ms"] = {"trees_per_call": small_calls,
+                                       "note": "the same gradients call on 1 / 100 / 400 / 1600 of the trees, mean of 40 calls"}
         if resident is not None:
             out["resident"] = resident
         if world == 1 and not args.no_cpu_baseline:
