@@ -11,7 +11,7 @@ while [ $# -ge 3 ]; do
   cp walk_pipe.hip kernels.hpp model.hpp $d/
   (cd ../.. && env $envs python3 scripts/gen_walk_pipe.py >/dev/null && cp bito_amd/csrc/walk_pipe_gen.inc $d/)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form $flags -c $d/walk_pipe.hip -o $d/walk_pipe.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/$name.so kernels.o gs_kernels.o walk_lds.o $d/walk_pipe.o walk_tree.o time_tree.o engine.o beagle_shim.o gp_engine.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/$name.so kernels.o gs_kernels.o walk_lds.o $d/walk_pipe.o walk_tree.o time_tree.o worker.o engine.o beagle_shim.o gp_engine.o
   echo built $name
 done
 (cd ../.. && python3 scripts/gen_walk_pipe.py >/dev/null)  # restore the shipped .inc
