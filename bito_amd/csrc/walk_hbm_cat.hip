@@ -124,22 +124,39 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
                     const double* __restrict__ all_mats, const TreeModel* __restrict__ models,
                     const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
                     double* __restrict__ arena_base, double* __restrict__ part_ll, double* __restrict__ part_grad,
-                    int deriv_mode) {
+                    int deriv_mode, int tile_count, int chunk, int by_xcd) {
   extern __shared__ double lds[];  // [threads][4] hand-over column | [threads][4] pending column | [threads] terms | [threads] exponents
   const int n = d.taxon_count, N = d.node_count, NI = n - 1, Ppad = d.pattern_stride, C = d.category_count;
-  const int tree = tree0 + blockIdx.y;
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id (observed, not promised: a wrong guess costs speed
+  // only).  A tree's tiles all read the same 4.6 KB-per-node table of transition matrices, wave by wave through the
+  // scalar cache and L2: with id % 8 picking the tree among eight, each XCD's L2 holds the matrices of the one or two
+  // trees its CUs are walking instead of those of every tree in flight (a dozen at config 4's size: 60 MB through
+  // 4 MB).  The trees past the last full eight are dealt tile by tile.
+  int tree_local, tile_id;
+  {
+    const int id = blockIdx.x, full = by_xcd ? (chunk & ~7) : 0;
+    if (id < full * tile_count) {
+      const int j = id >> 3;
+      tree_local = (j / tile_count) * 8 + (id & 7);
+      tile_id = j % tile_count;
+    } else {
+      const int rest = id - full * tile_count;
+      tree_local = full + rest / tile_count;
+      tile_id = rest % tile_count;
+    }
+  }
+  const int tree = tree0 + tree_local;
   const int tid = threadIdx.x, lane = tid & 63, threads = blockDim.x;
   const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int p = blockIdx.x * kCatTile + lane;
+  const int p = tile_id * kCatTile + lane;
   const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
   const double* __restrict__ mats = all_mats + ((size_t)tree * (N - 1) * C + c) * kMatStride;  // + node * C * kMatStride
   const size_t node_mat = (size_t)C * kMatStride;
   const TreeModel* __restrict__ tm = models + tree;
   // every per-lane access: descriptor (wave-uniform base) + wave-uniform byte offset + this lane's 32-bit offset
-  const BufferRsrc tips = MakeRsrc(tip_states + (size_t)blockIdx.x * kCatTile);  // [taxon * Ppad][lane]
-  const int tile_count = gridDim.x;
+  const BufferRsrc tips = MakeRsrc(tip_states + (size_t)tile_id * kCatTile);  // [taxon * Ppad][lane]
   // [(node - n) * C * 2 KB][state * 512 + lane * 8]
-  const BufferRsrc arena = MakeRsrc(arena_base + (((size_t)blockIdx.y * tile_count + blockIdx.x) * NI * C + c) * 4 * kCatTile);
+  const BufferRsrc arena = MakeRsrc(arena_base + (((size_t)tree_local * tile_count + tile_id) * NI * C + c) * 4 * kCatTile);
   const BufferRsrc matrows = MakeRsrc(mats);  // [node * C * kMatStride * 8][(kMatPT + state * 4) * 8]
   const unsigned node_bytes = (unsigned)C * 4 * kCatTile * 8, mat_bytes = (unsigned)C * kMatStride * 8;
   const unsigned ulane = lane;
@@ -278,7 +295,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
 
   if (c == 0) {
     const double wll = WaveSum(ll);
-    if (lane == 0) part_ll[(size_t)tree * gridDim.x + blockIdx.x] = wll;
+    if (lane == 0) part_ll[(size_t)tree * tile_count + tile_id] = wll;
   }
   // ---- pre-order + edge derivatives -----------------------------------------
   // Messages: a_k = P_k x_k.  With u the pre-order partial of the node,
@@ -290,7 +307,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     const double rate = deriv_mode ? tm->cat_rate_deriv[c] : tm->cat_rate[c];
     // rescaled: w_p sigma_c r_c (then times num_c / den_c per edge); plain: w_p w_c r_c / L_p (then times num_c)
     const double gw = RESCALE ? weight * (mine / total) * rate : weight * (tm->cat_weight[c] / total) * rate;
-    double* __restrict__ my_row = part_grad + (((size_t)tree * gridDim.x + blockIdx.x) * C + c) * N;
+    double* __restrict__ my_row = part_grad + (((size_t)tree * tile_count + tile_id) * C + c) * N;
     const double* __restrict__ Q = tm->Q;
     bool u_forwarded = false;
     pend_owner = -1;  // (what the post-order pass left there is in the arena as well)
@@ -455,10 +472,12 @@ int HbmWalkGradRows(const BatchDims& d) {
 void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk, int want_gradient,
                       int rescaling, int deriv_mode, hipStream_t stream) {
   const int threads = 64 * d.category_count;
-  const dim3 grid(HbmCatTiles(d.pattern_count), chunk), block(threads);
+  const int tiles = HbmCatTiles(d.pattern_count);
+  const dim3 grid((unsigned)tiles * (unsigned)chunk), block(threads);
   const size_t lds = (size_t)threads * (8 * sizeof(double) + sizeof(double) + sizeof(int));
+  static const int by_xcd = [] { const char* v = getenv("BITO_AMD_HBM_BY_XCD"); return v ? atoi(v) : 1; }();
 #define BITO_CAT(G, R) hipLaunchKernelGGL((walk_hbm_cat_kernel<G, R>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model, \
-                                          b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad, deriv_mode)
+                                          b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad, deriv_mode, tiles, chunk, by_xcd)
   if (want_gradient) { if (rescaling) BITO_CAT(true, true); else BITO_CAT(true, false); }
   else { if (rescaling) BITO_CAT(false, true); else BITO_CAT(false, false); }
 #undef BITO_CAT
