@@ -721,9 +721,9 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       if (node == N - 1) {
         load_pi(bb);
         site += model[kGsCatWeight + c] * GsDot(bb, a);
-      } else if (active && (!chain || (ch[(node + 1 - n) * 2] != node && ch[(node + 1 - n) * 2 + 1] != node))) {
-        // (a vector that the next node consumes from registers needs no copy in memory: the pre-order pass
-        // works from the MESSAGES kept above, not from the partials)
+      } else if (active && (GRAD || !chain || node + 1 >= N || (ch[(node + 1 - n) * 2] != node && ch[(node + 1 - n) * 2 + 1] != node))) {
+        // (a log-likelihood-only walk needs no copy in memory of a vector that is consumed from
+        // registers by the next node)
         GsStore(slot(node, c), lane, a);
       }
     }
@@ -771,7 +771,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       // walk_hbm_kernel)
       const double step_inv = RESCALE ? *inv_at(node) : 1.0;
       for (int c = 0; c < C; c++) {
-        GsPlv u, af, al, wf, wl, x;
+        GsPlv u, wf, wl, x;
         if (node == N - 1) {
           load_pi(u);
         } else if (have_u) {
@@ -780,10 +780,10 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           GsLoad(slot(node, c), lane, u);
         }
         // child messages: a_f -> w_l = u . a_f (what the LAST child sees), a_l -> w_f = u . a_l
-        if (cf < n) GsTip(rec(cf, c, 0), sf, kq, af);
-        else GsLoad(mslot(cf, c), lane, af);
-        if (cl < n) GsTip(rec(cl, c, 0), sl, kq, al);
-        else GsLoad(mslot(cl, c), lane, al);
+        if (cf < n) GsTip(rec(cf, c, 0), sf, kq, wl);
+        else GsLoad(mslot(cf, c), lane, wl);
+        if (cl < n) GsTip(rec(cl, c, 0), sl, kq, wf);
+        else GsLoad(mslot(cl, c), lane, wf);
         const double wc = model[kGsCatWeight + c];
         {
           double sden = 0.0;
@@ -791,26 +791,30 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-              const double uu = u.b[m][r];
-              wf.b[m][r] = uu * al.b[m][r];
-              wl.b[m][r] = uu * af.b[m][r];
-              sden += wf.b[m][r] * af.b[m][r];
+              const double af = wl.b[m][r], al = wf.b[m][r], uu = u.b[m][r];
+              wf.b[m][r] = uu * al;
+              wl.b[m][r] = uu * af;
+              sden += wf.b[m][r] * af;
             }
           den += wc * sden;
         }
-        // per child: pre-order partial q = P^T w (kept for the child's own step: in registers when that step comes
-        // next, else in the cell that held the child's post-order partial), and the edge derivative
-        // w^T (r_c Q) (P x) = (Q^T w) . a r_c with the child's message a = P x -- the reference's
-        // pre^T (r_c Q) post = w^T P (r_c Q) x (src/fat_beagle.cpp:101-160) with Q and P = exp(Q t) commuted, so that
-        // the pass needs the messages only; a tip child reads dP's column instead
+        // per child: pre-order partial q = P^T w (stored in place of the child's post-order partial
+        // x), and the edge derivative in the reference's own form  pre^T (r_c Q) post = (Q^T q) . x r_c
+        // (src/fat_beagle.cpp:101-160); a tip child reads dP's column instead.
+        // (Tried and withdrawn: w^T (r_c Q) (P x) with the child's MESSAGE P x, which the pass has in hand anyway --
+        // x need not be read again, chained partials need not be stored at all: 56.8 -> 54.2 ms per 4096 config-5
+        // trees.  Q and the ROUNDED P of a codon model do not commute to better than about 1e-6 relative (V e^{Lt} V^-1
+        // at 61 states), and on short branches with large derivatives that is a thousand tolerances away from the
+        // reference's form: seeded sweep cases 104 and 119 of tests/test_gpu_fuzz.py.)
         const double rc = model[(deriv_mode ? kGsCatRateDeriv : kGsCatRate) + c];  // site-model pass: d r_c / d shape
         if (cf < n) {
           GsTip(rec(cf, c, 1), sf, kq, x);
           numf += wc * GsDot(wf, x);
         } else {
           pipe.MatVec(wf, y);
-          pipe.MatVec(wf, x);
-          numf += wc * rc * GsDot(x, af);
+          pipe.MatVec(y, wf);
+          GsLoad(slot(cf, c), lane, x);  // (x is read before q takes its place)
+          numf += wc * rc * GsDot(wf, x);
           if (RESCALE) {
 #pragma unroll
             for (int m = 0; m < 4; m++) y.b[m] *= step_inv;
@@ -822,8 +826,9 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           numl += wc * GsDot(wl, x);
         } else {
           pipe.MatVec(wl, y);
-          pipe.MatVec(wl, x);
-          numl += wc * rc * GsDot(x, al);
+          pipe.MatVec(y, wl);
+          GsLoad(slot(cl, c), lane, x);
+          numl += wc * rc * GsDot(wl, x);
           if (RESCALE) {
 #pragma unroll
             for (int m = 0; m < 4; m++) y.b[m] *= step_inv;

@@ -60,7 +60,7 @@ struct DeviceBatch {
   TreeModel* model;           // [T]
   double* mats;               // [T][N-1][C][kMatStride]   (HBM-arena kernel)
   double* images;             // [T][N-1][kImgStride]      (LDS kernel)
-  int32_t* sched;             // [T][2][n+1][16]           step descriptors (LDS kernel)
+  int32_t* sched;             // [T][2][n+1][16]           step descriptors (LDS kernel); step records in visiting order (HBM-arena walk)
   const uint32_t* pipe_masks; // [tiles][n][waves][16/C]   packed tip masks per pattern tile (walk_pipe_kernel)
   int32_t* pipe_queue;        // [2] next unit of work, workgroups that have left (walk_pipe_kernel; zero between launches)
   // traversal scratch + outputs
@@ -255,6 +255,9 @@ constexpr double kPipeReversibleMinBranch = 9e-7;  // (just below exp(-13.9), th
 bool HbmCatKernelApplies(const BatchDims& d);
 // out_site from walk_hbm_cat_kernel's per-category gradient rows (after the walk of every chunk), no second traversal
 void LaunchSiteFromCategoryRows(const BatchDims& d, const DeviceBatch& b, int rows, hipStream_t stream);
+// the order in which walk_hbm_cat_kernel takes a tree's internal nodes, as step records in b.sched (HbmOrderInts int32)
+size_t HbmOrderInts(const BatchDims& d);
+void LaunchHbmOrder(const BatchDims& d, const DeviceBatch& b, hipStream_t stream);
 void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk_trees, int want_gradient,
                       int rescaling, int deriv_mode, hipStream_t stream);
 

@@ -77,6 +77,107 @@ inline int HbmCatTiles(int pattern_count) { return (pattern_count + kCatTile - 1
 // registers: held to 64 it spills (config 4, 125 trees, same box: 84.8 ms against 69.9), at six waves per SIMD it
 // gains 2.5-4 % (66.7 / 69.4 ms against 69.9 / 71.2; 41 taxa: 3.54 against 3.78 ms) -- the arena traffic it saves is
 // paid for in vector and scalar work at lower occupancy.
+// ---- visiting order -------------------------------------------------------------------------------------------
+// The walk keeps the vector it has just computed in registers and ONE or TWO older ones in LDS columns (below); every
+// other operand is read back from the arena.  How often that happens depends on the ORDER in which a node's two subtrees
+// are visited: the one that needs more pending vectors first (Sethi-Ullman labelling of expression trees), so that the
+// single vector that waits while the second subtree is walked is rarely displaced.  The node ids of the wire format are
+// a post-order already, but with the children in id order: on BASELINE config 4's trees (1000 taxa) the walk in id order
+// moves 1672 vectors per tree and pass, in this order 1478 (scripts/sim_hbm_traffic.py; the least possible, one store
+// and one load of every stored vector, is 1329).  Cherries are no steps of their own (rebuilt where they are used) and
+// do not appear in the order.
+// order[tree] = NI + 1 records of eight int32: record 0 = {steps}, record 1 + k = step k = {node, child 0, child 1, node
+// of step k - 1 (the step that follows in the pre-order pass), children of child 0, children of child 1 (-1, -1 under a
+// tip)} -- everything a step must know about the topology in ONE scalar load whose address does not depend on an
+// earlier load (the child lists are not read by the walk at all).  One workgroup per tree, the tree's tables in LDS
+// (25 bytes per internal node), one lane labels them, all write the records; trees too large for that are walked in
+// id order.
+constexpr int kStepInts = 8;
+__device__ __forceinline__ void WriteStep(int32_t* __restrict__ out, int k, int n, int node, int next, int c0, int c1,
+                                          const int32_t* __restrict__ c) {
+  int4 lo, hi;
+  lo.x = node; lo.y = c0; lo.z = c1; lo.w = next;
+  hi.x = c0 >= n ? c[2 * (c0 - n)] : -1; hi.y = c0 >= n ? c[2 * (c0 - n) + 1] : -1;
+  hi.z = c1 >= n ? c[2 * (c1 - n)] : -1; hi.w = c1 >= n ? c[2 * (c1 - n) + 1] : -1;
+  int4* rec = reinterpret_cast<int4*>(out + (size_t)(1 + k) * kStepInts);
+  rec[0] = lo;
+  rec[1] = hi;
+}
+
+__global__ void __launch_bounds__(64)
+hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __restrict__ order, int in_lds) {
+  extern __shared__ int32_t order_lds[];
+  const int n = d.taxon_count, NI = n - 1, lane = threadIdx.x;
+  const int32_t* __restrict__ ch = children + (size_t)blockIdx.x * NI * 2;
+  int32_t* __restrict__ out = order + (size_t)blockIdx.x * (NI + 1) * kStepInts;
+  if (!in_lds) {
+    if (lane == 0) {
+      int k = 0, prev = -1;
+      for (int v = 0; v < NI; v++) {
+        const int c0 = ch[2 * v], c1 = ch[2 * v + 1];
+        if (c0 < n && c1 < n && v != NI - 1) continue;
+        WriteStep(out, k++, n, n + v, prev, c0, c1, ch);
+        prev = n + v;
+      }
+      out[0] = k;
+    }
+    return;
+  }
+  int32_t* c = order_lds;        // [NI][2] children
+  int32_t* size = c + 2 * NI;    // steps in the subtree (0: a cherry)
+  int32_t* need = size + NI;     // pending vectors the subtree's walk needs at once
+  int32_t* start = need + NI;    // position of the subtree's first step
+  int32_t* at = start + NI;      // node of step k
+  int8_t* flip = reinterpret_cast<int8_t*>(at + NI);  // child 1's subtree is visited first
+  for (int i = lane; i < 2 * NI; i += 64) c[i] = ch[i];
+  __syncthreads();
+  if (lane == 0) {
+    for (int v = 0; v < NI; v++) {  // ids ascend from the tips to the root
+      const int c0 = c[2 * v], c1 = c[2 * v + 1];
+      const int s0 = c0 >= n ? size[c0 - n] : 0, s1 = c1 >= n ? size[c1 - n] : 0;
+      const int a = s0 ? need[c0 - n] : 0, b = s1 ? need[c1 - n] : 0;
+      flip[v] = b > a;  // the heavier subtree first (ties: id order)
+      if (c0 < n && c1 < n && v != NI - 1) {
+        size[v] = 0;
+        need[v] = 0;
+      } else {
+        size[v] = s0 + s1 + 1;
+        need[v] = (s0 == 0 || s1 == 0) ? max(max(a, b), 1) : (a == b ? a + 1 : max(a, b));
+      }
+    }
+    start[NI - 1] = 0;
+    for (int v = NI - 1; v >= 0; v--) {  // and back down: where each subtree's steps begin
+      if (size[v] == 0) continue;
+      const int st = start[v], f = c[2 * v + flip[v]], s = c[2 * v + 1 - flip[v]];
+      int sf = 0;
+      if (f >= n) {
+        start[f - n] = st;
+        sf = size[f - n];
+      }
+      if (s >= n) start[s - n] = st + sf;
+      at[st + size[v] - 1] = n + v;
+    }
+    out[0] = size[NI - 1];
+  }
+  __syncthreads();
+  const int steps = size[NI - 1];
+  for (int k = lane; k < steps; k += 64) {
+    const int node = at[k];
+    WriteStep(out, k, n, node, k > 0 ? at[k - 1] : -1, c[2 * (node - n)], c[2 * (node - n) + 1], c);
+  }
+}
+
+inline size_t HbmOrderLdsBytes(const BatchDims& d) { return (size_t)(d.taxon_count - 1) * (6 * sizeof(int32_t) + 1) + 16; }
+size_t HbmOrderInts(const BatchDims& d) { return (size_t)d.tree_count * d.taxon_count * kStepInts; }
+
+void LaunchHbmOrder(const BatchDims& d, const DeviceBatch& b, hipStream_t stream) {
+  const size_t lds = HbmOrderLdsBytes(d);
+  const bool in_lds = lds <= 150 * 1024;
+  if (in_lds && lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hbm_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(hbm_order_kernel, dim3(d.tree_count), dim3(64), in_lds ? lds : 0, stream, d, b.children, b.sched, in_lds ? 1 : 0);
+}
+
 #ifndef HBM_CAT_WAVES
 #define HBM_CAT_WAVES 8
 #endif
@@ -120,7 +221,7 @@ __device__ __forceinline__ void ScalePow2(double v[4], int& exponent_sum) {
 
 template <bool GRAD, bool RESCALE>
 __global__ void __launch_bounds__(256, HBM_CAT_WAVES)
-walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children,
+walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children, const int32_t* __restrict__ order,
                     const double* __restrict__ all_mats, const TreeModel* __restrict__ models,
                     const uint8_t* __restrict__ tip_states, const double* __restrict__ weights,
                     double* __restrict__ arena_base, double* __restrict__ part_ll, double* __restrict__ part_grad,
@@ -149,7 +250,9 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   const int tid = threadIdx.x, lane = tid & 63, threads = blockDim.x;
   const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = tile_id * kCatTile + lane;
-  const int32_t* __restrict__ ch = children + (size_t)tree * NI * 2;
+  // the steps' records (hbm_order_kernel): {node, child 0, child 1, next | children of child 0, of child 1}
+  const int4* __restrict__ ord = reinterpret_cast<const int4*>(order + (size_t)tree * (NI + 1) * kStepInts);
+  const int steps = __builtin_amdgcn_readfirstlane(ord[0].x);
   const double* __restrict__ mats = all_mats + ((size_t)tree * (N - 1) * C + c) * kMatStride;  // + node * C * kMatStride
   const size_t node_mat = (size_t)C * kMatStride;
   const TreeModel* __restrict__ tm = models + tree;
@@ -161,38 +264,38 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   const unsigned node_bytes = (unsigned)C * 4 * kCatTile * 8, mat_bytes = (unsigned)C * kMatStride * 8;
   const unsigned ulane = lane;
   const unsigned lane8 = ulane * 8;  // (constant offsets go to the scalar offset: added to this they would be hoisted into registers of their own)
-  const double weight = weights[p];
   struct Child {
     int kind;  // 0 tip, 1 stored internal node, 2 cherry
     int a, b;
     int s, sb;
   };
-  auto classify = [&](int cc) {
-    Child ci{0, 0, 0, 0, 0};
+  // (a, b: the child's own children out of the step's record)
+  auto classify = [&](int cc, int a, int b) {
+    Child ci{0, a, b, 0, 0};
     if (cc < n) {
       ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)cc * Ppad, 0);
+    } else if (a < n && b < n) {
+      ci.kind = 2;
+      ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)a * Ppad, 0);
+      ci.sb = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)b * Ppad, 0);
     } else {
-      ci.a = __builtin_amdgcn_readfirstlane(ch[(cc - n) * 2]);
-      ci.b = __builtin_amdgcn_readfirstlane(ch[(cc - n) * 2 + 1]);
-      if (ci.a < n && ci.b < n) {
-        ci.kind = 2;
-        ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)ci.a * Ppad, 0);
-        ci.sb = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)ci.b * Ppad, 0);
-      } else {
-        ci.kind = 1;
-      }
+      ci.kind = 1;
     }
     return ci;
   };
-  // Two thread-private LDS columns of four doubles.  `fwd` hands a vector to the step that follows immediately
-  // (pre-order: the partial of child node - 1).  `pend` keeps ONE vector that is needed later -- post-order: the
-  // partial of a node whose parent is not the next step (also stored in the arena: the pre-order pass reads it
-  // there); pre-order: the partial of the child that is NOT processed next -- until its reader comes, unless a
-  // younger such vector takes the column first (the walk is depth-first, so the youngest is needed soonest; the
-  // older one moves to the arena then).  Hits save the arena round trip of about half of those vectors.
+  // Two thread-private LDS columns of four doubles.  Pre-order: `fwd` hands a vector to the step that follows
+  // immediately (the partial of the child that is processed next) and `pend` keeps ONE vector that is needed later -- the
+  // partial of the child that is NOT processed next -- until its reader comes, unless a younger such vector takes the
+  // column first (the walk is depth-first, so the youngest is needed soonest; the older one moves to the arena then).
+  // Post-order: nothing is handed over through LDS (the step's result stays in registers), so BOTH columns keep
+  // vectors that are needed later: the partial of a node whose parent is not the next step (also stored in the arena:
+  // the pre-order pass reads it there), the oldest giving way.  Hits save the arena round trip of most of those vectors
+  // (hbm_order_kernel's order is chosen for it).
   double* __restrict__ fwd = lds + 4 * tid;
   double* __restrict__ pend = lds + 4 * threads + 4 * tid;
   int pend_owner = -1;  // node whose vector `pend` holds (wave-uniform)
+  int fwd_owner = -1;   // post-order only: node whose vector `fwd` holds
+  bool fwd_younger = false;  // post-order, both columns taken: `fwd` holds the younger vector
   // row `state` of the transposed transition matrix of the branch above `node` (a tip's message)
   auto tip_row = [&](int node, int state, double out[4]) {
     BufLoadRow(matrows, (unsigned)(kMatPT * 8) + (unsigned)state * 32, (unsigned)node * mat_bytes, out);
@@ -208,10 +311,40 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = pend[i];
       pend_owner = -1;
+    } else if (cc == fwd_owner) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = fwd[i];
+      fwd_owner = -1;
     } else {
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = BufLoad(arena, lane8, (unsigned)(cc - n) * node_bytes + i * 512);
     }
+  };
+  // post-order: the vector of node `owner` (in v) into a column -- a free one, else the one with the older vector,
+  // which log-likelihood-only walks (no copy in the arena yet) move to its cell first
+  auto keep = [&](int owner, const double v[4]) {
+    // (the owners are updated by selects, not inside the branches: stores to two variables that the optimiser can
+    // merge into one store through a selected ADDRESS keep both variables in scratch memory)
+    const bool into_fwd = __builtin_amdgcn_readfirstlane((int)(pend_owner >= 0 && (fwd_owner < 0 || !fwd_younger))) != 0;
+    const int old = into_fwd ? fwd_owner : pend_owner;
+    if (into_fwd) {
+      if (!GRAD && old >= 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(old - n) * node_bytes + i * 512, fwd[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) fwd[i] = v[i];
+    } else {
+      if (!GRAD && old >= 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(old - n) * node_bytes + i * 512, pend[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) pend[i] = v[i];
+    }
+    fwd_owner = into_fwd ? owner : fwd_owner;
+    pend_owner = into_fwd ? pend_owner : owner;
+    fwd_younger = into_fwd;
   };
 
   // ---- post-order ------------------------------------------------------------
@@ -219,27 +352,15 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   double site = 0.0;
   double dd[4];
   int last = -1;
-  bool unsaved = false;
-  for (int node = n; node < N; ++node) {
-    const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
-    const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
-    if (c0 < n && c1 < n && node != N - 1) continue;  // a cherry: rebuilt where it is used
-    const Child k0 = classify(c0), k1 = classify(c1);
-    if (GRAD && last >= 0 && c0 != last && c1 != last) {  // its parent comes later: keep a copy at hand
-#pragma unroll
-      for (int i = 0; i < 4; i++) pend[i] = dd[i];
-      pend_owner = last;
-    }
-    if (!GRAD && unsaved && c0 != last && c1 != last) {
-      // log-likelihood only: the column is the partial's only home until a younger one needs it
-      if (pend_owner >= 0) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(pend_owner - n) * node_bytes + i * 512, pend[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) pend[i] = dd[i];
-      pend_owner = last;
-    }
+  for (int k = 0; k < steps; ++k) {
+    const int4 rec = ord[2 + 2 * k], sub = ord[3 + 2 * k];
+    const int node = __builtin_amdgcn_readfirstlane(rec.x);
+    const int c0 = __builtin_amdgcn_readfirstlane(rec.y), c1 = __builtin_amdgcn_readfirstlane(rec.z);
+    const Child k0 = classify(c0, __builtin_amdgcn_readfirstlane(sub.x), __builtin_amdgcn_readfirstlane(sub.y));
+    const Child k1 = classify(c1, __builtin_amdgcn_readfirstlane(sub.z), __builtin_amdgcn_readfirstlane(sub.w));
+    // the previous step's vector, when its parent comes later: keep a copy at hand (log-likelihood only: the column
+    // is the partial's only home until a younger one needs it)
+    if (last >= 0 && c0 != last && c1 != last) keep(last, dd);
     double A[4], B[4];
     const double* m0 = mats + c0 * node_mat;
     const double* m1 = mats + c1 * node_mat;
@@ -276,8 +397,6 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     } else if (GRAD) {
 #pragma unroll
       for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(node - n) * node_bytes + i * 512, dd[i]);
-    } else {
-      unsaved = true;
     }
   }
   // ---- the categories of a pattern meet: L_p and this category's share of it ---
@@ -291,6 +410,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   double total = 0.0;
   for (int k = 0; k < C; k++) total += RESCALE ? __builtin_amdgcn_ldexp(terms[k * 64 + lane], exps[k * 64 + lane] - emax) : terms[k * 64 + lane];
   const double mine = RESCALE ? __builtin_amdgcn_ldexp(site, exponent_sum - emax) : site;
+  const double weight = weights[p];  // (loaded here: two registers the post-order loop does not have to carry)
   const double ll = weight * (log(total) + (RESCALE ? emax * 0.693147180559945309417232121458 : 0.0));
 
   if (c == 0) {
@@ -310,7 +430,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     double* __restrict__ my_row = part_grad + (((size_t)tree * tile_count + tile_id) * C + c) * N;
     const double* __restrict__ Q = tm->Q;
     bool u_forwarded = false;
-    pend_owner = -1;  // (what the post-order pass left there is in the arena as well)
+    pend_owner = fwd_owner = -1;  // (what the post-order pass left there is in the arena as well)
     // message of a child: tip -> its row of P^T; stored -> P x; cherry -> P (a_a . a_b)
     auto message = [&](const Child& ci, int cc, double A[4]) {
       const double* m = mats + cc * node_mat;
@@ -345,7 +465,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     };
     // an internal child's pre-order partial P^T (u . a_sibling): stored in place (the child's cell held its
     // post-order partial, read for this step's message), handed to the next step through the thread's LDS
-    // column when the child is processed next (node - 1), or consumed here by a cherry's two tip edges
+    // column when the child is processed next, or consumed here by a cherry's two tip edges
     auto pre_part = [&](const Child& ci, int cc, const double UAs[4], double rden, bool forward) {
       if (ci.kind == 0) return;
       double q[4];
@@ -368,11 +488,13 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       for (int i = 0; i < 4; i++) pend[i] = q[i];
       pend_owner = cc;
     };
-    for (int node = N - 1; node >= n; --node) {
-      const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
-      const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
-      if (c0 < n && c1 < n && node != N - 1) continue;  // a cherry: handled inside its parent's step
-      const Child k0 = classify(c0), k1 = classify(c1);
+    for (int k = steps - 1; k >= 0; --k) {
+      const int4 rec = ord[2 + 2 * k], sub = ord[3 + 2 * k];
+      const int node = __builtin_amdgcn_readfirstlane(rec.x);
+      const int c0 = __builtin_amdgcn_readfirstlane(rec.y), c1 = __builtin_amdgcn_readfirstlane(rec.z);
+      const int next = __builtin_amdgcn_readfirstlane(rec.w);  // the step that follows
+      const Child k0 = classify(c0, __builtin_amdgcn_readfirstlane(sub.x), __builtin_amdgcn_readfirstlane(sub.y));
+      const Child k1 = classify(c1, __builtin_amdgcn_readfirstlane(sub.z), __builtin_amdgcn_readfirstlane(sub.w));
       double U[4], A0[4], A1[4];
       if (node == N - 1) {
 #pragma unroll
@@ -390,8 +512,8 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       }
       message(k0, c0, A0);
       message(k1, c1, A1);
-      const bool fwd0 = k0.kind == 1 && c0 == node - 1;
-      const bool fwd1 = k1.kind == 1 && c1 == node - 1;
+      const bool fwd0 = k0.kind == 1 && c0 == next;
+      const bool fwd1 = k1.kind == 1 && c1 == next;
       double UA1[4], UA0[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) UA1[i] = U[i] * A1[i];
@@ -476,7 +598,7 @@ void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int c
   const dim3 grid((unsigned)tiles * (unsigned)chunk), block(threads);
   const size_t lds = (size_t)threads * (8 * sizeof(double) + sizeof(double) + sizeof(int));
   static const int by_xcd = [] { const char* v = getenv("BITO_AMD_HBM_BY_XCD"); return v ? atoi(v) : 1; }();
-#define BITO_CAT(G, R) hipLaunchKernelGGL((walk_hbm_cat_kernel<G, R>), grid, block, lds, stream, d, tree0, b.children, b.mats, b.model, \
+#define BITO_CAT(G, R) hipLaunchKernelGGL((walk_hbm_cat_kernel<G, R>), grid, block, lds, stream, d, tree0, b.children, b.sched, b.mats, b.model, \
                                           b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad, deriv_mode, tiles, chunk, by_xcd)
   if (want_gradient) { if (rescaling) BITO_CAT(true, true); else BITO_CAT(true, false); }
   else { if (rescaling) BITO_CAT(false, true); else BITO_CAT(false, false); }

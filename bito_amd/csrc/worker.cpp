@@ -626,6 +626,8 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   const int set = (int)(e->run_counter++ % (unsigned)Worker::kSets);
   // scratch sized for this run
   HIP_TRY(e, (set == 0 ? e->mats : set == 1 ? e->mats2 : e->mats3).Reserve((size_t)T * NB * d.category_count * kMatStride));
+  if (HbmCatKernelApplies(d))  // the steps' order (hbm_order_kernel)
+    HIP_TRY(e, (set == 0 ? e->sched : set == 1 ? e->sched2 : e->sched3).Reserve(HbmOrderInts(d)));
   const size_t per_tree = HbmArenaBytesPerTree(d);
   size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
   // grid.y limit
@@ -651,6 +653,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
       e->inputs_on_host = false;
     }
     LaunchMatrices(d, b, want_gradient, deriv_mode, prep);
+    if (HbmCatKernelApplies(d)) LaunchHbmOrder(d, b, prep);
     if (!in_line) {
       HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
       HIP_TRY(e, hipStreamWaitEvent(walk, e->ev_prep_done[set], 0));

@@ -35,7 +35,7 @@ def children_of(parent_ids, n):
     return ch
 
 
-def kernel_traffic(ch, n, order=None, depth=1):
+def kernel_traffic(ch, n, order=None, depth=1, pre_depth=None):
     """(post-order reads, post-order writes, pre-order reads, pre-order writes) of the gradient pass.
     order: the sequence of internal nodes (default: ascending ids); depth: entries of the pending stack."""
     N = n + len(ch)
@@ -67,6 +67,8 @@ def kernel_traffic(ch, n, order=None, depth=1):
             writes += 1
     post = (reads, writes)
     # ---- pre-order (reverse order)
+    if pre_depth is not None:
+        depth = pre_depth
     reads = writes = 0
     pend = []
     forwarded = -1
@@ -146,6 +148,8 @@ def main():
         row["max need"] = int(need.max())
         for depth in (1, 2, 3, 4, 8):
             row[f"heavy d{depth}"] = kernel_traffic(ch, n, order, depth)
+        row["heavy d2/1"] = kernel_traffic(ch, n, order, 2, 1)
+        row["ids d2/1"] = kernel_traffic(ch, n, None, 2, 1)
         row["ids d2"] = kernel_traffic(ch, n, None, 2)
         row["ids d4"] = kernel_traffic(ch, n, None, 4)
         rows.append(row)
