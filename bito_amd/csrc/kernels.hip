@@ -171,7 +171,7 @@ void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b
 // Transition matrices: one thread per (tree, branch, category).
 
 __global__ void __launch_bounds__(256)
-transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient, int deriv_mode) {
+transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient, int deriv_mode, int stride) {
 // No FMA contraction and a fixed summation order here: see model.hpp.
 #pragma clang fp contract(off)
   const int C = d.category_count, NB = d.node_count - 1;
@@ -198,7 +198,7 @@ transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient, int de
       for (int k = 0; k < 4; k++) s += m->V[i * 4 + k] * e[k] * m->Vinv[k * 4 + j];
       P[i * 4 + j] = s;
     }
-  double* out = b.mats + idx * kMatStride;
+  double* out = b.mats + idx * stride;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -207,8 +207,10 @@ transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient, int de
       out[kMatPT + j * 4 + i] = P[i * 4 + j];
     }
     out[kMatPT + 16 + i] = 1.0;   // gap: the all-ones column BEAGLE appends
-    out[kMatDPT + 16 + i] = 0.0;  // Q 1 = 0
   }
+  if (stride == kMatHot) return;  // (walk_hbm_cat_kernel forms dP x as r_c Q (P x))
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[kMatDPT + 16 + i] = 0.0;  // Q 1 = 0
   // deriv_mode 1: the site-model pass, Q scaled by d r_c / d shape (fat_beagle.cpp:542-546)
   const double drate = deriv_mode ? m->cat_rate_deriv[c] : rate;
   if (want_gradient) {
@@ -229,11 +231,11 @@ transition_matrices_kernel(BatchDims d, DeviceBatch b, int want_gradient, int de
 }
 
 void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, int deriv_mode,
-                    hipStream_t stream) {
+                    hipStream_t stream, bool hot_only) {
   const size_t total = (size_t)d.tree_count * (d.node_count - 1) * d.category_count;
   const int blocks = (int)((total + 255) / 256);
   hipLaunchKernelGGL(transition_matrices_kernel, dim3(blocks), dim3(256), 0, stream, d, b,
-                     want_gradient, deriv_mode);
+                     want_gradient, deriv_mode, hot_only ? kMatHot : kMatStride);
 }
 
 // --------------------------------------------------------------------------

@@ -17,7 +17,9 @@ namespace bito_amd {
 //   [32,52) PT5    [state 0..4][i]    column lookup for tip children; row 4 (gap) = 1
 //   [52,72) dPT5   [state 0..4][i]    same for dP; row 4 (gap) = 0 (rows of Q sum to 0)
 constexpr int kMatStride = 72;
-constexpr int kMatP = 0, kMatDP = 16, kMatPT = 32, kMatDPT = 52;
+// (what walk_hbm_cat_kernel reads -- P and the rows of P^T -- first: that walk's records are these kMatHot doubles only,
+// half the bytes that must stay in an XCD's L2 while a tree is walked)
+constexpr int kMatP = 0, kMatPT = 16, kMatHot = 36, kMatDP = 36, kMatDPT = 52;
 
 struct BatchDims {
   int32_t taxon_count;    // n
@@ -58,7 +60,7 @@ struct DeviceBatch {
   int32_t* children;          // [T][n-1][2]  children of internal node n+k
   double* branch;             // [T][N]       effective branch lengths
   TreeModel* model;           // [T]
-  double* mats;               // [T][N-1][C][kMatStride]   (HBM-arena kernel)
+  double* mats;               // [T][N-1][C][kMatStride]   (HBM-arena kernel; [T][N-1][C][kMatHot] for walk_hbm_cat_kernel)
   double* images;             // [T][N-1][kImgStride]      (LDS kernel)
   int32_t* sched;             // [T][2][n+1][16]           step descriptors (LDS kernel); step records in visiting order (HBM-arena walk)
   const uint32_t* pipe_masks; // [tiles][n][waves][16/C]   packed tip masks per pattern tile (walk_pipe_kernel)
@@ -168,7 +170,7 @@ void LaunchSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b
 bool SetupReadsHostInputs(const BatchDims& d, const ModelSpec& spec);
 // deriv_mode 0: dP = P (r_c Q); 1: dP = P ((d r_c / d shape) Q) for the site-model gradient pass.
 void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient, int deriv_mode,
-                    hipStream_t stream);
+                    hipStream_t stream, bool hot_only = false);
 // Same arithmetic, written as MFMA operand images (one wave per tree-branch).
 void LaunchMatrixImages(const BatchDims& d, const DeviceBatch& b, int want_gradient, int deriv_mode,
                         hipStream_t stream);

@@ -76,7 +76,10 @@ inline int HbmCatTiles(int pattern_count) { return (pattern_count + kCatTile - 1
 // nodes of a random tree) rebuilt and folded into the parent's step like cherries.  The nested step needs 75
 // registers: held to 64 it spills (config 4, 125 trees, same box: 84.8 ms against 69.9), at six waves per SIMD it
 // gains 2.5-4 % (66.7 / 69.4 ms against 69.9 / 71.2; 41 taxa: 3.54 against 3.78 ms) -- the arena traffic it saves is
-// paid for in vector and scalar work at lower occupancy.
+// paid for in vector and scalar work at lower occupancy.  Likewise BOTH columns as pending vectors in the pre-order
+// pass too, the next step's partial handed over in registers (1478 -> 1392 vector transfers per config-4 tree): those
+// eight registers are alive at the loop's edge and the step spills three or four at 64 (config 4 69.1 against
+// 63.1 ms, 100 taxa 9.5 against 8.0 ms).
 // ---- visiting order -------------------------------------------------------------------------------------------
 // The walk keeps the vector it has just computed in registers and ONE or TWO older ones in LDS columns (below); every
 // other operand is read back from the arena.  How often that happens depends on the ORDER in which a node's two subtrees
@@ -191,15 +194,26 @@ typedef unsigned UInt4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ BufferRsrc MakeRsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
+// Cache policy of the arena accesses (auxiliary bits of the buffer instructions: 1 sc0, 2 nt, 16 sc1).  A vector that is
+// written is read back a whole subtree later, or in the other pass: kept in L2 it only displaces what IS read again and
+// again -- the tree's transition matrices, which every wave fetches with scalar loads the step then waits for.
+// Non-temporal loads and stores: config 4 64.0 -> 59.7 ms per 125 trees, 100 taxa 8.03 -> 7.47 ms per 1600 (stores
+// alone 62.6, loads alone 63.8; sc1 variants the same as nt within a percent).
+#ifndef HBM_CAT_LOAD_AUX
+#define HBM_CAT_LOAD_AUX 2
+#endif
+#ifndef HBM_CAT_STORE_AUX
+#define HBM_CAT_STORE_AUX 2
+#endif
 __device__ __forceinline__ double BufLoad(BufferRsrc r, unsigned lane_bytes, unsigned uniform_bytes) {
-  const UInt2 v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, 0);
+  const UInt2 v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, HBM_CAT_LOAD_AUX);
   return __hiloint2double(v.y, v.x);
 }
 __device__ __forceinline__ void BufStore(BufferRsrc r, unsigned lane_bytes, unsigned uniform_bytes, double x) {
   UInt2 v;
   v.x = __double2loint(x);
   v.y = __double2hiint(x);
-  __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_bytes, uniform_bytes, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_bytes, uniform_bytes, HBM_CAT_STORE_AUX);
 }
 // four consecutive doubles (a row of a transposed matrix, picked per lane)
 __device__ __forceinline__ void BufLoadRow(BufferRsrc r, unsigned lane_bytes, unsigned uniform_bytes, double out[4]) {
@@ -253,15 +267,15 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   // the steps' records (hbm_order_kernel): {node, child 0, child 1, next | children of child 0, of child 1}
   const int4* __restrict__ ord = reinterpret_cast<const int4*>(order + (size_t)tree * (NI + 1) * kStepInts);
   const int steps = __builtin_amdgcn_readfirstlane(ord[0].x);
-  const double* __restrict__ mats = all_mats + ((size_t)tree * (N - 1) * C + c) * kMatStride;  // + node * C * kMatStride
-  const size_t node_mat = (size_t)C * kMatStride;
+  const double* __restrict__ mats = all_mats + ((size_t)tree * (N - 1) * C + c) * kMatHot;  // + node * C * kMatHot
+  const size_t node_mat = (size_t)C * kMatHot;
   const TreeModel* __restrict__ tm = models + tree;
   // every per-lane access: descriptor (wave-uniform base) + wave-uniform byte offset + this lane's 32-bit offset
   const BufferRsrc tips = MakeRsrc(tip_states + (size_t)tile_id * kCatTile);  // [taxon * Ppad][lane]
   // [(node - n) * C * 2 KB][state * 512 + lane * 8]
   const BufferRsrc arena = MakeRsrc(arena_base + (((size_t)tree_local * tile_count + tile_id) * NI * C + c) * 4 * kCatTile);
-  const BufferRsrc matrows = MakeRsrc(mats);  // [node * C * kMatStride * 8][(kMatPT + state * 4) * 8]
-  const unsigned node_bytes = (unsigned)C * 4 * kCatTile * 8, mat_bytes = (unsigned)C * kMatStride * 8;
+  const BufferRsrc matrows = MakeRsrc(mats);  // [node * C * kMatHot * 8][(kMatPT + state * 4) * 8]
+  const unsigned node_bytes = (unsigned)C * 4 * kCatTile * 8, mat_bytes = (unsigned)C * kMatHot * 8;
   const unsigned ulane = lane;
   const unsigned lane8 = ulane * 8;  // (constant offsets go to the scalar offset: added to this they would be hoisted into registers of their own)
   struct Child {

@@ -652,7 +652,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
       e->inputs_pending = true;
       e->inputs_on_host = false;
     }
-    LaunchMatrices(d, b, want_gradient, deriv_mode, prep);
+    LaunchMatrices(d, b, want_gradient, deriv_mode, prep, /*hot_only=*/HbmCatKernelApplies(d));
     if (HbmCatKernelApplies(d)) LaunchHbmOrder(d, b, prep);
     if (!in_line) {
       HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
