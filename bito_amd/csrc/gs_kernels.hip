@@ -515,13 +515,30 @@ void LaunchGsSchedule(const BatchDims& d, const DeviceBatch& b, hipStream_t stre
                      GsScheduleStride(d));
 }
 
+// (non-temporal arena accesses, which pay in walk_hbm_cat_kernel, cost here: 59.5 against 56.8 ms per 4096 config-5
+// trees -- the vectors ARE read again soon, messages by the same wave's pre-order pass out of L2 / MALL)
+#ifndef GS_ARENA_NT
+#define GS_ARENA_NT 0
+#endif
 __device__ __forceinline__ void GsLoad(const double* __restrict__ slot, int lane, GsPlv& x) {
 #pragma unroll
-  for (int m = 0; m < 4; m++) x.b[m] = *reinterpret_cast<const v4d*>(slot + m * 256 + lane * 4);
+  for (int m = 0; m < 4; m++) {
+#if GS_ARENA_NT
+    x.b[m] = __builtin_nontemporal_load(reinterpret_cast<const v4d*>(slot + m * 256 + lane * 4));
+#else
+    x.b[m] = *reinterpret_cast<const v4d*>(slot + m * 256 + lane * 4);
+#endif
+  }
 }
 __device__ __forceinline__ void GsStore(double* __restrict__ slot, int lane, const GsPlv& x) {
 #pragma unroll
-  for (int m = 0; m < 4; m++) *reinterpret_cast<v4d*>(slot + m * 256 + lane * 4) = x.b[m];
+  for (int m = 0; m < 4; m++) {
+#if GS_ARENA_NT
+    __builtin_nontemporal_store(x.b[m], reinterpret_cast<v4d*>(slot + m * 256 + lane * 4));
+#else
+    *reinterpret_cast<v4d*>(slot + m * 256 + lane * 4) = x.b[m];
+#endif
+  }
 }
 // tip child: row `state` of the transposed table
 __device__ __forceinline__ void GsTip(const double* __restrict__ table, int state, int kq, GsPlv& x) {
