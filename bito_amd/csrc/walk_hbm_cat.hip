@@ -440,11 +440,23 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   if (GRAD) {
     const double rate = deriv_mode ? tm->cat_rate_deriv[c] : tm->cat_rate[c];
     // rescaled: w_p sigma_c r_c (then times num_c / den_c per edge); plain: w_p w_c r_c / L_p (then times num_c)
-    const double gw = RESCALE ? weight * (mine / total) * rate : weight * (tm->cat_weight[c] / total) * rate;
+    // Without rescaling the whole pre-order pass of a pattern is scaled by the power of two that brings L_p to [0.5, 1)
+    // (through the root's partial, below; exact, and w_p w_c r_c / L_p is formed with the scaled L_p): on trees of
+    // hundreds of taxa L_p sits near the bottom of the double range -- where the reference still returns finite
+    // derivatives -- and 1 / L_p alone is infinite, the edge sums denormal or zero.  L_p = 0: no shift, and the
+    // derivatives are non-finite as the reference's.
+    const int shift = RESCALE ? 0 : min(-__builtin_amdgcn_frexp_exp(total), 1000);
+    const double gw = RESCALE ? weight * (mine / total) * rate
+                              : weight * (tm->cat_weight[c] / __builtin_amdgcn_ldexp(total, shift)) * rate;
     double* __restrict__ my_row = part_grad + (((size_t)tree * tile_count + tile_id) * C + c) * N;
     const double* __restrict__ Q = tm->Q;
     bool u_forwarded = false;
-    pend_owner = fwd_owner = -1;  // (what the post-order pass left there is in the arena as well)
+    // (what the post-order pass left in the columns is in the arena as well.)  The root's partial -- the stationary
+    // frequencies -- waits for the first step in the column like any pending vector
+    fwd_owner = -1;
+    pend_owner = N - 1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) pend[i] = __builtin_amdgcn_ldexp(tm->pi[i], shift);
     // message of a child: tip -> its row of P^T; stored -> P x; cherry -> P (a_a . a_b)
     auto message = [&](const Child& ci, int cc, double A[4]) {
       const double* m = mats + cc * node_mat;
@@ -510,10 +522,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       const Child k0 = classify(c0, __builtin_amdgcn_readfirstlane(sub.x), __builtin_amdgcn_readfirstlane(sub.y));
       const Child k1 = classify(c1, __builtin_amdgcn_readfirstlane(sub.z), __builtin_amdgcn_readfirstlane(sub.w));
       double U[4], A0[4], A1[4];
-      if (node == N - 1) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) U[i] = tm->pi[i];
-      } else if (u_forwarded) {
+      if (u_forwarded) {
 #pragma unroll
         for (int i = 0; i < 4; i++) U[i] = fwd[i];
       } else if (node == pend_owner) {

@@ -15,11 +15,15 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 forced_kernel = int(sys.argv[3]) if len(sys.argv) > 3 else None
 FORCED = (_capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE, _capi.KERNEL_LDS_PIPE)
 skipped = 0
+unstable = 0
 rng = np.random.default_rng(seed)
 bad = 0
 t0 = time.time()
 for case in range(cases):
-    n = int(rng.choice([3, 4, 5, 6, 8, 11, 16, 23, 27, 31, 36, 38, 40, 44, 48, 49, 52, 56, 57, 60, 64, 65, 90]))
+    sizes = [3, 4, 5, 6, 8, 11, 16, 23, 27, 31, 36, 38, 40, 44, 48, 49, 52, 56, 57, 60, 64, 65, 90]
+    if os.environ.get("FUZZ_LARGE_TREES"):  # (the HBM-arena walk's visiting order and pending columns: deeper trees)
+        sizes += [130, 200, 333]
+    n = int(rng.choice(sizes))
     P = int(rng.choice([1, 5, 16, 63, 64, 65, 130, 300]))
     T = int(rng.choice([1, 2, 7, 33]))
     sub = str(rng.choice(["JC69", "HKY", "GTR", "GY94"], p=[0.3, 0.3, 0.3, 0.1]))
@@ -92,6 +96,19 @@ for case in range(cases):
         ok = close(out["log_likelihood"], ref["log_likelihood"], 1e-10) and close(out["branch_lengths"], ref["branch_lengths"], 1e-6)
         ll2 = gpu.log_likelihoods(pid, bl, params, rescaling=rescaling)
         ok = ok and close(ll2, ref["log_likelihood"], 1e-10)
+        if not ok and not rescaling and not codon:
+            # Without rescaling a large tree's pattern likelihoods can sit at the bottom of the double range; the
+            # reference's derivative there is a ratio of denormal numbers -- rounding noise, finite or not by accident.
+            # Such trees are recognised by the reference itself: its gradient WITH rescaling (the same mathematical
+            # quantity, computed in range) differs from its gradient without.  They are left out of the comparison of
+            # gradients (the log-likelihoods of all trees must still agree).
+            ref2 = cpu.gradients(pid, bl, params, rescaling=True)
+            stable = np.array([close(ref["branch_lengths"][t], ref2["branch_lengths"][t], 1e-6) for t in range(T)])
+            if (not stable.all() and close(out["log_likelihood"], ref["log_likelihood"], 1e-10)
+                    and close(ll2, ref["log_likelihood"], 1e-10)
+                    and close(out["branch_lengths"][stable], ref["branch_lengths"][stable], 1e-6)):
+                unstable += 1
+                ok = True
         if not ok:
             bad += 1
             dl = np.nanmax(np.abs(out["log_likelihood"] - ref["log_likelihood"]))
@@ -109,4 +126,5 @@ for case in range(cases):
     except Exception as e:  # noqa: BLE001
         bad += 1
         print("ERROR", desc, repr(e)[:300])
-print(f"{cases} cases, {bad} bad, {skipped} declined by a forced kernel, {time.time() - t0:.0f} s")
+print(f"{cases} cases, {bad} bad, {skipped} declined by a forced kernel, {unstable} with trees on which the reference's own "
+      f"gradient without rescaling is rounding noise (left out), {time.time() - t0:.0f} s")
