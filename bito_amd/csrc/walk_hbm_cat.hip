@@ -4,6 +4,12 @@
 #include "kernels.hpp"
 #include <cstdlib>
 
+// model.hpp switches fused multiply-add contraction off for the set-up arithmetic (errors in P(t) are coherent across
+// the site patterns; its operation order is part of the numerical contract).  The walk's own sums are per pattern,
+// their rounding errors independent from pattern to pattern: contracted, a 4 x 4 product is 4 instructions per row
+// instead of 7, and the walk spends more than half its time issuing them.
+#pragma clang fp contract(fast)
+
 namespace bito_amd {
 
 // Two sums over the 64 lanes at once, without LDS round trips or address registers: v_permlane32_swap puts
@@ -312,6 +318,9 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   bool fwd_younger = false;  // post-order, both columns taken: `fwd` holds the younger vector
   // row `state` of the transposed transition matrix of the branch above `node` (a tip's message)
   auto tip_row = [&](int node, int state, double out[4]) {
+    // (opaque: the row's offset is formed HERE, where the row is needed -- formed where the state is loaded, as the
+    // compiler would have it, the step waits for a tip's byte from HBM before it has requested anything else)
+    asm volatile("" : "+v"(state));
     BufLoadRow(matrows, (unsigned)(kMatPT * 8) + (unsigned)state * 32, (unsigned)node * mat_bytes, out);
   };
   auto fetch = [&](const Child& ci, int cc, double x[4]) {
