@@ -465,6 +465,10 @@ void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const dou
 // (global_load_lds_dwordx4 issued before the MFMAs) -- one workgroup barrier per image, L2 read once
 // per workgroup instead of once per wave.
 
+// (from here on the walk's own arithmetic: per pattern, free to use fused multiply-add -- model.hpp's file-scope
+// contract(off) is meant for the set-up kernels above, which repeat it in their bodies)
+#pragma clang fp contract(fast)
+
 struct GsPlv {
   v4d b[4];
 };

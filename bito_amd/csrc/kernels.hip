@@ -239,6 +239,8 @@ void LaunchMatrices(const BatchDims& d, const DeviceBatch& b, int want_gradient,
 }
 
 // --------------------------------------------------------------------------
+// (the walk's own arithmetic is per pattern and may use fused multiply-add; the set-up kernels above may not)
+#pragma clang fp contract(fast)
 // Traversal with the PLV arena in HBM.
 //
 // One thread owns one site pattern and walks the whole tree for it; patterns are
