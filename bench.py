@@ -229,7 +229,7 @@ def main():
                          "125 per GPU at 8 GPUs; one GPU alone takes 125)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-resident", action="store_true", help="skip the second timed region (resident batch)")
+    ap.add_argument("--no-resident", action="store_true", help="the timed region only: skip the small-collection calls and the second timed region (resident batch)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 HBM arena, 2 LDS")
     ap.add_argument("--sum-ll-reduce", choices=("auto", "on", "off"), default="auto",
                     help="per step, all-reduce the summed log-likelihood over the ranks (RCCL); auto = when there "
@@ -365,7 +365,7 @@ def main():
 
     # the same blocking call on small collections (BASELINE's literal "100 topologies", vip's particle loop): ms per call
     small_calls = None
-    if args.workload == "ds1" and world == 1:
+    if args.workload == "ds1" and world == 1 and not args.no_resident:
         small_calls = {}
         for count in (1, 100, 400, 1600):
             if count > T:
