@@ -266,7 +266,7 @@ int EvaluateByKind(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32
   const ModelSpec& m = w0->spec;
   const int C = m.category_count;
   const bool candidates = !single && !rescaling && m.state_count == 4 && (C == 1 || C == 2 || C == 4) &&
-                          e->n > kPipeExactTaxa && e->n <= 64 && tree_count >= 2 && e->kernel_choice == BITO_AMD_KERNEL_AUTO &&
+                          e->n > kPipeExactTaxa && e->n <= kPipeAutoTaxa && tree_count >= 2 && e->kernel_choice == BITO_AMD_KERNEL_AUTO &&
                           parent_ids && branch_lengths && (m.param_count == 0 || params) && !(want_gradient == 0 && C == 1);
   if (!candidates)
     return Evaluate(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, rescaling, want_gradient,

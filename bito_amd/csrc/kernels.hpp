@@ -252,6 +252,11 @@ int HbmWalkGradRows(const BatchDims& d);
 // form of the pre-order recursion, which the engine uses only when every branch length is at least
 // kPipeReversibleMinBranch (about 1e-6) (walk_pipe.hip, scripts/gen_walk_pipe.py)
 constexpr int kPipeExactTaxa = 38;
+// AUTO sends trees beyond this to the HBM-arena walk although walk_pipe_kernel takes up to 64 taxa: from 59 taxa on
+// most trees need its one-group-per-wave class, and the HBM walk of round 3's end is the faster one there (1600 trees x
+// 1000 patterns, ms per pass, walk_pipe_kernel / walk_hbm_cat_kernel: 56 taxa 3.56 / 3.94, 57: 3.84 / 4.0, 60: 4.40 /
+// 4.28, 64: 4.68 / 4.56; profiles/r3_midsize_56_to_64_taxa.log, profiles/r3_v5_hbm_sizes.log)
+constexpr int kPipeAutoTaxa = 58;
 constexpr double kPipeReversibleRateScale = 0.2;  // smallest off-diagonal rate of the matrices that bound was measured on
 constexpr double kPipeReversibleMinBranch = 9e-7;  // (just below exp(-13.9), the reference optimiser's own floor: src/dag_branch_handler.hpp:272)
 bool HbmCatKernelApplies(const BatchDims& d);

@@ -444,7 +444,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     default:
       // AUTO: the hand-scheduled LDS walk where it applies (up to 38 taxa: every branch's images in the AGPR
       // file), measured 1.44 ms against walk_lds_kernel's 2.00 ms per 1600 config-3 trees
-      use_pipe = pplan.groups > 0 && !rescaling && pipe_branches_ok;
+      use_pipe = pplan.groups > 0 && !rescaling && pipe_branches_ok && d.taxon_count <= kPipeAutoTaxa;
       // ... except a log-likelihood-only pass with one rate category: walk_hbm_kernel never stores a partial there
       // (each node's is forwarded in registers to its parent) and runs 0.17 ms per 1600 DS1 JC69 trees
       // against 0.32 ms (walk_pipe_kernel) and 0.37 ms (walk_lds_kernel); scripts/gpu_config2.py

@@ -45,7 +45,7 @@ extern "C" {
 #define BITO_AMD_GRAD_LOG_DET_JACOBIAN_GRADIENT 32 /* include_log_det_jacobian_gradient */
 
 /* Kernel selection (diagnostics / benchmarking).  AUTO picks walk_pipe_kernel (partial-likelihood messages in
- * LDS, matrix images in registers) for trees of up to 38 taxa -- up to 64 when the batch's shortest branch times its
+ * LDS, matrix images in registers) for trees of up to 38 taxa -- up to 58 when the batch's shortest branch times its
  * smallest off-diagonal rate (over 0.2) is 9e-7 or more -- with 1, 2 or 4 rate categories and no rescaling, the
  * HBM-arena walk otherwise. */
 #define BITO_AMD_KERNEL_AUTO 0
