@@ -19,6 +19,7 @@
 //
 // FP64 throughout, no atomics, every sum in a fixed order.
 #include "kernels.hpp"
+#include "wave_sums.hpp"
 
 // build-time knobs of the traversal kernel (scripts/build_gs_variants.sh measures the alternatives)
 #ifndef GS_SCHED_BARRIER
@@ -557,12 +558,8 @@ __device__ __forceinline__ double GsDot(const GsPlv& a, const GsPlv& b) {
     for (int r = 0; r < 4; r++) s += a.b[m][r] * b.b[m][r];
   return s;
 }
-// sum over the four lanes that hold one pattern's states (kq = 0..3)
-__device__ __forceinline__ double GsPatternSum(double v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
+// sum over the four lanes that hold one pattern's states (kq = 0..3: lanes 16 apart), in each of them
+__device__ __forceinline__ double GsPatternSum(double v) { return SwapSum32(SwapSum16(v)); }
 
 // The workgroup's image pipeline (all 256 threads call every member together).
 struct GsImagePipe {
@@ -860,16 +857,13 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
         }
       }
       have_u = chain && cl >= n && cl == node - 1;  // the next node's own pre-order partial is in y
+      // den is a pattern's sum (its four lanes), the numerators stay per lane: sum over lanes of num_lane . w_p / den_p is
+      // the edge's derivative.  Both edges' sums at once on the vector ALU (the sum of the first ends up in lane 31, of the
+      // second in lane 63) -- as 36 dependent ds_bpermute round trips these sums were a sixth of a step
       den = GsPatternSum(den);
-      numf = GsPatternSum(numf);
-      numl = GsPatternSum(numl);
-      const double scale = kq == 0 ? weight / den : 0.0;
-      const double gf = WaveSum64(numf * scale);
-      const double gl = WaveSum64(numl * scale);
-      if (lane == 0 && active) {
-        grow[cf] = gf;
-        grow[cl] = gl;
-      }
+      const double scale = weight / den;
+      const double g = PairSum(numf * scale, numl * scale);
+      if (active && (lane & 31) == 31) grow[lane < 32 ? cf : cl] = g;
     }
   }
 }

@@ -2,6 +2,7 @@
 // Reference path: FatBeagle::LogLikelihoodInternals / Gradient (src/fat_beagle.cpp:253-373), the arithmetic of
 // kernels.hip (walk_hbm_kernel) re-dealt over threads.  FP64, no atomics, fixed summation order.
 #include "kernels.hpp"
+#include "wave_sums.hpp"
 #include <cstdlib>
 
 // model.hpp switches fused multiply-add contraction off for the set-up arithmetic (errors in P(t) are coherent across
@@ -11,28 +12,6 @@
 #pragma clang fp contract(fast)
 
 namespace bito_amd {
-
-// Two sums over the 64 lanes at once, without LDS round trips or address registers: v_permlane32_swap puts
-// a's upper half beside its lower half in lanes 0-31 and b's likewise in lanes 32-63 (one addition halves
-// both), then five DPP steps reduce each half: lane 31 ends up with the sum of a, lane 63 with the sum of b.
-// Fixed order.
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ double DppAdd(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, false);
-  return v + __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double PairSum(double a, double b) {
-  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-  double v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-  v = DppAdd<0x111, 0xf>(v);  // row_shr:1
-  v = DppAdd<0x112, 0xf>(v);  // row_shr:2
-  v = DppAdd<0x114, 0xf>(v);  // row_shr:4
-  v = DppAdd<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row's sum
-  v = DppAdd<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3 -> lanes 31 and 63 hold the halves' sums
-  return v;
-}
 
 __device__ __forceinline__ double WaveSum(double v) {
 #pragma unroll
