@@ -522,10 +522,29 @@ void LaunchGsSchedule(const BatchDims& d, const DeviceBatch& b, hipStream_t stre
 
 // (non-temporal arena accesses, which pay in walk_hbm_cat_kernel, cost here: 59.5 against 56.8 ms per 4096 config-5
 // trees -- the vectors ARE read again soon, messages by the same wave's pre-order pass out of L2 / MALL)
+#ifndef GS_X_EARLY
+#define GS_X_EARLY 0
+#endif
+#ifndef GS_ASM_FETCH
+#define GS_ASM_FETCH 1
+#endif
+#ifndef GS_EXP_NOLOAD
+#define GS_EXP_NOLOAD 0
+#endif
+#ifndef GS_EXP_NOSTORE
+#define GS_EXP_NOSTORE 0
+#endif
+#ifndef GS_EXP_NOMFMA
+#define GS_EXP_NOMFMA 0
+#endif
 #ifndef GS_ARENA_NT
 #define GS_ARENA_NT 0
 #endif
 __device__ __forceinline__ void GsLoad(const double* __restrict__ slot, int lane, GsPlv& x) {
+#if GS_EXP_NOLOAD
+  for (int m = 0; m < 4; m++) x.b[m] = v4d{1.0, 0.5, 0.25, 0.125};
+  return;
+#endif
 #pragma unroll
   for (int m = 0; m < 4; m++) {
 #if GS_ARENA_NT
@@ -536,6 +555,9 @@ __device__ __forceinline__ void GsLoad(const double* __restrict__ slot, int lane
   }
 }
 __device__ __forceinline__ void GsStore(double* __restrict__ slot, int lane, const GsPlv& x) {
+#if GS_EXP_NOSTORE
+  return;
+#endif
 #pragma unroll
   for (int m = 0; m < 4; m++) {
 #if GS_ARENA_NT
@@ -575,26 +597,67 @@ struct GsImagePipe {
   }
 
   // global -> LDS without passing through registers (global_load_lds_dwordx4): every thread moves
-  // 8 x 16 bytes of the 32 KB image; the LDS address is wave-uniform base + 16 * lane
+  // 8 x 16 bytes of the 32 KB image; the LDS address is wave-uniform base (M0) + 16 * lane.
+  // Written as assembly on purpose: the compiler cannot tell the buffer such a load fills from the buffer the
+  // contraction reads, and put s_waitcnt vmcnt(0) in front of the first ds_read behind the builtin form -- the wave sat
+  // out the whole transfer of image j + 1 before the first product with image j.  MatVec waits for these loads itself
+  // (vmcnt(0) in front of its barrier).
   __device__ __forceinline__ void Fetch(int entry, int buffer) {
+#if GS_ASM_FETCH
+    static_assert(GS_WG_WAVES == 4 || GS_WG_WAVES == 8, "eight loads of 4 KB or four of 8 KB per workgroup");
+    const double* src = Image(entry);
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)src);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)src >> 32));
+    uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds + buffer * 4096 + (tid & ~63) * 2));
+    uint32_t v = tid * 16;
+#if GS_WG_WAVES == 4
+#define GS_FETCH_NEXT "v_add_u32 %[v], 0x1000, %[v]\n s_add_u32 m0, m0, 0x1000\n s_nop 0\n global_load_lds_dwordx4 %[v], %[s]\n"
+#define GS_FETCH_REST GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT
+#else
+#define GS_FETCH_NEXT "v_add_u32 %[v], 0x2000, %[v]\n s_add_u32 m0, m0, 0x2000\n s_nop 0\n global_load_lds_dwordx4 %[v], %[s]\n"
+#define GS_FETCH_REST GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT
+#endif
+    asm volatile("s_mov_b32 m0, %[m]\n s_nop 0\n global_load_lds_dwordx4 %[v], %[s]\n" GS_FETCH_REST
+                 : [v] "+v"(v)
+                 : [m] "s"(m), [s] "s"(((uint64_t)hi << 32) | lo)
+                 : "memory", "scc");  // (M0: the compiler has no other use for it in this kernel)
+#undef GS_FETCH_NEXT
+#undef GS_FETCH_REST
+#else
     const double* src = Image(entry) + tid * 2;
     double* dst = lds + buffer * 4096 + (tid & ~63) * 2;
 #pragma unroll
     for (int i = 0; i < 32 / GS_WG_WAVES; i++)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (GS_WG_WAVES * 128)),
                                        (__attribute__((address_space(3))) void*)(dst + i * (GS_WG_WAVES * 128)), 16, 0, 0);
+#endif
+  }
+
+  __device__ __forceinline__ void FetchWait() {
+#if GS_ASM_FETCH
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   }
 
   __device__ __forceinline__ void Begin() {
     j = 0;
     Fetch(jobs[0], 0);
+    FetchWait();
     __syncthreads();
   }
 
   // out = (image j) x; leaves image j+1 in the other buffer
   __device__ __forceinline__ void MatVec(const GsPlv& x, GsPlv& out) {
+    GsPlv xx = x;
 #if GS_SCHED_BARRIER
     __builtin_amdgcn_sched_barrier(0);  // keep the caller's loads from being hoisted across the contraction
+#endif
+#if GS_ASM_FETCH
+    {  // x complete before the fetch is issued (the compiler's wait for x would otherwise count the fetch's loads as well)
+      v4d x0 = x.b[0], x1 = x.b[1], x2 = x.b[2], x3 = x.b[3];
+      asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+      xx.b[0] = x0, xx.b[1] = x1, xx.b[2] = x2, xx.b[3] = x3;
+    }
 #endif
     Fetch(__builtin_amdgcn_readfirstlane(jobs[j + 1]), (j + 1) & 1);
     const v2d* p = reinterpret_cast<const v2d*>(lds + (j & 1) * 4096) + lane;
@@ -605,12 +668,12 @@ struct GsImagePipe {
 #pragma unroll
     for (int mb = 0; mb < 4; mb++) a[mb] = p[(mb * 8) * 64];
 #pragma unroll
-    for (int k2 = 0; k2 < 8; k2++) {
+    for (int k2 = 0; k2 < (GS_EXP_NOMFMA ? 1 : 8); k2++) {
       if (k2 < 7) {
 #pragma unroll
         for (int mb = 0; mb < 4; mb++) an[mb] = p[(mb * 8 + k2 + 1) * 64];
       }
-      const double b0 = x.b[k2 >> 1][(k2 & 1) * 2], b1 = x.b[k2 >> 1][(k2 & 1) * 2 + 1];
+      const double b0 = xx.b[k2 >> 1][(k2 & 1) * 2], b1 = xx.b[k2 >> 1][(k2 & 1) * 2 + 1];
 #pragma unroll
       for (int mb = 0; mb < 4; mb++) acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb].x, b0, acc[mb], 0, 0, 0);
 #pragma unroll
@@ -621,6 +684,7 @@ struct GsImagePipe {
 #pragma unroll
     for (int mb = 0; mb < 4; mb++) out.b[mb] = acc[mb];
     j++;
+    FetchWait();
     __syncthreads();
 #if GS_SCHED_BARRIER
     __builtin_amdgcn_sched_barrier(0);
@@ -829,9 +893,15 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           GsTip(rec(cf, c, 1), sf, kq, x);
           numf += wc * GsDot(wf, x);
         } else {
+#if GS_X_EARLY
+          GsLoad(slot(cf, c), lane, x);  // (x is read before q takes its place; in flight behind the two contractions)
+          pipe.MatVec(wf, y);
+          pipe.MatVec(y, wf);
+#else
           pipe.MatVec(wf, y);
           pipe.MatVec(y, wf);
           GsLoad(slot(cf, c), lane, x);  // (x is read before q takes its place)
+#endif
           numf += wc * rc * GsDot(wf, x);
           if (RESCALE) {
 #pragma unroll
@@ -843,9 +913,15 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           GsTip(rec(cl, c, 1), sl, kq, x);
           numl += wc * GsDot(wl, x);
         } else {
+#if GS_X_EARLY
+          GsLoad(slot(cl, c), lane, x);
+          pipe.MatVec(wl, y);
+          pipe.MatVec(y, wl);
+#else
           pipe.MatVec(wl, y);
           pipe.MatVec(y, wl);
           GsLoad(slot(cl, c), lane, x);
+#endif
           numl += wc * rc * GsDot(wl, x);
           if (RESCALE) {
 #pragma unroll

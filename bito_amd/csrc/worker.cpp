@@ -118,12 +118,13 @@ int ParseSpec(const char* sub, const char* site, const char* clock, ModelSpec* m
   return BITO_AMD_OK;
 }
 
-// GTRModel/HKYModel::SetParameters checks (reference src/substitution_model.cpp:33-47,120-139).
-int ValidateParams(Worker* e, int tree_count, const double* params) {
+// GTRModel/HKYModel::SetParameters checks (reference src/substitution_model.cpp:33-47,120-139) of trees
+// [t0, t1).  Touches nothing but *msg: the host threads of a blocking call check disjoint ranges side by side.
+int ValidateParamsRange(const Worker* e, int t0, int t1, const double* params, std::string* msg) {
   const ModelSpec& m = e->spec;
   if (m.substitution == kJC69) return BITO_AMD_OK;
   const char* name = m.substitution == kGTR ? "GTR" : (m.substitution == kGY94 ? "GY94" : "HKY");
-  for (int t = 0; t < tree_count; t++) {
+  for (int t = t0; t < t1; t++) {
     const double* row = params + (size_t)t * m.param_count;
     const double* f = row + m.freq_start;
     if (std::fabs(f[0] + f[1] + f[2] + f[3] - 1.) >= 0.001) {
@@ -131,14 +132,16 @@ int ValidateParams(Worker* e, int tree_count, const double* params) {
       std::snprintf(buf, sizeof(buf),
                     "%s frequencies do not sum to 1 +/- 0.001! frequency vector: (%g,%g,%g,%g) [tree %d]",
                     name, f[0], f[1], f[2], f[3], t + e->id_offset);
-      return Fail(e, BITO_AMD_ERR_BAD_PARAMS, buf);
+      *msg = buf;
+      return BITO_AMD_ERR_BAD_PARAMS;
     }
     if (m.substitution == kGY94) {
       const double* r = row + m.rates_start;
       if (!(r[0] > 0.) || !(r[1] > 0.)) {
         char buf[256];
         std::snprintf(buf, sizeof(buf), "GY94 kappa and omega must be positive: (%g,%g) [tree %d]", r[0], r[1], t + e->id_offset);
-        return Fail(e, BITO_AMD_ERR_BAD_PARAMS, buf);
+        *msg = buf;
+        return BITO_AMD_ERR_BAD_PARAMS;
       }
     }
     if (m.substitution == kGTR) {
@@ -150,19 +153,25 @@ int ValidateParams(Worker* e, int tree_count, const double* params) {
         std::snprintf(buf, sizeof(buf),
                       "GTR rates do not sum to 1 +/- 0.001! rate vector: (%g,%g,%g,%g,%g,%g) [tree %d]",
                       r[0], r[1], r[2], r[3], r[4], r[5], t + e->id_offset);
-        return Fail(e, BITO_AMD_ERR_BAD_PARAMS, buf);
+        *msg = buf;
+        return BITO_AMD_ERR_BAD_PARAMS;
       }
     }
   }
   return BITO_AMD_OK;
 }
 
+int ValidateParams(Worker* e, int tree_count, const double* params) {
+  std::string msg;
+  const int rc = ValidateParamsRange(e, 0, tree_count, params, &msg);
+  return rc ? Fail(e, rc, msg) : rc;
+}
+
 // The parent-id vector must describe a bito topology: leaves 0..n-1, internal ids
 // in post-order (every parent id larger than its children), bifurcating except for
 // the trifurcating root of an unrooted tree (reference src/node.cpp:383-402,511-551;
 // src/unrooted_tree.cpp:46-52).
-int ValidateTrees(Worker* e, int tree_count, int rooted, int node_count,
-                  const int32_t* parent_ids, int* min_cherries = nullptr, std::vector<int32_t>* cherries_of = nullptr) {
+int ValidateTreeShape(Worker* e, int rooted, int node_count) {
   const int n = e->n, M = node_count;
   if (M != (rooted ? 2 * n - 1 : 2 * n - 2)) {
     char buf[200];
@@ -171,9 +180,17 @@ int ValidateTrees(Worker* e, int tree_count, int rooted, int node_count,
     return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
   }
   if (M < 3) return Fail(e, BITO_AMD_ERR_BAD_TREE, "tree too small");
+  return BITO_AMD_OK;
+}
+
+// Trees [t0, t1) of a block whose shape ValidateTreeShape has accepted; writes the range's rows of cherries_of, the
+// range's fewest cherries and, on failure, *msg -- nothing else (see ValidateParamsRange).
+int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_count, const int32_t* parent_ids,
+                       int* fewest_out, int32_t* cherries_of, std::string* msg) {
+  const int n = e->n, M = node_count;
   std::vector<int> count(M), tip_children(M);
   int fewest = M;
-  for (int t = 0; t < tree_count; t++) {
+  for (int t = t0; t < t1; t++) {
     const int32_t* par = parent_ids + (size_t)t * (M - 1);
     std::fill(count.begin(), count.end(), 0);
     std::fill(tip_children.begin(), tip_children.end(), 0);
@@ -183,7 +200,8 @@ int ValidateTrees(Worker* e, int tree_count, int rooted, int node_count,
         char buf[200];
         std::snprintf(buf, sizeof(buf), "tree %d: parent id %d of node %d is not a valid internal id",
                       t + e->id_offset, p, child);
-        return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
+        *msg = buf;
+        return BITO_AMD_ERR_BAD_TREE;
       }
       count[p]++;
       if (child < n) tip_children[p]++;
@@ -194,19 +212,29 @@ int ValidateTrees(Worker* e, int tree_count, int rooted, int node_count,
     for (int i = n; i < M - 1; i++) cherries += tip_children[i] == 2;
     if (!rooted) cherries += tip_children[M - 1] == 3;
     fewest = std::min(fewest, cherries);
-    if (cherries_of) (*cherries_of)[t] = cherries;
+    if (cherries_of) cherries_of[t] = cherries;
     for (int i = n; i < M; i++) {
       const int want = (!rooted && i == M - 1) ? 3 : 2;
       if (count[i] != want) {
         char buf[200];
         std::snprintf(buf, sizeof(buf), "tree %d: node %d has %d children, expected %d", t + e->id_offset, i,
                       count[i], want);
-        return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
+        *msg = buf;
+        return BITO_AMD_ERR_BAD_TREE;
       }
     }
   }
-  if (min_cherries) *min_cherries = fewest;
+  if (fewest_out) *fewest_out = fewest;
   return BITO_AMD_OK;
+}
+
+int ValidateTrees(Worker* e, int tree_count, int rooted, int node_count,
+                  const int32_t* parent_ids, int* min_cherries = nullptr, std::vector<int32_t>* cherries_of = nullptr) {
+  if (int rc = ValidateTreeShape(e, rooted, node_count)) return rc;
+  std::string msg;
+  const int rc = ValidateTreesRange(e, 0, tree_count, rooted, node_count, parent_ids, min_cherries,
+                                    cherries_of ? cherries_of->data() : nullptr, &msg);
+  return rc ? Fail(e, rc, msg) : rc;
 }
 
 // General-state path: trees whose parameter rows are bit-identical share one model record (rate
@@ -257,6 +285,29 @@ double MinOffDiagonalRate(const ModelSpec& m, const double* params, size_t T) {
         if (i != j) lowest = std::min(lowest, Q[i * 4 + j]);
   }
   return lowest;
+}
+
+// Blocking calls, large chunks: alternatives to the direct PCIe paths (0 = never; scripts/gpu_host_threads_sweep.sh,
+// 6400 config-3 trees as chunks of 1024 + 5376: 4.19 ms per call, 4.12 with the inputs of the second chunk copied, no
+// change with the results copied -- the device writes host memory at about 20 GB/s either way).
+// BITO_AMD_RESULTS_COPY_MIN: chunks of that many trees and more have their final sums written to HBM and copied to
+// the pinned buffer by the copy engine, with the completion flag stored behind the copy, instead of the final-sums
+// kernel writing pinned host memory itself.  BITO_AMD_INPUTS_COPY_MIN: a later chunk of a call (a traversal is
+// running beside it) of that many trees and more gets its inputs by a copy command, which needs no CU and lands during
+// that traversal, instead of the set-up kernel reading the pinned buffer once it has found a CU.
+int ResultsCopyMin() {
+  static const int v = [] {
+    const char* s = std::getenv("BITO_AMD_RESULTS_COPY_MIN");
+    return s ? std::atoi(s) : 0;
+  }();
+  return v;
+}
+int InputsCopyMin() {
+  static const int v = [] {
+    const char* s = std::getenv("BITO_AMD_INPUTS_COPY_MIN");
+    return s ? std::atoi(s) : 2000;
+  }();
+  return v;
 }
 
 double PipeReversibleMinBranch() {  // (BITO_AMD_PIPE_MIN_BRANCH: measurements of that bound)
@@ -405,7 +456,8 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call WorkerUpload first");
   HIP_TRY(e, hipSetDevice(e->device));
   e->busy = true;
-  e->results_on_host = e->one_shot != 0;
+  e->results_on_host = e->one_shot != 0 && !(ResultsCopyMin() > 0 && e->dims.tree_count >= ResultsCopyMin());
+  e->flag_behind_copy = e->one_shot != 0 && !e->results_on_host;
   const BatchDims& d = e->dims;
   const int T = d.tree_count;
   const size_t NB = (size_t)d.node_count - 1;
@@ -817,18 +869,26 @@ int WorkerBlock(const Worker* e, int32_t idx, char* name, size_t name_len,
 // worker to be idle first.
 int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
                 const double* branch_lengths, const double* rates, const double* params, int wait) {
+  if (int rc = WorkerStageBegin(e, tree_count, rooted, node_count, parent_ids, branch_lengths, rates, params, wait)) return rc;
+  StagePart part;
+  WorkerStageFill(e, 0, tree_count, &part);
+  return WorkerStageEnd(e, &part, 1);
+}
+
+// WorkerStage in three steps, so that the engine level can have several host threads check and pack disjoint ranges
+// of a large block (WorkerStageFill makes no HIP call and writes only its own rows): Begin and End on the calling
+// thread, Fill(t0, t1) for ranges that cover [0, tree_count) on any threads in between.
+int WorkerStageBegin(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
+                     const double* branch_lengths, const double* rates, const double* params, int wait) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   e->resident = false;
   if (tree_count < 1 || !parent_ids || !branch_lengths)
     return Fail(e, BITO_AMD_ERR_BAD_ARG, "need at least one tree and non-NULL parent_ids / branch_lengths");
   if (e->spec.param_count > 0 && !params)
     return Fail(e, BITO_AMD_ERR_BAD_ARG, "params is NULL but the model has parameters");
-  int min_cherries = 0;
+  if (int rc = ValidateTreeShape(e, rooted, node_count)) return rc;
   e->tree_cherries.assign((size_t)tree_count, 0);
   e->pipe_split = Worker::PipeSplit{};
-  int rc = ValidateTrees(e, tree_count, rooted, node_count, parent_ids, &min_cherries, &e->tree_cherries);
-  if (rc) return rc;
-  if (params && (rc = ValidateParams(e, tree_count, params))) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
   // A set-up kernel of an earlier, still running pass may be reading the input buffers, an earlier copy the staging
   // buffer.  (Only when something may be in flight: a stream synchronisation is not free even on an idle stream --
@@ -841,16 +901,27 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
     e->prep_used = false;
   }
   e->busy = true;
-  const int n = e->n, N = 2 * n - 1, M = node_count, C = e->spec.category_count;
+  const int n = e->n, N = 2 * n - 1, M = node_count;
   const size_t T = tree_count;
   const size_t pc = (size_t)e->spec.param_count;
   e->has_rates = rooted && rates != nullptr;
   // layout of the input block, in doubles (the parent ids close it, as int32)
-  const size_t off_params = T * M, off_rates = off_params + T * std::max<size_t>(pc, 1),
-               off_pid = off_rates + (e->has_rates ? T * (M - 1) : 0);
-  const size_t bytes = off_pid * sizeof(double) + T * (M - 1) * sizeof(int32_t);
-  HIP_TRY(e, e->in_block.Reserve((bytes + sizeof(double) - 1) / sizeof(double)));
-  HIP_TRY(e, e->pin_in.Reserve(bytes));
+  Worker::Staging& st = e->staging;
+  st = Worker::Staging{};
+  st.tree_count = tree_count;
+  st.rooted = rooted;
+  st.node_count = node_count;
+  st.wait = wait;
+  st.parent_ids = parent_ids;
+  st.branch_lengths = branch_lengths;
+  st.rates = e->has_rates ? rates : nullptr;
+  st.params = pc > 0 ? params : nullptr;
+  st.off_params = T * M;
+  st.off_rates = st.off_params + T * std::max<size_t>(pc, 1);
+  st.off_pid = st.off_rates + (e->has_rates ? T * (M - 1) : 0);
+  st.bytes = st.off_pid * sizeof(double) + T * (M - 1) * sizeof(int32_t);
+  HIP_TRY(e, e->in_block.Reserve((st.bytes + sizeof(double) - 1) / sizeof(double)));
+  HIP_TRY(e, e->pin_in.Reserve(st.bytes));
   HIP_TRY(e, e->children.Reserve(T * (n - 1) * 2));
   HIP_TRY(e, e->branch.Reserve(T * N));
   HIP_TRY(e, e->model.Reserve(T));
@@ -871,14 +942,54 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
     HIP_TRY(e, hipMemset(e->done_counter.ptr, 0, sizeof(int32_t)));
   }
   e->branch_in.ptr = e->in_block.ptr;
-  e->params.ptr = e->in_block.ptr + off_params;
-  e->rates.ptr = e->has_rates ? e->in_block.ptr + off_rates : nullptr;
-  e->parent_ids.ptr = reinterpret_cast<int32_t*>(e->in_block.ptr + off_pid);
+  e->params.ptr = e->in_block.ptr + st.off_params;
+  e->rates.ptr = e->has_rates ? e->in_block.ptr + st.off_rates : nullptr;
+  e->parent_ids.ptr = reinterpret_cast<int32_t*>(e->in_block.ptr + st.off_pid);
+  st.open = true;
+  return BITO_AMD_OK;
+}
+
+void WorkerStageFill(Worker* e, int32_t t0, int32_t t1, StagePart* out) {
+  const Worker::Staging& st = e->staging;
+  const size_t M = (size_t)st.node_count, pc = (size_t)e->spec.param_count;
+  const size_t a = (size_t)t0, count = (size_t)(t1 - t0);
+  *out = StagePart{};
+  out->first_tree = t0;
+  out->code = ValidateTreesRange(e, t0, t1, st.rooted, st.node_count, st.parent_ids, &out->min_cherries,
+                                 e->tree_cherries.data(), &out->message);
+  if (!out->code && st.params) out->code = ValidateParamsRange(e, t0, t1, st.params, &out->message);
+  if (out->code) return;
   double* stage = static_cast<double*>(e->pin_in.ptr);
-  std::memcpy(stage, branch_lengths, T * M * sizeof(double));
-  if (pc > 0) std::memcpy(stage + off_params, params, T * pc * sizeof(double));
-  if (e->has_rates) std::memcpy(stage + off_rates, rates, T * (M - 1) * sizeof(double));
-  std::memcpy(stage + off_pid, parent_ids, T * (M - 1) * sizeof(int32_t));
+  std::memcpy(stage + a * M, st.branch_lengths + a * M, count * M * sizeof(double));
+  if (pc > 0) std::memcpy(stage + st.off_params + a * pc, st.params + a * pc, count * pc * sizeof(double));
+  if (st.rates) std::memcpy(stage + st.off_rates + a * (M - 1), st.rates + a * (M - 1), count * (M - 1) * sizeof(double));
+  std::memcpy(reinterpret_cast<int32_t*>(stage + st.off_pid) + a * (M - 1), st.parent_ids + a * (M - 1),
+              count * (M - 1) * sizeof(int32_t));
+  if (e->n > kPipeExactTaxa) {
+    out->min_branch = MinBranchLength(st.branch_lengths + a * M, st.rooted && st.rates ? st.rates + a * (M - 1) : nullptr, count, M);
+    out->min_rate = MinOffDiagonalRate(e->spec, st.params ? st.params + a * pc : nullptr, count);
+  }
+}
+
+int WorkerStageEnd(Worker* e, const StagePart* parts, int part_count) {
+  Worker::Staging& st = e->staging;
+  if (!st.open) return Fail(e, BITO_AMD_ERR_STATE, "WorkerStageEnd without WorkerStageBegin");
+  st.open = false;
+  // the error a serial pass over the trees would have met first
+  const StagePart* bad = nullptr;
+  for (int i = 0; i < part_count; i++)
+    if (parts[i].code && (!bad || parts[i].first_tree < bad->first_tree)) bad = &parts[i];
+  if (bad) return Fail(e, bad->code, bad->message);
+  int min_cherries = st.node_count;
+  double min_branch = std::numeric_limits<double>::infinity(), min_rate = std::numeric_limits<double>::infinity();
+  for (int i = 0; i < part_count; i++) {
+    min_cherries = std::min(min_cherries, parts[i].min_cherries);
+    min_branch = std::min(min_branch, parts[i].min_branch);
+    min_rate = std::min(min_rate, parts[i].min_rate);
+  }
+  const int tree_count = st.tree_count, rooted = st.rooted, wait = st.wait;
+  const int n = e->n, N = 2 * n - 1, M = st.node_count, C = e->spec.category_count;
+  const double* stage = static_cast<const double*>(e->pin_in.ptr);
   // A blocking call's chunk of trees small enough for the staging set-up kernel: no copy at all, that kernel reads
   // the pinned buffer over PCIe (measured: the copy engine's start-up and the hand-over to the kernel behind it cost
   // 30 us per call) and writes the device copies.  Otherwise one copy, on the stream the set-up kernels follow on
@@ -890,18 +1001,19 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
   probe.rooted = rooted;
   probe.tree_count = tree_count;
   e->inputs_on_host = e->one_shot && !wait && e->spec.state_count == 4 && e->kernel_choice != BITO_AMD_KERNEL_GENERAL &&
-                      SetupReadsHostInputs(probe, e->spec);
+                      SetupReadsHostInputs(probe, e->spec) &&
+                      !(e->one_shot == 2 && InputsCopyMin() > 0 && tree_count >= InputsCopyMin());
   if (!e->inputs_on_host) {
-    HIP_TRY(e, hipMemcpyAsync(e->in_block.ptr, stage, bytes, hipMemcpyHostToDevice, SetupStream(e)));
+    HIP_TRY(e, hipMemcpyAsync(e->in_block.ptr, stage, st.bytes, hipMemcpyHostToDevice, SetupStream(e)));
     HIP_TRY(e, hipEventRecord(e->ev_inputs, SetupStream(e)));
     e->inputs_pending = true;
   }
-  e->min_branch = e->n > kPipeExactTaxa ? MinBranchLength(branch_lengths, rooted ? rates : nullptr, T, M) : 0.0;
-  e->min_rate = e->n > kPipeExactTaxa ? MinOffDiagonalRate(e->spec, params, T) : 1.0;
+  e->min_branch = e->n > kPipeExactTaxa ? min_branch : 0.0;
+  e->min_rate = e->n > kPipeExactTaxa ? min_rate : 1.0;
   e->gs_index_valid = false;
   if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL) {
     static const double none = 0.0;
-    if ((rc = UploadModelIndex(e, tree_count, e->spec.param_count > 0 ? params : &none))) return rc;
+    if (int rc = UploadModelIndex(e, tree_count, e->spec.param_count > 0 ? st.params : &none)) return rc;
   }
   if (wait) {
     HIP_TRY(e, hipStreamSynchronize(SetupStream(e)));
@@ -952,17 +1064,23 @@ int WorkerFetchResults(Worker* e, int want_gradient, int want_site) {
   }
   HIP_TRY(e, e->pin_out.Reserve((T * (N + 2)) * sizeof(double)));
   double* out = static_cast<double*>(e->pin_out.ptr);
-  HIP_TRY(e, hipMemcpyAsync(out, e->cur_ll(), T * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  hipStream_t stream = (e->flag_behind_copy && e->last_walk) ? e->last_walk : e->stream;
+  HIP_TRY(e, hipMemcpyAsync(out, e->cur_ll(), T * sizeof(double), hipMemcpyDeviceToHost, stream));
   if (want_gradient)
-    HIP_TRY(e, hipMemcpyAsync(out + T, e->out_grad.ptr, T * N * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(out + T, e->out_grad.ptr, T * N * sizeof(double), hipMemcpyDeviceToHost, stream));
   if (want_site && e->site_ready)
-    HIP_TRY(e, hipMemcpyAsync(out + T + T * N, e->out_site.ptr, T * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(out + T + T * N, e->out_site.ptr, T * sizeof(double), hipMemcpyDeviceToHost, stream));
+  if (e->flag_behind_copy) {
+    LaunchSignal(static_cast<unsigned long long*>(e->pin_flag.ptr), ++e->ticket, stream);
+    HIP_TRY(e, hipGetLastError());
+    return BITO_AMD_OK;
+  }
   HIP_TRY(e, hipEventRecord(e->ev_results, e->stream));
   return BITO_AMD_OK;
 }
 
 bool WorkerResultsReady(Worker* e) {
-  if (e->results_on_host)
+  if (e->results_on_host || e->flag_behind_copy)
     return __atomic_load_n(static_cast<volatile uint64_t*>(e->pin_flag.ptr), __ATOMIC_ACQUIRE) == e->ticket;
   return hipEventQuery(e->ev_results) == hipSuccess;
 }
@@ -970,7 +1088,7 @@ bool WorkerResultsReady(Worker* e) {
 int WorkerResults(Worker* e, const double** ll, const double** grad, const double** site) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   HIP_TRY(e, hipSetDevice(e->device));
-  if (e->results_on_host) {
+  if (e->results_on_host || e->flag_behind_copy) {
     // poll the flag the chunk's last kernel stores; now and then ask the stream whether it has failed
     volatile uint64_t* flag = static_cast<volatile uint64_t*>(e->pin_flag.ptr);
     for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != e->ticket; spins++) {

@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <functional>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -119,6 +120,7 @@ struct Worker {
   DeviceBuffer<int32_t> done_counter;  // workgroups of the final-sums kernel that have finished (it leaves 0)
   bool signalled = false;        // the last pass's final-sums kernel stores the ticket itself (no kernel behind it)
   bool results_on_host = false;  // the resident pass's results are in pin_out, not in the device buffers
+  bool flag_behind_copy = false; // ... or a blocking call's chunk has them copied there, the completion flag stored behind the copies
   bool inputs_pending = false;      // the copy of the resident batch's inputs may still be in flight
   bool inputs_on_host = false;      // ... or has not been made: the next pass's set-up kernel reads pin_in and makes it
   // Blocking calls (engine.cpp): this worker walks ONE chunk of the call, so its set-up kernels have no earlier
@@ -132,6 +134,14 @@ struct Worker {
   bool busy = false;       // something may still be in flight on the worker's streams
   bool prep_used = false;  // ... on the set-up stream (pipelined passes since the last synchronisation)
   int id_offset = 0;  // index of the resident block's first tree in the caller's collection (error messages)
+  // the block being staged between WorkerStageBegin and WorkerStageEnd: the caller's arrays and the layout of pin_in
+  struct Staging {
+    bool open = false;
+    int tree_count = 0, rooted = 0, node_count = 0, wait = 0;
+    const int32_t* parent_ids = nullptr;
+    const double *branch_lengths = nullptr, *rates = nullptr, *params = nullptr;
+    size_t off_params = 0, off_rates = 0, off_pid = 0, bytes = 0;
+  } staging;
   DeviceBuffer<int32_t> children, sched, children2, sched2, children3, sched3;
   DeviceBuffer<int32_t> pipe_masks;  // packed tip masks per pattern tile (walk_pipe_kernel): a function of the alignment and the plan
   long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
@@ -211,6 +221,19 @@ int32_t WorkerBlockCount(const Worker* e);
 int WorkerBlock(const Worker* e, int32_t idx, char* name, size_t name_len, int32_t* start, int32_t* len);
 int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
                 const double* branch_lengths, const double* rates, const double* params, int wait);
+// ... in three steps (worker.cpp): Begin and End on the calling thread, Fill for disjoint ranges of trees that cover
+// the block on any host threads in between (no HIP call, no write outside the range's own rows)
+struct StagePart {
+  int code = 0;          // BITO_AMD_OK or the error the range's first bad tree gives
+  std::string message;
+  int first_tree = 0;
+  int min_cherries = 1 << 30;
+  double min_branch = std::numeric_limits<double>::infinity(), min_rate = std::numeric_limits<double>::infinity();
+};
+int WorkerStageBegin(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
+                     const double* branch_lengths, const double* rates, const double* params, int wait);
+void WorkerStageFill(Worker* e, int32_t t0, int32_t t1, StagePart* out);
+int WorkerStageEnd(Worker* e, const StagePart* parts, int part_count);
 int WorkerUpload(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
                  const double* branch_lengths, const double* rates, const double* params);
 int WorkerValidate(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,

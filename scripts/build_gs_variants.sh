@@ -9,6 +9,6 @@ mkdir -p ../variants
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form $flags -c gs_kernels.hip -o /tmp/gs_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/$name.so kernels.o /tmp/gs_$name.o walk_lds.o walk_tree.o time_tree.o worker.o engine.o beagle_shim.o gp_engine.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/$name.so kernels.o walk_hbm_cat.o /tmp/gs_$name.o walk_lds.o walk_pipe.o walk_tree.o time_tree.o worker.o engine.o beagle_shim.o gp_engine.o
   echo built $name
 done
