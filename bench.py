@@ -291,8 +291,14 @@ def main():
     S = 61 if codon else 4
     N = 2 * n - 1
 
+    # host threads of a blocking call (checking and packing inputs, copying results out): the engine's default is
+    # min(8, usable CPUs); with several ranks on one node the CPUs are shared among them
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    affinity, quota = usable_cpus()
+    cpus = max(1, min(affinity, int(quota + 0.5)) if quota else affinity)
+    host_threads = max(1, min(8, cpus // max(local_world, 1)))
     eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights,
-                          device_id=local_rank)
+                          device_id=local_rank, host_threads=host_threads)
     if not codon:
         eng.set_kernel(args.kernel)
 
@@ -469,6 +475,7 @@ def main():
                 "trees_per_gpu": T,
                 "trees_total": total_trees,
                 "kernel": kernel,
+                "host_threads_per_rank": host_threads,
                 "multi_gpu": ("trees sharded by rank; per step one asynchronous RCCL all-reduce of the summed "
                               "log-likelihood (8 bytes)" if reduce_ll else
                               "trees sharded by rank, no data-path collective (barrier + max-over-ranks timing only)")

@@ -41,7 +41,7 @@ SYMBOLS = [
 
 class EngineSpec(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("use_tip_states", C.c_int32), ("arena_bytes", C.c_uint64),
-                ("device_count", C.c_int32), ("reserved", C.c_int32), ("devices", C.POINTER(C.c_int32))]
+                ("device_count", C.c_int32), ("host_threads", C.c_int32), ("devices", C.POINTER(C.c_int32))]
 
 
 _lib = None

@@ -438,6 +438,7 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
   e->patterns.assign(patterns, patterns + (size_t)taxon_count * pattern_count);
   e->weights.assign(weights, weights + pattern_count);
   e->arena_bytes = spec ? spec->arena_bytes : 0;
+  e->host_threads = spec ? std::max(0, spec->host_threads) : 0;
   if (const char* v = std::getenv("BITO_AMD_HOST_THREADS")) e->host_threads = std::max(1, std::atoi(v));
   if (e->host_threads == 0) e->host_threads = std::min(8, UsableCpus());
   if (e->host_threads > 1) {

@@ -51,9 +51,12 @@ def _ip(a: np.ndarray):
 
 class Engine:
     def __init__(self, model: PhyloModelSpecification, patterns: np.ndarray, weights: np.ndarray,
-                 device_id: int = 0, use_tip_states: bool = True, arena_bytes: int = 0, devices=None):
+                 device_id: int = 0, use_tip_states: bool = True, arena_bytes: int = 0, devices=None,
+                 host_threads: int = 0):
         """``devices``: HIP ordinals of the GPUs this engine drives (default: ``[device_id]``); the counterpart of
-        the reference's ``thread_count`` (src/engine.cpp:10-31).  Blocking calls shard their trees over them."""
+        the reference's ``thread_count`` (src/engine.cpp:10-31).  Blocking calls shard their trees over them.
+        ``host_threads``: host threads a blocking call may use for checking and packing its inputs and copying its
+        results out (0: min(8, usable CPUs); 1: the calling thread alone)."""
         self._h = None
         L = _capi.lib()
         self.patterns = np.ascontiguousarray(patterns, dtype=np.int32)
@@ -65,7 +68,7 @@ class Engine:
         if not devs:
             raise BitoAmdError(_capi.ERR_BAD_ARG, "Device count needs to be strictly positive.")
         dev_array = (C.c_int32 * len(devs))(*devs)
-        spec = _capi.EngineSpec(devs[0], int(use_tip_states), arena_bytes, len(devs), 0, dev_array)
+        spec = _capi.EngineSpec(devs[0], int(use_tip_states), arena_bytes, len(devs), int(host_threads), dev_array)
         h = C.c_void_p()
         err = C.create_string_buffer(512)
         rc = L.bito_amd_engine_create(C.byref(spec), model.substitution.encode(), model.site.encode(),

@@ -40,7 +40,7 @@ class Engine {
          int32_t device_count = 1, const std::vector<int32_t>& devices = {}) {
     // device_count stands where the reference has thread_count (src/engine.hpp:20-24): how many FatBeagle
     // instances -- here GPUs -- serve one call
-    bito_amd_engine_spec es{device_id, 1, 0, device_count, 0, devices.empty() ? nullptr : devices.data()};
+    bito_amd_engine_spec es{device_id, 1, 0, device_count, /*host_threads=*/0, devices.empty() ? nullptr : devices.data()};
     char err[512] = {0};
     const int rc = bito_amd_engine_create(&es, spec.substitution_.c_str(), spec.site_.c_str(), spec.clock_.c_str(),
                                           taxon_count, pattern_count, patterns.data(), weights.data(), &e_, err,

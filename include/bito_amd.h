@@ -72,7 +72,11 @@ typedef struct {
   uint64_t arena_bytes;   /* cap on the HBM PLV arena per device; 0 = default (3/4 of free HBM: the engine owns its GPUs) */
   int32_t device_count;   /* GPUs this engine drives, >= 1 ("Thread count needs to be strictly positive.",
                              src/engine.cpp:14-16) */
-  int32_t reserved;       /* 0 */
+  int32_t host_threads;   /* host threads a blocking call may use for its own share of the work -- checking the
+                             wire-format rows, packing them into pinned memory, copying results out -- as the reference
+                             gives every FatBeagle instance a thread (EngineSpecification::thread_count_,
+                             src/engine.hpp:20-24).  0 = default: min(8, CPUs this process may use); 1 = the calling
+                             thread alone.  The helpers sleep between calls; all device work is issued by the caller. */
   const int32_t *devices; /* device_count HIP ordinals, or NULL: device_id, device_id + 1, ...  A device may be named
                              more than once (each entry is served like a device of its own): that is how the
                              multi-device path is exercised on a one-GPU machine. */

@@ -224,3 +224,47 @@ def test_collections_that_mix_short_and_ordinary_branches_are_evaluated_by_kind(
     pid[30, 0] = 0
     with pytest.raises(bito_amd.BitoAmdError, match="tree 30: parent id 0"):
         gpu.gradients(pid, bl, w.params)
+
+
+@pytest.mark.gpu
+def test_host_threads_check_and_pack_ranges_of_a_large_chunk():
+    """A blocking call's host share -- checks, packing, copy-out -- runs in ranges over helper threads for chunks of
+    1024 trees and more (engine.cpp, host_pool.hpp).  Same results as the calling thread alone (to the order of the
+    pattern-tile sums, which follows the chunk plan), against the oracle on a sample; and the error a serial pass over
+    the trees would have met first, whichever thread finds it."""
+    from oracle import oracle
+
+    w = workloads.ds1_gtr_weibull4(30)  # 3000 trees: chunks of 1024 + 1976 with helper threads
+    alone = bito_amd.Engine(_spec(w), w.patterns, w.weights, host_threads=1)
+    many = bito_amd.Engine(_spec(w), w.patterns, w.weights, host_threads=6)
+    a = alone.gradients(w.parent_ids, w.branch_lengths, w.params)
+    b = many.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert _close(a["log_likelihood"], b["log_likelihood"], 0.1 * LL_ATOL, 0.1 * LL_RTOL)
+    assert _close(a["branch_lengths"], b["branch_lengths"], 0.1 * GRAD_ATOL, 0.1 * GRAD_RTOL)
+    sel = np.r_[0:6, 1020:1030, 1350:1356, 2994:3000]  # (chunk and range boundaries among them)
+    cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
+    ref = cpu.gradients(w.parent_ids[sel], w.branch_lengths[sel], w.params[sel])
+    assert _close(b["log_likelihood"][sel], ref["log_likelihood"], LL_ATOL, LL_RTOL)
+    assert _close(b["branch_lengths"][sel], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
+    # a second call on the same engines (the helpers went back to sleep in between), fresh branch lengths
+    bl2 = w.branch_lengths * 1.03125
+    a2 = alone.gradients(w.parent_ids, bl2, w.params)
+    b2 = many.gradients(w.parent_ids, bl2, w.params)
+    assert _close(a2["log_likelihood"], b2["log_likelihood"], 0.1 * LL_ATOL, 0.1 * LL_RTOL)
+    assert not np.array_equal(b2["log_likelihood"], b["log_likelihood"])
+    # bad trees in two different ranges of the second chunk, and a bad parameter row in between: the first one is named
+    pid = w.parent_ids.copy()
+    par = w.params.copy()
+    pid[2900, 0] = 0
+    par[2000, 0] += 0.5
+    pid[1500, 3] = 0
+    for eng in (alone, many):
+        with pytest.raises(bito_amd.BitoAmdError, match="tree 1500: parent id 0 of node 3"):
+            eng.gradients(pid, w.branch_lengths, par)
+    pid[1500] = w.parent_ids[1500]
+    for eng in (alone, many):
+        with pytest.raises(bito_amd.BitoAmdError, match=r"frequencies do not sum to 1.*\[tree 2000\]"):
+            eng.gradients(pid, w.branch_lengths, par)
+    # and the engines still work after a failed call
+    c = many.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert np.array_equal(c["log_likelihood"], b["log_likelihood"])
