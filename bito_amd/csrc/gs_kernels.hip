@@ -475,8 +475,11 @@ struct GsPlv {
 };
 
 // Image order of one tree.  Post-order: per internal node and category, P of each internal child.
-// Pre-order: per internal node (parents first), category and internal child: P^T of the child, then
-// the model's Q^T (entry -1).  Other entries are record numbers (br * C + c) * 3 + which.
+// Pre-order: per internal node (parents first) and category: the model's Q^T (entry -1; not for the root), then P^T
+// of each internal child.  Other entries are record numbers (br * C + c) * 3 + which.
+#ifndef GS_OWN_EDGE
+#define GS_OWN_EDGE 1  // 0: round 2's pre-order pass (a child's edge derivative in its parent's step, from the child's re-read post-order partial)
+#endif
 __global__ void __launch_bounds__(64)
 gs_schedule_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __restrict__ jobs, int stride) {
   const int t = blockIdx.x * 64 + threadIdx.x;
@@ -499,6 +502,11 @@ gs_schedule_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* _
     const int c0 = ch[(node - n) * 2], c1 = ch[(node - n) * 2 + 1];
     const int last = c1 >= n ? c1 : c0, first = c1 >= n ? c0 : c1;
     for (int c = 0; c < C; c++) {
+#if GS_OWN_EDGE
+      if (node != N - 1) out[at++] = -1;
+      if (first >= n) out[at++] = (first * C + c) * 3 + 2;
+      if (last >= n) out[at++] = (last * C + c) * 3 + 2;
+#else
       if (first >= n) {
         out[at++] = (first * C + c) * 3 + 2;
         out[at++] = -1;
@@ -507,6 +515,7 @@ gs_schedule_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* _
         out[at++] = (last * C + c) * 3 + 2;
         out[at++] = -1;
       }
+#endif
     }
   }
   const int tail = at ? out[at - 1] : 0;
@@ -803,9 +812,9 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       if (node == N - 1) {
         load_pi(bb);
         site += model[kGsCatWeight + c] * GsDot(bb, a);
-      } else if (active && (GRAD || !chain || node + 1 >= N || (ch[(node + 1 - n) * 2] != node && ch[(node + 1 - n) * 2 + 1] != node))) {
-        // (a log-likelihood-only walk needs no copy in memory of a vector that is consumed from
-        // registers by the next node)
+      } else if (active && ((GRAD && !GS_OWN_EDGE) || !chain || node + 1 >= N || (ch[(node + 1 - n) * 2] != node && ch[(node + 1 - n) * 2 + 1] != node))) {
+        // (no copy in memory of a vector that is consumed from registers by the next node: the pre-order pass does
+        // not read post-order partials either, it rebuilds them from the children's messages)
         GsStore(slot(node, c), lane, a);
       }
     }
@@ -836,6 +845,125 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
   if (lane == 0 && active) part_ll[(size_t)tree * tiles + tile] = wll;
 
   // ---- pre-order + edge derivatives: one step per internal node, parents first -------------
+#if GS_OWN_EDGE
+  // A step has the node's pre-order partial u (from its parent's step: in registers when the node is its parent's
+  // chained child, else from the arena) and the messages a_f = P_f x_f, a_l = P_l x_l of its two children (kept by
+  // the post-order pass, or a tip's table row).  From these alone:
+  //   * the node's OWN edge: its post-order partial is x = a_f . a_l, so the reference's  pre^T (r_c Q) post  of the
+  //     edge above it (src/fat_beagle.cpp:101-160) is (Q^T u) . a_f . a_l -- one contraction with Q^T; no post-order
+  //     partial is read back, and the post-order pass keeps in memory only the partials a sibling's step loads;
+  //   * the pattern's likelihood  den = u . a_f . a_l  (any positive per-pattern factor cancels in num / den);
+  //   * the children's pre-order partials  q_f = P_f^T (u . a_l),  q_l = P_l^T (u . a_f): stored, or handed to the
+  //     next step in registers; a tip child's edge derivative from its dP table row.
+  // (Round 2 formed a child's edge derivative in the parent's step, (Q^T q_child) . x_child with x_child re-read:
+  // per internal node one more 8 KB load and one more 8 KB store per pattern tile.  The form  w^T (r_c Q) (P x)  with
+  // the child's MESSAGE is not an alternative: Q and the ROUNDED P of a codon model do not commute to better than
+  // about 1e-6 relative, a thousand tolerances on short branches with large derivatives.)
+  if (GRAD) {
+    double* __restrict__ grow = part_grad + ((size_t)tree * tiles + tile) * N;
+    if (lane == 0 && active) grow[N - 1] = 0.0;
+    GsPlv y;              // pre-order partial of the child processed last; survives into the next iteration
+    bool have_u = false;  // y is node's own pre-order partial (wave-uniform)
+    for (int node = N - 1; node >= n; --node) {
+      const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
+      const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
+      const int cl = c1 >= n ? c1 : c0, cf = c1 >= n ? c0 : c1;  // chained child (if any) last
+      const int sf = cf < n ? tips[(size_t)cf * Ppad] : 0;
+      const int sl = cl < n ? tips[(size_t)cl * Ppad] : 0;
+      double den = 0.0, numf = 0.0, numl = 0.0, numo = 0.0;
+      // Rescaled pre-order partials: a child's partial is divided by this node's POST-order factor
+      // (any positive per-pattern factor cancels in num / den; this one keeps the products O(1), see
+      // walk_hbm_kernel)
+      const double step_inv = RESCALE ? *inv_at(node) : 1.0;
+      for (int c = 0; c < C; c++) {
+        GsPlv u, af, al;
+        if (node == N - 1) {
+          load_pi(u);
+        } else if (have_u) {
+          u = y;
+        } else {
+          GsLoad(slot(node, c), lane, u);
+        }
+        if (cf < n) GsTip(rec(cf, c, 0), sf, kq, af);
+        else GsLoad(mslot(cf, c), lane, af);
+        if (cl < n) GsTip(rec(cl, c, 0), sl, kq, al);
+        else GsLoad(mslot(cl, c), lane, al);
+        const double wc = model[kGsCatWeight + c];
+        const double rc = model[(deriv_mode ? kGsCatRateDeriv : kGsCatRate) + c];  // site-model pass: d r_c / d shape
+        if (node != N - 1) {
+          GsPlv t;
+          pipe.MatVec(u, t);  // Q^T u
+          double so = 0.0, sd = 0.0;
+#pragma unroll
+          for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const double x = af.b[m][r] * al.b[m][r];
+              so += t.b[m][r] * x;
+              sd += u.b[m][r] * x;
+            }
+          numo += wc * rc * so;
+          den += wc * sd;
+        } else {
+          double sd = 0.0;
+#pragma unroll
+          for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sd += u.b[m][r] * (af.b[m][r] * al.b[m][r]);
+          den += wc * sd;
+        }
+        // what each child sees from above: w_f = u . a_l, w_l = u . a_f (in place)
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const v4d f = af.b[m];
+          af.b[m] = u.b[m] * al.b[m];  // w_f
+          al.b[m] = u.b[m] * f;        // w_l
+        }
+        if (cf < n) {
+          GsPlv x;
+          GsTip(rec(cf, c, 1), sf, kq, x);
+          numf += wc * GsDot(af, x);
+        } else {
+          pipe.MatVec(af, y);
+          if (RESCALE) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) y.b[m] *= step_inv;
+          }
+          if (active) GsStore(slot(cf, c), lane, y);
+        }
+        if (cl < n) {
+          GsPlv x;
+          GsTip(rec(cl, c, 1), sl, kq, x);
+          numl += wc * GsDot(al, x);
+        } else {
+          pipe.MatVec(al, y);
+          if (RESCALE) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) y.b[m] *= step_inv;
+          }
+          // the chained child's pre-order partial goes to memory only if its own step will not take
+          // it from registers (it always will with one category; the store is then not needed)
+          if (active && !(chain && cl == node - 1)) GsStore(slot(cl, c), lane, y);
+        }
+      }
+      have_u = chain && cl >= n && cl == node - 1;  // the next node's own pre-order partial is in y
+      // den is a pattern's sum (its four lanes), the numerators stay per lane: sum over lanes of num_lane . w_p / den_p is
+      // an edge's derivative.  Two edges' sums at once on the vector ALU (the first ends up in lane 31, the second in
+      // lane 63): the tip children's edges, then the node's own
+      den = GsPatternSum(den);
+      const double scale = weight / den;
+      if (cf < n || cl < n) {
+        const double g = PairSum(numf * scale, numl * scale);
+        const int child = lane < 32 ? cf : cl;
+        if (active && (lane & 31) == 31 && child < n) grow[child] = g;
+      }
+      if (node != N - 1) {
+        const double g = PairSum(numo * scale, 0.0);
+        if (active && lane == 31) grow[node] = g;
+      }
+    }
+  }
+#else
   if (GRAD) {
     double* __restrict__ grow = part_grad + ((size_t)tree * tiles + tile) * N;
     if (lane == 0 && active) grow[N - 1] = 0.0;
@@ -942,6 +1070,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       if (active && (lane & 31) == 31) grow[lane < 32 ? cf : cl] = g;
     }
   }
+#endif
 }
 
 size_t GsArenaDoublesPerTree(const BatchDims& d, int tiles, int want_gradient) {
