@@ -28,6 +28,31 @@
 #ifndef GS_WAVES
 #define GS_WAVES 2  // waves per SIMD the register allocation is held to
 #endif
+// (the traversal's variants; GS_EXP_*: timing-only ablations, their results mean nothing -- BENCH_ABLATION=1 for bench.py)
+#ifndef GS_SPARSE_DP
+#define GS_SPARSE_DP 1
+#endif
+#ifndef GS_SIBLING_EARLY
+#define GS_SIBLING_EARLY 0
+#endif
+#ifndef GS_X_EARLY
+#define GS_X_EARLY 0
+#endif
+#ifndef GS_ASM_FETCH
+#define GS_ASM_FETCH 1
+#endif
+#ifndef GS_EXP_NOLOAD
+#define GS_EXP_NOLOAD 0
+#endif
+#ifndef GS_EXP_NOSTORE
+#define GS_EXP_NOSTORE 0
+#endif
+#ifndef GS_EXP_NOMFMA
+#define GS_EXP_NOMFMA 0
+#endif
+#ifndef GS_OWN_EDGE
+#define GS_OWN_EDGE 1  // 0: round 2's pre-order pass (a child's edge derivative in its parent's step, from the child's re-read post-order partial)
+#endif
 #ifndef GS_WG_WAVES
 #define GS_WG_WAVES 4  // waves (16-pattern tiles of one tree) per workgroup of the traversal kernel (8: measured slower)
 #endif
@@ -173,6 +198,24 @@ gs_model_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, const int32_t* __res
   for (int i = 0; i < 64; i++) {
     out[kGsQ + i * 64 + lane] = A[i * kLd + lane];
     out[kGsQtImage + GsImageIndex(lane, i)] = A[i * kLd + lane];  // MFMA image of Q^T: M[lane][i] = Q[i][lane]
+  }
+  {
+    // the nonzero entries of column `lane` of Q, rows ascending (gs_matrices_kernel: dP = P (r_c Q) term by term --
+    // the terms a dense fused multiply-add chain over all rows would add are these and exact zeros)
+    int cnt = 0;
+    for (int k = 0; k < 64; k++) {
+      const double q = A[k * kLd + lane];
+      if (q != 0.0) {
+        if (cnt < kGsQnzMax) {
+          out[kGsQnzIdx + lane * kGsQnzMax + cnt] = (double)k;
+          out[kGsQnzVal + lane * kGsQnzMax + cnt] = q;
+        }
+        cnt++;
+      }
+    }
+    out[kGsQnzCount + lane] = (double)cnt;
+    const bool fits = __all(cnt <= kGsQnzMax);
+    if (lane == 0) out[kGsQnzFlag] = fits ? 1.0 : 0.0;
   }
   // symmetrise: D^{1/2} Q D^{-1/2}, lower triangle computed, upper mirrored; parked in the V slot
   // of the record until the eigensolver kernel replaces it
@@ -367,11 +410,26 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
 #pragma clang fp contract(off)
   __shared__ double Pl[64 * kPld];
   __shared__ double e[64];
+#if GS_SPARSE_DP
+  // the nonzero entries of Q's columns (leaf branches with gradient; 40 KB per workgroup with them: four per CU still)
+  __shared__ double nz_val[64 * kGsQnzMax];
+  __shared__ uint8_t nz_idx[64 * kGsQnzMax], nz_cnt[64];
+#endif
   const int C = d.category_count, NB = d.node_count - 1, n = d.taxon_count;
   const int br = blockIdx.x / C, c = blockIdx.x % C;
   const int tree = tree0 + blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, ii = lane & 15;
   const double* __restrict__ m = gs_model + (size_t)model_index[tree] * kGsModelStride;
+#if GS_SPARSE_DP
+  const bool sparse_dp = br < n && want_gradient && m[kGsQnzFlag] != 0.0;
+  if (sparse_dp) {  // (in flight under the first product)
+    for (int i = tid; i < 64 * kGsQnzMax; i += 256) {
+      nz_val[i] = m[kGsQnzVal + i];
+      nz_idx[i] = (uint8_t)m[kGsQnzIdx + i];
+    }
+    if (tid < 64) nz_cnt[tid] = (uint8_t)m[kGsQnzCount + tid];
+  }
+#endif
   const double rate = m[kGsCatRate + c];
   const double time = branch[(size_t)tree * d.node_count + br] * rate;
   if (tid < 64) e[tid] = DetExp(m[kGsLambda + tid] * time);
@@ -435,6 +493,36 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
   if (!want_gradient) return;
   // dP = P (r_c Q); deriv_mode 1: the site-model pass, r_c -> d r_c / d shape
   const double drate = deriv_mode ? m[kGsCatRateDeriv + c] : rate;
+#if GS_SPARSE_DP
+  if (sparse_dp) {
+    // Q of a codon model has at most ten entries per column: the product on the vector ALU, straight into the table
+    // positions, one fused multiply-add per nonzero entry in ascending row order -- bit for bit what the dense chain on
+    // the matrix pipe gives (its other terms are exact zeros), at a tenth of the arithmetic and none of it on the pipe
+    // this kernel and the traversal wait for
+    v2d* __restrict__ out = reinterpret_cast<v2d*>(rec + 4096);
+#pragma unroll 2
+    for (int i = 0; i < 8; i++) {
+      const int pos = i * 256 + tid;
+      const int s = pos >> 5, at = (pos & 31) * 2;
+      const int mm = at >> 4, q = (at >> 2) & 3, r = at & 3;
+      const int st0 = 16 * mm + 4 * r + q, st1 = st0 + 4;
+      double d0 = 0.0, d1 = 0.0;
+      if (s != S) {
+        const int cnt = nz_cnt[s];
+        const uint8_t* idx = nz_idx + s * kGsQnzMax;
+        const double* val = nz_val + s * kGsQnzMax;
+        for (int e = 0; e < cnt; e++) {
+          const int k = idx[e];
+          const double qv = val[e] * drate;
+          d0 = __builtin_fma(Pl[st0 * kPld + k], qv, d0);
+          d1 = __builtin_fma(Pl[st1 * kPld + k], qv, d1);
+        }
+      }
+      out[pos] = v2d{d0, d1};
+    }
+    return;
+  }
+#endif
   v4d accd[4];
   gemm([&](int ks) { return Pl[(16 * w + ii) * kPld + 4 * ks + kq]; }, m + kGsQ, drate, accd);
   __syncthreads();
@@ -477,9 +565,6 @@ struct GsPlv {
 // Image order of one tree.  Post-order: per internal node and category, P of each internal child.
 // Pre-order: per internal node (parents first) and category: the model's Q^T (entry -1; not for the root), then P^T
 // of each internal child.  Other entries are record numbers (br * C + c) * 3 + which.
-#ifndef GS_OWN_EDGE
-#define GS_OWN_EDGE 1  // 0: round 2's pre-order pass (a child's edge derivative in its parent's step, from the child's re-read post-order partial)
-#endif
 __global__ void __launch_bounds__(64)
 gs_schedule_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __restrict__ jobs, int stride) {
   const int t = blockIdx.x * 64 + threadIdx.x;
@@ -531,21 +616,6 @@ void LaunchGsSchedule(const BatchDims& d, const DeviceBatch& b, hipStream_t stre
 
 // (non-temporal arena accesses, which pay in walk_hbm_cat_kernel, cost here: 59.5 against 56.8 ms per 4096 config-5
 // trees -- the vectors ARE read again soon, messages by the same wave's pre-order pass out of L2 / MALL)
-#ifndef GS_X_EARLY
-#define GS_X_EARLY 0
-#endif
-#ifndef GS_ASM_FETCH
-#define GS_ASM_FETCH 1
-#endif
-#ifndef GS_EXP_NOLOAD
-#define GS_EXP_NOLOAD 0
-#endif
-#ifndef GS_EXP_NOSTORE
-#define GS_EXP_NOSTORE 0
-#endif
-#ifndef GS_EXP_NOMFMA
-#define GS_EXP_NOMFMA 0
-#endif
 #ifndef GS_ARENA_NT
 #define GS_ARENA_NT 0
 #endif
@@ -769,6 +839,11 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
     double cat_max = 0.0;  // RESCALE with several categories: maximum over all of them
     for (int c = 0; c < C; c++) {
       GsPlv bb, x;
+#if GS_SIBLING_EARLY
+      // (the sibling's partial is requested before the first child's contraction, not behind it)
+      GsPlv x2;
+      if (cs >= n && cf >= n) GsLoad(slot(cs, c), lane, x2);
+#endif
       if (cf < n) {
         GsTip(rec(cf, c, 0), sf, kq, a);
       } else {
@@ -780,7 +855,12 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       if (cs < n) {
         GsTip(rec(cs, c, 0), ss, kq, bb);
       } else {
+#if GS_SIBLING_EARLY
+        if (cf >= n) x = x2;
+        else GsLoad(slot(cs, c), lane, x);
+#else
         GsLoad(slot(cs, c), lane, x);
+#endif
         pipe.MatVec(x, bb);
         if (GRAD && active) GsStore(mslot(cs, c), lane, bb);
       }

@@ -289,7 +289,11 @@ void LaunchSignal(unsigned long long* flag, unsigned long long value, hipStream_
 constexpr int kGsV = 0, kGsVinv = 4096, kGsQ = 8192, kGsLambda = 12288, kGsPi = kGsLambda + 64, kGsSq = kGsPi + 64,
               kGsCatRate = kGsSq + 64, kGsCatWeight = kGsCatRate + kMaxCategories,
               kGsCatRateDeriv = kGsCatWeight + kMaxCategories, kGsQtImage = kGsCatRateDeriv + kMaxCategories,
-              kGsModelStride = kGsQtImage + 4096;  // kGsQtImage: Q^T as an MFMA A-operand image
+              // kGsQtImage: Q^T as an MFMA A-operand image; behind it the nonzero entries of every COLUMN of Q in ascending
+              // row order (a codon model's column has at most ten), for dP = P (r_c Q) on the vector ALU: count per column
+              // (kGsQnzFlag: 1 when every column fits kGsQnzMax entries), row indices and values [64][kGsQnzMax]
+              kGsQnzMax = 10, kGsQnzFlag = kGsQtImage + 4096, kGsQnzCount = kGsQnzFlag + 8, kGsQnzIdx = kGsQnzCount + 64,
+              kGsQnzVal = kGsQnzIdx + 64 * kGsQnzMax, kGsModelStride = kGsQnzVal + 64 * kGsQnzMax;
 inline int GsTiles(int pattern_count) { return (pattern_count + 15) / 16; }  // 16 site patterns per wave
 size_t GsArenaDoublesPerTree(const BatchDims& d, int tiles, int want_gradient);
 size_t GsImageDoublesPerTree(const BatchDims& d);
