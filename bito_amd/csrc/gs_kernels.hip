@@ -47,6 +47,12 @@
 #ifndef GS_EXP_NOSTORE
 #define GS_EXP_NOSTORE 0
 #endif
+#ifndef GS_EXP_MAT_NOWRITE
+#define GS_EXP_MAT_NOWRITE 0
+#endif
+#ifndef GS_EXP_MAT_NOGEMM
+#define GS_EXP_MAT_NOGEMM 0
+#endif
 #ifndef GS_EXP_NOMFMA
 #define GS_EXP_NOMFMA 0
 #endif
@@ -441,7 +447,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
 #pragma unroll
     for (int nb = 0; nb < 4; nb++) acc[nb] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
-    for (int ks = 0; ks < 16; ks++) {
+    for (int ks = 0; ks < (GS_EXP_MAT_NOGEMM ? 1 : 16); ks++) {
       const double a = a_of(ks);
       const double* brow = B + (4 * ks + kq) * 64 + ii;
 #pragma unroll
@@ -470,8 +476,8 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
       const int pos = i * 256 + tid;  // = (mb * 8 + ks2) * 64 + 16 kq' + ii'
       const int l = pos & 63, blk = pos >> 6, mb = blk >> 3, ks2 = blk & 7;
       const int row = 16 * mb + (l & 15), col = 8 * ks2 + (l >> 4);
-      out0[pos] = v2d{Pl[row * kPld + col], Pl[row * kPld + col + 4]};
-      if (want_gradient) out2[pos] = v2d{Pl[col * kPld + row], Pl[(col + 4) * kPld + row]};
+      if (!GS_EXP_MAT_NOWRITE || Pl[0] == 123.0) out0[pos] = v2d{Pl[row * kPld + col], Pl[row * kPld + col + 4]};
+      if (want_gradient && (!GS_EXP_MAT_NOWRITE || Pl[0] == 123.0)) out2[pos] = v2d{Pl[col * kPld + row], Pl[(col + 4) * kPld + row]};
     }
     return;
   }
@@ -486,7 +492,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
       const int st0 = 16 * mm + 4 * r + q, st1 = st0 + 4;
       v2d v{Pl[st0 * kPld + s], Pl[st1 * kPld + s]};
       if (s == S) v = is_p ? v2d{st0 < S ? 1.0 : 0.0, st1 < S ? 1.0 : 0.0} : v2d{0.0, 0.0};
-      out[pos] = v;
+      if (!GS_EXP_MAT_NOWRITE || Pl[0] == 123.0) out[pos] = v;
     }
   };
   table(rec, true);
@@ -518,7 +524,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
           d1 = __builtin_fma(Pl[st1 * kPld + k], qv, d1);
         }
       }
-      out[pos] = v2d{d0, d1};
+      if (!GS_EXP_MAT_NOWRITE || Pl[0] == 123.0) out[pos] = v2d{d0, d1};
     }
     return;
   }
