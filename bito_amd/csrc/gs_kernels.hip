@@ -47,12 +47,6 @@
 #ifndef GS_EXP_NOSTORE
 #define GS_EXP_NOSTORE 0
 #endif
-#ifndef GS_EXP_MAT_NOWRITE
-#define GS_EXP_MAT_NOWRITE 0
-#endif
-#ifndef GS_EXP_MAT_NOGEMM
-#define GS_EXP_MAT_NOGEMM 0
-#endif
 #ifndef GS_EXP_NOMFMA
 #define GS_EXP_NOMFMA 0
 #endif
@@ -409,52 +403,47 @@ void LaunchGsSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch&
 
 constexpr int kPld = 66;  // LDS row stride of P (even: 16-byte aligned pairs)
 
+// (Round 3: a workgroup takes kGsMatJobs consecutive (branch, category) jobs of its tree and keeps what they share --
+// its rows of V in registers, V^-1 in LDS in the B-operand order, the lists of Q's nonzero entries -- instead of one job
+// per workgroup with 80 loads per lane through L1 in front of its 64 matrix instructions: 557 k workgroups per 4096
+// config-5 trees spent half the kernel's time outside their products.)
+constexpr int kGsMatJobs = 8;
+
 __global__ void __launch_bounds__(256)
 gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ branch,
                    const int32_t* __restrict__ model_index, const double* __restrict__ gs_model,
                    double* __restrict__ imgs, int want_gradient, int deriv_mode) {
 #pragma clang fp contract(off)
-  __shared__ double Pl[64 * kPld];
-  __shared__ double e[64];
-#if GS_SPARSE_DP
-  // the nonzero entries of Q's columns (leaf branches with gradient; 40 KB per workgroup with them: four per CU still)
-  __shared__ double nz_val[64 * kGsQnzMax];
-  __shared__ uint8_t nz_idx[64 * kGsQnzMax], nz_cnt[64];
-#endif
+  extern __shared__ double mat_lds[];
+  double* const Pl = mat_lds;                                   // [64][kPld]  P, row-major
+  v2d* const Bl = reinterpret_cast<v2d*>(Pl + 64 * kPld);       // [16 k-steps][2][64 lanes] pairs of V^-1 entries
+  double* const e = reinterpret_cast<double*>(Bl + 16 * 2 * 64);  // [64] exp(lambda t r_c)
+  double* const nz_val = e + 64;                                // [64][kGsQnzMax] nonzero entries of Q's columns
+  uint8_t* const nz_idx = reinterpret_cast<uint8_t*>(nz_val + 64 * kGsQnzMax);
+  uint8_t* const nz_cnt = nz_idx + 64 * kGsQnzMax;
   const int C = d.category_count, NB = d.node_count - 1, n = d.taxon_count;
-  const int br = blockIdx.x / C, c = blockIdx.x % C;
+  const int jobs = NB * C;
+  const int job0 = blockIdx.x * kGsMatJobs, job1 = min(job0 + kGsMatJobs, jobs);
   const int tree = tree0 + blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, ii = lane & 15;
   const double* __restrict__ m = gs_model + (size_t)model_index[tree] * kGsModelStride;
-#if GS_SPARSE_DP
-  const bool sparse_dp = br < n && want_gradient && m[kGsQnzFlag] != 0.0;
-  if (sparse_dp) {  // (in flight under the first product)
+  // what the jobs share
+  double v_row[16];  // V[16 w + ii][4 ks + kq]: this lane's A operands before the scaling by e
+#pragma unroll
+  for (int ks = 0; ks < 16; ks++) v_row[ks] = m[kGsV + (16 * w + ii) * 64 + 4 * ks + kq];
+  for (int i = tid; i < 16 * 2 * 64; i += 256) {
+    const int l = i & 63, h = (i >> 6) & 1, ks = i >> 7;
+    const double* src = m + kGsVinv + (4 * ks + (l >> 4)) * 64 + 32 * h + (l & 15);
+    Bl[i] = v2d{src[0], src[16]};
+  }
+  const bool sparse_dp = GS_SPARSE_DP && want_gradient && m[kGsQnzFlag] != 0.0;
+  if (sparse_dp) {
     for (int i = tid; i < 64 * kGsQnzMax; i += 256) {
       nz_val[i] = m[kGsQnzVal + i];
       nz_idx[i] = (uint8_t)m[kGsQnzIdx + i];
     }
     if (tid < 64) nz_cnt[tid] = (uint8_t)m[kGsQnzCount + tid];
   }
-#endif
-  const double rate = m[kGsCatRate + c];
-  const double time = branch[(size_t)tree * d.node_count + br] * rate;
-  if (tid < 64) e[tid] = DetExp(m[kGsLambda + tid] * time);
-  __syncthreads();
-  double* __restrict__ rec = imgs + (((size_t)blockIdx.y * NB + br) * C + c) * (3 * 4096);
-
-  // rows 16 w .. 16 w + 15 of A B, A given by a(ks) = A[16 w + ii][4 ks + kq], B row-major in global
-  auto gemm = [&](auto a_of, const double* __restrict__ B, double scale, v4d acc[4]) {
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) acc[nb] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int ks = 0; ks < (GS_EXP_MAT_NOGEMM ? 1 : 16); ks++) {
-      const double a = a_of(ks);
-      const double* brow = B + (4 * ks + kq) * 64 + ii;
-#pragma unroll
-      for (int nb = 0; nb < 4; nb++)
-        acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[16 * nb] * scale, acc[nb], 0, 0, 0);
-    }
-  };
   // result registers -> row-major LDS: register r of lane 16 q + j holds row 4 r + q, column j
   auto to_lds = [&](const v4d acc[4]) {
 #pragma unroll
@@ -462,86 +451,119 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
 #pragma unroll
       for (int r = 0; r < 4; r++) Pl[(16 * w + 4 * r + kq) * kPld + 16 * nb + ii] = acc[nb][r];
   };
-  v4d acc[4];
-  gemm([&](int ks) { return m[kGsV + (16 * w + ii) * 64 + 4 * ks + kq] * e[4 * ks + kq]; }, m + kGsVinv, 1.0, acc);
-  to_lds(acc);
-  __syncthreads();
 
-  if (br >= n) {
-    // internal branch: image of P, and of P^T for the pre-order pass; 16-byte coalesced stores
-    v2d* __restrict__ out0 = reinterpret_cast<v2d*>(rec);
-    v2d* __restrict__ out2 = reinterpret_cast<v2d*>(rec + 8192);
+  for (int job = job0; job < job1; job++) {
+    const int br = job / C, c = job % C;
+    const double rate = m[kGsCatRate + c];
+    const double time = branch[(size_t)tree * d.node_count + br] * rate;
+    __syncthreads();  // (the previous job's readers of Pl and e are done; the first job: Bl and the lists are in place)
+    if (tid < 64) e[tid] = DetExp(m[kGsLambda + tid] * time);
+    __syncthreads();
+    double* __restrict__ rec = imgs + (((size_t)blockIdx.y * NB + br) * C + c) * (3 * 4096);
+    // rows 16 w .. 16 w + 15 of (V diag e) V^-1
+    v4d acc[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int pos = i * 256 + tid;  // = (mb * 8 + ks2) * 64 + 16 kq' + ii'
-      const int l = pos & 63, blk = pos >> 6, mb = blk >> 3, ks2 = blk & 7;
-      const int row = 16 * mb + (l & 15), col = 8 * ks2 + (l >> 4);
-      if (!GS_EXP_MAT_NOWRITE || Pl[0] == 123.0) out0[pos] = v2d{Pl[row * kPld + col], Pl[row * kPld + col + 4]};
-      if (want_gradient && (!GS_EXP_MAT_NOWRITE || Pl[0] == 123.0)) out2[pos] = v2d{Pl[col * kPld + row], Pl[(col + 4) * kPld + row]};
+    for (int nb = 0; nb < 4; nb++) acc[nb] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ks++) {
+      const double a = v_row[ks] * e[4 * ks + kq];
+      const v2d b01 = Bl[(ks * 2) * 64 + lane], b23 = Bl[(ks * 2 + 1) * 64 + lane];
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b01.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b01.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b23.x, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b23.y, acc[3], 0, 0, 0);
     }
-    return;
-  }
-  // leaf branch: transposed look-up tables; position 16 m + 4 q + r of row s holds state 16 m + 4 r + q
-  auto table = [&](double* __restrict__ dst, bool is_p) {
-    v2d* __restrict__ out = reinterpret_cast<v2d*>(dst);
+    to_lds(acc);
+    __syncthreads();
+
+    if (br >= n) {
+      // internal branch: image of P, and of P^T for the pre-order pass; 16-byte coalesced stores
+      v2d* __restrict__ out0 = reinterpret_cast<v2d*>(rec);
+      v2d* __restrict__ out2 = reinterpret_cast<v2d*>(rec + 8192);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int pos = i * 256 + tid;  // pair index: row s = pos / 32, positions 2 (pos % 32), +1
-      const int s = pos >> 5, at = (pos & 31) * 2;
-      const int mm = at >> 4, q = (at >> 2) & 3, r = at & 3;  // r in {0, 2}
-      const int st0 = 16 * mm + 4 * r + q, st1 = st0 + 4;
-      v2d v{Pl[st0 * kPld + s], Pl[st1 * kPld + s]};
-      if (s == S) v = is_p ? v2d{st0 < S ? 1.0 : 0.0, st1 < S ? 1.0 : 0.0} : v2d{0.0, 0.0};
-      if (!GS_EXP_MAT_NOWRITE || Pl[0] == 123.0) out[pos] = v;
-    }
-  };
-  table(rec, true);
-  if (!want_gradient) return;
-  // dP = P (r_c Q); deriv_mode 1: the site-model pass, r_c -> d r_c / d shape
-  const double drate = deriv_mode ? m[kGsCatRateDeriv + c] : rate;
-#if GS_SPARSE_DP
-  if (sparse_dp) {
-    // Q of a codon model has at most ten entries per column: the product on the vector ALU, straight into the table
-    // positions, one fused multiply-add per nonzero entry in ascending row order -- bit for bit what the dense chain on
-    // the matrix pipe gives (its other terms are exact zeros), at a tenth of the arithmetic and none of it on the pipe
-    // this kernel and the traversal wait for
-    v2d* __restrict__ out = reinterpret_cast<v2d*>(rec + 4096);
-#pragma unroll 2
-    for (int i = 0; i < 8; i++) {
-      const int pos = i * 256 + tid;
-      const int s = pos >> 5, at = (pos & 31) * 2;
-      const int mm = at >> 4, q = (at >> 2) & 3, r = at & 3;
-      const int st0 = 16 * mm + 4 * r + q, st1 = st0 + 4;
-      double d0 = 0.0, d1 = 0.0;
-      if (s != S) {
-        const int cnt = nz_cnt[s];
-        const uint8_t* idx = nz_idx + s * kGsQnzMax;
-        const double* val = nz_val + s * kGsQnzMax;
-        for (int e = 0; e < cnt; e++) {
-          const int k = idx[e];
-          const double qv = val[e] * drate;
-          d0 = __builtin_fma(Pl[st0 * kPld + k], qv, d0);
-          d1 = __builtin_fma(Pl[st1 * kPld + k], qv, d1);
-        }
+      for (int i = 0; i < 8; i++) {
+        const int pos = i * 256 + tid;  // = (mb * 8 + ks2) * 64 + 16 kq' + ii'
+        const int l = pos & 63, blk = pos >> 6, mb = blk >> 3, ks2 = blk & 7;
+        const int row = 16 * mb + (l & 15), col = 8 * ks2 + (l >> 4);
+        out0[pos] = v2d{Pl[row * kPld + col], Pl[row * kPld + col + 4]};
+        if (want_gradient) out2[pos] = v2d{Pl[col * kPld + row], Pl[(col + 4) * kPld + row]};
       }
-      if (!GS_EXP_MAT_NOWRITE || Pl[0] == 123.0) out[pos] = v2d{d0, d1};
+      continue;
     }
-    return;
+    // leaf branch: transposed look-up tables; position 16 m + 4 q + r of row s holds state 16 m + 4 r + q
+    auto table = [&](double* __restrict__ dst, bool is_p) {
+      v2d* __restrict__ out = reinterpret_cast<v2d*>(dst);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int pos = i * 256 + tid;  // pair index: row s = pos / 32, positions 2 (pos % 32), +1
+        const int s = pos >> 5, at = (pos & 31) * 2;
+        const int mm = at >> 4, q = (at >> 2) & 3, r = at & 3;  // r in {0, 2}
+        const int st0 = 16 * mm + 4 * r + q, st1 = st0 + 4;
+        v2d v{Pl[st0 * kPld + s], Pl[st1 * kPld + s]};
+        if (s == S) v = is_p ? v2d{st0 < S ? 1.0 : 0.0, st1 < S ? 1.0 : 0.0} : v2d{0.0, 0.0};
+        out[pos] = v;
+      }
+    };
+    table(rec, true);
+    if (!want_gradient) continue;
+    // dP = P (r_c Q); deriv_mode 1: the site-model pass, r_c -> d r_c / d shape
+    const double drate = deriv_mode ? m[kGsCatRateDeriv + c] : rate;
+    if (sparse_dp) {
+      // Q of a codon model has at most ten entries per column: the product on the vector ALU, straight into the table
+      // positions, one fused multiply-add per nonzero entry in ascending row order -- bit for bit what the dense chain on
+      // the matrix pipe gives (its other terms are exact zeros), at a tenth of the arithmetic and none of it on the pipe
+      // this kernel and the traversal wait for
+      v2d* __restrict__ out = reinterpret_cast<v2d*>(rec + 4096);
+#pragma unroll 2
+      for (int i = 0; i < 8; i++) {
+        const int pos = i * 256 + tid;
+        const int s = pos >> 5, at = (pos & 31) * 2;
+        const int mm = at >> 4, q = (at >> 2) & 3, r = at & 3;
+        const int st0 = 16 * mm + 4 * r + q, st1 = st0 + 4;
+        double d0 = 0.0, d1 = 0.0;
+        if (s != S) {
+          const int cnt = nz_cnt[s];
+          const uint8_t* idx = nz_idx + s * kGsQnzMax;
+          const double* val = nz_val + s * kGsQnzMax;
+          for (int t = 0; t < cnt; t++) {
+            const int k = idx[t];
+            const double qv = val[t] * drate;
+            d0 = __builtin_fma(Pl[st0 * kPld + k], qv, d0);
+            d1 = __builtin_fma(Pl[st1 * kPld + k], qv, d1);
+          }
+        }
+        out[pos] = v2d{d0, d1};
+      }
+      continue;
+    }
+    // (a model whose Q is not that sparse: the second product on the matrix pipe, B = r_c Q from the model record)
+    v4d accd[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) accd[nb] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ks++) {
+      const double a = Pl[(16 * w + ii) * kPld + 4 * ks + kq];
+      const double* brow = m + kGsQ + (4 * ks + kq) * 64 + ii;
+#pragma unroll
+      for (int nb = 0; nb < 4; nb++)
+        accd[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[16 * nb] * drate, accd[nb], 0, 0, 0);
+    }
+    __syncthreads();
+    to_lds(accd);
+    __syncthreads();
+    table(rec + 4096, false);
   }
-#endif
-  v4d accd[4];
-  gemm([&](int ks) { return Pl[(16 * w + ii) * kPld + 4 * ks + kq]; }, m + kGsQ, drate, accd);
-  __syncthreads();
-  to_lds(accd);
-  __syncthreads();
-  table(rec + 4096, false);
 }
 
 void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const double* branch,
                       const int32_t* model_index, const double* gs_model, double* imgs, int want_gradient,
                       int deriv_mode, hipStream_t stream) {
-  const dim3 grid((d.node_count - 1) * d.category_count, chunk);
-  hipLaunchKernelGGL(gs_matrices_kernel, grid, dim3(256), 0, stream, d, S, tree0, branch, model_index, gs_model,
+  const int jobs = (d.node_count - 1) * d.category_count;
+  const dim3 grid((jobs + kGsMatJobs - 1) / kGsMatJobs, chunk);
+  const size_t lds = (64 * kPld + 16 * 2 * 64 * 2 + 64 + 64 * kGsQnzMax) * sizeof(double) + 64 * kGsQnzMax + 64;
+  // (72 KB of LDS: two workgroups per CU; the attribute is per device, and a process may drive several)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gs_matrices_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  hipLaunchKernelGGL(gs_matrices_kernel, grid, dim3(256), lds, stream, d, S, tree0, branch, model_index, gs_model,
                      imgs, want_gradient, deriv_mode);
 }
 
