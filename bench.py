@@ -293,10 +293,9 @@ def main():
 
     # host threads of a blocking call (checking and packing inputs, copying results out): the engine's default is
     # min(8, usable CPUs); with several ranks on one node the CPUs are shared among them
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    affinity, quota = usable_cpus()
-    cpus = max(1, min(affinity, int(quota + 0.5)) if quota else affinity)
-    host_threads = max(1, min(8, cpus // max(local_world, 1)))
+    from bito_amd.dist import host_threads_for_rank
+
+    host_threads = host_threads_for_rank()
     eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights,
                           device_id=local_rank, host_threads=host_threads)
     if not codon:

@@ -41,6 +41,27 @@ def _group_info():
     return dist, dist.get_rank(), dist.get_world_size()
 
 
+def host_threads_for_rank(cap: int = 8) -> int:
+    """``host_threads`` for this rank's ``bito_amd.Engine``: the CPUs this process may use (affinity mask, cgroup
+    quota) shared among the ranks of the node (``LOCAL_WORLD_SIZE``, as torch.distributed.run exports it), at most
+    ``cap``.  An engine's own default -- min(8, usable CPUs) -- assumes it has the node to itself."""
+    import os
+
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+            if quota != "max":
+                cpus = min(cpus, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    return max(1, min(cap, cpus // local_world))
+
+
 class ShardedEngine:
     """A rank's engine behind the whole collection's interface.
 

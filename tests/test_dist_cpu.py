@@ -129,3 +129,20 @@ def test_single_process_passthrough():
     res = bdist.sharded_evaluate(lambda lo, hi: {"log_likelihood": np.arange(lo, hi, dtype=float),
                                                   "branch_lengths": np.ones((hi - lo, 5))}, 6, 5)
     assert res["sum_log_likelihood"] == 15.0 and res["branch_lengths"].shape == (6, 5)
+
+
+def test_host_threads_are_shared_among_the_ranks_of_a_node(monkeypatch):
+    """An engine's helper threads (bito_amd_engine_spec.host_threads) divide the CPUs the process may use by the
+    ranks of the node, as torch.distributed.run exports them."""
+    import os
+
+    from bito_amd.dist import host_threads_for_rank
+
+    cpus = len(os.sched_getaffinity(0))
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    alone = host_threads_for_rank()
+    assert 1 <= alone <= min(8, cpus)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", str(4 * cpus))
+    assert host_threads_for_rank() == 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    assert host_threads_for_rank(cap=3) <= 3
