@@ -287,21 +287,12 @@ double MinOffDiagonalRate(const ModelSpec& m, const double* params, size_t T) {
   return lowest;
 }
 
-// Blocking calls, large chunks: alternatives to the direct PCIe paths (0 = never; scripts/gpu_host_threads_sweep.sh,
-// 6400 config-3 trees as chunks of 1024 + 5376: 4.19 ms per call, 4.12 with the inputs of the second chunk copied, no
-// change with the results copied -- the device writes host memory at about 20 GB/s either way).
-// BITO_AMD_RESULTS_COPY_MIN: chunks of that many trees and more have their final sums written to HBM and copied to
-// the pinned buffer by the copy engine, with the completion flag stored behind the copy, instead of the final-sums
-// kernel writing pinned host memory itself.  BITO_AMD_INPUTS_COPY_MIN: a later chunk of a call (a traversal is
-// running beside it) of that many trees and more gets its inputs by a copy command, which needs no CU and lands during
-// that traversal, instead of the set-up kernel reading the pinned buffer once it has found a CU.
-int ResultsCopyMin() {
-  static const int v = [] {
-    const char* s = std::getenv("BITO_AMD_RESULTS_COPY_MIN");
-    return s ? std::atoi(s) : 0;
-  }();
-  return v;
-}
+// Blocking calls: a later chunk of a call (a traversal is running beside it) of this many trees and more gets its
+// inputs by a copy command, which needs no CU and lands during that traversal, instead of the set-up kernel reading the
+// pinned buffer once it has found a CU (BITO_AMD_INPUTS_COPY_MIN; 0 = never.  scripts/gpu_host_threads_sweep.sh, 6400
+// config-3 trees as chunks of 1024 + 5376: 4.19 ms per call, 4.12 with the second chunk's inputs copied.  The same for
+// the results -- final sums into HBM, copied out with the completion flag stored behind the copy -- changed nothing:
+// the device writes host memory at about 20 GB/s by kernel and by copy engine alike.)
 int InputsCopyMin() {
   static const int v = [] {
     const char* s = std::getenv("BITO_AMD_INPUTS_COPY_MIN");
@@ -456,8 +447,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   if (!e->resident) return Fail(e, BITO_AMD_ERR_STATE, "no batch is resident: call WorkerUpload first");
   HIP_TRY(e, hipSetDevice(e->device));
   e->busy = true;
-  e->results_on_host = e->one_shot != 0 && !(ResultsCopyMin() > 0 && e->dims.tree_count >= ResultsCopyMin());
-  e->flag_behind_copy = e->one_shot != 0 && !e->results_on_host;
+  e->results_on_host = e->one_shot != 0;
   const BatchDims& d = e->dims;
   const int T = d.tree_count;
   const size_t NB = (size_t)d.node_count - 1;
@@ -1064,23 +1054,17 @@ int WorkerFetchResults(Worker* e, int want_gradient, int want_site) {
   }
   HIP_TRY(e, e->pin_out.Reserve((T * (N + 2)) * sizeof(double)));
   double* out = static_cast<double*>(e->pin_out.ptr);
-  hipStream_t stream = (e->flag_behind_copy && e->last_walk) ? e->last_walk : e->stream;
-  HIP_TRY(e, hipMemcpyAsync(out, e->cur_ll(), T * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(e, hipMemcpyAsync(out, e->cur_ll(), T * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   if (want_gradient)
-    HIP_TRY(e, hipMemcpyAsync(out + T, e->out_grad.ptr, T * N * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(e, hipMemcpyAsync(out + T, e->out_grad.ptr, T * N * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   if (want_site && e->site_ready)
-    HIP_TRY(e, hipMemcpyAsync(out + T + T * N, e->out_site.ptr, T * sizeof(double), hipMemcpyDeviceToHost, stream));
-  if (e->flag_behind_copy) {
-    LaunchSignal(static_cast<unsigned long long*>(e->pin_flag.ptr), ++e->ticket, stream);
-    HIP_TRY(e, hipGetLastError());
-    return BITO_AMD_OK;
-  }
+    HIP_TRY(e, hipMemcpyAsync(out + T + T * N, e->out_site.ptr, T * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipEventRecord(e->ev_results, e->stream));
   return BITO_AMD_OK;
 }
 
 bool WorkerResultsReady(Worker* e) {
-  if (e->results_on_host || e->flag_behind_copy)
+  if (e->results_on_host)
     return __atomic_load_n(static_cast<volatile uint64_t*>(e->pin_flag.ptr), __ATOMIC_ACQUIRE) == e->ticket;
   return hipEventQuery(e->ev_results) == hipSuccess;
 }
@@ -1088,7 +1072,7 @@ bool WorkerResultsReady(Worker* e) {
 int WorkerResults(Worker* e, const double** ll, const double** grad, const double** site) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
   HIP_TRY(e, hipSetDevice(e->device));
-  if (e->results_on_host || e->flag_behind_copy) {
+  if (e->results_on_host) {
     // poll the flag the chunk's last kernel stores; now and then ask the stream whether it has failed
     volatile uint64_t* flag = static_cast<volatile uint64_t*>(e->pin_flag.ptr);
     for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != e->ticket; spins++) {

@@ -120,7 +120,6 @@ struct Worker {
   DeviceBuffer<int32_t> done_counter;  // workgroups of the final-sums kernel that have finished (it leaves 0)
   bool signalled = false;        // the last pass's final-sums kernel stores the ticket itself (no kernel behind it)
   bool results_on_host = false;  // the resident pass's results are in pin_out, not in the device buffers
-  bool flag_behind_copy = false; // ... or a blocking call's chunk has them copied there, the completion flag stored behind the copies
   bool inputs_pending = false;      // the copy of the resident batch's inputs may still be in flight
   bool inputs_on_host = false;      // ... or has not been made: the next pass's set-up kernel reads pin_in and makes it
   // Blocking calls (engine.cpp): this worker walks ONE chunk of the call, so its set-up kernels have no earlier

@@ -1,6 +1,7 @@
 """Randomised parity sweep on the GPU box: random tree shapes, sizes, pattern counts, models, category counts,
 kernels, rescaling, rooted/unrooted, against the CPU checker.
-usage: python scripts/gpu_fuzz.py [cases] [seed] [kernel forced in every case, e.g. 5 = walk_pipe_kernel]"""
+usage: python scripts/gpu_fuzz.py [cases] [seed] [kernel forced in every case, e.g. 5 = walk_pipe_kernel]
+FUZZ_LARGE_TREES=1: trees of up to 333 taxa as well; FUZZ_CODON=1: every case the 61-state codon model"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -28,6 +29,8 @@ for case in range(cases):
     T = int(rng.choice([1, 2, 7, 33]))
     sub = str(rng.choice(["JC69", "HKY", "GTR", "GY94"], p=[0.3, 0.3, 0.3, 0.1]))
     site = str(rng.choice(["constant", "weibull+2", "weibull+3", "weibull+4", "weibull+6"]))
+    if os.environ.get("FUZZ_CODON"):  # (every case the 61-state model: the general-state kernels alone)
+        sub = "GY94"
     codon = sub == "GY94"
     if codon:  # the 61-state checker is a scalar port: keep these small
         n, P, T = min(n, 16), min(P, 65), min(T, 7)

@@ -234,14 +234,14 @@ def test_host_threads_check_and_pack_ranges_of_a_large_chunk():
     the trees would have met first, whichever thread finds it."""
     from oracle import oracle
 
-    w = workloads.ds1_gtr_weibull4(30)  # 3000 trees: chunks of 1024 + 1976 with helper threads
+    w = workloads.ds1_gtr_weibull4(31)  # 3100 trees: chunks of 1024 + 2076 with helper threads (the second chunk's inputs by a copy command)
     alone = bito_amd.Engine(_spec(w), w.patterns, w.weights, host_threads=1)
     many = bito_amd.Engine(_spec(w), w.patterns, w.weights, host_threads=6)
     a = alone.gradients(w.parent_ids, w.branch_lengths, w.params)
     b = many.gradients(w.parent_ids, w.branch_lengths, w.params)
     assert _close(a["log_likelihood"], b["log_likelihood"], 0.1 * LL_ATOL, 0.1 * LL_RTOL)
     assert _close(a["branch_lengths"], b["branch_lengths"], 0.1 * GRAD_ATOL, 0.1 * GRAD_RTOL)
-    sel = np.r_[0:6, 1020:1030, 1350:1356, 2994:3000]  # (chunk and range boundaries among them)
+    sel = np.r_[0:6, 1020:1030, 1366:1374, 3094:3100]  # (chunk and range boundaries among them)
     cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
     ref = cpu.gradients(w.parent_ids[sel], w.branch_lengths[sel], w.params[sel])
     assert _close(b["log_likelihood"][sel], ref["log_likelihood"], LL_ATOL, LL_RTOL)
