@@ -755,16 +755,13 @@ struct GsImagePipe {
 
   // out = (image j) x; leaves image j+1 in the other buffer
   __device__ __forceinline__ void MatVec(const GsPlv& x, GsPlv& out) {
-    GsPlv xx = x;
 #if GS_SCHED_BARRIER
     __builtin_amdgcn_sched_barrier(0);  // keep the caller's loads from being hoisted across the contraction
 #endif
 #if GS_ASM_FETCH
-    {  // x complete before the fetch is issued (the compiler's wait for x would otherwise count the fetch's loads as well)
-      v4d x0 = x.b[0], x1 = x.b[1], x2 = x.b[2], x3 = x.b[3];
-      asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-      xx.b[0] = x0, xx.b[1] = x1, xx.b[2] = x2, xx.b[3] = x3;
-    }
+    // x complete before the fetch is issued (the compiler's wait for x would otherwise count the fetch's loads as well);
+    // an empty statement that only READS x: operands that were also written cost sixteen register moves per call
+    asm volatile("" : : "v"(x.b[0]), "v"(x.b[1]), "v"(x.b[2]), "v"(x.b[3]));
 #endif
     Fetch(__builtin_amdgcn_readfirstlane(jobs[j + 1]), (j + 1) & 1);
     const v2d* p = reinterpret_cast<const v2d*>(lds + (j & 1) * 4096) + lane;
@@ -780,7 +777,7 @@ struct GsImagePipe {
 #pragma unroll
         for (int mb = 0; mb < 4; mb++) an[mb] = p[(mb * 8 + k2 + 1) * 64];
       }
-      const double b0 = xx.b[k2 >> 1][(k2 & 1) * 2], b1 = xx.b[k2 >> 1][(k2 & 1) * 2 + 1];
+      const double b0 = x.b[k2 >> 1][(k2 & 1) * 2], b1 = x.b[k2 >> 1][(k2 & 1) * 2 + 1];
 #pragma unroll
       for (int mb = 0; mb < 4; mb++) acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb].x, b0, acc[mb], 0, 0, 0);
 #pragma unroll
@@ -875,9 +872,12 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       if (cf < n) {
         GsTip(rec(cf, c, 0), sf, kq, a);
       } else {
-        if (chain && cf == node - 1) x = a;  // (always so when ids are in post-order)
-        else GsLoad(slot(cf, c), lane, x);
-        pipe.MatVec(x, a);
+        if (chain && cf == node - 1) {  // (always so when ids are in post-order)
+          pipe.MatVec(a, a);  // (the contraction has read its operand before it hands out its result: no copy of a)
+        } else {
+          GsLoad(slot(cf, c), lane, x);
+          pipe.MatVec(x, a);
+        }
         if (GRAD && active) GsStore(mslot(cf, c), lane, a);
       }
       if (cs < n) {
@@ -970,8 +970,8 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
   if (GRAD) {
     double* __restrict__ grow = part_grad + ((size_t)tree * tiles + tile) * N;
     if (lane == 0 && active) grow[N - 1] = 0.0;
-    GsPlv y;              // pre-order partial of the child processed last; survives into the next iteration
-    bool have_u = false;  // y is node's own pre-order partial (wave-uniform)
+    GsPlv u;              // the node's pre-order partial; the chained child's is formed in place and survives into the next iteration
+    bool have_u = false;  // u is node's own pre-order partial already (wave-uniform)
     for (int node = N - 1; node >= n; --node) {
       const int c0 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2]);
       const int c1 = __builtin_amdgcn_readfirstlane(ch[(node - n) * 2 + 1]);
@@ -984,14 +984,9 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       // walk_hbm_kernel)
       const double step_inv = RESCALE ? *inv_at(node) : 1.0;
       for (int c = 0; c < C; c++) {
-        GsPlv u, af, al;
-        if (node == N - 1) {
-          load_pi(u);
-        } else if (have_u) {
-          u = y;
-        } else {
-          GsLoad(slot(node, c), lane, u);
-        }
+        GsPlv af, al;
+        if (node == N - 1) load_pi(u);
+        else if (!have_u) GsLoad(slot(node, c), lane, u);
         if (cf < n) GsTip(rec(cf, c, 0), sf, kq, af);
         else GsLoad(mslot(cf, c), lane, af);
         if (cl < n) GsTip(rec(cl, c, 0), sl, kq, al);
@@ -1032,6 +1027,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           GsTip(rec(cf, c, 1), sf, kq, x);
           numf += wc * GsDot(af, x);
         } else {
+          GsPlv y;
           pipe.MatVec(af, y);
           if (RESCALE) {
 #pragma unroll
@@ -1044,17 +1040,17 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           GsTip(rec(cl, c, 1), sl, kq, x);
           numl += wc * GsDot(al, x);
         } else {
-          pipe.MatVec(al, y);
+          pipe.MatVec(al, u);  // (u has had its last use: the child's partial takes its place)
           if (RESCALE) {
 #pragma unroll
-            for (int m = 0; m < 4; m++) y.b[m] *= step_inv;
+            for (int m = 0; m < 4; m++) u.b[m] *= step_inv;
           }
           // the chained child's pre-order partial goes to memory only if its own step will not take
           // it from registers (it always will with one category; the store is then not needed)
-          if (active && !(chain && cl == node - 1)) GsStore(slot(cl, c), lane, y);
+          if (active && !(chain && cl == node - 1)) GsStore(slot(cl, c), lane, u);
         }
       }
-      have_u = chain && cl >= n && cl == node - 1;  // the next node's own pre-order partial is in y
+      have_u = chain && cl >= n && cl == node - 1;  // the next node's own pre-order partial is in u
       // den is a pattern's sum (its four lanes), the numerators stay per lane: sum over lanes of num_lane . w_p / den_p is
       // an edge's derivative.  Two edges' sums at once on the vector ALU (the first ends up in lane 31, the second in
       // lane 63): the tip children's edges, then the node's own
