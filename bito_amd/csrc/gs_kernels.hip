@@ -647,31 +647,44 @@ void LaunchGsSchedule(const BatchDims& d, const DeviceBatch& b, hipStream_t stre
 #ifndef GS_ARENA_NT
 #define GS_ARENA_NT 0
 #endif
-__device__ __forceinline__ void GsLoad(const double* __restrict__ slot, int lane, GsPlv& x) {
+// Stored vectors go through buffer instructions: the slot's address is wave-uniform (scalar registers: a descriptor
+// built by scalar instructions), a lane adds ONE 32-bit offset that never changes (lane_bytes = 32 lane) and the
+// instruction its constant -- no 64-bit per-lane address arithmetic on the vector ALU, which a wave gets one issue
+// slot of in ~58 cycles while its SIMD's other wave issues FP64 matrix instructions (77 v_lshl_add_u64 in the kernel
+// before).
+typedef unsigned GsUInt4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t GsRsrc(const double* slot) {
+  // (the address is wave-uniform by construction; said explicitly, or a descriptor the compiler happened to form on
+  // the vector ALU costs a four-register readfirstlane loop around every access)
+  const uintptr_t a = reinterpret_cast<uintptr_t>(slot);
+  const uintptr_t u = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a) |
+                      ((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<double*>(u), 0, 8192, 0x00020000);
+}
+__device__ __forceinline__ void GsLoad(const double* __restrict__ slot, unsigned lane_bytes, GsPlv& x) {
 #if GS_EXP_NOLOAD
   for (int m = 0; m < 4; m++) x.b[m] = v4d{1.0, 0.5, 0.25, 0.125};
   return;
 #endif
+  const __amdgpu_buffer_rsrc_t r = GsRsrc(slot);
 #pragma unroll
   for (int m = 0; m < 4; m++) {
-#if GS_ARENA_NT
-    x.b[m] = __builtin_nontemporal_load(reinterpret_cast<const v4d*>(slot + m * 256 + lane * 4));
-#else
-    x.b[m] = *reinterpret_cast<const v4d*>(slot + m * 256 + lane * 4);
-#endif
+    const GsUInt4 lo = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes + (m & 1) * 2048, (m >> 1) * 4096, GS_ARENA_NT ? 2 : 0);
+    const GsUInt4 hi = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes + (m & 1) * 2048 + 16, (m >> 1) * 4096, GS_ARENA_NT ? 2 : 0);
+    const v2d a = __builtin_bit_cast(v2d, lo), b = __builtin_bit_cast(v2d, hi);
+    x.b[m] = v4d{a.x, a.y, b.x, b.y};
   }
 }
-__device__ __forceinline__ void GsStore(double* __restrict__ slot, int lane, const GsPlv& x) {
+__device__ __forceinline__ void GsStore(double* __restrict__ slot, unsigned lane_bytes, const GsPlv& x) {
 #if GS_EXP_NOSTORE
   return;
 #endif
+  const __amdgpu_buffer_rsrc_t r = GsRsrc(slot);
 #pragma unroll
   for (int m = 0; m < 4; m++) {
-#if GS_ARENA_NT
-    __builtin_nontemporal_store(x.b[m], reinterpret_cast<v4d*>(slot + m * 256 + lane * 4));
-#else
-    *reinterpret_cast<v4d*>(slot + m * 256 + lane * 4) = x.b[m];
-#endif
+    const v2d a{x.b[m][0], x.b[m][1]}, b{x.b[m][2], x.b[m][3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(GsUInt4, a), r, lane_bytes + (m & 1) * 2048, (m >> 1) * 4096, GS_ARENA_NT ? 2 : 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(GsUInt4, b), r, lane_bytes + (m & 1) * 2048 + 16, (m >> 1) * 4096, GS_ARENA_NT ? 2 : 0);
   }
 }
 // tip child: row `state` of the transposed table
@@ -711,24 +724,28 @@ struct GsImagePipe {
   // (vmcnt(0) in front of its barrier).
   __device__ __forceinline__ void Fetch(int entry, int buffer) {
 #if GS_ASM_FETCH
-    static_assert(GS_WG_WAVES == 4 || GS_WG_WAVES == 8, "eight loads of 4 KB or four of 8 KB per workgroup");
+    // wave w moves bytes [w * 32 KB / waves, ...) of the image, 1 KB per instruction; the instruction's offset field
+    // (0 .. 3072) counts for the global AND the LDS address, so four instructions share a base: no vector instruction
+    // in a fetch (seven additions before)
+    static_assert(GS_WG_WAVES == 4 || GS_WG_WAVES == 8, "eight or four loads of 1 KB per wave");
     const double* src = Image(entry);
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)src);
     uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)src >> 32));
-    uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds + buffer * 4096 + (tid & ~63) * 2));
-    uint32_t v = tid * 16;
+    const uint32_t wave_bytes = (tid >> 6) * (32768 / GS_WG_WAVES);
+    uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds + buffer * 4096) + wave_bytes);
+    const uint32_t v = wave_bytes + (tid & 63) * 16, v2 = v + 4096;  // (loop invariants: two registers for the whole walk)
+#define GS_FETCH_4(V) "global_load_lds_dwordx4 %[" V "], %[s]\n global_load_lds_dwordx4 %[" V "], %[s] offset:1024\n" \
+                      "global_load_lds_dwordx4 %[" V "], %[s] offset:2048\n global_load_lds_dwordx4 %[" V "], %[s] offset:3072\n"
 #if GS_WG_WAVES == 4
-#define GS_FETCH_NEXT "v_add_u32 %[v], 0x1000, %[v]\n s_add_u32 m0, m0, 0x1000\n s_nop 0\n global_load_lds_dwordx4 %[v], %[s]\n"
-#define GS_FETCH_REST GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT
+#define GS_FETCH_REST "s_add_u32 m0, m0, 0x1000\n s_nop 0\n" GS_FETCH_4("v2")
 #else
-#define GS_FETCH_NEXT "v_add_u32 %[v], 0x2000, %[v]\n s_add_u32 m0, m0, 0x2000\n s_nop 0\n global_load_lds_dwordx4 %[v], %[s]\n"
-#define GS_FETCH_REST GS_FETCH_NEXT GS_FETCH_NEXT GS_FETCH_NEXT
+#define GS_FETCH_REST
 #endif
-    asm volatile("s_mov_b32 m0, %[m]\n s_nop 0\n global_load_lds_dwordx4 %[v], %[s]\n" GS_FETCH_REST
-                 : [v] "+v"(v)
-                 : [m] "s"(m), [s] "s"(((uint64_t)hi << 32) | lo)
+    asm volatile("s_mov_b32 m0, %[m]\n s_nop 0\n" GS_FETCH_4("v") GS_FETCH_REST
+                 :
+                 : [v] "v"(v), [v2] "v"(v2), [m] "s"(m), [s] "s"(((uint64_t)hi << 32) | lo)
                  : "memory", "scc");  // (M0: the compiler has no other use for it in this kernel)
-#undef GS_FETCH_NEXT
+#undef GS_FETCH_4
 #undef GS_FETCH_REST
 #else
     const double* src = Image(entry) + tid * 2;
@@ -806,7 +823,9 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
                double* __restrict__ part_grad) {
   extern __shared__ double lds[];  // two image buffers
   const int n = d.taxon_count, N = d.node_count, NI = n - 1, C = d.category_count, Ppad = d.pattern_stride;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, pn = lane & 15;
+  // (the wave's number as a scalar: everything derived from it -- its tile, its vectors' addresses -- is then scalar
+  // arithmetic, and the vector loads and stores take a scalar base + one constant lane offset)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, kq = lane >> 4, pn = lane & 15;
   // a wave past the last tile repeats the last tile's work (it must take part in the image
   // pipeline) and stores nothing
   // Workgroups are dealt to the 8 XCDs round-robin by linear id: id % 8 picks the XCD.  All tile groups
@@ -815,6 +834,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
   const int tree_local = (int)(blockIdx.x / 8 / groups) * 8 + (int)(blockIdx.x % 8);
   const int group = (int)(blockIdx.x / 8) % groups;
   if (tree_local >= chunk) return;
+  const unsigned lane_bytes = lane * 32;  // a lane's byte offset into a stored vector (GsLoad / GsStore)
   const bool active = group * GS_WG_WAVES + wave < tiles;
   const int tile = active ? group * GS_WG_WAVES + wave : tiles - 1;
   const int tree = tree0 + tree_local;
@@ -867,7 +887,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
 #if GS_SIBLING_EARLY
       // (the sibling's partial is requested before the first child's contraction, not behind it)
       GsPlv x2;
-      if (cs >= n && cf >= n) GsLoad(slot(cs, c), lane, x2);
+      if (cs >= n && cf >= n) GsLoad(slot(cs, c), lane_bytes, x2);
 #endif
       if (cf < n) {
         GsTip(rec(cf, c, 0), sf, kq, a);
@@ -875,22 +895,22 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
         if (chain && cf == node - 1) {  // (always so when ids are in post-order)
           pipe.MatVec(a, a);  // (the contraction has read its operand before it hands out its result: no copy of a)
         } else {
-          GsLoad(slot(cf, c), lane, x);
+          GsLoad(slot(cf, c), lane_bytes, x);
           pipe.MatVec(x, a);
         }
-        if (GRAD && active) GsStore(mslot(cf, c), lane, a);
+        if (GRAD && active) GsStore(mslot(cf, c), lane_bytes, a);
       }
       if (cs < n) {
         GsTip(rec(cs, c, 0), ss, kq, bb);
       } else {
 #if GS_SIBLING_EARLY
         if (cf >= n) x = x2;
-        else GsLoad(slot(cs, c), lane, x);
+        else GsLoad(slot(cs, c), lane_bytes, x);
 #else
-        GsLoad(slot(cs, c), lane, x);
+        GsLoad(slot(cs, c), lane_bytes, x);
 #endif
         pipe.MatVec(x, bb);
-        if (GRAD && active) GsStore(mslot(cs, c), lane, bb);
+        if (GRAD && active) GsStore(mslot(cs, c), lane_bytes, bb);
       }
 #pragma unroll
       for (int m = 0; m < 4; m++) a.b[m] *= bb.b[m];
@@ -923,7 +943,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       } else if (active && ((GRAD && !GS_OWN_EDGE) || !chain || node + 1 >= N || (ch[(node + 1 - n) * 2] != node && ch[(node + 1 - n) * 2 + 1] != node))) {
         // (no copy in memory of a vector that is consumed from registers by the next node: the pre-order pass does
         // not read post-order partials either, it rebuilds them from the children's messages)
-        GsStore(slot(node, c), lane, a);
+        GsStore(slot(node, c), lane_bytes, a);
       }
     }
     if (RESCALE && C > 1) {
@@ -938,10 +958,10 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
         log_scale += log(mx);
         for (int c = 0; c < C; c++) {
           GsPlv v;
-          GsLoad(slot(node, c), lane, v);
+          GsLoad(slot(node, c), lane_bytes, v);
 #pragma unroll
           for (int m = 0; m < 4; m++) v.b[m] *= inv;
-          if (active) GsStore(slot(node, c), lane, v);
+          if (active) GsStore(slot(node, c), lane_bytes, v);
         }
       }
       if (GRAD && active && kq == 0) *inv_at(node) = inv;
@@ -986,11 +1006,11 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       for (int c = 0; c < C; c++) {
         GsPlv af, al;
         if (node == N - 1) load_pi(u);
-        else if (!have_u) GsLoad(slot(node, c), lane, u);
+        else if (!have_u) GsLoad(slot(node, c), lane_bytes, u);
         if (cf < n) GsTip(rec(cf, c, 0), sf, kq, af);
-        else GsLoad(mslot(cf, c), lane, af);
+        else GsLoad(mslot(cf, c), lane_bytes, af);
         if (cl < n) GsTip(rec(cl, c, 0), sl, kq, al);
-        else GsLoad(mslot(cl, c), lane, al);
+        else GsLoad(mslot(cl, c), lane_bytes, al);
         const double wc = model[kGsCatWeight + c];
         const double rc = model[(deriv_mode ? kGsCatRateDeriv : kGsCatRate) + c];  // site-model pass: d r_c / d shape
         if (node != N - 1) {
@@ -1033,7 +1053,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
 #pragma unroll
             for (int m = 0; m < 4; m++) y.b[m] *= step_inv;
           }
-          if (active) GsStore(slot(cf, c), lane, y);
+          if (active) GsStore(slot(cf, c), lane_bytes, y);
         }
         if (cl < n) {
           GsPlv x;
@@ -1047,7 +1067,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           }
           // the chained child's pre-order partial goes to memory only if its own step will not take
           // it from registers (it always will with one category; the store is then not needed)
-          if (active && !(chain && cl == node - 1)) GsStore(slot(cl, c), lane, u);
+          if (active && !(chain && cl == node - 1)) GsStore(slot(cl, c), lane_bytes, u);
         }
       }
       have_u = chain && cl >= n && cl == node - 1;  // the next node's own pre-order partial is in u
@@ -1091,13 +1111,13 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
         } else if (have_u) {
           u = y;
         } else {
-          GsLoad(slot(node, c), lane, u);
+          GsLoad(slot(node, c), lane_bytes, u);
         }
         // child messages: a_f -> w_l = u . a_f (what the LAST child sees), a_l -> w_f = u . a_l
         if (cf < n) GsTip(rec(cf, c, 0), sf, kq, wl);
-        else GsLoad(mslot(cf, c), lane, wl);
+        else GsLoad(mslot(cf, c), lane_bytes, wl);
         if (cl < n) GsTip(rec(cl, c, 0), sl, kq, wf);
-        else GsLoad(mslot(cl, c), lane, wf);
+        else GsLoad(mslot(cl, c), lane_bytes, wf);
         const double wc = model[kGsCatWeight + c];
         {
           double sden = 0.0;
@@ -1126,33 +1146,33 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           numf += wc * GsDot(wf, x);
         } else {
 #if GS_X_EARLY
-          GsLoad(slot(cf, c), lane, x);  // (x is read before q takes its place; in flight behind the two contractions)
+          GsLoad(slot(cf, c), lane_bytes, x);  // (x is read before q takes its place; in flight behind the two contractions)
           pipe.MatVec(wf, y);
           pipe.MatVec(y, wf);
 #else
           pipe.MatVec(wf, y);
           pipe.MatVec(y, wf);
-          GsLoad(slot(cf, c), lane, x);  // (x is read before q takes its place)
+          GsLoad(slot(cf, c), lane_bytes, x);  // (x is read before q takes its place)
 #endif
           numf += wc * rc * GsDot(wf, x);
           if (RESCALE) {
 #pragma unroll
             for (int m = 0; m < 4; m++) y.b[m] *= step_inv;
           }
-          if (active) GsStore(slot(cf, c), lane, y);
+          if (active) GsStore(slot(cf, c), lane_bytes, y);
         }
         if (cl < n) {
           GsTip(rec(cl, c, 1), sl, kq, x);
           numl += wc * GsDot(wl, x);
         } else {
 #if GS_X_EARLY
-          GsLoad(slot(cl, c), lane, x);
+          GsLoad(slot(cl, c), lane_bytes, x);
           pipe.MatVec(wl, y);
           pipe.MatVec(y, wl);
 #else
           pipe.MatVec(wl, y);
           pipe.MatVec(y, wl);
-          GsLoad(slot(cl, c), lane, x);
+          GsLoad(slot(cl, c), lane_bytes, x);
 #endif
           numl += wc * rc * GsDot(wl, x);
           if (RESCALE) {
@@ -1161,7 +1181,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
           }
           // the chained child's pre-order partial goes to memory only if its own step will not take
           // it from registers (it always will with one category; the store is then not needed)
-          if (active && !(chain && cl == node - 1)) GsStore(slot(cl, c), lane, y);
+          if (active && !(chain && cl == node - 1)) GsStore(slot(cl, c), lane_bytes, y);
         }
       }
       have_u = chain && cl >= n && cl == node - 1;  // the next node's own pre-order partial is in y
