@@ -244,6 +244,8 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
     stamp("copied out", k);
     return BITO_AMD_OK;
   };
+  // a call that will hand ranges to the helper threads wakes them now: they are up by the time the first chunk is staged
+  if (e->host_threads != 1 && tree_count >= e->par_min_trees) Pool(e)->Arm();
   std::vector<char> slot_busy(e->devices.size(), 0);
   for (size_t k = 0; k < e->shards.size(); k++) {
     const Shard& s = e->shards[k];

@@ -990,6 +990,7 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
   if (GRAD) {
     double* __restrict__ grow = part_grad + ((size_t)tree * tiles + tile) * N;
     if (lane == 0 && active) grow[N - 1] = 0.0;
+    const double site_scale = weight / site;
     GsPlv u;              // the node's pre-order partial; the chained child's is formed in place and survives into the next iteration
     bool have_u = false;  // u is node's own pre-order partial already (wave-uniform)
     for (int node = N - 1; node >= n; --node) {
@@ -1023,11 +1024,11 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
             for (int r = 0; r < 4; r++) {
               const double x = af.b[m][r] * al.b[m][r];
               so += t.b[m][r] * x;
-              sd += u.b[m][r] * x;
+              if (RESCALE) sd += u.b[m][r] * x;
             }
           numo += wc * rc * so;
           den += wc * sd;
-        } else {
+        } else if (RESCALE) {
           double sd = 0.0;
 #pragma unroll
           for (int m = 0; m < 4; m++)
@@ -1074,8 +1075,10 @@ gs_walk_kernel(BatchDims d, int S, int tree0, int chunk, int tiles, int sched_st
       // den is a pattern's sum (its four lanes), the numerators stay per lane: sum over lanes of num_lane . w_p / den_p is
       // an edge's derivative.  Two edges' sums at once on the vector ALU (the first ends up in lane 31, the second in
       // lane 63): the tip children's edges, then the node's own
-      den = GsPatternSum(den);
-      const double scale = weight / den;
+      // (Without rescaling u . a_f . a_l is the pattern's likelihood at EVERY node -- the post-order pass left it in
+      // `site` --, so the walk takes weight / site, once, and forms no sum and no quotient per step.  With rescaling the
+      // steps' sums differ by the scale factors between the node and the root.)
+      const double scale = RESCALE ? weight / GsPatternSum(den) : site_scale;
       if (cf < n || cl < n) {
         const double g = PairSum(numf * scale, numl * scale);
         const int child = lane < 32 ? cf : cl;

@@ -6,9 +6,11 @@
 // independent per tree, so a large chunk is cut into ranges, one per thread.  All HIP calls stay on the calling
 // thread.
 //
-// The helpers sleep on a condition variable between calls.  Arm() wakes them ahead of a job whose start time
-// matters (the copy-out of a call's last chunk): armed helpers poll for the job for a few milliseconds before they
-// go back to sleep, so the job starts without a wake-up on its critical path.
+// The helpers sleep on a condition variable between bursts of calls.  A wake-up costs 30 to 150 us depending on the
+// host, so it is kept off a call's critical path: Arm() wakes the helpers ahead of a job whose start time matters (at
+// the start of a large call, while the caller stages the first chunk itself; ahead of the copy-out of the last chunk)
+// and they poll for it for a few milliseconds; after a job they keep polling for 1.5 ms -- the next job of the call,
+// or the next call of a loop, finds them awake.
 #pragma once
 
 #include <atomic>
@@ -84,27 +86,32 @@ class HostPool {
   void Loop(int part) {
     unsigned seen = 0, seen_arm = 0;
     for (;;) {
-      {
+      // poll for the next job while armed (by Arm(), or by the job just done: calls come in bursts) ...
+      while (generation_.load(std::memory_order_acquire) == seen &&
+             Now() <= armed_until_.load(std::memory_order_relaxed))
+        Pause();
+      // ... then sleep until there is one, or somebody arms the pool
+      if (generation_.load(std::memory_order_acquire) == seen) {
         std::unique_lock<std::mutex> lock(mu_);
         cv_.wait(lock, [&] {
           return generation_.load(std::memory_order_acquire) != seen ||
                  arm_generation_.load(std::memory_order_acquire) != seen_arm;
         });
         seen_arm = arm_generation_.load(std::memory_order_acquire);
+        if (generation_.load(std::memory_order_acquire) == seen) continue;  // (armed: back to polling)
       }
-      // armed: poll for the job without the lock
-      while (generation_.load(std::memory_order_acquire) == seen) {
-        Pause();
-        if (Now() > armed_until_.load(std::memory_order_relaxed)) break;
-      }
-      if (generation_.load(std::memory_order_acquire) == seen) continue;  // (the linger ran out)
       seen = generation_.load(std::memory_order_acquire);
       if (stop_) return;
       const std::function<void(int)>* job = job_;
       if (job) (*job)(part);
+      // the next job of this call, or the next call, is probably not far: stay awake for a while
+      const long long until = Now() + kLingerAfterJobNs;
+      if (armed_until_.load(std::memory_order_relaxed) < until) armed_until_.store(until, std::memory_order_relaxed);
       pending_.fetch_sub(1, std::memory_order_release);
     }
   }
+
+  static constexpr long long kLingerAfterJobNs = 1500000;  // 1.5 ms
 
   std::vector<std::thread> threads_;
   std::mutex mu_;
