@@ -244,8 +244,14 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
     stamp("copied out", k);
     return BITO_AMD_OK;
   };
-  // a call that will hand ranges to the helper threads wakes them now: they are up by the time the first chunk is staged
-  if (e->host_threads != 1 && tree_count >= e->par_min_trees) Pool(e)->Arm();
+  // a call that will hand ranges to the helper threads wakes them now: they are up by the time the first chunk is staged.
+  // (In a loop of calls they still poll from the call before: then smaller chunks -- the first one of a large call --
+  // are worth cutting up as well.)
+  int par_min_trees = e->par_min_trees;
+  if (e->host_threads != 1 && tree_count >= e->par_min_trees) {
+    if (Pool(e)->Hot()) par_min_trees = std::min(par_min_trees, 256);
+    Pool(e)->Arm();
+  }
   std::vector<char> slot_busy(e->devices.size(), 0);
   for (size_t k = 0; k < e->shards.size(); k++) {
     const Shard& s = e->shards[k];
@@ -274,7 +280,7 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
                               pc > 0 ? params + (size_t)s.t0 * pc : nullptr, /*wait=*/0);
     if (!rc) {
       // the host's share of the chunk -- checks, one pack into pinned memory -- in ranges over the host threads
-      if (e->host_threads != 1 && s.count >= e->par_min_trees) {
+      if (e->host_threads != 1 && s.count >= par_min_trees) {
         std::vector<StagePart> parts((size_t)Pool(e)->parts());
         ParallelRanges(e, (size_t)s.count, [&](int part, size_t a, size_t b) { WorkerStageFill(w, (int32_t)a, (int32_t)b, &parts[(size_t)part]); });
         rc = WorkerStageEnd(w, parts.data(), (int)parts.size());

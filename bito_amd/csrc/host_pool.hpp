@@ -42,6 +42,9 @@ class HostPool {
 
   int parts() const { return (int)threads_.size() + 1; }
 
+  // the helpers are polling right now (a job or an Arm() less than the linger ago): a job starts at once
+  bool Hot() const { return !threads_.empty() && Now() <= armed_until_.load(std::memory_order_relaxed); }
+
   // fn(part) for part = 0 .. parts() - 1, part 0 on the calling thread; returns when every part is done
   void Run(const std::function<void(int)>& fn) {
     if (threads_.empty()) {
