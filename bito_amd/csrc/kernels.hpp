@@ -65,6 +65,8 @@ struct DeviceBatch {
   int32_t* sched;             // [T][2][n+1][16]           step descriptors (LDS kernel); step records in visiting order (HBM-arena walk)
   const uint32_t* pipe_masks; // [tiles][n][waves][16/C]   packed tip masks per pattern tile (walk_pipe_kernel)
   int32_t* pipe_queue;        // [2] next unit of work, workgroups that have left (walk_pipe_kernel; zero between launches)
+  uint8_t* pipe_done;         // [T] or null: walk_pipe_kernel's whole-tree units write their tree's final results themselves
+                              //     (out_ll, out_grad) and set the tree's flag; the final-sums kernel leaves those trees alone
   // traversal scratch + outputs
   double* arena;              // [chunk][n-1][C][4][Ppad]
   double* scale_arena;        // [chunk][n-1][Ppad]  post-order 1/scale factors (rescaled gradients)
@@ -278,7 +280,7 @@ struct ReduceDone {
   int* counter = nullptr;
 };
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
-                  hipStream_t stream, int grad_rows = 0, ReduceDone done = ReduceDone{});
+                  hipStream_t stream, int grad_rows = 0, ReduceDone done = ReduceDone{}, const uint8_t* skip = nullptr);
 // one thread stores `value` to `flag` (pinned host memory) behind everything enqueued on the stream so far
 void LaunchSignal(unsigned long long* flag, unsigned long long value, hipStream_t stream);
 

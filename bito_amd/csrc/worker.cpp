@@ -354,6 +354,7 @@ DeviceBatch MakeBatch(Worker* e, int set = 0) {
   b.sched = (set == 0 ? e->sched : set == 1 ? e->sched2 : e->sched3).ptr;
   b.pipe_masks = reinterpret_cast<const uint32_t*>(e->pipe_masks.ptr);
   b.pipe_queue = e->pipe_queue.ptr;
+  b.pipe_done = nullptr;  // (RunResident sets it for walk_pipe_kernel passes)
   b.arena = e->arena.ptr;
   b.scale_arena = e->scale_arena.ptr;
   b.part_ll = e->part_ll.ptr;
@@ -598,7 +599,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
         build_masks_a = true;
       }
     }
-    const DeviceBatch b = MakeBatch(e, set);
+    DeviceBatch b = MakeBatch(e, set);
     hipStream_t prep = SetupStream(e);
     const hipStream_t walk = WalkStream(e);
     const bool in_line = prep == walk;  // set-up in front of the traversal, on its stream
@@ -642,6 +643,15 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     if (use_tree) LaunchWalkTree(d, b, tplan, want_gradient, walk);
     else if (use_pipe) {
       const int site = want_site && want_gradient && deriv_mode == 0;
+      // whole-tree units write their trees' results themselves (BITO_AMD_PIPE_DIRECT=0: all through the final-sums kernel)
+      static const bool direct = [] {
+        const char* v = std::getenv("BITO_AMD_PIPE_DIRECT");
+        return v == nullptr || std::atoi(v) != 0;
+      }();
+      if (direct && !site) {
+        HIP_TRY(e, e->pipe_done.Reserve((size_t)T));
+        b.pipe_done = e->pipe_done.ptr;
+      }
       if (two_classes) {
         LaunchWalkPipe(d, b, split.plan_a, want_gradient, site, deriv_mode, walk,
                        PipeClass{split.count_a, e->pipe_order.ptr, reinterpret_cast<const uint32_t*>(e->pipe_masks_a.ptr), grad_rows, e->reserve_cus});
@@ -656,7 +666,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     e->kernel_name = use_tree ? "walk_tree_kernel" : (use_pipe ? "walk_pipe_kernel" : "walk_lds_kernel");
     e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
     // (walk_pipe_kernel's partial log-likelihoods are per run of tiles as well)
-    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, walk, grad_rows, DoneByReduce(e));
+    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, walk, grad_rows, DoneByReduce(e), use_pipe ? b.pipe_done : nullptr);
     if (!bare) HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], walk));
     e->last_pass_done = bare ? nullptr : e->ev_walk_done[set];
     HIP_TRY(e, hipGetLastError());

@@ -145,6 +145,7 @@ struct Worker {
   DeviceBuffer<int32_t> pipe_masks;  // packed tip masks per pattern tile (walk_pipe_kernel): a function of the alignment and the plan
   long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
   DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
+  DeviceBuffer<uint8_t> pipe_done;   // per tree: its whole-tree unit wrote the final results itself (kernels.hpp: DeviceBatch::pipe_done)
   // walk_pipe_kernel in two launches: the trees of the resident batch that keep few enough vectors for four
   // pattern groups per wave (class A), and the others (class B) -- one tree with few cherries would otherwise
   // halve the groups of the whole batch
@@ -195,7 +196,7 @@ struct Worker {
     for (auto& r : out_ll_ring) r.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
     tt_out.Free(); tt_aux.Free();
-    children2.Free(); sched2.Free(); pipe_masks.Free(); pipe_queue.Free(); pipe_order.Free(); pipe_masks_a.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
+    children2.Free(); sched2.Free(); pipe_masks.Free(); pipe_queue.Free(); pipe_done.Free(); pipe_order.Free(); pipe_masks_a.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
     children3.Free(); sched3.Free(); branch3.Free(); images3.Free(); model3.Free();
     for (int i = 0; i < kSets; i++) {
       if (ev_prep_done[i]) (void)hipEventDestroy(ev_prep_done[i]);
