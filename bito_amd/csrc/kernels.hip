@@ -657,12 +657,12 @@ const char* WalkHbmKernelName(int category_count, int, int) {
 
 __global__ void __launch_bounds__(256)
 reduce_tiles_kernel(BatchDims d, DeviceBatch b, int tiles, int grad_rows, int want_gradient, ReduceDone done,
-                    const uint8_t* __restrict__ skip) {
+                    const uint8_t* __restrict__ skip, int first_tree) {
   const int N = d.node_count;
   const int per_tree = want_gradient ? N + 1 : 1;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < (size_t)d.tree_count * per_tree) {
-    const int t = (int)(idx / per_tree), e = (int)(idx % per_tree);
+  if (idx < (size_t)(d.tree_count - first_tree) * per_tree) {
+    const int t = first_tree + (int)(idx / per_tree), e = (int)(idx % per_tree);
     if (skip != nullptr && skip[t]) {
       // (the traversal wrote this tree's results itself: walk_pipe_kernel's whole-tree units)
     } else if (e == per_tree - 1) {
@@ -697,12 +697,14 @@ reduce_tiles_kernel(BatchDims d, DeviceBatch b, int tiles, int grad_rows, int wa
 }
 
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
-                  hipStream_t stream, int grad_rows, ReduceDone done, const uint8_t* skip) {
+                  hipStream_t stream, int grad_rows, ReduceDone done, const uint8_t* skip, int first_tree) {
   if (grad_rows <= 0) grad_rows = tiles;
-  const size_t total = (size_t)d.tree_count * (want_gradient ? d.node_count + 1 : 1);
-  const int blocks = (int)((total + 255) / 256);
+  // (trees below first_tree have their results already: walk_pipe_kernel's whole-tree units of a one-class launch;
+  // at least one workgroup, which stores a blocking call's completion flag)
+  const size_t total = (size_t)(d.tree_count - first_tree) * (want_gradient ? d.node_count + 1 : 1);
+  const int blocks = std::max(1, (int)((total + 255) / 256));
   hipLaunchKernelGGL(reduce_tiles_kernel, dim3(blocks), dim3(256), 0, stream, d, b, tiles, grad_rows,
-                     want_gradient, done, skip);
+                     want_gradient, done, skip, first_tree);
 }
 
 // Completion flag of a blocking call's chunk: stored behind the kernels that wrote the chunk's results into pinned

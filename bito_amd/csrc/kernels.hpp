@@ -280,7 +280,8 @@ struct ReduceDone {
   int* counter = nullptr;
 };
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
-                  hipStream_t stream, int grad_rows = 0, ReduceDone done = ReduceDone{}, const uint8_t* skip = nullptr);
+                  hipStream_t stream, int grad_rows = 0, ReduceDone done = ReduceDone{}, const uint8_t* skip = nullptr,
+                  int first_tree = 0);
 // one thread stores `value` to `flag` (pinned host memory) behind everything enqueued on the stream so far
 void LaunchSignal(unsigned long long* flag, unsigned long long value, hipStream_t stream);
 

@@ -644,11 +644,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     else if (use_pipe) {
       const int site = want_site && want_gradient && deriv_mode == 0;
       // whole-tree units write their trees' results themselves (BITO_AMD_PIPE_DIRECT=0: all through the final-sums kernel)
-      static const bool direct = [] {
-        const char* v = std::getenv("BITO_AMD_PIPE_DIRECT");
-        return v == nullptr || std::atoi(v) != 0;
-      }();
-      if (direct && !site) {
+      if (e->pipe_direct && !site) {
         HIP_TRY(e, e->pipe_done.Reserve((size_t)T));
         b.pipe_done = e->pipe_done.ptr;
       }
@@ -666,7 +662,10 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     e->kernel_name = use_tree ? "walk_tree_kernel" : (use_pipe ? "walk_pipe_kernel" : "walk_lds_kernel");
     e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
     // (walk_pipe_kernel's partial log-likelihoods are per run of tiles as well)
-    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, walk, grad_rows, DoneByReduce(e), use_pipe ? b.pipe_done : nullptr);
+    // (one-class launches: the whole-tree units are trees 0 .. whole_trees-1, all written by the traversal)
+    const int reduce_from = (use_pipe && b.pipe_done != nullptr && !two_classes) ? plan.whole_trees : 0;
+    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, walk, grad_rows, DoneByReduce(e),
+                 use_pipe ? b.pipe_done : nullptr, reduce_from);
     if (!bare) HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], walk));
     e->last_pass_done = bare ? nullptr : e->ev_walk_done[set];
     HIP_TRY(e, hipGetLastError());
@@ -806,6 +805,7 @@ int WorkerCreate(int32_t device_id, uint64_t arena_bytes, const char* substituti
       return dev_fail("hipStreamCreate", hrc);
   }
   if (const char* serial = std::getenv("BITO_AMD_SERIAL_SETUP")) e->serial_setup = std::atoi(serial);
+  if (const char* direct = std::getenv("BITO_AMD_PIPE_DIRECT")) e->pipe_direct = std::atoi(direct) != 0;
   for (int i = 0; i < Worker::kSets; i++) {
     if ((hrc = hipEventCreateWithFlags(&e->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess ||
         (hrc = hipEventCreateWithFlags(&e->ev_walk_done[i], hipEventDisableTiming)) != hipSuccess)

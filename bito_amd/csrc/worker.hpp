@@ -146,6 +146,7 @@ struct Worker {
   long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
   DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
   DeviceBuffer<uint8_t> pipe_done;   // per tree: its whole-tree unit wrote the final results itself (kernels.hpp: DeviceBatch::pipe_done)
+  bool pipe_direct = true;           // (BITO_AMD_PIPE_DIRECT=0 when the worker is created: everything through the final-sums kernel)
   // walk_pipe_kernel in two launches: the trees of the resident batch that keep few enough vectors for four
   // pattern groups per wave (class A), and the others (class B) -- one tree with few cherries would otherwise
   // halve the groups of the whole batch

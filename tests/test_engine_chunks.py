@@ -268,3 +268,30 @@ def test_host_threads_check_and_pack_ranges_of_a_large_chunk():
     # and the engines still work after a failed call
     c = many.gradients(w.parent_ids, w.branch_lengths, w.params)
     assert np.array_equal(c["log_likelihood"], b["log_likelihood"])
+
+
+@pytest.mark.gpu
+def test_whole_tree_units_write_the_final_sums_the_final_sums_kernel_would():
+    """walk_pipe_kernel's whole-tree units store their tree's results themselves (a blocking call's results cross
+    PCIe during the traversal); the final-sums kernel would have added zeros to the same numbers: bit for bit the
+    results of an engine that sends everything through that kernel (BITO_AMD_PIPE_DIRECT=0), blocking calls and passes
+    over a resident batch alike, rooted trees (one zeroed entry) and unrooted ones (two)."""
+    w = workloads.ds1_gtr_weibull4(30)  # 3000 trees: whole-tree units for most, runs of tiles for the rest
+    direct = bito_amd.Engine(_spec(w), w.patterns, w.weights)
+    with _Env(BITO_AMD_PIPE_DIRECT=0):
+        plain = bito_amd.Engine(_spec(w), w.patterns, w.weights)
+    a = direct.gradients(w.parent_ids, w.branch_lengths, w.params)
+    b = plain.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert direct.kernel_name() == plain.kernel_name() == "walk_pipe_kernel"
+    assert np.array_equal(a["log_likelihood"], b["log_likelihood"])
+    assert np.array_equal(a["branch_lengths"], b["branch_lengths"])
+    assert np.all(a["branch_lengths"][:, -2:] == 0.0)  # (unrooted: the root's and the fixed node's entries)
+    for eng in (direct, plain):
+        eng.upload(w.parent_ids, w.branch_lengths * 1.0625, w.params)
+        eng.run(True)
+    la, ga = direct.download()
+    lb, gb = plain.download()
+    assert np.array_equal(la, lb) and np.array_equal(ga, gb)
+    assert not np.array_equal(la, a["log_likelihood"])
+    ll_only = direct.log_likelihoods(w.parent_ids, w.branch_lengths, w.params)
+    assert np.array_equal(ll_only, plain.log_likelihoods(w.parent_ids, w.branch_lengths, w.params))
