@@ -19,6 +19,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "host_pool.hpp"
@@ -747,17 +748,39 @@ int bito_amd_engine_kernel_timing(bito_amd_engine* e, int32_t enable) {
 
 int bito_amd_engine_kernel_elapsed(bito_amd_engine* e, double* kernel_ms, int32_t* kernel_launches) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
+  // Time the traversal kernels were running, per device slot the UNION of the launches' spans: the chunks of a blocking
+  // call run on two streams, and the second chunk's workgroups move in while the first chunk's are still leaving (its
+  // set-up ran beside the first traversal) -- the sum of the spans would count that stretch twice.
   double total = 0;
   int launches = 0;
-  for (auto& lanes : e->workers)
-    for (auto& w : lanes)
-      if (w) {
-        double ms = 0;
-        int32_t count = 0;
-        if (int rc = WorkerKernelElapsed(w.get(), &ms, &count)) return Propagate(e, w.get(), rc);
-        total += ms;
-        launches += count;
+  for (auto& lanes : e->workers) {
+    hipEvent_t base = nullptr;
+    std::vector<std::pair<double, double>> spans;
+    for (auto& w : lanes) {
+      if (!w) continue;
+      if (hipSetDevice(w->device) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess ||
+          (w->last_walk && w->last_walk != w->stream && hipStreamSynchronize(w->last_walk) != hipSuccess))
+        return Fail(e, BITO_AMD_ERR_DEVICE, "kernel timing: the worker's streams could not be synchronised");
+      for (size_t i = 0; i + 1 < w->ev_used; i += 2) {
+        if (!base) base = w->ev_pool[i];
+        float t0 = 0, t1 = 0;
+        if (hipEventElapsedTime(&t0, base, w->ev_pool[i]) != hipSuccess ||
+            hipEventElapsedTime(&t1, base, w->ev_pool[i + 1]) != hipSuccess)
+          return Fail(e, BITO_AMD_ERR_DEVICE, "kernel timing: hipEventElapsedTime failed");
+        spans.emplace_back((double)t0, (double)t1);
       }
+    }
+    std::sort(spans.begin(), spans.end());
+    double covered_to = -1e300;
+    for (const auto& s : spans) {
+      const double from = std::max(s.first, covered_to);
+      if (s.second > from) total += s.second - from;
+      covered_to = std::max(covered_to, s.second);
+    }
+    launches += (int)spans.size();
+    for (auto& w : lanes)
+      if (w) w->ev_used = 0;
+  }
   if (kernel_ms) *kernel_ms = total;
   if (kernel_launches) *kernel_launches = launches;
   return BITO_AMD_OK;

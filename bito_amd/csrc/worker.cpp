@@ -1581,25 +1581,6 @@ int WorkerKernelTiming(Worker* e, int32_t enable) {
   return BITO_AMD_OK;
 }
 
-int WorkerKernelElapsed(Worker* e, double* kernel_ms, int32_t* kernel_launches) {
-  if (!e) return BITO_AMD_ERR_BAD_ARG;
-  HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  if (e->last_walk && e->last_walk != e->stream) HIP_TRY(e, hipStreamSynchronize(e->last_walk));
-  double k = 0;
-  int launches = 0;
-  for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
-    float kms = 0;
-    HIP_TRY(e, hipEventElapsedTime(&kms, e->ev_pool[i], e->ev_pool[i + 1]));
-    k += kms;
-    launches++;
-  }
-  e->ev_used = 0;
-  if (kernel_ms) *kernel_ms = k;
-  if (kernel_launches) *kernel_launches = launches;
-  return BITO_AMD_OK;
-}
-
 int WorkerReadGeneralModel(Worker* e, int32_t tree, double* out, size_t capacity) {
   if (!e || !out) return BITO_AMD_ERR_BAD_ARG;
   const double* gs_model = e->gs_model.ptr;

@@ -287,7 +287,6 @@ int WorkerTimeTreeGradients(Worker* e, int32_t tree_count, const int32_t* parent
                             double* out_site, double* out_subst, double* out_clock, double* out_ratios);
 int WorkerSetKernel(Worker* e, int32_t kernel);
 int WorkerKernelTiming(Worker* e, int32_t enable);
-int WorkerKernelElapsed(Worker* e, double* kernel_ms, int32_t* kernel_launches);
 int WorkerReadGeneralModel(Worker* e, int32_t tree, double* out, size_t capacity);
 const char* WorkerKernelName(const Worker* e);
 int WorkerTimeRuns(Worker* e, int32_t want_gradient, int32_t rescaling, int32_t steps, double* total_ms,

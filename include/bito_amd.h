@@ -285,9 +285,11 @@ int bito_amd_engine_time_runs(bito_amd_engine *e, int32_t want_gradient, int32_t
                               int32_t steps, double *total_ms, double *kernel_ms,
                               int32_t *kernel_launches);
 /* Event timing of the traversal kernel inside ordinary bito_amd_engine_run calls:
- * enable, run any number of passes, sync, then read the summed duration of the
- * traversal-kernel launches since enabling (HIP events recorded on the engine's
- * stream around each launch).  Reading resets the accumulation. */
+ * enable, run any number of passes or blocking calls, then read the time the
+ * traversal kernel was running since enabling (HIP events recorded on the launches'
+ * streams around each launch; where the chunks of a blocking call overlap -- the next
+ * chunk's workgroups move in as the previous chunk's leave -- the union of the spans,
+ * not their sum) and the number of launches.  Reading resets the accumulation. */
 int bito_amd_engine_kernel_timing(bito_amd_engine *e, int32_t enable);
 int bito_amd_engine_kernel_elapsed(bito_amd_engine *e, double *kernel_ms, int32_t *kernel_launches);
 /* General-state kernels only: the per-tree model record the set-up kernel produced for `tree` of the
