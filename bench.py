@@ -345,6 +345,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = eng.kernel_elapsed()
+    span_sum_ms = eng.kernel_span_sum()
     eng.kernel_timing(False)
     kernel = eng.kernel_name()
 
@@ -485,6 +486,10 @@ def main():
                                         args.workload),
         }
         out["roofline"]["launches_per_step"] = launches / args.steps
+        # `avg_kernel_ms` is the time the kernel was running per launch: the union of the launches' spans (the chunks
+        # of a call overlap: the second chunk's workgroups move in while the first chunk's leave).  A profiler's
+        # per-launch average is the spans' sum / launches:
+        out["roofline"]["avg_launch_span_ms"] = span_sum_ms / max(launches, 1)
         if small_calls:
             out["blocking_call_ms"] = {"trees_per_call": small_calls,
                                        "note": "the same gradients call on 1 / 100 / 400 / 1600 of the trees, mean of 40 calls"}

@@ -30,7 +30,7 @@ SYMBOLS = [
     "bito_amd_engine_block", "bito_amd_engine_log_likelihoods", "bito_amd_engine_gradients",
     "bito_amd_engine_upload", "bito_amd_engine_update", "bito_amd_engine_run", "bito_amd_engine_sync",
     "bito_amd_engine_download", "bito_amd_engine_download_async", "bito_amd_engine_results_async", "bito_amd_engine_stream", "bito_amd_engine_set_kernel", "bito_amd_plan_pipe_walk", "bito_amd_engine_time_runs",
-    "bito_amd_engine_kernel_timing", "bito_amd_engine_kernel_elapsed", "bito_amd_engine_kernel_name",
+    "bito_amd_engine_kernel_timing", "bito_amd_engine_kernel_elapsed", "bito_amd_engine_kernel_span_sum", "bito_amd_engine_kernel_name",
     "bito_amd_version", "bito_amd_engine_read_general_model",
     "bito_amd_engine_time_trees_from_branch_lengths", "bito_amd_engine_time_trees_from_height_ratios",
     "bito_amd_engine_log_det_jacobian", "bito_amd_engine_gradient_log_det_jacobian",
@@ -89,6 +89,8 @@ def lib():
     L.bito_amd_engine_time_runs.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, ip]
     L.bito_amd_engine_kernel_timing.argtypes = [vp, C.c_int32]
     L.bito_amd_engine_kernel_elapsed.argtypes = [vp, dp, ip]
+    L.bito_amd_engine_kernel_span_sum.argtypes = [vp]
+    L.bito_amd_engine_kernel_span_sum.restype = C.c_double
     L.bito_amd_engine_read_general_model.argtypes = [vp, C.c_int32, dp, C.c_size_t]
     L.bito_amd_engine_kernel_name.restype = C.c_char_p
     L.bito_amd_engine_kernel_name.argtypes = [vp]

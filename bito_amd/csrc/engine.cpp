@@ -66,6 +66,7 @@ struct bito_amd_engine {
   int host_threads = 0, par_min_trees = 1024;
   size_t par_min_bytes = (size_t)512 << 10;
   std::unique_ptr<HostPool> pool;
+  double span_sum_ms = 0;  // of the last bito_amd_engine_kernel_elapsed: the launches' spans added up (overlaps counted twice)
 };
 
 namespace {
@@ -751,7 +752,7 @@ int bito_amd_engine_kernel_elapsed(bito_amd_engine* e, double* kernel_ms, int32_
   // Time the traversal kernels were running, per device slot the UNION of the launches' spans: the chunks of a blocking
   // call run on two streams, and the second chunk's workgroups move in while the first chunk's are still leaving (its
   // set-up ran beside the first traversal) -- the sum of the spans would count that stretch twice.
-  double total = 0;
+  double total = 0, span_sum = 0;
   int launches = 0;
   for (auto& lanes : e->workers) {
     hipEvent_t base = nullptr;
@@ -771,6 +772,7 @@ int bito_amd_engine_kernel_elapsed(bito_amd_engine* e, double* kernel_ms, int32_
       }
     }
     std::sort(spans.begin(), spans.end());
+    for (const auto& s : spans) span_sum += s.second - s.first;
     double covered_to = -1e300;
     for (const auto& s : spans) {
       const double from = std::max(s.first, covered_to);
@@ -781,10 +783,13 @@ int bito_amd_engine_kernel_elapsed(bito_amd_engine* e, double* kernel_ms, int32_
     for (auto& w : lanes)
       if (w) w->ev_used = 0;
   }
+  e->span_sum_ms = span_sum;
   if (kernel_ms) *kernel_ms = total;
   if (kernel_launches) *kernel_launches = launches;
   return BITO_AMD_OK;
 }
+
+double bito_amd_engine_kernel_span_sum(const bito_amd_engine* e) { return e ? e->span_sum_ms : 0.0; }
 
 int bito_amd_engine_read_general_model(bito_amd_engine* e, int32_t tree, double* out, size_t capacity) {
   if (!e || !out) return BITO_AMD_ERR_BAD_ARG;

@@ -436,6 +436,11 @@ class Engine:
         self._check(_capi.lib().bito_amd_engine_kernel_elapsed(self._h, C.byref(kern), C.byref(launches)))
         return kern.value, launches.value
 
+    def kernel_span_sum(self) -> float:
+        """The launches' spans of the last ``kernel_elapsed`` added up, in ms (what a profiler's per-launch durations
+        sum to; ``kernel_elapsed`` itself reports the union of the spans: overlapping chunks counted once)."""
+        return float(_capi.lib().bito_amd_engine_kernel_span_sum(self._h))
+
     def time_runs(self, want_gradient: bool, rescaling: bool, steps: int):
         total, kern, launches = C.c_double(), C.c_double(), C.c_int32()
         self._check(_capi.lib().bito_amd_engine_time_runs(self._h, int(want_gradient), int(rescaling), steps,

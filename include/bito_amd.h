@@ -292,6 +292,9 @@ int bito_amd_engine_time_runs(bito_amd_engine *e, int32_t want_gradient, int32_t
  * not their sum) and the number of launches.  Reading resets the accumulation. */
 int bito_amd_engine_kernel_timing(bito_amd_engine *e, int32_t enable);
 int bito_amd_engine_kernel_elapsed(bito_amd_engine *e, double *kernel_ms, int32_t *kernel_launches);
+/* ... and what a profiler's per-launch durations add up to for the launches of the last
+ * bito_amd_engine_kernel_elapsed: the spans summed, overlaps counted in both launches. */
+double bito_amd_engine_kernel_span_sum(const bito_amd_engine *e);
 /* General-state kernels only: the per-tree model record the set-up kernel produced for `tree` of the
  * resident batch after a run -- V [64][64], V^-1 [64][64], Q [64][64], lambda [64], pi [64],
  * sqrt(pi) [64], then 16 category rates, 16 weights, 16 d rate / d shape (row-major, padded to 64
