@@ -293,3 +293,25 @@ def test_pipe_walk_planner():
                 if p["groups"]:
                     assert p["lds_bytes"] <= 160 * 1024 and p["slots"] >= max(1, n - 2 - cherries)
                     assert p["tiles"] * p["patterns_per_workgroup"] >= 500 and p["tiles"] % p["tile_run"] == 0
+
+
+def test_host_pool_runs_every_part_once_and_is_race_free(tmp_path):
+    """bito_amd/csrc/host_pool.hpp (the helper threads of a blocking call) on its own, no GPU: tests/host_pool_test.cpp
+    built with g++ -- under ThreadSanitizer when its runtime is installed -- runs thousands of jobs on pools of 0 to 7
+    helpers that are armed, lingering or asleep when a job arrives."""
+    import shutil
+    import subprocess
+
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_pool_test.cpp")
+    exe = str(tmp_path / "host_pool_test")
+    base = [gxx, "-O1", "-g", "-std=c++17", "-pthread", src, "-o", exe]
+    built = subprocess.run(base[:5] + ["-fsanitize=thread"] + base[5:], capture_output=True, text=True)
+    if built.returncode != 0:
+        built = subprocess.run(base, capture_output=True, text=True)
+    assert built.returncode == 0, built.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "0 bad" in run.stdout, run.stdout + run.stderr
+    assert "ThreadSanitizer" not in run.stderr, run.stderr
