@@ -59,7 +59,9 @@ def host_threads_for_rank(cap: int = 8) -> int:
     except (OSError, ValueError):
         pass
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
-    return max(1, min(cap, cpus // local_world))
+    # (a rank's calling thread polls for its results: it keeps a CPU of the rank's share to itself when the share is small)
+    share = cpus // local_world
+    return max(1, min(cap, share if share > cap else share - 1))
 
 
 class ShardedEngine:
