@@ -313,21 +313,27 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
       SyncShards(e, e->shards.size());
       return rc;
     }
-  e->resident = true;
-  e->rooted = rooted;
-  e->node_count = node_count;
-  e->tree_count = tree_count;
   if (want_site && out_site) {
-    // kernels that do not produce the site-model gradient in the main pass: a second traversal per block
+    // kernels that do not produce the site-model gradient in the main pass: a second traversal per block.  Every
+    // chunk has drained by now, so each worker runs the pass on its OWN streams and waits for it there: the streams a
+    // chunk was lent for the call belong to other workers, and a download ordered behind this worker's stream alone
+    // would read pin_out before the lent stream's traversal has written it.
     for (const Shard& s : e->shards) {
       Worker* w = ShardWorker(e, s);
       if (w->site_ready) continue;
+      w->one_shot = 0;
+      w->lent_walk = w->lent_setup = nullptr;
+      w->reserve_cus = 0;
       const int rc = WorkerSiteGradientSecondPass(w, rooted, node_count, branch_lengths + (size_t)s.t0 * M,
                                                   has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr, rescaling,
                                                   out_site + s.t0);
       if (rc) return Propagate(e, w, rc);
     }
   }
+  e->resident = true;  // (only once nothing can fail any more)
+  e->rooted = rooted;
+  e->node_count = node_count;
+  e->tree_count = tree_count;
   return BITO_AMD_OK;
 }
 
@@ -434,8 +440,19 @@ int bito_amd_engine_create(const bito_amd_engine_spec* spec, const char* substit
   if (taxon_count < 2 || pattern_count < 1 || !patterns || !weights)
     return report(BITO_AMD_ERR_BAD_ARG, "need at least 2 taxa, 1 site pattern and non-NULL arrays");
   // "Thread count needs to be strictly positive." (reference src/engine.cpp:14-16): here, devices
-  const int device_count = spec ? spec->device_count : 1;
+  // (0 = the default, one device, like host_threads and arena_bytes: a zero-initialised spec, or one written for the
+  // three-field struct of earlier headers, keeps working)
+  const int device_count = (spec && spec->device_count != 0) ? spec->device_count : 1;
   if (device_count < 1) return report(BITO_AMD_ERR_BAD_ARG, "Device count needs to be strictly positive.");
+  {
+    int present = 0;
+    if (hipGetDeviceCount(&present) == hipSuccess && present > 0)
+      for (int k = 0; k < device_count; k++) {
+        const int id = spec && spec->devices ? spec->devices[k] : (spec ? spec->device_id : 0) + k;
+        if (id < 0 || id >= present)
+          return report(BITO_AMD_ERR_BAD_ARG, "device " + std::to_string(id) + " (slot " + std::to_string(k) + ") does not exist: this machine has " + std::to_string(present));
+      }
+  }
   auto e = std::make_unique<bito_amd_engine>();
   for (int k = 0; k < device_count; k++)
     e->devices.push_back(spec && spec->devices ? spec->devices[k] : (spec ? spec->device_id : 0) + k);

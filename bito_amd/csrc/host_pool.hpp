@@ -21,6 +21,8 @@
 #include <thread>
 #include <vector>
 
+#include "cpu_pause.hpp"
+
 namespace bito_amd {
 
 class HostPool {
@@ -78,13 +80,7 @@ class HostPool {
   static long long Now() {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
   }
-  static void Pause() {
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#else
-    std::this_thread::yield();
-#endif
-  }
+  static void Pause() { CpuPause(); }
 
   void Loop(int part) {
     unsigned seen = 0, seen_arm = 0;

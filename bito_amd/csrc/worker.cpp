@@ -324,6 +324,19 @@ bool TreeFitsReversibleForm(const ModelSpec& m, int32_t rooted, int32_t node_cou
 
 namespace {
 
+// Bytes a pass may spend on its PLV arena.  A caller's cap (bito_amd_engine_spec.arena_bytes) holds as given.  The
+// default -- 3/4 of the HBM that was free when the worker was created -- is each worker's own figure, and an engine
+// keeps up to eight lane workers per device slot (and may name one GPU in several slots): when the pass wants more
+// than this worker holds already, the budget is also held to what the device has free NOW, so that the workers of a
+// device shrink their chunks instead of running it out of memory.
+size_t ArenaBudget(Worker* e, size_t wanted_bytes) {
+  const size_t held = (e->arena.capacity + e->images.capacity) * sizeof(double);
+  if (!e->arena_auto || wanted_bytes <= held) return (size_t)e->arena_limit;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)e->arena_limit;
+  return std::max<size_t>(std::min<size_t>((size_t)e->arena_limit, held + free_b / 4 * 3), (size_t)1 << 28);
+}
+
 DeviceBatch MakeBatch(Worker* e, int set = 0) {
   DeviceBatch b{};
   b.parent_ids = e->parent_ids.ptr;
@@ -413,7 +426,7 @@ int RunResidentGeneral(Worker* e, int want_gradient, int rescaling, int deriv_mo
   // serial on `stream`, buffer set 0, trees in chunks sized to the budget
   HIP_TRY(e, hipStreamSynchronize(e->prep_stream));
   const size_t per_tree = (img_per_tree + arena_per_tree) * sizeof(double);
-  size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
+  size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, ArenaBudget(e, (size_t)T * per_tree) / per_tree));
   chunk = std::min<size_t>(chunk, 65535);
   HIP_TRY(e, e->gs_model.Reserve((size_t)T * kGsModelStride));
   HIP_TRY(e, e->images.Reserve(chunk * img_per_tree));
@@ -680,7 +693,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   if (HbmCatKernelApplies(d))  // the steps' order (hbm_order_kernel)
     HIP_TRY(e, (set == 0 ? e->sched : set == 1 ? e->sched2 : e->sched3).Reserve(HbmOrderInts(d)));
   const size_t per_tree = HbmArenaBytesPerTree(d);
-  size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, e->arena_limit / per_tree));
+  size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)T, ArenaBudget(e, (size_t)T * per_tree) / per_tree));
   // grid.y limit
   chunk = std::min<size_t>(chunk, 65535);
   HIP_TRY(e, e->arena.Reserve(chunk * per_tree / sizeof(double)));
@@ -821,6 +834,7 @@ int WorkerCreate(int32_t device_id, uint64_t arena_bytes, const char* substituti
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
   e->arena_limit = arena_bytes ? arena_bytes : std::max<size_t>(free_b / 4 * 3, (size_t)1 << 28);
+  e->arena_auto = arena_bytes == 0;
   // Compact tip states, gap for every symbol >= 4 and for the padding columns
   // (SitePattern symbol table, reference src/site_pattern.cpp:16-46).
   const int S = e->spec.state_count;
@@ -1086,7 +1100,7 @@ int WorkerResults(Worker* e, const double** ll, const double** grad, const doubl
     // poll the flag the chunk's last kernel stores; now and then ask the stream whether it has failed
     volatile uint64_t* flag = static_cast<volatile uint64_t*>(e->pin_flag.ptr);
     for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != e->ticket; spins++) {
-      __builtin_ia32_pause();
+      CpuPause();
       if ((spins & 0xffff) == 0xffff) {
         const hipError_t state = hipStreamQuery(e->last_walk ? e->last_walk : e->stream);
         if (state != hipSuccess && state != hipErrorNotReady)

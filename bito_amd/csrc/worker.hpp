@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/bito_amd.h"
+#include "cpu_pause.hpp"
 #include "kernels.hpp"
 #include "model.hpp"
 
@@ -77,6 +78,7 @@ struct Worker {
   int device = 0;
   int n = 0, P = 0, Ppad = 0;
   uint64_t arena_limit = 0;
+  bool arena_auto = true;  // arena_limit is the default (a share of the free HBM), not a caller's cap
   hipStream_t stream = nullptr;
   // Set-up pipeline of the LDS kernels: the set-up kernels of pass k+1 (topology, model, matrix images,
   // step tables) run on prep_stream while earlier passes' traversals are still on `stream`; they write into the

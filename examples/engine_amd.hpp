@@ -40,6 +40,9 @@ class Engine {
          int32_t device_count = 1, const std::vector<int32_t>& devices = {}) {
     // device_count stands where the reference has thread_count (src/engine.hpp:20-24): how many FatBeagle
     // instances -- here GPUs -- serve one call
+    // ("Thread count needs to be strictly positive.", src/engine.cpp:14-16 -- the C ABI itself reads a 0 as its
+    // default, one device, so that a zero-initialised spec works)
+    if (device_count < 1) throw std::runtime_error("Device count needs to be strictly positive.");
     bito_amd_engine_spec es{device_id, 1, 0, device_count, /*host_threads=*/0, devices.empty() ? nullptr : devices.data()};
     char err[512] = {0};
     const int rc = bito_amd_engine_create(&es, spec.substitution_.c_str(), spec.site_.c_str(), spec.clock_.c_str(),

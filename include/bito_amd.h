@@ -70,13 +70,17 @@ typedef struct {
                              held as compact states, which is what BEAGLE's
                              tip-state path computes (fat_beagle.cpp:269-275) */
   uint64_t arena_bytes;   /* cap on the HBM PLV arena per device; 0 = default (3/4 of free HBM: the engine owns its GPUs) */
-  int32_t device_count;   /* GPUs this engine drives, >= 1 ("Thread count needs to be strictly positive.",
-                             src/engine.cpp:14-16) */
+  int32_t device_count;   /* GPUs this engine drives; 0 = default (one); negative: "Thread count needs to be strictly
+                             positive." (src/engine.cpp:14-16).  Every ordinal named is checked against the
+                             machine's device count when the engine is created. */
   int32_t host_threads;   /* host threads a blocking call may use for its own share of the work -- checking the
                              wire-format rows, packing them into pinned memory, copying results out -- as the reference
                              gives every FatBeagle instance a thread (EngineSpecification::thread_count_,
                              src/engine.hpp:20-24).  0 = default: min(8, CPUs this process may use); 1 = the calling
-                             thread alone.  The helpers sleep between calls; all device work is issued by the caller. */
+                             thread alone.  The helpers sleep between calls, but keep polling (a core each) for 8 ms after a
+                             large call has woken them and 1.5 ms after every job, so that a loop of calls never pays a
+                             wake-up: a process that runs several engines or ranks should divide its CPUs among them
+                             here (bench.py does, by LOCAL_WORLD_SIZE). */
   const int32_t *devices; /* device_count HIP ordinals, or NULL: device_id, device_id + 1, ...  A device may be named
                              more than once (each entry is served like a device of its own): that is how the
                              multi-device path is exercised on a one-GPU machine. */

@@ -51,7 +51,7 @@ def test_device_count_must_be_positive():
     import ctypes as C
 
     L = _capi.lib()
-    spec = _capi.EngineSpec(0, 1, 0, 0, 0, None)
+    spec = _capi.EngineSpec(0, 1, 0, -1, 0, None)  # (0 is the C ABI's default, one device)
     handle, err = C.c_void_p(), C.create_string_buffer(256)
     pat = np.ascontiguousarray(w.patterns, dtype=np.int32)
     wts = np.ascontiguousarray(w.weights)
@@ -98,6 +98,31 @@ def test_chunked_call_matches_oracle_and_single_chunk():
     eng.gradients_into(np.ascontiguousarray(w.parent_ids, dtype=np.int32), np.ascontiguousarray(w.branch_lengths),
                        np.ascontiguousarray(w.params), ll3, grad3)
     assert np.array_equal(ll3, out["log_likelihood"]) and np.array_equal(grad3, out["branch_lengths"])
+
+
+@pytest.mark.gpu
+def test_site_gradient_by_second_pass_on_a_chunked_call():
+    """weibull+6 runs on walk_hbm_kernel, which does not produce the site-model gradient in the main pass: Evaluate
+    then makes a second traversal per chunk.  With one host thread a call is cut into three chunks and more, and
+    chunks from the third on were lent ANOTHER worker's stream for the call -- the second pass must run on the
+    worker's own streams (round 3's advisor finding: the download was ordered behind the wrong stream)."""
+    from oracle import oracle
+
+    w = workloads.ds1_gtr_weibull4(2)  # 200 trees
+    w.site = "weibull+6"
+    cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, flags=oracle.GRAD_SITE_MODEL)
+    with _Env(BITO_AMD_HOST_THREADS=1, **SMALL_CHUNKS):
+        eng = bito_amd.Engine(_spec(w), w.patterns, w.weights)
+    for _ in range(3):  # (a race: more than one try)
+        out = eng.gradients(w.parent_ids, w.branch_lengths, w.params, flags=_capi.GRAD_SITE_MODEL)
+        assert eng.kernel_name().startswith("walk_hbm_kernel")
+        assert _close(out["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL)
+        assert _close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
+        assert _close(out["site_model"], ref["site_model"], GRAD_ATOL, GRAD_RTOL)
+    # the batch is resident again afterwards, with the main pass's results
+    ll, grad = eng.download()
+    assert np.array_equal(ll, out["log_likelihood"]) and np.array_equal(grad, out["branch_lengths"])
 
 
 @pytest.mark.gpu
