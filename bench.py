@@ -159,59 +159,101 @@ def cpu_baseline(w, seconds: float):
                       "cannot be built here)"}
 
 
-def arithmetic_view(n, P, C, S, trees_per_launch, avg_kernel_s):
-    """Algorithmic FP64 flops per launch (every child message a full matrix-vector
-    product, tips included) against the guide's dense FP64 matrix peak; the rate v_mfma_f64_4x4x4_4b sustains
-    from one wave per SIMD on the box (68 TFLOP/s, profiles/r1_microbench.json) is given beside it."""
-    flops = algorithmic_flops_per_tree(n, P, C, S) * trees_per_launch
-    achieved = flops / avg_kernel_s / 1e12
-    return {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "sustained_peak": FP64_MFMA_PEAK_TFLOPS,
-            "frac_of_sustained": achieved / FP64_MFMA_PEAK_TFLOPS,
-            "algorithmic_flops_per_tree": algorithmic_flops_per_tree(n, P, C, S)}
-
-
-def measured_traffic(kernel: str, trees_per_launch: float, workload: str):
-    """HBM bytes per launch of the traversal kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json), scaled per tree to this launch size when the pass was taken at another one."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def _committed_row(filename: str, kernel: str, workload: str, trees_per_launch: float):
+    """the row of a hand-maintained summary under profiles/ (each names the rocprofv3 pass it was read from) for this
+    kernel and workload, the one taken nearest to this launch size"""
     try:
-        with open(path) as fh:
+        with open(os.path.join(ROOT, "profiles", filename)) as fh:
             rows = [r for r in json.load(fh) if r["kernel"] == kernel and r.get("workload", "ds1") == workload]
     except (OSError, ValueError, KeyError):
         return None
     if not rows:
         return None
-    row = min(rows, key=lambda r: abs(r["trees_per_launch"] - trees_per_launch))
-    return row["hbm_bytes_per_launch"] / row["trees_per_launch"] * trees_per_launch
+    return min(rows, key=lambda r: abs(r.get("trees_per_launch", trees_per_launch) - trees_per_launch))
 
 
 def roofline_object(kernel, n, P, C, S, want_gradient, trees_per_launch, avg_kernel_s, workload_key):
-    alg_bytes = algorithmic_bytes_per_tree(n, P, C, want_gradient, S) * trees_per_launch
-    achieved = alg_bytes / avg_kernel_s / 1e9
-    traffic = measured_traffic(kernel, trees_per_launch, workload_key)
-    hbm_view = {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        # the PMC-measured bytes over the same launch time: what the kernel really asks of HBM
-        "actual_hbm_GBps": (traffic / avg_kernel_s / 1e9) if traffic else None,
-        "actual_frac_of_peak": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-        "algorithmic_bytes_per_tree": algorithmic_bytes_per_tree(n, P, C, want_gradient, S),
-    }
-    if S == 61:
-        flops = algorithmic_flops_per_tree(n, P, C, S) * trees_per_launch
-        arithmetic = {"bound": "mfma", "achieved": flops / avg_kernel_s / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                      "unit": "TFLOP/s", "frac": flops / avg_kernel_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
-                      "note": "algorithmic flops of SURVEY 8d (tip children counted as full products); "
-                              "v_mfma_f64_16x16x4 sustains 47.6 TFLOP/s on this part (profiles/r1_microbench.json)"}
-    else:
-        arithmetic = arithmetic_view(n, P, C, S, trees_per_launch, avg_kernel_s)
-    common = {"traffic": traffic, "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3,
-              "trees_per_launch": trees_per_launch}
+    """`roofline` of the dominant kernel.  Four views, every one labelled with where its numerator comes from:
+    the algorithmic bytes and flops of SURVEY.md 8d (an op-by-op model: every partial crosses HBM, every child message
+    is a full matrix-vector product) and what the kernel really did -- HBM bytes and matrix instructions from committed
+    rocprofv3 counter passes (profiles/traffic.json, profiles/executed.json; replayed per tree, the files name the
+    passes).  `achieved` / `frac` follow the bound: the LDS-resident walks are priced on the FP64 matrix peak by
+    algorithmic flops; the 61-state walk on the matrix peak by EXECUTED flops (the algorithmic model counts tip
+    children as full 61 x 61 products, which the kernel rightly does not compute: that model exceeds the peak and is
+    kept as a ratio, not a fraction); the HBM-arena walks on HBM by measured traffic (fused: fewer bytes than op by op)."""
+    alg_bytes_tree = algorithmic_bytes_per_tree(n, P, C, want_gradient, S)
+    alg_flops_tree = algorithmic_flops_per_tree(n, P, C, S)
+    alg_gbps = alg_bytes_tree * trees_per_launch / avg_kernel_s / 1e9
+    alg_tflops = alg_flops_tree * trees_per_launch / avg_kernel_s / 1e12
+    trow = _committed_row("traffic.json", kernel, workload_key, trees_per_launch)
+    traffic = trow["hbm_bytes_per_launch"] / trow["trees_per_launch"] * trees_per_launch if trow else None
+    erow = _committed_row("executed.json", kernel, workload_key, trees_per_launch)
+    executed = None
+    if erow:
+        flops = erow["matrix_instructions_per_tree"] * erow["flops_per_instruction"] * trees_per_launch
+        executed = {"achieved": flops / avg_kernel_s / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flops / avg_kernel_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                    "matrix_instructions_per_tree": erow["matrix_instructions_per_tree"],
+                    "flops_per_instruction": erow["flops_per_instruction"], "source": erow["source"]}
+    hbm_measured = None
+    if traffic:
+        hbm_measured = {"achieved": traffic / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS}
+    model = {"note": "SURVEY.md 8d, op-by-op: ratios to the peaks, not fractions (a fused kernel moves fewer bytes; tip "
+                     "children need no matrix product)",
+             "algorithmic_bytes_per_tree": alg_bytes_tree, "algorithmic_flops_per_tree": alg_flops_tree,
+             "bytes_rate_GBps": alg_gbps, "bytes_ratio_to_hbm_peak": alg_gbps / HBM_PEAK_GBS,
+             "flops_rate_TFLOPs": alg_tflops, "flops_ratio_to_matrix_peak": alg_tflops / FP64_MATRIX_PEAK_TFLOPS}
+    common = {"traffic": traffic, "traffic_source": trow["source"] if trow else None, "kernel": kernel,
+              "avg_kernel_ms": avg_kernel_s * 1e3, "trees_per_launch": trees_per_launch}
     if kernel in ("walk_pipe_kernel", "walk_lds_kernel", "walk_tree_kernel"):
-        # These kernels keep every partial in LDS: HBM sees 0.3 % of the op-by-op byte model (`traffic`), so
-        # the resource that bounds them is the FP64 matrix / vector pipe.  The byte view is kept beside it.
-        return {**arithmetic, **common, "hbm_view": hbm_view}
-    return {**hbm_view, **common, "arithmetic": arithmetic}
+        # every partial stays in LDS (HBM sees 0.2 % of the byte model): bounded by the FP64 matrix / vector pipe
+        out = {"bound": "mfma", "achieved": alg_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": alg_tflops / FP64_MATRIX_PEAK_TFLOPS, "numerator": "algorithmic flops (SURVEY.md 8d)",
+               "sustained_peak": FP64_MFMA_PEAK_TFLOPS, "frac_of_sustained": alg_tflops / FP64_MFMA_PEAK_TFLOPS,
+               "algorithmic_flops_per_tree": alg_flops_tree, "executed": executed, "hbm_measured": hbm_measured}
+    elif S != 4 and executed is not None:
+        out = {"bound": "mfma", "achieved": executed["achieved"], "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": executed["frac"], "numerator": "executed matrix instructions x flops per instruction (counters)",
+               "executed": executed, "hbm_measured": hbm_measured,
+               "note": "v_mfma_f64_16x16x4 sustains 47.6 TFLOP/s on this part (profiles/r1_microbench.json)"}
+    elif hbm_measured is not None:
+        out = {"bound": "hbm", "achieved": hbm_measured["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": hbm_measured["frac"], "numerator": "HBM bytes measured by rocprofv3 (FETCH_SIZE x 2 + WRITE_SIZE)",
+               "executed": executed}
+    else:  # no committed counter pass for this kernel: the op-by-op model alone, held to the contract's frac <= 1
+        out = {"bound": "hbm", "achieved": alg_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": alg_gbps / HBM_PEAK_GBS if alg_gbps <= HBM_PEAK_GBS else None,
+               "numerator": "algorithmic bytes (SURVEY.md 8d); no measured traffic committed for this kernel"}
+    return {**out, **common, "model": model}
+
+
+def check_against_oracle(w, out_ll, out_grad, count=8):
+    """(outside every timed region) `count` trees spread over the timed batch, the engine's last results against the CPU
+    checker on the inputs of the last step: max |dLL| and max |dgrad| go into the line"""
+    T = w.tree_count
+    sel = np.unique(np.linspace(0, T - 1, min(count, T)).astype(int))
+    if w.substitution == "GY94":
+        from oracle import gs
+
+        cpu = gs.GsOracleEngine(w.substitution, w.site, w.patterns, w.weights, min(len(sel), 8))
+    else:
+        from oracle import oracle
+
+        cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, min(len(sel), 8))
+    bl = w.last_branch_lengths[sel]
+    if w.want_gradient:
+        ref = cpu.gradients(w.parent_ids[sel], bl, w.params[sel], rescaling=w.rescaling)
+        ref_ll, ref_grad = ref["log_likelihood"], ref["branch_lengths"]
+    else:
+        ref_ll, ref_grad = cpu.log_likelihoods(w.parent_ids[sel], bl, w.params[sel], rescaling=w.rescaling), None
+    dll = float(np.max(np.abs(out_ll[sel] - ref_ll) / (1.0 + 2e-4 * np.abs(ref_ll))))  # 1e-10 + 2e-14 |LL|, as the tests
+    res = {"trees_checked": [int(t) for t in sel], "max_dll": float(np.max(np.abs(out_ll[sel] - ref_ll))),
+           "max_dll_scaled": dll, "checker": "the CPU oracle (oracle/), on the inputs of the last timed step"}
+    if ref_grad is not None:
+        res["max_dgrad"] = float(np.max(np.abs(out_grad[sel] - ref_grad)))
+        res["max_dgrad_relative"] = float(np.max(np.abs(out_grad[sel] - ref_grad) / (1.0 + 1e-3 * np.abs(ref_grad))))
+    return res
 
 
 def main():
@@ -230,7 +272,16 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="the timed region only: skip the small-collection calls and the second timed region (resident batch)")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 HBM arena, 2 LDS")
+    ap.add_argument("--resident-only", action="store_true",
+                    help="profiling: one blocking call, then only the second timed region (one traversal launch per pass); "
+                         "`value` is then null")
+    ap.add_argument("--no-parity-check", action="store_true",
+                    help="skip the check of eight of the timed batch's trees against the CPU oracle behind the timed region")
+    ap.add_argument("--engine-devices", type=str, default="",
+                    help="ONE process, one engine over several device slots (the in-process counterpart of --gpus N under "
+                         "torch.distributed.run): a number N = devices 0..N-1, or a list such as 0,0,0,0 (one GPU named four "
+                         "times: the N-slot code path on a one-GPU box); every slot gets --replicas x 100 trees")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 HBM arena, 2 LDS, 5 / 6 walk_pipe_kernel with one / two waves per SIMD")
     ap.add_argument("--sum-ll-reduce", choices=("auto", "on", "off"), default="auto",
                     help="per step, all-reduce the summed log-likelihood over the ranks (RCCL); auto = when there "
                          "is more than one rank")
@@ -268,12 +319,20 @@ def main():
     if args.sum_ll_reduce == "on" and dist is None:
         raise SystemExit("--sum-ll-reduce on needs a process group (launch with torch.distributed.run)")
 
+    slots = []
+    if args.engine_devices:
+        if world > 1:
+            raise SystemExit("--engine-devices is the one-process mode: do not launch it under torch.distributed.run")
+        slots = ([int(x) for x in args.engine_devices.split(",")] if "," in args.engine_devices
+                 else list(range(int(args.engine_devices))))
+    shards = max(len(slots), 1)  # device slots of this process's engine
+
     # every rank builds its own block of the same replicated workload
     codon = args.workload == "codon"
     config4 = args.workload == "config4"
     scaling = "weak"
     if codon:
-        per_rank = args.trees or 4096
+        per_rank = (args.trees or 4096) * shards
         w = workloads.flua_codon(per_rank * world).shard(rank, world)
     elif config4:
         # BASELINE config 4: 1000 sampled trees sharded across the ranks (strong scaling: the collection is fixed);
@@ -283,8 +342,8 @@ def main():
         w = workloads.synthetic_gtr_weibull4(1000, 10000, tree_count=hi - lo, first_tree=lo)
         scaling = "strong" if world > 1 else "weak"
     else:  # (a rank generates its own block of the 100 x replicas x world trees: same trees as the whole, sharded)
-        per_rank = 100 * args.replicas
-        w = workloads.ds1_gtr_weibull4(args.replicas * world, first_tree=rank * per_rank, tree_count=per_rank)
+        per_rank = 100 * args.replicas * shards
+        w = workloads.ds1_gtr_weibull4(args.replicas * world * shards, first_tree=rank * per_rank, tree_count=per_rank)
     T = w.tree_count
     n, P = w.patterns.shape
     C = 1 if codon else 4
@@ -297,7 +356,7 @@ def main():
 
     host_threads = host_threads_for_rank()
     eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock), w.patterns, w.weights,
-                          device_id=local_rank, host_threads=host_threads)
+                          device_id=local_rank, host_threads=host_threads, devices=slots or None)
     if not codon:
         eng.set_kernel(args.kernel)
 
@@ -315,6 +374,7 @@ def main():
         # the call the reference's Engine::Gradients is: host trees + parameter rows in, host results out
         bl = bl_sets[counter[0] & 1]
         counter[0] += 1
+        w.last_branch_lengths = bl
         if w.want_gradient:
             eng.gradients_into(pid, bl, params, out_ll, out_grad, rescaling=w.rescaling)
         else:
@@ -334,13 +394,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    timed_steps = 1 if args.resident_only else args.steps
+    for _ in range(0 if args.resident_only else args.warmup):
         step()
     fence()
     pending.clear()
     eng.kernel_timing(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(timed_steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -358,6 +419,13 @@ def main():
     # (BENCH_ABLATION=1: timing-only kernel variants of scripts/build_*_variants.sh, whose results mean nothing)
     if not os.environ.get("BENCH_ABLATION") and not (np.all(np.isfinite(out_ll)) and (not w.want_gradient or np.all(np.isfinite(out_grad)))):
         raise SystemExit("non-finite results in the timed batch")
+    # ... and they are the right numbers: eight trees of the last step against the CPU checker
+    parity = None
+    if rank == 0 and not args.no_parity_check and not os.environ.get("BENCH_ABLATION"):
+        parity = check_against_oracle(w, out_ll, out_grad if w.want_gradient else None)
+        bad = parity["max_dll_scaled"] > 1e-10 or parity.get("max_dgrad_relative", 0.0) > 1e-6
+        if bad:
+            raise SystemExit(f"the timed batch's results differ from the CPU checker's: {parity}")
     summed_ll = None
     if reduce_ll:
         # the last reduction must be the sum over every rank's block: check it against a gather of the
@@ -372,7 +440,7 @@ def main():
 
     # the same blocking call on small collections (BASELINE's literal "100 topologies", vip's particle loop): ms per call
     small_calls = None
-    if args.workload == "ds1" and world == 1 and not args.no_resident:
+    if args.workload == "ds1" and world == 1 and not args.no_resident and not args.resident_only and not slots:
         small_calls = {}
         for count in (1, 100, 400, 1600):
             if count > T:
@@ -437,8 +505,8 @@ def main():
     out = None
     if rank == 0:
         total_trees = world * T
-        value = total_trees * args.steps / elapsed
-        trees_per_launch = T * args.steps / max(launches, 1)
+        value = None if args.resident_only else total_trees * args.steps / elapsed
+        trees_per_launch = T * timed_steps / max(launches, 1)
         avg_kernel_s = kernel_ms * 1e-3 / max(launches, 1)
         if codon:
             metric = "tree log-likelihoods+gradients/sec (fluA codon GY94, 61 states)"
@@ -459,10 +527,10 @@ def main():
             "metric": metric,
             "value": value,
             "unit": "trees/s",
-            "n_gpus": world,
+            "n_gpus": len(set(slots)) if slots else world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / timed_steps * 1e3,
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -475,6 +543,8 @@ def main():
                 "trees_per_gpu": T,
                 "trees_total": total_trees,
                 "kernel": kernel,
+                **({"kernel_form": eng.kernel_form()} if eng.kernel_form() else {}),
+                **({"engine_device_slots": slots} if slots else {}),
                 "host_threads_per_rank": host_threads,
                 "multi_gpu": ("trees sharded by rank; per step one asynchronous RCCL all-reduce of the summed "
                               "log-likelihood (8 bytes)" if reduce_ll else
@@ -485,7 +555,9 @@ def main():
             "roofline": roofline_object(kernel, n, P, C, S, w.want_gradient, trees_per_launch, avg_kernel_s,
                                         args.workload),
         }
-        out["roofline"]["launches_per_step"] = launches / args.steps
+        out["roofline"]["launches_per_step"] = launches / timed_steps
+        if parity is not None:
+            out["parity"] = parity
         # `avg_kernel_ms` is the time the kernel was running per launch: the union of the launches' spans (the chunks
         # of a call overlap: the second chunk's workgroups move in while the first chunk's leave).  A profiler's
         # per-launch average is the spans' sum / launches:

@@ -21,7 +21,7 @@ GRAD_STICKBREAKING = 8
 GRAD_RATIOS_ROOT_HEIGHT = 16
 GRAD_LOG_DET_JACOBIAN_GRADIENT = 32
 
-KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS, KERNEL_LDS_TREE, KERNEL_GENERAL, KERNEL_LDS_PIPE = 0, 1, 2, 3, 4, 5
+KERNEL_AUTO, KERNEL_HBM_ARENA, KERNEL_LDS, KERNEL_LDS_TREE, KERNEL_GENERAL, KERNEL_LDS_PIPE, KERNEL_LDS_PIPE2 = 0, 1, 2, 3, 4, 5, 6
 
 # Every symbol include/bito_amd.h declares (tests check that the library exports them all).
 SYMBOLS = [
@@ -30,7 +30,7 @@ SYMBOLS = [
     "bito_amd_engine_block", "bito_amd_engine_log_likelihoods", "bito_amd_engine_gradients",
     "bito_amd_engine_upload", "bito_amd_engine_update", "bito_amd_engine_run", "bito_amd_engine_sync",
     "bito_amd_engine_download", "bito_amd_engine_download_async", "bito_amd_engine_results_async", "bito_amd_engine_stream", "bito_amd_engine_set_kernel", "bito_amd_plan_pipe_walk", "bito_amd_engine_time_runs",
-    "bito_amd_engine_kernel_timing", "bito_amd_engine_kernel_elapsed", "bito_amd_engine_kernel_span_sum", "bito_amd_engine_kernel_name",
+    "bito_amd_engine_kernel_timing", "bito_amd_engine_kernel_elapsed", "bito_amd_engine_kernel_span_sum", "bito_amd_engine_kernel_name", "bito_amd_engine_kernel_form",
     "bito_amd_version", "bito_amd_engine_read_general_model",
     "bito_amd_engine_time_trees_from_branch_lengths", "bito_amd_engine_time_trees_from_height_ratios",
     "bito_amd_engine_log_det_jacobian", "bito_amd_engine_gradient_log_det_jacobian",
@@ -94,6 +94,8 @@ def lib():
     L.bito_amd_engine_read_general_model.argtypes = [vp, C.c_int32, dp, C.c_size_t]
     L.bito_amd_engine_kernel_name.restype = C.c_char_p
     L.bito_amd_engine_kernel_name.argtypes = [vp]
+    L.bito_amd_engine_kernel_form.restype = C.c_char_p
+    L.bito_amd_engine_kernel_form.argtypes = [vp]
     L.bito_amd_engine_time_trees_from_branch_lengths.argtypes = [vp, C.c_int32, ip, dp, dp, dp, dp, dp]
     L.bito_amd_engine_time_trees_from_height_ratios.argtypes = [vp, C.c_int32, ip, dp, dp, dp, dp]
     L.bito_amd_engine_log_det_jacobian.argtypes = [vp, C.c_int32, ip, dp, dp, dp]

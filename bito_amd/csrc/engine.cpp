@@ -819,6 +819,12 @@ int bito_amd_engine_read_general_model(bito_amd_engine* e, int32_t tree, double*
   return Fail(e, BITO_AMD_ERR_STATE, "no general-state model is resident for that tree");
 }
 
+const char* bito_amd_engine_kernel_form(const bito_amd_engine* e) {
+  if (!e) return "";
+  const Worker* w = e->resident && !e->shards.empty() ? ShardWorker(e, e->shards[0]) : Primary(e);
+  return w ? w->kernel_form.c_str() : "";
+}
+
 const char* bito_amd_engine_kernel_name(const bito_amd_engine* e) {
   if (!e) return "";
   return WorkerKernelName(e->resident && !e->shards.empty() ? ShardWorker(e, e->shards[0]) : Primary(e));

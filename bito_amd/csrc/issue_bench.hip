@@ -118,6 +118,31 @@ PAIR(p_mfma_branch, MFV, "s_branch 1f\n s_nop 0\n 1:\n")
 PAIR(p_mix_mix, MIX, MIX)
 PAIR(p_mix_idle, MIX, "s_nop 0\n")
 
+// round 4: why two waves per SIMD did not help walk_pipe_kernel -- which instruction kinds of two sibling waves overlap
+PAIR(p_salu_salu, "s_add_u32 s40, s41, 1\n", "s_add_u32 s40, s41, 1\n")
+PAIR(p_nop_nop, "s_nop 0\n", "s_nop 0\n")
+PAIR(p_nop3_nop3, "s_nop 3\n", "s_nop 3\n")
+PAIR(p_mfma2salu_same, MFV "s_add_u32 s40, s41, 1\n s_add_u32 s42, s41, 1\n", MFV "s_add_u32 s40, s41, 1\n s_add_u32 s42, s41, 1\n")
+PAIR(p_mfma4salu_same, MFV "s_add_u32 s40, s41, 1\n s_add_u32 s42, s41, 1\n s_add_u32 s40, s41, 1\n s_add_u32 s42, s41, 1\n", MFV "s_add_u32 s40, s41, 1\n s_add_u32 s42, s41, 1\n s_add_u32 s40, s41, 1\n s_add_u32 s42, s41, 1\n")
+PAIR(p_mfmavalu_same, MFV "v_add_u32 v104, v105, v106\n", MFV "v_add_u32 v104, v105, v106\n")
+PAIR(p_mfmamul_same, MFV "v_mul_f64 v[104:105], %1, %2\n", MFV "v_mul_f64 v[104:105], %1, %2\n")
+PAIR(p_mfma2mul_same, MFV "v_mul_f64 v[104:105], %1, %2\n v_mul_f64 v[106:107], %1, %2\n", MFV "v_mul_f64 v[104:105], %1, %2\n v_mul_f64 v[106:107], %1, %2\n")
+// dependent chains: matrix result -> wait states -> multiply -> wait states -> matrix operand
+#define DEP "v_mfma_f64_4x4x4_4b_f64 v[100:101], %1, %2, 0\n s_nop 5\n v_mul_f64 v[102:103], v[100:101], %2\n s_nop 1\n v_mfma_f64_4x4x4_4b_f64 v[104:105], %1, v[102:103], 0\n s_nop 5\n v_mul_f64 v[106:107], v[104:105], %2\n s_nop 1\n"
+PAIR(p_dep_dep, DEP, DEP)
+PAIR(p_dep_idle, DEP, "s_nop 0\n")
+// two groups' worth of the same chain interleaved (what G = 2 gives a wave)
+#define DEP2 "v_mfma_f64_4x4x4_4b_f64 v[100:101], %1, %2, 0\n v_mfma_f64_4x4x4_4b_f64 v[102:103], %1, %3, 0\n s_nop 4\n v_mul_f64 v[100:101], v[100:101], %2\n v_mul_f64 v[102:103], v[102:103], %2\n s_nop 0\n v_mfma_f64_4x4x4_4b_f64 v[104:105], %1, v[100:101], 0\n v_mfma_f64_4x4x4_4b_f64 v[106:107], %1, v[102:103], 0\n s_nop 4\n v_mul_f64 v[104:105], v[104:105], %2\n v_mul_f64 v[106:107], v[106:107], %2\n s_nop 0\n"
+PAIR(p_dep2_dep2, DEP2, DEP2)
+PAIR(p_dep2_idle, DEP2, "s_nop 0\n")
+PAIR(p_setpc_setpc, "s_getpc_b64 s[40:41]\n s_add_u32 s40, s40, 16\n s_addc_u32 s41, s41, 0\n s_setpc_b64 s[40:41]\n", "s_getpc_b64 s[40:41]\n s_add_u32 s40, s40, 16\n s_addc_u32 s41, s41, 0\n s_setpc_b64 s[40:41]\n")
+PAIR(p_dsread_dsread, "ds_read_b128 v[104:107], %4\n", "ds_read_b128 v[104:107], %4\n")
+PAIR(p_dswrite_dswrite, "ds_write_b128 %4, v[104:107]\n", "ds_write_b128 %4, v[104:107]\n")
+// index mode around the matrix instructions, as the loops use it
+#define IDX "s_mov_b32 s42, 0\n s_set_gpr_idx_on s42, gpr_idx(SRC0)\n v_mfma_f64_4x4x4_4b_f64 v[100:101], v[104:105], %1, 0\n v_mfma_f64_4x4x4_4b_f64 v[102:103], v[104:105], %1, 0\n s_set_gpr_idx_off\n"
+PAIR(p_idx_idx, IDX, IDX)
+PAIR(p_idx_idle, IDX, "s_nop 0\n")
+
 int main() {
   long long* out; double* sink; hipMalloc(&out, 16); hipMalloc(&sink, 256 * 512 * 8);
 #define RUN(k, n) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -138,6 +163,8 @@ int main() {
 #define RUNP(k) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     hipLaunchKernelGGL(k, dim3(256), dim3(512), 150 * 1024, 0, out, sink); long long c[2]; hipMemcpy(c, out, 16, hipMemcpyDeviceToHost); \
     printf("%-20s %7.2f | %7.2f cycles per repetition (two waves per SIMD: first text | second text)\n", #k, c[0] / 1024.0, c[1] / 1024.0); }
+  RUNP(p_salu_salu) RUNP(p_nop_nop) RUNP(p_nop3_nop3) RUNP(p_mfma2salu_same) RUNP(p_mfma4salu_same) RUNP(p_mfmavalu_same) RUNP(p_mfmamul_same) RUNP(p_mfma2mul_same)
+  RUNP(p_dep_dep) RUNP(p_dep_idle) RUNP(p_dep2_dep2) RUNP(p_dep2_idle) RUNP(p_setpc_setpc) RUNP(p_dsread_dsread) RUNP(p_dswrite_dswrite) RUNP(p_idx_idx) RUNP(p_idx_idle)
   RUNP(p_mfma_mfma) RUNP(p_mfma_valu32) RUNP(p_mfma_mul64) RUNP(p_mfma_salu) RUNP(p_mfma_dsread128) RUNP(p_mfma_dswrite128)
   RUNP(p_valu32_valu32) RUNP(p_mul64_mul64) RUNP(p_mul64_valu32) RUNP(p_branch_branch) RUNP(p_mfma_branch) RUNP(p_mix_mix) RUNP(p_mix_idle)
     return 0;

@@ -188,6 +188,7 @@ struct LdsPlan {
   int grad_rows = 0;   // (walk_pipe_kernel) partial gradient rows per tree: one per run; 0 = one per tile
   int whole_trees = 0; // (walk_pipe_kernel) the first so many trees are walked by one workgroup each, all tiles
   int slots = 0;       // (walk_pipe_kernel) vectors a wave keeps in LDS
+  int layout = 0;      // (walk_pipe_kernel) 0 / 1: one wave per SIMD (1: the wide loops, 49 taxa and more), 2: two waves per SIMD
 };
 LdsPlan PlanLds(const BatchDims& d);
 size_t LdsScheduleInts(const BatchDims& d);
@@ -204,8 +205,11 @@ LdsPlan PlanPipe(const BatchDims& d);
 // A batch may be walked as two classes of trees, each with its own plan (trees with few cherries keep more
 // vectors per wave and leave room for fewer pattern groups): the plan for `tree_count` trees that keep at most
 // `slots` vectors, the most vectors that fit beside G groups, and a tree's count from its cherries.
-LdsPlan PlanPipeClass(const BatchDims& d, int tree_count, int slots, int force_groups);
-int PipeMaxSlots(const BatchDims& d, int G);
+constexpr int kPipePlanAuto = 0, kPipePlanTwoWaves = 2;  // (LdsPlan::layout as PlanPipeClass takes it)
+LdsPlan PlanPipeClass(const BatchDims& d, int tree_count, int slots, int force_groups, int layout = kPipePlanAuto);
+int PipeMaxSlots(const BatchDims& d, int G, int layout = kPipePlanAuto);
+// two waves per SIMD (round 4): trees of up to 28 taxa, one image per branch (reversible form), 256 registers per wave
+bool PipeTwoApplies(const BatchDims& d);
 int PipeSlotsOfTree(const BatchDims& d, int cherries);
 struct PipeClass {
   int tree_count;          // trees of this launch
@@ -218,8 +222,12 @@ struct PipeClass {
 size_t PipeScheduleInts(const BatchDims& d);
 size_t PipeMaskInts(const BatchDims& d, const LdsPlan& plan);
 void LaunchPipeMasks(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, uint32_t* masks, hipStream_t stream);
+// split_slots > 0: the batch is walked as two classes -- class A's trees (at most split_slots stored vectors and, when
+// class_a is given, flagged there: a device array of one byte per tree) get their step tables for split_groups pattern
+// groups per wave in layout split_layout, the others for `plan`
 void LaunchPipePrepare(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream,
-                       bool beside_traversal, int split_slots, int split_groups = 4);
+                       bool beside_traversal, int split_slots, int split_groups = 4, int split_layout = kPipePlanAuto,
+                       const uint8_t* class_a = nullptr);
 // deriv_mode 1: the edge derivatives use d r_c / d shape in place of r_c (site-model pass)
 void LaunchWalkPipe(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient, int want_site,
                     int deriv_mode, hipStream_t stream, const PipeClass& cls);

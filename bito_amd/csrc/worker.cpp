@@ -324,6 +324,37 @@ bool TreeFitsReversibleForm(const ModelSpec& m, int32_t rooted, int32_t node_cou
 
 namespace {
 
+// Does the batch being staged want the reversible-form guard evaluated tree by tree?  (The two-wave form of
+// walk_pipe_kernel: up to 28 taxa, 1 / 2 / 4 rate categories; kernels.hpp.)
+bool TracksTreeGuard(const Worker* e, int rooted, const double* rates) {
+  (void)rooted;
+  (void)rates;
+  BatchDims probe{};
+  probe.taxon_count = e->n;
+  probe.category_count = e->spec.category_count;
+  return e->spec.state_count == 4 && PipeTwoApplies(probe) &&
+         ((e->pipe_two != 0 && e->kernel_choice == BITO_AMD_KERNEL_AUTO) || e->kernel_choice == BITO_AMD_KERNEL_LDS_PIPE2);
+}
+
+// ok[t] = may tree t take the one-image-per-branch form (TreeFitsReversibleForm), for t in [t0, t1); consecutive trees
+// with the same parameter row share the rate matrix's figure
+void TreeGuardRange(const ModelSpec& m, const double* branch_lengths, const double* rates, const double* params, size_t t0,
+                    size_t t1, size_t M, uint8_t* ok) {
+  const size_t pc = (size_t)m.param_count;
+  const double bound = PipeReversibleMinBranch();
+  const double* last_row = nullptr;
+  double q_factor = 1.0;
+  for (size_t t = t0; t < t1; t++) {
+    const double* row = (params && pc) ? params + t * pc : nullptr;
+    if (t == t0 || (row && std::memcmp(row, last_row, pc * sizeof(double)) != 0)) {
+      q_factor = std::min(MinOffDiagonalRate(m, row, 1) / kPipeReversibleRateScale, 1.0);
+      last_row = row;
+    }
+    const double t_min = MinBranchLength(branch_lengths + t * M, rates ? rates + t * (M - 1) : nullptr, 1, M);
+    ok[t] = t_min * q_factor >= bound;
+  }
+}
+
 // Bytes a pass may spend on its PLV arena.  A caller's cap (bito_amd_engine_spec.arena_bytes) holds as given.  The
 // default -- 3/4 of the HBM that was free when the worker was created -- is each worker's own figure, and an engine
 // keeps up to eight lane workers per device slot (and may name one GPU in several slots): when the pass wants more
@@ -486,6 +517,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   switch (e->kernel_choice) {
     case BITO_AMD_KERNEL_HBM_ARENA: use_tree = use_lds = false; break;
     case BITO_AMD_KERNEL_LDS_PIPE:
+    case BITO_AMD_KERNEL_LDS_PIPE2:
       use_tree = false;
       use_pipe = pplan.groups > 0 && !rescaling && pipe_branches_ok;
       if (!use_pipe) return Fail(e, BITO_AMD_ERR_STATE, "the pipelined LDS kernel was forced but cannot run this batch (needs 1, 2 or 4 rate categories, no rescaling, a tree whose stored vectors fit in 160 KB of LDS, and from 39 taxa on branch lengths of 9e-7 and more)");
@@ -524,6 +556,60 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   // walk_pipe_kernel: when the batch as a whole cannot have four pattern groups per wave (its tree with the
   // fewest cherries keeps too many vectors) but many of its trees could, they are walked in a launch of their own
   Worker::PipeSplit& split = e->pipe_split;
+  // Two waves per SIMD (up to 28 taxa): the trees that hold the reversible-form guard and keep few enough vectors for
+  // two pattern groups per wave beside eight waves form class A; if that is every tree the batch is one launch of that
+  // form, otherwise the rest runs on the one-wave kernel behind it.
+  const bool two_wanted = use_pipe && PipeTwoApplies(d) && (int)e->tree_rev_ok.size() == T && (int)e->tree_cherries.size() == T &&
+                          ((e->pipe_two != 0 && e->kernel_choice == BITO_AMD_KERNEL_AUTO) || e->kernel_choice == BITO_AMD_KERNEL_LDS_PIPE2);
+  if (use_pipe && !split.built && two_wanted) {
+    // (two pattern groups per wave when three quarters of the trees and more leave room for them, else one)
+    for (int groups : {2, 1}) {
+      const int room = PipeMaxSlots(d, groups, kPipePlanTwoWaves);
+      if (room <= 0) continue;
+      std::vector<int32_t> a, bb;
+      int need_a = 1, need_b = 1;
+      for (int t = 0; t < T; t++) {
+        const int need = PipeSlotsOfTree(d, e->tree_cherries[t]);
+        const bool in_a = need <= room && e->tree_rev_ok[t];
+        (in_a ? a : bb).push_back(t);
+        (in_a ? need_a : need_b) = std::max(in_a ? need_a : need_b, need);
+      }
+      if ((int)a.size() * 4 < 3 * T) continue;
+      const LdsPlan pa = PlanPipeClass(d, (int)a.size(), need_a, groups, kPipePlanTwoWaves);
+      if (pa.groups != groups) continue;
+      if (bb.empty()) {
+        split.built = true;
+        split.all_two = true;
+        split.plan_a = pa;
+        break;
+      }
+      const LdsPlan pb = PlanPipeClass(d, (int)bb.size(), need_b, 0);
+      if (pb.groups <= 0) continue;
+      split.built = split.active = split.flagged = true;
+      split.count_a = (int)a.size();
+      split.count_b = (int)bb.size();
+      split.slots_a = room;
+      split.groups_a = pa.groups;
+      split.layout_a = kPipePlanTwoWaves;
+      split.plan_a = pa;
+      split.plan_b = pb;
+      split.order_host = a;
+      split.order_host.insert(split.order_host.end(), bb.begin(), bb.end());
+      // the order list, and behind it one byte per tree: class A (the step tables are built per class)
+      const size_t ints = (size_t)T + ((size_t)T + 3) / 4;
+      if (ints > e->pipe_order.capacity) HIP_TRY(e, hipStreamSynchronize(WalkStream(e)));
+      HIP_TRY(e, e->pipe_order.Reserve(ints));
+      HIP_TRY(e, e->pin_order.Reserve(ints * sizeof(int32_t)));
+      std::memcpy(e->pin_order.ptr, split.order_host.data(), (size_t)T * sizeof(int32_t));
+      uint8_t* flags = reinterpret_cast<uint8_t*>(static_cast<int32_t*>(e->pin_order.ptr) + T);
+      std::memset(flags, 0, (size_t)T);
+      for (int32_t t : a) flags[t] = 1;
+      HIP_TRY(e, hipMemcpyAsync(e->pipe_order.ptr, e->pin_order.ptr, ints * sizeof(int32_t), hipMemcpyHostToDevice, SetupStream(e)));
+      break;
+    }
+  }
+  if (e->kernel_choice == BITO_AMD_KERNEL_LDS_PIPE2 && use_pipe && !(split.all_two || (split.active && split.layout_a == kPipePlanTwoWaves)))
+    return Fail(e, BITO_AMD_ERR_STATE, "the two-wave form of the pipelined LDS kernel was forced but cannot run this batch (needs up to 28 taxa, 1, 2 or 4 rate categories, no rescaling, and for at least three quarters of the trees: branch lengths that hold the reversible-form guard and stored vectors that fit beside two pattern groups per wave)");
   if (use_pipe && !split.built) {
     split.built = true;
     split.active = false;
@@ -576,6 +662,8 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   }
   const bool two_classes = use_pipe && split.active;
   if (two_classes) plan = split.plan_b;  // (class B's plan is the one the shared buffers and tables are sized by)
+  if (use_pipe && split.all_two) plan = split.plan_a;
+  const uint8_t* class_flags = (two_classes && split.flagged) ? reinterpret_cast<const uint8_t*>(e->pipe_order.ptr + T) : nullptr;
   const int tiles = use_tree ? tplan.tiles : (use_lds ? std::max(plan.tiles, two_classes ? split.plan_a.tiles : 0) : HbmWalkTiles(d));
   HIP_TRY(e, e->part_ll.Reserve((size_t)T * tiles));
   // partial gradient rows per tree: one per tile (LDS kernels), per run of tiles (pipelined LDS kernel), per wave (HBM kernel)
@@ -594,7 +682,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
       HIP_TRY(e, hipMemsetAsync(e->pipe_queue.ptr, 0, 2 * sizeof(int32_t), SetupStream(e)));
     }
     if (use_pipe) {  // the tile masks depend on the alignment and the plan only: built once
-      const long long key = (long long)plan.groups | ((long long)plan.tiles << 8);
+      const long long key = (long long)plan.groups | ((long long)plan.layout << 4) | ((long long)plan.tiles << 8);
       if (e->pipe_masks_key != key) {
         HIP_TRY(e, hipStreamSynchronize(WalkStream(e)));  // (a traversal may still be reading the old ones)
         HIP_TRY(e, e->pipe_masks.Reserve(PipeMaskInts(d, plan)));
@@ -604,7 +692,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     }
     bool build_masks_a = false;
     if (two_classes) {
-      const long long key = (long long)split.plan_a.groups | ((long long)split.plan_a.tiles << 8);
+      const long long key = (long long)split.plan_a.groups | ((long long)split.plan_a.layout << 4) | ((long long)split.plan_a.tiles << 8);
       if (e->pipe_masks_a_key != key) {
         HIP_TRY(e, hipStreamSynchronize(WalkStream(e)));
         HIP_TRY(e, e->pipe_masks_a.Reserve(PipeMaskInts(d, split.plan_a)));
@@ -635,7 +723,8 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
         e->inputs_on_host = false;
       }
       if (use_pipe) {
-        LaunchPipePrepare(d, b, plan, prep, busy, two_classes ? split.slots_a : 0, two_classes ? split.groups_a : 4);
+        LaunchPipePrepare(d, b, plan, prep, busy, two_classes ? split.slots_a : 0, two_classes ? split.groups_a : 4,
+                          two_classes ? split.layout_a : kPipePlanAuto, class_flags);
         if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);
         if (build_masks_a) LaunchPipeMasks(d, b, split.plan_a, reinterpret_cast<uint32_t*>(e->pipe_masks_a.ptr), prep);
       } else {
@@ -673,6 +762,15 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     else LaunchWalkLds(d, b, plan, want_gradient, want_site && want_gradient && deriv_mode == 0, walk);
     if (e->timing) HIP_TRY(e, hipEventRecord(ev1, walk));
     e->kernel_name = use_tree ? "walk_tree_kernel" : (use_pipe ? "walk_pipe_kernel" : "walk_lds_kernel");
+    if (use_pipe) {
+      auto form = [](const LdsPlan& p, int trees) {
+        return std::to_string(trees) + " trees " + (p.layout == kPipePlanTwoWaves ? "two waves" : "one wave") + " per SIMD x " +
+               std::to_string(p.groups) + " pattern groups";
+      };
+      e->kernel_form = two_classes ? form(split.plan_a, split.count_a) + " + " + form(split.plan_b, split.count_b) : form(plan, T);
+    } else {
+      e->kernel_form.clear();
+    }
     e->site_ready = use_lds && want_gradient && deriv_mode == 0 && want_site;
     // (walk_pipe_kernel's partial log-likelihoods are per run of tiles as well)
     // (one-class launches: the whole-tree units are trees 0 .. whole_trees-1, all written by the traversal)
@@ -819,6 +917,7 @@ int WorkerCreate(int32_t device_id, uint64_t arena_bytes, const char* substituti
   }
   if (const char* serial = std::getenv("BITO_AMD_SERIAL_SETUP")) e->serial_setup = std::atoi(serial);
   if (const char* direct = std::getenv("BITO_AMD_PIPE_DIRECT")) e->pipe_direct = std::atoi(direct) != 0;
+  if (const char* two = std::getenv("BITO_AMD_PIPE_TWO")) e->pipe_two = std::atoi(two);
   for (int i = 0; i < Worker::kSets; i++) {
     if ((hrc = hipEventCreateWithFlags(&e->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess ||
         (hrc = hipEventCreateWithFlags(&e->ev_walk_done[i], hipEventDisableTiming)) != hipSuccess)
@@ -902,6 +1001,8 @@ int WorkerStageBegin(Worker* e, int32_t tree_count, int32_t rooted, int32_t node
     return Fail(e, BITO_AMD_ERR_BAD_ARG, "params is NULL but the model has parameters");
   if (int rc = ValidateTreeShape(e, rooted, node_count)) return rc;
   e->tree_cherries.assign((size_t)tree_count, 0);
+  if (TracksTreeGuard(e, rooted, rates)) e->tree_rev_ok.assign((size_t)tree_count, 0);
+  else e->tree_rev_ok.clear();
   e->pipe_split = Worker::PipeSplit{};
   HIP_TRY(e, hipSetDevice(e->device));
   // A set-up kernel of an earlier, still running pass may be reading the input buffers, an earlier copy the staging
@@ -983,6 +1084,9 @@ void WorkerStageFill(Worker* e, int32_t t0, int32_t t1, StagePart* out) {
     out->min_branch = MinBranchLength(st.branch_lengths + a * M, st.rooted && st.rates ? st.rates + a * (M - 1) : nullptr, count, M);
     out->min_rate = MinOffDiagonalRate(e->spec, st.params ? st.params + a * pc : nullptr, count);
   }
+  if (!e->tree_rev_ok.empty())  // (small trees: the two-wave form, tree by tree)
+    TreeGuardRange(e->spec, st.branch_lengths, st.rooted && st.rates ? st.rates : nullptr, st.params, a, a + count, M,
+                   e->tree_rev_ok.data());
 }
 
 int WorkerStageEnd(Worker* e, const StagePart* parts, int part_count) {
@@ -1128,6 +1232,7 @@ int WorkerUpdate(Worker* e, const double* branch_lengths, const double* params) 
   HIP_TRY(e, hipSetDevice(e->device));
   HIP_TRY(e, hipStreamSynchronize(e->prep_stream));  // (see WorkerUpload)
   const size_t T = e->dims.tree_count;
+  bool h_params_keep = false;
   if (params && e->spec.param_count > 0) {
     int rc = ValidateParams(e, (int)T, params);
     if (rc) return rc;
@@ -1136,11 +1241,22 @@ int WorkerUpdate(Worker* e, const double* branch_lengths, const double* params) 
     if (e->spec.state_count != 4 || e->kernel_choice == BITO_AMD_KERNEL_GENERAL)
       if ((rc = UploadModelIndex(e, (int)T, params))) return rc;
     if (e->n > kPipeExactTaxa) e->min_rate = MinOffDiagonalRate(e->spec, params, T);
+    h_params_keep = true;
   }
   if (branch_lengths) {
     HIP_TRY(e, hipMemcpyAsync(e->branch_in.ptr, branch_lengths, T * e->dims.in_node_count * sizeof(double), hipMemcpyHostToDevice, e->stream));
     // (rates, when a batch has them, stay on the device: unknown here, so no claim about the effective lengths)
     e->min_branch = (e->n > kPipeExactTaxa && !e->has_rates) ? MinBranchLength(branch_lengths, nullptr, T, (size_t)e->dims.in_node_count) : 0.0;
+  }
+  if (!e->tree_rev_ok.empty() && (branch_lengths || h_params_keep)) {
+    // the two-wave form's classes follow the new values.  (Only the array that came with this call is known here: with
+    // new branch lengths AND the batch's parameter rows the guard is re-evaluated tree by tree; otherwise -- rates on
+    // the device, or one of the two arrays missing -- no tree is claimed to hold it and the batch runs on the one-wave kernel.)
+    if (branch_lengths && !e->has_rates && (params || e->spec.param_count == 0))
+      TreeGuardRange(e->spec, branch_lengths, nullptr, params, 0, T, (size_t)e->dims.in_node_count, e->tree_rev_ok.data());
+    else
+      std::fill(e->tree_rev_ok.begin(), e->tree_rev_ok.end(), (uint8_t)0);
+    e->pipe_split = Worker::PipeSplit{};
   }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return BITO_AMD_OK;

@@ -153,13 +153,25 @@ struct Worker {
   // pattern groups per wave (class A), and the others (class B) -- one tree with few cherries would otherwise
   // halve the groups of the whole batch
   std::vector<int32_t> tree_cherries;  // per tree of the resident batch (counted while it is validated)
+  // Two waves per SIMD (round 4, trees of up to 28 taxa): that form keeps one image per branch, i.e. the reversible form
+  // of the pre-order recursion, which a tree may take only when its shortest branch times its smallest off-diagonal
+  // rate clears the bound of DESIGN.md section 3 -- decided PER TREE while the batch is staged (the trees that do not, and
+  // the ones that keep too many vectors, form class B and run on the one-wave kernel with (P, P^T) pairs).
+  // AUTO does not take it: measured on config 3 it is 13 % SLOWER than one wave per SIMD with four groups (4.23 against
+  // 3.75 ms per 6400 trees; profiles/r4_pipe_two_waves.md has the numbers and the reasons) -- it runs when the kernel is
+  // pinned (BITO_AMD_KERNEL_LDS_PIPE2) or with BITO_AMD_PIPE_TWO=1 in the environment.
+  int pipe_two = 0;                    // 1: AUTO takes the two-wave form where it applies (BITO_AMD_PIPE_TWO)
+  std::vector<uint8_t> tree_rev_ok;    // per tree of the resident batch: the guard holds (empty: not evaluated)
   struct PipeSplit {
     bool built = false, active = false;
-    int count_a = 0, count_b = 0, slots_a = 0, groups_a = 4;
+    bool all_two = false;  // the whole batch runs in the two-wave form (plan_a is its plan)
+    int count_a = 0, count_b = 0, slots_a = 0, groups_a = 4, layout_a = 0;
+    bool flagged = false;  // class A is given by a per-tree flag array (behind the order list), not by the slot count alone
     LdsPlan plan_a{}, plan_b{};
     std::vector<int32_t> order_host;
   } pipe_split;
-  DeviceBuffer<int32_t> pipe_order;    // class A's tree ids, then class B's
+  std::string kernel_form;             // how the last walk_pipe_kernel pass ran (waves per SIMD, groups, classes)
+  DeviceBuffer<int32_t> pipe_order;    // class A's tree ids, then class B's (then, as bytes, a flag per tree: class A)
   DeviceBuffer<int32_t> pipe_masks_a;  // packed tip masks for class A's plan
   long long pipe_masks_a_key = -1;
   DeviceBuffer<double> branch, mats, mats2, mats3, images, arena, part_ll, part_grad,

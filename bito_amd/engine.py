@@ -428,6 +428,10 @@ class Engine:
     def kernel_name(self) -> str:
         return _capi.lib().bito_amd_engine_kernel_name(self._h).decode()
 
+    def kernel_form(self) -> str:
+        """how the last walk_pipe_kernel pass ran (waves per SIMD, pattern groups per wave, classes); diagnostics"""
+        return _capi.lib().bito_amd_engine_kernel_form(self._h).decode()
+
     def kernel_timing(self, enable: bool):
         self._check(_capi.lib().bito_amd_engine_kernel_timing(self._h, int(enable)))
 

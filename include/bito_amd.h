@@ -55,7 +55,10 @@ extern "C" {
 #define BITO_AMD_KERNEL_GENERAL 4  /* gs_walk_kernel: the general-state-count kernels (any model; the only
                                       choice for the 61-state codon model) */
 #define BITO_AMD_KERNEL_LDS_PIPE 5 /* walk_pipe_kernel: walk_lds_kernel's mapping, child messages in LDS, both
-                                      tree loops hand-scheduled (software-pipelined) gfx950 assembly */
+                                      tree loops hand-scheduled (software-pipelined) gfx950 assembly; one wave per SIMD */
+#define BITO_AMD_KERNEL_LDS_PIPE2 6 /* walk_pipe_kernel with two waves per SIMD (up to 28 taxa; trees that do not hold the
+                                       reversible-form guard, or keep too many vectors, run on the one-wave form behind
+                                       the others: at most a quarter of the batch) */
 
 typedef struct bito_amd_engine bito_amd_engine;
 
@@ -306,6 +309,9 @@ double bito_amd_engine_kernel_span_sum(const bito_amd_engine *e);
 int bito_amd_engine_read_general_model(bito_amd_engine *e, int32_t tree, double *out, size_t capacity);
 /* Name of the traversal kernel the last run used (for matching rocprof rows). */
 const char *bito_amd_engine_kernel_name(const bito_amd_engine *e);
+/* how the last walk_pipe_kernel pass ran: trees, waves per SIMD and pattern groups per wave of each class ("" for the
+ * other kernels); diagnostics */
+const char *bito_amd_engine_kernel_form(const bito_amd_engine *e);
 /* Library/device info string, e.g. "bito_amd 0.1 gfx950 256CU". */
 const char *bito_amd_version(void);
 

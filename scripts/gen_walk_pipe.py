@@ -336,22 +336,46 @@ class Loops:
     WIDE_IMAGE_REGS = 252  # (the wide kernels carry at most two pattern groups: the compiler needs no AGPR there, checked at build time)
     assert WIDE_REV_BASE + 2 * WIDE_MAX_INNER <= WIDE_IMAGE_REGS
 
-    def __init__(self, G, exact=True, wide=False):
+    #   * up to 28 taxa, TWO WAVES PER SIMD (round 4): the one-image layout inside 256 registers per wave -- P of a tip's
+    #     branch at a[2 tip], of an internal branch at a[TWO_REV_BASE + 2 j]: 4 n - 4 = 108 AGPRs at 28 taxa, which leaves
+    #     148 VGPRs: 28 mask registers, the loops' own 102 beside two pattern groups, and v0..v15 for the compiler.  The
+    #     workgroup is eight waves, so a tile's mask rows keep a stride of 32 dwords (a wave copies its rows as whole
+    #     dwords per lane) of which a lane loads the first 28.  Why: a lone wave's vector, LDS and scalar instructions
+    #     never overlap its own matrix instructions; a sibling wave's do (profiles/r2_issue_costs.txt, p_mix_mix).
+    TWO_MAX_TIPS = 28
+    TWO_TIP_SLOTS = 32
+    TWO_REV_BASE = 2 * TWO_MAX_TIPS
+    TWO_MAX_INNER = TWO_MAX_TIPS - 2
+    TWO_IMAGE_REGS = TWO_REV_BASE + 2 * TWO_MAX_INNER
+    TWO_VBASE = 16
+    TWO_VLIMIT = 256 - TWO_IMAGE_REGS
+    TWO_WAVES = 8
+
+    def __init__(self, G, exact=True, wide=False, two=False):
         self.G = G
         self.exact = exact  # image layout the pre-order loop is generated for (the only place the loops differ)
         self.wide = wide
+        self.two = two
+        self.waves = 4
+        self.vbase, vlimit = VBASE, VLIMIT
+        self.image_regs = self.WIDE_IMAGE_REGS if wide else self.IMAGE_REGS
         if wide:  # (instance attributes shadow the class's: every use below goes through self)
             assert G < 4 and not exact
             self.MAX_TIPS, self.REV_BASE, self.MAX_INNER = self.WIDE_MAX_TIPS, self.WIDE_REV_BASE, self.WIDE_MAX_INNER
+        if two:
+            assert G < 4 and not exact and not wide
+            self.MAX_TIPS, self.REV_BASE, self.MAX_INNER = self.TWO_MAX_TIPS, self.TWO_REV_BASE, self.TWO_MAX_INNER
+            self.vbase, vlimit, self.image_regs, self.waves = self.TWO_VBASE, self.TWO_VLIMIT, self.TWO_IMAGE_REGS, self.TWO_WAVES
         self.e = None
-        V = Alloc(VBASE, VLIMIT, "VGPR")
+        V = Alloc(self.vbase, vlimit, "VGPR")
         S = Alloc(SBASE, SLIMIT, "SGPR")
         g2 = lambda name: [V.get(2, f"{name}{g}", 2) for g in range(G)]
         # persistent
         # packed masks of tip t (byte g = mask of this lane's pattern in group g): 32 slots beside four groups'
         # registers, 48 beside fewer
-        self.TIP_SLOTS = self.WIDE_TIP_SLOTS if wide else (32 if G == 4 else 48)
-        self.TMV = V.get(self.TIP_SLOTS, "TMV", 4)
+        self.TIP_SLOTS = self.WIDE_TIP_SLOTS if wide else (self.TWO_TIP_SLOTS if two else (32 if G == 4 else 48))
+        self.TIP_REGS = self.TWO_MAX_TIPS if two else self.TIP_SLOTS  # (the mask registers a lane holds; TIP_SLOTS: its row in LDS)
+        self.TMV = V.get(self.TIP_REGS, "TMV", 4)
         self.U = g2("U")                      # pre-order partial of the step's node
         self.ONE = V.get(2, "ONE", 2)
         self.TP = [[V.get(2, f"TP{t}_{g}", 2) for g in range(G)] for t in range(4)]  # tip operands (lo word stays 0)
@@ -425,6 +449,8 @@ class Loops:
         if os.environ.get("PIPE_NO_MFMA"):  # timing experiment: results are wrong
             self.e.ins(f"v_mov_b64 {vp(dst)}, {vp(b)}", "valu", reads=[b, b + 1], writes=[dst, dst + 1])
             return
+        if os.environ.get("PIPE_DROP_MFMA"):  # timing experiment (round 4's ablation table): no matrix instruction at all
+            return
         if isinstance(a, tuple):
             assert self.idx_mode == "SRC0"
             self.e.ins(f"v_mfma_f64_4x4x4_4b_f64 {vp(dst)}, {ap(a[1])}, {vp(b)}, 0", "mfma", reads=[b, b + 1], writes=[dst, dst + 1],
@@ -439,6 +465,11 @@ class Loops:
 
     def valu(self, text, reads, writes, indexed_ok=False):
         assert self.idx_mode is None or indexed_ok, f"VALU inside an index-mode region: {text}"
+        # timing experiments (results are wrong): no FP64 vector arithmetic / no tip operands (the address arithmetic stays)
+        if os.environ.get("PIPE_DROP_F64") and text.startswith(("v_mul_f64", "v_fma_f64", "v_mov_b64")):
+            return
+        if os.environ.get("PIPE_DROP_TIPS") and "sdwa" in text:
+            return
         self.e.ins(text, "valu", reads=list(reads), writes=list(writes), indexed=self.idx_mode is not None)
 
     def vmul(self, dst, a, b):
@@ -535,7 +566,7 @@ class Loops:
             for g in range(self.G):
                 hi = self.TP[slot_tip][g] + 1
                 self.valu(f"v_lshlrev_b32_sdwa v{hi}, %[sh0], v{self.TMV} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "
-                          f"src1_sel:BYTE_{g}", list(range(self.TMV, self.TMV + self.TIP_SLOTS)), [hi], indexed_ok=True)
+                          f"src1_sel:BYTE_{g}", list(range(self.TMV, self.TMV + self.TIP_REGS)), [hi], indexed_ok=True)
         if requests and not leave_on:
             self.idx_off()
 
@@ -545,7 +576,7 @@ class Loops:
         self.v32(f"v_sub_u32 v{k}, 30, %[sh0]", [], [k])
         self.v32(f"v_mov_b32 v{self.AD[4]}, 0x01010101", [], [self.AD[4]])
         self.v32(f"v_lshlrev_b32 v{k}, v{k}, v{self.AD[4]}", [k, self.AD[4]], [k])
-        for t in range(min(self.TIP_SLOTS, self.MAX_TIPS)):
+        for t in range(min(self.TIP_REGS, self.MAX_TIPS)):
             self.v32(f"v_and_b32 v{self.TMV + t}, v{k}, v{self.TMV + t}", [k, self.TMV + t], [self.TMV + t])
 
     # ---- edge sums: 64 lanes -> the gradient row entries of the four blocks (rate categories) ----
@@ -659,7 +690,7 @@ class Loops:
             for g in range(G):
                 self.v32(f"v_mov_b32 v{self.TP[t][g]}, 0", [], [self.TP[t][g]])
         # packed masks of tip t into TMV[t]: this lane's tip slots are consecutive bytes
-        for k in range(self.TIP_SLOTS // 4):
+        for k in range(self.TIP_REGS // 4):
             self.mem(f"ds_read_b128 v[{self.TMV + 4 * k}:{self.TMV + 4 * k + 3}], %[tiprow] offset:{16 * k}",
                      writes=list(range(self.TMV + 4 * k, self.TMV + 4 * k + 4)))
         self.e.control(f"s_getpc_b64 s[{self.BASE[0]}:{self.BASE[0] + 1}]")
@@ -810,6 +841,8 @@ class Loops:
         e = self.e
         e.comment(f"post-order loop, G = {G}")
         names = [v[0] for v in self.POST_VARIANTS]
+        if os.environ.get("PIPE_EMPTY_LOOPS"):  # timing experiment: what a tile costs OUTSIDE the two loops
+            self.branch(None, self.L("skip"))
         self.loop_entry(names, two_ahead=True)
         self.go_first(delayed_store=True)
         for parity in (0, 1):
@@ -820,6 +853,8 @@ class Loops:
             self.branch(None, self.L("root"))
         self.label(self.L("root"))
         self.wait(vm=0, lgkm=0)
+        if os.environ.get("PIPE_EMPTY_LOOPS"):
+            self.label(self.L("skip"))
         for g in range(G):
             self.e.ins(f"v_mov_b64 %[r{g}], {vp(self.X[0][g])}", "valu", reads=[self.X[0][g], self.X[0][g] + 1])
         return e
@@ -963,6 +998,8 @@ class Loops:
         e = self.e
         e.comment(f"pre-order loop, G = {G}")
         names = [v[0] for v in self.PRE_VARIANTS] + ["cc", "cc"]  # (body indices 8, 9 do not occur)
+        if os.environ.get("PIPE_EMPTY_LOOPS"):
+            self.branch(None, self.L("skip"))
         self.loop_entry(names[:10])
         self.e.ins(f"v_mov_b64 {vp(self.ONE)}, 1.0", "valu", writes=[self.ONE, self.ONE + 1])
         for s in (0, 1):
@@ -988,6 +1025,8 @@ class Loops:
         self.flush_stage1(self.ES[0], self.ES[1])
         self.flush_stage3()
         self.wait(vm=0, lgkm=0)
+        if os.environ.get("PIPE_EMPTY_LOOPS"):
+            self.label(self.L("skip"))
         return e
 
     # =============================== image loader ==================================================
@@ -1013,7 +1052,8 @@ class Loops:
                 self.e.control(f"s_cbranch_scc1 {warm}")
             self.mem(f"s_load_dword s{self.TMP[2]}, %[tab], {hex(64 * k)}")
         self.e.label(warm)
-        # global -> LDS: this wave's branches are wave, wave + 4, ...
+        # global -> LDS: this wave's branches are wave, wave + W, ... (W waves per workgroup)
+        W = self.waves
         self.salu(f"s_add_u32 s{s_nb}, %[ntips], %[ninner]")
         self.salu(f"s_lshl_b32 s{s_m0}, %[wave], 10")
         self.salu(f"s_mov_b64 s[{ip}:{ip + 1}], %[img]")
@@ -1022,15 +1062,15 @@ class Loops:
         self.salu(f"s_add_u32 s{s_m0}, s{s_m0}, %[stage_s]")
         self.salu(f"s_mov_b32 s{s_branch}, %[wave]")
         staged = self.L("staged")
-        for k in range((self.MAX_TIPS + self.MAX_INNER + 3) // 4):
+        for k in range((self.MAX_TIPS + self.MAX_INNER + W - 1) // W):
             self.salu(f"s_cmp_ge_u32 s{s_branch}, s{s_nb}")
             self.e.control(f"s_cbranch_scc1 {staged}")
             self.salu(f"s_mov_b32 m0, s{s_m0}")
             self.salu("s_nop 0")
             self.mem(f"global_load_lds_dwordx4 %[lane16], s[{ip}:{ip + 1}]")
-            self.salu(f"s_add_u32 s{s_branch}, s{s_branch}, 4")
-            self.salu(f"s_add_u32 s{s_m0}, s{s_m0}, 4096")
-            self.salu(f"s_add_u32 s{ip}, s{ip}, 4096")
+            self.salu(f"s_add_u32 s{s_branch}, s{s_branch}, {W}")
+            self.salu(f"s_add_u32 s{s_m0}, s{s_m0}, {1024 * W}")
+            self.salu(f"s_add_u32 s{ip}, s{ip}, {1024 * W}")
             self.salu(f"s_addc_u32 s{ip + 1}, s{ip + 1}, 0")
         self.e.label(staged)
         self.wait(vm=0)
@@ -1074,8 +1114,8 @@ def as_macro(name, lines):
 
 
 def clobbers(loops):
-    regs = [f"v{r}" for r in range(VBASE, loops.vnext)] + \
-           [f"a{r}" for r in range(Loops.WIDE_IMAGE_REGS if loops.wide else Loops.IMAGE_REGS)] + \
+    regs = [f"v{r}" for r in range(loops.vbase, loops.vnext)] + \
+           [f"a{r}" for r in range(loops.image_regs)] + \
            [f"s{r}" for r in range(SBASE, loops.snext)]
     return ", ".join(f'"{r}"' for r in regs) + ', "vcc", "scc", "memory"  /* (not m0: clang rejects it on a clobber list as a reserved register; it keeps no value there across a statement) */'
 
@@ -1095,7 +1135,7 @@ def main():
             out.append(as_macro(f"WALK_PIPE_PRE_REV_ASM_G{G}", Loops(G, exact=False).pre_loop().finish()))
         out.append(f"#define WALK_PIPE_CLOBBERS_G{G} {clobbers(loops)}")
         out.append(f"#define WALK_PIPE_TIP_SLOTS_G{G} {loops.TIP_SLOTS}")
-        listing.append(f"G={G}: VGPR v{VBASE}..v{loops.vnext - 1}, AGPR a0..a{Loops.IMAGE_REGS - 1}, SGPR s{SBASE}..s{loops.snext - 1}; "
+        listing.append(f"G={G}: VGPR v{loops.vbase}..v{loops.vnext - 1}, AGPR a0..a{Loops.IMAGE_REGS - 1}, SGPR s{SBASE}..s{loops.snext - 1}; "
                        f"post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
     for G in (1, 2):  # the wide layout: 49 to 56 taxa
         loops = Loops(G, exact=False, wide=True)
@@ -1104,13 +1144,29 @@ def main():
         out.append(as_macro(f"WALK_PIPE_POST_W_ASM_G{G}", post.finish()))
         out.append(as_macro(f"WALK_PIPE_PRE_REV_W_ASM_G{G}", pre.finish()))
         out.append(f"#define WALK_PIPE_CLOBBERS_W_G{G} {clobbers(loops)}")
-        listing.append(f"G={G} wide: VGPR v{VBASE}..v{loops.vnext - 1}; post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
+        listing.append(f"G={G} wide: VGPR v{loops.vbase}..v{loops.vnext - 1}; post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
     out.append(as_macro("WALK_PIPE_LOAD_REV_W_ASM", Loops(1, exact=False, wide=True).load_images(False).finish()))
     out.append(f"#define WALK_PIPE_W_TIP_SLOTS {Loops.WIDE_TIP_SLOTS}")
     out.append(f"#define WALK_PIPE_W_MAX_TIPS {Loops.WIDE_MAX_TIPS}")
     out.append(f"#define WALK_PIPE_W_MAX_INNER {Loops.WIDE_MAX_INNER}")
     out.append(f"#define WALK_PIPE_W_REV_BASE {Loops.WIDE_REV_BASE}")
     out.append(f"#define WALK_PIPE_W_IMAGE_REGS {Loops.WIDE_IMAGE_REGS}")
+    for G in (1, 2):  # two waves per SIMD: up to 28 taxa inside 256 registers per wave
+        loops = Loops(G, exact=False, two=True)
+        post = loops.post_loop()
+        pre = Loops(G, exact=False, two=True).pre_loop()
+        out.append(as_macro(f"WALK_PIPE_POST_T_ASM_G{G}", post.finish()))
+        out.append(as_macro(f"WALK_PIPE_PRE_REV_T_ASM_G{G}", pre.finish()))
+        out.append(f"#define WALK_PIPE_CLOBBERS_T_G{G} {clobbers(loops)}")
+        listing.append(f"G={G} two waves per SIMD: VGPR v{loops.vbase}..v{loops.vnext - 1}, AGPR a0..a{loops.image_regs - 1}; "
+                       f"post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
+    out.append(as_macro("WALK_PIPE_LOAD_REV_T_ASM", Loops(1, exact=False, two=True).load_images(False).finish()))
+    out.append(f"#define WALK_PIPE_T_TIP_SLOTS {Loops.TWO_TIP_SLOTS}")
+    out.append(f"#define WALK_PIPE_T_MAX_TIPS {Loops.TWO_MAX_TIPS}")
+    out.append(f"#define WALK_PIPE_T_MAX_INNER {Loops.TWO_MAX_INNER}")
+    out.append(f"#define WALK_PIPE_T_REV_BASE {Loops.TWO_REV_BASE}")
+    out.append(f"#define WALK_PIPE_T_IMAGE_REGS {Loops.TWO_IMAGE_REGS}")
+    out.append(f"#define WALK_PIPE_T_VBASE {Loops.TWO_VBASE}")
     loops = Loops(1)
     out.append(as_macro("WALK_PIPE_LOAD_EXACT_ASM", loops.load_images(True).finish()))
     loops = Loops(1)

@@ -1,6 +1,6 @@
 """Randomised parity sweep on the GPU box: random tree shapes, sizes, pattern counts, models, category counts,
 kernels, rescaling, rooted/unrooted, against the CPU checker.
-usage: python scripts/gpu_fuzz.py [cases] [seed] [kernel forced in every case, e.g. 5 = walk_pipe_kernel]
+usage: python scripts/gpu_fuzz.py [cases] [seed] [kernel forced in every case, e.g. 5 = walk_pipe_kernel, 6 = its two-wave form]
 FUZZ_LARGE_TREES=1: trees of up to 333 taxa as well; FUZZ_CODON=1: every case the 61-state codon model"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,7 @@ from oracle import gs
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 forced_kernel = int(sys.argv[3]) if len(sys.argv) > 3 else None
-FORCED = (_capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE, _capi.KERNEL_LDS_PIPE)
+FORCED = (_capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE, _capi.KERNEL_LDS_PIPE, _capi.KERNEL_LDS_PIPE2)
 skipped = 0
 unstable = 0
 rng = np.random.default_rng(seed)
@@ -36,7 +36,7 @@ for case in range(cases):
         n, P, T = min(n, 16), min(P, 65), min(T, 7)
         site = str(rng.choice(["constant", "weibull+2"]))
     kernel = int(rng.choice([_capi.KERNEL_AUTO, _capi.KERNEL_HBM_ARENA, _capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE,
-                             _capi.KERNEL_LDS_PIPE]))
+                             _capi.KERNEL_LDS_PIPE, _capi.KERNEL_LDS_PIPE2]))
     if forced_kernel is not None:
         kernel = forced_kernel
     rooted = bool(rng.integers(0, 2)) or n == 3 and False

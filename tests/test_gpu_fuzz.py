@@ -33,8 +33,8 @@ def _sweep(script, *args):
     return int(summary.group(1)), int(summary.group(3) or 0)
 
 
-@pytest.mark.parametrize("cases,seed,kernel", [(160, 3101, None), (80, 3102, 5), (80, 3103, 1), (80, 3104, 2)],
-                         ids=["any-kernel", "walk_pipe_kernel", "hbm-arena", "walk_lds_kernel"])
+@pytest.mark.parametrize("cases,seed,kernel", [(160, 3101, None), (80, 3102, 5), (80, 3103, 1), (80, 3104, 2), (120, 3105, 6)],
+                         ids=["any-kernel", "walk_pipe_kernel", "hbm-arena", "walk_lds_kernel", "walk_pipe_kernel-two-waves"])
 def test_seeded_sweep_per_tree_path(cases, seed, kernel):
     args = (cases, seed) if kernel is None else (cases, seed, kernel)
     done, declined = _sweep("gpu_fuzz.py", *args)
