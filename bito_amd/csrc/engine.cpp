@@ -66,6 +66,10 @@ struct bito_amd_engine {
   int host_threads = 0, par_min_trees = 1024;
   size_t par_min_bytes = (size_t)512 << 10;
   std::unique_ptr<HostPool> pool;
+  // one issuing thread per device slot beyond the first (the reference runs a thread per FatBeagle instance,
+  // src/task_processor.hpp:43-140): a call over several devices hands every slot's block to its own thread, so that no
+  // device waits for the host to be done with another one's.  Created on the first call that uses several slots.
+  std::unique_ptr<HostPool> slot_pool;
   double span_sum_ms = 0;  // of the last bito_amd_engine_kernel_elapsed: the launches' spans added up (overlaps counted twice)
 };
 
@@ -136,6 +140,45 @@ void ParallelRanges(bito_amd_engine* e, size_t count, const std::function<void(i
   });
 }
 
+// fn(slot, first tree, trees, the slot's first worker) for every device slot's contiguous block of a collection of
+// tree_count trees, each slot on a host thread of its own (slot 0 on the caller's).  fn returns a C-ABI code and, when
+// it fails, leaves the message with its worker; what is reported is the failure of the slot with the lowest trees -- the
+// one a serial pass would have met first.  Blocks: slot s takes trees [T s / D, T (s + 1) / D).
+int RunPerSlot(bito_amd_engine* e, int tree_count, const std::function<int(int, int, int, Worker*)>& fn) {
+  const int D = (int)e->devices.size();
+  for (int s = 0; s < D; s++) {
+    Worker* w = nullptr;
+    if (int rc = GetWorker(e, s, 0, &w)) return rc;
+  }
+  if (!e->slot_pool) e->slot_pool = std::make_unique<HostPool>(D - 1);
+  std::vector<int> codes((size_t)D, BITO_AMD_OK);
+  e->slot_pool->Run([&](int slot) {
+    const int t0 = (int)((long long)tree_count * slot / D), t1 = (int)((long long)tree_count * (slot + 1) / D);
+    if (t1 == t0) return;
+    Worker* w = e->workers[slot][0].get();
+    (void)hipSetDevice(e->devices[slot]);
+    w->id_offset = t0;
+    codes[(size_t)slot] = fn(slot, t0, t1 - t0, w);
+  });
+  for (int s = 0; s < D; s++)
+    if (codes[(size_t)s]) return Propagate(e, e->workers[s][0].get(), codes[(size_t)s]);
+  return BITO_AMD_OK;
+}
+
+// the resident batch after a call that left one block on every slot's first worker
+void SetSlotResident(bito_amd_engine* e, int rooted, int node_count, int tree_count) {
+  const int D = (int)e->devices.size();
+  e->shards.clear();
+  for (int s = 0; s < D; s++) {
+    const int t0 = (int)((long long)tree_count * s / D), t1 = (int)((long long)tree_count * (s + 1) / D);
+    if (t1 > t0) e->shards.push_back({s, 0, t0, t1 - t0});
+  }
+  e->resident = true;
+  e->rooted = rooted;
+  e->node_count = node_count;
+  e->tree_count = tree_count;
+}
+
 // Chunk sizes for `count` trees on one device.  The first chunk is small, so that the device starts early; the
 // following ones grow, so that the host -- which validates and stages about five times faster than the device
 // traverses -- stays a chunk ahead and the set-up kernels of chunk k+1 are in the queue before the traversal of
@@ -194,10 +237,6 @@ int PlanShards(bito_amd_engine* e, int tree_count, bool single, std::vector<Shar
   return BITO_AMD_OK;
 }
 
-void SyncShards(bito_amd_engine* e, size_t issued) {
-  for (size_t k = 0; k < issued && k < e->shards.size(); k++) (void)WorkerSync(ShardWorker(e, e->shards[k]));
-}
-
 // The blocking evaluation behind bito_amd_engine_log_likelihoods / _gradients: stage, run and fetch every chunk
 // without waiting, copy results out as they arrive.
 int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,
@@ -211,19 +250,47 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
   if (pc > 0 && !params) return Fail(e, BITO_AMD_ERR_BAD_ARG, "params is NULL but the model has parameters");
   if (int rc = PlanShards(e, tree_count, single, &e->shards)) return rc;
   const bool has_rates = rooted && rates != nullptr;
-  size_t drained = 0;
+  // One issuing thread per device slot (the reference runs a thread per FatBeagle instance,
+  // src/task_processor.hpp:43-140): with several slots every slot's chunks are staged, issued and drained by the slot's
+  // own thread, so that no device waits for the host to be done with another one's -- slot 7 of an eight-GPU engine
+  // would otherwise see its first chunk issued behind seven other stage + launch sequences.  A one-slot call (the
+  // headline path) stays on the calling thread and cuts large chunks into ranges over the helper threads instead.
+  // (BITO_AMD_SLOT_THREADS=0: every slot from the calling thread, chunk k of every slot before chunk k + 1 of any.)
+  static const bool slot_threads = [] {
+    const char* v = std::getenv("BITO_AMD_SLOT_THREADS");
+    return v == nullptr || std::atoi(v) != 0;
+  }();
+  std::vector<std::vector<size_t>> lists;
+  {
+    int slots_used = 0;
+    std::vector<char> seen(e->devices.size(), 0);
+    for (const Shard& s : e->shards)
+      if (!seen[(size_t)s.slot]) {
+        seen[(size_t)s.slot] = 1;
+        slots_used++;
+      }
+    if (slots_used > 1 && slot_threads) {
+      lists.resize(e->devices.size());
+      for (size_t k = 0; k < e->shards.size(); k++) lists[(size_t)e->shards[k].slot].push_back(k);
+    } else {
+      lists.resize(1);
+      for (size_t k = 0; k < e->shards.size(); k++) lists[0].push_back(k);
+    }
+  }
+  const bool threaded = lists.size() > 1;
   // (BITO_AMD_TRACE_CALL=1: host-side time line of the call on stderr -- when each chunk was issued and when its
   // results had arrived)
   static const bool trace = std::getenv("BITO_AMD_TRACE_CALL") != nullptr;
   const auto call_start = std::chrono::steady_clock::now();
   auto stamp = [&](const char* what, size_t k) {
     if (trace)
-      std::fprintf(stderr, "  %8.1f us  %s chunk %zu (%d trees)\n",
+      std::fprintf(stderr, "  %8.1f us  %s chunk %zu (slot %d lane %d, %d trees)\n",
                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - call_start).count(), what, k,
-                   e->shards[k].count);
+                   e->shards[k].slot, e->shards[k].lane, e->shards[k].count);
   };
   auto big_copy = [&](const Shard& s) {
-    return e->host_threads != 1 && (size_t)s.count * (want_gradient && out_grad ? N + 1 : 1) * sizeof(double) >= e->par_min_bytes;
+    return !threaded && e->host_threads != 1 &&
+           (size_t)s.count * (want_gradient && out_grad ? N + 1 : 1) * sizeof(double) >= e->par_min_bytes;
   };
   auto drain = [&](size_t k) -> int {
     const Shard& s = e->shards[k];
@@ -231,7 +298,7 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
     const double *ll = nullptr, *grad = nullptr, *site = nullptr;
     // (a large block: the helper threads are woken now and poll for the copy while this thread polls for the results)
     if (big_copy(s) && !WorkerResultsReady(w)) Pool(e)->Arm();
-    if (int rc = Propagate(e, w, WorkerResults(w, &ll, &grad, &site))) return rc;
+    if (int rc = WorkerResults(w, &ll, &grad, &site)) return rc;
     stamp("results of", k);
     const bool with_site = want_site && out_site && w->site_ready;
     auto copy = [&](size_t a, size_t b) {  // trees [a, b) of the chunk
@@ -250,69 +317,93 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
   // (In a loop of calls they still poll from the call before: then smaller chunks -- the first one of a large call --
   // are worth cutting up as well.)
   int par_min_trees = e->par_min_trees;
-  if (e->host_threads != 1 && tree_count >= e->par_min_trees) {
+  if (!threaded && e->host_threads != 1 && tree_count >= e->par_min_trees) {
     if (Pool(e)->Hot()) par_min_trees = std::min(par_min_trees, 256);
     Pool(e)->Arm();
   }
-  std::vector<char> slot_busy(e->devices.size(), 0);
-  for (size_t k = 0; k < e->shards.size(); k++) {
-    const Shard& s = e->shards[k];
-    Worker* w = ShardWorker(e, s);
-    w->one_shot = slot_busy[s.slot] ? 2 : 1;
-    // The slot's stream pair: every chunk's traversal, final sums and completion flag on the first worker's
-    // stream, in order; the copies and set-up kernels of the later chunks on its (low-priority) set-up stream,
-    // beside the traversal of the chunk before.  Two streams per device, whatever the number of chunks: the
-    // runtime multiplexes streams onto four hardware queues, and with a stream per chunk the chunks' commands
-    // queued up behind one another's traversals (measured: copies waiting a millisecond).
-    // (walk_streams == 2: the chunks' traversals alternate between the first two workers' streams, so that chunk
-    // k+1's resident workgroups move in as chunk k's leave -- the ragged end of one launch filled by the next)
-    Worker* first = e->workers[s.slot][0].get();
-    Worker* second = (e->walk_streams > 1 && e->workers[s.slot].size() > 1) ? e->workers[s.slot][1].get() : first;
-    w->lent_walk = s.lane > 0 ? ((s.lane & 1) ? second->stream : first->stream) : nullptr;
-    w->lent_setup = s.lane > 0 ? first->prep_stream : nullptr;
-    w->id_offset = s.t0;
-    slot_busy[s.slot] = 1;
-    // a traversal holds every CU it is given until its queue of work is empty: while a later chunk of this device
-    // still has its set-up kernels to run, it leaves them one CU per XCD
-    w->reserve_cus = 0;
-    for (size_t later = k + 1; later < e->shards.size(); later++)
-      if (e->shards[later].slot == s.slot) w->reserve_cus = e->reserve_cus;
-    int rc = WorkerStageBegin(w, s.count, rooted, node_count, parent_ids + (size_t)s.t0 * (M - 1),
-                              branch_lengths + (size_t)s.t0 * M, has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr,
-                              pc > 0 ? params + (size_t)s.t0 * pc : nullptr, /*wait=*/0);
-    if (!rc) {
-      // the host's share of the chunk -- checks, one pack into pinned memory -- in ranges over the host threads
-      if (e->host_threads != 1 && s.count >= par_min_trees) {
-        std::vector<StagePart> parts((size_t)Pool(e)->parts());
-        ParallelRanges(e, (size_t)s.count, [&](int part, size_t a, size_t b) { WorkerStageFill(w, (int32_t)a, (int32_t)b, &parts[(size_t)part]); });
-        rc = WorkerStageEnd(w, parts.data(), (int)parts.size());
-      } else {
-        StagePart part;
-        WorkerStageFill(w, 0, s.count, &part);
-        rc = WorkerStageEnd(w, &part, 1);
+  // what one issuing thread does with its chunks, in order; returns the first failure (the failing worker holds the message)
+  struct Outcome {
+    int rc = BITO_AMD_OK;
+    Worker* worker = nullptr;
+    int t0 = 0;
+  };
+  auto run_list = [&](const std::vector<size_t>& mine, Outcome* oc) {
+    size_t drained = 0;
+    std::vector<char> slot_busy(e->devices.size(), 0);
+    auto fail = [&](int rc, size_t k, size_t issued) {
+      oc->rc = rc;
+      oc->worker = ShardWorker(e, e->shards[k]);
+      oc->t0 = e->shards[k].t0;
+      for (size_t i = 0; i < issued && i < mine.size(); i++) (void)WorkerSync(ShardWorker(e, e->shards[mine[i]]));
+    };
+    for (size_t i = 0; i < mine.size(); i++) {
+      const size_t k = mine[i];
+      const Shard& s = e->shards[k];
+      Worker* w = ShardWorker(e, s);
+      if (threaded) (void)hipSetDevice(e->devices[(size_t)s.slot]);
+      w->one_shot = slot_busy[s.slot] ? 2 : 1;
+      // The slot's stream pair: every chunk's traversal, final sums and completion flag on the first worker's
+      // stream, in order; the copies and set-up kernels of the later chunks on its (low-priority) set-up stream,
+      // beside the traversal of the chunk before.  Two streams per device, whatever the number of chunks: the
+      // runtime multiplexes streams onto four hardware queues, and with a stream per chunk the chunks' commands
+      // queued up behind one another's traversals (measured: copies waiting a millisecond).
+      // (walk_streams == 2: the chunks' traversals alternate between the first two workers' streams, so that chunk
+      // k+1's resident workgroups move in as chunk k's leave -- the ragged end of one launch filled by the next)
+      Worker* first = e->workers[s.slot][0].get();
+      Worker* second = (e->walk_streams > 1 && e->workers[s.slot].size() > 1) ? e->workers[s.slot][1].get() : first;
+      w->lent_walk = s.lane > 0 ? ((s.lane & 1) ? second->stream : first->stream) : nullptr;
+      w->lent_setup = s.lane > 0 ? first->prep_stream : nullptr;
+      w->id_offset = s.t0;
+      slot_busy[s.slot] = 1;
+      // a traversal holds every CU it is given until its queue of work is empty: while a later chunk of this device
+      // still has its set-up kernels to run, it leaves them one CU per XCD
+      w->reserve_cus = 0;
+      for (size_t later = k + 1; later < e->shards.size(); later++)
+        if (e->shards[later].slot == s.slot) w->reserve_cus = e->reserve_cus;
+      int rc = WorkerStageBegin(w, s.count, rooted, node_count, parent_ids + (size_t)s.t0 * (M - 1),
+                                branch_lengths + (size_t)s.t0 * M, has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr,
+                                pc > 0 ? params + (size_t)s.t0 * pc : nullptr, /*wait=*/0);
+      if (!rc) {
+        // the host's share of the chunk -- checks, one pack into pinned memory -- in ranges over the host threads
+        if (!threaded && e->host_threads != 1 && s.count >= par_min_trees) {
+          std::vector<StagePart> parts((size_t)Pool(e)->parts());
+          ParallelRanges(e, (size_t)s.count, [&](int part, size_t a, size_t b) { WorkerStageFill(w, (int32_t)a, (int32_t)b, &parts[(size_t)part]); });
+          rc = WorkerStageEnd(w, parts.data(), (int)parts.size());
+        } else {
+          StagePart part;
+          WorkerStageFill(w, 0, s.count, &part);
+          rc = WorkerStageEnd(w, &part, 1);
+        }
+      }
+      stamp("staged", k);
+      if (!rc) rc = WorkerRunPass(w, want_gradient, rescaling, 0, want_site);
+      if (!rc) rc = WorkerFetchResults(w, want_gradient, want_site);
+      stamp("issued", k);
+      if (rc) return fail(rc, k, i + 1);
+      // results that have arrived meanwhile (in order: the chunks finish in the order they were issued, near enough)
+      while (drained < i && WorkerResultsReady(ShardWorker(e, e->shards[mine[drained]]))) {
+        const size_t kd = mine[drained++];
+        if (int rc2 = drain(kd)) return fail(rc2, kd, i + 1);
       }
     }
-    stamp("staged", k);
-    if (!rc) rc = WorkerRunPass(w, want_gradient, rescaling, 0, want_site);
-    if (!rc) rc = WorkerFetchResults(w, want_gradient, want_site);
-    stamp("issued", k);
-    if (rc) {
-      Propagate(e, w, rc);
-      SyncShards(e, k + 1);
-      return rc;
-    }
-    // results that have arrived meanwhile (in order: the chunks finish in the order they were issued, near enough)
-    while (drained < k && WorkerResultsReady(ShardWorker(e, e->shards[drained])))
-      if (int rc2 = drain(drained++)) {
-        SyncShards(e, k + 1);
-        return rc2;
-      }
+    for (; drained < mine.size(); drained++)
+      if (int rc = drain(mine[drained])) return fail(rc, mine[drained], mine.size());
+  };
+  std::vector<Outcome> outcomes(lists.size());
+  if (!threaded) {
+    run_list(lists[0], &outcomes[0]);
+  } else {
+    if (!e->slot_pool) e->slot_pool = std::make_unique<HostPool>((int)e->devices.size() - 1);
+    e->slot_pool->Run([&](int slot) {
+      if (!lists[(size_t)slot].empty()) run_list(lists[(size_t)slot], &outcomes[(size_t)slot]);
+    });
   }
-  for (; drained < e->shards.size(); drained++)
-    if (int rc = drain(drained)) {
-      SyncShards(e, e->shards.size());
-      return rc;
-    }
+  {
+    const Outcome* bad = nullptr;  // the failure a serial pass over the trees would have met first
+    for (const Outcome& oc : outcomes)
+      if (oc.rc && (!bad || oc.t0 < bad->t0)) bad = &oc;
+    if (bad) return Propagate(e, bad->worker, bad->rc);
+  }
   if (want_site && out_site) {
     // kernels that do not produce the site-model gradient in the main pass: a second traversal per block.  Every
     // chunk has drained by now, so each worker runs the pass on its OWN streams and waits for it there: the streams a
@@ -424,6 +515,11 @@ void SetSingleResident(bito_amd_engine* e, int rooted, int node_count, int tree_
   e->tree_count = tree_count;
 }
 
+bool OneSlot(const bito_amd_engine* e, int tree_count) { return e->devices.size() == 1 || tree_count < (int)e->devices.size(); }
+template <typename T>
+const T* At(const T* p, size_t offset) { return p ? p + offset : nullptr; }
+template <typename T>
+T* At(T* p, size_t offset) { return p ? p + offset : nullptr; }
 }  // namespace
 
 extern "C" {
@@ -558,41 +654,78 @@ int bito_amd_engine_gradients(bito_amd_engine* e, int32_t tree_count, int32_t ro
   return BITO_AMD_OK;
 }
 
-// ---- time trees: one worker (the transforms are O(n) per tree and keep their inputs on that worker) ----
+// ---- time trees: Engine::LogLikelihoods / Gradients(RootedTreeCollection) and the height-ratio transforms run over
+// every FatBeagle of the engine (reference src/engine.cpp:76-119); here over every device slot: the collection is cut
+// into one contiguous block per slot, each block handled by the slot's first worker on a host thread of its own ----
 
 int bito_amd_engine_time_trees_from_branch_lengths(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
                                                    const double* branch_lengths, const double* tip_dates,
                                                    double* out_node_bounds, double* out_node_heights,
                                                    double* out_height_ratios) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
-  Worker* w = Primary(e);
-  return Propagate(e, w, WorkerTimeTreesFromBranchLengths(w, tree_count, parent_ids, branch_lengths, tip_dates,
-                                                          out_node_bounds, out_node_heights, out_height_ratios));
+  if (OneSlot(e, tree_count)) {
+    Worker* w = Primary(e);
+    w->id_offset = 0;
+    return Propagate(e, w, WorkerTimeTreesFromBranchLengths(w, tree_count, parent_ids, branch_lengths, tip_dates,
+                                                            out_node_bounds, out_node_heights, out_height_ratios));
+  }
+  const size_t N = 2 * (size_t)e->n - 1, R = (size_t)e->n - 1;
+  return RunPerSlot(e, tree_count, [&](int, int t0, int count, Worker* w) {
+    const size_t t = (size_t)t0;
+    return WorkerTimeTreesFromBranchLengths(w, count, At(parent_ids, t * (N - 1)), At(branch_lengths, t * N), tip_dates,
+                                            At(out_node_bounds, t * N), At(out_node_heights, t * N), At(out_height_ratios, t * R));
+  });
 }
 
 int bito_amd_engine_time_trees_from_height_ratios(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
                                                   const double* node_bounds, const double* height_ratios,
                                                   double* out_node_heights, double* out_branch_lengths) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
-  Worker* w = Primary(e);
-  return Propagate(e, w, WorkerTimeTreesFromHeightRatios(w, tree_count, parent_ids, node_bounds, height_ratios,
-                                                         out_node_heights, out_branch_lengths));
+  if (OneSlot(e, tree_count)) {
+    Worker* w = Primary(e);
+    w->id_offset = 0;
+    return Propagate(e, w, WorkerTimeTreesFromHeightRatios(w, tree_count, parent_ids, node_bounds, height_ratios,
+                                                           out_node_heights, out_branch_lengths));
+  }
+  const size_t N = 2 * (size_t)e->n - 1, R = (size_t)e->n - 1;
+  return RunPerSlot(e, tree_count, [&](int, int t0, int count, Worker* w) {
+    const size_t t = (size_t)t0;
+    return WorkerTimeTreesFromHeightRatios(w, count, At(parent_ids, t * (N - 1)), At(node_bounds, t * N), At(height_ratios, t * R),
+                                           At(out_node_heights, t * N), At(out_branch_lengths, t * N));
+  });
 }
 
 int bito_amd_engine_log_det_jacobian(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
                                      const double* node_heights, const double* node_bounds, double* out) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
-  Worker* w = Primary(e);
-  return Propagate(e, w, WorkerLogDetJacobian(w, tree_count, parent_ids, node_heights, node_bounds, out));
+  if (OneSlot(e, tree_count)) {
+    Worker* w = Primary(e);
+    w->id_offset = 0;
+    return Propagate(e, w, WorkerLogDetJacobian(w, tree_count, parent_ids, node_heights, node_bounds, out));
+  }
+  const size_t N = 2 * (size_t)e->n - 1;
+  return RunPerSlot(e, tree_count, [&](int, int t0, int count, Worker* w) {
+    const size_t t = (size_t)t0;
+    return WorkerLogDetJacobian(w, count, At(parent_ids, t * (N - 1)), At(node_heights, t * N), At(node_bounds, t * N), At(out, t));
+  });
 }
 
 int bito_amd_engine_gradient_log_det_jacobian(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
                                               const double* node_heights, const double* node_bounds,
                                               const double* height_ratios, double* out) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
-  Worker* w = Primary(e);
-  return Propagate(e, w, WorkerGradientLogDetJacobian(w, tree_count, parent_ids, node_heights, node_bounds,
-                                                      height_ratios, out));
+  if (OneSlot(e, tree_count)) {
+    Worker* w = Primary(e);
+    w->id_offset = 0;
+    return Propagate(e, w, WorkerGradientLogDetJacobian(w, tree_count, parent_ids, node_heights, node_bounds,
+                                                        height_ratios, out));
+  }
+  const size_t N = 2 * (size_t)e->n - 1, R = (size_t)e->n - 1;
+  return RunPerSlot(e, tree_count, [&](int, int t0, int count, Worker* w) {
+    const size_t t = (size_t)t0;
+    return WorkerGradientLogDetJacobian(w, count, At(parent_ids, t * (N - 1)), At(node_heights, t * N), At(node_bounds, t * N),
+                                        At(height_ratios, t * R), At(out, t * R));
+  });
 }
 
 int bito_amd_engine_ratio_gradient_of_height_gradient(bito_amd_engine* e, int32_t tree_count,
@@ -600,9 +733,18 @@ int bito_amd_engine_ratio_gradient_of_height_gradient(bito_amd_engine* e, int32_
                                                       const double* node_bounds, const double* height_ratios,
                                                       const double* height_gradient, double* out) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
-  Worker* w = Primary(e);
-  return Propagate(e, w, WorkerRatioGradientOfHeightGradient(w, tree_count, parent_ids, node_heights, node_bounds,
-                                                             height_ratios, height_gradient, out));
+  if (OneSlot(e, tree_count)) {
+    Worker* w = Primary(e);
+    w->id_offset = 0;
+    return Propagate(e, w, WorkerRatioGradientOfHeightGradient(w, tree_count, parent_ids, node_heights, node_bounds,
+                                                               height_ratios, height_gradient, out));
+  }
+  const size_t N = 2 * (size_t)e->n - 1, R = (size_t)e->n - 1;
+  return RunPerSlot(e, tree_count, [&](int, int t0, int count, Worker* w) {
+    const size_t t = (size_t)t0;
+    return WorkerRatioGradientOfHeightGradient(w, count, At(parent_ids, t * (N - 1)), At(node_heights, t * N), At(node_bounds, t * N),
+                                               At(height_ratios, t * R), At(height_gradient, t * R), At(out, t * R));
+  });
 }
 
 int bito_amd_engine_time_tree_log_likelihoods(bito_amd_engine* e, int32_t tree_count, const int32_t* parent_ids,
@@ -611,15 +753,29 @@ int bito_amd_engine_time_tree_log_likelihoods(bito_amd_engine* e, int32_t tree_c
                                               const double* params, int32_t rescaling,
                                               int32_t include_log_det_jacobian, double* out) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
-  Worker* w = Primary(e);
   e->resident = false;
-  w->one_shot = 0;
-  w->reserve_cus = 0;
-  w->id_offset = 0;
-  const int rc = WorkerTimeTreeLogLikelihoods(w, tree_count, parent_ids, branch_lengths, rates, node_heights,
-                                              node_bounds, params, rescaling, include_log_det_jacobian, out);
-  if (rc) return Propagate(e, w, rc);
-  SetSingleResident(e, 1, 2 * e->n - 1, tree_count);
+  if (OneSlot(e, tree_count)) {
+    Worker* w = Primary(e);
+    w->one_shot = 0;
+    w->reserve_cus = 0;
+    w->id_offset = 0;
+    const int rc = WorkerTimeTreeLogLikelihoods(w, tree_count, parent_ids, branch_lengths, rates, node_heights,
+                                                node_bounds, params, rescaling, include_log_det_jacobian, out);
+    if (rc) return Propagate(e, w, rc);
+    SetSingleResident(e, 1, 2 * e->n - 1, tree_count);
+    return BITO_AMD_OK;
+  }
+  const size_t N = 2 * (size_t)e->n - 1, pc = (size_t)Primary(e)->spec.param_count;
+  const int rc = RunPerSlot(e, tree_count, [&](int, int t0, int count, Worker* w) {
+    const size_t t = (size_t)t0;
+    w->one_shot = 0;
+    w->reserve_cus = 0;
+    return WorkerTimeTreeLogLikelihoods(w, count, At(parent_ids, t * (N - 1)), At(branch_lengths, t * N), At(rates, t * (N - 1)),
+                                        At(node_heights, t * N), At(node_bounds, t * N), At(params, t * pc), rescaling,
+                                        include_log_det_jacobian, At(out, t));
+  });
+  if (rc) return rc;
+  SetSlotResident(e, 1, 2 * e->n - 1, tree_count);
   return BITO_AMD_OK;
 }
 
@@ -630,16 +786,34 @@ int bito_amd_engine_time_tree_gradients(bito_amd_engine* e, int32_t tree_count, 
                                         int32_t flags, double fd_delta, double* out_ll, double* out_branch,
                                         double* out_site, double* out_subst, double* out_clock, double* out_ratios) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
-  Worker* w = Primary(e);
   e->resident = false;
-  w->one_shot = 0;
-  w->reserve_cus = 0;
-  w->id_offset = 0;
-  const int rc = WorkerTimeTreeGradients(w, tree_count, parent_ids, branch_lengths, rates, rate_count, node_heights,
-                                         node_bounds, height_ratios, params, rescaling, flags, fd_delta, out_ll,
-                                         out_branch, out_site, out_subst, out_clock, out_ratios);
-  if (rc) return Propagate(e, w, rc);
-  SetSingleResident(e, 1, 2 * e->n - 1, tree_count);
+  if (OneSlot(e, tree_count)) {
+    Worker* w = Primary(e);
+    w->one_shot = 0;
+    w->reserve_cus = 0;
+    w->id_offset = 0;
+    const int rc = WorkerTimeTreeGradients(w, tree_count, parent_ids, branch_lengths, rates, rate_count, node_heights,
+                                           node_bounds, height_ratios, params, rescaling, flags, fd_delta, out_ll,
+                                           out_branch, out_site, out_subst, out_clock, out_ratios);
+    if (rc) return Propagate(e, w, rc);
+    SetSingleResident(e, 1, 2 * e->n - 1, tree_count);
+    return BITO_AMD_OK;
+  }
+  const ModelSpec& m = Primary(e)->spec;
+  const size_t N = 2 * (size_t)e->n - 1, R = (size_t)e->n - 1, pc = (size_t)m.param_count;
+  const size_t subst_stride = (size_t)m.rates_len + 4, clock_stride = rate_count == 1 ? 1 : N - 1;
+  const int rc = RunPerSlot(e, tree_count, [&](int, int t0, int count, Worker* w) {
+    const size_t t = (size_t)t0;
+    w->one_shot = 0;
+    w->reserve_cus = 0;
+    return WorkerTimeTreeGradients(w, count, At(parent_ids, t * (N - 1)), At(branch_lengths, t * N), At(rates, t * (N - 1)),
+                                   rate_count, At(node_heights, t * N), At(node_bounds, t * N), At(height_ratios, t * R),
+                                   At(params, t * pc), rescaling, flags, fd_delta, At(out_ll, t), At(out_branch, t * N),
+                                   At(out_site, t), At(out_subst, t * subst_stride), At(out_clock, t * clock_stride),
+                                   At(out_ratios, t * R));
+  });
+  if (rc) return rc;
+  SetSlotResident(e, 1, 2 * e->n - 1, tree_count);
   return BITO_AMD_OK;
 }
 

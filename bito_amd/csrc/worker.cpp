@@ -1527,7 +1527,7 @@ int WorkerTimeTreesFromBranchLengths(Worker* e, int32_t tree_count,
       char buf[200];
       std::snprintf(buf, sizeof(buf),
                     "Tree isn't time-calibrated in RootedTree::InitializeTimeTreeUsingBranchLengths. "
-                    "Height difference: %f (tree %zu)", diff[t], t);
+                    "Height difference: %f (tree %zu)", diff[t], t + (size_t)e->id_offset);
       return Fail(e, BITO_AMD_ERR_BAD_TREE, buf);
     }
   if ((rc = ToHost(e, out_node_bounds, e->tt_bounds.ptr, T * N))) return rc;

@@ -116,7 +116,11 @@ class _GenericInstance:
     # -- engine life cycle (reference src/generic_sbn_instance.hpp:235-284,380-386)
     def prepare_for_phylo_likelihood(self, model_specification: PhyloModelSpecification, thread_count: int = 1,
                                      beagle_flags: Sequence = (), use_tip_states: bool = True,
-                                     tree_count_option: Optional[int] = None, device_id: Optional[int] = None):
+                                     tree_count_option: Optional[int] = None, device_id: Optional[int] = None,
+                                     devices: Optional[Sequence[int]] = None):
+        """``devices``: the GPUs behind this instance's engine (default: one, ``device_id``) -- what the reference's
+        ``thread_count`` FatBeagle instances are (src/generic_sbn_instance.cpp MakeEngine, src/engine.cpp:10-31): every
+        collection-level call is sharded over them."""
         if thread_count == 0:
             raise RuntimeError("Thread count needs to be strictly positive.")
         if not self._alignment:
@@ -128,7 +132,7 @@ class _GenericInstance:
             self._engine.close()
         self._engine = Engine(model_specification, site_pattern.patterns, site_pattern.weights,
                               device_id=self._device_id if device_id is None else device_id,
-                              use_tip_states=use_tip_states)
+                              use_tip_states=use_tip_states, devices=devices)
         self.resize_phylo_model_params(tree_count_option)
 
     def resize_phylo_model_params(self, tree_count_option: Optional[int] = None):

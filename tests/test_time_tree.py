@@ -102,7 +102,39 @@ def test_uninitialized_time_trees_raise(data_dir):
 
 
 @pytest.mark.gpu
-def test_time_tree_transforms_match_oracle(data_dir):
+def test_rooted_instance_goldens_on_an_engine_over_two_device_slots(data_dir):
+    """Engine::Gradients(RootedTreeCollection) runs over every FatBeagle of the engine (reference src/engine.cpp:94-119):
+    the physher goldens of src/rooted_sbn_instance.hpp:277-307 on a collection of three copies of the fluA tree, sharded
+    over two device slots (GPU 0 named twice: 1 + 2 trees, each slot on its own host thread)."""
+    import copy
+
+    g = GOLD["flua_time_tree"]
+    inst = bito_amd.rooted_instance("charlie")
+    inst.read_newick_file(os.path.join(data_dir, "fluA.tree"), False)
+    inst.tree_collection.trees.extend(copy.deepcopy(inst.tree_collection.trees[0]) for _ in range(2))
+    inst.parse_dates_from_taxon_names(True)
+    inst.read_fasta_file(os.path.join(data_dir, "fluA.fa"))
+    inst.prepare_for_phylo_likelihood(spec("JC69", "constant", "strict"), 2, devices=[0, 0])
+    assert inst._get_engine().device_count == 2
+    for tree in inst.tree_collection.trees:
+        tree.rates[:] = 0.001
+    likelihood = inst.log_likelihoods()
+    assert likelihood.shape == (3,) and np.abs(likelihood - (g["log_likelihood"] + g["log_det_jacobian"])).max() < 1e-4
+    assert np.abs(inst.log_det_jacobian_of_height_transform() - g["log_det_jacobian"]).max() < 1e-6
+    gradients = inst.phylo_gradients()
+    assert len(gradients) == 3
+    for grad in gradients:
+        assert np.abs(grad.gradient["ratios_root_height"] - g["ratios_root_height_gradient"]).max() < 1e-4
+        assert abs(grad.log_likelihood - g["log_likelihood"]) < 1e-4
+    # the batch stays resident, one block per slot: passes over it and downloads address it through the shard list
+    eng = inst._get_engine()
+    ll, grad = eng.download()
+    assert ll.shape == (3,) and np.abs(ll - g["log_likelihood"]).max() < 1e-4 and grad.shape[0] == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]], ids=["one-slot", "two-slots", "three-slots"])
+def test_time_tree_transforms_match_oracle(data_dir, devices):
     tc = treeio.read_newick_file(os.path.join(data_dir, "fluA.tree"))
     sp = SitePattern(treeio.read_fasta(os.path.join(data_dir, "fluA.fa")), tc.taxon_names)
     dates = treeio.parse_dates_from_taxon_names(tc.taxon_names)
@@ -124,7 +156,8 @@ def test_time_tree_transforms_match_oracle(data_dir):
         ratios.append(r)
     pid = np.repeat(pid1, T, axis=0)
     ratios = np.array(ratios)
-    eng = bito_amd.Engine(spec("JC69", "weibull+4"), sp.patterns, sp.weights)
+    # (seven trees over two or three device slots -- GPU 0 named more than once: blocks of 3 + 4, of 2 + 2 + 3)
+    eng = bito_amd.Engine(spec("JC69", "weibull+4"), sp.patterns, sp.weights, devices=devices)
     bounds = np.stack([tt.node_bounds for tt in refs])
     heights, bl = eng.time_trees_from_height_ratios(pid, bounds, ratios)
     assert np.abs(heights - np.stack([tt.node_heights for tt in refs])).max() < 1e-12
@@ -165,6 +198,12 @@ def test_time_tree_transforms_match_oracle(data_dir):
     with pytest.raises(bito_amd.BitoAmdError, match="number of rates"):
         eng.time_tree_gradients(pid, bl, heights, bounds, ratios, params, rates=rates, rate_count=3,
                                 flags=_capi.GRAD_CLOCK_MODEL)
+    # an error in a later slot's block names the caller's tree
+    if devices is not None:
+        off = bl.copy()
+        off[T - 1, 3] += 0.5
+        with pytest.raises(bito_amd.BitoAmdError, match=rf"time-calibrated.*\(tree {T - 1}\)"):
+            eng.time_trees_from_branch_lengths(pid, off, dates)
     # log-likelihood with the Jacobian of the height transform
     ll = eng.time_tree_log_likelihoods(pid, bl, heights, bounds, params, rates=rates)
     assert np.abs(ll - (ref["log_likelihood"] + ldj)).max() < 1e-9
