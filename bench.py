@@ -256,6 +256,130 @@ def check_against_oracle(w, out_ll, out_grad, count=8):
     return res
 
 
+def gp_workload(args):
+    """Path B: one step = the branch lengths set, then the three schedules
+    GPInstance::EstimateBranchLengths alternates (reference src/gp_instance.cpp:241-308, src/gp_dag.cpp:78-121,177-304) --
+    PopulatePLVs, ComputeLikelihoods and ONE BranchLengthOptimization sweep over every edge of the DAG -- through
+    bito_amd_gp_process_operations, the per-GPCSP log-likelihoods read back at the end.  One DAG is one shared structure:
+    it does not shard by trees, so this workload is one GPU, replicas only.  Reported: edges x site
+    patterns per second, ms per step and per schedule, the dependency levels the executor cuts the schedules into, the
+    algorithmic bytes they move, and the same step on the CPU oracle (oracle/gp_oracle.c, one thread)."""
+    import torch
+
+    from bito_amd import gp, workloads
+
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("--workload gp is one DAG on one GPU (it does not shard by trees): run it without torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
+    dag, sp = workloads.ds1_subsplit_dag(10) if args.gp_dag == "ds1" else workloads.seeded_subsplit_dag(20)
+    P = sp.patterns.shape[1]
+    bl0 = np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)
+    schedules = {"populate_plvs": dag.populate_plvs(), "compute_likelihoods": dag.compute_likelihoods(),
+                 "branch_length_optimization": dag.branch_length_optimization()}
+
+    def step(eng):
+        eng.set_branch_lengths(bl0)  # (every step the same work: a sweep moves the lengths)
+        eng.reset_optimization_count()
+        for s in schedules.values():
+            eng.process_operations(s)
+
+    eng = gp.GPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+    eng.set_sbn_parameters(dag.uniform_on_topological_support_prior())
+    for _ in range(args.warmup):
+        step(eng)
+    eng.get_per_gpcsp_log_likelihoods()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(eng)
+    per_edge = eng.get_per_gpcsp_log_likelihoods()  # (a device-to-host copy on the executor's stream: the fence)
+    elapsed = time.perf_counter() - t0
+    after = eng.get_branch_lengths()
+    # the schedules one by one (outside the timed region), each fenced by a read-back
+    parts = {}
+    for name, s in schedules.items():
+        eng.set_branch_lengths(bl0)
+        eng.reset_optimization_count()
+        if name != "populate_plvs":
+            eng.process_operations(schedules["populate_plvs"])
+        eng.get_branch_lengths()
+        p0 = time.perf_counter()
+        for _ in range(5):
+            eng.process_operations(s)
+        eng.get_branch_lengths()
+        parts[name] = (time.perf_counter() - p0) / 5 * 1e3
+    # what the schedules are made of: operations by kind, bytes by the op-by-op model (a PLV is 4 x P doubles + P counts)
+    plv_bytes = 4 * P * 8 + P * 4
+    names = {0: "ZeroPLV", 1: "SetToStationaryDistribution", 2: "IncrementWithWeightedEvolvedPLV", 3: "Multiply",
+             4: "Likelihood", 5: "OptimizeBranchLength", 6: "UpdateSBNProbabilities", 7: "ResetMarginalLikelihood",
+             8: "IncrementMarginalLikelihood", 9: "PrepForMarginalization"}  # (gp_operation.hpp:162-167)
+    reads_writes = {0: 1, 1: 1, 2: 3, 3: 3, 4: 2, 5: 2, 6: 0, 7: 0, 8: 1, 9: 2}  # PLVs an operation reads + writes
+    kinds, alg_bytes, op_total = {}, 0, 0
+    for s in schedules.values():
+        for op in s.ops:
+            kinds[names.get(op[0], str(op[0]))] = kinds.get(names.get(op[0], str(op[0])), 0) + 1
+            alg_bytes += reads_writes.get(op[0], 2) * plv_bytes
+            op_total += 1
+    ms = elapsed / args.steps * 1e3
+    out = {
+        "metric": "GP subsplit-DAG sweeps: edges x site patterns per second (PopulatePLVs + ComputeLikelihoods + one "
+                  "BranchLengthOptimization sweep)",
+        "value": dag.gpcsp_count * P * args.steps / elapsed, "unit": "edge-patterns/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Path B: subsplit DAG of {'the ten DS1 golden trees' if args.gp_dag == 'ds1' else '20 seeded random topologies over the DS1 taxa'}"
+                               f" ({dag.node_count} nodes, {dag.gpcsp_count} edges, 27 taxa, {P} patterns, JC69), branch lengths U(0.01, 0.2) set every step",
+                   "operations_per_step": op_total, "operations_by_kind": kinds, "ms_by_schedule": parts,
+                   "multi_gpu": "one DAG is one shared structure: replicas only (SURVEY.md 8e)"},
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "numerator": "op-by-op bytes of the step's operations (PLVs read + written, 4 x P doubles + P counts each)",
+                     "algorithmic_bytes_per_step": alg_bytes,
+                     "note": "the whole arena of this DAG is %.1f MB and stays in L2 / Infinity Cache: the step is bound by its "
+                             "dependent chains, not by bytes -- an edge's optimisation is one workgroup running some thirty "
+                             "function evaluations one after the other (39 us per edge, 81 %% of the step's GPU time), and the "
+                             "edges of a sweep depend on one another; the PLV schedules cost 1.35 us per dependency level "
+                             "(profiles/r4_gp_ds1_kernel_stats.csv, DESIGN.md section 9)" % (6 * dag.node_count * plv_bytes / 1e6)},
+        "results": {"sum_per_gpcsp_log_likelihood": float(np.sum(per_edge)),
+                    "mean_abs_branch_length_change": float(np.mean(np.abs(after - bl0)))},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import gp as ogp  # (the checker, timed on the host: the cpu_baseline leg)
+
+        cpu = ogp.OracleGPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+        cpu.set_sbn_parameters(dag.uniform_on_topological_support_prior())
+        step(cpu)
+        count, c0 = 0, time.perf_counter()
+        while time.perf_counter() - c0 < min(args.cpu_seconds, 20.0) or count < 2:
+            step(cpu)
+            count += 1
+        dt = time.perf_counter() - c0
+        ref_edge, ref_after = cpu.get_per_gpcsp_log_likelihoods(), cpu.get_branch_lengths()
+        # the two schedules without an optimiser in them, from the same branch lengths: held to the likelihood bar
+        fixed = []
+        for engine in (eng, cpu):
+            engine.set_branch_lengths(bl0)
+            engine.process_operations(schedules["populate_plvs"])
+            engine.process_operations(schedules["compute_likelihoods"])
+            fixed.append(engine.get_per_gpcsp_log_likelihoods())
+        d_fixed = float(np.max(np.abs(fixed[0] - fixed[1]) / (1.0 + 2e-4 * np.abs(fixed[1]))))
+        if d_fixed > 1e-10:
+            raise SystemExit(f"per-GPCSP log-likelihoods differ from the CPU checker's: {d_fixed}")
+        out["cpu_baseline"] = {"value": dag.gpcsp_count * P * count / dt, "unit": "edge-patterns/s", "cores": 1, "kind": "port",
+                               "ms_per_step": dt / count * 1e3,
+                               "sample": f"{count} steps of the same workload, {dt:.1f} s, oracle/gp_oracle.c on one thread "
+                                         "(the reference's GPEngine is single-threaded Eigen code, src/gp_engine.cpp)"}
+        out["parity"] = {"max_d_per_gpcsp_log_likelihood_fixed_lengths": float(np.max(np.abs(fixed[0] - fixed[1]))),
+                         "max_d_scaled_fixed_lengths": d_fixed,
+                         "after_one_sweep": {"max_d_branch_length": float(np.max(np.abs(after - ref_after))),
+                                             "max_d_per_gpcsp_log_likelihood": float(np.max(np.abs(per_edge - ref_edge))),
+                                             "note": "Brent stops at 10 significant BITS (ldexp(1, 1 - digits), reference "
+                                                     "src/optimization.hpp:75): two correct runs agree in the argmin to about 1e-3 relative"},
+                         "checker": "oracle/gp_oracle.c on the same schedules and branch lengths"}
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,9 +387,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=64,
                     help="x100 DS1 topologies per GPU and call (SURVEY 8d: replicated to fill the device; 6400 trees = 4 ms)")
-    ap.add_argument("--workload", choices=["ds1", "config4", "codon"], default="ds1",
+    ap.add_argument("--workload", choices=["ds1", "config4", "codon", "gp"], default="ds1",
                     help="ds1 = BASELINE config 3 (the headline metric); config4 = synthetic 1000 taxa x 10 000 patterns, "
-                         "1000 trees over the ranks, rescaling on; codon = config 5 (fluA as codons, GY94)")
+                         "1000 trees over the ranks, rescaling on; codon = config 5 (fluA as codons, GY94); gp = Path B, the "
+                         "GPOperation schedules of a subsplit DAG (--gp-dag ds1 | seeded)")
+    ap.add_argument("--gp-dag", choices=["ds1", "seeded"], default="ds1",
+                    help="gp workload: the DAG of the ten DS1 golden trees (84 nodes, 119 edges) or of 20 seeded random "
+                         "topologies over the same taxa (502 nodes, 970 edges)")
     ap.add_argument("--trees", type=int, default=0,
                     help="codon workload: trees per GPU (default 4096); config4: trees in all (default 1000, "
                          "125 per GPU at 8 GPUs; one GPU alone takes 125)")
@@ -287,6 +415,8 @@ def main():
                          "is more than one rank")
     args = ap.parse_args()
 
+    if args.workload == "gp":
+        return gp_workload(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

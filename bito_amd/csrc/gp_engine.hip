@@ -291,12 +291,19 @@ struct OptSettings {
 constexpr double kMinLogBl = -13.9, kMaxLogBl = 1.1, kNewtonEps = 1e-10, kStep = 5e-4, kLogStep = 1.0005,
                  kDiffThreshold = 1e-15;
 constexpr int kOptMaxIter = 1000;
+// Waves of the workgroup that optimises an edge.  Every function evaluation of an optimiser is a reduction over the
+// patterns -- a logarithm and two divisions per pattern -- and an optimisation is a dependent chain of some thirty of
+// them, an edge at a time: what counts is the latency of ONE evaluation, and that is two workgroup barriers and the
+// cross-wave sum as much as the arithmetic.  Measured on the DS1 ten-tree DAG (bench.py --workload gp, 118 optimised edges
+// of 934 patterns per sweep): four waves 4.98 ms per sweep (42 us per edge), sixteen waves -- one pattern per thread --
+// 7.22 ms.
+constexpr int kOptWaves = 4, kOptThreads = 64 * kOptWaves;
 
 struct EdgeFunction {
   const double* A;
   const double* B;
   const double* weights;
-  double* sh;  // [3][4] block-reduction scratch in LDS
+  double* sh;  // [3][kOptWaves] block-reduction scratch in LDS
   double resc;
   int P;
 
@@ -316,12 +323,15 @@ struct EdgeFunction {
     __syncthreads();  // the previous evaluation's readers are done with sh
     for (int k = 0; k < 3; k++) {
       for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
-      if ((threadIdx.x & 63) == 0) sh[k * 4 + (threadIdx.x >> 6)] = v[k];
+      if ((threadIdx.x & 63) == 0) sh[k * kOptWaves + (threadIdx.x >> 6)] = v[k];
     }
     __syncthreads();
-    out[0] = sh[0] + sh[1] + sh[2] + sh[3] + resc;
-    out[1] = sh[4] + sh[5] + sh[6] + sh[7];
-    out[2] = sh[8] + sh[9] + sh[10] + sh[11];
+    double total[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++)
+      for (int w = 0; w < kOptWaves; w++) total[k] += sh[k * kOptWaves + w];  // (fixed order: every thread the same bits)
+    out[0] = total[0] + resc;
+    out[1] = total[1];
+    out[2] = total[2];
   }
   __device__ double NegLL(double x) const {  // brent_nongrad_func: x is the LOG branch length
     double o[3];
@@ -402,7 +412,7 @@ __device__ void BrentMinimize(const EdgeFunction& f, bool with_gradients, double
   *fx_out = fx;
 }
 
-// The whole optimisation of one edge by one workgroup of 256 threads; sh[12] and sh_resc[4] are LDS scratch,
+// The whole optimisation of one edge by one workgroup of kOptThreads threads; sh[3 kOptWaves] and sh_resc[kOptWaves] are LDS scratch,
 // coef holds 2 * Ppad doubles private to the workgroup.
 __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict__ plv, const int* __restrict__ counts,
                              const double* __restrict__ weights, double* __restrict__ bl, double* __restrict__ diff,
@@ -433,7 +443,9 @@ __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict_
   for (int s = 32; s > 0; s >>= 1) resc += __shfl_xor(resc, s);
   if ((threadIdx.x & 63) == 0) sh_resc[threadIdx.x >> 6] = resc;
   __syncthreads();
-  const EdgeFunction f{coef, coef + Ppad, weights, sh, sh_resc[0] + sh_resc[1] + sh_resc[2] + sh_resc[3], P};
+  double resc_total = 0;
+  for (int w = 0; w < kOptWaves; w++) resc_total += sh_resc[w];
+  const EdgeFunction f{coef, coef + Ppad, weights, sh, resc_total, P};
   const double current = bl[edge];
   double result = current;
   switch (cfg.method) {
@@ -499,30 +511,30 @@ __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kOptThreads)
 gp_optimize_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const double* __restrict__ plv,
                    const int* __restrict__ counts, const double* __restrict__ weights, double* __restrict__ bl,
                    double* __restrict__ diff, double* __restrict__ coef, int P, int Ppad, double log_threshold,
                    OptSettings cfg) {
-  __shared__ double sh[12];
-  __shared__ double sh_resc[4];
+  __shared__ double sh[3 * kOptWaves];
+  __shared__ double sh_resc[kOptWaves];
   for (int64_t o = 0; o < op_count; o++)
     OptimizeEdge(ops[o], plv, counts, weights, bl, diff, coef, sh, sh_resc, P, Ppad, log_threshold, cfg);
 }
 
 // A workgroup interprets a whole sub-stream, per-pattern ops and optimiser ops alike: thread t owns the
-// patterns t, t + 256, ... in every op, so per-pattern ops need no barrier between them; an optimiser op
+// patterns t, t + kOptThreads, ... in every op, so per-pattern ops need no barrier between them; an optimiser op
 // is a block-wide reduction and publishes the new branch length to the whole workgroup.  Grid = one
 // workgroup per independent sub-stream (NNI proposals with optimize_new_edges).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kOptThreads)
 gp_block_stream_kernel(const bito_amd_gp_op* __restrict__ ops, const int64_t* __restrict__ offsets,
                        const uint64_t* __restrict__ side, double* __restrict__ plv, int* __restrict__ counts,
                        const double* __restrict__ weights, double* __restrict__ bl, const double* __restrict__ q,
                        double* __restrict__ ll, double* __restrict__ marginal, double* __restrict__ diff,
                        double* __restrict__ coef, int P, int Ppad, double threshold, double log_threshold,
                        OptSettings cfg) {
-  __shared__ double sh[12];
-  __shared__ double sh_resc[4];
+  __shared__ double sh[3 * kOptWaves];
+  __shared__ double sh_resc[kOptWaves];
   const int64_t first = offsets[blockIdx.x], last = offsets[blockIdx.x + 1];
   double* my_coef = coef + (size_t)blockIdx.x * 2 * Ppad;
   for (int64_t o = first; o < last; o++) {
@@ -561,7 +573,7 @@ int RunSegment(bito_amd_gp_engine* e, int64_t first, int64_t count) {
 
 int RunOptimize(bito_amd_gp_engine* e, int64_t first, int64_t count) {
   const OptSettings cfg{e->method, e->significant_digits, e->optimization_count != 0};  // !IsFirstOptimization()
-  hipLaunchKernelGGL(gp_optimize_kernel, dim3(1), dim3(256), 0, 0, e->d_ops + first, count, e->plv, e->counts,
+  hipLaunchKernelGGL(gp_optimize_kernel, dim3(1), dim3(kOptThreads), 0, 0, e->d_ops + first, count, e->plv, e->counts,
                      e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, cfg);
   GP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
@@ -873,11 +885,52 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
     GP_TRY(e, hipGetLastError());
     return BITO_AMD_OK;
   };
+  // A branch-length optimisation sweep (GPDAG::BranchLengthOptimization, reference src/gp_dag.cpp:78-121) alternates
+  // one OptimizeBranchLength with the handful of per-pattern operations that refresh the PLVs around the edge: launched
+  // piece by piece that is two launches per edge (DS1 ten-tree DAG: 236 launches, 21 us each, for 118 edges).  A stretch
+  // with three optimisations and more goes to ONE workgroup that interprets all of it (gp_block_stream_kernel: the
+  // workgroup the optimiser needs anyway; thread t keeps patterns t, t + 256, ... through every operation, so nothing
+  // but the optimiser's own reductions synchronises) -- same arithmetic in the same order, bit for bit.  MEASURED
+  // SLOWER, so it stays behind BITO_AMD_GP_FUSED_SWEEP=1: 5.84 against 4.98 ms per sweep on that DAG (47.5 against 40.4 on the
+  // 970-edge DAG) -- the per-pattern operations between two optimisations, spread over fifteen workgroups by their own
+  // launch, cost one workgroup more than the two launches cost; the sweep is bound by the optimiser's chain of function
+  // evaluations either way (tests/test_gp.py holds the two routes to the same bits).
+  const char* fused_env = std::getenv("BITO_AMD_GP_FUSED_SWEEP");  // (read per call: the tests compare both routes)
+  const bool fused_sweep = fused_env != nullptr && std::atoi(fused_env) != 0;
   int64_t start = 0;
   for (int64_t o = 0; o <= op_count; o++) {
     const bool is_opt = o < op_count && ops[o].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH;
     const bool boundary = o == op_count || is_opt || ops[o].opcode == BITO_AMD_GP_UPDATE_SBN_PROBABILITIES;
     if (!boundary) continue;
+    if (is_opt && fused_sweep) {
+      int64_t end = o, optimisations = 0;
+      while (end < op_count && ops[end].opcode != BITO_AMD_GP_UPDATE_SBN_PROBABILITIES)
+        optimisations += ops[end++].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH;
+      if (optimisations >= 3) {
+        // (a long run of per-pattern operations in front of the first optimisation keeps its levelled launch)
+        int64_t from = start;
+        if (o - start >= kLevelMinOps) {
+          if (int rc = run_segment(start, o - start)) return rc;
+          from = o;
+        }
+        if (e->offsets_cap < 2) {
+          if (e->d_offsets) (void)hipFree(e->d_offsets);
+          e->offsets_cap = 0;
+          GP_TRY(e, hipMalloc((void**)&e->d_offsets, 2 * sizeof(int64_t)));
+          e->offsets_cap = 2;
+        }
+        const int64_t range[2] = {from, end};
+        GP_TRY(e, hipMemcpy(e->d_offsets, range, sizeof(range), hipMemcpyHostToDevice));
+        const OptSettings cfg{e->method, e->significant_digits, e->optimization_count != 0};
+        hipLaunchKernelGGL(gp_block_stream_kernel, dim3(1), dim3(kOptThreads), 0, 0, e->d_ops, (const int64_t*)e->d_offsets, e->d_side,
+                           e->plv, e->counts, e->weights, e->bl, e->q, e->ll, e->marginal, e->diff, e->coef, e->P, e->Ppad,
+                           e->threshold, e->log_threshold, cfg);
+        GP_TRY(e, hipGetLastError());
+        start = end;
+        o = end - 1;
+        continue;
+      }
+    }
     int rc = run_segment(start, o - start);
     if (rc) return rc;
     if (is_opt) {
@@ -953,7 +1006,7 @@ int bito_amd_gp_process_operation_batches(bito_amd_gp_engine* e, const bito_amd_
       e->coef_blocks = batch_count;
     }
     const OptSettings cfg{e->method, e->significant_digits, e->optimization_count != 0};
-    hipLaunchKernelGGL(gp_block_stream_kernel, dim3((unsigned)batch_count), dim3(256), 0, 0, e->d_ops,
+    hipLaunchKernelGGL(gp_block_stream_kernel, dim3((unsigned)batch_count), dim3(kOptThreads), 0, 0, e->d_ops,
                        (const int64_t*)e->d_offsets, e->d_side, e->plv, e->counts, e->weights, e->bl, e->q, e->ll,
                        e->marginal, e->diff, e->coef, e->P, e->Ppad, e->threshold, e->log_threshold, cfg);
   }

@@ -243,3 +243,77 @@ def flua_codon(tree_count: int = 64, site: str = "constant", seed: int = 2024060
     row = CODON_PARAMS + ([0.7] if site != "constant" else [])
     return Workload(f"fluA codon GY94+{site} LL+grad", "GY94", site, "none", sp.patterns, sp.weights, pid, bl,
                     np.tile(np.array(row), (tree_count, 1)), False, True)
+
+
+def postorder_parent_ids(parents) -> np.ndarray:
+    """Parent-id vector with arbitrary internal ids (root = the largest id) -> bito's ids: leaves keep theirs, internal
+    nodes are numbered in post-order with the children visited in id order (Node::Polish, src/node.cpp:383-402)."""
+    parents = [int(x) for x in parents]
+    count = len(parents) + 1
+    n = (count + 1) // 2
+    kids = {}
+    for c, p in enumerate(parents):
+        kids.setdefault(p, []).append(c)
+    new_id, next_id = {}, [n]
+    stack = [(count - 1, False)]
+    while stack:  # (iterative: the synthetic trees are deep)
+        v, done = stack.pop()
+        if v < n:
+            new_id[v] = v
+        elif done:
+            new_id[v] = next_id[0]
+            next_id[0] += 1
+        else:
+            stack.append((v, True))
+            stack.extend((c, False) for c in sorted(kids[v], reverse=True))
+    out = [0] * (count - 1)
+    for c, p in enumerate(parents):
+        out[new_id[c]] = new_id[p]
+    return np.array(out, dtype=np.int32)
+
+
+def ds1_subsplit_dag(tree_count: int = 10):
+    """Path B's workload: the subsplit DAG of DS1 topologies -- the ten trees of
+    DS1.subsampled_10.t (the reference's GP test set) or, beyond ten, the first `tree_count` of DS1.100_topologies.nwk --
+    each unrooted tree rooted on its first root child, as GPInstance reads rooted trees.  Returns (dag, SitePattern)."""
+    from .gp_dag import SubsplitDAG
+
+    if tree_count <= 10:
+        tc = treeio.read_nexus_file(os.path.join(DATA_DIR, "DS1.subsampled_10.t"))
+    else:
+        tc = treeio.read_newick_file(os.path.join(DATA_DIR, "DS1.100_topologies.nwk"))
+    sp = SitePattern(treeio.read_fasta(os.path.join(DATA_DIR, "DS1.fasta")), tc.taxon_names)
+    pids = []
+    for t in tc.trees[:tree_count]:
+        p = np.asarray(t.parent_ids).copy()
+        M = len(p) + 1
+        kids = [c for c in range(M - 1) if p[c] == M - 1]
+        q = np.append(p, M)  # a new root above the old one and its first child
+        q[kids[0]] = M
+        pids.append(postorder_parent_ids(q))
+    return SubsplitDAG(len(tc.taxon_names), pids), sp
+
+
+def seeded_subsplit_dag(tree_count: int = 20, seed: int = 3):
+    """A larger Path B workload: the subsplit DAG of `tree_count` seeded random rooted topologies over DS1's 27 taxa (random
+    pair joining, seed + tree index) on the DS1 alignment -- random trees share few subsplits, so the DAG grows with
+    every tree.  Returns (dag, SitePattern)."""
+    from .gp_dag import SubsplitDAG
+
+    tc = treeio.read_nexus_file(os.path.join(DATA_DIR, "DS1.subsampled_10.t"))
+    sp = SitePattern(treeio.read_fasta(os.path.join(DATA_DIR, "DS1.fasta")), tc.taxon_names)
+    n = len(tc.taxon_names)
+    pids = []
+    for i in range(tree_count):
+        rng = np.random.default_rng(seed + i)
+        nodes = list(range(n))
+        parents = {}
+        next_id = n
+        while len(nodes) > 1:
+            a, b = sorted(rng.choice(len(nodes), 2, replace=False))
+            y, x = nodes.pop(b), nodes.pop(a)
+            parents[x] = parents[y] = next_id
+            nodes.append(next_id)
+            next_id += 1
+        pids.append(postorder_parent_ids([parents[c] for c in range(2 * n - 2)]))
+    return SubsplitDAG(n, pids), sp

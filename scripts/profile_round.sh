@@ -34,5 +34,32 @@ json.dump(out, open(f'{R}/gpurun_out/{T}_pmc.json','w'), indent=1)
 print(k, 'fetch(raw) %.1f MB  write %.1f MB  hbm/launch %.1f MB'%(fetch/1e6, write/1e6, (2*fetch+write)/1e6))
 for r in csv.DictReader(open(f'{R}/gpurun_out/{T}_stats/s_kernel_stats.csv')):
     print(r['Name'][:60], r['Calls'], r['AverageNs'], r['Percentage'])
+# The traversal launches of one blocking call OVERLAP (the second chunk's workgroups move in as the first chunk's leave), so
+# the per-launch average of the stats file counts that stretch twice: from the kernel trace of the same run, the spans of
+# the walk kernel's launches added up and their UNION, per device, and both per launch -- what bench.py reports as
+# avg_launch_span_ms and avg_kernel_ms, reproducible from this file alone.
+import glob
+trace = glob.glob(f'{R}/gpurun_out/{T}_stats/**/*kernel_trace.csv', recursive=True)
+if trace:
+    per_dev = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace[0])):
+        if 'walk_' in r['Kernel_Name'] and 'walk_' in k and r['Kernel_Name'].split('(')[0] == k:
+            per_dev[r.get('Agent_Id', '0')].append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
+    spans = {'kernel': k, 'source': 'rocprofv3 --kernel-trace of: ' + out['command'].split(' -- ')[-1].replace('--pmc FETCH_SIZE|WRITE_SIZE (separate passes) ', ''), 'devices': {}}
+    for dev, iv in per_dev.items():
+        iv.sort()
+        total = sum(b - a for a, b in iv)
+        union, cur_a, cur_b = 0, None, None
+        for a, b in iv:
+            if cur_b is None or a > cur_b:
+                if cur_b is not None: union += cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        if cur_b is not None: union += cur_b - cur_a
+        spans['devices'][dev] = {'launches': len(iv), 'sum_of_spans_ms': total / 1e6, 'union_of_spans_ms': union / 1e6,
+                                 'avg_launch_span_ms': total / 1e6 / len(iv), 'avg_kernel_ms_union': union / 1e6 / len(iv)}
+    json.dump(spans, open(f'{R}/gpurun_out/{T}_kernel_spans.json', 'w'), indent=1)
+    print('kernel spans:', json.dumps(spans['devices']))
 print(open(f'{R}/gpurun_out/{T}_bench.json').read())
 PY

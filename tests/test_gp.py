@@ -532,3 +532,40 @@ def test_gp_rescaling_counts_and_plvs_as_the_reference_holds_them(data_dir, bran
     # the raw per-pattern view differs from the reference's wherever a pattern was rescaled more often than its PLV
     assert differing > 0
     assert abs(gpu.get_log_marginal_likelihood() - cpu.get_log_marginal_likelihood()) < 1e-9
+
+
+@pytest.mark.gpu
+def test_fused_optimisation_sweep_is_bitwise_the_piecewise_one():
+    """A branch-length optimisation sweep runs as ONE workgroup that interprets the whole stretch of the stream (round 4:
+    two launches per edge before); same arithmetic in the same order, so the branch lengths, their changes and the
+    per-GPCSP log-likelihoods are the piecewise launches' bit for bit -- on the DS1 ten-tree DAG (118 optimised edges),
+    Brent and Newton (reference schedule: src/gp_dag.cpp:78-121; optimisers: src/optimization.hpp:71-417)."""
+    import os
+
+    from bito_amd import workloads
+
+    dag, sp = workloads.ds1_subsplit_dag(10)
+    bl0 = np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)
+    results = {}
+    for fused in ("1", "0"):
+        os.environ["BITO_AMD_GP_FUSED_SWEEP"] = fused
+        try:
+            eng = gp.GPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
+            eng.set_sbn_parameters(dag.uniform_on_topological_support_prior())
+            out = []
+            for method in (gp.BRENT, gp.NEWTON):
+                eng.set_optimization_method(method)
+                eng.set_branch_lengths(bl0)
+                eng.reset_optimization_count()
+                eng.process_operations(dag.populate_plvs())
+                eng.process_operations(dag.branch_length_optimization())
+                eng.process_operations(dag.populate_plvs())
+                eng.process_operations(dag.compute_likelihoods())
+                out.append((eng.get_branch_lengths(), eng.get_branch_length_differences(), eng.get_per_gpcsp_log_likelihoods()))
+            results[fused] = out
+        finally:
+            os.environ.pop("BITO_AMD_GP_FUSED_SWEEP", None)
+    for a, b in zip(results["1"], results["0"]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert np.abs(results["1"][0][0] - bl0).max() > 1e-3  # (the sweep did move the lengths)
