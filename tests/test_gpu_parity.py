@@ -418,18 +418,22 @@ def test_large_tree_with_rescaling_vs_oracle():
     assert np.all(np.isfinite(out["branch_lengths"]))
 
 
-def test_config4_full_size_eight_trees():
-    """BASELINE config 4 shape (1000 taxa x 10000 patterns, rescaling on): eight of its trees against the oracle --
-    the first four and four from the last rank's block of the 8-GPU sharding (trees 875..878)."""
-    w = workloads.synthetic_gtr_weibull4(n=1000, P=10000, tree_count=4)
-    tail = workloads.synthetic_gtr_weibull4(n=1000, P=10000, tree_count=4, first_tree=875)
-    assert np.array_equal(w.patterns, tail.patterns)
-    w.parent_ids = np.concatenate([w.parent_ids, tail.parent_ids])
-    w.branch_lengths = np.concatenate([w.branch_lengths, tail.branch_lengths])
-    w.params = np.concatenate([w.params, tail.params])
+def test_config4_full_size_sixteen_trees():
+    """BASELINE config 4 shape (1000 taxa x 10000 patterns, rescaling on): sixteen of its 1000 trees against the oracle,
+    two from the block of every rank of the 8-GPU sharding (trees 125 r and 125 r + 124: the first and the last tree a
+    rank walks)."""
+    picks = [125 * r + k for r in range(8) for k in (0, 124)]
+    parts = [workloads.synthetic_gtr_weibull4(n=1000, P=10000, tree_count=1, first_tree=t) for t in picks]
+    w = parts[0]
+    for other in parts[1:]:
+        assert np.array_equal(w.patterns, other.patterns)
+    w.parent_ids = np.concatenate([x.parent_ids for x in parts])
+    w.branch_lengths = np.concatenate([x.branch_lengths for x in parts])
+    w.params = np.concatenate([x.params for x in parts])
     gpu, cpu = engines(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
     out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
     ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=True)
+    assert gpu.kernel_name() == "walk_hbm_cat_kernel"
     assert np.all(np.isfinite(out["log_likelihood"]))
     assert ll_close(out["log_likelihood"], ref["log_likelihood"])
     assert np.abs(out["branch_lengths"] - ref["branch_lengths"]).max() <= GRAD_ATOL + 1e-9 * np.abs(ref["branch_lengths"]).max()
