@@ -210,6 +210,42 @@ __device__ __forceinline__ void BufLoadRow(BufferRsrc r, unsigned lane_bytes, un
   out[3] = __hiloint2double(b.w, b.z);
 }
 
+// A stored vector of a (node, category) is four rows of 64 patterns, 8 bytes per lane and access.  HBM_CAT_ROWS=0 builds
+// the other layout -- per lane its four states side by side, two 16-byte accesses per lane and vector (1 KB per
+// wave-instruction; 16 bytes per lane is what the memory system moves best, MI355X_MICROARCH.md).  Measured SLOWER
+// with the gradient (round 4, same box): config 4 63.5 against 55.1 ms per 125 trees, 64 taxa 5.09 against 4.52 ms per
+// 1600, log-likelihood only the same -- the pre-order step has no four consecutive registers to land a 16-byte load in
+// at 64 VGPRs, and the four 8-byte requests of a vector were never the limit (the walk changes by under 2 % between
+// five and eight waves per SIMD: scripts/build_hbm_cat_variants.sh w7 / w6 / w5).
+#ifndef HBM_CAT_ROWS
+#define HBM_CAT_ROWS 1
+#endif
+__device__ __forceinline__ void ArenaLoad(BufferRsrc r, unsigned lane, unsigned node_offset, double x[4]) {
+#if HBM_CAT_ROWS
+#pragma unroll
+  for (int i = 0; i < 4; i++) x[i] = BufLoad(r, lane * 8, node_offset + i * 512);
+#else
+  const UInt4 a = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 32, node_offset, HBM_CAT_LOAD_AUX);
+  const UInt4 b = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 32, node_offset + 16, HBM_CAT_LOAD_AUX);
+  x[0] = __hiloint2double(a.y, a.x);
+  x[1] = __hiloint2double(a.w, a.z);
+  x[2] = __hiloint2double(b.y, b.x);
+  x[3] = __hiloint2double(b.w, b.z);
+#endif
+}
+__device__ __forceinline__ void ArenaStore(BufferRsrc r, unsigned lane, unsigned node_offset, const double x[4]) {
+#if HBM_CAT_ROWS
+#pragma unroll
+  for (int i = 0; i < 4; i++) BufStore(r, lane * 8, node_offset + i * 512, x[i]);
+#else
+  UInt4 a, b;
+  a.x = __double2loint(x[0]); a.y = __double2hiint(x[0]); a.z = __double2loint(x[1]); a.w = __double2hiint(x[1]);
+  b.x = __double2loint(x[2]); b.y = __double2hiint(x[2]); b.z = __double2loint(x[3]); b.w = __double2hiint(x[3]);
+  __builtin_amdgcn_raw_buffer_store_b128(a, r, lane * 32, node_offset, HBM_CAT_STORE_AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(b, r, lane * 32, node_offset + 16, HBM_CAT_STORE_AUX);
+#endif
+}
+
 __device__ __forceinline__ void ScalePow2(double v[4], int& exponent_sum) {
   const double mx = fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
   const int ex = __builtin_amdgcn_frexp_exp(mx);  // 0 for mx == 0
@@ -262,7 +298,6 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   const BufferRsrc matrows = MakeRsrc(mats);  // [node * C * kMatHot * 8][(kMatPT + state * 4) * 8]
   const unsigned node_bytes = (unsigned)C * 4 * kCatTile * 8, mat_bytes = (unsigned)C * kMatHot * 8;
   const unsigned ulane = lane;
-  const unsigned lane8 = ulane * 8;  // (constant offsets go to the scalar offset: added to this they would be hoisted into registers of their own)
   struct Child {
     int kind;  // 0 tip, 1 stored internal node, 2 cherry
     int a, b;
@@ -318,8 +353,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       for (int i = 0; i < 4; i++) x[i] = fwd[i];
       fwd_owner = -1;
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = BufLoad(arena, lane8, (unsigned)(cc - n) * node_bytes + i * 512);
+      ArenaLoad(arena, ulane, (unsigned)(cc - n) * node_bytes, x);
     }
   };
   // post-order: the vector of node `owner` (in v) into a column -- a free one, else the one with the older vector,
@@ -331,15 +365,19 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     const int old = into_fwd ? fwd_owner : pend_owner;
     if (into_fwd) {
       if (!GRAD && old >= 0) {
+        double o[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(old - n) * node_bytes + i * 512, fwd[i]);
+        for (int i = 0; i < 4; i++) o[i] = fwd[i];
+        ArenaStore(arena, ulane, (unsigned)(old - n) * node_bytes, o);
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) fwd[i] = v[i];
     } else {
       if (!GRAD && old >= 0) {
+        double o[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(old - n) * node_bytes + i * 512, pend[i]);
+        for (int i = 0; i < 4; i++) o[i] = pend[i];
+        ArenaStore(arena, ulane, (unsigned)(old - n) * node_bytes, o);
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) pend[i] = v[i];
@@ -397,8 +435,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     if (node == N - 1) {
       site = tm->cat_weight[c] * (tm->pi[0] * dd[0] + tm->pi[1] * dd[1] + tm->pi[2] * dd[2] + tm->pi[3] * dd[3]);
     } else if (GRAD) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(node - n) * node_bytes + i * 512, dd[i]);
+      ArenaStore(arena, ulane, (unsigned)(node - n) * node_bytes, dd);
     }
   }
   // ---- the categories of a pattern meet: L_p and this category's share of it ---
@@ -495,8 +532,10 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
         return;
       }
       if (pend_owner >= 0) {  // an older vector waits in the column: it moves to its cell in the arena
+        double o[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) BufStore(arena, lane8, (unsigned)(pend_owner - n) * node_bytes + i * 512, pend[i]);
+        for (int i = 0; i < 4; i++) o[i] = pend[i];
+        ArenaStore(arena, ulane, (unsigned)(pend_owner - n) * node_bytes, o);
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) pend[i] = q[i];
@@ -518,8 +557,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
         for (int i = 0; i < 4; i++) U[i] = pend[i];
         pend_owner = -1;
       } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++) U[i] = BufLoad(arena, lane8, (unsigned)(node - n) * node_bytes + i * 512);
+        ArenaLoad(arena, ulane, (unsigned)(node - n) * node_bytes, U);
       }
       message(k0, c0, A0);
       message(k1, c1, A1);
