@@ -29,7 +29,7 @@ SYMBOLS = [
     "bito_amd_engine_param_count", "bito_amd_engine_device_count", "bito_amd_engine_category_count", "bito_amd_engine_state_count", "bito_amd_engine_block_count",
     "bito_amd_engine_block", "bito_amd_engine_log_likelihoods", "bito_amd_engine_gradients",
     "bito_amd_engine_upload", "bito_amd_engine_update", "bito_amd_engine_run", "bito_amd_engine_sync",
-    "bito_amd_engine_download", "bito_amd_engine_download_async", "bito_amd_engine_results_async", "bito_amd_engine_stream", "bito_amd_engine_set_kernel", "bito_amd_plan_pipe_walk", "bito_amd_engine_time_runs",
+    "bito_amd_engine_download", "bito_amd_engine_download_async", "bito_amd_engine_results_async", "bito_amd_engine_stream", "bito_amd_engine_set_kernel", "bito_amd_plan_pipe_walk", "bito_amd_count_unstored_nodes", "bito_amd_engine_time_runs",
     "bito_amd_engine_kernel_timing", "bito_amd_engine_kernel_elapsed", "bito_amd_engine_kernel_span_sum", "bito_amd_engine_kernel_name", "bito_amd_engine_kernel_form",
     "bito_amd_version", "bito_amd_engine_read_general_model",
     "bito_amd_engine_time_trees_from_branch_lengths", "bito_amd_engine_time_trees_from_height_ratios",
@@ -82,6 +82,7 @@ def lib():
     L.bito_amd_engine_download.argtypes = [vp, vp, vp]
     L.bito_amd_engine_download_async.argtypes = [vp, vp, vp]
     L.bito_amd_plan_pipe_walk.argtypes = [C.c_int32] * 5 + [ip]
+    L.bito_amd_count_unstored_nodes.argtypes = [C.c_int32] * 4 + [ip, C.c_int32, ip]
     L.bito_amd_engine_results_async.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp)]
     L.bito_amd_engine_stream.restype = vp
     L.bito_amd_engine_stream.argtypes = [vp]

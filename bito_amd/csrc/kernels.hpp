@@ -31,6 +31,9 @@ struct BatchDims {
   int32_t category_count; // C
   int32_t tree_count;     // T
   int32_t min_cherries;   // fewest cherries (internal nodes over two tips, root excepted) of any tree of the batch
+  int32_t min_unstored;   // fewest nodes walk_pipe_kernel keeps no vector for: cherries and, with pipe_fold, the pitchforks
+                          // (a tip and a cherry under one node) it folds into their parents' steps
+  int32_t pipe_fold;      // walk_pipe_kernel folds pitchforks like cherries (worker.cpp counts them the same way)
 };
 
 // MFMA operand images, one set per (tree, branch), 3 x 64 doubles, lane order of
@@ -210,7 +213,7 @@ LdsPlan PlanPipeClass(const BatchDims& d, int tree_count, int slots, int force_g
 int PipeMaxSlots(const BatchDims& d, int G, int layout = kPipePlanAuto);
 // two waves per SIMD (round 4): trees of up to 28 taxa, one image per branch (reversible form), 256 registers per wave
 bool PipeTwoApplies(const BatchDims& d);
-int PipeSlotsOfTree(const BatchDims& d, int cherries);
+int PipeSlotsOfTree(const BatchDims& d, int unstored);  // (cherries + folded pitchforks: Worker::tree_cherries)
 struct PipeClass {
   int tree_count;          // trees of this launch
   const int32_t* order;    // their ids (device), or nullptr: trees 0 .. tree_count-1
@@ -262,11 +265,12 @@ int HbmWalkGradRows(const BatchDims& d);
 // form of the pre-order recursion, which the engine uses only when every branch length is at least
 // kPipeReversibleMinBranch (about 1e-6) (walk_pipe.hip, scripts/gen_walk_pipe.py)
 constexpr int kPipeExactTaxa = 38;
-// AUTO sends trees beyond this to the HBM-arena walk although walk_pipe_kernel takes up to 64 taxa: from 59 taxa on
-// most trees need its one-group-per-wave class, and the HBM walk of round 3's end is the faster one there (1600 trees x
-// 1000 patterns, ms per pass, walk_pipe_kernel / walk_hbm_cat_kernel: 56 taxa 3.56 / 3.94, 57: 3.84 / 4.0, 60: 4.40 /
-// 4.28, 64: 4.68 / 4.56; profiles/r3_midsize_56_to_64_taxa.log, profiles/r3_v5_hbm_sizes.log)
-constexpr int kPipeAutoTaxa = 58;
+// AUTO takes walk_pipe_kernel up to the size it is built for, 64 taxa (a VGPR per tip for its packed masks, 4n - 4 image
+// registers).  Round 3 stopped at 58: beyond, most trees kept too many vectors for two pattern groups per wave.  With
+// pitchforks folded into their parents' steps (round 4) nine 64-taxon trees in ten run with two: 1600 trees x 1000
+// patterns, ms per pass, walk_pipe_kernel before / now / walk_hbm_cat_kernel: 56 taxa 3.56 / 2.62 / 3.91, 60: 4.40 / 2.82 /
+// 4.20, 64: 4.68 / 3.16 / 4.50 (profiles/r4_midsize_fold.log)
+constexpr int kPipeAutoTaxa = 64;
 constexpr double kPipeReversibleRateScale = 0.2;  // smallest off-diagonal rate of the matrices that bound was measured on
 constexpr double kPipeReversibleMinBranch = 9e-7;  // (just below exp(-13.9), the reference optimiser's own floor: src/dag_branch_handler.hpp:272)
 bool HbmCatKernelApplies(const BatchDims& d);

@@ -183,13 +183,63 @@ int ValidateTreeShape(Worker* e, int rooted, int node_count) {
   return BITO_AMD_OK;
 }
 
+// Nodes of one tree that walk_pipe_kernel keeps no vector for, counted exactly as its step tables are built
+// (walk_pipe.hip, PipeSchedulePart): on the DETRIFURCATED tree (SetupTopologyCore: an unrooted tree's root keeps children 1
+// and 2 of the trifurcation, a new root joins child 0 with it) the cherries -- internal nodes over two tips, the root
+// excepted -- and, with `fold`, the pitchforks (a tip and a cherry under one node) whose sibling is a tip or a stored
+// node; of two pitchforks under one node the one with the lower id.  The parent-id row has passed the range checks.
+int UnstoredNodes(int n, int M, int rooted, const int32_t* par, bool fold, std::vector<int>* kids_buf, std::vector<int>* parent_buf) {
+  const int N = 2 * n - 1, NI = n - 1;
+  std::vector<int>& ch = *kids_buf;
+  std::vector<int>& up = *parent_buf;
+  ch.assign((size_t)2 * NI, -1);
+  up.assign((size_t)N, -1);
+  int third = -1;
+  for (int child = 0; child < M - 1; child++) {
+    const int k = par[child] - n;
+    if (ch[2 * k] < 0) ch[2 * k] = child;
+    else if (ch[2 * k + 1] < 0) ch[2 * k + 1] = child;
+    else third = child;
+  }
+  if (!rooted) {
+    const int r = M - 1, a = ch[2 * (r - n)], bb = ch[2 * (r - n) + 1];
+    ch[2 * (r - n)] = bb;
+    ch[2 * (r - n) + 1] = third;
+    ch[2 * (r + 1 - n)] = a;
+    ch[2 * (r + 1 - n) + 1] = r;
+  }
+  for (int j = 0; j < NI; j++) {
+    if (ch[2 * j] < 0 || ch[2 * j + 1] < 0) return 0;  // (not a bifurcating tree: the shape check reports it)
+    up[ch[2 * j]] = n + j;
+    up[ch[2 * j + 1]] = n + j;
+  }
+  auto cherry = [&](int c) { return c >= n && c != N - 1 && ch[2 * (c - n)] < n && ch[2 * (c - n) + 1] < n; };
+  auto fork = [&](int c) {
+    if (c < n || c == N - 1) return false;
+    const int a = ch[2 * (c - n)], b = ch[2 * (c - n) + 1];
+    return (a < n && cherry(b)) || (b < n && cherry(a));
+  };
+  int unstored = 0;
+  for (int c = n; c < N - 1; c++) {
+    if (cherry(c)) {
+      unstored++;
+    } else if (fold && fork(c)) {
+      const int p = up[c];
+      const int sib = ch[2 * (p - n)] == c ? ch[2 * (p - n) + 1] : ch[2 * (p - n)];
+      if (sib < n || (!cherry(sib) && (!fork(sib) || c < sib))) unstored++;
+    }
+  }
+  return unstored;
+}
+
 // Trees [t0, t1) of a block whose shape ValidateTreeShape has accepted; writes the range's rows of cherries_of, the
 // range's fewest cherries and, on failure, *msg -- nothing else (see ValidateParamsRange).
 int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_count, const int32_t* parent_ids,
-                       int* fewest_out, int32_t* cherries_of, std::string* msg) {
+                       int* fewest_out, int32_t* cherries_of, std::string* msg, int* fewest_unstored_out = nullptr) {
   const int n = e->n, M = node_count;
   std::vector<int> count(M), tip_children(M);
-  int fewest = M;
+  std::vector<int> kids, parent_of;  // (the detrifurcated tree, for the pitchfork count)
+  int fewest = M, fewest_unstored = M;
   for (int t = t0; t < t1; t++) {
     const int32_t* par = parent_ids + (size_t)t * (M - 1);
     std::fill(count.begin(), count.end(), 0);
@@ -213,6 +263,14 @@ int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_cou
     if (!rooted) cherries += tip_children[M - 1] == 3;
     fewest = std::min(fewest, cherries);
     if (cherries_of) cherries_of[t] = cherries;
+    bool shape_ok = true;
+    for (int i = n; i < M && shape_ok; i++) shape_ok = count[i] == ((!rooted && i == M - 1) ? 3 : 2);
+    if (shape_ok && (cherries_of || fewest_unstored_out)) {
+      // what walk_pipe_kernel keeps no vector for: cherries and folded pitchforks of the tree as it is walked
+      const int unstored = UnstoredNodes(n, M, rooted, par, e->pipe_fold != 0, &kids, &parent_of);
+      fewest_unstored = std::min(fewest_unstored, unstored);
+      if (cherries_of) cherries_of[t] = unstored;
+    }
     for (int i = n; i < M; i++) {
       const int want = (!rooted && i == M - 1) ? 3 : 2;
       if (count[i] != want) {
@@ -225,6 +283,7 @@ int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_cou
     }
   }
   if (fewest_out) *fewest_out = fewest;
+  if (fewest_unstored_out) *fewest_unstored_out = fewest_unstored;
   return BITO_AMD_OK;
 }
 
@@ -649,13 +708,18 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
           split.plan_b = pb;
           split.order_host = a;
           split.order_host.insert(split.order_host.end(), bb.begin(), bb.end());
+          split.flagged = true;  // (the step tables take a tree's class from the host's list, never from a count of their own)
           // (through pinned memory, in stream order: an earlier traversal that reads the list has finished by then,
           // and the staging copy is rewritten only by the next batch, which waits for the worker to be idle)
-          if ((size_t)T > e->pipe_order.capacity) HIP_TRY(e, hipStreamSynchronize(WalkStream(e)));
-          HIP_TRY(e, e->pipe_order.Reserve((size_t)T));
-          HIP_TRY(e, e->pin_order.Reserve((size_t)T * sizeof(int32_t)));
+          const size_t ints = (size_t)T + ((size_t)T + 3) / 4;  // the order list, then one byte per tree: class A
+          if (ints > e->pipe_order.capacity) HIP_TRY(e, hipStreamSynchronize(WalkStream(e)));
+          HIP_TRY(e, e->pipe_order.Reserve(ints));
+          HIP_TRY(e, e->pin_order.Reserve(ints * sizeof(int32_t)));
           std::memcpy(e->pin_order.ptr, split.order_host.data(), (size_t)T * sizeof(int32_t));
-          HIP_TRY(e, hipMemcpyAsync(e->pipe_order.ptr, e->pin_order.ptr, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, SetupStream(e)));
+          uint8_t* flags = reinterpret_cast<uint8_t*>(static_cast<int32_t*>(e->pin_order.ptr) + T);
+          std::memset(flags, 0, (size_t)T);
+          for (int32_t t : a) flags[t] = 1;
+          HIP_TRY(e, hipMemcpyAsync(e->pipe_order.ptr, e->pin_order.ptr, ints * sizeof(int32_t), hipMemcpyHostToDevice, SetupStream(e)));
         }
       }
     }
@@ -918,6 +982,7 @@ int WorkerCreate(int32_t device_id, uint64_t arena_bytes, const char* substituti
   if (const char* serial = std::getenv("BITO_AMD_SERIAL_SETUP")) e->serial_setup = std::atoi(serial);
   if (const char* direct = std::getenv("BITO_AMD_PIPE_DIRECT")) e->pipe_direct = std::atoi(direct) != 0;
   if (const char* two = std::getenv("BITO_AMD_PIPE_TWO")) e->pipe_two = std::atoi(two);
+  if (const char* fold = std::getenv("BITO_AMD_PIPE_FOLD")) e->pipe_fold = std::atoi(fold);
   for (int i = 0; i < Worker::kSets; i++) {
     if ((hrc = hipEventCreateWithFlags(&e->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess ||
         (hrc = hipEventCreateWithFlags(&e->ev_walk_done[i], hipEventDisableTiming)) != hipSuccess)
@@ -1071,7 +1136,7 @@ void WorkerStageFill(Worker* e, int32_t t0, int32_t t1, StagePart* out) {
   *out = StagePart{};
   out->first_tree = t0;
   out->code = ValidateTreesRange(e, t0, t1, st.rooted, st.node_count, st.parent_ids, &out->min_cherries,
-                                 e->tree_cherries.data(), &out->message);
+                                 e->tree_cherries.data(), &out->message, &out->min_unstored);
   if (!out->code && st.params) out->code = ValidateParamsRange(e, t0, t1, st.params, &out->message);
   if (out->code) return;
   double* stage = static_cast<double*>(e->pin_in.ptr);
@@ -1098,10 +1163,11 @@ int WorkerStageEnd(Worker* e, const StagePart* parts, int part_count) {
   for (int i = 0; i < part_count; i++)
     if (parts[i].code && (!bad || parts[i].first_tree < bad->first_tree)) bad = &parts[i];
   if (bad) return Fail(e, bad->code, bad->message);
-  int min_cherries = st.node_count;
+  int min_cherries = st.node_count, min_unstored = st.node_count;
   double min_branch = std::numeric_limits<double>::infinity(), min_rate = std::numeric_limits<double>::infinity();
   for (int i = 0; i < part_count; i++) {
     min_cherries = std::min(min_cherries, parts[i].min_cherries);
+    min_unstored = std::min(min_unstored, parts[i].min_unstored);
     min_branch = std::min(min_branch, parts[i].min_branch);
     min_rate = std::min(min_rate, parts[i].min_rate);
   }
@@ -1146,6 +1212,8 @@ int WorkerStageEnd(Worker* e, const StagePart* parts, int part_count) {
   e->dims.category_count = C;
   e->dims.tree_count = tree_count;
   e->dims.min_cherries = min_cherries;
+  e->dims.min_unstored = std::max(min_unstored, min_cherries);
+  e->dims.pipe_fold = e->pipe_fold;
   e->resident = true;
   return BITO_AMD_OK;
 }
@@ -1690,9 +1758,23 @@ extern "C" int bito_amd_plan_pipe_walk(int32_t taxon_count, int32_t pattern_coun
   d.category_count = category_count;
   d.tree_count = tree_count;
   d.min_cherries = min_cherries;
+  d.min_unstored = min_cherries;
+  d.pipe_fold = 0;
   const LdsPlan p = PlanPipe(d);
   const int32_t out[7] = {p.groups, p.patterns_per_block, p.tiles, (int32_t)p.lds_bytes, p.tile_run, p.whole_trees, p.slots};
   for (int k = 0; k < 7; k++) plan[k] = out[k];
+  return BITO_AMD_OK;
+}
+
+// nodes of each tree that walk_pipe_kernel keeps no vector for (cherries, and with `fold` the pitchforks it folds): the
+// host's count, which sizes a tree's LDS slots and must be the step tables' own (tests hold it to a restatement)
+extern "C" int bito_amd_count_unstored_nodes(int32_t taxon_count, int32_t tree_count, int32_t rooted, int32_t node_count,
+                                             const int32_t* parent_ids, int32_t fold, int32_t* out) {
+  if (!parent_ids || !out || taxon_count < 3 || tree_count < 1) return BITO_AMD_ERR_BAD_ARG;
+  if (node_count != (rooted ? 2 * taxon_count - 1 : 2 * taxon_count - 2)) return BITO_AMD_ERR_BAD_ARG;
+  std::vector<int> kids, up;
+  for (int t = 0; t < tree_count; t++)
+    out[t] = UnstoredNodes(taxon_count, node_count, rooted, parent_ids + (size_t)t * (node_count - 1), fold != 0, &kids, &up);
   return BITO_AMD_OK;
 }
 

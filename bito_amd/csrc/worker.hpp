@@ -152,7 +152,7 @@ struct Worker {
   // walk_pipe_kernel in two launches: the trees of the resident batch that keep few enough vectors for four
   // pattern groups per wave (class A), and the others (class B) -- one tree with few cherries would otherwise
   // halve the groups of the whole batch
-  std::vector<int32_t> tree_cherries;  // per tree of the resident batch (counted while it is validated)
+  std::vector<int32_t> tree_cherries;  // per tree of the resident batch: nodes walk_pipe_kernel keeps no vector for -- cherries and folded pitchforks (counted while it is validated)
   // Two waves per SIMD (round 4, trees of up to 28 taxa): that form keeps one image per branch, i.e. the reversible form
   // of the pre-order recursion, which a tree may take only when its shortest branch times its smallest off-diagonal
   // rate clears the bound of DESIGN.md section 3 -- decided PER TREE while the batch is staged (the trees that do not, and
@@ -160,6 +160,9 @@ struct Worker {
   // AUTO does not take it: measured on config 3 it is 13 % SLOWER than one wave per SIMD with four groups (4.23 against
   // 3.75 ms per 6400 trees; profiles/r4_pipe_two_waves.md has the numbers and the reasons) -- it runs when the kernel is
   // pinned (BITO_AMD_KERNEL_LDS_PIPE2) or with BITO_AMD_PIPE_TWO=1 in the environment.
+  // walk_pipe_kernel folds pitchforks (a tip and a cherry under one node) into their parents' steps (round 4;
+  // BITO_AMD_PIPE_FOLD=0: every pitchfork a step of its own, as before)
+  int pipe_fold = 1;
   int pipe_two = 0;                    // 1: AUTO takes the two-wave form where it applies (BITO_AMD_PIPE_TWO)
   std::vector<uint8_t> tree_rev_ok;    // per tree of the resident batch: the guard holds (empty: not evaluated)
   struct PipeSplit {
@@ -242,7 +245,7 @@ struct StagePart {
   int code = 0;          // BITO_AMD_OK or the error the range's first bad tree gives
   std::string message;
   int first_tree = 0;
-  int min_cherries = 1 << 30;
+  int min_cherries = 1 << 30, min_unstored = 1 << 30;
   double min_branch = std::numeric_limits<double>::infinity(), min_rate = std::numeric_limits<double>::infinity();
 };
 int WorkerStageBegin(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,

@@ -45,7 +45,7 @@ extern "C" {
 #define BITO_AMD_GRAD_LOG_DET_JACOBIAN_GRADIENT 32 /* include_log_det_jacobian_gradient */
 
 /* Kernel selection (diagnostics / benchmarking).  AUTO picks walk_pipe_kernel (partial-likelihood messages in
- * LDS, matrix images in registers) for trees of up to 38 taxa -- up to 58 when the batch's shortest branch times its
+ * LDS, matrix images in registers) for trees of up to 38 taxa -- up to 64 when the batch's shortest branch times its
  * smallest off-diagonal rate (over 0.2) is 9e-7 or more -- with 1, 2 or 4 rate categories and no rescaling, the
  * HBM-arena walk otherwise. */
 #define BITO_AMD_KERNEL_AUTO 0
@@ -285,6 +285,12 @@ int bito_amd_engine_set_kernel(bito_amd_engine *e, int32_t kernel);
  * keeps in LDS. */
 int bito_amd_plan_pipe_walk(int32_t taxon_count, int32_t pattern_count, int32_t category_count,
                             int32_t tree_count, int32_t min_cherries, int32_t plan[7]);
+/* Diagnostics / tests: per tree, the nodes walk_pipe_kernel keeps no LDS vector for -- cherries (internal nodes over two
+ * tips, the root excepted) and, with fold != 0, the pitchforks (a tip and a cherry under one node) whose sibling is a tip
+ * or a stored node, counted on the detrifurcated tree exactly as the kernel's step tables are built.  parent_ids
+ * [tree_count][node_count - 1], node_count 2n-2 (unrooted) or 2n-1 (rooted); out [tree_count]. */
+int bito_amd_count_unstored_nodes(int32_t taxon_count, int32_t tree_count, int32_t rooted, int32_t node_count,
+                                  const int32_t *parent_ids, int32_t fold, int32_t *out);
 /* Runs `steps` passes back to back with HIP events on the engine's stream.
  * total_ms: wall time of all steps; kernel_ms: summed duration of the dominant
  * (traversal) kernel only; kernel_launches: how many such launches that was. */

@@ -35,7 +35,7 @@ SETPC_WAIT_STATES = 4 # what the 21 cycles of a taken s_setpc_b64 count for
 
 VBASE = 32   # first VGPR the loops may use (v0..v31 and a224.. stay with the compiler)
 VLIMIT = 256
-SBASE, SLIMIT = 36, 100  # SGPRs
+SBASE, SLIMIT = 32, 100  # SGPRs (s0..s31 stay with the compiler)
 
 
 import re
@@ -409,10 +409,10 @@ class Loops:
         self.WMASK = S.get(2, "WMASK", 2)
         self.BASE = [S.get(2, "BASE0", 2), S.get(2, "BASE1", 2)]  # code address of the bodies of parity 0 / 1
         self.PC = S.get(2, "PC", 2)
-        self.OFFTAB = S.get(11, "OFFTAB")  # code offsets of the bodies (5 + 5 hand-over forms) and of the loop exit
+        self.OFFTAB = S.get(2 * len(self.KINDS) + 1, "OFFTAB")  # code offsets of the bodies (kinds + their hand-over forms) and of the loop exit
         self.IMGP = S.get(2, "IMGP", 2)   # (the image loader's pointer; the loops use the pair as scratch)
         self.TMP = [self.IMGP, self.IMGP + 1, S.get(1, "TMP2")]
-        self.TMPM = [S.get(1, f"TMPM{k}") for k in range(2)]  # scratch of messages() only
+        self.TMPM = [S.get(1, f"TMPM{k}") for k in range(4)]  # scratch of messages() only
         self.snext = S.next
         self.V, self.S = V, S
 
@@ -702,25 +702,48 @@ class Loops:
         self.salu(f"s_addc_u32 s{self.BASE[1] + 1}, s{self.BASE[0] + 1}, 0")
         for k, name in enumerate(names):
             self.salu(f"s_mov_b32 s{self.OFFTAB + k}, {self.L(name + '_0')}-{self.L('block0')}")
-        self.salu(f"s_mov_b32 s{self.OFFTAB + 10}, {self.L('out_0')}-{self.L('block0')}")
+        self.salu(f"s_mov_b32 s{self.OFFTAB + 2 * len(self.KINDS)}, {self.L('out_0')}-{self.L('block0')}")
 
     # ---- child messages of one slot (both passes) ---------------------------------------------------
+    def fork(self, kinds):
+        """registers and descriptor fields of the pitchfork slot of a step, or None.  The pitchfork's vectors beyond a
+        cherry's -- the third tip's message MC and the inner cherry's message MH -- live in the MA / MB registers of the
+        OTHER slot, which a tip or a stored cell there leaves idle; its third tip operand in the other slot's spare one."""
+        if "F" not in kinds:
+            return None
+        s = kinds.index("F")
+        o = 1 - s
+        assert kinds[o] in ("T", "C")
+        tip = [[self.TIPA0, self.TIPB0], [self.TIPA1, self.TIPB1]]
+        return dict(s=s, MA=self.MA[s], MB=self.MB[s], MC=self.MA[o], MH=self.MB[o], X=self.X[s], MSG=self.MSG[s],
+                    TPA=self.TP[2 * s], TPB=self.TP[2 * s + 1], TPC=self.TP[2 * o + 1],
+                    tipa=tip[s][0], tipbc=tip[s][1],                    # tip A; the cherry's tips: B | C << 8
+                    img=[self.IMG0, self.IMG1][s],                      # image register of the node's branch | of the cherry's << 8
+                    edge_h=[self.OFFC0, self.OFFC1][s])                 # gradient-row offset of the cherry's branch (the slot has no cell)
+
     def messages(self, kinds, scalar_work=None):
-        """leaves the message of a tip / cherry slot s in MSG[s] -- a stored cell's message is M[s] itself.
-        Cherry: MA, MB (tip messages) are kept for the pre-order pass.  scalar_work: emits scalar instructions
-        the body needs anyway (they may use M0); they are placed where they fill wait states -- between a
-        cherry's tip products and their product -- or, without a cherry, at the end"""
+        """leaves the message of a tip / cherry / pitchfork slot s in MSG[s] -- a stored cell's message is M[s] itself.
+        Cherry: MA, MB (tip messages) are kept for the pre-order pass; pitchfork: MA, MB, MC and the inner cherry's
+        message MH.  scalar_work: emits scalar instructions the body needs anyway (they may use M0); they are placed where
+        they fill wait states -- between a cherry's tip products and their product -- or, without one, at the end"""
         G = self.G
         t = self.TMPM
         tip = [[self.TIPA0, self.TIPB0], [self.TIPA1, self.TIPB1]]
         img = [self.IMG0, self.IMG1]
+        F = self.fork(kinds)
         wanted = []
+        if F:  # (the third tip's id out of its packed field first: the index-mode region below reads it)
+            self.salu(f"s_lshr_b32 s{t[3]}, {self.cur(F['tipbc'])}, 8")
         for s in (0, 1):
             if kinds[s] == "T":
                 wanted.append((2 * s, self.cur(tip[s][0])))
             elif kinds[s] == "H":
                 wanted.append((2 * s, self.cur(tip[s][0])))
                 wanted.append((2 * s + 1, self.cur(tip[s][1])))
+            elif kinds[s] == "F":  # (an index is the low byte of its register: the packed field serves tip B as it is)
+                wanted.append((self.TP.index(F["TPA"]), self.cur(F["tipa"])))
+                wanted.append((self.TP.index(F["TPB"]), self.cur(F["tipbc"])))
+                wanted.append((self.TP.index(F["TPC"]), f"s{t[3]}"))
         self.tip_operands(wanted, leave_on=bool(wanted))
         # one index-mode region for all the tip products (s_set_gpr_idx_on switches the mode from source 1 to
         # source 0 as it sets the index; further indices by s_set_gpr_idx_idx)
@@ -749,23 +772,48 @@ class Loops:
                 index(f"s{t[1]}")
                 for g in range(G):
                     self.mfma(self.MB[s][g], ("A", 0), self.TP[2 * s + 1][g])
+            elif kinds[s] == "F":
+                # 2 A, 2 B (the low byte of (B | C << 8) << 1) and 2 C (the low byte of (B | C << 8) >> 7: B < 128)
+                self.salu(f"s_lshl_b32 s{t[0]}, {self.cur(F['tipa'])}, 1")
+                self.salu(f"s_lshl_b32 s{t[1]}, {self.cur(F['tipbc'])}, 1")
+                self.salu(f"s_lshr_b32 s{t[2]}, {self.cur(F['tipbc'])}, 7")
+                for sg, dst, tp in ((t[0], F["MA"], F["TPA"]), (t[1], F["MB"], F["TPB"]), (t[2], F["MC"], F["TPC"])):
+                    index(f"s{sg}")
+                    for g in range(G):
+                        self.mfma(dst[g], ("A", 0), tp[g])
         if not first:
             self.idx_off()
-        if scalar_work is not None and "H" in kinds:
+        if scalar_work is not None and ("H" in kinds or F):
             scalar_work()
             scalar_work = None
             self.e.comment("(scalar work in the wait states between the tip products and their product)")  # (a comment pins them here)
+        if F:  # the inner cherry's image register (after the scalar work: that may use the temporaries' neighbours, not these)
+            self.salu(f"s_lshr_b32 s{t[0]}, {self.cur(F['img'])}, 8")
         for s in (0, 1):
             if kinds[s] == "H":
                 for g in range(G):
                     self.vmul(self.X[s][g], self.MA[s][g], self.MB[s][g])
+            elif kinds[s] == "F":
+                for g in range(G):
+                    self.vmul(F["X"][g], F["MB"][g], F["MC"][g])  # the inner cherry's partial
         first = True
         for s in (0, 1):
             if kinds[s] == "H":
                 index(self.cur(img[s]))
                 for g in range(G):
                     self.mfma(self.MSG[s][g], ("A", 0), self.X[s][g])
+            elif kinds[s] == "F":
+                index(f"s{t[0]}")
+                for g in range(G):
+                    self.mfma(F["MH"][g], ("A", 0), F["X"][g])  # ... and its message
         if not first:
+            self.idx_off()
+        if F:  # the pitchfork's own partial and message
+            for g in range(G):
+                self.vmul(F["X"][g], F["MA"][g], F["MH"][g])
+            self.idx_on(self.cur(F["img"]), "SRC0")
+            for g in range(G):
+                self.mfma(F["MSG"][g], ("A", 0), F["X"][g])
             self.idx_off()
         if scalar_work is not None:
             scalar_work()
@@ -776,7 +824,13 @@ class Loops:
     # =============================== post-order loop ===============================================
     # body index = position here; the second five hand a vector to the NEXT step in registers (post-order:
     # this node's message is that step's slot-1 operand; pre-order: slot 1's partial is that step's U)
-    KINDS = [("cc", "C", "C"), ("tc", "T", "C"), ("hc", "H", "C"), ("th", "T", "H"), ("hh", "H", "H")]
+    # Child kinds: T tip, C stored cell, H cherry (two tips; rebuilt, never stored), F PITCHFORK (round 4): a tip and a
+    # cherry under one node, folded into its parent's step like a cherry when the node's sibling is a tip or a stored cell
+    # (kinds tf, fc: one pitchfork per step, so its extra vectors live in registers the sibling's kind leaves idle and the
+    # loops need no register more).  A sixth of a random tree's internal nodes are pitchforks: a DS1 tree keeps 14 vectors
+    # instead of 17.5, a 64-taxon tree 33 instead of 41 -- which is what lets it run with two pattern groups per wave.
+    KINDS = [("cc", "C", "C"), ("tc", "T", "C"), ("hc", "H", "C"), ("th", "T", "H"), ("hh", "H", "H"), ("tf", "T", "F"),
+             ("fc", "F", "C")]
     POST_VARIANTS = [(n, a, b, False) for n, a, b in KINDS] + [(n + "f", a, b, True) for n, a, b in KINDS]
     PRE_VARIANTS = [(n, a, b, False) for n, a, b in KINDS] + [(n + "f", a, b, True) for n, a, b in KINDS if b == "C"]
 
@@ -974,6 +1028,61 @@ class Loops:
             self.flush_addresses(f"s{t[1]}", f"s{t[2]}")
             self.flush_stage1(self.EA, self.EB)
             pending = True
+        # a pitchfork child: the edges of its tip A and of its cherry H, then the cherry's partial and its two tip edges
+        # (same forms as a cherry's tail, two levels deep; every product lands in registers that are dead by then:
+        # Q m in MSG[s] and UC[0] -- neither slot's stored partial goes there in these kinds --, u . m in place)
+        F = self.fork(kinds)
+        if F:
+            s = F["s"]
+            q, DQA, DQH = F["X"], self.MSG[s], self.UC[0]
+            tm = self.TMPM
+            for g in range(G):
+                self.mfma(DQA[g], "Q", F["MA"][g])
+            self.salu(f"s_lshl_b32 s{t[1]}, {self.cur(F['tipa'])}, 3")  # gradient row of tip A's edge: 8 x tip id
+            for g in range(G):
+                self.mfma(DQH[g], "Q", F["MH"][g])
+            if pending:
+                nst += self.flush_stage3()
+                pending = False
+            for g in range(G):
+                self.vmul(F["MH"][g], q[g], F["MH"][g])  # u . m_H: tip A's edge
+                self.vmul(F["MA"][g], q[g], F["MA"][g])  # u . m_A: the cherry's edge, and what its partial is made of
+            for g in range(G):
+                if g == 0:
+                    self.vmul(self.EA, F["MH"][g], DQA[g])
+                    self.vmul(self.EB, F["MA"][g], DQH[g])
+                else:
+                    self.vfma(self.EA, F["MH"][g], DQA[g], self.EA)
+                    self.vfma(self.EB, F["MA"][g], DQH[g], self.EB)
+            self.flush_addresses(f"s{t[1]}", self.cur(F["edge_h"]))
+            self.flush_stage1(self.EA, self.EB)
+            self.salu(f"s_lshr_b32 s{tm[0]}, {self.cur(F['img'])}, 8")  # the cherry's image register
+            self.idx_on(f"s{tm[0]}", "SRC0")
+            for g in range(G):
+                self.mfma(q[g], ("A", 2 if self.exact else 0), F["MA"][g])  # the cherry's partial (over the pitchfork's)
+            self.idx_off()
+            for g in range(G):
+                self.mfma(DQA[g], "Q", F["MB"][g])
+            self.salu(f"s_and_b32 s{t[1]}, {self.cur(F['tipbc'])}, 0xff")  # rows of the cherry's tips B and C
+            self.salu(f"s_lshl_b32 s{t[1]}, s{t[1]}, 3")
+            self.salu(f"s_lshr_b32 s{t[2]}, {self.cur(F['tipbc'])}, 8")
+            self.salu(f"s_lshl_b32 s{t[2]}, s{t[2]}, 3")
+            for g in range(G):
+                self.mfma(DQH[g], "Q", F["MC"][g])
+            nst += self.flush_stage3()  # (A's and H's sums leave)
+            for g in range(G):
+                self.vmul(F["MC"][g], q[g], F["MC"][g])  # u_H . m_C: tip B's edge
+                self.vmul(F["MB"][g], q[g], F["MB"][g])  # u_H . m_B: tip C's
+            for g in range(G):
+                if g == 0:
+                    self.vmul(self.EA, F["MC"][g], DQA[g])
+                    self.vmul(self.EB, F["MB"][g], DQH[g])
+                else:
+                    self.vfma(self.EA, F["MC"][g], DQA[g], self.EA)
+                    self.vfma(self.EB, F["MB"][g], DQH[g], self.EB)
+            self.flush_addresses(f"s{t[1]}", f"s{t[2]}")
+            self.flush_stage1(self.EA, self.EB)
+            pending = True
         # edge sums of this step's two child edges (flushed by the next body)
         for s in (0, 1):
             for g in range(G):
@@ -997,10 +1106,11 @@ class Loops:
         G = self.G
         e = self.e
         e.comment(f"pre-order loop, G = {G}")
-        names = [v[0] for v in self.PRE_VARIANTS] + ["cc", "cc"]  # (body indices 8, 9 do not occur)
+        # (body index = kind, + the number of kinds with slot 1's partial handed over: only kinds with a stored cell there)
+        names = [n for n, _, _ in self.KINDS] + [n + "f" if b == "C" else "cc" for n, a, b in self.KINDS]
         if os.environ.get("PIPE_EMPTY_LOOPS"):
             self.branch(None, self.L("skip"))
-        self.loop_entry(names[:10])
+        self.loop_entry(names)
         self.e.ins(f"v_mov_b64 {vp(self.ONE)}, 1.0", "valu", writes=[self.ONE, self.ONE + 1])
         for s in (0, 1):
             self.e.ins(f"v_mov_b64 {vp(self.ES[s])}, 0", "valu", writes=[self.ES[s], self.ES[s] + 1])
@@ -1171,6 +1281,7 @@ def main():
     out.append(as_macro("WALK_PIPE_LOAD_EXACT_ASM", loops.load_images(True).finish()))
     loops = Loops(1)
     out.append(as_macro("WALK_PIPE_LOAD_REV_ASM", loops.load_images(False).finish()))
+    out.append(f"#define WALK_PIPE_KINDS {len(Loops.KINDS)}  /* body index = kind (cc tc hc th hh tf fc), + this with a vector handed over; exit = twice this */")
     out.append(f"#define WALK_PIPE_MAX_TIPS {Loops.MAX_TIPS}")
     out.append(f"#define WALK_PIPE_MAX_INNER {Loops.MAX_INNER}")
     out.append(f"#define WALK_PIPE_EXACT_TAXA {Loops.EXACT_TAXA}")

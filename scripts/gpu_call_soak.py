@@ -19,8 +19,10 @@ spec = bito_amd.PhyloModelSpecification(full.substitution, full.site, full.clock
 os.environ["BITO_AMD_CHUNK_FIRST"] = "1000000"
 plain = bito_amd.Engine(spec, full.patterns, full.weights)  # one chunk whatever the size
 del os.environ["BITO_AMD_CHUNK_FIRST"]
+# (the multi-slot engines run every slot on its own issuing thread: round 4)
 engines = {"one slot": bito_amd.Engine(spec, full.patterns, full.weights),
-           "two slots": bito_amd.Engine(spec, full.patterns, full.weights, devices=[0, 0])}
+           "two slots": bito_amd.Engine(spec, full.patterns, full.weights, devices=[0, 0]),
+           "five slots": bito_amd.Engine(spec, full.patterns, full.weights, devices=[0] * 5)}
 cpu = oracle.OracleEngine(full.substitution, full.site, full.clock, full.patterns, full.weights, 8)
 bad = 0
 t0 = time.time()

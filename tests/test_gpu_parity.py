@@ -844,9 +844,9 @@ def test_pipe_walk_on_extreme_tree_shapes(n, site):
 
 
 def test_auto_kernel_choice_at_the_pipe_walk_limits():
-    """AUTO: walk_pipe_kernel up to 58 taxa (from 49: the wide register layout; trees that keep too many vectors
-    for two pattern groups per wave run with one and half-size cells; the kernel itself takes up to 64 taxa, but
-    from 59 on the HBM-arena walk is the faster one) -- from 39 taxa on (one matrix image per branch, the reversible
+    """AUTO: walk_pipe_kernel up to 64 taxa, the size it is built for (from 49: the wide register layout; trees that keep
+    too many vectors for two pattern groups per wave run with one and half-size cells -- few of them since round 4 folds
+    pitchforks into their parents' steps) -- from 39 taxa on (one matrix image per branch, the reversible
     form of the pre-order recursion) only when no branch is shorter than 1e-6; everything else, and rescaling at any
     size, goes to the HBM-arena walk (walk_hbm_cat_kernel); each against the oracle."""
     rng = np.random.default_rng(29)
@@ -855,8 +855,10 @@ def test_auto_kernel_choice_at_the_pipe_walk_limits():
                                            (58, False, 1e-3, "walk_pipe_kernel"), (29, True, 0.0, "walk_hbm_cat_kernel"),
                                            # (round 3's sizes behind the earlier cases, whose random draws stay as they were)
                                            (49, False, 1e-3, "walk_pipe_kernel"), (52, False, 1e-3, "walk_pipe_kernel"),
-                                           (56, False, 1e-3, "walk_pipe_kernel"), (64, False, 1e-3, "walk_hbm_cat_kernel"),
-                                           (52, False, 1e-8, "walk_hbm_cat_kernel"), (66, False, 1e-3, "walk_hbm_cat_kernel")):
+                                           (56, False, 1e-3, "walk_pipe_kernel"), (64, False, 1e-3, "walk_pipe_kernel"),
+                                           (52, False, 1e-8, "walk_hbm_cat_kernel"), (66, False, 1e-3, "walk_hbm_cat_kernel"),
+                                           (60, False, 1e-3, "walk_pipe_kernel"), (64, False, 1e-8, "walk_hbm_cat_kernel"),
+                                           (65, False, 1e-3, "walk_hbm_cat_kernel")):
         patterns = rng.integers(0, 4, (n, 70)).astype(np.int32)
         weights = np.ones(70)
         pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(4)])

@@ -315,3 +315,64 @@ def test_host_pool_runs_every_part_once_and_is_race_free(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "0 bad" in run.stdout, run.stdout + run.stderr
     assert "ThreadSanitizer" not in run.stderr, run.stderr
+
+
+def test_unstored_node_count_matches_a_restatement():
+    """walk_pipe_kernel keeps no LDS vector for cherries and for the pitchforks it folds into their parents' steps (a tip
+    and a cherry under one node whose sibling is a tip or a stored node; of two sibling pitchforks the lower id).  The host
+    sizes a tree's LDS slots by this count, so it is held to an independent restatement here, rooted and unrooted
+    (the unrooted tree as it is walked: UnrootedTree::Detrifurcate, reference src/unrooted_tree.cpp:27-37)."""
+    import ctypes as C
+
+    from test_gpu_parity import _random_rooted_parent_ids
+
+    def restated(par, n, rooted, fold):
+        M = len(par) + 1
+        kids = {}
+        for child, p in enumerate(par):
+            kids.setdefault(int(p), []).append(child)
+        if not rooted:
+            r = M - 1
+            a, b, c = kids[r]
+            kids[r] = [b, c]
+            kids[r + 1] = [a, r]
+        root = 2 * n - 2
+        up = {c: p for p, cs in kids.items() for c in cs}
+        cherry = lambda v: v >= n and v != root and all(x < n for x in kids[v])  # noqa: E731
+        fork = lambda v: v >= n and v != root and sorted((x < n, cherry(x)) for x in kids[v]) == [(False, True), (True, False)]  # noqa: E731
+        count = 0
+        for v in range(n, root):
+            if cherry(v):
+                count += 1
+            elif fold and fork(v):
+                sib = [x for x in kids[up[v]] if x != v][0]
+                if sib < n or (not cherry(sib) and (not fork(sib) or v < sib)):
+                    count += 1
+        return count
+
+    rng = np.random.default_rng(17)
+    L = _capi.lib()
+    for n in (3, 4, 5, 9, 27, 64):
+        for rooted in (0, 1):
+            T = 40
+            if rooted:
+                pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(T)]).astype(np.int32)
+            else:
+                pid = np.stack([workloads.random_unrooted_tree(n, rng, 0.1).parent_ids for _ in range(T)]).astype(np.int32)
+            pid = np.ascontiguousarray(pid)
+            for fold in (0, 1):
+                out = np.zeros(T, dtype=np.int32)
+                rc = L.bito_amd_count_unstored_nodes(n, T, rooted, pid.shape[1] + 1, pid.ctypes.data_as(C.POINTER(C.c_int32)), fold,
+                                                     out.ctypes.data_as(C.POINTER(C.c_int32)))
+                assert rc == 0
+                assert list(out) == [restated(row, n, rooted, fold) for row in pid], (n, rooted, fold)
+    # the DS1 topologies: 17.5 stored vectors per tree without folding, 14.2 with
+    w = workloads.ds1_gtr_weibull4(1)
+    pid = np.ascontiguousarray(w.parent_ids, dtype=np.int32)
+    counts = []
+    for fold in (0, 1):
+        out = np.zeros(100, dtype=np.int32)
+        assert L.bito_amd_count_unstored_nodes(27, 100, 0, 52, pid.ctypes.data_as(C.POINTER(C.c_int32)), fold,
+                                               out.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        counts.append(26 - out.mean())  # internal nodes - unstored = stored vectors + the root
+    assert 17.0 < counts[0] < 18.5 and 13.5 < counts[1] < 15.0, counts
