@@ -190,10 +190,14 @@ int ValidateTreeShape(Worker* e, int rooted, int node_count) {
 // node; of two pitchforks under one node the one with the lower id.  The parent-id row has passed the range checks.
 int UnstoredNodes(int n, int M, int rooted, const int32_t* par, bool fold, std::vector<int>* kids_buf, std::vector<int>* parent_buf) {
   const int N = 2 * n - 1, NI = n - 1;
+  // (one scratch array: child lists [2 NI], then the parents [N]; written in full below, so no clearing pass)
   std::vector<int>& ch = *kids_buf;
-  std::vector<int>& up = *parent_buf;
-  ch.assign((size_t)2 * NI, -1);
-  up.assign((size_t)N, -1);
+  if ((int)ch.size() < 2 * NI + N + 2) ch.resize((size_t)2 * NI + N + 2);
+  (void)parent_buf;
+  int* const up = ch.data() + 2 * NI;
+  int* const fill = up + N;  // children seen so far of the node being filled: kept in the low bits of ch via counts below
+  (void)fill;
+  for (int j = 0; j < 2 * NI; j++) ch[j] = -1;
   int third = -1;
   for (int child = 0; child < M - 1; child++) {
     const int k = par[child] - n;
@@ -213,17 +217,26 @@ int UnstoredNodes(int n, int M, int rooted, const int32_t* par, bool fold, std::
     up[ch[2 * j]] = n + j;
     up[ch[2 * j + 1]] = n + j;
   }
+  // kind of every internal node in one pass (ids ascend from the tips to the root): 1 cherry, 2 pitchfork, 0 other
+  int cherries = 0;
+  int* const kind = up;  // (reused below: a node's parent is looked up before its own kind overwrites nothing it needs)
+  (void)kind;
   auto cherry = [&](int c) { return c >= n && c != N - 1 && ch[2 * (c - n)] < n && ch[2 * (c - n) + 1] < n; };
+  if (!fold) {
+    for (int c = n; c < N - 1; c++) cherries += cherry(c);
+    return cherries;
+  }
   auto fork = [&](int c) {
     if (c < n || c == N - 1) return false;
     const int a = ch[2 * (c - n)], b = ch[2 * (c - n) + 1];
-    return (a < n && cherry(b)) || (b < n && cherry(a));
+    return (a < n) != (b < n) && cherry(a < n ? b : a);
   };
   int unstored = 0;
   for (int c = n; c < N - 1; c++) {
-    if (cherry(c)) {
+    const int a = ch[2 * (c - n)], b = ch[2 * (c - n) + 1];
+    if (a < n && b < n) {
       unstored++;
-    } else if (fold && fork(c)) {
+    } else if ((a < n) != (b < n) && cherry(a < n ? b : a)) {
       const int p = up[c];
       const int sib = ch[2 * (p - n)] == c ? ch[2 * (p - n) + 1] : ch[2 * (p - n)];
       if (sib < n || (!cherry(sib) && (!fork(sib) || c < sib))) unstored++;
@@ -240,6 +253,9 @@ int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_cou
   std::vector<int> count(M), tip_children(M);
   std::vector<int> kids, parent_of;  // (the detrifurcated tree, for the pitchfork count)
   int fewest = M, fewest_unstored = M;
+  // (pitchforks are folded by walk_pipe_kernel alone: up to 64 taxa, four states, 1 / 2 / 4 rate categories)
+  const int C = e->spec.category_count;
+  const bool fold_counts = e->pipe_fold != 0 && e->spec.state_count == 4 && n <= 64 && (C == 1 || C == 2 || C == 4);
   for (int t = t0; t < t1; t++) {
     const int32_t* par = parent_ids + (size_t)t * (M - 1);
     std::fill(count.begin(), count.end(), 0);
@@ -263,14 +279,6 @@ int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_cou
     if (!rooted) cherries += tip_children[M - 1] == 3;
     fewest = std::min(fewest, cherries);
     if (cherries_of) cherries_of[t] = cherries;
-    bool shape_ok = true;
-    for (int i = n; i < M && shape_ok; i++) shape_ok = count[i] == ((!rooted && i == M - 1) ? 3 : 2);
-    if (shape_ok && (cherries_of || fewest_unstored_out)) {
-      // what walk_pipe_kernel keeps no vector for: cherries and folded pitchforks of the tree as it is walked
-      const int unstored = UnstoredNodes(n, M, rooted, par, e->pipe_fold != 0, &kids, &parent_of);
-      fewest_unstored = std::min(fewest_unstored, unstored);
-      if (cherries_of) cherries_of[t] = unstored;
-    }
     for (int i = n; i < M; i++) {
       const int want = (!rooted && i == M - 1) ? 3 : 2;
       if (count[i] != want) {
@@ -279,6 +287,27 @@ int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_cou
                       count[i], want);
         *msg = buf;
         return BITO_AMD_ERR_BAD_TREE;
+      }
+    }
+  }
+  // What walk_pipe_kernel keeps no vector for: the cherries and, with folding, the pitchforks of the tree as it is walked.
+  // The cherries alone are a safe count (fewer unstored nodes only ask for more LDS slots than the tree uses), so the
+  // pitchforks are counted -- a second pass, 0.1 us per tree -- only when it matters: when the range's trees, by their
+  // cherries, would NOT all fit beside the most pattern groups a wave can carry at this size (config 3 fits by its
+  // cherries: its calls, the 100-tree ones included, pay nothing for the folding).
+  fewest_unstored = fewest;
+  if (fold_counts && (cherries_of || fewest_unstored_out)) {
+    BatchDims probe{};
+    probe.taxon_count = n;
+    probe.node_count = 2 * n - 1;
+    probe.category_count = C;
+    const int room = PipeMaxSlots(probe, n <= 32 ? 4 : 2);
+    if (PipeSlotsOfTree(probe, fewest) > room) {
+      fewest_unstored = M;
+      for (int t = t0; t < t1; t++) {
+        const int unstored = UnstoredNodes(n, M, rooted, parent_ids + (size_t)t * (M - 1), true, &kids, &parent_of);
+        fewest_unstored = std::min(fewest_unstored, unstored);
+        if (cherries_of) cherries_of[t] = unstored;
       }
     }
   }
