@@ -342,12 +342,13 @@ class Loops:
     #     workgroup is eight waves, so a tile's mask rows keep a stride of 32 dwords (a wave copies its rows as whole
     #     dwords per lane) of which a lane loads the first 28.  Why: a lone wave's vector, LDS and scalar instructions
     #     never overlap its own matrix instructions; a sibling wave's do (profiles/r2_issue_costs.txt, p_mix_mix).
-    TWO_MAX_TIPS = 28
-    TWO_TIP_SLOTS = 32
+    # (PIPE_TWO_TIPS / PIPE_TWO_VBASE: measurement builds -- fewer taxa leave the compiler more of the 256 registers)
+    TWO_MAX_TIPS = int(os.environ.get("PIPE_TWO_TIPS", 28))
+    TWO_TIP_SLOTS = 32 if TWO_MAX_TIPS > 16 else 16
     TWO_REV_BASE = 2 * TWO_MAX_TIPS
     TWO_MAX_INNER = TWO_MAX_TIPS - 2
     TWO_IMAGE_REGS = TWO_REV_BASE + 2 * TWO_MAX_INNER
-    TWO_VBASE = 16
+    TWO_VBASE = int(os.environ.get("PIPE_TWO_VBASE", 16))
     TWO_VLIMIT = 256 - TWO_IMAGE_REGS
     TWO_WAVES = 8
 
