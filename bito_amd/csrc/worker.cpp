@@ -301,7 +301,7 @@ int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_cou
     probe.taxon_count = n;
     probe.node_count = 2 * n - 1;
     probe.category_count = C;
-    const int room = PipeMaxSlots(probe, n <= 32 ? 4 : 2);
+    const int room = PipeMaxSlots(probe, n <= kPipeExactTaxa ? 4 : 2);  // (four groups per wave up to 38 taxa, two beyond)
     if (PipeSlotsOfTree(probe, fewest) > room) {
       fewest_unstored = M;
       for (int t = t0; t < t1; t++) {

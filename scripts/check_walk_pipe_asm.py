@@ -57,7 +57,7 @@ def main(path):
         if not layout:
             print(f"cannot read the layout of {kernel}", file=sys.stderr)
             return 1
-        limit = {0: LIMIT, 1: WIDE_LIMIT, 2: TWO_LIMIT}[int(layout.group(1))]
+        limit = {0: LIMIT, 1: WIDE_LIMIT, 2: TWO_LIMIT, 3: LIMIT}[int(layout.group(1))]
         for mm in re.finditer(r"\ba\[?(\d+)", text.split(";")[0]):
             if int(mm.group(1)) < limit:
                 stray += 1

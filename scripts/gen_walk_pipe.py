@@ -352,8 +352,17 @@ class Loops:
     TWO_VLIMIT = 256 - TWO_IMAGE_REGS
     TWO_WAVES = 8
 
-    def __init__(self, G, exact=True, wide=False, two=False):
+    #   * 33 to 38 taxa with FOUR pattern groups per wave (round 4, "many"): the exact layout with 40 mask registers beside
+    #     the four groups' own -- v32..v253 -- in mask rows of 48 dwords (a wave copies its rows as whole dwords per lane).
+    #     Up to 32 taxa keep the 32-register loops (every mask register is an instruction in a loop's prologue).
+    MANY_TIP_REGS = 40
+    MANY_TIP_SLOTS = 48
+    MANY_MAX_TIPS = 38
+
+    def __init__(self, G, exact=True, wide=False, two=False, many=False):
         self.G = G
+        self.many = many
+        assert not many or (G == 4 and exact and not wide and not two)
         self.exact = exact  # image layout the pre-order loop is generated for (the only place the loops differ)
         self.wide = wide
         self.two = two
@@ -374,8 +383,8 @@ class Loops:
         # persistent
         # packed masks of tip t (byte g = mask of this lane's pattern in group g): 32 slots beside four groups'
         # registers, 48 beside fewer
-        self.TIP_SLOTS = self.WIDE_TIP_SLOTS if wide else (self.TWO_TIP_SLOTS if two else (32 if G == 4 else 48))
-        self.TIP_REGS = self.TWO_MAX_TIPS if two else self.TIP_SLOTS  # (the mask registers a lane holds; TIP_SLOTS: its row in LDS)
+        self.TIP_SLOTS = self.WIDE_TIP_SLOTS if wide else (self.TWO_TIP_SLOTS if two else (self.MANY_TIP_SLOTS if many else (32 if G == 4 else 48)))
+        self.TIP_REGS = self.TWO_MAX_TIPS if two else (self.MANY_TIP_REGS if many else self.TIP_SLOTS)  # (the mask registers a lane holds; TIP_SLOTS: its row in LDS)
         self.TMV = V.get(self.TIP_REGS, "TMV", 4)
         self.U = g2("U")                      # pre-order partial of the step's node
         self.ONE = V.get(2, "ONE", 2)
@@ -1262,6 +1271,16 @@ def main():
     out.append(f"#define WALK_PIPE_W_MAX_INNER {Loops.WIDE_MAX_INNER}")
     out.append(f"#define WALK_PIPE_W_REV_BASE {Loops.WIDE_REV_BASE}")
     out.append(f"#define WALK_PIPE_W_IMAGE_REGS {Loops.WIDE_IMAGE_REGS}")
+    # four pattern groups per wave with 40 mask registers: 33 to 38 taxa
+    loops = Loops(4, many=True)
+    post = loops.post_loop()
+    pre = Loops(4, many=True).pre_loop()
+    out.append(as_macro("WALK_PIPE_POST_M_ASM_G4", post.finish()))
+    out.append(as_macro("WALK_PIPE_PRE_M_ASM_G4", pre.finish()))
+    out.append(f"#define WALK_PIPE_CLOBBERS_M_G4 {clobbers(loops)}")
+    out.append(f"#define WALK_PIPE_M_TIP_SLOTS {Loops.MANY_TIP_SLOTS}")
+    out.append(f"#define WALK_PIPE_M_MAX_TIPS {Loops.MANY_MAX_TIPS}")
+    listing.append(f"G=4, 40 mask registers: VGPR v{loops.vbase}..v{loops.vnext - 1}; post {len(post.lines)} lines {post.count}, pre {len(pre.lines)} lines {pre.count}")
     for G in (1, 2):  # two waves per SIMD: up to 28 taxa inside 256 registers per wave
         loops = Loops(G, exact=False, two=True)
         post = loops.post_loop()

@@ -265,8 +265,11 @@ def test_pipe_walk_planner():
     # tip masks: 32 registers beside four groups, 48 beside two (one image per branch: the AGPR file would hold 57
     # taxa); beyond that, or when the stored vectors of the tree with the fewest cherries do not fit LDS: not taken
     assert _pipe_plan(32, 934, 4, 1600, 14)["groups"] == 4
-    assert _pipe_plan(33, 934, 4, 1600, 14)["groups"] == 2
+    # 33 to 38 taxa: four groups beside 40 mask registers (round 4) when the stored vectors leave room, else two
+    assert _pipe_plan(33, 934, 4, 1600, 14)["groups"] == 4
+    assert _pipe_plan(38, 934, 4, 1600, 18)["groups"] == 4
     assert _pipe_plan(38, 934, 4, 1600, 10)["groups"] == 2
+    assert _pipe_plan(39, 934, 4, 1600, 19)["groups"] == 2
     assert _pipe_plan(41, 934, 4, 1600, 9)["groups"] == 2
     assert _pipe_plan(48, 934, 4, 1600, 14)["groups"] == 2
     # 38 vectors per wave: 160 KB do not hold them beside two groups (1 KB cells); one group per wave keeps 512-byte
