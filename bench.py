@@ -37,6 +37,7 @@ import numpy as np  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 68.0  # measured, scripts: bito_amd/csrc/microbench.hip
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PATTERN_CEILING_GBS = 5000.0  # measured: random 2 KB pieces, reads and writes in equal parts (hbm_pattern_bench.hip)
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (MI355X_MICROARCH.md)
 
 
@@ -220,7 +221,12 @@ def roofline_object(kernel, n, P, C, S, want_gradient, trees_per_launch, avg_ker
     elif hbm_measured is not None:
         out = {"bound": "hbm", "achieved": hbm_measured["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": hbm_measured["frac"], "numerator": "HBM bytes measured by rocprofv3 (FETCH_SIZE x 2 + WRITE_SIZE)",
-               "executed": executed}
+               "executed": executed,
+               # what this memory takes from independent waves that read and write 2 KB pieces at random places in equal
+               # parts (the arena walk's pattern): bito_amd/csrc/hbm_pattern_bench.hip, profiles/r4_hbm/hbm_pattern_bench.txt
+               "pattern_ceiling": {"GBps": HBM_PATTERN_CEILING_GBS, "frac": hbm_measured["achieved"] / HBM_PATTERN_CEILING_GBS,
+                                   "source": "profiles/r4_hbm/hbm_pattern_bench.txt (1 read + 1 write, 2 KB pieces: 4.96-5.07 TB/s "
+                                             "whatever the piece size; reads alone 6.9, a sequential copy 6.3)"}}
     else:  # no committed counter pass for this kernel: the op-by-op model alone, held to the contract's frac <= 1
         out = {"bound": "hbm", "achieved": alg_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": alg_gbps / HBM_PEAK_GBS if alg_gbps <= HBM_PEAK_GBS else None,

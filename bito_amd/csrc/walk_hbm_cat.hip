@@ -57,14 +57,32 @@ inline int HbmCatTiles(int pattern_count) { return (pattern_count + kCatTile - 1
 
 // Tried on top of this kernel and dropped: a node's child pair requested one node ahead (the scalar load off the
 // step's dependent chain: config 2 0.585 against 0.51-0.53 ms per 6400 trees, config 4 72.5 against 70.1 ms -- the
-// request in flight turns the step's first wait for LDS into a wait for everything); and PITCHFORKS (a cherry and a tip under one node -- a sixth of the internal
-// nodes of a random tree) rebuilt and folded into the parent's step like cherries.  The nested step needs 75
-// registers: held to 64 it spills (config 4, 125 trees, same box: 84.8 ms against 69.9), at six waves per SIMD it
-// gains 2.5-4 % (66.7 / 69.4 ms against 69.9 / 71.2; 41 taxa: 3.54 against 3.78 ms) -- the arena traffic it saves is
-// paid for in vector and scalar work at lower occupancy.  Likewise BOTH columns as pending vectors in the pre-order
-// pass too, the next step's partial handed over in registers (1478 -> 1392 vector transfers per config-4 tree): those
-// eight registers are alive at the loop's edge and the step spills three or four at 64 (config 4 69.1 against
-// 63.1 ms, 100 taxa 9.5 against 8.0 ms).
+// request in flight turns the step's first wait for LDS into a wait for everything).  BOTH columns as pending vectors in
+// the pre-order pass too, the next step's partial handed over in registers (6 % fewer vector transfers): round 3, at 64
+// registers, it spilled (69.1 against 63.1 ms); round 4, on the folded walk at seven and six waves per SIMD (72 / 78
+// registers), 49.4 / 47.5 ms against 46.6 -- the walk is no longer bound by the arena alone (below).
+// Round 4, what bounds this walk (config 4, 125 trees per launch; profiles/r4_hbm/):
+//   * hbm_pattern_bench.hip: independent waves that read and write 2 KB pieces at random places, in equal parts, move
+//     5.0 TB/s on this part -- whatever the piece size (2 to 32 KB), the width of the accesses, the window a workgroup
+//     stays in or the cache policy; reads alone 6.9, writes alone 5.5, a sequential copy 6.3.  Round 3's kernel moved its
+//     256.9 GB at 4.7: at that ceiling.  Its arithmetic alone (HBM_EXP_NOLOAD / NOSTORE builds) takes 33 of the 55 ms, the
+//     time does not change between four and eight waves per SIMD, and a build with a third fewer vector instructions
+//     (seven waves: no spilled scalars) gains 3 %.
+//   * So: fewer vectors.  PITCHFORKS (a tip and a cherry under one node -- a sixth of a random tree's internal nodes)
+//     are rebuilt from their three tips' matrix rows where they are used, like cherries: no step, no cell.  Round 3 had
+//     measured this at 2.5-4 % (the kernel was not at the memory's ceiling then, and the nested step spilled at 64
+//     registers); at seven waves per SIMD (72 registers, 24 lane moves of scalars instead of 384): 1478 -> 1104 vector
+//     transfers per tree (scripts/sim_hbm_traffic.py), 256.9 -> 193.5 GB per launch (PMC), 54.9 -> 46.6 ms, 64 taxa
+//     4.57 -> 3.74 ms per 1600 trees, 100 taxa 7.23 -> 5.92.  The arithmetic alone is 30 ms now (fewer steps).
+//   * Not the way: the same walk with a pattern's four states in four LANES and every 4 x 4 product on
+//     v_mfma_f64_4x4x4_4b (parity-green at the first run; 72.5 ms against 54.9, 64 taxa 5.76 against 4.57).  On this part
+//     the FP64 matrix pipe has the vector ALU's rate and does not run beside it (issue_bench p_mfma_mul64: a sibling
+//     wave's v_mul_f64 gets one issue slot per matrix instruction), sums over states cost a whole product with a matrix
+//     of ones, per-pattern scalars are four registers instead of one.  Four generic columns with owners and ages in
+//     scalar registers instead of two hand-written ones: 74.1 ms (788 lane moves of spilled scalars).  Q fetched where
+//     it is used instead of kept in 32 scalar registers for the loop (no spills left): 98.1 ms -- the step then waits
+//     for two more scalar loads.  Half of the first round's workgroups started late (were the post-order phases of all
+//     resident waves colliding?): no change.
 // ---- visiting order -------------------------------------------------------------------------------------------
 // The walk keeps the vector it has just computed in registers and ONE or TWO older ones in LDS columns (below); every
 // other operand is read back from the arena.  How often that happens depends on the ORDER in which a node's two subtrees
@@ -74,37 +92,64 @@ inline int HbmCatTiles(int pattern_count) { return (pattern_count + kCatTile - 1
 // moves 1672 vectors per tree and pass, in this order 1478 (scripts/sim_hbm_traffic.py; the least possible, one store
 // and one load of every stored vector, is 1329).  Cherries are no steps of their own (rebuilt where they are used) and
 // do not appear in the order.
-// order[tree] = NI + 1 records of eight int32: record 0 = {steps}, record 1 + k = step k = {node, child 0, child 1, node
-// of step k - 1 (the step that follows in the pre-order pass), children of child 0, children of child 1 (-1, -1 under a
-// tip)} -- everything a step must know about the topology in ONE scalar load whose address does not depend on an
-// earlier load (the child lists are not read by the walk at all).  One workgroup per tree, the tree's tables in LDS
+// order[tree] = NI + 1 records of twelve int32: record 0 = {steps}, record 1 + k = step k = {node, child 0, child 1, node
+// of step k - 1 (the step that follows in the pre-order pass) | children of child 0, children of child 1 (-1, -1 under a
+// tip; a pitchfork: its tip, then its cherry) | the tips of a pitchfork child's cherry (else -1, -1)} -- everything a
+// step must know about the topology in scalar loads whose address does not depend on an earlier load (the child lists are
+// not read by the walk at all).  One workgroup per tree, the tree's tables in LDS
 // (25 bytes per internal node), one lane labels them, all write the records; trees too large for that are walked in
 // id order.
-constexpr int kStepInts = 8;
-__device__ __forceinline__ void WriteStep(int32_t* __restrict__ out, int k, int n, int node, int next, int c0, int c1,
+constexpr int kStepInts = 12;
+// Unstored nodes: cherries, and with `fold` PITCHFORKS -- a tip and a cherry under one node (a sixth of a random tree's
+// internal nodes) --, rebuilt from their tips' matrix rows where they are used, like cherries: no step, no cell traffic.
+__device__ __forceinline__ bool IsCherry(const int32_t* __restrict__ c, int n, int root, int v) {
+  return v >= n && v != root && c[2 * (v - n)] < n && c[2 * (v - n) + 1] < n;
+}
+__device__ __forceinline__ bool IsFork(const int32_t* __restrict__ c, int n, int root, int v) {
+  if (v < n || v == root) return false;
+  const int a = c[2 * (v - n)], b = c[2 * (v - n) + 1];
+  return (a < n && IsCherry(c, n, root, b)) || (b < n && IsCherry(c, n, root, a));
+}
+// what a step knows about child cc: {its children (a pitchfork: its tip, then its cherry), the cherry's tips of a pitchfork}
+__device__ __forceinline__ void ChildInfo(const int32_t* __restrict__ c, int n, int root, int fold, int cc, int& a, int& b, int& hb, int& hc) {
+  a = b = hb = hc = -1;
+  if (cc < n) return;
+  a = c[2 * (cc - n)];
+  b = c[2 * (cc - n) + 1];
+  if (fold && IsFork(c, n, root, cc)) {
+    if (a >= n) {
+      const int t = a;
+      a = b;
+      b = t;
+    }
+    hb = c[2 * (b - n)];
+    hc = c[2 * (b - n) + 1];
+  }
+}
+__device__ __forceinline__ void WriteStep(int32_t* __restrict__ out, int k, int n, int root, int fold, int node, int next, int c0, int c1,
                                           const int32_t* __restrict__ c) {
-  int4 lo, hi;
+  int4 lo, mid, hi;
   lo.x = node; lo.y = c0; lo.z = c1; lo.w = next;
-  hi.x = c0 >= n ? c[2 * (c0 - n)] : -1; hi.y = c0 >= n ? c[2 * (c0 - n) + 1] : -1;
-  hi.z = c1 >= n ? c[2 * (c1 - n)] : -1; hi.w = c1 >= n ? c[2 * (c1 - n) + 1] : -1;
+  ChildInfo(c, n, root, fold, c0, mid.x, mid.y, hi.x, hi.y);
+  ChildInfo(c, n, root, fold, c1, mid.z, mid.w, hi.z, hi.w);
   int4* rec = reinterpret_cast<int4*>(out + (size_t)(1 + k) * kStepInts);
   rec[0] = lo;
-  rec[1] = hi;
+  rec[1] = mid;
+  rec[2] = hi;
 }
 
 __global__ void __launch_bounds__(64)
-hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __restrict__ order, int in_lds) {
+hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __restrict__ order, int in_lds, int fold) {
   extern __shared__ int32_t order_lds[];
-  const int n = d.taxon_count, NI = n - 1, lane = threadIdx.x;
+  const int n = d.taxon_count, NI = n - 1, lane = threadIdx.x, root = n + NI - 1;
   const int32_t* __restrict__ ch = children + (size_t)blockIdx.x * NI * 2;
   int32_t* __restrict__ out = order + (size_t)blockIdx.x * (NI + 1) * kStepInts;
   if (!in_lds) {
     if (lane == 0) {
       int k = 0, prev = -1;
       for (int v = 0; v < NI; v++) {
-        const int c0 = ch[2 * v], c1 = ch[2 * v + 1];
-        if (c0 < n && c1 < n && v != NI - 1) continue;
-        WriteStep(out, k++, n, n + v, prev, c0, c1, ch);
+        if (IsCherry(ch, n, root, n + v) || (fold && IsFork(ch, n, root, n + v))) continue;
+        WriteStep(out, k++, n, root, fold, n + v, prev, ch[2 * v], ch[2 * v + 1], ch);
         prev = n + v;
       }
       out[0] = k;
@@ -112,7 +157,7 @@ hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __r
     return;
   }
   int32_t* c = order_lds;        // [NI][2] children
-  int32_t* size = c + 2 * NI;    // steps in the subtree (0: a cherry)
+  int32_t* size = c + 2 * NI;    // steps in the subtree (0: an unstored node)
   int32_t* need = size + NI;     // pending vectors the subtree's walk needs at once
   int32_t* start = need + NI;    // position of the subtree's first step
   int32_t* at = start + NI;      // node of step k
@@ -125,7 +170,7 @@ hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __r
       const int s0 = c0 >= n ? size[c0 - n] : 0, s1 = c1 >= n ? size[c1 - n] : 0;
       const int a = s0 ? need[c0 - n] : 0, b = s1 ? need[c1 - n] : 0;
       flip[v] = b > a;  // the heavier subtree first (ties: id order)
-      if (c0 < n && c1 < n && v != NI - 1) {
+      if (IsCherry(c, n, root, n + v) || (fold && IsFork(c, n, root, n + v))) {
         size[v] = 0;
         need[v] = 0;
       } else {
@@ -151,23 +196,29 @@ hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __r
   const int steps = size[NI - 1];
   for (int k = lane; k < steps; k += 64) {
     const int node = at[k];
-    WriteStep(out, k, n, node, k > 0 ? at[k - 1] : -1, c[2 * (node - n)], c[2 * (node - n) + 1], c);
+    WriteStep(out, k, n, root, fold, node, k > 0 ? at[k - 1] : -1, c[2 * (node - n)], c[2 * (node - n) + 1], c);
   }
 }
 
 inline size_t HbmOrderLdsBytes(const BatchDims& d) { return (size_t)(d.taxon_count - 1) * (6 * sizeof(int32_t) + 1) + 16; }
 size_t HbmOrderInts(const BatchDims& d) { return (size_t)d.tree_count * d.taxon_count * kStepInts; }
 
+// BITO_AMD_HBM_FOLD=0: a step and a cell for every pitchfork
+static int HbmFolds() {
+  static const int v = [] { const char* e = getenv("BITO_AMD_HBM_FOLD"); return e ? atoi(e) != 0 : 1; }();
+  return v;
+}
+
 void LaunchHbmOrder(const BatchDims& d, const DeviceBatch& b, hipStream_t stream) {
   const size_t lds = HbmOrderLdsBytes(d);
   const bool in_lds = lds <= 150 * 1024;
   if (in_lds && lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hbm_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(hbm_order_kernel, dim3(d.tree_count), dim3(64), in_lds ? lds : 0, stream, d, b.children, b.sched, in_lds ? 1 : 0);
+  hipLaunchKernelGGL(hbm_order_kernel, dim3(d.tree_count), dim3(64), in_lds ? lds : 0, stream, d, b.children, b.sched, in_lds ? 1 : 0, HbmFolds());
 }
 
 #ifndef HBM_CAT_WAVES
-#define HBM_CAT_WAVES 8
+#define HBM_CAT_WAVES 7
 #endif
 
 // Buffer accesses: a wave-uniform 128-bit descriptor (base in scalar registers), a wave-uniform byte offset, and
@@ -221,6 +272,10 @@ __device__ __forceinline__ void BufLoadRow(BufferRsrc r, unsigned lane_bytes, un
 #define HBM_CAT_ROWS 1
 #endif
 __device__ __forceinline__ void ArenaLoad(BufferRsrc r, unsigned lane, unsigned node_offset, double x[4]) {
+#if HBM_EXP_NOLOAD  // (timing only: what the walk costs without its arena reads)
+  for (int i = 0; i < 4; i++) x[i] = 0.25 + 0.125 * i;
+  return;
+#endif
 #if HBM_CAT_ROWS
 #pragma unroll
   for (int i = 0; i < 4; i++) x[i] = BufLoad(r, lane * 8, node_offset + i * 512);
@@ -234,6 +289,9 @@ __device__ __forceinline__ void ArenaLoad(BufferRsrc r, unsigned lane, unsigned 
 #endif
 }
 __device__ __forceinline__ void ArenaStore(BufferRsrc r, unsigned lane, unsigned node_offset, const double x[4]) {
+#if HBM_EXP_NOSTORE  // (timing only)
+  return;
+#endif
 #if HBM_CAT_ROWS
 #pragma unroll
   for (int i = 0; i < 4; i++) BufStore(r, lane * 8, node_offset + i * 512, x[i]);
@@ -299,15 +357,21 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   const unsigned node_bytes = (unsigned)C * 4 * kCatTile * 8, mat_bytes = (unsigned)C * kMatHot * 8;
   const unsigned ulane = lane;
   struct Child {
-    int kind;  // 0 tip, 1 stored internal node, 2 cherry
-    int a, b;
-    int s, sb;
+    int kind;  // 0 tip, 1 stored internal node, 2 cherry, 3 pitchfork
+    int a, b;  // its children (a pitchfork: its tip, then its cherry)
+    int hb, hc;  // a pitchfork's cherry's tips
+    int s, sb, sc;  // states: the tip's own | a cherry's two tips' | a pitchfork's tip's and its cherry's two
   };
-  // (a, b: the child's own children out of the step's record)
-  auto classify = [&](int cc, int a, int b) {
-    Child ci{0, a, b, 0, 0};
+  // (a, b, hb, hc: out of the step's record)
+  auto classify = [&](int cc, int a, int b, int hb, int hc) {
+    Child ci{0, a, b, hb, hc, 0, 0, 0};
     if (cc < n) {
       ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)cc * Ppad, 0);
+    } else if (hb >= 0) {
+      ci.kind = 3;
+      ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)a * Ppad, 0);
+      ci.sb = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)hb * Ppad, 0);
+      ci.sc = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)hc * Ppad, 0);
     } else if (a < n && b < n) {
       ci.kind = 2;
       ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)a * Ppad, 0);
@@ -342,6 +406,16 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       double ra[4], rb[4];
       tip_row(ci.a, ci.s, ra);
       tip_row(ci.b, ci.sb, rb);
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = ra[i] * rb[i];
+    } else if (ci.kind == 3) {  // a pitchfork's partial: a_tip . P_H (a_b . a_c)
+      double ra[4], rb[4];
+      tip_row(ci.hb, ci.sb, ra);
+      tip_row(ci.hc, ci.sc, rb);
+#pragma unroll
+      for (int i = 0; i < 4; i++) ra[i] *= rb[i];
+      MatVec(mats + ci.b * node_mat + kMatP, ra, rb);
+      tip_row(ci.a, ci.s, ra);
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = ra[i] * rb[i];
     } else if (cc == pend_owner) {
@@ -393,11 +467,13 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   double dd[4];
   int last = -1;
   for (int k = 0; k < steps; ++k) {
-    const int4 rec = ord[2 + 2 * k], sub = ord[3 + 2 * k];
+    const int4 rec = ord[3 + 3 * k], sub = ord[4 + 3 * k], fork = ord[5 + 3 * k];
     const int node = __builtin_amdgcn_readfirstlane(rec.x);
     const int c0 = __builtin_amdgcn_readfirstlane(rec.y), c1 = __builtin_amdgcn_readfirstlane(rec.z);
-    const Child k0 = classify(c0, __builtin_amdgcn_readfirstlane(sub.x), __builtin_amdgcn_readfirstlane(sub.y));
-    const Child k1 = classify(c1, __builtin_amdgcn_readfirstlane(sub.z), __builtin_amdgcn_readfirstlane(sub.w));
+    const Child k0 = classify(c0, __builtin_amdgcn_readfirstlane(sub.x), __builtin_amdgcn_readfirstlane(sub.y),
+                              __builtin_amdgcn_readfirstlane(fork.x), __builtin_amdgcn_readfirstlane(fork.y));
+    const Child k1 = classify(c1, __builtin_amdgcn_readfirstlane(sub.z), __builtin_amdgcn_readfirstlane(sub.w),
+                              __builtin_amdgcn_readfirstlane(fork.z), __builtin_amdgcn_readfirstlane(fork.w));
     // the previous step's vector, when its parent comes later: keep a copy at hand (log-likelihood only: the column
     // is the partial's only home until a younger one needs it)
     if (last >= 0 && c0 != last && c1 != last) keep(last, dd);
@@ -494,10 +570,10 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       }
     };
     // the two tip edges of a cherry child whose pre-order partial is q
-    auto cherry_edges = [&](const Child& ci, const double q[4], double rden) {
+    auto cherry_edges = [&](int ta, int state_a, int tb, int state_b, const double q[4], double rden) {
       double aa[4], ab[4], qa[4];
-      tip_row(ci.a, ci.s, aa);
-      tip_row(ci.b, ci.sb, ab);
+      tip_row(ta, state_a, aa);
+      tip_row(tb, state_b, ab);
       MatVec(Q, aa, qa);
       double sa = 0.0, sb = 0.0;
 #pragma unroll
@@ -506,7 +582,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
 #pragma unroll
       for (int i = 0; i < 4; i++) sb += q[i] * (aa[i] * qa[i]);
       const double g = PairSum(sa * rden, sb * rden);
-      if ((lane & 31) == 31) my_row[lane < 32 ? ci.a : ci.b] = g;
+      if ((lane & 31) == 31) my_row[lane < 32 ? ta : tb] = g;
     };
     // a child's edge term: sum_i (u . a_sibling)_i (Q a)_i, times w_p sigma_c r_c / den
     auto edge_term = [&](const double A[4], const double UAs[4], double rden) {
@@ -522,7 +598,36 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       double q[4];
       MatVecT(mats + cc * node_mat + kMatP, UAs, q);
       if (ci.kind == 2) {
-        cherry_edges(ci, q, rden);
+        cherry_edges(ci.a, ci.s, ci.b, ci.sb, q, rden);
+        return;
+      }
+      if (ci.kind == 3) {
+        // pitchfork: tip a and cherry H = ci.b (tips hb, hc) under cc.  With a_a the tip's row and m = P_H (a_b . a_c):
+        //   edge of a:  sum_i (q . m)_i (Q a_a)_i      edge of H:  sum_i (q . a_a)_i (Q m)_i      partial of H:  P_H^T (q . a_a)
+        double ra[4], m[4], t[4];
+        {
+          double rb[4];
+          tip_row(ci.hb, ci.sb, t);
+          tip_row(ci.hc, ci.sc, rb);
+#pragma unroll
+          for (int i = 0; i < 4; i++) t[i] *= rb[i];
+        }
+        MatVec(mats + ci.b * node_mat + kMatP, t, m);
+        tip_row(ci.a, ci.s, ra);
+        MatVec(Q, ra, t);
+        double ea = 0.0, eh = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) ea += (q[i] * m[i]) * t[i];
+        MatVec(Q, m, t);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          ra[i] *= q[i];  // q . a_a
+          eh += ra[i] * t[i];
+        }
+        const double g = PairSum(ea * rden, eh * rden);
+        if ((lane & 31) == 31) my_row[lane < 32 ? ci.a : ci.b] = g;
+        MatVecT(mats + ci.b * node_mat + kMatP, ra, t);
+        cherry_edges(ci.hb, ci.sb, ci.hc, ci.sc, t, rden);
         return;
       }
       if (RESCALE) { int unused = 0; ScalePow2(q, unused); }
@@ -542,12 +647,14 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       pend_owner = cc;
     };
     for (int k = steps - 1; k >= 0; --k) {
-      const int4 rec = ord[2 + 2 * k], sub = ord[3 + 2 * k];
+      const int4 rec = ord[3 + 3 * k], sub = ord[4 + 3 * k], fork = ord[5 + 3 * k];
       const int node = __builtin_amdgcn_readfirstlane(rec.x);
       const int c0 = __builtin_amdgcn_readfirstlane(rec.y), c1 = __builtin_amdgcn_readfirstlane(rec.z);
       const int next = __builtin_amdgcn_readfirstlane(rec.w);  // the step that follows
-      const Child k0 = classify(c0, __builtin_amdgcn_readfirstlane(sub.x), __builtin_amdgcn_readfirstlane(sub.y));
-      const Child k1 = classify(c1, __builtin_amdgcn_readfirstlane(sub.z), __builtin_amdgcn_readfirstlane(sub.w));
+      const Child k0 = classify(c0, __builtin_amdgcn_readfirstlane(sub.x), __builtin_amdgcn_readfirstlane(sub.y),
+                                __builtin_amdgcn_readfirstlane(fork.x), __builtin_amdgcn_readfirstlane(fork.y));
+      const Child k1 = classify(c1, __builtin_amdgcn_readfirstlane(sub.z), __builtin_amdgcn_readfirstlane(sub.w),
+                                __builtin_amdgcn_readfirstlane(fork.z), __builtin_amdgcn_readfirstlane(fork.w));
       double U[4], A0[4], A1[4];
       if (u_forwarded) {
 #pragma unroll

@@ -100,7 +100,12 @@ for case in range(cases):
             fa, fb = np.isfinite(a), np.isfinite(b)  # a likelihood of exactly zero is -inf or nan on either side
             return np.array_equal(fa, fb) and np.allclose(a[fa], b[fa], rtol=rtol, atol=atol)
 
-        ok = close(out["log_likelihood"], ref["log_likelihood"], 1e-10) and close(out["branch_lengths"], ref["branch_lengths"], 1e-6)
+        # a tree whose likelihood is exactly zero on both sides (log-likelihood -inf or nan: conflicting states across
+        # zero-length branches) has no derivative; what either side returns for it is 0/0 arithmetic, compared in the
+        # cases where it comes out the same way (most) but not required to (seed 7201 case 977: 333 taxa, rescaling, a
+        # tenth of the branches zero -- 226 entries finite on the GPU, nan in the checker, round 3's kernel and this one)
+        possible = np.isfinite(np.asarray(out["log_likelihood"])) | np.isfinite(np.asarray(ref["log_likelihood"]))
+        ok = close(out["log_likelihood"], ref["log_likelihood"], 1e-10) and close(out["branch_lengths"][possible], ref["branch_lengths"][possible], 1e-6)
         ll2 = gpu.log_likelihoods(pid, bl, params, rescaling=rescaling)
         ok = ok and close(ll2, ref["log_likelihood"], 1e-10)
         if not ok and not rescaling and not codon:

@@ -1,7 +1,7 @@
 """Arena traffic of walk_hbm_cat_kernel on a tree, counted on the CPU (vector transfers per tree: one transfer = one
 partial-likelihood vector of a (tile, category) written to or read from the HBM arena).  Mirrors the kernel's hand-over
 rules (bito_amd/csrc/walk_hbm_cat.hip: `last`, the `pend` column, the `fwd` column) and prices alternatives: another
-visiting order (heavier subtree first), a deeper stack of pending vectors.
+visiting order (heavier subtree first), a deeper stack of pending vectors, pitchforks rebuilt like cherries (`fold`).
 
     python scripts/sim_hbm_traffic.py [taxa] [trees]
 """
@@ -35,14 +35,29 @@ def children_of(parent_ids, n):
     return ch
 
 
-def kernel_traffic(ch, n, order=None, depth=1, pre_depth=None):
+def unstored_nodes(ch, n, fold):
+    """cherries, and with fold the pitchforks (a tip and a cherry under one node): rebuilt where they are used"""
+    N = n + len(ch)
+    root = N - 1
+    cherry = {v for v in range(n, N) if ch[v - n, 0] < n and ch[v - n, 1] < n and v != root}
+    out = set(cherry)
+    if fold:
+        for v in range(n, N - 1):
+            c0, c1 = ch[v - n]
+            if (c0 < n and c1 in cherry) or (c1 < n and c0 in cherry):
+                out.add(v)
+    return out
+
+
+def kernel_traffic(ch, n, order=None, depth=1, pre_depth=None, fold=False):
     """(post-order reads, post-order writes, pre-order reads, pre-order writes) of the gradient pass.
-    order: the sequence of internal nodes (default: ascending ids); depth: entries of the pending stack."""
+    order: the sequence of internal nodes (default: ascending ids); depth: entries of the pending stack;
+    fold: pitchforks are not stored either (round 4)."""
     N = n + len(ch)
     root = N - 1
     if order is None:
         order = list(range(n, N))
-    cherry = {v for v in range(n, N) if ch[v - n, 0] < n and ch[v - n, 1] < n and v != root}
+    cherry = unstored_nodes(ch, n, fold)
     stored = lambda v: v >= n and v not in cherry
     steps = [v for v in order if v not in cherry]
     # ---- post-order
@@ -100,12 +115,13 @@ def kernel_traffic(ch, n, order=None, depth=1, pre_depth=None):
     return post + (reads, writes)
 
 
-def heavy_first_order(ch, n, light_first=False):
+def heavy_first_order(ch, n, light_first=False, fold=False):
     """depth-first post-order that visits the child whose subtree needs more pending vectors first (Sethi-Ullman)"""
     N = n + len(ch)
     root = N - 1
     need = np.zeros(N, dtype=np.int64)
-    cherry = lambda v: v >= n and ch[v - n, 0] < n and ch[v - n, 1] < n and v != root
+    unstored = unstored_nodes(ch, n, fold)
+    cherry = lambda v: v in unstored
     for v in range(n, N):
         c0, c1 = ch[v - n]
         a = 0 if (c0 < n or cherry(c0)) else need[c0]
@@ -149,12 +165,18 @@ def main():
         for depth in (1, 2, 3, 4, 8):
             row[f"heavy d{depth}"] = kernel_traffic(ch, n, order, depth)
         row["heavy d2/1"] = kernel_traffic(ch, n, order, 2, 1)
+        forder, _ = heavy_first_order(ch, n, fold=True)
+        row["fold d2/1"] = kernel_traffic(ch, n, forder, 2, 1, fold=True)  # the kernel since round 4
+        row["fold d2"] = kernel_traffic(ch, n, forder, 2, fold=True)
+        row["fold d4"] = kernel_traffic(ch, n, forder, 4, fold=True)
+        row["stored, folded"] = N - n - len(unstored_nodes(ch, n, True)) - 1
         row["ids d2/1"] = kernel_traffic(ch, n, None, 2, 1)
         row["ids d2"] = kernel_traffic(ch, n, None, 2)
         row["ids d4"] = kernel_traffic(ch, n, None, 4)
         rows.append(row)
-    keys = [k for k in rows[0] if k not in ("stored", "max need")]
-    print(f"{n} taxa, {T} trees: stored vectors {np.mean([r['stored'] for r in rows]):.0f}, "
+    keys = [k for k in rows[0] if k not in ("stored", "max need", "stored, folded")]
+    print(f"{n} taxa, {T} trees: stored vectors {np.mean([r['stored'] for r in rows]):.0f} "
+          f"(pitchforks folded: {np.mean([r['stored, folded'] for r in rows]):.0f}), "
           f"Sethi-Ullman need max {max(r['max need'] for r in rows)}")
     for k in keys:
         a = np.array([r[k] for r in rows], dtype=float).mean(axis=0)

@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _sweep(script, *args):
+def _sweep(script, *args, env=None):
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), *[str(a) for a in args]],
-                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500, cwd=ROOT)
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500, cwd=ROOT,
+                          env={**os.environ, **(env or {})})
     out = proc.stdout
     try:  # (kept next to the other measurements when the directory is there)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -40,6 +41,15 @@ def test_seeded_sweep_per_tree_path(cases, seed, kernel):
     done, declined = _sweep("gpu_fuzz.py", *args)
     assert done == cases
     assert declined < cases  # (a forced kernel declines the shapes it does not take; it must take some)
+
+
+def test_seeded_sweep_hbm_arena_walk_large_trees_folded_and_not():
+    """The HBM-arena walk pinned, trees of up to 333 taxa among the sizes: as built (pitchforks -- a tip and a cherry under
+    one node -- rebuilt from their tips' matrix rows like cherries: no step, no cell) and with a step and a cell for every
+    pitchfork (BITO_AMD_HBM_FOLD=0, read once per process: hence the sweep's own process)."""
+    for env in ({"FUZZ_LARGE_TREES": "1"}, {"FUZZ_LARGE_TREES": "1", "BITO_AMD_HBM_FOLD": "0"}):
+        done, declined = _sweep("gpu_fuzz.py", 100, 3106, 1, env=env)
+        assert done == 100 and declined == 0
 
 
 def test_seeded_sweep_gp_executor():
