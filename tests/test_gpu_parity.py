@@ -998,6 +998,40 @@ def test_pipe_walk_in_two_classes():
         assert ll_close(gpu.log_likelihoods(pid, bl * scale, params), ref["log_likelihood"])
 
 
+@pytest.mark.parametrize("n", [33, 35, 36, 38])
+def test_pipe_walk_four_groups_per_wave_beyond_32_taxa(n):
+    """33 to 38 taxa with four pattern groups per wave (layout 3 of walk_pipe.hip: 40 mask registers instead of 32;
+    two groups before round 4): random trees (those that keep few enough vectors for four groups -- at 38 taxa the
+    engine walks the batch in two classes, most trees with two groups), every category count, the site-model pass,
+    log-likelihood only; against the oracle."""
+    rng = np.random.default_rng(3300 + n)
+    P, T = 300, 24
+    patterns = rng.integers(0, 4, (n, P)).astype(np.int32)
+    patterns[rng.random((n, P)) < 0.03] = 4
+    weights = rng.integers(1, 4, P).astype(np.float64)
+    pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(T)])
+    bl = rng.exponential(0.1, (T, 2 * n - 1))
+    bl[:, -1] = 0.0
+    for site in ("weibull+4", "weibull+2", "constant"):
+        gpu, cpu = engines("GTR", site, "none", patterns, weights, 8)
+        params = gpu.default_params(T)
+        params[:, :4] = rng.dirichlet([5, 5, 5, 5], T)
+        params[:, 4:10] = rng.dirichlet([3] * 6, T)
+        if site != "constant":
+            params[:, 10] = rng.uniform(0.3, 2.0, T)
+        flags = _capi.GRAD_SITE_MODEL if site != "constant" else 0
+        out = gpu.gradients(pid, bl, params, flags=flags)
+        assert gpu.kernel_name() == "walk_pipe_kernel"
+        if n <= 36:
+            assert "x 4 pattern groups" in gpu.kernel_form(), gpu.kernel_form()
+        ref = cpu.gradients(pid, bl, params, flags=oracle.GRAD_SITE_MODEL if flags else 0)
+        assert ll_close(out["log_likelihood"], ref["log_likelihood"]), site
+        assert grad_close(out["branch_lengths"], ref["branch_lengths"]), site
+        if flags:
+            assert grad_close(out["site_model"], ref["site_model"]), site
+        assert ll_close(gpu.log_likelihoods(pid, bl, params), ref["log_likelihood"]), site
+
+
 def test_general_kernel_model_index_follows_the_resident_batch():
     """Selecting the general-state kernels AFTER a batch was uploaded under another kernel choice must not
     reuse the model index of an earlier batch: set_kernel(GENERAL), upload A, set_kernel(AUTO), upload B (same
