@@ -1005,7 +1005,7 @@ def test_pipe_walk_four_groups_per_wave_beyond_32_taxa(n):
     engine walks the batch in two classes, most trees with two groups), every category count, the site-model pass,
     log-likelihood only; against the oracle."""
     rng = np.random.default_rng(3300 + n)
-    P, T = 300, 24
+    P, T = 300, 48  # (32 trees and more: the engine may walk a batch in two classes)
     patterns = rng.integers(0, 4, (n, P)).astype(np.int32)
     patterns[rng.random((n, P)) < 0.03] = 4
     weights = rng.integers(1, 4, P).astype(np.float64)
@@ -1022,7 +1022,7 @@ def test_pipe_walk_four_groups_per_wave_beyond_32_taxa(n):
         flags = _capi.GRAD_SITE_MODEL if site != "constant" else 0
         out = gpu.gradients(pid, bl, params, flags=flags)
         assert gpu.kernel_name() == "walk_pipe_kernel"
-        if n <= 36:
+        if n <= 36 and site == "weibull+4":
             assert "x 4 pattern groups" in gpu.kernel_form(), gpu.kernel_form()
         ref = cpu.gradients(pid, bl, params, flags=oracle.GRAD_SITE_MODEL if flags else 0)
         assert ll_close(out["log_likelihood"], ref["log_likelihood"]), site
