@@ -124,11 +124,40 @@ setup_trees_lds_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, int trees) {
   const int lanes = trees <= 64 ? 64 : 128;       // threads per job
   const int job = tid / lanes, who = tid % lanes;  // job 0: eigensystem; 1: topology (+ rates when there is no job 2); 2: rates
   if (who < count) {
-    if (job == 0) SetupSubstitution(spec, prm + who * pc, &b.model[t0 + who]);
+    TreeModel* mine = &b.model[t0 + who];
+    if (job == 0) {
+      if (b.model_reuse != nullptr) {  // (the host found every row of the call equal to the cached model's: kernels.hpp)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          mine->V[i] = b.model_reuse->V[i];
+          mine->Vinv[i] = b.model_reuse->Vinv[i];
+          mine->Q[i] = b.model_reuse->Q[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          mine->lambda[i] = b.model_reuse->lambda[i];
+          mine->pi[i] = b.model_reuse->pi[i];
+        }
+      } else {
+        SetupSubstitution(spec, prm + who * pc, mine);
+      }
+    }
     if (job == 1) SetupTopologyCore(d, par + who * (M - 1), ch + who * 2 * NI, bl + who * N, RW ? rts + who * RW : nullptr);
-    if (job == (lanes == 64 ? 2 : 1)) SetupSiteRates(spec, prm + who * pc, &b.model[t0 + who]);
+    if (job == (lanes == 64 ? 2 : 1)) {
+      if (b.model_reuse != nullptr) {
+        for (int i = 0; i < kMaxCategories; i++) {
+          mine->cat_rate[i] = b.model_reuse->cat_rate[i];
+          mine->cat_weight[i] = b.model_reuse->cat_weight[i];
+          mine->cat_rate_deriv[i] = b.model_reuse->cat_rate_deriv[i];
+        }
+      } else {
+        SetupSiteRates(spec, prm + who * pc, mine);
+      }
+    }
   }
   __syncthreads();
+  // (tree 0's model for the next call; on a reuse the cache holds these very values already)
+  if (b.model_cache != nullptr && b.model_reuse == nullptr && blockIdx.x == 0 && tid == 0) *b.model_cache = b.model[0];
   for (int i = tid; i < count * 2 * NI; i += step) b.children[(size_t)t0 * 2 * NI + i] = ch[i];
   for (int i = tid; i < count * N; i += step) b.branch[(size_t)t0 * N + i] = bl[i];
 }

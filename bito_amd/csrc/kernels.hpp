@@ -63,6 +63,12 @@ struct DeviceBatch {
   int32_t* children;          // [T][n-1][2]  children of internal node n+k
   double* branch;             // [T][N]       effective branch lengths
   TreeModel* model;           // [T]
+  // A small blocking call whose parameter rows all equal the row the LAST such call's tree 0 had (the host compares them
+  // while it stages the call): setup_trees_lds_kernel copies that tree's model -- kept in model_cache -- instead of
+  // forming the rate matrix, the eigensystem and the category rates again (the serial 4 x 4 Jacobi is 10 of a 100-tree
+  // call's 26 us of set-up).  Same bits: the copy is what the same arithmetic on the same row gave.  Null otherwise.
+  const TreeModel* model_reuse;
+  TreeModel* model_cache;     // where tree 0's model is left when it was computed (null: nowhere)
   double* mats;               // [T][N-1][C][kMatStride]   (HBM-arena kernel; [T][N-1][C][kMatHot] for walk_hbm_cat_kernel)
   double* images;             // [T][N-1][kImgStride]      (LDS kernel)
   int32_t* sched;             // [T][2][n+1][16]           step descriptors (LDS kernel); step records in visiting order (HBM-arena walk)

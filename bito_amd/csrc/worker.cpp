@@ -44,6 +44,11 @@ hipStream_t SetupStream(const Worker* e) {
   if (e->one_shot) return e->lent_setup ? e->lent_setup : e->stream;
   return e->serial_setup ? e->stream : e->prep_stream;
 }
+// BITO_AMD_MODEL_CACHE=0: every call forms every tree's eigensystem and category rates again
+static bool ModelCacheOn() {
+  static const bool on = [] { const char* v = std::getenv("BITO_AMD_MODEL_CACHE"); return !(v && v[0] == '0'); }();
+  return on;
+}
 hipStream_t WalkStream(const Worker* e) { return (e->one_shot && e->lent_walk) ? e->lent_walk : e->stream; }
 
 // A blocking call's chunk whose final-sums kernel is the last kernel of the pass: that kernel stores the completion
@@ -456,6 +461,13 @@ size_t ArenaBudget(Worker* e, size_t wanted_bytes) {
   return std::max<size_t>(std::min<size_t>((size_t)e->arena_limit, held + free_b / 4 * 3), (size_t)1 << 28);
 }
 
+// behind a set-up launch: what the model cache holds from now on (kernels.hpp, DeviceBatch::model_cache)
+void NoteModelCache(Worker* e, const DeviceBatch& b) {
+  if (b.model_cache == nullptr || b.model_reuse != nullptr) return;  // (not written, or it holds these values already)
+  e->model_cache_row = e->staging.row0;
+  e->model_cache_valid = !e->staging.row0.empty();
+}
+
 DeviceBatch MakeBatch(Worker* e, int set = 0) {
   DeviceBatch b{};
   b.parent_ids = e->parent_ids.ptr;
@@ -475,6 +487,10 @@ DeviceBatch MakeBatch(Worker* e, int set = 0) {
     b.branch_in = reinterpret_cast<const double*>(stage);
     b.rates = e->has_rates ? reinterpret_cast<const double*>(stage + (reinterpret_cast<const char*>(e->rates.ptr) - block)) : nullptr;
     b.params = reinterpret_cast<const double*>(stage + (reinterpret_cast<const char*>(e->params.ptr) - block));
+    // (the staging set-up kernel of a small blocking call: tree 0's model kept for the next call, or the last call's
+    // copied when WorkerStageEnd found every parameter row of this call equal to the one it was formed from)
+    b.model_cache = e->model_cache.ptr;
+    b.model_reuse = (e->model_reuse_next && e->model_cache.ptr != nullptr) ? e->model_cache.ptr : nullptr;
   }
   b.tip_states = e->tip_states.ptr;
   b.weights = e->weights.ptr;
@@ -799,6 +815,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     const bool in_line = prep == walk;  // set-up in front of the traversal, on its stream
     e->last_walk = walk;
     const bool bare = e->serial_setup == 2 && e->run_counter > (unsigned)Worker::kSets;
+    bool inputs_event_due = false;
     if (!bare) {
       if (!in_line) {
         e->prep_used = e->prep_used || !e->one_shot;  // (a lent stream is not this worker's to wait for)
@@ -810,8 +827,13 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
       const bool busy = e->one_shot ? e->one_shot == 2
                                     : (!e->serial_setup && e->last_pass_done != nullptr && hipEventQuery(e->last_pass_done) == hipErrorNotReady);
       LaunchSetup(d, e->spec, b, want_gradient, prep, /*beside_traversal=*/busy);
-      if (e->inputs_on_host) {  // (that kernel made the device copies of the inputs: later passes wait for it)
-        HIP_TRY(e, hipEventRecord(e->ev_inputs, prep));
+      NoteModelCache(e, b);
+      // (that kernel made the device copies of the inputs: later passes wait for it.  The event is recorded behind the
+      // kernels that follow on the same stream, not between the set-up and the image kernel: there the marker costs the
+      // 6 us it takes the queue to retire it before the next kernel starts -- a 100-tree call's set-up and image
+      // kernels are 26 and 20 us)
+      if (e->inputs_on_host) {
+        inputs_event_due = true;
         e->inputs_pending = true;
         e->inputs_on_host = false;
       }
@@ -825,6 +847,10 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
         if (use_lds) LaunchLdsSchedule(d, b, plan, prep);
       }
       if (!in_line) {
+        if (inputs_event_due) {
+          HIP_TRY(e, hipEventRecord(e->ev_inputs, prep));
+          inputs_event_due = false;
+        }
         HIP_TRY(e, hipEventRecord(e->ev_prep_done[set], prep));
         HIP_TRY(e, hipStreamWaitEvent(walk, e->ev_prep_done[set], 0));
       }
@@ -870,6 +896,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     const int reduce_from = (use_pipe && b.pipe_done != nullptr && !two_classes) ? plan.whole_trees : 0;
     LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, walk, grad_rows, DoneByReduce(e),
                  use_pipe ? b.pipe_done : nullptr, reduce_from);
+    if (inputs_event_due) HIP_TRY(e, hipEventRecord(e->ev_inputs, walk));  // (in line: the set-up ran on this stream)
     if (!bare) HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], walk));
     e->last_pass_done = bare ? nullptr : e->ev_walk_done[set];
     HIP_TRY(e, hipGetLastError());
@@ -902,6 +929,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
       if (e->inputs_pending && !e->one_shot) HIP_TRY(e, hipStreamWaitEvent(prep, e->ev_inputs, 0));
     }
     LaunchSetup(d, e->spec, b, want_gradient, prep);
+    NoteModelCache(e, b);
     if (e->inputs_on_host) {
       HIP_TRY(e, hipEventRecord(e->ev_inputs, prep));
       e->inputs_pending = true;
@@ -1216,6 +1244,18 @@ int WorkerStageEnd(Worker* e, const StagePart* parts, int part_count) {
   e->inputs_on_host = e->one_shot && !wait && e->spec.state_count == 4 && e->kernel_choice != BITO_AMD_KERNEL_GENERAL &&
                       SetupReadsHostInputs(probe, e->spec) &&
                       !(e->one_shot == 2 && InputsCopyMin() > 0 && tree_count >= InputsCopyMin());
+  // the model of the last small call's tree 0 serves this call when every parameter row equals the row it came from
+  e->model_reuse_next = false;
+  st.row0.clear();
+  if (e->inputs_on_host && e->spec.param_count > 0 && ModelCacheOn()) {
+    const size_t pc = (size_t)e->spec.param_count;
+    HIP_TRY(e, e->model_cache.Reserve(1));
+    st.row0.assign(st.params, st.params + pc);
+    bool same = e->model_cache_valid && e->model_cache_row.size() == pc;
+    for (int t = 0; same && t < tree_count; t++)
+      same = std::memcmp(st.params + (size_t)t * pc, e->model_cache_row.data(), pc * sizeof(double)) == 0;
+    e->model_reuse_next = same;
+  }
   if (!e->inputs_on_host) {
     HIP_TRY(e, hipMemcpyAsync(e->in_block.ptr, stage, st.bytes, hipMemcpyHostToDevice, SetupStream(e)));
     HIP_TRY(e, hipEventRecord(e->ev_inputs, SetupStream(e)));

@@ -142,6 +142,7 @@ struct Worker {
     const int32_t* parent_ids = nullptr;
     const double *branch_lengths = nullptr, *rates = nullptr, *params = nullptr;
     size_t off_params = 0, off_rates = 0, off_pid = 0, bytes = 0;
+    std::vector<double> row0;  // tree 0's parameter row, when the call's set-up may leave its model in model_cache
   } staging;
   DeviceBuffer<int32_t> children, sched, children2, sched2, children3, sched3;
   DeviceBuffer<int32_t> pipe_masks;  // packed tip masks per pattern tile (walk_pipe_kernel): a function of the alignment and the plan
@@ -190,6 +191,11 @@ struct Worker {
   double min_rate = 1.0;    // smallest off-diagonal entry of the batch's normalised rate matrices (39 taxa and more only)
   double min_branch = 0.0;  // smallest branch length of the resident batch (known for 39 taxa and more only, else 0)
   DeviceBuffer<TreeModel> model, model2, model3;
+  // the model of tree 0 of the last small blocking call whose set-up left it (DeviceBatch::model_cache), the parameter
+  // row it was formed from, and whether the call now staged may copy it (every row equal to that one)
+  DeviceBuffer<TreeModel> model_cache;
+  std::vector<double> model_cache_row;
+  bool model_cache_valid = false, model_reuse_next = false;
   DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
   DeviceBuffer<int32_t> gs_model_index;  // [T] first tree with the same parameter row
   bool gs_index_valid = false;           // the index was built from the parameter rows that are resident now
