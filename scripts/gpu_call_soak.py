@@ -25,6 +25,7 @@ engines = {"one slot": bito_amd.Engine(spec, full.patterns, full.weights),
            "five slots": bito_amd.Engine(spec, full.patterns, full.weights, devices=[0] * 5)}
 cpu = oracle.OracleEngine(full.substitution, full.site, full.clock, full.patterns, full.weights, 8)
 bad = 0
+last_row = None
 t0 = time.time()
 for it in range(iterations):
     T = int(rng.choice([1, 3, 50, 100, 511, 512, 1023, 1024, 1025, 2000, 3333, 6400, 9000]))
@@ -33,6 +34,16 @@ for it in range(iterations):
     bl = full.branch_lengths[start:start + T] * rng.uniform(0.5, 2.0)
     par = full.params[start:start + T].copy()
     par[:, -1] = rng.uniform(0.3, 2.0, T)
+    # (round 4: small calls keep the last call's model when the parameter rows repeat -- rows that are all equal, equal
+    # to the call before, or equal but for one tree, in turn with a row per tree)
+    style = it % 5
+    if style == 1 or (style in (2, 3) and last_row is None):
+        par[:] = par[0]
+    elif style in (2, 3):
+        par[:] = last_row
+        if style == 3:
+            par[T // 2, -1] = rng.uniform(0.3, 2.0)
+    last_row = par[0].copy()
     mode = it % 3
     want = plain.gradients(pid, bl, par, flags=_capi.GRAD_SITE_MODEL if mode == 2 else 0) if mode else \
         {"log_likelihood": plain.log_likelihoods(pid, bl, par)}
@@ -48,7 +59,7 @@ for it in range(iterations):
             bad += 1
             print(f"MISMATCH iteration {it} {name}: T={T} start={start} mode={mode} "
                   f"dLL={np.abs(got['log_likelihood'] - want['log_likelihood']).max():.3e}")
-    if it % 20 == 0:  # a sample against the CPU checker
+    if it % 4 == 0:  # a sample against the CPU checker
         sel = rng.choice(T, size=min(T, 8), replace=False)
         ref = cpu.log_likelihoods(pid[sel], bl[sel], par[sel])
         if not np.allclose(want["log_likelihood"][sel], ref, rtol=2e-14, atol=1e-10):
