@@ -96,7 +96,7 @@ __device__ __forceinline__ int GsImageIndex(int row, int col) {
 
 __global__ void __launch_bounds__(64)
 gs_model_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, const int32_t* __restrict__ model_index,
-                double* __restrict__ gs_model) {
+                double* __restrict__ gs_model, int topology_only) {
 #pragma clang fp contract(off)
   __shared__ double A[64 * kLd];
   __shared__ double pi[64], sq[64], rowsum[64];
@@ -104,7 +104,7 @@ gs_model_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, const int32_t* __res
   const int t = blockIdx.x, lane = threadIdx.x;
   const int S = spec.state_count;
   if (lane == 0) SetupTopology(d, b, t);
-  if (model_index[t] != t) return;
+  if (topology_only || model_index[t] != t) return;  // (topology_only: the models of the batch before still stand)
   const double* __restrict__ row = b.params + (size_t)t * spec.param_count;
   double* __restrict__ out = gs_model + (size_t)t * kGsModelStride;
 
@@ -373,10 +373,13 @@ gs_eigen_kernel(const int32_t* __restrict__ model_index, double* __restrict__ gs
   if (tid < 64) out[kGsLambda + tid] = A[tid * kLd + tid];
 }
 
+// models_stand: the parameter rows are those of the batch before, whose models are still in gs_model (worker.cpp,
+// UploadModelIndex): the trees' topologies and effective branch lengths only
 void LaunchGsSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, const int32_t* model_index,
-                   double* gs_model, hipStream_t stream) {
-  hipLaunchKernelGGL(gs_model_kernel, dim3(d.tree_count), dim3(64), 0, stream, d, spec, b, model_index, gs_model);
-  hipLaunchKernelGGL(gs_eigen_kernel, dim3(d.tree_count), dim3(256), 0, stream, model_index, gs_model);
+                   double* gs_model, hipStream_t stream, bool models_stand) {
+  hipLaunchKernelGGL(gs_model_kernel, dim3(d.tree_count), dim3(64), 0, stream, d, spec, b, model_index, gs_model,
+                     models_stand ? 1 : 0);
+  if (!models_stand) hipLaunchKernelGGL(gs_eigen_kernel, dim3(d.tree_count), dim3(256), 0, stream, model_index, gs_model);
 }
 
 // --------------------------------------------------------------------------------------------

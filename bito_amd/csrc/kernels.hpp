@@ -319,7 +319,7 @@ inline int GsTiles(int pattern_count) { return (pattern_count + 15) / 16; }  // 
 size_t GsArenaDoublesPerTree(const BatchDims& d, int tiles, int want_gradient);
 size_t GsImageDoublesPerTree(const BatchDims& d);
 void LaunchGsSetup(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, const int32_t* model_index,
-                   double* gs_model, hipStream_t stream);
+                   double* gs_model, hipStream_t stream, bool models_stand = false);
 // b.images is the chunk's record array [chunk][N-1][C][3][4096]; b.arena the chunk's PLV arena
 void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const double* branch,
                       const int32_t* model_index, const double* gs_model, double* imgs, int want_gradient,

@@ -198,6 +198,12 @@ struct Worker {
   bool model_cache_valid = false, model_reuse_next = false;
   DeviceBuffer<double> gs_model;  // general-state path: per-model V, V^-1, Q, lambda, pi, category rates
   DeviceBuffer<int32_t> gs_model_index;  // [T] first tree with the same parameter row
+  // general-state path: the parameter rows the index and the models on the device were formed from (host copy), and
+  // whether those models still stand (UploadModelIndex, RunResidentGeneral)
+  std::vector<double> gs_rows;
+  int gs_rows_trees = 0;
+  bool gs_models_fresh = false;
+  const double* gs_model_seen = nullptr;
   bool gs_index_valid = false;           // the index was built from the parameter rows that are resident now
   // time-tree transforms (row f2): staging for host inputs, scratch and results
   DeviceBuffer<int32_t> tt_parents;

@@ -105,3 +105,59 @@ def test_same_bits_with_the_cache_off():
         assert proc.returncode == 0, proc.stderr[-2000:]
         digests.append(proc.stdout.strip().splitlines()[-1])
     assert digests[0] == digests[1]
+
+
+def test_general_state_path_keeps_models_but_not_topologies():
+    """61 states: the rate matrices and 64 x 64 eigensystems of the batch before stand when the parameter rows repeat
+    (worker.cpp, UploadModelIndex); the trees' topologies and branch lengths are set up on every pass all the same --
+    other trees, other branch lengths, then other rows, blocking calls and passes over a resident batch, each against
+    the CPU checker."""
+    from oracle import gs
+    from test_gpu_parity import _random_rooted_parent_ids
+
+    rng = np.random.default_rng(61)
+    n, P, T = 9, 40, 6
+    patterns = rng.integers(0, 61, (n, P)).astype(np.int32)
+    weights = rng.integers(1, 4, P).astype(np.float64)
+    gpu = bito_amd.Engine(bito_amd.PhyloModelSpecification("GY94", "constant", "none"), patterns, weights)
+    cpu = gs.GsOracleEngine("GY94", "constant", patterns, weights, 4)
+    params = gpu.default_params(T)
+    params[:, :4] = rng.dirichlet([5, 5, 5, 5])
+    params[:, 4] = 2.0
+    params[:, 5] = 0.4
+
+    def check(pid, bl, par):
+        out = gpu.gradients(pid, bl, par)
+        ref = cpu.gradients(pid, bl, par)
+        assert _close(out["log_likelihood"], ref["log_likelihood"], 1e-10, 2e-14)
+        assert _close(out["branch_lengths"], ref["branch_lengths"], 1e-6, 1e-9)
+        return out
+
+    pid = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(T)])
+    bl = rng.exponential(0.1, (T, 2 * n - 1))
+    bl[:, -1] = 0.0
+    first = check(pid, bl, params)
+    assert _same_bits(check(pid, bl, params), first)           # same rows: the models stand
+    pid2 = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(T)])
+    bl2 = rng.exponential(0.05, (T, 2 * n - 1))
+    bl2[:, -1] = 0.0
+    check(pid2, bl2, params)                                    # other trees, the same rows
+    other = params.copy()
+    other[3, 5] = 0.9
+    check(pid2, bl2, other)                                     # one row changed
+    assert _same_bits(check(pid, bl, params), first)
+    # passes over the resident batch: new branch lengths, then new rows
+    gpu.upload(pid, bl, params)
+    gpu.run(True)
+    ll, grad = gpu.download()
+    assert np.array_equal(ll, first["log_likelihood"]) and np.array_equal(grad, first["branch_lengths"])
+    gpu.update(branch_lengths=bl2)
+    gpu.run(True)
+    ll, grad = gpu.download()
+    ref = cpu.gradients(pid, bl2, params)
+    assert _close(ll, ref["log_likelihood"], 1e-10, 2e-14) and _close(grad, ref["branch_lengths"], 1e-6, 1e-9)
+    gpu.update(params=other)
+    gpu.run(True)
+    ll, grad = gpu.download()
+    ref = cpu.gradients(pid, bl2, other)
+    assert _close(ll, ref["log_likelihood"], 1e-10, 2e-14) and _close(grad, ref["branch_lengths"], 1e-6, 1e-9)
