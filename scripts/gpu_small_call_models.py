@@ -6,7 +6,7 @@ import numpy as np
 import bito_amd
 from bito_amd import workloads
 
-base = workloads.ds1_gtr_weibull4(1)
+base = workloads.ds1_gtr_weibull4(64)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 only = sys.argv[2] if len(sys.argv) > 2 else None
 for sub, site in (("GTR", "weibull+4"), ("JC69", "weibull+4"), ("GTR", "constant")):
