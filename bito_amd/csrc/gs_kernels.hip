@@ -410,6 +410,12 @@ constexpr int kPld = 66;  // LDS row stride of P (even: 16-byte aligned pairs)
 // its rows of V in registers, V^-1 in LDS in the B-operand order, the lists of Q's nonzero entries -- instead of one job
 // per workgroup with 80 loads per lane through L1 in front of its 64 matrix instructions: 557 k workgroups per 4096
 // config-5 trees spent half the kernel's time outside their products.)
+// (Round 4, tried and dropped: ONE image per internal branch read both ways by the walk -- units of a row swizzled by
+// unit ^ (4 kq) ^ (row & 1), so that the 16-byte reads of P x keep whole rows and the 8-byte reads of P^T w spread a
+// 16-lane group over 16 double-word banks -- a third fewer bytes written here.  Parity-green at the first run; this
+// kernel 11.6 -> 10.9 ms per 4096 config-5 trees, the walk 43.3 -> 43.6-44.1 (237 registers instead of 216, twice the
+// LDS instructions in a third of its contractions): 73.6 k trees/s against 74.0 k.  The kernel is not bound by its
+// writes alone.)
 constexpr int kGsMatJobs = 8;
 
 __global__ void __launch_bounds__(256)
