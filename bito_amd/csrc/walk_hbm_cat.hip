@@ -39,7 +39,8 @@ __device__ __forceinline__ void MatVecT(const double* __restrict__ M, const doub
 // categories of its pattern: 128 registers, four waves per SIMD, a load-wait round per category and step).
 // Here a thread owns ONE category of one pattern: a workgroup is C waves over the same 64 patterns, wave c
 // walks the tree in category c.  The matrices stay wave-uniform (scalar loads), a thread needs a third of the
-// registers, and twice as many waves per SIMD have their loads in flight.  Categories meet only twice:
+// registers, and twice as many waves per SIMD have their loads in flight (eight until round 3, seven since the
+// pitchforks are rebuilt in the step: HBM_CAT_WAVES).  Categories meet only twice:
 //   * after the post-order pass, through LDS: site likelihood L_p = sum_c w_c s_c, and each thread's share
 //     sigma_c = w_c s_c / L_p of it;
 //   * never in the pre-order pass: d log L_p / dt_e = sum_c sigma_c num_c / den_c, where num_c and den_c are the
@@ -223,7 +224,7 @@ void LaunchHbmOrder(const BatchDims& d, const DeviceBatch& b, hipStream_t stream
 
 // Buffer accesses: a wave-uniform 128-bit descriptor (base in scalar registers), a wave-uniform byte offset, and
 // ONE 32-bit lane offset in a vector register -- no 64-bit per-lane pointers (the compiler otherwise keeps one
-// per stream, registers this kernel does not have at eight waves per SIMD).
+// per stream, registers this kernel does not have at seven or eight waves per SIMD).
 using BufferRsrc = __amdgpu_buffer_rsrc_t;
 typedef unsigned UInt2 __attribute__((ext_vector_type(2)));
 typedef unsigned UInt4 __attribute__((ext_vector_type(4)));
@@ -537,7 +538,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   //     den = sum_i u_i a0_i a1_i,   num_0 = sum_i u_i a1_i (Q a0)_i   (dP x = r_c Q P x: Q and P commute; the
   //     factor r_c, or d r_c / d shape for the site-model pass, multiplies the wave's weight once),
   //     pre(child 0) = P_0^T (u . a1).
-  // The step is written child by child so that few vectors are live at a time (eight waves per SIMD).
+  // The step is written child by child so that few vectors are live at a time (seven waves per SIMD: 72 registers).
   if (GRAD) {
     const double rate = deriv_mode ? tm->cat_rate_deriv[c] : tm->cat_rate[c];
     // rescaled: w_p sigma_c r_c (then times num_c / den_c per edge); plain: w_p w_c r_c / L_p (then times num_c)
@@ -675,7 +676,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       for (int i = 0; i < 4; i++) UA1[i] = U[i] * A1[i];
       // Rescaled vectors carry unknown powers of two, the same in num_c and den_c: the ratio form, gw / den by
       // reciprocal and two Newton steps (relative error ~1e-16; the full division's special-case handling costs
-      // a dozen registers the step does not have at eight waves per SIMD).  Without rescaling the numerator is
+      // a dozen registers the step does not have at seven waves per SIMD).  Without rescaling the numerator is
       // the reference's own term and w_p w_c r_c / L_p multiplies it directly: no division, and a category that
       // has underflowed (large tree, short branches: the slow categories go first) contributes its zero instead
       // of 0/0, while a pattern whose likelihood is zero still turns the tree's derivatives non-finite as the
