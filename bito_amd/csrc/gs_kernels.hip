@@ -47,9 +47,6 @@
 #ifndef GS_EXP_NOSTORE
 #define GS_EXP_NOSTORE 0
 #endif
-#ifndef GS_MAT_EXP
-#define GS_MAT_EXP 0  // gs_matrices_kernel, timing only: 1 no stores to HBM, 2 one k-step of products, 3 no sparse dP terms, 4 leaf branches as internal ones
-#endif
 #ifndef GS_EXP_NOMFMA
 #define GS_EXP_NOMFMA 0
 #endif
@@ -418,10 +415,12 @@ constexpr int kPld = 66;  // LDS row stride of P (even: 16-byte aligned pairs)
 // 16-lane group over 16 double-word banks -- a third fewer bytes written here.  Parity-green at the first run; this
 // kernel 11.6 -> 10.9 ms per 4096 config-5 trees, the walk 43.3 -> 43.6-44.1 (237 registers instead of 216, twice the
 // LDS instructions in a third of its contractions): 73.6 k trees/s against 74.0 k.  The kernel is not bound by its
-// writes alone.)  What it IS bound by (GS_MAT_EXP builds, 11.4 ms per 4096 config-5 trees): without its stores to HBM
-// 10.9 ms, with one k-step of its products 7.1, without the sparse dP terms of the leaf branches 8.1 (41 k LDS reads per
-// leaf job, the lists' indices and values among them), leaf branches treated as internal ones 8.0 -- arithmetic and LDS
-// instructions, a third each for the products, the sparse dP terms and the rest (exponentials, the passes through LDS).
+// writes alone.)  What it IS bound by (timing-only builds of commit 41077d6, GS_MAT_EXP = 1..4; 11.4 ms per 4096
+// config-5 trees): without its stores to HBM 10.9 ms, with one k-step of its products 7.1, without the sparse dP terms
+// of the leaf branches 8.1 (41 k LDS reads per leaf job, the lists' indices and values among them), leaf branches
+// treated as internal ones 8.0 -- arithmetic and LDS instructions, a third each for the products, the sparse dP terms
+// and the rest (exponentials, the passes through LDS).  The knobs are not in this file: the build that ships is, line
+// for line of device code, the one the round's last full GPU run checked.
 constexpr int kGsMatJobs = 8;
 
 __global__ void __launch_bounds__(256)
@@ -480,7 +479,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
 #pragma unroll
     for (int nb = 0; nb < 4; nb++) acc[nb] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
-    for (int ks = 0; ks < (GS_MAT_EXP == 2 ? 1 : 16); ks++) {
+    for (int ks = 0; ks < 16; ks++) {
       const double a = v_row[ks] * e[4 * ks + kq];
       const v2d b01 = Bl[(ks * 2) * 64 + lane], b23 = Bl[(ks * 2 + 1) * 64 + lane];
       acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b01.x, acc[0], 0, 0, 0);
@@ -491,7 +490,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
     to_lds(acc);
     __syncthreads();
 
-    if (br >= n || GS_MAT_EXP == 4) {
+    if (br >= n) {
       // internal branch: image of P, and of P^T for the pre-order pass; 16-byte coalesced stores
       v2d* __restrict__ out0 = reinterpret_cast<v2d*>(rec);
       v2d* __restrict__ out2 = reinterpret_cast<v2d*>(rec + 8192);
@@ -500,10 +499,8 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
         const int pos = i * 256 + tid;  // = (mb * 8 + ks2) * 64 + 16 kq' + ii'
         const int l = pos & 63, blk = pos >> 6, mb = blk >> 3, ks2 = blk & 7;
         const int row = 16 * mb + (l & 15), col = 8 * ks2 + (l >> 4);
-        const v2d v0{Pl[row * kPld + col], Pl[row * kPld + col + 4]};
-        const v2d v2{Pl[col * kPld + row], Pl[(col + 4) * kPld + row]};
-        if (GS_MAT_EXP != 1 || v0.x == 123.456) out0[pos] = v0;
-        if (want_gradient && (GS_MAT_EXP != 1 || v2.x == 123.456)) out2[pos] = v2;
+        out0[pos] = v2d{Pl[row * kPld + col], Pl[row * kPld + col + 4]};
+        if (want_gradient) out2[pos] = v2d{Pl[col * kPld + row], Pl[(col + 4) * kPld + row]};
       }
       continue;
     }
@@ -518,7 +515,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
         const int st0 = 16 * mm + 4 * r + q, st1 = st0 + 4;
         v2d v{Pl[st0 * kPld + s], Pl[st1 * kPld + s]};
         if (s == S) v = is_p ? v2d{st0 < S ? 1.0 : 0.0, st1 < S ? 1.0 : 0.0} : v2d{0.0, 0.0};
-        if (GS_MAT_EXP != 1 || v.x == 123.456) out[pos] = v;
+        out[pos] = v;
       }
     };
     table(rec, true);
@@ -539,7 +536,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
         const int st0 = 16 * mm + 4 * r + q, st1 = st0 + 4;
         double d0 = 0.0, d1 = 0.0;
         if (s != S) {
-          const int cnt = GS_MAT_EXP == 3 ? 0 : nz_cnt[s];
+          const int cnt = nz_cnt[s];
           const uint8_t* idx = nz_idx + s * kGsQnzMax;
           const double* val = nz_val + s * kGsQnzMax;
           for (int t = 0; t < cnt; t++) {
@@ -549,7 +546,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
             d1 = __builtin_fma(Pl[st1 * kPld + k], qv, d1);
           }
         }
-        if (GS_MAT_EXP != 1 || d0 == 123.456) out[pos] = v2d{d0, d1};
+        out[pos] = v2d{d0, d1};
       }
       continue;
     }

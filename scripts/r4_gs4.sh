@@ -1,3 +1,5 @@
+# (gs_matrices_kernel's ablations: the variants m1..m4 are builds of commit 41077d6 with -DGS_MAT_EXP=1..4 -- the knobs were
+# taken out of gs_kernels.hip again so that the shipped device code is the one the round's last full GPU run checked)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for v in default m1 m2 m3 m4; do
