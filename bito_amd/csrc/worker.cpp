@@ -188,15 +188,12 @@ int ValidateTreeShape(Worker* e, int rooted, int node_count) {
 // and 2 of the trifurcation, a new root joins child 0 with it) the cherries -- internal nodes over two tips, the root
 // excepted -- and, with `fold`, the pitchforks (a tip and a cherry under one node) whose sibling is a tip or a stored
 // node; of two pitchforks under one node the one with the lower id.  The parent-id row has passed the range checks.
-int UnstoredNodes(int n, int M, int rooted, const int32_t* par, bool fold, std::vector<int>* kids_buf, std::vector<int>* parent_buf) {
+int UnstoredNodes(int n, int M, int rooted, const int32_t* par, bool fold, std::vector<int>* kids_buf) {
   const int N = 2 * n - 1, NI = n - 1;
   // (one scratch array: child lists [2 NI], then the parents [N]; written in full below, so no clearing pass)
   std::vector<int>& ch = *kids_buf;
   if ((int)ch.size() < 2 * NI + N + 2) ch.resize((size_t)2 * NI + N + 2);
-  (void)parent_buf;
   int* const up = ch.data() + 2 * NI;
-  int* const fill = up + N;  // children seen so far of the node being filled: kept in the low bits of ch via counts below
-  (void)fill;
   for (int j = 0; j < 2 * NI; j++) ch[j] = -1;
   int third = -1;
   for (int child = 0; child < M - 1; child++) {
@@ -217,10 +214,7 @@ int UnstoredNodes(int n, int M, int rooted, const int32_t* par, bool fold, std::
     up[ch[2 * j]] = n + j;
     up[ch[2 * j + 1]] = n + j;
   }
-  // kind of every internal node in one pass (ids ascend from the tips to the root): 1 cherry, 2 pitchfork, 0 other
   int cherries = 0;
-  int* const kind = up;  // (reused below: a node's parent is looked up before its own kind overwrites nothing it needs)
-  (void)kind;
   auto cherry = [&](int c) { return c >= n && c != N - 1 && ch[2 * (c - n)] < n && ch[2 * (c - n) + 1] < n; };
   if (!fold) {
     for (int c = n; c < N - 1; c++) cherries += cherry(c);
@@ -251,7 +245,7 @@ int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_cou
                        int* fewest_out, int32_t* cherries_of, std::string* msg, int* fewest_unstored_out = nullptr) {
   const int n = e->n, M = node_count;
   std::vector<int> count(M), tip_children(M);
-  std::vector<int> kids, parent_of;  // (the detrifurcated tree, for the pitchfork count)
+  std::vector<int> kids;  // (the detrifurcated tree, for the pitchfork count)
   int fewest = M, fewest_unstored = M;
   // (pitchforks are folded by walk_pipe_kernel alone: up to 64 taxa, four states, 1 / 2 / 4 rate categories)
   const int C = e->spec.category_count;
@@ -305,7 +299,7 @@ int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_cou
     if (PipeSlotsOfTree(probe, fewest) > room) {
       fewest_unstored = M;
       for (int t = t0; t < t1; t++) {
-        const int unstored = UnstoredNodes(n, M, rooted, parent_ids + (size_t)t * (M - 1), true, &kids, &parent_of);
+        const int unstored = UnstoredNodes(n, M, rooted, parent_ids + (size_t)t * (M - 1), true, &kids);
         fewest_unstored = std::min(fewest_unstored, unstored);
         if (cherries_of) cherries_of[t] = unstored;
       }
@@ -732,6 +726,8 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
       break;
     }
   }
+  if (e->kernel_choice == BITO_AMD_KERNEL_LDS_PIPE2 && use_pipe && PipeTwoApplies(d) && (int)e->tree_rev_ok.size() != T)
+    return Fail(e, BITO_AMD_ERR_STATE, "the two-wave form of the pipelined LDS kernel was selected after this batch was uploaded: the reversible-form guard is evaluated tree by tree at upload, so upload the batch again after selecting the form");
   if (e->kernel_choice == BITO_AMD_KERNEL_LDS_PIPE2 && use_pipe && !(split.all_two || (split.active && split.layout_a == kPipePlanTwoWaves)))
     return Fail(e, BITO_AMD_ERR_STATE, "the two-wave form of the pipelined LDS kernel was forced but cannot run this batch (needs up to 28 taxa, 1, 2 or 4 rate categories, no rescaling, and for at least three quarters of the trees: branch lengths that hold the reversible-form guard and stored vectors that fit beside two pattern groups per wave)");
   if (use_pipe && !split.built) {
@@ -1861,9 +1857,23 @@ extern "C" int bito_amd_count_unstored_nodes(int32_t taxon_count, int32_t tree_c
                                              const int32_t* parent_ids, int32_t fold, int32_t* out) {
   if (!parent_ids || !out || taxon_count < 3 || tree_count < 1) return BITO_AMD_ERR_BAD_ARG;
   if (node_count != (rooted ? 2 * taxon_count - 1 : 2 * taxon_count - 2)) return BITO_AMD_ERR_BAD_ARG;
-  std::vector<int> kids, up;
-  for (int t = 0; t < tree_count; t++)
-    out[t] = UnstoredNodes(taxon_count, node_count, rooted, parent_ids + (size_t)t * (node_count - 1), fold != 0, &kids, &up);
+  // the rows come from the caller: the same range and shape checks as every other entry point (ValidateTreesRange)
+  // before UnstoredNodes indexes by them -- parent ids in [n, M) above their child, two children per internal node,
+  // three at an unrooted tree's root
+  const int n = taxon_count, M = node_count;
+  std::vector<int> kids, count(M);
+  for (int t = 0; t < tree_count; t++) {
+    const int32_t* par = parent_ids + (size_t)t * (M - 1);
+    std::fill(count.begin(), count.end(), 0);
+    for (int child = 0; child < M - 1; child++) {
+      const int p = par[child];
+      if (p < n || p >= M || p <= child) return BITO_AMD_ERR_BAD_TREE;
+      count[p]++;
+    }
+    for (int i = n; i < M; i++)
+      if (count[i] != ((!rooted && i == M - 1) ? 3 : 2)) return BITO_AMD_ERR_BAD_TREE;
+    out[t] = UnstoredNodes(n, M, rooted, par, fold != 0, &kids);
+  }
   return BITO_AMD_OK;
 }
 
@@ -1871,6 +1881,9 @@ namespace bito_amd {
 
 int WorkerSetKernel(Worker* e, int32_t kernel) {
   if (!e) return BITO_AMD_ERR_BAD_ARG;
+  // a resident batch's class split (which trees take the two-wave form, which share a launch plan) was decided under the
+  // old choice: the next pass decides again, as it does after an update of the batch's values
+  if (kernel != e->kernel_choice) e->pipe_split = Worker::PipeSplit{};
   e->kernel_choice = kernel;
   return BITO_AMD_OK;
 }

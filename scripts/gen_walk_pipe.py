@@ -1311,11 +1311,18 @@ def main():
     out.append("// " + "\n// ".join(listing))
     out.append("// clang-format on")
     path = os.path.join(root, "bito_amd", "csrc", "walk_pipe_gen.inc")
-    with open(path, "w") as fh:
-        fh.write("\n".join(out) + "\n")
+    args = sys.argv[1:]
+    if "--out" in args:  # (the currency test writes beside the tracked file, not over it: --out <path>)
+        k = args.index("--out")
+        path = args[k + 1]
+        del args[k:k + 2]
+    text = "\n".join(out) + "\n"
+    if not (os.path.exists(path) and open(path).read() == text):  # (an unchanged file keeps its time stamp: no rebuild)
+        with open(path, "w") as fh:
+            fh.write(text)
     print("\n".join(listing))
-    if len(sys.argv) > 1:  # plain listing of one loop for reading: gen_walk_pipe.py pre4 > /tmp/pre4.s
-        want = sys.argv[1]
+    if args:  # plain listing of one loop for reading: gen_walk_pipe.py pre4 > /tmp/pre4.s
+        want = args[0]
         loops = Loops(int(want[-1]))
         e = loops.post_loop() if want.startswith("post") else (loops.pre_loop() if want.startswith("pre") else loops.load_images(True))
         sys.stderr.write("\n".join(e.finish()) + "\n")

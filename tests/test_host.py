@@ -211,21 +211,15 @@ def test_generated_walk_loops_are_current_and_checked(tmp_path):
     """bito_amd/csrc/walk_pipe_gen.inc is generated: the committed file must be what scripts/gen_walk_pipe.py
     emits today, and the compiled kernel must leave the AGPRs that hold a tree's matrix images alone outside its
     own asm statements (the Makefile runs the same check at build time)."""
-    import shutil
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     committed = os.path.join(root, "bito_amd", "csrc", "walk_pipe_gen.inc")
-    before = open(committed).read()
-    keep = tmp_path / "walk_pipe_gen.inc"
-    shutil.copy(committed, keep)
-    try:
-        subprocess.run([sys.executable, os.path.join(root, "scripts", "gen_walk_pipe.py")], check=True,
-                       stdout=subprocess.DEVNULL)
-        assert open(committed).read() == before, "walk_pipe_gen.inc is stale: run scripts/gen_walk_pipe.py"
-    finally:
-        shutil.copy(keep, committed)
+    fresh = tmp_path / "walk_pipe_gen.inc"  # (generated beside the tracked file, which keeps its content and time stamp)
+    subprocess.run([sys.executable, os.path.join(root, "scripts", "gen_walk_pipe.py"), "--out", str(fresh)], check=True,
+                   stdout=subprocess.DEVNULL)
+    assert open(committed).read() == fresh.read_text(), "walk_pipe_gen.inc is stale: run scripts/gen_walk_pipe.py"
     listing = os.path.join(root, "bito_amd", "csrc", "walk_pipe.gfx950.s")
     if os.path.exists(listing):  # (written by the build)
         done = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_walk_pipe_asm.py"), listing],
@@ -379,3 +373,31 @@ def test_unstored_node_count_matches_a_restatement():
                                                out.ctypes.data_as(C.POINTER(C.c_int32))) == 0
         counts.append(26 - out.mean())  # internal nodes - unstored = stored vectors + the root
     assert 17.0 < counts[0] < 18.5 and 13.5 < counts[1] < 15.0, counts
+
+
+def test_unstored_node_count_rejects_rows_that_are_not_trees():
+    """bito_amd_count_unstored_nodes is a public entry point: rows that are not bito topologies (a parent id outside
+    [n, M), a parent below its child, an internal node without exactly two children) come back as BAD_TREE instead of
+    being used as indices."""
+    import ctypes as C
+
+    from test_gpu_parity import _random_rooted_parent_ids
+
+    L = _capi.lib()
+    ip = C.POINTER(C.c_int32)
+    n = 6
+    for rooted in (0, 1):
+        rng = np.random.default_rng(5 + rooted)
+        good = (_random_rooted_parent_ids(n, rng) if rooted else workloads.random_unrooted_tree(n, rng, 0.1).parent_ids)
+        good = np.ascontiguousarray(good, dtype=np.int32)
+        M = good.shape[0] + 1
+        out = np.zeros(1, dtype=np.int32)
+        assert L.bito_amd_count_unstored_nodes(n, 1, rooted, M, good.ctypes.data_as(ip), 1, out.ctypes.data_as(ip)) == 0
+        for child, value in ((0, n - 1), (0, -3), (1, M), (2, 10 ** 6), (n, n), (0, int(good[1]))):
+            bad = good.copy()
+            bad[child] = value
+            if np.array_equal(bad, good):
+                continue
+            rc = L.bito_amd_count_unstored_nodes(n, 1, rooted, M, bad.ctypes.data_as(ip), 1, out.ctypes.data_as(ip))
+            assert rc == _capi.ERR_BAD_TREE, (rooted, child, value, rc)
+        assert L.bito_amd_count_unstored_nodes(n, 1, rooted, M + 1, good.ctypes.data_as(ip), 1, out.ctypes.data_as(ip)) != 0
