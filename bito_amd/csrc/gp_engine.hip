@@ -19,8 +19,22 @@
 #include <vector>
 #include <algorithm>
 
+#include <cstring>
+#include <list>
+#include <memory>
+
 #include "../../include/bito_amd.h"
 #include "../../include/bito_amd_gp.h"
+#include "gp_schedule.hpp"
+
+// a stream the executor has scheduled before (gp_schedule.hpp), found again by content
+struct GpCachedSchedule {
+  uint64_t hash = 0;
+  bool reorder = true;
+  std::vector<bito_amd_gp_op> ops;  // the stream as the caller gave it
+  std::vector<uint64_t> side;
+  bito_amd_gp_schedule::Schedule schedule;
+};
 
 struct bito_amd_gp_engine {
   int device = 0, n = 0, P = 0, Ppad = 0, nodes = 0, gpcsps = 0, plvs = 0;
@@ -36,11 +50,16 @@ struct bito_amd_gp_engine {
   int64_t* d_offsets = nullptr;
   int64_t* d_levels = nullptr;  // level offsets of the levelled segments of the resident stream
   size_t ops_cap = 0, side_cap = 0, offsets_cap = 0, levels_cap = 0, coef_blocks = 1;  // coef holds coef_blocks x [2][Ppad]
+  std::list<std::shared_ptr<GpCachedSchedule>> schedules;  // most recently used first
+  // diagnostics: every function evaluation of the Brent optimisers as rows (edge, x, f, kind), see bito_amd_gp.h
+  double* trace_rows = nullptr;
+  unsigned long long* trace_cursor = nullptr;
+  int64_t trace_capacity = 0;
   std::string err;
   ~bito_amd_gp_engine() {
     (void)hipSetDevice(device);
     for (void* p : {(void*)plv, (void*)weights, (void*)bl, (void*)q, (void*)ll, (void*)marginal, (void*)scratch, (void*)diff, (void*)coef,
-                    (void*)counts, (void*)d_ops, (void*)d_side, (void*)d_offsets, (void*)d_levels})
+                    (void*)counts, (void*)d_ops, (void*)d_side, (void*)d_offsets, (void*)d_levels, (void*)trace_rows, (void*)trace_cursor})
       if (p) (void)hipFree(p);
   }
 };
@@ -286,6 +305,10 @@ gp_derivatives_kernel(const double* __restrict__ plv, const int* __restrict__ co
 // The optimisers restate src/optimization.hpp:71-417; constants from src/dag_branch_handler.hpp:266-295.
 struct OptSettings {
   int method, significant_digits, check_convergence;
+  // diagnostics (bito_amd_gp_set_optimizer_trace): rows of (edge, x, f, kind), appended by thread 0 of the workgroup
+  double* trace_rows;
+  unsigned long long* trace_cursor;
+  long long trace_capacity;
 };
 
 constexpr double kMinLogBl = -13.9, kMaxLogBl = 1.1, kNewtonEps = 1e-10, kStep = 5e-4, kLogStep = 1.0005,
@@ -306,6 +329,11 @@ struct EdgeFunction {
   double* sh;  // [3][kOptWaves] block-reduction scratch in LDS
   double resc;
   int P;
+  // diagnostics: the optimiser's evaluations are recorded when a trace buffer is set
+  double* trace_rows;
+  unsigned long long* trace_cursor;
+  long long trace_capacity;
+  double edge;
 
   // log-likelihood and its first two derivatives in t; every thread of the block gets the values
   __device__ void operator()(double t, double out[3]) const {
@@ -313,7 +341,7 @@ struct EdgeFunction {
     double a0 = 0, a1 = 0, a2 = 0;
     for (int p = threadIdx.x; p < P; p += blockDim.x) {
       const double be = B[p] * e;
-      const double l = A[p] + be, d = kLam * be, dd = kLam * kLam * be;
+      const double l = fma(B[p], e, A[p]), d = kLam * be, dd = kLam * kLam * be;
       const double w = weights[p];
       a0 += w * log(l);
       a1 += w * (d / l);
@@ -333,10 +361,33 @@ struct EdgeFunction {
     out[1] = total[1];
     out[2] = total[2];
   }
-  __device__ double NegLL(double x) const {  // brent_nongrad_func: x is the LOG branch length
-    double o[3];
-    (*this)(exp(x), o);
-    return -o[0];
+  // The log-likelihood alone: what Brent asks for at every trial point (brent_nongrad_func, src/gp_engine.cpp:605-612).
+  // The same per-pattern terms in the same order and the same reduction tree as out[0] above -- the same bits -- without
+  // the two derivative sums (two divisions per pattern, two of the three cross-wave sums).
+  __device__ double Value(double t) const {
+    const double e = exp(kLam * t);
+    double a0 = 0;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) a0 += weights[p] * log(fma(B[p], e, A[p]));
+    __syncthreads();  // the previous evaluation's readers are done with sh
+    for (int o = 32; o > 0; o >>= 1) a0 += __shfl_xor(a0, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a0;
+    __syncthreads();
+    double total = 0;
+    for (int w = 0; w < kOptWaves; w++) total += sh[w];
+    return total + resc;
+  }
+  // brent_nongrad_func: x is the LOG branch length.  kind (trace only): 0 the handler's evaluation of the current
+  // length, 1 Brent's first point, 2 a trial point, 3 the gradient variant's second trial.
+  __device__ double NegLL(double x, int kind) const {
+    const double f = -Value(exp(x));
+    if (trace_rows && threadIdx.x == 0) {
+      const unsigned long long at = atomicAdd(trace_cursor, 1ull);
+      if ((long long)at < trace_capacity) {
+        double* row = trace_rows + 4 * at;
+        row[0] = edge; row[1] = x; row[2] = f; row[3] = (double)kind;
+      }
+    }
+    return f;
   }
 };
 
@@ -347,7 +398,7 @@ __device__ void BrentMinimize(const EdgeFunction& f, bool with_gradients, double
   const double golden = 0.3819660f;
   double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
   w = v = x = guess;
-  fw = fv = fx = f.NegLL(x);
+  fw = fv = fx = f.NegLL(x, 1);
   delta2 = delta = 0;
   int count = max_iter;
   do {
@@ -377,7 +428,7 @@ __device__ void BrentMinimize(const EdgeFunction& f, bool with_gradients, double
       delta = golden * delta2;
     }
     u = (fabs(delta) >= fract1) ? x + delta : (delta > 0 ? x + fabs(fract1) : x - fabs(fract1));
-    fu = f.NegLL(u);
+    fu = f.NegLL(u, 2);
     bool accepted = false;
     if (fu <= fx) {
       if (u >= x) mn = x; else mx = x;
@@ -389,7 +440,7 @@ __device__ void BrentMinimize(const EdgeFunction& f, bool with_gradients, double
       const double t = exp(x);
       f(t, o);
       const double u2 = x - step_size * (-t * o[1]);
-      const double fu2 = f.NegLL(u2);
+      const double fu2 = f.NegLL(u2, 3);
       if (fu2 <= fx) {
         if (u2 >= x) mn = x; else mx = x;
         v = w; w = x; x = u2;
@@ -445,14 +496,14 @@ __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict_
   __syncthreads();
   double resc_total = 0;
   for (int w = 0; w < kOptWaves; w++) resc_total += sh_resc[w];
-  const EdgeFunction f{coef, coef + Ppad, weights, sh, resc_total, P};
+  const EdgeFunction f{coef, coef + Ppad, weights, sh, resc_total, P, cfg.trace_rows, cfg.trace_cursor, cfg.trace_capacity, (double)edge};
   const double current = bl[edge];
   double result = current;
   switch (cfg.method) {
     case 0:
     case 1: {  // BrentOptimization(WithGradients), dag_branch_handler.cpp:150-211
       const double cur_log = log(current);
-      const double cur_nll = f.NegLL(cur_log);
+      const double cur_nll = f.NegLL(cur_log, 0);
       double x, fx;
       BrentMinimize(f, cfg.method == 1, cur_log, kMinLogBl, kMaxLogBl, cfg.significant_digits, kOptMaxIter, kLogStep,
                     &x, &fx);
@@ -511,15 +562,18 @@ __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict_
   }
 }
 
+// One workgroup per optimisation of the launch.  The optimisations of a launch are independent of one another
+// (gp_schedule.hpp: equal optimiser depth, so no PLV or branch length one writes is read or written by another); each has
+// its own coefficient block.
 __global__ void __launch_bounds__(kOptThreads)
-gp_optimize_kernel(const bito_amd_gp_op* __restrict__ ops, int64_t op_count, const double* __restrict__ plv,
+gp_optimize_kernel(const bito_amd_gp_op* __restrict__ ops, const double* __restrict__ plv,
                    const int* __restrict__ counts, const double* __restrict__ weights, double* __restrict__ bl,
                    double* __restrict__ diff, double* __restrict__ coef, int P, int Ppad, double log_threshold,
                    OptSettings cfg) {
   __shared__ double sh[3 * kOptWaves];
   __shared__ double sh_resc[kOptWaves];
-  for (int64_t o = 0; o < op_count; o++)
-    OptimizeEdge(ops[o], plv, counts, weights, bl, diff, coef, sh, sh_resc, P, Ppad, log_threshold, cfg);
+  OptimizeEdge(ops[blockIdx.x], plv, counts, weights, bl, diff, coef + (size_t)blockIdx.x * 2 * Ppad, sh, sh_resc, P, Ppad,
+               log_threshold, cfg);
 }
 
 // A workgroup interprets a whole sub-stream, per-pattern ops and optimiser ops alike: thread t owns the
@@ -567,14 +621,6 @@ int RunSegment(bito_amd_gp_engine* e, int64_t first, int64_t count) {
   hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64), dim3(64), 0, 0, e->d_ops + first, count,
                      (const int64_t*)nullptr, e->d_side, e->plv, e->counts, e->bl, e->q, e->ll, e->marginal, e->P,
                      e->Ppad, e->threshold, e->log_threshold);
-  GP_TRY(e, hipGetLastError());
-  return BITO_AMD_OK;
-}
-
-int RunOptimize(bito_amd_gp_engine* e, int64_t first, int64_t count) {
-  const OptSettings cfg{e->method, e->significant_digits, e->optimization_count != 0};  // !IsFirstOptimization()
-  hipLaunchKernelGGL(gp_optimize_kernel, dim3(1), dim3(kOptThreads), 0, 0, e->d_ops + first, count, e->plv, e->counts,
-                     e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, cfg);
   GP_TRY(e, hipGetLastError());
   return BITO_AMD_OK;
 }
@@ -725,8 +771,8 @@ int bito_amd_gp_log_likelihood_matrix(bito_amd_gp_engine* e, double* out) {
 }
 
 // ids are validated once on the host, then the stream and its side array go to the device
-static int ValidateAndUpload(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count, const uint64_t* side,
-                             int64_t side_count, bool batched, const bito_amd_gp_op* device_image = nullptr) {
+static int ValidateOps(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count, const uint64_t* side,
+                       int64_t side_count, bool batched) {
   const uint64_t plv_limit = (uint64_t)e->plvs + (uint64_t)e->spare_plvs;
   const uint64_t gp_limit = (uint64_t)e->gpcsps + (uint64_t)e->spare_gpcsps;
   for (int64_t o = 0; o < op_count; o++) {
@@ -756,6 +802,12 @@ static int ValidateAndUpload(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, i
                   "GP op " + std::to_string(o) + " has an index out of range" +
                       (batched ? " or is not allowed in a batch of independent sub-streams" : ""));
   }
+  return BITO_AMD_OK;
+}
+
+// the stream (or the scheduled image of it) and its side array go to the device
+static int UploadOps(bito_amd_gp_engine* e, const bito_amd_gp_op* image, int64_t op_count, const uint64_t* side,
+                     int64_t side_count) {
   if (side_count > 0 && side) {
     if ((size_t)side_count > e->side_cap) {
       (void)hipFree(e->d_side);
@@ -771,203 +823,193 @@ static int ValidateAndUpload(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, i
     GP_TRY(e, hipMalloc((void**)&e->d_ops, op_count * sizeof(bito_amd_gp_op)));
     e->ops_cap = op_count;
   }
-  if (op_count > 0)
-    GP_TRY(e, hipMemcpy(e->d_ops, device_image ? device_image : ops, op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
+  if (op_count > 0) GP_TRY(e, hipMemcpy(e->d_ops, image, op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
   return BITO_AMD_OK;
 }
 
-// Dependency levels of a run of per-pattern operations.  An operation reads and writes whole PLVs (with
-// their rescaling counts), log-likelihood rows and the marginal row; its level is one more than the
-// latest earlier operation it must follow (read-after-write, write-after-read, write-after-write), so
-// operations of one level touch disjoint results and chains on one destination keep their order --
-// the arithmetic is the sequential one, bit for bit.  Returns the operations sorted by level (stable)
-// and appends the level boundaries (absolute indices into the stream) to `offsets`.
-constexpr int64_t kLevelMinOps = 48;  // shorter runs stay with the one-thread-per-pattern interpreter
+static int ValidateAndUpload(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count, const uint64_t* side,
+                             int64_t side_count, bool batched) {
+  if (int rc = ValidateOps(e, ops, op_count, side, side_count, batched)) return rc;
+  return UploadOps(e, ops, op_count, side, side_count);
+}
 
-static void LevelSegment(const bito_amd_gp_op* ops, int64_t first, int64_t count, const uint64_t* side,
-                         bito_amd_gp_op* sorted, std::vector<int64_t>* offsets) {
-  struct Use { int write = -1, read = -1; };
-  std::unordered_map<uint64_t, Use> use;  // key: resource kind in the top bits
-  auto plv = [](uint64_t id) { return id; };
-  auto row = [](uint64_t id) { return id | (1ull << 62); };
-  const uint64_t marginal = 1ull << 63;
-  std::vector<int> level(count);
-  int deepest = -1;
-  for (int64_t k = 0; k < count; k++) {
-    const bito_amd_gp_op& op = ops[first + k];
-    uint64_t reads[2 + 64], writes[2];
-    int nr = 0, nw = 0;
-    std::vector<uint64_t> many;  // PrepForMarginalization with more than 64 sources
-    switch (op.opcode) {
-      case BITO_AMD_GP_ZERO_PLV:
-      case BITO_AMD_GP_SET_TO_STATIONARY_DISTRIBUTION: writes[nw++] = plv(op.a); break;
-      case BITO_AMD_GP_INCREMENT_WITH_WEIGHTED_EVOLVED_PLV:
-        writes[nw++] = plv(op.a); reads[nr++] = plv(op.a); reads[nr++] = plv(op.c); break;
-      case BITO_AMD_GP_MULTIPLY: writes[nw++] = plv(op.a); reads[nr++] = plv(op.b); reads[nr++] = plv(op.c); break;
-      case BITO_AMD_GP_LIKELIHOOD: writes[nw++] = row(op.a); reads[nr++] = plv(op.b); reads[nr++] = plv(op.c); break;
-      case BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD: writes[nw++] = marginal; break;
-      case BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD:
-        writes[nw++] = marginal; writes[nw++] = row(op.b);
-        reads[nr++] = marginal; reads[nr++] = plv(op.a); reads[nr++] = plv(op.c); break;
-      case BITO_AMD_GP_PREP_FOR_MARGINALIZATION:
-        writes[nw++] = plv(op.a); reads[nr++] = plv(op.a);
-        for (uint32_t j = 0; j < op.count; j++) {
-          if (nr < 66) reads[nr++] = plv(side[op.b + j]);
-          else many.push_back(plv(side[op.b + j]));
-        }
-        break;
-      default: break;
-    }
-    int lv = 0;
-    auto after_write = [&](uint64_t r) { auto it = use.find(r); if (it != use.end()) lv = std::max(lv, it->second.write + 1); };
-    auto after_any = [&](uint64_t r) {
-      auto it = use.find(r);
-      if (it != use.end()) lv = std::max(lv, std::max(it->second.write, it->second.read) + 1);
-    };
-    for (int j = 0; j < nr; j++) after_write(reads[j]);
-    for (uint64_t r : many) after_write(r);
-    for (int j = 0; j < nw; j++) after_any(writes[j]);
-    for (int j = 0; j < nr; j++) { Use& u = use[reads[j]]; u.read = std::max(u.read, lv); }
-    for (uint64_t r : many) { Use& u = use[r]; u.read = std::max(u.read, lv); }
-    for (int j = 0; j < nw; j++) use[writes[j]].write = lv;
-    level[k] = lv;
-    deepest = std::max(deepest, lv);
+// Runs of per-pattern operations shorter than this stay with the one-thread-per-pattern interpreter (gp_ops_kernel walks
+// them in image order, which respects their levels); longer ones go level by level through gp_levels_kernel.
+constexpr int64_t kLevelMinOps = 48;
+
+static OptSettings Settings(const bito_amd_gp_engine* e) {
+  return OptSettings{e->method, e->significant_digits, e->optimization_count != 0,  // !IsFirstOptimization()
+                     e->trace_rows, e->trace_cursor, (long long)e->trace_capacity};
+}
+
+static uint64_t HashStream(const bito_amd_gp_op* ops, int64_t op_count, const uint64_t* side, int64_t side_count, bool reorder) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)op_count ^ ((uint64_t)side_count << 32) ^ (reorder ? 1 : 0);
+  auto mix = [&](uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xff51afd7ed558ccdull;
+  };
+  for (int64_t o = 0; o < op_count; o++) {
+    mix(((uint64_t)ops[o].opcode << 32) | ops[o].count);
+    mix(ops[o].a);
+    mix(ops[o].b);
+    mix(ops[o].c);
   }
-  std::vector<int64_t> start(deepest + 2, 0);
-  for (int64_t k = 0; k < count; k++) start[level[k] + 1]++;
-  for (int l = 0; l <= deepest; l++) start[l + 1] += start[l];
-  for (int l = 0; l <= deepest + 1; l++) offsets->push_back(first + start[l]);
-  std::vector<int64_t> cursor(start.begin(), start.end() - 1);
-  for (int64_t k = 0; k < count; k++) sorted[first + cursor[level[k]]++] = ops[first + k];
+  for (int64_t k = 0; k < side_count; k++) mix(side[k]);
+  return h;
+}
+
+// The schedule of a stream (gp_schedule.hpp), kept by content: a sweep's schedule is replayed many times
+// (GPInstance::EstimateBranchLengths alternates the same three streams until convergence, src/gp_instance.cpp:241-308).
+static std::shared_ptr<GpCachedSchedule> ScheduleOf(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count,
+                                                    const uint64_t* side, int64_t side_count, bool reorder) {
+  const uint64_t h = HashStream(ops, op_count, side, side_count, reorder);
+  for (auto it = e->schedules.begin(); it != e->schedules.end(); ++it) {
+    const GpCachedSchedule& c = **it;
+    if (c.hash == h && c.reorder == reorder && (int64_t)c.ops.size() == op_count && (int64_t)c.side.size() == side_count &&
+        (op_count == 0 || std::memcmp(c.ops.data(), ops, (size_t)op_count * sizeof(bito_amd_gp_op)) == 0) &&
+        (side_count == 0 || std::memcmp(c.side.data(), side, (size_t)side_count * sizeof(uint64_t)) == 0)) {
+      std::shared_ptr<GpCachedSchedule> hit = *it;
+      e->schedules.erase(it);
+      e->schedules.push_front(hit);
+      return hit;
+    }
+  }
+  auto fresh = std::make_shared<GpCachedSchedule>();
+  fresh->hash = h;
+  fresh->reorder = reorder;
+  fresh->ops.assign(ops, ops + op_count);
+  if (side_count > 0) fresh->side.assign(side, side + side_count);
+  bito_amd_gp_schedule::ScheduleStream(ops, op_count, side, reorder, &fresh->schedule);
+  e->schedules.push_front(fresh);
+  if (e->schedules.size() > 16) e->schedules.pop_back();
+  return fresh;
+}
+
+int bito_amd_gp_schedule_operations(const bito_amd_gp_op* ops, int64_t op_count, const uint64_t* side, int64_t side_count,
+                                    int32_t reorder, bito_amd_gp_op* out_ops, int32_t* out_launch, int32_t* out_level,
+                                    int32_t* out_launch_kinds, int64_t* out_launch_count) {
+  if (op_count < 0 || (op_count > 0 && (!ops || !out_ops)) || !out_launch_count) return BITO_AMD_ERR_BAD_ARG;
+  for (int64_t o = 0; o < op_count; o++)
+    if (ops[o].opcode == BITO_AMD_GP_PREP_FOR_MARGINALIZATION && (!side || ops[o].b + ops[o].count > (uint64_t)side_count))
+      return BITO_AMD_ERR_BAD_ARG;
+  bito_amd_gp_schedule::Schedule S;
+  bito_amd_gp_schedule::ScheduleStream(ops, op_count, side, reorder != 0, &S);
+  if ((int64_t)S.image.size() != op_count) return BITO_AMD_ERR_STATE;
+  for (int64_t o = 0; o < op_count; o++) {
+    out_ops[o] = S.image[o];
+    if (out_launch) out_launch[o] = S.launch_of[o];
+    if (out_level) out_level[o] = S.level_of[o];
+  }
+  if (out_launch_kinds)
+    for (size_t k = 0; k < S.launches.size(); k++) out_launch_kinds[k] = S.launches[k].kind;
+  *out_launch_count = (int64_t)S.launches.size();
+  return BITO_AMD_OK;
 }
 
 int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t op_count,
                                    const uint64_t* side, int64_t side_count) {
   if (!e || (op_count > 0 && !ops)) return BITO_AMD_ERR_BAD_ARG;
   GP_TRY(e, hipSetDevice(e->device));
-  if (int rc = ValidateAndUpload(e, ops, op_count, side, side_count, false)) return rc;
-  // Long runs of per-pattern operations are sorted into dependency levels and walked by gp_levels_kernel;
-  // the device image of the stream holds them in that order.
-  std::vector<bito_amd_gp_op> image;
-  std::vector<int64_t> level_offsets;                            // all levelled segments, back to back
-  std::unordered_map<int64_t, std::pair<int64_t, int>> levelled;  // segment start -> (first offset, level count)
-  {
-    int64_t seg = 0;
-    for (int64_t o = 0; o <= op_count; o++) {
-      const bool boundary = o == op_count || ops[o].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH ||
-                            ops[o].opcode == BITO_AMD_GP_UPDATE_SBN_PROBABILITIES;
-      if (!boundary) continue;
-      if (o - seg >= kLevelMinOps) {
-        if (image.empty()) image.assign(ops, ops + op_count);
-        const int64_t at = (int64_t)level_offsets.size();
-        LevelSegment(ops, seg, o - seg, side, image.data(), &level_offsets);
-        levelled[seg] = {at, (int)(level_offsets.size() - at - 1)};
-      }
-      seg = o + 1;
-    }
-  }
-  if (!levelled.empty()) {
-    GP_TRY(e, hipMemcpy(e->d_ops, image.data(), op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
-    if (level_offsets.size() > e->levels_cap) {
+  // The stream is executed in the order gp_schedule.hpp gives it: per-pattern operations sorted into dependency levels,
+  // the optimisations of equal optimiser depth as concurrent workgroups of one launch -- the sequential arithmetic,
+  // bit for bit (tests/test_gp.py holds the two orders to the same bits).  BITO_AMD_GP_SCHEDULE=0: the optimisations one
+  // launch each in stream order (read per call: the tests compare both routes).
+  const char* env = std::getenv("BITO_AMD_GP_SCHEDULE");
+  const bool reorder = !(env != nullptr && env[0] == '0');
+  // (ids are validated on the stream as given, before anything is indexed by them)
+  if (int rc = ValidateOps(e, ops, op_count, side, side_count, false)) return rc;
+  const std::shared_ptr<GpCachedSchedule> cached = ScheduleOf(e, ops, op_count, side, side && side_count > 0 ? side_count : 0, reorder);
+  const bito_amd_gp_schedule::Schedule& S = cached->schedule;
+  if (int rc = UploadOps(e, S.image.data(), op_count, side, side_count)) return rc;
+  if (!S.level_offsets.empty()) {
+    if (S.level_offsets.size() > e->levels_cap) {
       if (e->d_levels) (void)hipFree(e->d_levels);
       e->levels_cap = 0;
-      GP_TRY(e, hipMalloc((void**)&e->d_levels, level_offsets.size() * sizeof(int64_t)));
-      e->levels_cap = level_offsets.size();
+      GP_TRY(e, hipMalloc((void**)&e->d_levels, S.level_offsets.size() * sizeof(int64_t)));
+      e->levels_cap = S.level_offsets.size();
     }
-    GP_TRY(e, hipMemcpy(e->d_levels, level_offsets.data(), level_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    GP_TRY(e, hipMemcpy(e->d_levels, S.level_offsets.data(), S.level_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   }
-  auto run_segment = [&](int64_t first, int64_t count) -> int {
-    auto it = levelled.find(first);
-    if (it == levelled.end()) return RunSegment(e, first, count);
-    hipLaunchKernelGGL(gp_levels_kernel, dim3((e->P + 63) / 64), dim3(64, kLevelWaves), 0, 0, e->d_ops,
-                       (const int64_t*)(e->d_levels + it->second.first), it->second.second, e->d_side, e->plv,
-                       e->counts, e->bl, e->q, e->ll, e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
-    GP_TRY(e, hipGetLastError());
-    return BITO_AMD_OK;
-  };
-  // A branch-length optimisation sweep (GPDAG::BranchLengthOptimization, reference src/gp_dag.cpp:78-121) alternates
-  // one OptimizeBranchLength with the handful of per-pattern operations that refresh the PLVs around the edge: launched
-  // piece by piece that is two launches per edge (DS1 ten-tree DAG: 236 launches, 21 us each, for 118 edges).  A stretch
-  // with three optimisations and more goes to ONE workgroup that interprets all of it (gp_block_stream_kernel: the
-  // workgroup the optimiser needs anyway; thread t keeps patterns t, t + 256, ... through every operation, so nothing
-  // but the optimiser's own reductions synchronises) -- same arithmetic in the same order, bit for bit.  MEASURED
-  // SLOWER, so it stays behind BITO_AMD_GP_FUSED_SWEEP=1: 5.84 against 4.98 ms per sweep on that DAG (47.5 against 40.4 on the
-  // 970-edge DAG) -- the per-pattern operations between two optimisations, spread over fifteen workgroups by their own
-  // launch, cost one workgroup more than the two launches cost; the sweep is bound by the optimiser's chain of function
-  // evaluations either way (tests/test_gp.py holds the two routes to the same bits).
-  const char* fused_env = std::getenv("BITO_AMD_GP_FUSED_SWEEP");  // (read per call: the tests compare both routes)
-  const bool fused_sweep = fused_env != nullptr && std::atoi(fused_env) != 0;
-  int64_t start = 0;
-  for (int64_t o = 0; o <= op_count; o++) {
-    const bool is_opt = o < op_count && ops[o].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH;
-    const bool boundary = o == op_count || is_opt || ops[o].opcode == BITO_AMD_GP_UPDATE_SBN_PROBABILITIES;
-    if (!boundary) continue;
-    if (is_opt && fused_sweep) {
-      int64_t end = o, optimisations = 0;
-      while (end < op_count && ops[end].opcode != BITO_AMD_GP_UPDATE_SBN_PROBABILITIES)
-        optimisations += ops[end++].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH;
-      if (optimisations >= 3) {
-        // (a long run of per-pattern operations in front of the first optimisation keeps its levelled launch)
-        int64_t from = start;
-        if (o - start >= kLevelMinOps) {
-          if (int rc = run_segment(start, o - start)) return rc;
-          from = o;
+  if ((size_t)S.max_concurrent_optimisers > e->coef_blocks) {
+    (void)hipFree(e->coef);
+    e->coef = nullptr;
+    e->coef_blocks = 0;
+    GP_TRY(e, hipMalloc((void**)&e->coef, (size_t)S.max_concurrent_optimisers * 2 * e->Ppad * sizeof(double)));
+    e->coef_blocks = (size_t)S.max_concurrent_optimisers;
+  }
+  for (const bito_amd_gp_schedule::Launch& L : S.launches) {
+    switch (L.kind) {
+      case bito_amd_gp_schedule::kPatternOps:
+        if (L.count >= kLevelMinOps && L.level_count > 1) {
+          hipLaunchKernelGGL(gp_levels_kernel, dim3((e->P + 63) / 64), dim3(64, kLevelWaves), 0, 0, e->d_ops,
+                             (const int64_t*)(e->d_levels + L.level_first), L.level_count, e->d_side, e->plv, e->counts,
+                             e->bl, e->q, e->ll, e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
+          GP_TRY(e, hipGetLastError());
+        } else if (int rc = RunSegment(e, L.first, L.count)) {
+          return rc;
         }
-        if (e->offsets_cap < 2) {
-          if (e->d_offsets) (void)hipFree(e->d_offsets);
-          e->offsets_cap = 0;
-          GP_TRY(e, hipMalloc((void**)&e->d_offsets, 2 * sizeof(int64_t)));
-          e->offsets_cap = 2;
-        }
-        const int64_t range[2] = {from, end};
-        GP_TRY(e, hipMemcpy(e->d_offsets, range, sizeof(range), hipMemcpyHostToDevice));
-        const OptSettings cfg{e->method, e->significant_digits, e->optimization_count != 0};
-        hipLaunchKernelGGL(gp_block_stream_kernel, dim3(1), dim3(kOptThreads), 0, 0, e->d_ops, (const int64_t*)e->d_offsets, e->d_side,
-                           e->plv, e->counts, e->weights, e->bl, e->q, e->ll, e->marginal, e->diff, e->coef, e->P, e->Ppad,
-                           e->threshold, e->log_threshold, cfg);
+        break;
+      case bito_amd_gp_schedule::kOptimisers:
+        // DAGBranchHandler::OptimizeBranchLength for every edge of the launch, a workgroup each
+        hipLaunchKernelGGL(gp_optimize_kernel, dim3((unsigned)L.count), dim3(kOptThreads), 0, 0, e->d_ops + L.first, e->plv,
+                           e->counts, e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, Settings(e));
         GP_TRY(e, hipGetLastError());
-        start = end;
-        o = end - 1;
-        continue;
-      }
-    }
-    int rc = run_segment(start, o - start);
-    if (rc) return rc;
-    if (is_opt) {
-      int64_t end = o;
-      while (end < op_count && ops[end].opcode == BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH) end++;
-      if ((rc = RunOptimize(e, o, end - o))) return rc;
-      start = end;
-      o = end - 1;
-      continue;
-    }
-    if (o < op_count) {
-      // UpdateSBNProbabilities (src/gp_engine.cpp:297-321): softmax over sibling GPCSPs of the
-      // weighted per-GPCSP log-likelihood plus the log prior.
-      const uint64_t a = ops[o].a, b = ops[o].b;
-      const int len = (int)(b - a);
-      std::vector<double> qv(e->gpcsps);
-      GP_TRY(e, hipMemcpy(qv.data(), e->q, e->gpcsps * sizeof(double), hipMemcpyDeviceToHost));
-      if (len == 1) {
-        qv[a] = 1.0;
-      } else {
-        std::vector<double> per(e->gpcsps);
-        rc = bito_amd_gp_per_gpcsp_log_likelihoods(e, per.data());
-        if (rc) return rc;
-        double norm = -INFINITY;
-        std::vector<double> lu(len);
-        for (int k = 0; k < len; k++) {
-          lu[k] = per[a + k] + std::log(qv[a + k]);
-          const double x = std::max(norm, lu[k]), y = std::min(norm, lu[k]);
-          norm = (x == -INFINITY || y - x < -36.04365338911715) ? x : x + std::log(1.0 + std::exp(y - x));
+        break;
+      default: {
+        // UpdateSBNProbabilities (src/gp_engine.cpp:297-321): softmax over sibling GPCSPs of the
+        // weighted per-GPCSP log-likelihood plus the log prior.
+        const uint64_t a = S.image[L.first].a, b = S.image[L.first].b;
+        const int len = (int)(b - a);
+        std::vector<double> qv(e->gpcsps);
+        GP_TRY(e, hipMemcpy(qv.data(), e->q, e->gpcsps * sizeof(double), hipMemcpyDeviceToHost));
+        if (len == 1) {
+          qv[a] = 1.0;
+        } else {
+          std::vector<double> per(e->gpcsps);
+          if (int rc = bito_amd_gp_per_gpcsp_log_likelihoods(e, per.data())) return rc;
+          double norm = -INFINITY;
+          std::vector<double> lu(len);
+          for (int k = 0; k < len; k++) {
+            lu[k] = per[a + k] + std::log(qv[a + k]);
+            const double x = std::max(norm, lu[k]), y = std::min(norm, lu[k]);
+            norm = (x == -INFINITY || y - x < -36.04365338911715) ? x : x + std::log(1.0 + std::exp(y - x));
+          }
+          for (int k = 0; k < len; k++) qv[a + k] = std::exp(lu[k] - norm);
         }
-        for (int k = 0; k < len; k++) qv[a + k] = std::exp(lu[k] - norm);
+        GP_TRY(e, hipMemcpy(e->q, qv.data(), e->gpcsps * sizeof(double), hipMemcpyHostToDevice));
+        break;
       }
-      GP_TRY(e, hipMemcpy(e->q, qv.data(), e->gpcsps * sizeof(double), hipMemcpyHostToDevice));
     }
-    start = o + 1;
   }
   GP_TRY(e, hipDeviceSynchronize());
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_set_optimizer_trace(bito_amd_gp_engine* e, int64_t capacity_rows) {
+  if (!e || capacity_rows < 0) return BITO_AMD_ERR_BAD_ARG;
+  GP_TRY(e, hipSetDevice(e->device));
+  GP_TRY(e, hipDeviceSynchronize());
+  if (e->trace_rows) (void)hipFree(e->trace_rows);
+  e->trace_rows = nullptr;
+  e->trace_capacity = 0;
+  if (capacity_rows == 0) return BITO_AMD_OK;
+  if (!e->trace_cursor) GP_TRY(e, hipMalloc((void**)&e->trace_cursor, sizeof(unsigned long long)));
+  GP_TRY(e, hipMemset(e->trace_cursor, 0, sizeof(unsigned long long)));
+  GP_TRY(e, hipMalloc((void**)&e->trace_rows, (size_t)capacity_rows * 4 * sizeof(double)));
+  GP_TRY(e, hipMemset(e->trace_rows, 0, (size_t)capacity_rows * 4 * sizeof(double)));
+  e->trace_capacity = capacity_rows;
+  return BITO_AMD_OK;
+}
+
+int bito_amd_gp_get_optimizer_trace(bito_amd_gp_engine* e, double* rows, int64_t capacity_rows, int64_t* row_count) {
+  if (!e || !row_count || capacity_rows < 0 || (capacity_rows > 0 && !rows)) return BITO_AMD_ERR_BAD_ARG;
+  if (!e->trace_rows) return Fail(e, BITO_AMD_ERR_STATE, "no optimiser trace is being recorded");
+  GP_TRY(e, hipSetDevice(e->device));
+  unsigned long long made = 0;
+  GP_TRY(e, hipMemcpy(&made, e->trace_cursor, sizeof(made), hipMemcpyDeviceToHost));
+  *row_count = (int64_t)made;
+  const int64_t have = std::min<int64_t>(std::min<int64_t>((int64_t)made, e->trace_capacity), capacity_rows);
+  if (have > 0) GP_TRY(e, hipMemcpy(rows, e->trace_rows, (size_t)have * 4 * sizeof(double), hipMemcpyDeviceToHost));
   return BITO_AMD_OK;
 }
 
@@ -1005,7 +1047,7 @@ int bito_amd_gp_process_operation_batches(bito_amd_gp_engine* e, const bito_amd_
       GP_TRY(e, hipMalloc((void**)&e->coef, (size_t)batch_count * 2 * e->Ppad * sizeof(double)));
       e->coef_blocks = batch_count;
     }
-    const OptSettings cfg{e->method, e->significant_digits, e->optimization_count != 0};
+    const OptSettings cfg = Settings(e);
     hipLaunchKernelGGL(gp_block_stream_kernel, dim3((unsigned)batch_count), dim3(kOptThreads), 0, 0, e->d_ops,
                        (const int64_t*)e->d_offsets, e->d_side, e->plv, e->counts, e->weights, e->bl, e->q, e->ll,
                        e->marginal, e->diff, e->coef, e->P, e->Ppad, e->threshold, e->log_threshold, cfg);

@@ -236,6 +236,7 @@ GP_SYMBOLS = [
     "bito_amd_gp_grow_spare", "bito_amd_gp_copy_gpcsp_data", "bito_amd_gp_process_operation_batches",
     "bito_amd_gp_per_gpcsp_log_likelihoods_range", "bito_amd_gp_branch_lengths_range",
     "bito_amd_gp_grow", "bito_amd_gp_get_plv", "bito_amd_gp_rescaling_counts", "bito_amd_gp_get_plv_as_reference",
+    "bito_amd_gp_schedule_operations", "bito_amd_gp_set_optimizer_trace", "bito_amd_gp_get_optimizer_trace",
 ]
 
 
@@ -269,8 +270,36 @@ def _lib():
         L.bito_amd_gp_get_plv.argtypes = [vp, C.c_int64, dp]
         L.bito_amd_gp_rescaling_counts.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
         L.bito_amd_gp_get_plv_as_reference.argtypes = [vp, C.c_int64, dp, C.POINTER(C.c_int32)]
+        i32p = C.POINTER(C.c_int32)
+        L.bito_amd_gp_schedule_operations.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                                      i32p, i32p, i32p, ip]
+        L.bito_amd_gp_set_optimizer_trace.argtypes = [vp, C.c_int64]
+        L.bito_amd_gp_get_optimizer_trace.argtypes = [vp, dp, C.c_int64, ip]
         L._gp_ready = True
     return L
+
+
+def schedule_operations(stream: OpStream, reorder: bool = True):
+    """The order in which the executor runs ``stream`` (bito_amd_gp_schedule_operations: host arithmetic only, no GPU):
+    returns (scheduled OpStream, launch index per op, level per op, launch kinds) -- kinds 0 per-pattern operations,
+    1 concurrent optimisations, 2 UpdateSBNProbabilities."""
+    ops, side = stream.arrays()
+    n = len(ops)
+    out = np.zeros(n, dtype=OP_DTYPE)
+    launch = np.zeros(max(n, 1), dtype=np.int32)
+    level = np.zeros(max(n, 1), dtype=np.int32)
+    kinds = np.zeros(max(n, 1), dtype=np.int32)
+    count = C.c_int64(0)
+    i32p = C.POINTER(C.c_int32)
+    rc = _lib().bito_amd_gp_schedule_operations(ops.ctypes.data, n, side.ctypes.data, len(side), 1 if reorder else 0,
+                                                out.ctypes.data, launch.ctypes.data_as(i32p), level.ctypes.data_as(i32p),
+                                                kinds.ctypes.data_as(i32p), C.byref(count))
+    if rc:
+        raise BitoAmdError(rc, "bito_amd_gp_schedule_operations rejected the stream")
+    scheduled = OpStream()
+    scheduled.ops = [tuple(int(v) for v in row) for row in out.tolist()]
+    scheduled.side = list(stream.side)
+    return scheduled, launch[:n].copy(), level[:n].copy(), kinds[:count.value].copy()
 
 
 class GPEngine:
@@ -339,6 +368,23 @@ class GPEngine:
     def process_operations(self, stream: OpStream):
         ops, side = stream.arrays()
         self._check(_lib().bito_amd_gp_process_operations(self._h, ops.ctypes.data, len(ops), side.ctypes.data, len(side)))
+
+    # -- diagnostics: the Brent optimisers' function evaluations as rows (gpcsp, x, f, kind) --
+    def start_optimizer_trace(self, capacity: int = 1 << 16):
+        self._trace_capacity = int(capacity)
+        self._check(_lib().bito_amd_gp_set_optimizer_trace(self._h, self._trace_capacity))
+
+    def optimizer_trace(self) -> np.ndarray:
+        rows = np.zeros((self._trace_capacity, 4))
+        made = C.c_int64(0)
+        self._check(_lib().bito_amd_gp_get_optimizer_trace(self._h, rows.ctypes.data_as(C.POINTER(C.c_double)),
+                                                           self._trace_capacity, C.byref(made)))
+        if made.value > self._trace_capacity:
+            raise BitoAmdError(_capi.ERR_STATE, f"optimiser trace overflow: {made.value} rows, capacity {self._trace_capacity}")
+        return rows[:made.value].copy()
+
+    def stop_optimizer_trace(self):
+        self._check(_lib().bito_amd_gp_set_optimizer_trace(self._h, 0))
 
     # -- spare slots and side-by-side sub-streams (NNI proposals; src/gp_engine.cpp:196-211,401-409) --
     def grow_spare(self, spare_plv_count: int, spare_gpcsp_count: int):

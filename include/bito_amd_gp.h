@@ -76,9 +76,34 @@ int bito_amd_gp_increment_optimization_count(bito_amd_gp_engine *e);
  * interprets the stream); an UpdateSBNProbabilities op ends the run.  OptimizeBranchLength
  * (GPEngine::OptimizeBranchLength, src/gp_engine.cpp:663-666 -> DAGBranchHandler::OptimizeBranchLength,
  * src/dag_branch_handler.cpp:123-300) runs the whole one-dimensional optimisation of the edge in one
- * single-workgroup launch: no host round trip per function evaluation. */
+ * single-workgroup launch: no host round trip per function evaluation.  The stream is executed in the order
+ * bito_amd_gp_schedule_operations describes. */
 int bito_amd_gp_process_operations(bito_amd_gp_engine *e, const bito_amd_gp_op *ops, int64_t op_count,
                                    const uint64_t *side, int64_t side_count);
+
+/* The order in which bito_amd_gp_process_operations executes a stream (host arithmetic only: no device is touched, so
+ * the order can be checked on a machine without a GPU -- tests replay it through the CPU checker).  The reference runs
+ * the operations one after the other (src/gp_engine.cpp:213-339); here a stream is placed by the dependency graph of
+ * its read and write sets: per-pattern operations in dependency levels, the OptimizeBranchLength operations of equal
+ * "optimiser depth" (longest chain of optimisations among an operation's predecessors) as ONE launch of concurrent
+ * workgroups -- the sequential arithmetic, bit for bit.  reorder = 0: optimisations one launch each, in stream order.
+ * out_ops[op_count]: the stream in execution order; out_launch / out_level [op_count] (may be NULL): the launch an
+ * operation belongs to and, in a per-pattern launch, its level (operations of one launch and level are independent);
+ * out_launch_kinds [>= launch count <= op_count] (may be NULL): 0 per-pattern operations, 1 concurrent optimisations,
+ * 2 UpdateSBNProbabilities. */
+int bito_amd_gp_schedule_operations(const bito_amd_gp_op *ops, int64_t op_count, const uint64_t *side,
+                                    int64_t side_count, int32_t reorder, bito_amd_gp_op *out_ops, int32_t *out_launch,
+                                    int32_t *out_level, int32_t *out_launch_kinds, int64_t *out_launch_count);
+
+/* Diagnostics: a record of every function evaluation the Brent optimisers make (Optimization::BrentMinimize(WithGradients),
+ * src/optimization.hpp:71-331, called from DAGBranchHandler::BrentOptimization, src/dag_branch_handler.cpp:150-211).
+ * _set_optimizer_trace(capacity_rows) starts (capacity_rows > 0: the buffer is cleared) or stops (0) recording;
+ * _get_optimizer_trace copies out up to capacity_rows rows of 4 doubles -- (gpcsp, x = log branch length, f = negative
+ * log-likelihood, kind: 0 the handler's evaluation of the current length, 1 Brent's first point, 2 a trial point, 3 the
+ * gradient variant's second trial) -- and the number of evaluations made (which may exceed the capacity).  Rows of
+ * edges optimised concurrently interleave; the rows of one edge are in order. */
+int bito_amd_gp_set_optimizer_trace(bito_amd_gp_engine *e, int64_t capacity_rows);
+int bito_amd_gp_get_optimizer_trace(bito_amd_gp_engine *e, double *rows, int64_t capacity_rows, int64_t *row_count);
 
 /* Spare slots behind the DAG's own ids -- GPEngine::GrowSparePLVs / GrowSpareGPCSPs
  * (src/gp_engine.hpp:56-57, src/gp_engine.cpp:196-211): after the call PLV ids

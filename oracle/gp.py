@@ -42,6 +42,10 @@ def lib():
         L.gp_oracle_grow.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.gp_oracle_get_plv.argtypes = [vp, C.c_int, dp]
         L.gp_oracle_rescaling_counts.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.gp_oracle_set_trace.argtypes = [vp, dp, C.c_int]
+        L.gp_oracle_trace_rows.restype = C.c_int
+        L.gp_oracle_trace_rows.argtypes = [vp]
+        L.gp_oracle_set_eval_noise.argtypes = [vp, C.c_double, C.c_uint64]
         _lib = L
     return _lib
 
@@ -86,6 +90,21 @@ class OracleGPEngine:
 
     def increment_optimization_count(self):
         lib().gp_oracle_increment_optimization_count(self._h)
+
+    # test instruments: every function evaluation of the Brent optimiser as rows (edge, x, f, kind), and a relative
+    # perturbation of the evaluations' values (what rounding noise of that size does to the iterates)
+    def start_optimizer_trace(self, capacity=1 << 16):
+        self._trace = np.zeros((capacity, 4))
+        lib().gp_oracle_set_trace(self._h, self._trace.ctypes.data_as(C.POINTER(C.c_double)), capacity)
+
+    def optimizer_trace(self):
+        rows = lib().gp_oracle_trace_rows(self._h)
+        if rows > len(self._trace):
+            raise RuntimeError(f"optimiser trace overflow: {rows} rows, capacity {len(self._trace)}")
+        return self._trace[:rows].copy()
+
+    def set_eval_noise(self, relative, seed=1):
+        lib().gp_oracle_set_eval_noise(self._h, float(relative), int(seed))
 
     def set_sbn_parameters(self, q):
         q = np.ascontiguousarray(q, dtype=np.float64)

@@ -54,6 +54,14 @@ typedef struct {
   int method;        /* OptimizationMethod, src/optimization.hpp:28-34 */
   int opt_count;     /* optimization_count_ */
   int significant_digits;
+  /* test instruments (not part of the reference): a record of every function evaluation the Brent optimiser makes --
+   * rows of (edge, x = log branch length, f = negative log-likelihood, kind: 0 the handler's own evaluation of the
+   * current length, 1 Brent's first point, 2 a trial point u, 3 the gradient variant's second trial) -- and a relative
+   * perturbation of every evaluation's value, to measure what rounding noise of a given size does to the iterates */
+  double *trace;
+  int trace_capacity, trace_rows;
+  double noise;
+  uint64_t noise_state;
 } gp_oracle;
 
 enum { OPT_BRENT = 0, OPT_BRENT_WITH_GRADIENTS = 1, OPT_GRADIENT_ASCENT = 2, OPT_LOGSPACE_GRADIENT_ASCENT = 3,
@@ -408,11 +416,40 @@ static void eval_at(const opt_ctx *c, double t, double out[3]) {
   c->g->bl[c->edge] = keep;
 }
 
+void gp_oracle_set_trace(gp_oracle *g, double *rows, int capacity) {
+  g->trace = rows;
+  g->trace_capacity = rows ? capacity : 0;
+  g->trace_rows = 0;
+}
+int gp_oracle_trace_rows(const gp_oracle *g) { return g->trace_rows; }
+void gp_oracle_set_eval_noise(gp_oracle *g, double relative, uint64_t seed) {
+  g->noise = relative;
+  g->noise_state = seed * 0x9E3779B97F4A7C15ull + 1;
+}
+static void trace_row(const opt_ctx *c, double x, double f, int kind) {
+  gp_oracle *g = c->g;
+  if (g->trace && g->trace_rows < g->trace_capacity) {
+    double *row = g->trace + 4 * (size_t)g->trace_rows;
+    row[0] = c->edge; row[1] = x; row[2] = f; row[3] = kind;
+  }
+  if (g->trace) g->trace_rows++;
+}
+
 /* brent_nongrad_func / brent_grad_func (src/gp_engine.cpp:605-625): x is the LOG branch length */
+static int g_trace_kind = 2;
 static double neg_ll(const opt_ctx *c, double x) {
   double o[3];
   eval_at(c, exp(x), o);
-  return -o[0];
+  double f = -o[0];
+  if (c->g->noise != 0) { /* (test instrument) xorshift64*: f (1 + noise u), u uniform in [-1, 1) */
+    uint64_t z = c->g->noise_state;
+    z ^= z >> 12; z ^= z << 25; z ^= z >> 27;
+    c->g->noise_state = z;
+    const double u = (double)((z * 0x2545F4914F6CDD1Dull) >> 11) / 4503599627370496.0 - 1.0;
+    f *= 1.0 + c->g->noise * u;
+  }
+  trace_row(c, x, f, g_trace_kind);
+  return f;
 }
 static void neg_ll_and_derivative(const opt_ctx *c, double x, double *f, double *df) {
   double o[3];
@@ -429,7 +466,9 @@ static void brent_minimize(const opt_ctx *c, int with_gradients, double guess, d
   const double golden = 0.3819660f;
   double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
   w = v = x = guess;
+  g_trace_kind = 1;
   fw = fv = fx = neg_ll(c, x);
+  g_trace_kind = 2;
   delta2 = delta = 0;
   int count = max_iter;
   do {
@@ -470,7 +509,9 @@ static void brent_minimize(const opt_ctx *c, int with_gradients, double guess, d
       double f0, df;
       neg_ll_and_derivative(c, x, &f0, &df);
       const double u2 = x - step_size * df;
+      g_trace_kind = 3;
       const double fu2 = neg_ll(c, u2);
+      g_trace_kind = 2;
       if (fu2 <= fx) {
         if (u2 >= x) min = x; else max = x;
         v = w; w = x; x = u2;
@@ -503,6 +544,7 @@ static void optimize_branch_length(gp_oracle *g, int edge, uint64_t rootward, ui
     case OPT_BRENT:
     case OPT_BRENT_WITH_GRADIENTS: {
       const double cur_log = log(current);
+      g_trace_kind = 0;
       const double cur_nll = neg_ll(&c, cur_log);
       double x, fx;
       brent_minimize(&c, g->method == OPT_BRENT_WITH_GRADIENTS, cur_log, kMinLogBl, kMaxLogBl, g->significant_digits,

@@ -211,11 +211,15 @@ def test_gp_branch_length_optimization_on_device(data_dir):
     # (measured: optimised lengths 1.8e-16 apart, marginals equal -- scripts/gpu_gp_diffs.py)
     assert np.abs(gpu.get_branch_lengths() - cpu.get_branch_lengths()).max() < 1e-12
     assert abs(gpu.get_log_marginal_likelihood() - cpu.get_log_marginal_likelihood()) < 1e-10
-    # one sweep on fluA (69 taxa, 136 optimised edges), every method; Brent stops at 10 significant
-    # BITS (ldexp(1, 1 - digits), src/optimization.hpp:75) so its argmin is compared loosely, its value tightly
+    # one sweep on fluA (69 taxa, 136 optimised edges), every method.  Brent is deterministic and none of its decisions on
+    # this workload is near a tie (tests/gp_trace.py, test_brent_trace_comparison: rounding noise moves the optimised
+    # lengths by 2e-12): the device follows the checker's iterates (test_device_brent_follows_the_checkers_iterates) and
+    # ends at its lengths.  The gradient variant's last decisions on an edge are near-ties by construction (its second
+    # trial point closes in on the best one as the derivative vanishes) and Brent stops at 10 significant BITS
+    # (ldexp(1, 1 - digits), src/optimization.hpp:75): its argmin is compared loosely.
     sp, tree, dag = _flu(data_dir)
     bl0 = dag.branch_lengths(np.full(tree.node_count, 0.01))
-    for method, bl_tol in ((gp.NEWTON, 1e-8), (gp.BRENT, 2e-2), (gp.BRENT_WITH_GRADIENTS, 2e-2)):
+    for method, bl_tol in ((gp.NEWTON, 1e-8), (gp.BRENT, 1e-8), (gp.BRENT_WITH_GRADIENTS, 2e-2)):
         results = []
         for factory in (_gpu_factory, _oracle_factory):
             eng = factory(sp, dag)
@@ -534,38 +538,221 @@ def test_gp_rescaling_counts_and_plvs_as_the_reference_holds_them(data_dir, bran
     assert abs(gpu.get_log_marginal_likelihood() - cpu.get_log_marginal_likelihood()) < 1e-9
 
 
+def _oracle_state(eng, dag):
+    plvs = np.stack([eng.get_plv(k) for k in range(6 * dag.node_count)])
+    return (eng.get_branch_lengths(), eng.get_branch_length_differences(), eng.get_per_gpcsp_log_likelihoods(),
+            eng.get_sbn_parameters(), plvs, eng.get_rescaling_counts(0, 6 * dag.node_count))
+
+
+def _run_streams_on_oracle(sp, dag, bl0, streams, method, threshold=1e-40):
+    eng = ogp.OracleGPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count, threshold)
+    eng.set_sbn_parameters(dag.uniform_on_topological_support_prior())
+    eng.set_optimization_method(method)
+    eng.set_branch_lengths(bl0)
+    eng.reset_optimization_count()
+    for s in streams:
+        eng.process_operations(s)
+    return _oracle_state(eng, dag)
+
+
+def _shuffled_within_levels(scheduled, launch, level, rng):
+    """the scheduled stream with the operations of every (launch, level) in a random order: by the schedule's own claim
+    they touch disjoint results, so any order of them computes the same bits"""
+    out = gp.OpStream()
+    out.side = list(scheduled.side)
+    order = np.arange(len(scheduled.ops))
+    keys = launch.astype(np.int64) * (1 << 32) + level
+    for key in np.unique(keys):
+        idx = np.nonzero(keys == key)[0]
+        order[idx] = rng.permutation(idx)
+    out.ops = [scheduled.ops[k] for k in order]
+    return out
+
+
+SCHEDULE_CASES = COMPOSITE_CASES + [("DS1.fasta", "ten-tree DAG")]
+
+
+@pytest.mark.parametrize("fasta,newick", SCHEDULE_CASES)
+def test_executor_schedule_is_the_sequential_arithmetic(data_dir, fasta, newick):
+    """The order in which the executor runs a stream (bito_amd_gp_schedule_operations, bito_amd/csrc/gp_schedule.hpp:
+    per-pattern operations by dependency level, the OptimizeBranchLength operations of equal optimiser depth as one
+    launch of concurrent workgroups) must compute what the reference's one-after-the-other execution computes
+    (src/gp_engine.cpp:213-339) -- bit for bit.  Checked on the CPU: the oracle, which executes strictly in stream order,
+    runs the stream as given, the scheduled stream, and the scheduled stream with every (launch, level) shuffled; branch
+    lengths, differences, log-likelihood rows, every PLV and every rescaling count must be identical.  Streams: the three
+    schedules of GPInstance::EstimateBranchLengths (src/gp_instance.cpp:241-308) and the SBN-parameter update
+    (src/gp_dag.cpp:123-137), whose UpdateSBNProbabilities operations are barriers."""
+    if newick == "ten-tree DAG":
+        dag, sp = workloads.ds1_subsplit_dag(10)
+        bl0 = np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)
+    else:
+        sp, dag, bl0 = _composite_case(data_dir, fasta, newick)
+        bl0 = np.maximum(bl0, 0.01)
+    streams = [dag.populate_plvs(), dag.compute_likelihoods(), dag.branch_length_optimization(), dag.populate_plvs(),
+               dag.optimize_sbn_parameters(), dag.branch_length_optimization(zero_before_update=True), dag.marginal_likelihood()]
+    rng = np.random.default_rng(23)
+    for method in (gp.BRENT, gp.NEWTON):
+        for threshold in (1e-40, 1e-4):  # (1e-4: the rescaling counts take part)
+            want = _run_streams_on_oracle(sp, dag, bl0, streams, method, threshold)
+            scheduled, shuffled = [], []
+            for s in streams:
+                t, launch, level, kinds = gp.schedule_operations(s)
+                assert sorted(t.ops) == sorted(s.ops)  # a permutation of the stream
+                scheduled.append(t)
+                shuffled.append(_shuffled_within_levels(t, launch, level, rng))
+            for variant in (scheduled, shuffled):
+                got = _run_streams_on_oracle(sp, dag, bl0, variant, method, threshold)
+                for x, y in zip(want, got):
+                    assert np.array_equal(x, y, equal_nan=True)
+            if newick != "ten-tree DAG":
+                break  # (one threshold for the small cases' second method keeps the CPU suite short)
+    # (the sweeps did move the lengths; on the ten-tree DAG Newton after the SBN update meets edges whose q underflowed to
+    # zero and returns nan for them, as the reference's arithmetic does -- the nans are compared like every other value)
+    assert np.nanmax(np.abs(want[0] - bl0)) > 1e-3
+
+
+def test_executor_schedule_shape(data_dir):
+    """What the schedule buys: the number of optimiser launches is the longest chain of optimisations in the stream's
+    dependency graph -- 56 instead of 118 on the DS1 ten-tree DAG --, a single tree's sweep stays one chain (every edge's
+    optimisation depends on the one before it through the partial vectors it refreshes), and without reordering every
+    optimisation is a launch of its own in stream order."""
+    dag, sp = workloads.ds1_subsplit_dag(10)
+    sweep = dag.branch_length_optimization()
+    optimisations = sum(1 for op in sweep.ops if op[0] == gp.OPTIMIZE_BRANCH_LENGTH)
+    t, launch, level, kinds = gp.schedule_operations(sweep)
+    assert optimisations == 118 and int((kinds == 1).sum()) == 56
+    assert np.all(np.diff(launch) >= 0) and launch[-1] == len(kinds) - 1
+    widths = np.bincount(launch[[k for k, op in enumerate(t.ops) if op[0] == gp.OPTIMIZE_BRANCH_LENGTH]])
+    assert widths.max() >= 3
+    # kinds alternate: never two per-pattern launches or two optimiser launches in a row
+    assert np.all(kinds[1:] != kinds[:-1])
+    plain, launch0, _, kinds0 = gp.schedule_operations(sweep, reorder=False)
+    assert int((kinds0 == 1).sum()) == 118
+    assert [op for op in plain.ops if op[0] == gp.OPTIMIZE_BRANCH_LENGTH] == [op for op in sweep.ops if op[0] == gp.OPTIMIZE_BRANCH_LENGTH]
+    # schedules without an optimiser are one launch of levelled per-pattern operations
+    t, launch, level, kinds = gp.schedule_operations(dag.populate_plvs())
+    assert list(kinds) == [0] and level.max() + 1 < len(t.ops) // 8
+    # a single tree (fluA, 69 taxa): one chain -- as many optimiser launches as optimisations
+    _, _, flu = _flu(data_dir)
+    _, _, _, kinds = gp.schedule_operations(flu.branch_length_optimization())
+    assert int((kinds == 1).sum()) == 136
+
+
+def _traced_sweep(factory, sp, dag, bl0, method, noise=0.0, sweeps=1):
+    eng = factory(sp, dag)
+    eng.set_sbn_parameters(dag.uniform_on_topological_support_prior()) if hasattr(dag, "uniform_on_topological_support_prior") else None
+    eng.set_branch_lengths(bl0)
+    eng.set_optimization_method(method)
+    eng.reset_optimization_count()
+    eng.start_optimizer_trace()
+    if noise:
+        eng.set_eval_noise(noise, 7)
+    eng.process_operations(dag.populate_plvs())
+    for _ in range(sweeps):
+        eng.process_operations(dag.branch_length_optimization())
+        eng.increment_optimization_count()
+    trace = eng.optimizer_trace()
+    if noise:
+        eng.set_eval_noise(0.0)
+    return trace, eng.get_branch_lengths()
+
+
+def test_brent_trace_comparison(data_dir):
+    """The instrument that holds the device's Brent to the checker's (tests/gp_trace.py), checked on the CPU: the checker
+    against itself with every function value perturbed by 1e-15 relative -- what separates two correct implementations --
+    follows the same iterates within the comparison's tolerances (same evaluation count on every edge, no near-tie on
+    these workloads), while a perturbation of 1e-7 relative is told apart.  Reference: src/optimization.hpp:71-331."""
+    import gp_trace
+
+    sp, tree, flu = _flu(data_dir)
+    cases = [(sp, flu, flu.branch_lengths(np.full(tree.node_count, 0.01)))]
+    dag, sp2 = workloads.ds1_subsplit_dag(10)
+    cases.append((sp2, dag, np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)))
+    for sp_, dag_, bl0 in cases:
+        clean, bl_clean = _traced_sweep(_oracle_factory, sp_, dag_, bl0, gp.BRENT)
+        noisy, bl_noisy = _traced_sweep(_oracle_factory, sp_, dag_, bl0, gp.BRENT, noise=1e-15)
+        problems, stats = gp_trace.compare(clean, noisy)
+        assert not problems, problems[:3]
+        # Brent's decisions are far from ties (8e-7 at the least on DS1): nothing is left uncompared
+        assert stats["explained_at"] is None and stats["compared"] == stats["rows"] == len(noisy)
+        assert stats["ties"] == 0 and stats["smallest_margin"] > 1e-8
+        assert np.abs(bl_clean - bl_noisy).max() < 1e-9
+        rough, _ = _traced_sweep(_oracle_factory, sp_, dag_, bl0, gp.BRENT, noise=1e-7)
+        problems, _ = gp_trace.compare(clean, rough)
+        assert problems
+        # The gradient variant is another matter: its second trial point (a step of 1.0005 x the derivative from the best
+        # point) closes in on the best point as the derivative vanishes, so its last decisions on an edge are near-ties by
+        # construction and rounding noise does flip some (fluA edge 74: 30 evaluations or 22).  The comparison says so.
+        clean, _ = _traced_sweep(_oracle_factory, sp_, dag_, bl0, gp.BRENT_WITH_GRADIENTS)
+        _, stats = gp_trace.compare(clean, clean)
+        assert stats["ties"] > 0 and stats["compared"] == len(clean)
+
+
 @pytest.mark.gpu
-def test_fused_optimisation_sweep_is_bitwise_the_piecewise_one():
-    """A branch-length optimisation sweep runs as ONE workgroup that interprets the whole stretch of the stream (round 4:
-    two launches per edge before); same arithmetic in the same order, so the branch lengths, their changes and the
-    per-GPCSP log-likelihoods are the piecewise launches' bit for bit -- on the DS1 ten-tree DAG (118 optimised edges),
-    Brent and Newton (reference schedule: src/gp_dag.cpp:78-121; optimisers: src/optimization.hpp:71-417)."""
+def test_device_brent_follows_the_checkers_iterates(data_dir):
+    """Brent is the reference's DEFAULT optimiser (src/dag_branch_handler.hpp:262) and it is deterministic: with function
+    values equal to rounding, the device's restatement of src/optimization.hpp:71-331 must visit the points the checker's
+    visits -- the same number of evaluations on every edge, every trial point within 1e-6 + 1e-10 / length in the log
+    length (tests/gp_trace.py; what rounding noise alone does is measured in test_brent_trace_comparison) -- and end
+    at the same branch lengths.  hello, fluA (136 edges, two sweeps: the second skips converged edges), the DS1 ten-tree
+    DAG (118 edges, optimised concurrently where the schedule allows).  (The gradient variant's last decisions on an edge
+    are near-ties by construction -- test_brent_trace_comparison -- and stay with the looser comparison of
+    test_gp_branch_length_optimization_on_device.)"""
+    import gp_trace
+
+    sp, tree, hello = hello_instance(data_dir)
+    cases = [("hello", sp, hello, hello.branch_lengths(tree.branch_lengths), 1)]
+    sp, tree, flu = _flu(data_dir)
+    cases.append(("fluA", sp, flu, flu.branch_lengths(np.full(tree.node_count, 0.01)), 2))
+    dag, sp2 = workloads.ds1_subsplit_dag(10)
+    cases.append(("DS1 DAG", sp2, dag, np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count), 1))
+    for name, sp_, dag_, bl0, sweeps in cases:
+        cpu, bl_cpu = _traced_sweep(_oracle_factory, sp_, dag_, bl0, gp.BRENT, sweeps=sweeps)
+        gpu, bl_gpu = _traced_sweep(_gpu_factory, sp_, dag_, bl0, gp.BRENT, sweeps=sweeps)
+        problems, stats = gp_trace.compare(cpu, gpu)
+        assert not problems, (name, problems[:3], stats)
+        # (no decision of the checker's run is near a tie on these workloads: nothing may be left uncompared)
+        assert stats["ties"] == 0 and stats["compared"] == len(cpu) == len(gpu), (name, stats)
+        assert np.abs(bl_gpu - bl_cpu).max() < 1e-8, name
+
+
+@pytest.mark.gpu
+def test_scheduled_sweep_is_bitwise_the_sequential_one():
+    """The executor runs a branch-length optimisation sweep in the order of gp_schedule.hpp (the optimisations of equal
+    optimiser depth as concurrent workgroups of one launch: 56 launches instead of 118 on the DS1 ten-tree DAG); the same
+    arithmetic on the same inputs, so the branch lengths, their changes and the per-GPCSP log-likelihoods are those of
+    the one-optimisation-per-launch route in stream order (BITO_AMD_GP_SCHEDULE=0) bit for bit -- Brent, Brent with
+    gradients and Newton (reference schedule: src/gp_dag.cpp:78-121; optimisers: src/optimization.hpp:71-417), without
+    and with rescaling in play, and on the 970-edge DAG of twenty seeded topologies."""
     import os
 
     from bito_amd import workloads
 
-    dag, sp = workloads.ds1_subsplit_dag(10)
-    bl0 = np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)
-    results = {}
-    for fused in ("1", "0"):
-        os.environ["BITO_AMD_GP_FUSED_SWEEP"] = fused
-        try:
-            eng = gp.GPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count)
-            eng.set_sbn_parameters(dag.uniform_on_topological_support_prior())
-            out = []
-            for method in (gp.BRENT, gp.NEWTON):
-                eng.set_optimization_method(method)
-                eng.set_branch_lengths(bl0)
-                eng.reset_optimization_count()
-                eng.process_operations(dag.populate_plvs())
-                eng.process_operations(dag.branch_length_optimization())
-                eng.process_operations(dag.populate_plvs())
-                eng.process_operations(dag.compute_likelihoods())
-                out.append((eng.get_branch_lengths(), eng.get_branch_length_differences(), eng.get_per_gpcsp_log_likelihoods()))
-            results[fused] = out
-        finally:
-            os.environ.pop("BITO_AMD_GP_FUSED_SWEEP", None)
-    for a, b in zip(results["1"], results["0"]):
-        for x, y in zip(a, b):
-            assert np.array_equal(x, y)
-    assert np.abs(results["1"][0][0] - bl0).max() > 1e-3  # (the sweep did move the lengths)
+    for (dag, sp), threshold in ((workloads.ds1_subsplit_dag(10), 1e-40), (workloads.ds1_subsplit_dag(10), 1e-4),
+                                 (workloads.seeded_subsplit_dag(20), 1e-40)):
+        bl0 = np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)
+        results = {}
+        for scheduled in ("1", "0"):
+            os.environ["BITO_AMD_GP_SCHEDULE"] = scheduled
+            try:
+                eng = gp.GPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count, threshold)
+                eng.set_sbn_parameters(dag.uniform_on_topological_support_prior())
+                out = []
+                for method in (gp.BRENT, gp.BRENT_WITH_GRADIENTS, gp.NEWTON):
+                    eng.set_optimization_method(method)
+                    eng.set_branch_lengths(bl0)
+                    eng.reset_optimization_count()
+                    eng.process_operations(dag.populate_plvs())
+                    eng.process_operations(dag.branch_length_optimization())
+                    eng.increment_optimization_count()  # (the second sweep skips converged edges: differences in play)
+                    eng.process_operations(dag.branch_length_optimization())
+                    eng.process_operations(dag.populate_plvs())
+                    eng.process_operations(dag.compute_likelihoods())
+                    out.append((eng.get_branch_lengths(), eng.get_branch_length_differences(), eng.get_per_gpcsp_log_likelihoods()))
+                results[scheduled] = out
+            finally:
+                os.environ.pop("BITO_AMD_GP_SCHEDULE", None)
+        for a, b in zip(results["1"], results["0"]):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+        assert np.abs(results["1"][0][0] - bl0).max() > 1e-3  # (the sweep did move the lengths)
