@@ -248,11 +248,12 @@ def check_against_oracle(w, out_ll, out_grad, count=8):
 
         cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, min(len(sel), 8))
     bl = w.last_branch_lengths[sel]
+    par = getattr(w, "last_params", w.params)[sel]
     if w.want_gradient:
-        ref = cpu.gradients(w.parent_ids[sel], bl, w.params[sel], rescaling=w.rescaling)
+        ref = cpu.gradients(w.parent_ids[sel], bl, par, rescaling=w.rescaling)
         ref_ll, ref_grad = ref["log_likelihood"], ref["branch_lengths"]
     else:
-        ref_ll, ref_grad = cpu.log_likelihoods(w.parent_ids[sel], bl, w.params[sel], rescaling=w.rescaling), None
+        ref_ll, ref_grad = cpu.log_likelihoods(w.parent_ids[sel], bl, par, rescaling=w.rescaling), None
     dll = float(np.max(np.abs(out_ll[sel] - ref_ll) / (1.0 + 2e-4 * np.abs(ref_ll))))  # 1e-10 + 2e-14 |LL|, as the tests
     res = {"trees_checked": [int(t) for t in sel], "max_dll": float(np.max(np.abs(out_ll[sel] - ref_ll))),
            "max_dll_scaled": dll, "checker": "the CPU oracle (oracle/), on the inputs of the last timed step"}
@@ -410,6 +411,10 @@ def main():
     ap.add_argument("--trees", type=int, default=0,
                     help="codon workload: trees per GPU (default 4096); config4: trees in all (default 1000, "
                          "125 per GPU at 8 GPUs; one GPU alone takes 125)")
+    ap.add_argument("--distinct-models", type=int, default=1,
+                    help="codon workload: how many different (kappa, omega) rows the trees of a batch carry (tree t has row "
+                         "t %% K; the reference hands every tree its own row, src/fat_beagle.hpp:173-181).  `value` is measured "
+                         "with this K; the line also carries K = 1, 64 and one row per tree (`distinct_models`)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="the timed region only: skip the small-collection calls and the second timed region (resident batch)")
@@ -503,25 +508,36 @@ def main():
     if not codon:
         eng.set_kernel(args.kernel)
 
-    # fresh host inputs per step: two sets of branch lengths take turns
+    # fresh host inputs per step: two sets of branch lengths take turns, and two sets of parameter rows -- the second
+    # differs from the first in the last bit of one rate (GTR's AC rate, kappa), so that no step finds the models of the
+    # step before still standing (round 4's model caches compare rows: worker.cpp UploadModelIndex, model_reuse) and
+    # `value` includes every tree's parameter row -> eigendecomposition, as SURVEY.md 8d's span says.  The rate of a loop
+    # of calls over FIXED parameter rows (the caches hit) is measured beside it: `model_cache_hit`.
     pid = np.ascontiguousarray(w.parent_ids, dtype=np.int32)
+    if codon and args.distinct_models != 1:
+        w.params = workloads.codon_rows(T, args.distinct_models if args.distinct_models > 0 else T)
     params = np.ascontiguousarray(w.params, dtype=np.float64)
+    rate_column = 4  # GTR: frequencies [0, 4), rates [4, 10); GY94: frequencies [0, 4), kappa, omega
+    param_sets = [params, workloads.other_bits(params, rate_column)]
     bl_sets = [np.ascontiguousarray(w.branch_lengths, dtype=np.float64),
                np.ascontiguousarray(w.branch_lengths * 1.03125, dtype=np.float64)]
     out_ll = np.zeros(T)
     out_grad = np.zeros((T, N))
     pending = []  # (work handle, tensor) of the reductions in flight
     counter = [0]
+    fixed_rows = [False]
 
     def step():
         # the call the reference's Engine::Gradients is: host trees + parameter rows in, host results out
         bl = bl_sets[counter[0] & 1]
+        par = param_sets[0 if fixed_rows[0] else counter[0] & 1]
         counter[0] += 1
         w.last_branch_lengths = bl
+        w.last_params = par
         if w.want_gradient:
-            eng.gradients_into(pid, bl, params, out_ll, out_grad, rescaling=w.rescaling)
+            eng.gradients_into(pid, bl, par, out_ll, out_grad, rescaling=w.rescaling)
         else:
-            eng.log_likelihoods_into(pid, bl, params, out_ll, rescaling=w.rescaling)
+            eng.log_likelihoods_into(pid, bl, par, out_ll, rescaling=w.rescaling)
         if reduce_ll:
             # trees are independent: the only exchange the path has is the summed log-likelihood of the whole
             # collection (the caller's objective), 8 bytes per step
@@ -569,6 +585,49 @@ def main():
         bad = parity["max_dll_scaled"] > 1e-10 or parity.get("max_dgrad_relative", 0.0) > 1e-6
         if bad:
             raise SystemExit(f"the timed batch's results differ from the CPU checker's: {parity}")
+    # the same loop over FIXED parameter rows: every call finds the models of the call before (round 4's caches hit)
+    cache_hit = None
+    if not args.resident_only and not args.no_resident:
+        fixed_rows[0] = True
+        for _ in range(2):
+            step()
+        fence()
+        pending.clear()
+        h0 = time.perf_counter()
+        for _ in range(timed_steps):
+            step()
+        fence()
+        h_elapsed = time.perf_counter() - h0
+        pending.clear()
+        if dist is not None:
+            tmax = torch.tensor([h_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            h_elapsed = float(tmax.item())
+        cache_hit = {"trees_per_s": world * T * timed_steps / h_elapsed, "ms_per_step": h_elapsed / timed_steps * 1e3,
+                     "note": "the timed loop again with the SAME parameter rows on every step: the models of the step before are "
+                             "found standing (worker.cpp: UploadModelIndex, DeviceBatch::model_reuse); `value` is the loop whose "
+                             "rows change every step"}
+        fixed_rows[0] = False
+    # config 5 with K different (kappa, omega) rows among the trees: 1, 64, one per tree (rows change every step)
+    distinct = None
+    if codon and world == 1 and not args.no_resident and not args.resident_only:
+        distinct = {}
+        for K in sorted({1, 64, T}):
+            rows = workloads.codon_rows(T, K)
+            sets = [np.ascontiguousarray(rows), workloads.other_bits(rows, rate_column)]
+            for k in range(2):
+                eng.gradients_into(pid, bl_sets[k & 1], sets[k & 1], out_ll, out_grad, rescaling=w.rescaling)
+            reps = max(3, min(args.steps, 8))
+            d0 = time.perf_counter()
+            for k in range(reps):
+                eng.gradients_into(pid, bl_sets[k & 1], sets[k & 1], out_ll, out_grad, rescaling=w.rescaling)
+            eng.sync()
+            dt = time.perf_counter() - d0
+            distinct[str(K)] = {"trees_per_s": T * reps / dt, "ms_per_step": dt / reps * 1e3}
+        distinct["note"] = ("K different parameter rows (kappa ~ U(1.5, 4), omega ~ U(0.1, 0.9), seeded) among the batch's trees, "
+                            "tree t carries row t % K; every row needs its own 64 x 64 eigensystem (gs_eigen_kernel)")
+        # (leave the engine as the timed loop left it)
+        eng.gradients_into(pid, w.last_branch_lengths, w.last_params, out_ll, out_grad, rescaling=w.rescaling)
     summed_ll = None
     if reduce_ll:
         # the last reduction must be the sum over every rank's block: check it against a gather of the
@@ -582,22 +641,24 @@ def main():
             raise SystemExit(f"summed log-likelihood {summed_ll} differs from the gathered sum {expect}")
 
     # the same blocking call on small collections (BASELINE's literal "100 topologies", vip's particle loop): ms per call
-    small_calls = None
+    small_calls = small_calls_hit = None
     if args.workload == "ds1" and world == 1 and not args.no_resident and not args.resident_only and not slots:
-        small_calls = {}
+        small_calls, small_calls_hit = {}, {}
         for count in (1, 100, 400, 1600):
             if count > T:
                 continue
             ll_s, grad_s = np.zeros(count), np.zeros((count, N))
-            pid_s, par_s = np.ascontiguousarray(pid[:count]), np.ascontiguousarray(params[:count])
+            pid_s = np.ascontiguousarray(pid[:count])
+            par_s = [np.ascontiguousarray(ps[:count]) for ps in param_sets]
             bl_s = [np.ascontiguousarray(b[:count]) for b in bl_sets]
-            for k in range(5):
-                eng.gradients_into(pid_s, bl_s[k & 1], par_s, ll_s, grad_s)
-            reps = 40
-            s0 = time.perf_counter()
-            for k in range(reps):
-                eng.gradients_into(pid_s, bl_s[k & 1], par_s, ll_s, grad_s)
-            small_calls[str(count)] = (time.perf_counter() - s0) / reps * 1e3
+            for fixed, into in ((False, small_calls), (True, small_calls_hit)):  # parameter rows change every call / never
+                for k in range(5):
+                    eng.gradients_into(pid_s, bl_s[k & 1], par_s[0 if fixed else k & 1], ll_s, grad_s)
+                reps = 40
+                s0 = time.perf_counter()
+                for k in range(reps):
+                    eng.gradients_into(pid_s, bl_s[k & 1], par_s[0 if fixed else k & 1], ll_s, grad_s)
+                into[str(count)] = (time.perf_counter() - s0) / reps * 1e3
 
     # second timed region: the same passes over a batch that stays in HBM (no host arrays cross PCIe)
     resident = None
@@ -706,8 +767,17 @@ def main():
         # per-launch average is the spans' sum / launches:
         out["roofline"]["avg_launch_span_ms"] = span_sum_ms / max(launches, 1)
         if small_calls:
-            out["blocking_call_ms"] = {"trees_per_call": small_calls,
-                                       "note": "the same gradients call on 1 / 100 / 400 / 1600 of the trees, mean of 40 calls"}
+            out["blocking_call_ms"] = {"trees_per_call": small_calls, "trees_per_call_model_cache_hit": small_calls_hit,
+                                       "note": "the same gradients call on 1 / 100 / 400 / 1600 of the trees, mean of 40 calls; "
+                                               "parameter rows that change with every call (trees_per_call) and rows that never "
+                                               "change (the last call's model is found standing)"}
+        if cache_hit is not None:
+            out["model_cache_hit"] = cache_hit
+        if distinct is not None:
+            out["distinct_models"] = distinct
+        if codon:
+            out["config"]["distinct_models_in_value"] = int(len(np.unique(params, axis=0)))
+        out["config"]["parameter_rows"] = "two sets take turns step by step (they differ in the last bit of one rate): no step finds the models of the step before"
         if resident is not None:
             out["resident"] = resident
         if world == 1 and not args.no_cpu_baseline:

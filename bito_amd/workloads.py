@@ -245,6 +245,26 @@ def flua_codon(tree_count: int = 64, site: str = "constant", seed: int = 2024060
                     np.tile(np.array(row), (tree_count, 1)), False, True)
 
 
+def codon_rows(tree_count: int, distinct: int, site: str = "constant", seed: int = 20240607) -> np.ndarray:
+    """Parameter rows for the codon workload with `distinct` different models among the trees (the reference hands every
+    tree its own parameter row, src/fat_beagle.hpp:173-181): row k of the distinct ones has kappa ~ U(1.5, 4) and
+    omega ~ U(0.1, 0.9) from a seeded generator (row 0 = CODON_PARAMS), tree t carries row t % distinct."""
+    rng = np.random.default_rng(seed)
+    rows = np.tile(np.array(CODON_PARAMS + ([0.7] if site != "constant" else [])), (max(int(distinct), 1), 1))
+    rows[1:, 4] = rng.uniform(1.5, 4.0, len(rows) - 1)
+    rows[1:, 5] = rng.uniform(0.1, 0.9, len(rows) - 1)
+    return np.ascontiguousarray(rows[np.arange(tree_count) % len(rows)])
+
+
+def other_bits(params: np.ndarray, column: int) -> np.ndarray:
+    """The same parameter rows with the last bit of one column flipped upwards (a rate, kappa): another model as far as
+    any cache that compares rows is concerned, the same model to 1e-16 for every result."""
+    out = np.array(params, dtype=np.float64, copy=True)
+    if out.shape[1] > column:
+        out[:, column] = np.nextafter(out[:, column], np.inf)
+    return np.ascontiguousarray(out)
+
+
 def postorder_parent_ids(parents) -> np.ndarray:
     """Parent-id vector with arbitrary internal ids (root = the largest id) -> bito's ids: leaves keep theirs, internal
     nodes are numbered in post-order with the children visited in id order (Node::Polish, src/node.cpp:383-402)."""

@@ -401,3 +401,21 @@ def test_unstored_node_count_rejects_rows_that_are_not_trees():
             rc = L.bito_amd_count_unstored_nodes(n, 1, rooted, M, bad.ctypes.data_as(ip), 1, out.ctypes.data_as(ip))
             assert rc == _capi.ERR_BAD_TREE, (rooted, child, value, rc)
         assert L.bito_amd_count_unstored_nodes(n, 1, rooted, M + 1, good.ctypes.data_as(ip), 1, out.ctypes.data_as(ip)) != 0
+
+
+def test_bench_parameter_rows_for_cache_misses_and_distinct_models():
+    """bench.py's timed loops alternate two sets of parameter rows that differ in the last bit of one rate (no step finds
+    the models of the step before), and the codon workload can carry K different (kappa, omega) rows among its trees
+    (the reference hands every tree its own row, src/fat_beagle.hpp:173-181)."""
+    w = workloads.ds1_gtr_weibull4(1)
+    other = workloads.other_bits(w.params, 4)
+    assert other.shape == w.params.shape and np.all(other[:, 4] > w.params[:, 4])
+    assert np.array_equal(np.delete(other, 4, axis=1), np.delete(w.params, 4, axis=1))
+    assert np.abs(other - w.params).max() < 1e-16 and abs(other[0, 4:10].sum() - 1.0) < 1e-3
+    for K in (1, 7, 64):
+        rows = workloads.codon_rows(64, K)
+        assert rows.shape == (64, 6) and len(np.unique(rows, axis=0)) == K
+        assert np.array_equal(rows[0], np.array(workloads.CODON_PARAMS)) and np.array_equal(rows[:K], rows[K:2 * K] if 2 * K <= 64 else rows[:K])
+        assert np.all(rows[:, :4] == np.array(workloads.CODON_PARAMS[:4]))
+        assert np.all((rows[:, 4] >= 1.5) & (rows[:, 4] <= 4.0) & (rows[:, 5] >= 0.1) & (rows[:, 5] <= 0.9))
+    assert np.array_equal(workloads.codon_rows(8, 3), workloads.codon_rows(8, 3))
