@@ -70,6 +70,10 @@ struct bito_amd_engine {
   // src/task_processor.hpp:43-140): a call over several devices hands every slot's block to its own thread, so that no
   // device waits for the host to be done with another one's.  Created on the first call that uses several slots.
   std::unique_ptr<HostPool> slot_pool;
+  // ... and the helper threads those issuing threads share (host_pool.hpp, SharedPool): a slot's chunk of a thousand
+  // trees and more is checked and packed in ranges that the helpers and the slot's own thread claim one by one, a large
+  // result block copied out the same way.  host_threads - 1 helpers; created with slot_pool.
+  std::unique_ptr<SharedPool> shared_pool;
   double span_sum_ms = 0;  // of the last bito_amd_engine_kernel_elapsed: the launches' spans added up (overlaps counted twice)
 };
 
@@ -128,6 +132,20 @@ HostPool* Pool(bito_amd_engine* e) {
     e->pool = std::make_unique<HostPool>(std::max(0, e->host_threads - 1));
   }
   return e->pool.get();
+}
+
+SharedPool* Shared(bito_amd_engine* e) {
+  if (!e->shared_pool) e->shared_pool = std::make_unique<SharedPool>(std::max(0, e->host_threads - 1));
+  return e->shared_pool.get();
+}
+
+// fn(part, begin, end) over [0, count) in `parts` contiguous ranges, claimed one by one by the calling thread and the
+// shared helpers (several issuing threads may be in here at once)
+void SharedRanges(bito_amd_engine* e, size_t count, int parts, const std::function<void(int, size_t, size_t)>& fn) {
+  Shared(e)->Run(parts, [&](int part) {
+    const size_t a = count * (size_t)part / (size_t)parts, b = count * ((size_t)part + 1) / (size_t)parts;
+    if (b > a) fn(part, a, b);
+  });
 }
 
 // fn(begin, end) over [0, count) in one contiguous range per host thread
@@ -288,10 +306,13 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - call_start).count(), what, k,
                    e->shards[k].slot, e->shards[k].lane, e->shards[k].count);
   };
-  auto big_copy = [&](const Shard& s) {
-    return !threaded && e->host_threads != 1 &&
+  auto big_block = [&](const Shard& s) {
+    return e->host_threads != 1 &&
            (size_t)s.count * (want_gradient && out_grad ? N + 1 : 1) * sizeof(double) >= e->par_min_bytes;
   };
+  auto big_copy = [&](const Shard& s) { return !threaded && big_block(s); };
+  // several issuing threads: ranges of about 512 trees, claimed by the thread itself and the shared helpers
+  auto shared_parts = [&](int count) { return std::max(1, std::min(Shared(e)->helpers() + 1, count / 512)); };
   auto drain = [&](size_t k) -> int {
     const Shard& s = e->shards[k];
     Worker* w = ShardWorker(e, s);
@@ -308,6 +329,8 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
     };
     if (big_copy(s))
       ParallelRanges(e, (size_t)s.count, [&](int, size_t a, size_t b) { copy(a, b); });
+    else if (threaded && big_block(s) && shared_parts(s.count) > 1)
+      SharedRanges(e, (size_t)s.count, shared_parts(s.count), [&](int, size_t a, size_t b) { copy(a, b); });
     else
       copy(0, (size_t)s.count);
     stamp("copied out", k);
@@ -321,6 +344,7 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
     if (Pool(e)->Hot()) par_min_trees = std::min(par_min_trees, 256);
     Pool(e)->Arm();
   }
+  if (threaded && e->host_threads != 1) Shared(e)->Arm();
   // what one issuing thread does with its chunks, in order; returns the first failure (the failing worker holds the message)
   struct Outcome {
     int rc = BITO_AMD_OK;
@@ -369,6 +393,13 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
           std::vector<StagePart> parts((size_t)Pool(e)->parts());
           ParallelRanges(e, (size_t)s.count, [&](int part, size_t a, size_t b) { WorkerStageFill(w, (int32_t)a, (int32_t)b, &parts[(size_t)part]); });
           rc = WorkerStageEnd(w, parts.data(), (int)parts.size());
+        } else if (threaded && e->host_threads != 1 && s.count >= par_min_trees && shared_parts(s.count) > 1) {
+          // (round 5: a slot's thread no longer packs its large chunks alone -- eight slots x 5376 trees were 0.33 ms of
+          // one thread each, the second chunks issued 0.74-0.78 ms into the call)
+          std::vector<StagePart> parts((size_t)shared_parts(s.count));
+          SharedRanges(e, (size_t)s.count, (int)parts.size(),
+                       [&](int part, size_t a, size_t b) { WorkerStageFill(w, (int32_t)a, (int32_t)b, &parts[(size_t)part]); });
+          rc = WorkerStageEnd(w, parts.data(), (int)parts.size());
         } else {
           StagePart part;
           WorkerStageFill(w, 0, s.count, &part);
@@ -409,17 +440,41 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
     // chunk has drained by now, so each worker runs the pass on its OWN streams and waits for it there: the streams a
     // chunk was lent for the call belong to other workers, and a download ordered behind this worker's stream alone
     // would read pin_out before the lent stream's traversal has written it.
-    for (const Shard& s : e->shards) {
-      Worker* w = ShardWorker(e, s);
-      if (w->site_ready) continue;
-      w->one_shot = 0;
-      w->lent_walk = w->lent_setup = nullptr;
-      w->reserve_cus = 0;
-      const int rc = WorkerSiteGradientSecondPass(w, rooted, node_count, branch_lengths + (size_t)s.t0 * M,
-                                                  has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr, rescaling,
-                                                  out_site + s.t0);
-      if (rc) return Propagate(e, w, rc);
-    }
+    // With several slots every slot's blocks go from the slot's own thread (round 5: they went slot after slot from the
+    // calling thread -- eight GPUs took turns at a pass each could run at once).
+    auto second_pass = [&](const std::vector<size_t>& mine, Outcome* oc) {
+      for (size_t k : mine) {
+        const Shard& s = e->shards[k];
+        Worker* w = ShardWorker(e, s);
+        if (w->site_ready) continue;
+        if (threaded) (void)hipSetDevice(e->devices[(size_t)s.slot]);
+        w->one_shot = 0;
+        w->lent_walk = w->lent_setup = nullptr;
+        w->reserve_cus = 0;
+        stamp("second pass (site-model gradient) of", k);
+        const int rc = WorkerSiteGradientSecondPass(w, rooted, node_count, branch_lengths + (size_t)s.t0 * M,
+                                                    has_rates ? rates + (size_t)s.t0 * (M - 1) : nullptr, rescaling,
+                                                    out_site + s.t0);
+        stamp("second pass done of", k);
+        if (rc) {
+          oc->rc = rc;
+          oc->worker = w;
+          oc->t0 = s.t0;
+          return;
+        }
+      }
+    };
+    std::vector<Outcome> passes(lists.size());
+    if (!threaded)
+      second_pass(lists[0], &passes[0]);
+    else
+      e->slot_pool->Run([&](int slot) {
+        if (!lists[(size_t)slot].empty()) second_pass(lists[(size_t)slot], &passes[(size_t)slot]);
+      });
+    const Outcome* bad = nullptr;
+    for (const Outcome& oc : passes)
+      if (oc.rc && (!bad || oc.t0 < bad->t0)) bad = &oc;
+    if (bad) return Propagate(e, bad->worker, bad->rc);
   }
   e->resident = true;  // (only once nothing can fail any more)
   e->rooted = rooted;

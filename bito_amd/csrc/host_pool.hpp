@@ -17,6 +17,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -120,6 +121,136 @@ class HostPool {
   const std::function<void(int)>* job_ = nullptr;
   bool stop_ = false;
   std::atomic<long long> armed_until_{0};  // steady-clock nanoseconds
+};
+
+// SharedPool -- helper threads that SEVERAL issuing threads hand ranges to at once.
+//
+// An engine over several device slots drives every slot from a host thread of its own (engine.cpp; the reference runs a
+// thread per FatBeagle instance, src/task_processor.hpp:43-140).  Each of those threads has chunks of a thousand trees
+// and more to check and pack (0.06 us per tree: 0.33 ms for a 5376-tree chunk on one thread) while its GPU waits for
+// the chunk -- HostPool above serves ONE caller at a time, so a slot thread packed its chunks alone.  Here every caller
+// publishes a job of `count` independent items; the helpers and the caller itself claim items by an atomic counter until
+// none is left, and the caller returns when all of its items are done.  A job lives in a shared_ptr that the helpers
+// copy under the pool's mutex, so a helper that arrives late at a finished job touches nothing that is gone.
+class SharedPool {
+ public:
+  explicit SharedPool(int helpers) {
+    for (int i = 0; i < helpers; i++) threads_.emplace_back([this] { Loop(); });
+  }
+  ~SharedPool() {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      stop_ = true;
+      epoch_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  SharedPool(const SharedPool&) = delete;
+  SharedPool& operator=(const SharedPool&) = delete;
+
+  int helpers() const { return (int)threads_.size(); }
+
+  // fn(item) for item = 0 .. count - 1, each exactly once, on the calling thread and whatever helpers are free;
+  // returns when every item is done.  Safe to call from several threads at the same time.
+  void Run(int count, const std::function<void(int)>& fn) {
+    if (count <= 0) return;
+    if (threads_.empty() || count == 1) {
+      for (int i = 0; i < count; i++) fn(i);
+      return;
+    }
+    auto job = std::make_shared<Job>();
+    job->fn = &fn;
+    job->count = count;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      jobs_.push_back(job);
+      epoch_.fetch_add(1, std::memory_order_release);
+      const long long until = Now() + kLingerNs;
+      if (armed_until_.load(std::memory_order_relaxed) < until) armed_until_.store(until, std::memory_order_relaxed);
+    }
+    cv_.notify_all();
+    Work(*job);
+    while (job->done.load(std::memory_order_acquire) != count) CpuPause();
+    std::lock_guard<std::mutex> lock(mu_);
+    for (size_t k = 0; k < jobs_.size(); k++)
+      if (jobs_[k] == job) {
+        jobs_.erase(jobs_.begin() + (long)k);
+        break;
+      }
+  }
+
+  // wakes the helpers ahead of the first job of a call: they poll for work for `linger`
+  void Arm(std::chrono::microseconds linger = std::chrono::microseconds(8000)) {
+    if (threads_.empty()) return;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      const long long until = Now() + std::chrono::duration_cast<std::chrono::nanoseconds>(linger).count();
+      if (armed_until_.load(std::memory_order_relaxed) < until) armed_until_.store(until, std::memory_order_relaxed);
+      epoch_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+  }
+
+ private:
+  struct Job {
+    const std::function<void(int)>* fn = nullptr;
+    int count = 0;
+    std::atomic<int> next{0}, done{0};
+  };
+  static long long Now() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+  // claims items of the job until none is left; true when it ran at least one
+  static bool Work(Job& job) {
+    bool any = false;
+    for (;;) {
+      const int i = job.next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= job.count) return any;
+      (*job.fn)(i);
+      job.done.fetch_add(1, std::memory_order_release);
+      any = true;
+    }
+  }
+  std::shared_ptr<Job> Pick() {  // a job that still has unclaimed items
+    std::lock_guard<std::mutex> lock(mu_);
+    for (const auto& j : jobs_)
+      if (j->next.load(std::memory_order_relaxed) < j->count) return j;
+    return nullptr;
+  }
+  void Loop() {
+    unsigned seen = epoch_.load(std::memory_order_acquire);
+    for (;;) {
+      if (std::shared_ptr<Job> job = Pick()) {
+        Work(*job);
+        continue;
+      }
+      if (Now() <= armed_until_.load(std::memory_order_relaxed)) {  // armed: poll
+        if (stop_flag()) return;
+        CpuPause();
+        continue;
+      }
+      std::unique_lock<std::mutex> lock(mu_);
+      if (stop_) return;
+      cv_.wait(lock, [&] { return stop_ || epoch_.load(std::memory_order_acquire) != seen; });
+      if (stop_) return;
+      seen = epoch_.load(std::memory_order_acquire);
+    }
+  }
+  bool stop_flag() {
+    std::lock_guard<std::mutex> lock(mu_);
+    return stop_;
+  }
+
+  static constexpr long long kLingerNs = 1500000;  // helpers keep polling 1.5 ms after the last job was published
+
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<std::shared_ptr<Job>> jobs_;
+  std::atomic<unsigned> epoch_{0};
+  std::atomic<long long> armed_until_{0};
+  bool stop_ = false;
 };
 
 }  // namespace bito_amd

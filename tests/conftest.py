@@ -26,7 +26,7 @@ def data_dir():
 # green under the driver before goes first and the tests of code whose device side changed in a round that had no GPU
 # access to check it (round 5: the GP executor's scheduled launches, gp_engine.hip) go last -- a failure there must not
 # hide the results of everything else.  Within a group the order is pytest's own.
-RUN_LAST = ("test_gp.py", "test_nni.py", "test_tp.py")
+RUN_LAST = ("test_round5_host.py", "test_gp.py", "test_nni.py", "test_tp.py")
 
 
 def pytest_collection_modifyitems(config, items):

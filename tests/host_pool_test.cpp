@@ -43,6 +43,37 @@ int main() {
       bad++;
     }
   }
+  // SharedPool: several issuing threads hand jobs to the same helpers at once; every item of every job exactly once,
+  // a caller returns only when all of its own items are done (helpers asleep, armed or lingering alike)
+  for (int helpers : {0, 2, 5}) {
+    bito_amd::SharedPool shared(helpers);
+    const int clients = 4;
+    std::atomic<int> wrong{0};
+    std::vector<std::thread> issuers;
+    for (int c = 0; c < clients; c++)
+      issuers.emplace_back([&, c] {
+        for (int job = 0; job < 1500; job++) {
+          const int count = 1 + (job * 7 + c) % 23;
+          std::vector<std::atomic<int>> hits((size_t)count);
+          for (auto& h : hits) h.store(0);
+          if (job % 11 == 0) shared.Arm(std::chrono::microseconds(100));
+          if (job % 400 == 399) std::this_thread::sleep_for(std::chrono::milliseconds(3));  // (the helpers fall asleep)
+          long sum = 0;
+          std::atomic<long> total{0};
+          shared.Run(count, [&](int item) {
+            hits[(size_t)item].fetch_add(1);
+            total.fetch_add(item + 1);
+          });
+          for (int i = 0; i < count; i++) {
+            sum += i + 1;
+            if (hits[(size_t)i].load() != 1) wrong.fetch_add(1);
+          }
+          if (total.load() != sum) wrong.fetch_add(1);
+        }
+      });
+    for (auto& t : issuers) t.join();
+    bad += wrong.load();
+  }
   std::printf("host_pool_test: %d bad\n", bad);
   return bad ? 1 : 0;
 }
