@@ -91,10 +91,12 @@ class OracleGPEngine:
     def increment_optimization_count(self):
         lib().gp_oracle_increment_optimization_count(self._h)
 
-    # test instruments: every function evaluation of the Brent optimiser as rows (edge, x, f, kind), and a relative
+    # test instruments: every function evaluation of the Brent optimiser as rows (edge, x, f, kind, margins), and a relative
     # perturbation of the evaluations' values (what rounding noise of that size does to the iterates)
     def start_optimizer_trace(self, capacity=1 << 16):
-        self._trace = np.zeros((capacity, 4))
+        """rows of 6: edge, x, f, kind, the smallest relative margin of the comparisons that chose the point, the
+        smallest |difference| of the comparisons of its value with the best points so far (gp_oracle.c)"""
+        self._trace = np.zeros((capacity, 6))
         lib().gp_oracle_set_trace(self._h, self._trace.ctypes.data_as(C.POINTER(C.c_double)), capacity)
 
     def optimizer_trace(self):

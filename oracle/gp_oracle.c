@@ -55,9 +55,12 @@ typedef struct {
   int opt_count;     /* optimization_count_ */
   int significant_digits;
   /* test instruments (not part of the reference): a record of every function evaluation the Brent optimiser makes --
-   * rows of (edge, x = log branch length, f = negative log-likelihood, kind: 0 the handler's own evaluation of the
-   * current length, 1 Brent's first point, 2 a trial point u, 3 the gradient variant's second trial) -- and a relative
-   * perturbation of every evaluation's value, to measure what rounding noise of a given size does to the iterates */
+   * rows of 6: (edge, x = log branch length, f = negative log-likelihood, kind: 0 the handler's own evaluation of the
+   * current length, 1 Brent's first point, 2 a trial point u, 3 the gradient variant's second trial; then how far from a
+   * tie the decisions around this evaluation were: [4] the comparisons that CHOSE the point (convergence test, parabola
+   * against golden section, clamps), smallest |lhs - rhs| / max(|lhs|, |rhs|), [5] the comparisons of its VALUE with the
+   * best three points so far, smallest |difference|) -- and a relative perturbation of every evaluation's value, to
+   * measure what rounding noise of a given size does to the iterates */
   double *trace;
   int trace_capacity, trace_rows;
   double noise;
@@ -426,13 +429,27 @@ void gp_oracle_set_eval_noise(gp_oracle *g, double relative, uint64_t seed) {
   g->noise = relative;
   g->noise_state = seed * 0x9E3779B97F4A7C15ull + 1;
 }
+static double g_trace_pre_margin = INFINITY; /* set by brent_minimize ahead of the evaluation it belongs to */
+static double *g_trace_last_row = NULL;      /* the row of the last evaluation: its value margin is filled in afterwards */
 static void trace_row(const opt_ctx *c, double x, double f, int kind) {
   gp_oracle *g = c->g;
+  g_trace_last_row = NULL;
   if (g->trace && g->trace_rows < g->trace_capacity) {
-    double *row = g->trace + 4 * (size_t)g->trace_rows;
-    row[0] = c->edge; row[1] = x; row[2] = f; row[3] = kind;
+    double *row = g->trace + 6 * (size_t)g->trace_rows;
+    row[0] = c->edge; row[1] = x; row[2] = f; row[3] = kind; row[4] = g_trace_pre_margin; row[5] = INFINITY;
+    g_trace_last_row = row;
   }
   if (g->trace) g->trace_rows++;
+  g_trace_pre_margin = INFINITY;
+}
+static void margin_of(double lhs, double rhs) { /* one comparison lhs ? rhs of the iteration in progress */
+  const double scale = fmax(fabs(lhs), fabs(rhs));
+  if (!(scale > 0)) return; /* 0 against 0 (the first parabola: v = w = x) falls the same way whatever the rounding */
+  const double m = fabs(lhs - rhs) / scale;
+  if (m < g_trace_pre_margin) g_trace_pre_margin = m;
+}
+static void value_margin(double a, double b) {
+  if (g_trace_last_row && fabs(a - b) < g_trace_last_row[5]) g_trace_last_row[5] = fabs(a - b);
 }
 
 /* brent_nongrad_func / brent_grad_func (src/gp_engine.cpp:605-625): x is the LOG branch length */
@@ -475,8 +492,15 @@ static void brent_minimize(const opt_ctx *c, int with_gradients, double guess, d
     mid = (min + max) / 2;
     fract1 = tolerance * fabs(x) + tolerance / 4;
     fract2 = 2 * fract1;
-    if (fabs(x - mid) <= (fract2 - (max - min) / 2)) break;
-    int use_bisection = 1;
+    margin_of(fabs(x - mid), fract2 - (max - min) / 2);
+    if (fabs(x - mid) <= (fract2 - (max - min) / 2)) {
+      /* (no evaluation follows: the margin of the decision to stop goes with the last evaluation made) */
+      if (g_trace_last_row && g_trace_pre_margin < g_trace_last_row[4]) g_trace_last_row[4] = g_trace_pre_margin;
+      g_trace_pre_margin = INFINITY;
+      break;
+    }
+    int use_bisection = 1, clamped = 0;
+    margin_of(fabs(delta2), fract1);
     if (fabs(delta2) > fract1) {
       double r = (x - w) * (fx - fv);
       double q = (x - v) * (fx - fw);
@@ -486,19 +510,33 @@ static void brent_minimize(const opt_ctx *c, int with_gradients, double guess, d
       q = fabs(q);
       const double td = delta2;
       delta2 = delta;
+      margin_of(fabs(p), fabs(q * td / 2));
+      if (!(fabs(p) >= fabs(q * td / 2))) {
+        margin_of(p, q * (min - x));
+        if (!(p <= q * (min - x))) margin_of(p, q * (max - x));
+      }
       if (!(fabs(p) >= fabs(q * td / 2)) && !(p <= q * (min - x)) && !(p >= q * (max - x))) {
         delta = p / q;
         u = x + delta;
-        if (((u - min) < fract2) || ((max - u) < fract2)) delta = (mid - x) < 0 ? -fabs(fract1) : fabs(fract1);
+        margin_of(u - min, fract2);
+        margin_of(max - u, fract2);
+        if (((u - min) < fract2) || ((max - u) < fract2)) {
+          margin_of(mid, x);
+          delta = (mid - x) < 0 ? -fabs(fract1) : fabs(fract1);
+          clamped = 1; /* (|delta| = fract1 exactly: the comparison below is no decision) */
+        }
         use_bisection = 0;
       }
     }
     if (use_bisection) {
+      margin_of(x, mid);
       delta2 = (x >= mid) ? min - x : max - x;
       delta = golden * delta2;
     }
+    if (!clamped) margin_of(fabs(delta), fract1);
     u = (fabs(delta) >= fract1) ? x + delta : (delta > 0 ? x + fabs(fract1) : x - fabs(fract1));
     fu = neg_ll(c, u);
+    value_margin(fu, fx);
     int accepted = 0;
     if (fu <= fx) {
       if (u >= x) min = x; else max = x;
@@ -512,6 +550,7 @@ static void brent_minimize(const opt_ctx *c, int with_gradients, double guess, d
       g_trace_kind = 3;
       const double fu2 = neg_ll(c, u2);
       g_trace_kind = 2;
+      value_margin(fu2, fx);
       if (fu2 <= fx) {
         if (u2 >= x) min = x; else max = x;
         v = w; w = x; x = u2;
@@ -521,12 +560,16 @@ static void brent_minimize(const opt_ctx *c, int with_gradients, double guess, d
     }
     if (!accepted) {
       if (u < x) min = u; else max = u;
+      if (!(w == x)) value_margin(fu, fw);
       if ((fu <= fw) || (w == x)) {
         v = w; w = u;
         fv = fw; fw = fu;
-      } else if ((fu <= fv) || (v == x) || (v == w)) {
-        v = u;
-        fv = fu;
+      } else {
+        if (!(v == x) && !(v == w)) value_margin(fu, fv);
+        if ((fu <= fv) || (v == x) || (v == w)) {
+          v = u;
+          fv = fu;
+        }
       }
     }
   } while (--count);

@@ -14,8 +14,17 @@ import numpy as np
 # The bar on a trial point: |dx| <= X_TOL + T_TOL / t  (1e-6 in the log length where the length is 1e-4 and more,
 # growing to 1e-4 at the lower bound of the lengths, 9e-7).
 X_TOL, T_TOL = 1e-6, 1e-10
-TIE = 1e-9  # a decision fu <= fx is "within rounding of a tie" when |fu - fx| <= TIE + 1e-13 |fx| (f itself is known to
-# about 1e-15 relative: two hundred times less on the workloads of the tests)
+# Near-ties.  Two kinds of decision make Brent's path: comparisons of function values (fu <= fx, <= fw, <= fv) -- a near-tie
+# when the values are within VALUE_TIE + 1e-13 |f| of each other (f itself is known to about 1e-15 relative: two hundred
+# times less on the workloads of the tests) -- and the comparisons that choose the next point: the convergence test, the
+# three tests that accept or reject the parabolic step, the clamps.  Those are formed from DIFFERENCES of function values,
+# so rounding noise reaches them amplified; they are near-ties below CHOICE_TIE relative.  One of them is a tie BY
+# CONSTRUCTION: a parabolic step that was rejected as a point (worse than the three best) becomes the new bound, the next
+# iteration fits the same parabola through the same three points, and `p >= q * (max - x)` compares p with q * (p / q)
+# (src/optimization.hpp:121-123) -- hello's edge 3 does it; which way it falls is decided by the last bit of the
+# function values, in the reference binary as in any restatement, and the two continuations end Brent's own tolerance
+# apart (2^-9 relative in the log length).  The CPU checker records both margins with every evaluation (rows of 6).
+VALUE_TIE, CHOICE_TIE = 1e-9, 1e-7
 
 
 def by_edge(trace):
@@ -30,32 +39,38 @@ def by_edge(trace):
     return {e: [np.array(r) for r in rs] for e, rs in runs.items()}
 
 
-def first_tie(run):  # (diagnostic scripts)
-    """index of the first trial point of a run whose accept / reject decision is within rounding of a tie, or None"""
-    best = None
-    for k, (_, _, f, kind) in enumerate(run):
+def tie_rows(run):
+    """indices of a reference run's evaluations around which a decision was a near-tie (rows of 6 with the checker's
+    margins; for rows of 4 the value comparisons with the best point so far only)"""
+    ties, best = [], None
+    for j, row in enumerate(run):
+        f, kind = row[2], row[3]
+        if len(row) >= 6:
+            if row[4] <= CHOICE_TIE or row[5] <= VALUE_TIE + 1e-13 * abs(f):
+                ties.append(j)
+            continue
         if kind == 0:
             continue
         if kind == 1 or best is None:
             best = f
             continue
-        if abs(f - best) <= TIE + 1e-13 * abs(best):
-            return k
+        if abs(f - best) <= VALUE_TIE + 1e-13 * abs(best):
+            ties.append(j)
         if f <= best:
             best = f
-    return None
+    return ties
 
 
 def compare(reference, other, x_tol=X_TOL, t_tol=T_TOL):
     """Returns (problems, stats).  problems: strings, empty when `other` follows `reference` -- per edge and run the same
     number of evaluations of the same kinds at points within x_tol + t_tol / length in the log length.  A difference that
-    shows up AFTER a near-tie decision of the reference run (in the order the reference optimised the edges: a flipped
-    decision changes every later edge of a sweep) is explained by it: the comparison stops there without a problem and
-    stats["explained_at"] says where.  stats: evaluations compared / in all, largest |dx|, |dt|, |df|, near-ties met."""
+    shows up at or after a near-tie decision of the reference run (in the order the reference optimised the edges: a
+    flipped decision changes every later edge of a sweep) is explained by it: the comparison stops there without a problem
+    and stats["explained_at"] says where.  stats: evaluations compared / in all, largest |dx|, |dt|, |df|, near-ties met."""
     ref, oth = by_edge(reference), by_edge(other)
     problems = []
     stats = {"rows": int(len(reference)), "compared": 0, "max_dx": 0.0, "max_dt": 0.0, "max_df": 0.0, "ties": 0,
-             "smallest_margin": float("inf"), "explained_at": None}
+             "smallest_choice_margin": float("inf"), "smallest_value_margin": float("inf"), "explained_at": None}
     order, seen = [], {}
     for row in np.asarray(reference):
         if row[3] == 0:
@@ -66,20 +81,10 @@ def compare(reference, other, x_tol=X_TOL, t_tol=T_TOL):
     for e, k in order:
         a = ref[e][k]
         b = oth[e][k] if e in oth and k < len(oth[e]) else np.zeros((0, 4))
-        # where this run's decisions are near-ties
-        ties, best = [], None
-        for j, (_, _, f, kind) in enumerate(a):
-            if kind == 0:
-                continue
-            if kind == 1 or best is None:
-                best = f
-                continue
-            margin = abs(f - best)
-            stats["smallest_margin"] = min(stats["smallest_margin"], margin)
-            if margin <= TIE + 1e-13 * abs(best):
-                ties.append(j)
-            if f <= best:
-                best = f
+        ties = tie_rows(a)
+        if a.shape[1] >= 6:
+            stats["smallest_choice_margin"] = min(stats["smallest_choice_margin"], float(a[:, 4].min()))
+            stats["smallest_value_margin"] = min(stats["smallest_value_margin"], float(a[:, 5].min()))
         stats["ties"] += len(ties)
         mismatch = None  # (index, message)
         for j in range(max(len(a), len(b))):
@@ -100,7 +105,8 @@ def compare(reference, other, x_tol=X_TOL, t_tol=T_TOL):
             stats["max_dt"] = max(stats["max_dt"], float(dt))
             stats["max_df"] = max(stats["max_df"], float(abs(a[j, 2] - b[j, 2])))
         if mismatch is not None:
-            if tie_seen or any(t < mismatch[0] for t in ties):
+            # (a near-tie around evaluation t decides evaluation t itself -- the comparisons that chose it -- or t + 1)
+            if tie_seen or any(t <= mismatch[0] for t in ties):
                 stats["explained_at"] = mismatch[1]
                 break
             problems.append(mismatch[1])

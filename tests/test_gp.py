@@ -675,7 +675,7 @@ def test_brent_trace_comparison(data_dir):
         assert not problems, problems[:3]
         # Brent's decisions are far from ties (8e-7 at the least on DS1): nothing is left uncompared
         assert stats["explained_at"] is None and stats["compared"] == stats["rows"] == len(noisy)
-        assert stats["ties"] == 0 and stats["smallest_margin"] > 1e-8
+        assert stats["ties"] == 0 and stats["smallest_value_margin"] > 1e-8 and stats["smallest_choice_margin"] > 1e-5
         assert np.abs(bl_clean - bl_noisy).max() < 1e-9
         rough, _ = _traced_sweep(_oracle_factory, sp_, dag_, bl0, gp.BRENT, noise=1e-7)
         problems, _ = gp_trace.compare(clean, rough)
@@ -711,25 +711,23 @@ def test_device_brent_follows_the_checkers_iterates(data_dir):
         gpu, bl_gpu = _traced_sweep(_gpu_factory, sp_, dag_, bl0, gp.BRENT, sweeps=sweeps)
         problems, stats = gp_trace.compare(cpu, gpu)
         assert not problems, (name, problems[:3], stats)
-        # (no decision of the checker's run is near a tie on these workloads: nothing may be left uncompared)
-        assert stats["ties"] == 0 and stats["compared"] == len(cpu) == len(gpu), (name, stats)
-        assert np.abs(bl_gpu - bl_cpu).max() < 1e-8, name
+        if name == "hello":
+            # its edge 3 meets the tie Brent has by construction (tests/gp_trace.py: a rejected parabolic step becomes the
+            # bound, the same parabola is fitted again and p is compared with q * (p / q)): from there on the two runs may
+            # part, and end Brent's own tolerance apart (2^-9 relative in the log length and 2^-11)
+            assert stats["ties"] == 1 and stats["compared"] >= 35, stats
+            assert np.all(np.abs(np.log(bl_gpu[1:]) - np.log(bl_cpu[1:])) <= 4 * (2.0 ** -9 * np.abs(np.log(bl_cpu[1:])) + 2.0 ** -11))
+        else:
+            # no decision of the checker's run is near a tie on these workloads (the comparisons that choose a point are 1e-4
+            # relative from one at the least, the values 7e-7): nothing may be left uncompared
+            assert stats["ties"] == 0 and stats["compared"] == len(cpu) == len(gpu), (name, stats)
+            assert np.abs(bl_gpu - bl_cpu).max() < 1e-8, name
 
 
-@pytest.mark.gpu
-def test_scheduled_sweep_is_bitwise_the_sequential_one():
-    """The executor runs a branch-length optimisation sweep in the order of gp_schedule.hpp (the optimisations of equal
-    optimiser depth as concurrent workgroups of one launch: 56 launches instead of 118 on the DS1 ten-tree DAG); the same
-    arithmetic on the same inputs, so the branch lengths, their changes and the per-GPCSP log-likelihoods are those of
-    the one-optimisation-per-launch route in stream order (BITO_AMD_GP_SCHEDULE=0) bit for bit -- Brent, Brent with
-    gradients and Newton (reference schedule: src/gp_dag.cpp:78-121; optimisers: src/optimization.hpp:71-417), without
-    and with rescaling in play, and on the 970-edge DAG of twenty seeded topologies."""
+def _scheduled_and_sequential_sweeps_agree(cases, methods):
     import os
 
-    from bito_amd import workloads
-
-    for (dag, sp), threshold in ((workloads.ds1_subsplit_dag(10), 1e-40), (workloads.ds1_subsplit_dag(10), 1e-4),
-                                 (workloads.seeded_subsplit_dag(20), 1e-40)):
+    for (dag, sp), threshold in cases:
         bl0 = np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)
         results = {}
         for scheduled in ("1", "0"):
@@ -738,7 +736,7 @@ def test_scheduled_sweep_is_bitwise_the_sequential_one():
                 eng = gp.GPEngine(sp.patterns, sp.weights, dag.node_count, dag.gpcsp_count, threshold)
                 eng.set_sbn_parameters(dag.uniform_on_topological_support_prior())
                 out = []
-                for method in (gp.BRENT, gp.BRENT_WITH_GRADIENTS, gp.NEWTON):
+                for method in methods:
                     eng.set_optimization_method(method)
                     eng.set_branch_lengths(bl0)
                     eng.reset_optimization_count()
@@ -756,3 +754,18 @@ def test_scheduled_sweep_is_bitwise_the_sequential_one():
             for x, y in zip(a, b):
                 assert np.array_equal(x, y)
         assert np.abs(results["1"][0][0] - bl0).max() > 1e-3  # (the sweep did move the lengths)
+
+
+@pytest.mark.gpu
+def test_scheduled_sweep_is_bitwise_the_sequential_one():
+    """The executor runs a branch-length optimisation sweep in the order of gp_schedule.hpp (the optimisations of equal
+    optimiser depth as concurrent workgroups of one launch: 56 launches instead of 118 on the DS1 ten-tree DAG); the same
+    arithmetic on the same inputs, so the branch lengths, their changes and the per-GPCSP log-likelihoods are those of
+    the one-optimisation-per-launch route in stream order (BITO_AMD_GP_SCHEDULE=0) bit for bit -- Brent, Brent with
+    gradients and Newton (reference schedule: src/gp_dag.cpp:78-121; optimisers: src/optimization.hpp:71-417), without
+    and with rescaling in play, and on the 970-edge DAG of twenty seeded topologies."""
+    from bito_amd import workloads
+
+    _scheduled_and_sequential_sweeps_agree(((workloads.ds1_subsplit_dag(10), 1e-40), (workloads.ds1_subsplit_dag(10), 1e-4),
+                                            (workloads.seeded_subsplit_dag(20), 1e-40)),
+                                           (gp.BRENT, gp.BRENT_WITH_GRADIENTS, gp.NEWTON))
