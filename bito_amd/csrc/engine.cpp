@@ -311,8 +311,10 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
            (size_t)s.count * (want_gradient && out_grad ? N + 1 : 1) * sizeof(double) >= e->par_min_bytes;
   };
   auto big_copy = [&](const Shard& s) { return !threaded && big_block(s); };
-  // several issuing threads: ranges of about 512 trees, claimed by the thread itself and the shared helpers
-  auto shared_parts = [&](int count) { return std::max(1, std::min(Shared(e)->helpers() + 1, count / 512)); };
+  // several issuing threads: ranges of half the threshold (512 trees), claimed by the thread itself and the shared helpers
+  auto shared_parts = [&](int count) {
+    return std::max(1, std::min(Shared(e)->helpers() + 1, count / std::max(1, e->par_min_trees / 2)));
+  };
   auto drain = [&](size_t k) -> int {
     const Shard& s = e->shards[k];
     Worker* w = ShardWorker(e, s);

@@ -20,6 +20,8 @@
 #error "tests/hip_emu switches fibers with x86-64 System V assembly"
 #endif
 
+#include <time.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -62,6 +64,55 @@ inline hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyK
 inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(dst, src, bytes, k); }
 inline hipError_t hipMemset(void* dst, int value, size_t bytes) { std::memset(dst, value, bytes); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t = nullptr) { return hipMemset(dst, value, bytes); }
+inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned = 0) {
+  *p = nullptr;
+  return posix_memalign(p, 4096, bytes ? bytes : 1) == 0 ? hipSuccess : hipErrorOutOfMemory;
+}
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+inline hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes) {
+  *free_bytes = (size_t)6 << 30;  // (what an arena may plan with on the CPU)
+  *total_bytes = (size_t)8 << 30;
+  return hipSuccess;
+}
+struct hipDeviceProp_t {
+  char gcnArchName[64];
+  int multiProcessorCount;
+  size_t totalGlobalMem;
+};
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+  std::snprintf(p->gcnArchName, sizeof(p->gcnArchName), "cpu-emulation");
+  p->multiProcessorCount = 1;
+  p->totalGlobalMem = (size_t)8 << 30;
+  return hipSuccess;
+}
+// streams and events: handles without behaviour (every command has completed when its call returns); an event keeps
+// the time of its record for hipEventElapsedTime
+struct hipEmuStream { int unused; };
+struct hipEmuEvent { double ms; };
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipEmuStream{0}; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEmuEvent{0}; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  e->ms = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  return hipSuccess;
+}
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->ms - a->ms); return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <typename F>
+inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+
 inline hipError_t hipMemcpy2D(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind) {
   for (size_t r = 0; r < height; r++) std::memmove((char*)dst + r * dpitch, (const char*)src + r * spitch, width);
   return hipSuccess;
@@ -112,13 +163,21 @@ struct Block {
   unsigned generation = 0;
   // per wave: exchange slots of the shuffles and a barrier of the wave's live lanes
   struct Wave {
-    double slot[kWave];
     uint64_t bits[kWave];
-    int arrived = 0, live = 0;
+    bool present[kWave];
+    int arrived = 0, live = 0, lanes = 0;  // lanes: threads the wave was launched with
     unsigned generation = 0;
   };
   std::vector<Wave> waves;
 };
+
+// the launch's dynamic LDS (`extern __shared__ T name[];` becomes `T* name = (T*)hip_emu::DynamicShared();` in the copies
+// of the sources the emulated build compiles, tests/hip_emu/prepare.py)
+inline std::vector<double>& DynamicStore() {
+  static thread_local std::vector<double> store;
+  return store;
+}
+inline void* DynamicShared() { return DynamicStore().data(); }
 
 inline Block*& Current() {
   static thread_local Block* b = nullptr;
@@ -200,7 +259,10 @@ inline void RunBlock(const std::function<void()>& body, dim3 block) {
   b.fibers.resize((size_t)count);
   b.live = count;
   b.waves.resize((size_t)(count + kWave - 1) / kWave);
-  for (int t = 0; t < count; t++) b.waves[(size_t)t / kWave].live++;
+  for (int t = 0; t < count; t++) {
+    b.waves[(size_t)t / kWave].live++;
+    b.waves[(size_t)t / kWave].lanes++;
+  }
   Current() = &b;
   std::vector<char*>& pool = StackPool();
   while ((int)pool.size() < count) pool.push_back(static_cast<char*>(std::malloc(kStack)));
@@ -242,9 +304,10 @@ inline void RunBlock(const std::function<void()>& body, dim3 block) {
 }
 
 template <typename F>
-inline void Launch(F&& body_of_thread, dim3 grid, dim3 block) {
+inline void Launch(F&& body_of_thread, dim3 grid, dim3 block, size_t shared_bytes) {
   std::lock_guard<std::mutex> lock(LaunchMutex());
   const std::function<void()> body = body_of_thread;
+  DynamicStore().assign(shared_bytes / sizeof(double) + 2, 0.0);
   gridDim = grid;
   blockDim = block;
   for (unsigned z = 0; z < grid.z; z++)
@@ -258,7 +321,7 @@ inline void Launch(F&& body_of_thread, dim3 grid, dim3 block) {
 }  // namespace hip_emu
 
 #define hipLaunchKernelGGL(kernel, grid, block, shared_bytes, stream, ...) \
-  hip_emu::Launch([=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
+  hip_emu::Launch([=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (size_t)(shared_bytes))
 
 inline void __syncthreads() { hip_emu::BlockBarrier(); }
 inline void __threadfence() {}
@@ -266,38 +329,153 @@ inline void __threadfence_block() {}
 inline void __threadfence_system() {}
 
 template <typename T>
-inline T __shfl_xor(T v, int mask) {
-  static_assert(sizeof(T) <= 8, "shuffle of a wider type");
-  hip_emu::Block* b = hip_emu::Current();
-  const int lin = hip_emu::Linear(), lane = lin % hip_emu::kWave;
-  hip_emu::Block::Wave& w = b->waves[(size_t)lin / hip_emu::kWave];
+inline T __shfl(T v, int src);
+template <typename T>
+inline T __shfl_xor(T v, int mask);
+// every lane of the wave publishes a 64-bit value; returns the wave's array (valid until the lane's next wave operation)
+namespace hip_emu {
+inline const uint64_t* Publish(uint64_t mine) {
+  Block* b = Current();
+  const int lin = Linear(), lane = lin % kWave;
+  Block::Wave& w = b->waves[(size_t)lin / kWave];
+  WaveBarrier();  // (the readers of the exchange before are done)
+  w.bits[lane] = mine;
+  w.present[lane] = true;
+  WaveBarrier();
+  return w.bits;
+}
+inline int Lane() { return Linear() % kWave; }
+template <typename T>
+inline T ReadFirstLane(T v) {
   uint64_t raw = 0;
   std::memcpy(&raw, &v, sizeof(T));
-  w.bits[lane] = raw;
-  hip_emu::WaveBarrier();
-  const uint64_t got = w.bits[(lane ^ mask) & (hip_emu::kWave - 1)];
-  hip_emu::WaveBarrier();
+  const uint64_t got = Publish(raw)[0];
   T out;
   std::memcpy(&out, &got, sizeof(T));
   return out;
 }
+}  // namespace hip_emu
 template <typename T>
 inline T __shfl(T v, int src) {
-  hip_emu::Block* b = hip_emu::Current();
-  const int lin = hip_emu::Linear(), lane = lin % hip_emu::kWave;
-  hip_emu::Block::Wave& w = b->waves[(size_t)lin / hip_emu::kWave];
+  static_assert(sizeof(T) <= 8, "shuffle of a wider type");
   uint64_t raw = 0;
   std::memcpy(&raw, &v, sizeof(T));
-  w.bits[lane] = raw;
-  hip_emu::WaveBarrier();
-  const uint64_t got = w.bits[src & (hip_emu::kWave - 1)];
-  hip_emu::WaveBarrier();
+  const uint64_t got = hip_emu::Publish(raw)[src & (hip_emu::kWave - 1)];
   T out;
   std::memcpy(&out, &got, sizeof(T));
   return out;
 }
 template <typename T>
-inline T __builtin_amdgcn_readfirstlane_emu(T v) { return __shfl(v, 0); }
+inline T __shfl_xor(T v, int mask) { return __shfl(v, hip_emu::Lane() ^ mask); }
+#define __builtin_amdgcn_readfirstlane(x) hip_emu::ReadFirstLane(x)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_ldexp(x, e) std::ldexp((double)(x), (int)(e))
+#define __builtin_amdgcn_rcp(x) (1.0 / (x))
+inline int hip_emu_frexp_exp(double x) {  // v_frexp_exp_i32_f64: 0 for zero, infinity and nan
+  if (x == 0.0 || !std::isfinite(x)) return 0;
+  int e = 0;
+  std::frexp(x, &e);
+  return e;
+}
+#define __builtin_amdgcn_frexp_exp(x) hip_emu_frexp_exp(x)
+
+inline uint64_t __ballot(int predicate) {
+  const uint64_t* all = hip_emu::Publish(predicate ? 1 : 0);
+  hip_emu::Block* b = hip_emu::Current();
+  const hip_emu::Block::Wave& w = b->waves[(size_t)hip_emu::Linear() / hip_emu::kWave];
+  uint64_t mask = 0;
+  for (int l = 0; l < hip_emu::kWave; l++)
+    if (l < w.lanes && all[l]) mask |= 1ull << l;
+  return mask;
+}
+inline int __all(int predicate) {
+  hip_emu::Block* b = hip_emu::Current();
+  const int lanes = b->waves[(size_t)hip_emu::Linear() / hip_emu::kWave].lanes;
+  const uint64_t want = lanes == 64 ? ~0ull : ((1ull << lanes) - 1);
+  return __ballot(predicate) == want;
+}
+inline int __any(int predicate) { return __ballot(predicate) != 0; }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+
+inline int __double2loint(double x) { uint64_t r; std::memcpy(&r, &x, 8); return (int)(uint32_t)r; }
+inline int __double2hiint(double x) { uint64_t r; std::memcpy(&r, &x, 8); return (int)(uint32_t)(r >> 32); }
+inline double __hiloint2double(int hi, int lo) {
+  const uint64_t r = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+  double x;
+  std::memcpy(&x, &r, 8);
+  return x;
+}
+
+// v_permlane32_swap / v_permlane16_swap (wave_sums.hpp): {new vdst, new vsrc}
+struct hip_emu_pair { int v[2]; int operator[](int i) const { return v[i]; } };
+inline hip_emu_pair __builtin_amdgcn_permlane32_swap(int vdst, int vsrc, bool, bool) {
+  const uint64_t* all = hip_emu::Publish(((uint64_t)(uint32_t)vdst << 32) | (uint32_t)vsrc);
+  const int lane = hip_emu::Lane();
+  hip_emu_pair r;
+  r.v[0] = lane < 32 ? vdst : (int)(uint32_t)all[lane - 32];           // upper half of vdst <- lower half of vsrc
+  r.v[1] = lane < 32 ? (int)(uint32_t)(all[lane + 32] >> 32) : vsrc;   // lower half of vsrc <- upper half of vdst
+  return r;
+}
+inline hip_emu_pair __builtin_amdgcn_permlane16_swap(int vdst, int vsrc, bool, bool) {
+  const uint64_t* all = hip_emu::Publish(((uint64_t)(uint32_t)vdst << 32) | (uint32_t)vsrc);
+  const int lane = hip_emu::Lane(), row = lane >> 4;
+  hip_emu_pair r;
+  r.v[0] = (row & 1) ? (int)(uint32_t)all[lane - 16] : vdst;           // odd rows of vdst <- even rows of vsrc
+  r.v[1] = (row & 1) ? vsrc : (int)(uint32_t)(all[lane + 16] >> 32);   // even rows of vsrc <- odd rows of vdst
+  return r;
+}
+// v_mov_b32 with DPP: row_shr:n (0x111-0x11f) and row_bcast:15 (0x142), the controls wave_sums.hpp uses; bank mask 0xf
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int, bool bound_ctrl) {
+  const uint64_t* all = hip_emu::Publish((uint32_t)src);
+  const int lane = hip_emu::Lane(), row = lane >> 4, in_row = lane & 15;
+  if (!((row_mask >> row) & 1)) return old;
+  if (ctrl >= 0x111 && ctrl <= 0x11f) {
+    const int n = ctrl - 0x110;
+    if (in_row >= n) return (int)(uint32_t)all[lane - n];
+    return bound_ctrl ? 0 : old;
+  }
+  if (ctrl == 0x142) return row > 0 ? (int)(uint32_t)all[row * 16 - 1] : old;
+  std::fprintf(stderr, "hip_emu: DPP control 0x%x is not emulated\n", ctrl);
+  std::abort();
+}
+
+// raw buffer instructions: a resource is a base address and a size; reads beyond it return zero, writes are dropped
+struct hip_emu_rsrc { char* base; uint32_t bytes; };
+#define __amdgpu_buffer_rsrc_t hip_emu_rsrc
+inline hip_emu_rsrc __builtin_amdgcn_make_buffer_rsrc(void* base, short, int num_records, int) {
+  return hip_emu_rsrc{static_cast<char*>(base), (uint32_t)num_records};
+}
+typedef unsigned hip_emu_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned hip_emu_u4 __attribute__((ext_vector_type(4)));
+template <typename T>
+inline T hip_emu_buffer_load(hip_emu_rsrc r, unsigned voffset, unsigned soffset) {
+  T out{};
+  const uint64_t at = (uint64_t)voffset + soffset;
+  if (at + sizeof(T) <= r.bytes) std::memcpy(&out, r.base + at, sizeof(T));
+  return out;
+}
+template <typename T>
+inline void hip_emu_buffer_store(T v, hip_emu_rsrc r, unsigned voffset, unsigned soffset) {
+  const uint64_t at = (uint64_t)voffset + soffset;
+  if (at + sizeof(T) <= r.bytes) std::memcpy(r.base + at, &v, sizeof(T));
+}
+#define __builtin_amdgcn_raw_buffer_load_b8(r, v, s, aux) hip_emu_buffer_load<unsigned char>(r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, aux) hip_emu_buffer_load<hip_emu_u2>(r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, aux) hip_emu_buffer_load<hip_emu_u4>(r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b64(x, r, v, s, aux) hip_emu_buffer_store<hip_emu_u2>(x, r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b128(x, r, v, s, aux) hip_emu_buffer_store<hip_emu_u4>(x, r, v, s)
+
+#define __HIP_MEMORY_SCOPE_SYSTEM 0
+#define __hip_atomic_store(ptr, value, order, scope) __atomic_store_n(ptr, value, order)
+
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct double2 { double x, y; };
+struct double4 { double x, y, z, w; };
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
 template <typename T>
 inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

@@ -1,0 +1,132 @@
+"""The per-tree engine -- engine.cpp, worker.cpp and the kernels that are plain HIP C++ (kernels.hip: set-up, transition
+matrices, walk_hbm_kernel, final sums; walk_hbm_cat.hip; time_tree.hip) -- executed on the CPU through the stand-in HIP
+runtime of tests/hip_emu, against the CPU checker.  walk_pipe_kernel (gfx950 assembly), the LDS walks and the general-state
+kernels are outside the emulated build: AUTO routes every batch to the HBM-arena walks here, the path the product takes
+for rescaling, five to eight rate categories and more than 64 taxa.  What this holds in a round without GPU access: the
+host side of a blocking call (chunks, device slots each on its own thread, the shared helper threads that pack large
+chunks, the site-model gradient's second pass from every slot's thread -- round 5's changes), and the logic of the
+HBM-arena kernels.  Small synthetic shapes: a tree costs a third of a second as fibers.  Each test runs in a process of its
+own (the library under test is chosen when bito_amd is first imported).  Test infrastructure: the product has no CPU path."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMU = os.path.join(HERE, "hip_emu", "_build", "libbito_amd_emu.so")
+
+PRELUDE = '''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+import bito_amd
+from bito_amd import _capi, workloads
+from oracle import oracle
+LL_ATOL, LL_RTOL, GRAD_ATOL, GRAD_RTOL = 1e-10, 2e-14, 1e-6, 1e-9
+def close(a, b, atol, rtol):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(np.all(np.abs(a - b) <= atol + rtol * np.abs(b)))
+def spec(w):
+    return bito_amd.PhyloModelSpecification(w.substitution, w.site, w.clock)
+def small(n, P, T, site="weibull+4"):
+    w = workloads.synthetic_gtr_weibull4(n, P, tree_count=T)
+    w.site = site
+    w.rescaling = False
+    if site == "constant":
+        w.params = np.ascontiguousarray(w.params[:, :10])
+    return w
+assert "cpu-emulation" in bito_amd.version()
+'''
+
+
+@pytest.fixture(scope="module")
+def emulated():
+    built = subprocess.run(["make", "-s", "-C", os.path.join(HERE, "hip_emu")], capture_output=True, text=True)
+    assert built.returncode == 0, built.stdout + built.stderr
+
+
+def run(body, timeout=600, **env):
+    code = PRELUDE.format(root=ROOT, here=HERE) + body
+    full = dict(os.environ, BITO_AMD_LIB=EMU, **{k: str(v) for k, v in env.items()})
+    done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout, env=full)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    return done.stdout
+
+
+def test_emulated_kernels_against_the_checker(emulated):
+    """walk_hbm_cat_kernel (one wave per rate category: with and without rescaling, log-likelihood only and with the
+    gradient, one and four categories) and walk_hbm_kernel (six categories) on 9- and 23-taxon trees, every result against
+    the CPU checker at the bars of tests/test_gpu_parity.py; unrooted and rooted trees."""
+    run('''
+for n, P, T, site in ((9, 70, 5, "weibull+4"), (23, 40, 3, "weibull+4"), (9, 70, 4, "weibull+6"), (12, 50, 4, "constant")):
+    w = small(n, P, T, site)
+    gpu = bito_amd.Engine(spec(w), w.patterns, w.weights)
+    cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 4)
+    for rescaling in (False, True):
+        out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+        ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+        assert gpu.kernel_name().startswith("walk_hbm"), gpu.kernel_name()
+        assert close(out["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL), (n, site, rescaling)
+        assert close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL), (n, site, rescaling)
+        ll = gpu.log_likelihoods(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+        assert close(ll, ref["log_likelihood"], LL_ATOL, LL_RTOL)
+    print(n, site, gpu.kernel_name())
+''')
+
+
+def test_emulated_chunks_slots_and_shared_helpers(emulated):
+    """A blocking call cut into chunks, on one slot and on three (GPU 0 named three times: every slot on an issuing thread
+    of its own), the slots' larger chunks packed in ranges by the shared helper threads (round 5; BITO_AMD_HOST_MIN_TREES
+    brings the threshold down to this test's size): the same results as an engine that never chunks, held to a tenth of
+    the tolerances, and to the CPU checker; errors name the caller's tree from whichever thread met them; the batch is
+    resident afterwards."""
+    run('''
+w = small(6, 24, 150)
+plain = bito_amd.Engine(spec(w), w.patterns, w.weights, host_threads=1)
+want = plain.gradients(w.parent_ids, w.branch_lengths, w.params)
+cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 4)
+ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+assert close(want["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL)
+assert close(want["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
+for slots, threads in ((1, 4), (3, 4), (3, 1), (2, 6)):
+    eng = bito_amd.Engine(spec(w), w.patterns, w.weights, devices=[0] * slots, host_threads=threads)
+    assert eng.device_count == slots
+    for _ in range(3):
+        out = eng.gradients(w.parent_ids, w.branch_lengths, w.params)
+        assert close(out["log_likelihood"], want["log_likelihood"], 0.1 * LL_ATOL, 0.1 * LL_RTOL), (slots, threads)
+        assert close(out["branch_lengths"], want["branch_lengths"], 0.1 * GRAD_ATOL, 0.1 * GRAD_RTOL), (slots, threads)
+    pid = w.parent_ids.copy()
+    pid[131, 0] = 0
+    try:
+        eng.gradients(pid, w.branch_lengths, w.params)
+        raise SystemExit("a bad tree went through")
+    except bito_amd.BitoAmdError as err:
+        assert "tree 131: parent id 0" in str(err), str(err)
+    again = eng.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert np.array_equal(again["log_likelihood"], out["log_likelihood"])
+    ll, grad = eng.download()
+    assert np.array_equal(ll, again["log_likelihood"]) and np.array_equal(grad, again["branch_lengths"])
+    print(slots, threads, "ok")
+''', BITO_AMD_CHUNK_FIRST=8, BITO_AMD_CHUNK_GROWTH=2, BITO_AMD_CHUNK_CAP=40, BITO_AMD_CHUNK_LANES=5, BITO_AMD_HOST_MIN_TREES=8)
+
+
+def test_emulated_site_gradient_second_pass_per_slot(emulated):
+    """weibull+6 with the site-model gradient (walk_hbm_kernel: a second traversal per block) on one slot and on three,
+    several chunks per slot: the second pass runs from every slot's own thread (round 5) and the three gradients are the
+    checker's."""
+    run('''
+w = small(7, 30, 41, "weibull+6")
+cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 4)
+ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, flags=oracle.GRAD_SITE_MODEL)
+for slots in (1, 3):
+    eng = bito_amd.Engine(spec(w), w.patterns, w.weights, devices=[0] * slots)
+    for _ in range(2):
+        out = eng.gradients(w.parent_ids, w.branch_lengths, w.params, flags=_capi.GRAD_SITE_MODEL)
+        assert eng.kernel_name().startswith("walk_hbm_kernel")
+        assert close(out["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL)
+        assert close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
+        assert close(out["site_model"], ref["site_model"], GRAD_ATOL, GRAD_RTOL)
+    print(slots, "ok")
+''', BITO_AMD_CHUNK_FIRST=4, BITO_AMD_CHUNK_GROWTH=2, BITO_AMD_CHUNK_CAP=16, BITO_AMD_CHUNK_LANES=4)
