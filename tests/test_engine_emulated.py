@@ -130,3 +130,26 @@ for slots in (1, 3):
         assert close(out["site_model"], ref["site_model"], GRAD_ATOL, GRAD_RTOL)
     print(slots, "ok")
 ''', BITO_AMD_CHUNK_FIRST=4, BITO_AMD_CHUNK_GROWTH=2, BITO_AMD_CHUNK_CAP=16, BITO_AMD_CHUNK_LANES=4)
+
+
+def test_emulated_codon_model(emulated):
+    """BASELINE config 5's path under emulation: two fluA trees under GY94 (61 states), each with its own (kappa, omega)
+    row -- model set-up, the 64 x 64 Jacobi eigensolver, transition-matrix images and the walk on
+    v_mfma_f64_16x16x4 (emulated with the lane layout and the fma-chain rounding measured on the device,
+    profiles/r1_mfma16_probe.json), images moved into LDS by global_load_lds -- against the general-state CPU checker at
+    the bars of tests/test_gpu_general.py; then the same rows again (the models of the call before stand) and other rows."""
+    run('''
+from oracle import gs
+w = workloads.flua_codon(2)
+w.params = workloads.codon_rows(2, 2)
+gpu = bito_amd.Engine(spec(w), w.patterns, w.weights)
+cpu = gs.GsOracleEngine(w.substitution, w.site, w.patterns, w.weights, 2)
+for params in (w.params, w.params, workloads.other_bits(w.params, 4)):
+    out = gpu.gradients(w.parent_ids, w.branch_lengths, params)
+    ref = cpu.gradients(w.parent_ids, w.branch_lengths, params)
+    assert gpu.kernel_name() == "gs_walk_kernel"
+    assert np.abs(out["log_likelihood"] - ref["log_likelihood"]).max() < 1e-10
+    assert np.abs(out["branch_lengths"] - ref["branch_lengths"]).max() < 1e-6 + 1e-9 * np.abs(ref["branch_lengths"]).max()
+assert not np.array_equal(w.params[0], w.params[1])
+print("codon ok", out["log_likelihood"])
+''', timeout=900)
