@@ -19,6 +19,7 @@ FORCED = (_capi.KERNEL_LDS, _capi.KERNEL_LDS_TREE, _capi.KERNEL_LDS_PIPE, _capi.
 ONLY = int(os.environ.get("FUZZ_ONLY", "-1"))
 skipped = 0
 unstable = 0
+unstable_trees = trees_seen = 0
 rng = np.random.default_rng(seed)
 bad = 0
 t0 = time.time()
@@ -93,6 +94,7 @@ for case in range(cases):
                 continue  # a forced kernel that does not take this shape says so
             raise
         ref = cpu.gradients(pid, bl, params, rescaling=rescaling)
+        trees_seen += T
         # degenerate inputs (zero-length branches between conflicting states) give -inf / nan / 1e17 on both sides:
         # equal non-finite values count as equal, huge gradients are compared relatively
         def close(a, b, atol, rtol=1e-9):
@@ -119,10 +121,17 @@ for case in range(cases):
             # log-likelihoods of all trees must still agree).
             ref2 = cpu.gradients(pid, bl, params, rescaling=True)
             stable = np.array([close(ref["branch_lengths"][t], ref2["branch_lengths"][t], 1e-7, 1e-10) for t in range(T)])
+            # (the trees left out are counted, not only the cases, a sweep fails when they pass a cap, and
+            # they are still compared -- against the reference's gradient WITH rescaling, the quantity computed in range,
+            # relatively: 1e-3 of the gradient's scale, the size of the reference's own disagreement with itself)
+            scale_of = lambda t: np.nanmax(np.abs(ref2["branch_lengths"][t])) if np.isfinite(ref2["branch_lengths"][t]).any() else 1.0  # noqa: E731
+            loosely = all(close(out["branch_lengths"][t], ref2["branch_lengths"][t], 1e-6 + 1e-3 * scale_of(t), 1e-3)
+                          for t in range(T) if not stable[t])
             if (not stable.all() and close(out["log_likelihood"], ref["log_likelihood"], 1e-10)
                     and close(ll2, ref["log_likelihood"], 1e-10)
-                    and close(out["branch_lengths"][stable], ref["branch_lengths"][stable], 1e-6)):
+                    and close(out["branch_lengths"][stable], ref["branch_lengths"][stable], 1e-6) and loosely):
                 unstable += 1
+                unstable_trees += int((~stable).sum())
                 ok = True
             elif ONLY >= 0:
                 for t in range(T):
@@ -149,4 +158,7 @@ for case in range(cases):
         bad += 1
         print("ERROR", desc, repr(e)[:300])
 print(f"{cases} cases, {bad} bad, {skipped} declined by a forced kernel, {unstable} with trees on which the reference's own "
-      f"gradient without rescaling is rounding noise (left out), {time.time() - t0:.0f} s")
+      f"gradient without rescaling is rounding noise ({unstable_trees} of {trees_seen} trees = {unstable_trees / max(trees_seen, 1):.2%}: "
+      f"held to the reference's gradient with rescaling at 1e-3 relative instead), {time.time() - t0:.0f} s")
+if unstable_trees > 0.01 * max(trees_seen, 1):
+    raise SystemExit("more than 1 % of the sweep's trees were left out of the tight gradient comparison")

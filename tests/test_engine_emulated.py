@@ -41,10 +41,27 @@ assert "cpu-emulation" in bito_amd.version()
 '''
 
 
+AS_PRODUCT = os.path.join(HERE, "hip_emu", "_build", "as_product")  # holds libbito_amd.so -> the emulated library
+
+
 @pytest.fixture(scope="module")
 def emulated():
     built = subprocess.run(["make", "-s", "-C", os.path.join(HERE, "hip_emu")], capture_output=True, text=True)
     assert built.returncode == 0, built.stdout + built.stderr
+    os.makedirs(AS_PRODUCT, exist_ok=True)
+    link = os.path.join(AS_PRODUCT, "libbito_amd.so")
+    if not os.path.islink(link):
+        os.symlink(os.path.join("..", "libbito_amd_emu.so"), link)
+
+
+def run_gpu_tests_emulated(args, timeout=900):
+    """`pytest -m gpu <args>` as it is, in a process whose bito_amd loads the emulated library (and whose C++ client
+    programs, which look libbito_amd.so up through their run path, find it first on LD_LIBRARY_PATH)"""
+    env = dict(os.environ, BITO_AMD_LIB=EMU, LD_LIBRARY_PATH=AS_PRODUCT + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    done = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", *args],
+                          capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-2000:]
+    return done.stdout
 
 
 def run(body, timeout=600, **env):
@@ -153,3 +170,19 @@ for params in (w.params, w.params, workloads.other_bits(w.params, 4)):
 assert not np.array_equal(w.params[0], w.params[1])
 print("codon ok", out["log_likelihood"])
 ''', timeout=900)
+
+
+def test_emulated_time_tree_gpu_tests_as_they_are(emulated):
+    """tests/test_time_tree.py -m gpu, unchanged, under emulation: the height-ratio transforms, log-det-Jacobian and
+    rooted gradients of time_tree.hip on one, two and three device slots, fluA's rooted goldens of the reference among
+    them (src/rooted_sbn_instance.hpp:60-330)."""
+    out = run_gpu_tests_emulated(["tests/test_time_tree.py"])
+    assert "8 passed" in out, out[-500:]
+
+
+def test_emulated_cpp_clients_as_they_are(emulated):
+    """tests/test_cabi_client.py -m gpu, unchanged, under emulation: the plain C++ programs of seam 2 (examples/engine_amd.hpp,
+    one and two device slots, bit for bit the ctypes route) and seam 1 (FatBeagle's call sequence over the 17 BEAGLE symbols:
+    the DS1 JC69 pybeagle log-likelihood and physher gradient goldens, src/unrooted_sbn_instance.hpp:245-348)."""
+    out = run_gpu_tests_emulated(["tests/test_cabi_client.py"])
+    assert "4 passed" in out, out[-500:]
