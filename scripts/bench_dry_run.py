@@ -1,0 +1,63 @@
+"""bench.py's control flow, end to end, WITHOUT a GPU: the emulated library (tests/hip_emu) in place of libbito_amd.so, the
+three torch.cuda calls bench.py makes turned into no-ops, and the workloads shrunk to a handful of tiny trees -- so that a
+slip in the bench script (a misspelt key, a wrong shape) is found on the CPU and not by the one GPU run a round may get.
+The numbers it prints mean nothing.  usage: python scripts/bench_dry_run.py [ds1 | codon | config4 | gp]"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "hip_emu", "_build", "libbito_amd_emu.so")
+
+BODY = r'''
+import os, runpy, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch
+torch.cuda.is_available = lambda: True
+torch.cuda.set_device = lambda d: None
+torch.cuda.synchronize = lambda *a: None
+from bito_amd import workloads
+small = lambda n, P, T: workloads.synthetic_gtr_weibull4(n, P, tree_count=T)
+def tiny_ds1(replicas=1, first_tree=0, tree_count=None):
+    w = small(6, 24, tree_count or 100 * replicas)
+    w.rescaling = False
+    return w
+workloads.ds1_gtr_weibull4 = tiny_ds1
+real_codon = workloads.flua_codon
+workloads.flua_codon = lambda T=64, site="constant", seed=20240605: real_codon(min(T, 2), site, seed)
+real_synth = workloads.synthetic_gtr_weibull4
+workloads.synthetic_gtr_weibull4 = lambda n=1000, P=10000, tree_count=125, first_tree=0: real_synth(40, 130, min(tree_count, 3), first_tree)
+sys.argv = ["bench.py"] + {argv!r}
+runpy.run_path(os.path.join({root!r}, "bench.py"), run_name="__main__")
+'''
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "ds1"
+    argv = {"ds1": ["--steps", "2", "--warmup", "1", "--replicas", "1", "--cpu-seconds", "2"],
+            "codon": ["--workload", "codon", "--trees", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
+            "config4": ["--workload", "config4", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
+            "gp": ["--workload", "gp", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"]}[which]
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hip_emu")])
+    env = dict(os.environ, BITO_AMD_LIB=EMU)
+    done = subprocess.run([sys.executable, "-c", BODY.format(root=ROOT, argv=argv)], capture_output=True, text=True, env=env)
+    if done.returncode != 0:
+        sys.stderr.write(done.stdout[-2000:] + done.stderr[-4000:])
+        raise SystemExit(f"bench.py {which}: exit code {done.returncode}")
+    line = json.loads(done.stdout.strip().splitlines()[-1])
+    keys = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline", "cpu_baseline", "parity", "model_cache_hit", "resident"]
+    if which == "gp":
+        keys = [k for k in keys if k not in ("model_cache_hit", "resident")]
+    missing = [k for k in keys if k not in line]
+    print(f"bench.py {which}: one JSON line, {len(line)} keys; missing {missing}; parity {line.get('parity')}")
+    print("   model_cache_hit", line.get("model_cache_hit"), "\n   blocking_call_ms", line.get("blocking_call_ms"),
+          "\n   distinct_models", line.get("distinct_models"), "\n   config", {k: v for k, v in line["config"].items() if k != "workload"})
+    if missing:
+        raise SystemExit(1)
+
+
+if __name__ == "__main__":
+    main()

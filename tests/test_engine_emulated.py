@@ -186,3 +186,16 @@ def test_emulated_cpp_clients_as_they_are(emulated):
     the DS1 JC69 pybeagle log-likelihood and physher gradient goldens, src/unrooted_sbn_instance.hpp:245-348)."""
     out = run_gpu_tests_emulated(["tests/test_cabi_client.py"])
     assert "4 passed" in out, out[-500:]
+
+
+def test_emulated_reference_goldens_and_seam_1_as_they_are(emulated):
+    """Tests of tests/test_gpu_parity.py -m gpu, unchanged, under emulation (AUTO routes to the HBM-arena walks there): the
+    reference's DS1 JC69 goldens -- 17-digit pybeagle log-likelihoods, the physher gradient -- with and without rescaling,
+    the DS1 JC69 + weibull+4 goldens, JC69 == GTR(equal) on the 100 DS1 topologies (src/unrooted_sbn_instance.hpp:245-348,
+    test/test_bito.py:97-122), fluA rooted with rates, the hello instance API, one to eight rate categories, pattern counts
+    around tile edges, the 17-symbol BEAGLE shim in FatBeagle's call sequence, the edge cases."""
+    out = run_gpu_tests_emulated(["tests/test_gpu_parity.py", "-n", "4", "-k",
+                                  "ds1_jc69_goldens or ds1_jc69_weibull_goldens or config2_ds1 or flua_rooted_with_rates or "
+                                  "beagle_shim or category_counts or edge_cases or hello_jc69 or one_rate_category_underflows or "
+                                  "pattern_counts_around or resident_update_and_time_tree or hbm_arena_walk_in_chunks"])
+    assert "21 passed" in out, out[-600:]
