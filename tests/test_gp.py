@@ -769,3 +769,29 @@ def test_scheduled_sweep_is_bitwise_the_sequential_one():
     _scheduled_and_sequential_sweeps_agree(((workloads.ds1_subsplit_dag(10), 1e-40), (workloads.ds1_subsplit_dag(10), 1e-4),
                                             (workloads.seeded_subsplit_dag(20), 1e-40)),
                                            (gp.BRENT, gp.BRENT_WITH_GRADIENTS, gp.NEWTON))
+
+
+def test_schedule_entry_point_rejects_streams_it_cannot_index():
+    """bito_amd_gp_schedule_operations indexes the side array by the stream's PrepForMarginalization records: a record
+    that points outside it is refused (BAD_ARG) before anything is read; an empty stream is fine."""
+    import ctypes as C
+
+    from bito_amd import _capi
+
+    L = gp._lib()
+    ops = np.zeros(2, dtype=gp.OP_DTYPE)
+    ops[0] = (gp.PREP_FOR_MARGINALIZATION, 3, 5, 1, 0)  # three sources from side[1 .. 4): side holds two entries
+    ops[1] = (gp.ZERO_PLV, 0, 5, 0, 0)
+    side = np.array([7, 8], dtype=np.uint64)
+    out = np.zeros(2, dtype=gp.OP_DTYPE)
+    count = C.c_int64(-1)
+    rc = L.bito_amd_gp_schedule_operations(ops.ctypes.data, 2, side.ctypes.data, 2, 1, out.ctypes.data, None, None, None, C.byref(count))
+    assert rc == _capi.ERR_BAD_ARG
+    rc = L.bito_amd_gp_schedule_operations(ops.ctypes.data, 2, None, 0, 1, out.ctypes.data, None, None, None, C.byref(count))
+    assert rc == _capi.ERR_BAD_ARG
+    rc = L.bito_amd_gp_schedule_operations(None, 0, None, 0, 1, None, None, None, None, C.byref(count))
+    assert rc == 0 and count.value == 0
+    ops[0] = (gp.PREP_FOR_MARGINALIZATION, 2, 5, 0, 0)
+    rc = L.bito_amd_gp_schedule_operations(ops.ctypes.data, 2, side.ctypes.data, 2, 1, out.ctypes.data, None, None, None, C.byref(count))
+    assert rc == 0 and count.value == 1  # (the ZeroPLV of PLV 5 must follow the Prep that writes its count: two levels, one launch)
+    assert [int(o["opcode"]) for o in out] == [gp.PREP_FOR_MARGINALIZATION, gp.ZERO_PLV]

@@ -145,3 +145,31 @@ def test_emulated_nni_and_top_pruning(emulated, data_dir):
                     raise
                 left_out.append(name)
     assert ran >= 11 and set(left_out) <= {"test_proposed_nni_scores_equal_tree_likelihoods", "test_top_tree_likelihoods_equal_tree_likelihoods"}, (ran, left_out)
+
+
+def test_emulated_optimizer_trace_entry_points(emulated, data_dir):
+    """bito_amd_gp_set_optimizer_trace / _get_optimizer_trace: nothing to read before a trace is started (STATE), rows of
+    one optimisation in order with the kinds 0, 1, 2 ..., an overflowing trace reports how many evaluations were made."""
+    from bito_amd.engine import BitoAmdError
+
+    sp, tree, dag = test_gp.hello_instance(data_dir)
+    eng = test_gp._gpu_factory(sp, dag)
+    eng._trace_capacity = 8
+    with pytest.raises(BitoAmdError):
+        eng.optimizer_trace()
+    eng.set_branch_lengths(dag.branch_lengths(tree.branch_lengths))
+    eng.process_operations(dag.populate_plvs())
+    eng.start_optimizer_trace(4096)
+    eng.process_operations(dag.branch_length_optimization())
+    rows = eng.optimizer_trace()
+    edges = sorted(set(int(e) for e in rows[:, 0]))
+    assert len(edges) == 4 and len(rows) > 30
+    for e in edges:
+        mine = rows[rows[:, 0] == e]
+        assert list(mine[:2, 3]) == [0.0, 1.0] and np.all(mine[2:, 3] == 2.0) and mine[0, 1] == mine[1, 1]
+    eng.start_optimizer_trace(5)  # (restarts: the buffer is cleared)
+    eng.process_operations(dag.branch_length_optimization())
+    with pytest.raises(BitoAmdError, match="overflow"):
+        eng.optimizer_trace()
+    eng.stop_optimizer_trace()
+    eng.process_operations(dag.branch_length_optimization())
