@@ -141,6 +141,7 @@ class SharedPool {
     {
       std::lock_guard<std::mutex> lock(mu_);
       stop_ = true;
+      stopping_.store(true, std::memory_order_release);
       epoch_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
@@ -165,19 +166,24 @@ class SharedPool {
     {
       std::lock_guard<std::mutex> lock(mu_);
       jobs_.push_back(job);
+      open_jobs_.fetch_add(1, std::memory_order_release);
       epoch_.fetch_add(1, std::memory_order_release);
       const long long until = Now() + kLingerNs;
       if (armed_until_.load(std::memory_order_relaxed) < until) armed_until_.store(until, std::memory_order_relaxed);
     }
     cv_.notify_all();
     Work(*job);
+    {
+      // (every item is claimed: the helpers need not look at this job again, whether or not the last items are done)
+      std::lock_guard<std::mutex> lock(mu_);
+      for (size_t k = 0; k < jobs_.size(); k++)
+        if (jobs_[k] == job) {
+          jobs_.erase(jobs_.begin() + (long)k);
+          break;
+        }
+      open_jobs_.fetch_sub(1, std::memory_order_release);
+    }
     while (job->done.load(std::memory_order_acquire) != count) CpuPause();
-    std::lock_guard<std::mutex> lock(mu_);
-    for (size_t k = 0; k < jobs_.size(); k++)
-      if (jobs_[k] == job) {
-        jobs_.erase(jobs_.begin() + (long)k);
-        break;
-      }
   }
 
   // wakes the helpers ahead of the first job of a call: they poll for work for `linger`
@@ -221,12 +227,15 @@ class SharedPool {
   void Loop() {
     unsigned seen = epoch_.load(std::memory_order_acquire);
     for (;;) {
-      if (std::shared_ptr<Job> job = Pick()) {
-        Work(*job);
-        continue;
+      // (polling helpers look at a counter, not at the list: the mutex stays free for the issuing threads)
+      if (open_jobs_.load(std::memory_order_acquire) > 0) {
+        if (std::shared_ptr<Job> job = Pick()) {
+          Work(*job);
+          continue;
+        }
       }
       if (Now() <= armed_until_.load(std::memory_order_relaxed)) {  // armed: poll
-        if (stop_flag()) return;
+        if (stopping_.load(std::memory_order_acquire)) return;
         CpuPause();
         continue;
       }
@@ -237,11 +246,6 @@ class SharedPool {
       seen = epoch_.load(std::memory_order_acquire);
     }
   }
-  bool stop_flag() {
-    std::lock_guard<std::mutex> lock(mu_);
-    return stop_;
-  }
-
   static constexpr long long kLingerNs = 1500000;  // helpers keep polling 1.5 ms after the last job was published
 
   std::vector<std::thread> threads_;
@@ -249,7 +253,9 @@ class SharedPool {
   std::condition_variable cv_;
   std::vector<std::shared_ptr<Job>> jobs_;
   std::atomic<unsigned> epoch_{0};
+  std::atomic<int> open_jobs_{0};  // jobs in the list (a job leaves it once all of its items are claimed)
   std::atomic<long long> armed_until_{0};
+  std::atomic<bool> stopping_{false};
   bool stop_ = false;
 };
 
