@@ -264,8 +264,8 @@ gs_model_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, const int32_t* __res
 
 // Set-up, part 2: symmetric eigensolve, one workgroup (4 waves) per distinct model.  Jacobi
 // iteration with the round-robin ordering: 63 rounds of 32 independent rotations per sweep; all
-// angles of a round are taken first, then the column updates (A and U), then the row updates, then
-// the annihilated pairs are set to exactly zero.  Wave g owns pairs 8 g .. 8 g + 7 of a round;
+// angles of a round are taken first, then the column updates (A and U), then the row updates, which
+// set the annihilated pairs to exactly zero.  Wave g owns pairs 8 g .. 8 g + 7 of a round;
 // their LDS traffic is issued as eight independent streams.
 __device__ __forceinline__ void GsPair(int r, int k, int& p, int& q) {
   const int a = k == 0 ? 63 : (r + k) % 63;
@@ -348,18 +348,13 @@ gs_eigen_kernel(const int32_t* __restrict__ model_index, double* __restrict__ gs
           ap[k] = A[p[k] * kLd + lane];
           aq[k] = A[q[k] * kLd + lane];
         }
+        // (the annihilated pair is set to exactly zero where the row update writes it -- round 5: it was a step of its
+        // own behind a fourth barrier per round; the same values in LDS before anything reads them)
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          A[p[k] * kLd + lane] = c[k] * ap[k] - s[k] * aq[k];
-          A[q[k] * kLd + lane] = s[k] * ap[k] + c[k] * aq[k];
+          A[p[k] * kLd + lane] = lane == q[k] ? 0.0 : c[k] * ap[k] - s[k] * aq[k];
+          A[q[k] * kLd + lane] = lane == p[k] ? 0.0 : s[k] * ap[k] + c[k] * aq[k];
         }
-      }
-      __syncthreads();
-      if (tid < 32) {
-        int pp, qq;
-        GsPair(r, tid, pp, qq);
-        A[pp * kLd + qq] = 0.0;
-        A[qq * kLd + pp] = 0.0;
       }
       __syncthreads();
     }

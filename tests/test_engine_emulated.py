@@ -199,3 +199,11 @@ def test_emulated_reference_goldens_and_seam_1_as_they_are(emulated):
                                   "beagle_shim or category_counts or edge_cases or hello_jc69 or one_rate_category_underflows or "
                                   "pattern_counts_around or resident_update_and_time_tree or hbm_arena_walk_in_chunks"])
     assert "21 passed" in out, out[-600:]
+
+
+def test_emulated_codon_model_setup_is_bitwise_the_checkers(emulated):
+    """tests/test_gpu_general.py::test_codon_model_setup_is_bitwise_the_oracles, unchanged, under emulation: rate matrix,
+    F1x4 frequencies and the 64 x 64 round-robin Jacobi eigensystem of gs_model_kernel / gs_eigen_kernel equal the CPU
+    checker's bit for bit (round 5 folded the eigensolver's zeroing step into its row update: three barriers per round)."""
+    out = run_gpu_tests_emulated(["tests/test_gpu_general.py", "-k", "bitwise"])
+    assert "1 passed" in out, out[-500:]
