@@ -264,8 +264,8 @@ gs_model_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, const int32_t* __res
 
 // Set-up, part 2: symmetric eigensolve, one workgroup (4 waves) per distinct model.  Jacobi
 // iteration with the round-robin ordering: 63 rounds of 32 independent rotations per sweep; all
-// angles of a round are taken first, then the column updates (A and U), then the row updates, which
-// set the annihilated pairs to exactly zero.  Wave g owns pairs 8 g .. 8 g + 7 of a round;
+// angles of a round are taken first (each wave its own pairs'), then the column updates (A and U), then
+// the row updates, which set the annihilated pairs to exactly zero: two barriers per round.  Wave g owns pairs 8 g .. 8 g + 7 of a round;
 // their LDS traffic is issued as eight independent streams.
 __device__ __forceinline__ void GsPair(int r, int k, int& p, int& q) {
   const int a = k == 0 ? 63 : (r + k) % 63;
@@ -279,7 +279,7 @@ gs_eigen_kernel(const int32_t* __restrict__ model_index, double* __restrict__ gs
 #pragma clang fp contract(off)
   __shared__ double A[64 * kLd];
   __shared__ double U[64 * kLd];
-  __shared__ double cs[32], sn[32], wmax[4];
+  __shared__ double wmax[4];
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
   if (model_index[t] != t) return;
   double* __restrict__ out = gs_model + (size_t)t * kGsModelStride;
@@ -300,28 +300,29 @@ gs_eigen_kernel(const int32_t* __restrict__ model_index, double* __restrict__ gs
     __syncthreads();
     if (mo < 1e-20) break;
     for (int r = 0; r < 63; r++) {
-      if (tid < 32) {
-        int p, q;
-        GsPair(r, tid, p, q);
-        const double apq = A[p * kLd + q];
-        double c = 1.0, s = 0.0;
+      // The angles of a wave's eight pairs are taken by the wave itself (lanes 0-7, handed round by shuffles): they read
+      // A[p][q], A[p][p], A[q][q] of the wave's OWN pairs, entries that only this wave's column updates touch before the
+      // next barrier -- so no barrier stands between the angles and the column updates (round 5: wave 0 took all 32
+      // angles and passed them through LDS behind a barrier of the workgroup; the same formulas, the same bits).
+      double c_mine = 1.0, s_mine = 0.0;
+      if (lane < 8) {
+        int pp, qq;
+        GsPair(r, g * 8 + lane, pp, qq);
+        const double apq = A[pp * kLd + qq];
         if (apq != 0.0) {
-          const double theta = (A[q * kLd + q] - A[p * kLd + p]) / (2.0 * apq);
+          const double theta = (A[qq * kLd + qq] - A[pp * kLd + pp]) / (2.0 * apq);
           const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-          c = 1.0 / sqrt(tt * tt + 1.0);
-          s = tt * c;
+          c_mine = 1.0 / sqrt(tt * tt + 1.0);
+          s_mine = tt * c_mine;
         }
-        cs[tid] = c;
-        sn[tid] = s;
       }
-      __syncthreads();
       int p[8], q[8];
       double c[8], s[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         GsPair(r, g * 8 + k, p[k], q[k]);
-        c[k] = cs[g * 8 + k];
-        s[k] = sn[g * 8 + k];
+        c[k] = __shfl(c_mine, k);
+        s[k] = __shfl(s_mine, k);
       }
       {  // column updates: lane = row
         double ap[8], aq[8], up[8], uq[8];
