@@ -326,7 +326,7 @@ struct EdgeFunction {
   const double* A;
   const double* B;
   const double* weights;
-  double* sh;  // [3][kOptWaves] block-reduction scratch in LDS
+  double* sh;  // [2][3][kOptWaves] block-reduction scratch in LDS, the two halves used by alternate evaluations
   double resc;
   int P;
   // diagnostics: the optimiser's evaluations are recorded when a trace buffer is set
@@ -334,9 +334,13 @@ struct EdgeFunction {
   unsigned long long* trace_cursor;
   long long trace_capacity;
   double edge;
+  // Evaluations alternate between the two halves of sh, so ONE barrier per evaluation is enough (round 5; two before):
+  // evaluation k + 1 writes the half evaluation k - 1 was read from, and no thread gets to that write before it has
+  // passed evaluation k's barrier -- which every thread reaches only after it has read evaluation k - 1's sums.
+  int phase;
 
   // log-likelihood and its first two derivatives in t; every thread of the block gets the values
-  __device__ void operator()(double t, double out[3]) const {
+  __device__ void operator()(double t, double out[3]) {
     const double e = exp(kLam * t);
     double a0 = 0, a1 = 0, a2 = 0;
     for (int p = threadIdx.x; p < P; p += blockDim.x) {
@@ -348,15 +352,15 @@ struct EdgeFunction {
       a2 += w * ((dd * l - d * d) / (l * l));
     }
     double v[3] = {a0, a1, a2};
-    __syncthreads();  // the previous evaluation's readers are done with sh
+    double* const buf = sh + (phase++ & 1) * 3 * kOptWaves;
     for (int k = 0; k < 3; k++) {
       for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
-      if ((threadIdx.x & 63) == 0) sh[k * kOptWaves + (threadIdx.x >> 6)] = v[k];
+      if ((threadIdx.x & 63) == 0) buf[k * kOptWaves + (threadIdx.x >> 6)] = v[k];
     }
     __syncthreads();
     double total[3] = {0, 0, 0};
     for (int k = 0; k < 3; k++)
-      for (int w = 0; w < kOptWaves; w++) total[k] += sh[k * kOptWaves + w];  // (fixed order: every thread the same bits)
+      for (int w = 0; w < kOptWaves; w++) total[k] += buf[k * kOptWaves + w];  // (fixed order: every thread the same bits)
     out[0] = total[0] + resc;
     out[1] = total[1];
     out[2] = total[2];
@@ -364,21 +368,21 @@ struct EdgeFunction {
   // The log-likelihood alone: what Brent asks for at every trial point (brent_nongrad_func, src/gp_engine.cpp:605-612).
   // The same per-pattern terms in the same order and the same reduction tree as out[0] above -- the same bits -- without
   // the two derivative sums (two divisions per pattern, two of the three cross-wave sums).
-  __device__ double Value(double t) const {
+  __device__ double Value(double t) {
     const double e = exp(kLam * t);
     double a0 = 0;
     for (int p = threadIdx.x; p < P; p += blockDim.x) a0 += weights[p] * log(fma(B[p], e, A[p]));
-    __syncthreads();  // the previous evaluation's readers are done with sh
+    double* const buf = sh + (phase++ & 1) * 3 * kOptWaves;
     for (int o = 32; o > 0; o >>= 1) a0 += __shfl_xor(a0, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a0;
+    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = a0;
     __syncthreads();
     double total = 0;
-    for (int w = 0; w < kOptWaves; w++) total += sh[w];
+    for (int w = 0; w < kOptWaves; w++) total += buf[w];
     return total + resc;
   }
   // brent_nongrad_func: x is the LOG branch length.  kind (trace only): 0 the handler's evaluation of the current
   // length, 1 Brent's first point, 2 a trial point, 3 the gradient variant's second trial.
-  __device__ double NegLL(double x, int kind) const {
+  __device__ double NegLL(double x, int kind) {
     const double f = -Value(exp(x));
     if (trace_rows && threadIdx.x == 0) {
       const unsigned long long at = atomicAdd(trace_cursor, 1ull);
@@ -392,7 +396,7 @@ struct EdgeFunction {
 };
 
 // Optimization::BrentMinimize / BrentMinimizeWithGradients (src/optimization.hpp:71-331)
-__device__ void BrentMinimize(const EdgeFunction& f, bool with_gradients, double guess, double mn, double mx,
+__device__ void BrentMinimize(EdgeFunction& f, bool with_gradients, double guess, double mn, double mx,
                               int significant_digits, int max_iter, double step_size, double* x_out, double* fx_out) {
   const double tolerance = ldexp(1.0, 1 - significant_digits);
   const double golden = 0.3819660f;
@@ -463,7 +467,7 @@ __device__ void BrentMinimize(const EdgeFunction& f, bool with_gradients, double
   *fx_out = fx;
 }
 
-// The whole optimisation of one edge by one workgroup of kOptThreads threads; sh[3 kOptWaves] and sh_resc[kOptWaves] are LDS scratch,
+// The whole optimisation of one edge by one workgroup of kOptThreads threads; sh[2][3 kOptWaves] and sh_resc[kOptWaves] are LDS scratch,
 // coef holds 2 * Ppad doubles private to the workgroup.
 __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict__ plv, const int* __restrict__ counts,
                              const double* __restrict__ weights, double* __restrict__ bl, double* __restrict__ diff,
@@ -496,7 +500,7 @@ __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict_
   __syncthreads();
   double resc_total = 0;
   for (int w = 0; w < kOptWaves; w++) resc_total += sh_resc[w];
-  const EdgeFunction f{coef, coef + Ppad, weights, sh, resc_total, P, cfg.trace_rows, cfg.trace_cursor, cfg.trace_capacity, (double)edge};
+  EdgeFunction f{coef, coef + Ppad, weights, sh, resc_total, P, cfg.trace_rows, cfg.trace_cursor, cfg.trace_capacity, (double)edge, 0};
   const double current = bl[edge];
   double result = current;
   switch (cfg.method) {
@@ -570,7 +574,7 @@ gp_optimize_kernel(const bito_amd_gp_op* __restrict__ ops, const double* __restr
                    const int* __restrict__ counts, const double* __restrict__ weights, double* __restrict__ bl,
                    double* __restrict__ diff, double* __restrict__ coef, int P, int Ppad, double log_threshold,
                    OptSettings cfg) {
-  __shared__ double sh[3 * kOptWaves];
+  __shared__ double sh[2 * 3 * kOptWaves];
   __shared__ double sh_resc[kOptWaves];
   OptimizeEdge(ops[blockIdx.x], plv, counts, weights, bl, diff, coef + (size_t)blockIdx.x * 2 * Ppad, sh, sh_resc, P, Ppad,
                log_threshold, cfg);
@@ -587,7 +591,7 @@ gp_block_stream_kernel(const bito_amd_gp_op* __restrict__ ops, const int64_t* __
                        double* __restrict__ ll, double* __restrict__ marginal, double* __restrict__ diff,
                        double* __restrict__ coef, int P, int Ppad, double threshold, double log_threshold,
                        OptSettings cfg) {
-  __shared__ double sh[3 * kOptWaves];
+  __shared__ double sh[2 * 3 * kOptWaves];
   __shared__ double sh_resc[kOptWaves];
   const int64_t first = offsets[blockIdx.x], last = offsets[blockIdx.x + 1];
   double* my_coef = coef + (size_t)blockIdx.x * 2 * Ppad;
