@@ -382,8 +382,7 @@ struct EdgeFunction {
   }
   // brent_nongrad_func: x is the LOG branch length.  kind (trace only): 0 the handler's evaluation of the current
   // length, 1 Brent's first point, 2 a trial point, 3 the gradient variant's second trial.
-  __device__ double NegLL(double x, int kind) {
-    const double f = -Value(exp(x));
+  __device__ void Trace(double x, double f, int kind) const {
     if (trace_rows && threadIdx.x == 0) {
       const unsigned long long at = atomicAdd(trace_cursor, 1ull);
       if ((long long)at < trace_capacity) {
@@ -391,18 +390,26 @@ struct EdgeFunction {
         row[0] = edge; row[1] = x; row[2] = f; row[3] = (double)kind;
       }
     }
+  }
+  __device__ double NegLL(double x, int kind) {
+    const double f = -Value(exp(x));
+    Trace(x, f, kind);
     return f;
   }
 };
 
 // Optimization::BrentMinimize / BrentMinimizeWithGradients (src/optimization.hpp:71-331)
-__device__ void BrentMinimize(EdgeFunction& f, bool with_gradients, double guess, double mn, double mx,
+// f_guess = f(guess): the handler has just evaluated the current length (src/dag_branch_handler.cpp:160-163) and Brent's
+// first point is that length again (src/optimization.hpp:93-94) -- the same function of the same argument, so the value
+// is handed over instead of being summed a second time (the trace still shows the reference's two evaluations).
+__device__ void BrentMinimize(EdgeFunction& f, bool with_gradients, double guess, double f_guess, double mn, double mx,
                               int significant_digits, int max_iter, double step_size, double* x_out, double* fx_out) {
   const double tolerance = ldexp(1.0, 1 - significant_digits);
   const double golden = 0.3819660f;
   double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
   w = v = x = guess;
-  fw = fv = fx = f.NegLL(x, 1);
+  fw = fv = fx = f_guess;
+  f.Trace(x, fx, 1);
   delta2 = delta = 0;
   int count = max_iter;
   do {
@@ -509,7 +516,7 @@ __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict_
       const double cur_log = log(current);
       const double cur_nll = f.NegLL(cur_log, 0);
       double x, fx;
-      BrentMinimize(f, cfg.method == 1, cur_log, kMinLogBl, kMaxLogBl, cfg.significant_digits, kOptMaxIter, kLogStep,
+      BrentMinimize(f, cfg.method == 1, cur_log, cur_nll, kMinLogBl, kMaxLogBl, cfg.significant_digits, kOptMaxIter, kLogStep,
                     &x, &fx);
       result = fx > cur_nll ? exp(cur_log) : exp(x);
       break;
