@@ -34,6 +34,20 @@ struct GpCachedSchedule {
   std::vector<bito_amd_gp_op> ops;  // the stream as the caller gave it
   std::vector<uint64_t> side;
   bito_amd_gp_schedule::Schedule schedule;
+  // its image on the device (scheduled operations, level offsets, side array), uploaded when the schedule is first run:
+  // a replayed stream -- the three schedules of GPInstance::EstimateBranchLengths alternate until convergence -- crosses
+  // PCIe once
+  int device = 0;
+  bito_amd_gp_op* d_ops = nullptr;
+  int64_t* d_levels = nullptr;
+  uint64_t* d_side = nullptr;
+  bool on_device = false;
+  ~GpCachedSchedule() {
+    if (d_ops || d_levels || d_side) (void)hipSetDevice(device);
+    if (d_ops) (void)hipFree(d_ops);
+    if (d_levels) (void)hipFree(d_levels);
+    if (d_side) (void)hipFree(d_side);
+  }
 };
 
 struct bito_amd_gp_engine {
@@ -48,8 +62,7 @@ struct bito_amd_gp_engine {
   bito_amd_gp_op* d_ops = nullptr;
   uint64_t* d_side = nullptr;
   int64_t* d_offsets = nullptr;
-  int64_t* d_levels = nullptr;  // level offsets of the levelled segments of the resident stream
-  size_t ops_cap = 0, side_cap = 0, offsets_cap = 0, levels_cap = 0, coef_blocks = 1;  // coef holds coef_blocks x [2][Ppad]
+  size_t ops_cap = 0, side_cap = 0, offsets_cap = 0, coef_blocks = 1;  // coef holds coef_blocks x [2][Ppad]
   std::list<std::shared_ptr<GpCachedSchedule>> schedules;  // most recently used first
   // diagnostics: every function evaluation of the Brent optimisers as rows (edge, x, f, kind), see bito_amd_gp.h
   double* trace_rows = nullptr;
@@ -59,7 +72,7 @@ struct bito_amd_gp_engine {
   ~bito_amd_gp_engine() {
     (void)hipSetDevice(device);
     for (void* p : {(void*)plv, (void*)weights, (void*)bl, (void*)q, (void*)ll, (void*)marginal, (void*)scratch, (void*)diff, (void*)coef,
-                    (void*)counts, (void*)d_ops, (void*)d_side, (void*)d_offsets, (void*)d_levels, (void*)trace_rows, (void*)trace_cursor})
+                    (void*)counts, (void*)d_ops, (void*)d_side, (void*)d_offsets, (void*)trace_rows, (void*)trace_cursor})
       if (p) (void)hipFree(p);
   }
 };
@@ -626,16 +639,6 @@ int Fail(bito_amd_gp_engine* e, int code, const std::string& msg) {
     if (rc_ != hipSuccess) return Fail(e, BITO_AMD_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(rc_)); \
   } while (0)
 
-// the op stream is resident in d_ops; a segment is [first, first + count)
-int RunSegment(bito_amd_gp_engine* e, int64_t first, int64_t count) {
-  if (count <= 0) return BITO_AMD_OK;
-  hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64), dim3(64), 0, 0, e->d_ops + first, count,
-                     (const int64_t*)nullptr, e->d_side, e->plv, e->counts, e->bl, e->q, e->ll, e->marginal, e->P,
-                     e->Ppad, e->threshold, e->log_threshold);
-  GP_TRY(e, hipGetLastError());
-  return BITO_AMD_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -929,18 +932,26 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
   const bool reorder = !(env != nullptr && env[0] == '0');
   // (ids are validated on the stream as given, before anything is indexed by them)
   if (int rc = ValidateOps(e, ops, op_count, side, side_count, false)) return rc;
-  const std::shared_ptr<GpCachedSchedule> cached = ScheduleOf(e, ops, op_count, side, side && side_count > 0 ? side_count : 0, reorder);
+  const int64_t side_used = side && side_count > 0 ? side_count : 0;
+  const std::shared_ptr<GpCachedSchedule> cached = ScheduleOf(e, ops, op_count, side, side_used, reorder);
   const bito_amd_gp_schedule::Schedule& S = cached->schedule;
-  if (int rc = UploadOps(e, S.image.data(), op_count, side, side_count)) return rc;
-  if (!S.level_offsets.empty()) {
-    if (S.level_offsets.size() > e->levels_cap) {
-      if (e->d_levels) (void)hipFree(e->d_levels);
-      e->levels_cap = 0;
-      GP_TRY(e, hipMalloc((void**)&e->d_levels, S.level_offsets.size() * sizeof(int64_t)));
-      e->levels_cap = S.level_offsets.size();
+  if (!cached->on_device) {
+    cached->device = e->device;
+    if (op_count > 0) {
+      GP_TRY(e, hipMalloc((void**)&cached->d_ops, (size_t)op_count * sizeof(bito_amd_gp_op)));
+      GP_TRY(e, hipMemcpy(cached->d_ops, S.image.data(), (size_t)op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
     }
-    GP_TRY(e, hipMemcpy(e->d_levels, S.level_offsets.data(), S.level_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (!S.level_offsets.empty()) {
+      GP_TRY(e, hipMalloc((void**)&cached->d_levels, S.level_offsets.size() * sizeof(int64_t)));
+      GP_TRY(e, hipMemcpy(cached->d_levels, S.level_offsets.data(), S.level_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    // (never a null pointer in a kernel's argument list: a stream without PrepForMarginalization gets one entry)
+    GP_TRY(e, hipMalloc((void**)&cached->d_side, (size_t)std::max<int64_t>(side_used, 1) * sizeof(uint64_t)));
+    if (side_used > 0) GP_TRY(e, hipMemcpy(cached->d_side, side, (size_t)side_used * sizeof(uint64_t), hipMemcpyHostToDevice));
+    cached->on_device = true;
   }
+  bito_amd_gp_op* const d_ops = cached->d_ops;
+  const uint64_t* const d_side = cached->d_side;
   if ((size_t)S.max_concurrent_optimisers > e->coef_blocks) {
     (void)hipFree(e->coef);
     e->coef = nullptr;
@@ -952,17 +963,20 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
     switch (L.kind) {
       case bito_amd_gp_schedule::kPatternOps:
         if (L.count >= kLevelMinOps && L.level_count > 1) {
-          hipLaunchKernelGGL(gp_levels_kernel, dim3((e->P + 63) / 64), dim3(64, kLevelWaves), 0, 0, e->d_ops,
-                             (const int64_t*)(e->d_levels + L.level_first), L.level_count, e->d_side, e->plv, e->counts,
+          hipLaunchKernelGGL(gp_levels_kernel, dim3((e->P + 63) / 64), dim3(64, kLevelWaves), 0, 0, d_ops,
+                             (const int64_t*)(cached->d_levels + L.level_first), L.level_count, d_side, e->plv, e->counts,
                              e->bl, e->q, e->ll, e->marginal, e->P, e->Ppad, e->threshold, e->log_threshold);
           GP_TRY(e, hipGetLastError());
-        } else if (int rc = RunSegment(e, L.first, L.count)) {
-          return rc;
+        } else if (L.count > 0) {
+          hipLaunchKernelGGL(gp_ops_kernel, dim3((e->P + 63) / 64), dim3(64), 0, 0, d_ops + L.first, L.count,
+                             (const int64_t*)nullptr, d_side, e->plv, e->counts, e->bl, e->q, e->ll, e->marginal, e->P,
+                             e->Ppad, e->threshold, e->log_threshold);
+          GP_TRY(e, hipGetLastError());
         }
         break;
       case bito_amd_gp_schedule::kOptimisers:
         // DAGBranchHandler::OptimizeBranchLength for every edge of the launch, a workgroup each
-        hipLaunchKernelGGL(gp_optimize_kernel, dim3((unsigned)L.count), dim3(kOptThreads), 0, 0, e->d_ops + L.first, e->plv,
+        hipLaunchKernelGGL(gp_optimize_kernel, dim3((unsigned)L.count), dim3(kOptThreads), 0, 0, d_ops + L.first, e->plv,
                            e->counts, e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, Settings(e));
         GP_TRY(e, hipGetLastError());
         break;
