@@ -1,7 +1,8 @@
 """bench.py's control flow, end to end, WITHOUT a GPU: the emulated library (tests/hip_emu) in place of libbito_amd.so, the
 three torch.cuda calls bench.py makes turned into no-ops, and the workloads shrunk to a handful of tiny trees -- so that a
 slip in the bench script (a misspelt key, a wrong shape) is found on the CPU and not by the one GPU run a round may get.
-The numbers it prints mean nothing.  usage: python scripts/bench_dry_run.py [ds1 | codon | config4 | gp]"""
+The numbers it prints mean nothing.  usage: python scripts/bench_dry_run.py [ds1 | ds1-dist | codon | config4 | gp]   (ds1-dist: the summed-log-likelihood
+all-reduce of a multi-rank run, on a one-rank gloo group)"""
 import json
 import os
 import subprocess
@@ -18,6 +19,30 @@ import torch
 torch.cuda.is_available = lambda: True
 torch.cuda.set_device = lambda d: None
 torch.cuda.synchronize = lambda *a: None
+if os.environ.get("BENCH_FORCE_DIST") == "1":
+    # the multi-rank code path on one rank: a gloo group in place of RCCL, "cuda" tensors that stay on the host
+    import torch.distributed as dist
+    real_init, real_tensor = dist.init_process_group, torch.tensor
+    def init(backend, **kw):
+        kw.pop("device_id", None)
+        return real_init("gloo", **kw)
+    dist.init_process_group = init
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.tensor = lambda *a, **k: real_tensor(*a, **{{kk: vv for kk, vv in k.items() if kk != "device"}})
+    real_device = torch.device
+    class FakeDevice:  # (bench.py builds torch.device("cuda", rank) for device_id, which init() above drops)
+        def __new__(cls, *a, **k):
+            return real_device("cpu") if a and a[0] == "cuda" else real_device(*a, **k)
+    torch.device = FakeDevice
+    import bito_amd.dist as bdist
+    class HostReducer:  # (ResidentSumReducer sums on the device and reduces with RCCL: its own tests are tests/test_dist_*.py)
+        def __init__(self, eng):
+            self.eng = eng
+        def run(self, want_gradient, rescaling):
+            self.eng.run(want_gradient, rescaling)
+        def finish(self):
+            pass
+    bdist.ResidentSumReducer = HostReducer
 from bito_amd import workloads
 small = lambda n, P, T: workloads.synthetic_gtr_weibull4(n, P, tree_count=T)
 def tiny_ds1(replicas=1, first_tree=0, tree_count=None):
@@ -36,12 +61,16 @@ runpy.run_path(os.path.join({root!r}, "bench.py"), run_name="__main__")
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "ds1"
+    force_dist = which.endswith("-dist")  # ds1-dist: BENCH_FORCE_DIST=1, the reduce path of a multi-rank run on one rank
+    which = which.replace("-dist", "")
     argv = {"ds1": ["--steps", "2", "--warmup", "1", "--replicas", "1", "--cpu-seconds", "2"],
             "codon": ["--workload", "codon", "--trees", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
             "config4": ["--workload", "config4", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
             "gp": ["--workload", "gp", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"]}[which]
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hip_emu")])
     env = dict(os.environ, BITO_AMD_LIB=EMU)
+    if force_dist:
+        env["BENCH_FORCE_DIST"] = "1"
     done = subprocess.run([sys.executable, "-c", BODY.format(root=ROOT, argv=argv)], capture_output=True, text=True, env=env)
     if done.returncode != 0:
         sys.stderr.write(done.stdout[-2000:] + done.stderr[-4000:])
