@@ -29,6 +29,7 @@ def lib():
         L.ref_polished_parent_ids.argtypes = [C.c_int, C.c_int, i32p, i32p, i32p, lp]
         L.ref_parent_id_round_trip.argtypes = [lp, C.c_int, lp]
         L.ref_detrifurcate.argtypes = [lp, C.c_int, dp, lp, dp]
+        L.ref_gp_operation.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
         L.ref_site_pattern.restype = vp
         L.ref_site_pattern.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
         L.ref_free_site_pattern.argtypes = [vp]
@@ -107,6 +108,15 @@ class SitePattern:
         lib().ref_patterns(h, self.patterns.ctypes.data_as(C.POINTER(C.c_int32)))
         lib().ref_weights(h, self.weights.ctypes.data_as(C.POINTER(C.c_double)))
         lib().ref_free_site_pattern(h)
+
+
+def gp_operation(opcode: int):
+    """(alternative index in the reference's std::variant GPOperation, a, b, c, count) of the reference's operation for an
+    opcode of include/bito_amd_gp.h, built with field values 11, 22, 33 (src/gp_operation.hpp:24-167)"""
+    out = (C.c_uint64 * 5)()
+    if lib().ref_gp_operation(int(opcode), out):
+        raise ValueError(opcode)
+    return tuple(int(v) for v in out)
 
 
 def _value(fn):

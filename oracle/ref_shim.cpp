@@ -8,6 +8,8 @@
 //   SURVEY 8a A1  SitePattern::Compress / GetPatterns / GetWeights          (src/site_pattern.cpp:16-131)
 //   SURVEY 8a A6  Node::Polish (which ids a topology's nodes get), Node::OfParentIdVector / ParentIdVector,
 //                 UnrootedTree::Detrifurcate                                (src/node.cpp:383-551, src/unrooted_tree.cpp:27-37)
+//   SURVEY 8b (3) the alternative index of every GPOperation in the reference's std::variant (src/gp_operation.hpp:162-167):
+//                 the opcodes of include/bito_amd_gp.h
 //   SURVEY 8f f1  Optimization::BrentMinimize(WithGradients), GradientAscent, LogSpaceGradientAscent,
 //                 NewtonRaphsonOptimization                                  (src/optimization.hpp:71-405)
 // Not buildable here, and therefore not in it: the Newick / Nexus parser (driver.cpp calls into taxon_name_munging.cpp,
@@ -19,6 +21,7 @@
 #include <vector>
 
 #include "alignment.hpp"
+#include "gp_operation.hpp"
 #include "optimization.hpp"
 #include "site_pattern.hpp"
 #include "unrooted_tree.hpp"
@@ -110,6 +113,44 @@ void ref_patterns(void* h, int32_t* out) {  // [sequence = taxon id][pattern]
 void ref_weights(void* h, double* out) {
   const auto& w = static_cast<SitePattern*>(h)->GetWeights();
   std::memcpy(out, w.data(), w.size() * sizeof(double));
+}
+
+// The reference's GPOperation for each opcode of include/bito_amd_gp.h, built with recognisable field values
+// (a = 11, b = 22, c = 33 in the order of bito_amd_gp_op's comment), and handed back as (variant index, a, b, c, count)
+// through the visitor a binding would use: the opcode numbering and the field order of the seam are the reference's.
+int ref_gp_operation(int opcode, uint64_t out[5]) {
+  using namespace GPOperations;
+  GPOperation op = ZeroPLV{0};
+  switch (opcode) {
+    case 0: op = ZeroPLV{11}; break;
+    case 1: op = SetToStationaryDistribution{11, 22}; break;
+    case 2: op = IncrementWithWeightedEvolvedPLV{11, 22, 33}; break;
+    case 3: op = Multiply{11, 22, 33}; break;
+    case 4: op = Likelihood{11, 22, 33}; break;
+    case 5: op = OptimizeBranchLength{11, 22, 33}; break;
+    case 6: op = UpdateSBNProbabilities{11, 22}; break;
+    case 7: op = ResetMarginalLikelihood{}; break;
+    case 8: op = IncrementMarginalLikelihood{11, 22, 33}; break;
+    case 9: op = PrepForMarginalization{11, {5, 6, 7}}; break;
+    default: return -1;
+  }
+  struct Fields {
+    uint64_t* o;
+    void operator()(const ZeroPLV& x) { o[1] = x.dest_; }
+    void operator()(const SetToStationaryDistribution& x) { o[1] = x.dest_; o[2] = x.root_gpcsp_idx_; }
+    void operator()(const IncrementWithWeightedEvolvedPLV& x) { o[1] = x.dest_; o[2] = x.gpcsp_; o[3] = x.src_; }
+    void operator()(const Multiply& x) { o[1] = x.dest_; o[2] = x.src1_; o[3] = x.src2_; }
+    void operator()(const Likelihood& x) { o[1] = x.dest_; o[2] = x.child_; o[3] = x.parent_; }
+    void operator()(const OptimizeBranchLength& x) { o[1] = x.leafward_; o[2] = x.rootward_; o[3] = x.gpcsp_; }
+    void operator()(const UpdateSBNProbabilities& x) { o[1] = x.start_; o[2] = x.stop_; }
+    void operator()(const ResetMarginalLikelihood&) {}
+    void operator()(const IncrementMarginalLikelihood& x) { o[1] = x.stationary_times_prior_; o[2] = x.rootsplit_; o[3] = x.p_; }
+    void operator()(const PrepForMarginalization& x) { o[1] = x.dest_; o[4] = x.src_vector_.size(); }
+  };
+  out[0] = op.index();
+  out[1] = out[2] = out[3] = out[4] = 0;
+  std::visit(Fields{out}, op);
+  return 0;
 }
 
 // the optimisers, on a function handed in by the caller

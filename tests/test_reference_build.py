@@ -198,3 +198,18 @@ def test_gradient_brent_newton_and_the_ascents_are_the_references(data_dir):
         one.ops = [op]
         eng.process_operations(one)
         assert eng.get_branch_lengths()[edge] == expect, method
+
+
+def test_gp_opcodes_are_the_variants_alternative_indices():
+    """Seam 3's opcode of an operation is the alternative index of the reference's std::variant GPOperation, and a, b, c are
+    the reference's fields in declaration order (src/gp_operation.hpp:24-167; INTEGRATION.md's Flatten visitor): read off
+    the reference's own types."""
+    names = ["ZERO_PLV", "SET_TO_STATIONARY", "INCREMENT_WITH_WEIGHTED_EVOLVED_PLV", "MULTIPLY", "LIKELIHOOD",
+             "OPTIMIZE_BRANCH_LENGTH", "UPDATE_SBN_PROBABILITIES", "RESET_MARGINAL_LIKELIHOOD", "INCREMENT_MARGINAL_LIKELIHOOD",
+             "PREP_FOR_MARGINALIZATION"]
+    fields = {0: (11, 0, 0), 1: (11, 22, 0), 2: (11, 22, 33), 3: (11, 22, 33), 4: (11, 22, 33), 5: (11, 22, 33), 6: (11, 22, 0),
+              7: (0, 0, 0), 8: (11, 22, 33), 9: (11, 0, 0)}
+    for opcode, name in enumerate(names):
+        assert getattr(gp, name) == opcode
+        index, a, b, c, count = ref.gp_operation(opcode)
+        assert index == opcode and (a, b, c) == fields[opcode] and count == (3 if opcode == 9 else 0)
