@@ -59,6 +59,8 @@ inline hipError_t hipMalloc(void** p, size_t bytes) {
   *p = std::malloc(bytes ? bytes : 1);
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
+template <typename T>
+inline hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(p), bytes); }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) { std::memmove(dst, src, bytes); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(dst, src, bytes, k); }
@@ -164,7 +166,8 @@ struct Block {
   // per wave: exchange slots of the shuffles and a barrier of the wave's live lanes
   struct Wave {
     uint64_t bits[kWave];
-    bool present[kWave];
+    unsigned stamp[kWave];  // the exchange a lane last took part in: a wave operation sees the lanes that called it
+    unsigned exchange = 0;  // (as the hardware's sees the lanes of the EXEC mask), not a lane's stale value
     int arrived = 0, live = 0, lanes = 0;  // lanes: threads the wave was launched with
     unsigned generation = 0;
   };
@@ -340,9 +343,16 @@ inline const uint64_t* Publish(uint64_t mine) {
   Block::Wave& w = b->waves[(size_t)lin / kWave];
   WaveBarrier();  // (the readers of the exchange before are done)
   w.bits[lane] = mine;
-  w.present[lane] = true;
+  w.stamp[lane] = w.generation;  // (the same for every lane of this exchange: the barrier above has just released them)
   WaveBarrier();
+  w.exchange = w.stamp[lane];
   return w.bits;
+}
+// did lane l take part in the exchange the caller has just returned from?
+inline bool Active(int l) {
+  Block* b = Current();
+  const Block::Wave& w = b->waves[(size_t)Linear() / kWave];
+  return l < w.lanes && w.stamp[l] == w.stamp[Linear() % kWave];
 }
 inline int Lane() { return Linear() % kWave; }
 template <typename T>
@@ -381,18 +391,16 @@ inline int hip_emu_frexp_exp(double x) {  // v_frexp_exp_i32_f64: 0 for zero, in
 
 inline uint64_t __ballot(int predicate) {
   const uint64_t* all = hip_emu::Publish(predicate ? 1 : 0);
-  hip_emu::Block* b = hip_emu::Current();
-  const hip_emu::Block::Wave& w = b->waves[(size_t)hip_emu::Linear() / hip_emu::kWave];
   uint64_t mask = 0;
   for (int l = 0; l < hip_emu::kWave; l++)
-    if (l < w.lanes && all[l]) mask |= 1ull << l;
+    if (hip_emu::Active(l) && all[l]) mask |= 1ull << l;
   return mask;
 }
-inline int __all(int predicate) {
-  hip_emu::Block* b = hip_emu::Current();
-  const int lanes = b->waves[(size_t)hip_emu::Linear() / hip_emu::kWave].lanes;
-  const uint64_t want = lanes == 64 ? ~0ull : ((1ull << lanes) - 1);
-  return __ballot(predicate) == want;
+inline int __all(int predicate) {  // over the lanes that call it
+  const uint64_t* all = hip_emu::Publish(predicate ? 1 : 0);
+  for (int l = 0; l < hip_emu::kWave; l++)
+    if (hip_emu::Active(l) && !all[l]) return 0;
+  return 1;
 }
 inline int __any(int predicate) { return __ballot(predicate) != 0; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

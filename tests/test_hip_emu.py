@@ -1,0 +1,36 @@
+"""The stand-in HIP runtime of tests/hip_emu against itself and against a record from the device.  selftest.hip: a block
+reduction through shuffles, dynamic LDS and two barriers with three of four waves leaving in between; the DPP /
+permlane sums of bito_amd/csrc/wave_sums.hpp, shuffles, readfirstlane, ballots and votes (in uniform and in divergent
+code: a vote counts the lanes that take part, as the hardware's EXEC mask does); atomics across workgroups.
+probe_mfma16.hip: the program that measured v_mfma_f64_16x16x4's lane layout and rounding on an MI355X in round 1 must
+print under emulation what it printed on the device (profiles/r1_mfma16_probe.json)."""
+import json
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMU = os.path.join(HERE, "hip_emu")
+
+
+def _build():
+    built = subprocess.run(["make", "-s", "-C", EMU, "tools"], capture_output=True, text=True)
+    assert built.returncode == 0, built.stdout + built.stderr
+
+
+def test_emulator_semantics():
+    _build()
+    done = subprocess.run([os.path.join(EMU, "_build", "selftest")], capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stdout + done.stderr
+    assert done.stdout.split() == ["block_sum", "ok", "wave_ops", "ok", "counter", "ok"]
+
+
+def test_emulated_mfma_is_what_the_device_measured():
+    _build()
+    done = subprocess.run([os.path.join(EMU, "_build", "probe_mfma16_emu")], capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stdout + done.stderr
+    got = json.loads(done.stdout)
+    with open(os.path.join(ROOT, "profiles", "r1_mfma16_probe.json")) as fh:
+        device = json.load(fh)
+    for key in ("matched", "of", "column_is_lane_mod_16", "bit_equal_to_sequential_fma_chain", "row_of[lane/16][register]"):
+        assert got[key] == device[key], key
