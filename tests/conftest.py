@@ -28,7 +28,7 @@ def data_dir():
 # threads and per-slot second pass, engine.cpp; one barrier fewer per round in gs_eigen_kernel -- all green under
 # tests/hip_emu, none yet on hardware) go last -- a
 # failure there must not hide the results of everything else.  Within a group the order is pytest's own.
-RUN_LAST = ("test_codon_fixtures.py", "test_gpu_general.py", "test_round5_host.py", "test_gp.py", "test_nni.py", "test_tp.py")
+RUN_LAST = ("test_codon_fixtures.py", "test_gpu_general.py", "test_round5_host.py", "test_gp.py", "test_gp_binding_client.py", "test_nni.py", "test_tp.py")
 
 
 def pytest_collection_modifyitems(config, items):
