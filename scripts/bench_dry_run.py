@@ -1,7 +1,7 @@
 """bench.py's control flow, end to end, WITHOUT a GPU: the emulated library (tests/hip_emu) in place of libbito_amd.so, the
 three torch.cuda calls bench.py makes turned into no-ops, and the workloads shrunk to a handful of tiny trees -- so that a
 slip in the bench script (a misspelt key, a wrong shape) is found on the CPU and not by the one GPU run a round may get.
-The numbers it prints mean nothing.  usage: python scripts/bench_dry_run.py [ds1 | ds1-dist | codon | config4 | gp]   (ds1-dist: the summed-log-likelihood
+The numbers it prints mean nothing.  usage: python scripts/bench_dry_run.py [ds1 | ds1-dist | codon | config4 | gp | gp-seeded]   (ds1-dist: the summed-log-likelihood
 all-reduce of a multi-rank run, on a one-rank gloo group)"""
 import json
 import os
@@ -66,7 +66,8 @@ def main():
     argv = {"ds1": ["--steps", "2", "--warmup", "1", "--replicas", "1", "--cpu-seconds", "2"],
             "codon": ["--workload", "codon", "--trees", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
             "config4": ["--workload", "config4", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
-            "gp": ["--workload", "gp", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"]}[which]
+            "gp": ["--workload", "gp", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
+            "gp-seeded": ["--workload", "gp", "--gp-dag", "seeded", "--steps", "1", "--warmup", "1", "--cpu-seconds", "1"]}[which]
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hip_emu")])
     env = dict(os.environ, BITO_AMD_LIB=EMU)
     if force_dist:
@@ -78,7 +79,7 @@ def main():
     line = json.loads(done.stdout.strip().splitlines()[-1])
     keys = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
             "data", "config", "roofline", "cpu_baseline", "parity", "model_cache_hit", "resident"]
-    if which == "gp":
+    if which.startswith("gp"):
         keys = [k for k in keys if k not in ("model_cache_hit", "resident")]
     missing = [k for k in keys if k not in line]
     print(f"bench.py {which}: one JSON line, {len(line)} keys; missing {missing}; parity {line.get('parity')}")

@@ -34,7 +34,7 @@ for name, sp_, dag_, bl0, sweeps in cases:
         problems, stats = gp_trace.compare(cpu, gpu)
         print(f"{name}, {label}: {len(cpu)} evaluations on the CPU, {len(gpu)} on the device; compared {stats['compared']}, "
               f"max |dx| {stats['max_dx']:.2e} |dt| {stats['max_dt']:.2e} |df| {stats['max_df']:.2e}, near-ties {stats['ties']}, "
-              f"smallest margins {stats["smallest_choice_margin"]:.2e} (choice) {stats["smallest_value_margin"]:.2e} (value); max |d length| {np.abs(bl_gpu - bl_cpu).max():.3e}"
+              f"smallest margins {stats['smallest_choice_margin']:.2e} (choice) {stats['smallest_value_margin']:.2e} (value); max |d length| {np.abs(bl_gpu - bl_cpu).max():.3e}"
               + (f"; explained by a near-tie: {stats['explained_at']}" if stats["explained_at"] else ""))
         for msg in problems[:3]:
             print("   PROBLEM", msg)
