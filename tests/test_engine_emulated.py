@@ -207,3 +207,30 @@ def test_emulated_codon_model_setup_is_bitwise_the_checkers(emulated):
     checker's bit for bit (round 5 folded the eigensolver's zeroing step into its row update: three barriers per round)."""
     out = run_gpu_tests_emulated(["tests/test_gpu_general.py", "-k", "bitwise"])
     assert "1 passed" in out, out[-500:]
+
+
+def test_emulated_hbm_walks_do_not_depend_on_the_batch(emulated):
+    """A tree's results from the HBM-arena walks -- config 4's path: rescaling, five to eight rate categories, more than 64
+    taxa -- are the same bits alone, inside a batch, and in a call cut into chunks over two device slots: their pattern
+    tiles are 64 wide whatever the batch and reduce_tiles_kernel adds them in tile order.  (The dependence DESIGN.md
+    section 3 documents is walk_pipe_kernel's: its tiles follow the launch plan of the batch.)  As the reference, whose
+    trees do not know of one another (src/fat_beagle.hpp:173-181)."""
+    run('''
+for site in ("weibull+4", "weibull+6"):
+    w = small(14, 300, 9, site)
+    for rescaling in (False, True):
+        eng = bito_amd.Engine(spec(w), w.patterns, w.weights)
+        whole = eng.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+        for t in (0, 4, 8):
+            one = eng.gradients(w.parent_ids[t:t + 1], w.branch_lengths[t:t + 1], w.params[t:t + 1], rescaling=rescaling)
+            assert one["log_likelihood"][0] == whole["log_likelihood"][t]
+            assert np.array_equal(one["branch_lengths"][0], whole["branch_lengths"][t])
+        os.environ.update(BITO_AMD_CHUNK_FIRST="2", BITO_AMD_CHUNK_CAP="4", BITO_AMD_CHUNK_GROWTH="2")
+        chunked = bito_amd.Engine(spec(w), w.patterns, w.weights, devices=[0, 0])
+        for k in ("BITO_AMD_CHUNK_FIRST", "BITO_AMD_CHUNK_CAP", "BITO_AMD_CHUNK_GROWTH"):
+            os.environ.pop(k)
+        out = chunked.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+        assert np.array_equal(out["log_likelihood"], whole["log_likelihood"])
+        assert np.array_equal(out["branch_lengths"], whole["branch_lengths"])
+        print(site, rescaling, eng.kernel_name(), "ok")
+''')
