@@ -100,6 +100,24 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in text.replace("CPU oracle and GPU engine", ""), f"{f} mentions the oracle"
 
 
+def test_product_knows_nothing_of_the_emulation_or_the_reference_build():
+    """tests/hip_emu (the stand-in HIP runtime the CPU suite runs the .hip sources under) and oracle/_ref (the reference's
+    own code compiled in place) are test infrastructure: the package, the headers, bench.py's measured path and the driver
+    entry points' product side do not mention them, and the only way a process loads the emulated library is the
+    BITO_AMD_LIB variable that tests set."""
+    for base in ("bito_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".inc")) or f == "Makefile":
+                    text = open(os.path.join(dirpath, f)).read()
+                    for word in ("hip_emu", "HIP_EMULATION", "_ref/", "libbito_ref", "libbito_amd_emu"):
+                        assert word not in text, (f, word)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert "hip_emu" not in bench and "_ref" not in bench
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "hip_emu" not in entry  # (build() does build oracle/_ref where the reference is present: building the checker is not using it)
+
+
 def test_newick_ids_follow_polish(data_dir):
     tc = treeio.read_newick_file(os.path.join(data_dir, "hello.nwk"))
     assert tc.taxon_names == ["mars", "saturn", "jupiter"]
