@@ -593,7 +593,8 @@ def main():
     # sanity: results of the timed calls are finite
     # (BENCH_ABLATION=1: timing-only kernel variants of scripts/build_*_variants.sh, whose results mean nothing)
     if not os.environ.get("BENCH_ABLATION") and not (np.all(np.isfinite(out_ll)) and (not w.want_gradient or np.all(np.isfinite(out_grad)))):
-        raise SystemExit("non-finite results in the timed batch")
+        bad = np.flatnonzero(~np.isfinite(out_ll) | (~np.isfinite(out_grad).all(axis=1) if w.want_gradient else False))
+        raise SystemExit(f"non-finite results in the timed batch: {len(bad)} of {len(out_ll)} trees, the first {bad[:8].tolist()}")
     # ... and they are the right numbers: eight trees of the last step against the CPU checker
     parity = None
     if rank == 0 and not args.no_parity_check and not os.environ.get("BENCH_ABLATION"):

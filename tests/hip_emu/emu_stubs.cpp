@@ -21,16 +21,6 @@ LdsPlan PlanLds(const BatchDims&) { return LdsPlan{}; }
 size_t LdsScheduleInts(const BatchDims&) { return 0; }
 void LaunchLdsSchedule(const BatchDims&, const DeviceBatch&, const LdsPlan&, hipStream_t) { NotEmulated("walk_lds_kernel"); }
 void LaunchWalkLds(const BatchDims&, const DeviceBatch&, const LdsPlan&, int, int, hipStream_t) { NotEmulated("walk_lds_kernel"); }
-LdsPlan PlanPipe(const BatchDims&) { return LdsPlan{}; }
-LdsPlan PlanPipeClass(const BatchDims&, int, int, int, int) { return LdsPlan{}; }
-int PipeMaxSlots(const BatchDims&, int, int) { return 0; }
-int PipeSlotsOfTree(const BatchDims&, int) { return 1 << 20; }
-bool PipeTwoApplies(const BatchDims&) { return false; }
-size_t PipeScheduleInts(const BatchDims&) { return 0; }
-size_t PipeMaskInts(const BatchDims&, const LdsPlan&) { return 0; }
-void LaunchPipeMasks(const BatchDims&, const DeviceBatch&, const LdsPlan&, uint32_t*, hipStream_t) { NotEmulated("walk_pipe_kernel"); }
-void LaunchPipePrepare(const BatchDims&, const DeviceBatch&, const LdsPlan&, hipStream_t, bool, int, int, int, const uint8_t*) { NotEmulated("walk_pipe_kernel"); }
-void LaunchWalkPipe(const BatchDims&, const DeviceBatch&, const LdsPlan&, int, int, int, hipStream_t, const PipeClass&) { NotEmulated("walk_pipe_kernel"); }
 void LaunchMatrixImages(const BatchDims&, const DeviceBatch&, int, int, hipStream_t) { NotEmulated("walk_lds_kernel's matrix images"); }
 TreePlan PlanTree(const BatchDims&) { return TreePlan{}; }
 void LaunchWalkTree(const BatchDims&, const DeviceBatch&, const TreePlan&, int, hipStream_t) { NotEmulated("walk_tree_kernel"); }

@@ -57,6 +57,10 @@ inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t bytes) {
   *p = std::malloc(bytes ? bytes : 1);
+  // (device memory starts out as garbage on the hardware too; HIP_EMU_POISON=1 makes a read of it show: all-ones words
+  // are NaNs as doubles and -1 as indices)
+  static const bool poison = std::getenv("HIP_EMU_POISON") != nullptr;
+  if (*p && poison) std::memset(*p, 0xff, bytes ? bytes : 1);
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 template <typename T>
@@ -77,6 +81,8 @@ inline hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes) {
   *total_bytes = (size_t)8 << 30;
   return hipSuccess;
 }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t, int) { *value = 2; return hipSuccess; }  // (two "CUs")
 struct hipDeviceProp_t {
   char gcnArchName[64];
   int multiProcessorCount;
@@ -163,9 +169,15 @@ struct Block {
   // the workgroup barrier
   int arrived = 0;
   unsigned generation = 0;
+  // s_barrier inside an interpreted asm statement: one participant per wave
+  int asm_arrived = 0;
+  unsigned asm_generation = 0;
   // per wave: exchange slots of the shuffles and a barrier of the wave's live lanes
   struct Wave {
     uint64_t bits[kWave];
+    void* machine = nullptr;                      // gfx950_asm.hpp: the wave's registers, kept from one asm statement to the next
+    std::vector<std::vector<uint64_t>>* staged = nullptr;  // ... and the operands of the statement being run
+    void (*release)(Wave&) = nullptr;                       // frees the two at the end of the workgroup
     unsigned stamp[kWave];  // the exchange a lane last took part in: a wave operation sees the lanes that called it
     unsigned exchange = 0;  // (as the hardware's sees the lanes of the EXEC mask), not a lane's stale value
     int arrived = 0, live = 0, lanes = 0;  // lanes: threads the wave was launched with
@@ -303,6 +315,8 @@ inline void RunBlock(const std::function<void()>& body, dim3 block) {
       std::abort();
     }
   }
+  for (Block::Wave& w : b.waves)
+    if (w.release) w.release(w);
   Current() = nullptr;
 }
 
@@ -505,6 +519,39 @@ inline void hip_emu_global_load_lds(const __attribute__((address_space(1))) void
 }
 #define __builtin_amdgcn_global_load_lds(src, dst, bytes, offset, aux) hip_emu_global_load_lds(src, dst, bytes)
 
+// v_mfma_f64_4x4x4_4b: A lane = 16 k + 4 b + i, B lane = 16 k + 4 b + j, D lane = 16 i + 4 b + j (walk_lds.hip)
+inline double hip_emu_mfma_f64_4x4x4(double a, double b, double c) {
+  uint64_t ra, rb;
+  std::memcpy(&ra, &a, 8);
+  std::memcpy(&rb, &b, 8);
+  uint64_t A[64], B[64];
+  std::memcpy(A, hip_emu::Publish(ra), sizeof(A));
+  std::memcpy(B, hip_emu::Publish(rb), sizeof(B));
+  const int lane = hip_emu::Lane(), i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+  double acc = c;
+  for (int k = 0; k < 4; k++) {
+    double x, y;
+    std::memcpy(&x, &A[16 * k + 4 * blk + i], 8);
+    std::memcpy(&y, &B[16 * k + 4 * blk + j], 8);
+    acc = std::fma(x, y, acc);
+  }
+  return acc;
+}
+#define __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, x, y, z) hip_emu_mfma_f64_4x4x4(a, b, c)
+// v_mov_b32 with DPP row_ror:n (0x121-0x12f): lane i of a row takes the value of lane (i - n) mod 16 of that row
+inline int __builtin_amdgcn_mov_dpp(int src, int ctrl, int, int, bool) {
+  const uint64_t* all = hip_emu::Publish((uint32_t)src);
+  const int lane = hip_emu::Lane(), row = lane & ~15, in_row = lane & 15;
+  if (ctrl >= 0x121 && ctrl <= 0x12f) return (int)(uint32_t)all[row + ((in_row - (ctrl - 0x120)) & 15)];
+  std::fprintf(stderr, "hip_emu: DPP control 0x%x is not emulated\n", ctrl);
+  std::abort();
+}
+inline long long clock64() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (long long)ts.tv_sec * 100000000ll + ts.tv_nsec / 10;
+}
+
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(ptr, value, order, scope) __atomic_store_n(ptr, value, order)
 
@@ -515,6 +562,7 @@ struct uint4 { unsigned x, y, z, w; };
 struct double2 { double x, y; };
 struct double4 { double x, y, z, w; };
 inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
 inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
 template <typename T>
@@ -532,3 +580,93 @@ inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 inline long long min(long long a, long long b) { return a < b ? a : b; }
 inline long long max(long long a, long long b) { return a > b ? a : b; }
+
+// ---- interpreted asm statements (gfx950_asm.hpp; prepare.py turns `asm volatile(text : outs : ins : clobbers)` of
+// walk_pipe.hip into hip_emu::RunAsm(text, {outs}, {ins})) ---------------------------------------------------------------
+#include "../gfx950_asm.hpp"
+
+namespace hip_emu {
+
+inline const Program& ProgramOf(const char* text) {
+  static std::unordered_map<const char*, Program> cache;  // (launches are serialised: no lock)
+  auto it = cache.find(text);
+  if (it == cache.end()) it = cache.emplace(text, ParseProgram(text)).first;
+  return it->second;
+}
+
+inline void RunAsm(const char* text, std::initializer_list<AsmOperand> outs, std::initializer_list<AsmOperand> ins) {
+  const Program& P = ProgramOf(text);
+  Block* b = Current();
+  const int lin = Linear(), lane = lin % kWave;
+  Block::Wave& w = b->waves[(size_t)lin / kWave];
+  const size_t count = P.operand_names.size();
+  std::vector<const AsmOperand*> bound(count, nullptr);
+  for (const auto* list : {&outs, &ins})
+    for (const AsmOperand& o : *list)
+      for (size_t k = 0; k < count; k++)
+        if (P.operand_names[k] == o.name) bound[k] = &o;
+  WaveBarrier();  // (the statement before is over for every lane)
+  if (lane == 0) {
+    if (!w.machine) w.machine = new WaveMachine();
+    w.release = [](Block::Wave& x) {
+      delete static_cast<WaveMachine*>(x.machine);
+      delete x.staged;
+      x.machine = nullptr;
+      x.staged = nullptr;
+    };
+    if (!w.staged) w.staged = new std::vector<std::vector<uint64_t>>();
+    w.staged->assign(count, std::vector<uint64_t>(64, 0));
+  }
+  WaveBarrier();
+  for (size_t k = 0; k < count; k++) {
+    if (!bound[k]) { std::fprintf(stderr, "hip_emu: asm operand %s is not bound\n", P.operand_names[k].c_str()); std::abort(); }
+    (*w.staged)[k][(size_t)lane] = bound[k]->value;
+  }
+  WaveBarrier();
+  if (lane == 0) {
+    std::vector<bool> scalar(count);
+    for (size_t k = 0; k < count; k++) scalar[k] = bound[k]->scalar;
+    AsmContext ctx;
+    ctx.lds = static_cast<char*>(DynamicShared());
+    ctx.lds_bytes = DynamicStore().size() * sizeof(double);
+    ctx.barrier = [b] {
+      const int waves = (int)b->waves.size();
+      const unsigned mine = b->asm_generation;
+      if (++b->asm_arrived == waves) {
+        b->asm_arrived = 0;
+        b->asm_generation++;
+      } else {
+        while (b->asm_generation == mine) Yield();
+      }
+    };
+    static const bool digest = std::getenv("HIP_EMU_ASM_DIGEST") != nullptr;
+    auto fnv = [](const void* data, size_t bytes, uint64_t h = 1469598103934665603ull) {
+      const unsigned char* c = static_cast<const unsigned char*>(data);
+      for (size_t i = 0; i < bytes; i++) h = (h ^ c[i]) * 1099511628211ull;
+      return h;
+    };
+    WaveMachine& M = *static_cast<WaveMachine*>(w.machine);
+    if (digest) {
+      uint64_t ho = 0;
+      for (size_t k = 0; k < count; k++) ho = fnv((*w.staged)[k].data(), scalar[k] ? 8 : 512, ho + k);
+      std::fprintf(stderr, "asm in  block %u wave %d stmt %p: lds %016llx operands %016llx v %016llx a %016llx s %016llx\n", blockIdx.x,
+                   lin / kWave, (const void*)text, (unsigned long long)fnv(ctx.lds, ctx.lds_bytes), (unsigned long long)ho,
+                   (unsigned long long)fnv(M.v.data(), 256 * 64 * 4), (unsigned long long)fnv(M.a.data(), M.a.size() * 4),
+                   (unsigned long long)fnv(M.s, 106 * 4));
+    }
+    Execute(P, M, *w.staged, scalar, ctx);
+    if (digest) {
+      uint64_t ho = 0;
+      for (size_t k = 0; k < count; k++) ho = fnv((*w.staged)[k].data(), scalar[k] ? 8 : 512, ho + k);
+      std::fprintf(stderr, "asm out block %u wave %d stmt %p: lds %016llx operands %016llx v %016llx a %016llx s %016llx\n", blockIdx.x,
+                   lin / kWave, (const void*)text, (unsigned long long)fnv(ctx.lds, ctx.lds_bytes), (unsigned long long)ho,
+                   (unsigned long long)fnv(M.v.data(), 256 * 64 * 4), (unsigned long long)fnv(M.a.data(), M.a.size() * 4),
+                   (unsigned long long)fnv(M.s, 106 * 4));
+    }
+  }
+  WaveBarrier();
+  for (size_t k = 0; k < count; k++)
+    if (bound[k]->output) std::memcpy(bound[k]->target, &(*w.staged)[k][(size_t)lane], (size_t)bound[k]->size);
+}
+
+}  // namespace hip_emu
