@@ -1,7 +1,8 @@
-// The kernels the emulated build leaves out: walk_pipe.hip (gfx950 assembly) and walk_lds.hip / walk_tree.hip (inline
-// assembly; pinned-only kernels).  Their planners report "does not apply",
-// so AUTO routes every four-state batch to the HBM-arena walks -- the code path the product takes for rescaling,
-// five to eight rate categories and more than 64 taxa -- and their launchers are never reached (they abort if they are).
+// The kernels the emulated build leaves out: walk_lds.hip / walk_tree.hip (inline assembly; pinned-only kernels that AUTO
+// never picks).  Their planners report "does not apply" and their launchers are never reached (they abort if they are).
+// walk_pipe.hip IS part of the build: its three asm statements run through the gfx950 interpreter (gfx950_asm.hpp), so
+// AUTO routes as in the product -- walk_pipe_kernel up to 64 taxa and four rate categories without rescaling, the
+// HBM-arena walks for the rest.
 // Test infrastructure only (tests/hip_emu).
 #include <hip/hip_runtime.h>
 

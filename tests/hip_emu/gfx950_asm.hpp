@@ -9,8 +9,13 @@
 // kernel keeps a tree's matrix images in AGPRs across statements).  Code addresses are virtual -- 8 bytes per
 // instruction -- which is all the generated code needs: every jump goes through label differences, s_getpc_b64 and
 // s_setpc_b64.  LDS addresses are byte offsets into the launch's dynamic LDS (prepare.py rewrites LdsAddress()
-// accordingly).  s_waitcnt / s_nop are no-ops: every instruction completes before the next starts.  The ~40 opcodes the
-// generator emits are implemented; an unknown one aborts with its text.
+// accordingly; M0 carries an 18-bit LDS base for global_load_lds: the images of a 64-taxon tree stage through 126 KB).
+// s_waitcnt / s_nop are no-ops: every instruction completes before the next starts.  An LDS read past the launch's
+// allocation returns zeros (the image loader over-reads its last rows into registers nothing uses, as the hardware lets
+// it); an LDS WRITE out of range aborts.  The ~40 opcodes the generator emits are implemented; an unknown one aborts with
+// its text.  Debugging aids (environment): HIP_EMU_ASM_TRACE=<n> prints the first n scalar instructions of a statement,
+// HIP_EMU_ASM_NONFINITE=1 the first instructions that write a non-finite double, HIP_EMU_ASM_DIGEST=1 (hip_runtime.h) a
+// hash of LDS, operands and register files at every statement's entry and exit -- two runs diffed show where they part.
 // v_mfma_f64_4x4x4_4b: four 4 x 4 x 4 blocks; A lane = 16 k + 4 b + i, B lane = 16 k + 4 b + j, D lane = 16 i + 4 b + j
 // (bito_amd/csrc/walk_lds.hip), summed as a fused multiply-add chain over k.
 #pragma once

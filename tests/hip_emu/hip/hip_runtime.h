@@ -7,7 +7,10 @@
 // cooperative fibers on one OS thread, barriers and wave shuffles with their real semantics -- so that logic errors
 // (a wrong index, a missed dependency, a race that a barrier was meant to close in program order) show up in the CPU
 // suite.  What it does not show: timing, the hardware's rounding under FMA contraction, memory-model effects between
-// workgroups, anything written in gfx950 assembly (walk_pipe.hip is out of its reach).
+// workgroups.  gfx950 assembly: walk_pipe.hip's three asm statements are INTERPRETED (gfx950_asm.hpp, RunAsm below);
+// walk_lds.hip / walk_tree.hip (pinned-only kernels with inline assembly of their own) stay outside.  Lanes of a wave do
+// not run in lockstep here: code that relies on that without a wave operation in between (one place, pipe_prepare's
+// exponentials handed round through LDS) gets a wave barrier in the prepared copy (prepare.py).
 //
 // Execution model: a kernel launch runs at once, on the launching thread, block after block (one launch at a time,
 // process-wide mutex); a block's threads are fibers (a dozen instructions of x86-64 context switch: the callee-saved

@@ -1,12 +1,14 @@
-"""The per-tree engine -- engine.cpp, worker.cpp and the kernels that are plain HIP C++ (kernels.hip: set-up, transition
-matrices, walk_hbm_kernel, final sums; walk_hbm_cat.hip; time_tree.hip) -- executed on the CPU through the stand-in HIP
-runtime of tests/hip_emu, against the CPU checker.  walk_pipe_kernel (gfx950 assembly), the LDS walks and the general-state
-kernels are outside the emulated build: AUTO routes every batch to the HBM-arena walks here, the path the product takes
-for rescaling, five to eight rate categories and more than 64 taxa.  What this holds in a round without GPU access: the
-host side of a blocking call (chunks, device slots each on its own thread, the shared helper threads that pack large
-chunks, the site-model gradient's second pass from every slot's thread -- round 5's changes), and the logic of the
-HBM-arena kernels.  Small synthetic shapes: a tree costs a third of a second as fibers.  Each test runs in a process of its
-own (the library under test is chosen when bito_amd is first imported).  Test infrastructure: the product has no CPU path."""
+"""The per-tree engine -- engine.cpp, worker.cpp and the kernels (kernels.hip: set-up, transition matrices,
+walk_hbm_kernel, final sums; walk_hbm_cat.hip; time_tree.hip as plain HIP C++; walk_pipe.hip with its gfx950 assembly
+interpreted instruction by instruction, tests/hip_emu/gfx950_asm.hpp) -- executed on the CPU through the stand-in HIP
+runtime of tests/hip_emu, against the CPU checker.  AUTO routes as in the product: walk_pipe_kernel for up to 64 taxa
+and four rate categories without rescaling (its own tests: tests/test_pipe_emulated.py), the HBM-arena walks for
+rescaling, five to eight rate categories and larger trees; only the pinned-only LDS walks are outside the emulated build.
+What this holds in a round without GPU access: the host side of a blocking call (chunks, device slots each on its own
+thread, the shared helper threads that pack large chunks, the site-model gradient's second pass from every slot's thread
+-- round 5's changes), and the logic of the kernels.  Small synthetic shapes: a tree costs a third of a second as fibers.
+Each test runs in a process of its own (the library under test is chosen when bito_amd is first imported).  Test
+infrastructure: the product has no CPU path."""
 import os
 import subprocess
 import sys
