@@ -15,12 +15,21 @@ import csv, collections, json
 out={}
 names=set()
 for f in ('$R/gpurun_out/pmc_${T}_a/a_counter_collection.csv','$R/gpurun_out/pmc_${T}_b/b_counter_collection.csv'):
-    agg=collections.defaultdict(lambda: collections.defaultdict(float)); launches=collections.defaultdict(set)
+    agg=collections.defaultdict(lambda: collections.defaultdict(float)); launches=collections.defaultdict(set); per={}; grid={}
     for r in csv.DictReader(open(f)):
         if 'walk_pipe' in r['Kernel_Name']:
             k=r['Kernel_Name'].split('(')[0]
             names.add(k)
-            agg[k][r['Counter_Name']]+=float(r['Counter_Value']); launches[k].add(r['Dispatch_Id'])
+            per.setdefault(k,{}).setdefault(r['Dispatch_Id'],collections.defaultdict(float))[r['Counter_Name']]+=float(r['Counter_Value'])
+            grid.setdefault(k,{})[r['Dispatch_Id']]=int(r['Grid_Size'])
+    # the mean over the FULL-SIZE dispatches only (the largest grid: the resident passes of 6400 trees): the blocking call
+    # in front of them runs as two smaller chunks, and round 4's files averaged those in as if they were full launches
+    for k in per:
+        top=max(grid[k].values())
+        for d,c in per[k].items():
+            if grid[k][d]==top:
+                launches[k].add(d)
+                for name,v in c.items(): agg[k][name]+=v
     for k in agg:
         for c,v in agg[k].items(): out.setdefault(k,{})[c]=v/len(launches[k])
         out[k]['launches']=len(launches[k])

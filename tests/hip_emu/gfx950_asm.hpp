@@ -68,7 +68,41 @@ struct Inst {
   int sel1 = -1;         // SDWA src1_sel BYTE_n
   int idx_mode = 0;      // gpr_idx(...) bits: SRC0 1, SRC1 2, SRC2 4, DST 8
   int target = -1;       // branch target (instruction index)
+  int cls = 0;           // InstClass: what the hardware's SQ_INSTS_* counters would file it under
 };
+
+// Executed wave-level instructions by class, over the process (HIP_EMU_ASM_COUNT=1 prints them at exit as one JSON line on
+// stderr).  The same quantities the hardware counts as SQ_INSTS_MFMA / _VALU (matrix instructions included) / _SALU /
+// _SMEM / _LDS / _VMEM_RD: profiles/r4_v2_pipe_one_wave_pmc.json holds them for a launch of 6400 DS1 trees, and
+// scripts/emu_pipe_instruction_mix.py sets the two side by side -- a check that the interpreter walks the instruction
+// stream the device does.  (The C++ around the statements is compiled code on the device and fibers here: not counted.)
+enum InstClass { kClassMfma, kClassValu, kClassSalu, kClassSmem, kClassLds, kClassVmemRd, kClassBranch, kClassWait, kClassCount };
+struct InstCounts {
+  long long n[kClassCount] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long statements = 0;
+  ~InstCounts() {
+    if (!std::getenv("HIP_EMU_ASM_COUNT")) return;
+    std::fprintf(stderr,
+                 "{\"asm_statements\": %lld, \"mfma\": %lld, \"valu_other\": %lld, \"salu\": %lld, \"smem\": %lld, \"lds\": %lld, "
+                 "\"vmem_rd\": %lld, \"branch\": %lld, \"wait_nop_barrier\": %lld}\n",
+                 statements, n[kClassMfma], n[kClassValu], n[kClassSalu], n[kClassSmem], n[kClassLds], n[kClassVmemRd],
+                 n[kClassBranch], n[kClassWait]);
+  }
+};
+inline InstCounts& Counts() {
+  static InstCounts c;
+  return c;
+}
+inline int ClassOf(const std::string& op) {
+  if (op.rfind("v_mfma", 0) == 0) return kClassMfma;
+  if (op.rfind("v_", 0) == 0) return kClassValu;
+  if (op.rfind("ds_", 0) == 0) return kClassLds;
+  if (op.rfind("global_", 0) == 0 || op.rfind("buffer_", 0) == 0) return kClassVmemRd;
+  if (op.rfind("s_load", 0) == 0) return kClassSmem;
+  if (op == "s_nop" || op == "s_waitcnt" || op == "s_barrier") return kClassWait;
+  if (op == "s_branch" || op.rfind("s_cbranch", 0) == 0 || op == "s_setpc_b64") return kClassBranch;
+  return kClassSalu;
+}
 struct Program {
   std::vector<Inst> code;
   std::vector<std::string> operand_names;
@@ -188,6 +222,7 @@ inline Program ParseProgram(const char* text) {
       if (comma == std::string::npos) break;
       at = comma + 1;
     }
+    in.cls = ClassOf(in.op);
     P.code.push_back(in);
   }
   return P;
@@ -333,12 +368,14 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
   };
   size_t pc = 0;
   long executed = 0;
+  Counts().statements++;
   while (pc < P.code.size()) {
     const Inst& in = P.code[pc];
     current = &in;
     const std::string& op = in.op;
     size_t next = pc + 1;
     if (++executed > 50000000) AsmFail(in, "no end in sight");
+    Counts().n[in.cls]++;
     static const long trace_until = std::getenv("HIP_EMU_ASM_TRACE") ? std::atol(std::getenv("HIP_EMU_ASM_TRACE")) : 0;
     if (executed <= trace_until && (op[0] == 's' && op != "s_nop" && op != "s_waitcnt"))
       std::fprintf(stderr, "  [%ld] pc %zu  %s   (m0 %u scc %d s32 %08x s48 %08x s92 %u)\n", executed, pc, in.text.c_str(), M.m0, (int)M.scc,

@@ -490,6 +490,22 @@ inline void hip_emu_buffer_store(T v, hip_emu_rsrc r, unsigned voffset, unsigned
 #define __builtin_amdgcn_raw_buffer_store_b64(x, r, v, s, aux) hip_emu_buffer_store<hip_emu_u2>(x, r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b128(x, r, v, s, aux) hip_emu_buffer_store<hip_emu_u4>(x, r, v, s)
 
+// matrix instructions the compiled C++ issues through builtins, wave-level, over the process (HIP_EMU_ASM_COUNT=1 prints
+// them at exit beside the interpreter's counts, gfx950_asm.hpp: what SQ_INSTS_MFMA counts on the device)
+namespace hip_emu {
+struct BuiltinCounts {
+  long long mfma_16x16x4 = 0, mfma_4x4x4 = 0;
+  ~BuiltinCounts() {
+    if (std::getenv("HIP_EMU_ASM_COUNT"))
+      std::fprintf(stderr, "{\"builtin_mfma_f64_16x16x4\": %lld, \"builtin_mfma_f64_4x4x4\": %lld}\n", mfma_16x16x4, mfma_4x4x4);
+  }
+};
+inline BuiltinCounts& Builtins() {
+  static BuiltinCounts c;
+  return c;
+}
+}  // namespace hip_emu
+
 // v_mfma_f64_16x16x4: A lane = 16 k + i, B lane = 16 k + j; register r of lane 16 q + j holds D[4 r + q][j]; one
 // instruction rounds like a sequential fma() chain over k = 0..3 (measured on the device: profiles/r1_mfma16_probe.json)
 template <typename V4>
@@ -501,6 +517,7 @@ inline V4 hip_emu_mfma_f64_16x16x4(double a, double b, V4 c) {
   std::memcpy(A, hip_emu::Publish(ra), sizeof(A));
   std::memcpy(B, hip_emu::Publish(rb), sizeof(B));
   const int lane = hip_emu::Lane(), q = lane >> 4, j = lane & 15;
+  if (lane == 0) hip_emu::Builtins().mfma_16x16x4++;
   V4 d = c;
   for (int r = 0; r < 4; r++) {
     const int i = 4 * r + q;
@@ -531,6 +548,7 @@ inline double hip_emu_mfma_f64_4x4x4(double a, double b, double c) {
   std::memcpy(A, hip_emu::Publish(ra), sizeof(A));
   std::memcpy(B, hip_emu::Publish(rb), sizeof(B));
   const int lane = hip_emu::Lane(), i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+  if (lane == 0) hip_emu::Builtins().mfma_4x4x4++;
   double acc = c;
   for (int k = 0; k < 4; k++) {
     double x, y;

@@ -128,3 +128,32 @@ ll = eng.log_likelihoods(tc.parent_id_matrix(), tc.branch_length_matrix(), eng.d
 assert eng.kernel_name() == "walk_pipe_kernel"
 assert abs(ll[0] - -84.852358) < 1e-6, ll
 '''.replace("{here!r}", repr(HERE)))
+
+
+def test_interpreter_issues_the_matrix_instructions_the_device_counted(emulated):
+    """The interpreter against the hardware's own counter: an MI355X counted SQ_INSTS_MFMA = 281 502 720 for one launch of
+    walk_pipe_kernel<4,4,true,0> over 6400 DS1 trees (the 100 topologies x 64; round 4's last build, per dispatch in
+    profiles/r4_v2_pipe_one_wave_pmc_per_dispatch.json).  The interpreter, walking the 100 distinct trees, must issue
+    exactly a sixty-fourth of that -- the asm statements' v_mfma_f64_4x4x4 plus the root's builtin -- or it does not walk
+    the step tables and loop bodies the device does.  (scripts/emu_pipe_instruction_mix.py prints every class and the
+    blocking call's 1024- and 5376-tree chunks, which agree as well.)"""
+    import json
+    import subprocess
+    import sys
+
+    device = json.load(open(os.path.join(ROOT, "profiles", "r4_v2_pipe_one_wave_pmc_per_dispatch.json")))
+    full = device["dispatches"]["19"]
+    assert full["grid_size"] == 65536 and device["_trees"]["19"] == 6400
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import emu_pipe_instruction_mix as mix
+
+    counts = mix.emulated_counts(100)
+    issued = counts["mfma"] + counts["builtin_mfma_f64_4x4x4"]
+    assert 64 * issued == int(full["SQ_INSTS_MFMA"]) == 281502720, (issued, full["SQ_INSTS_MFMA"])
+    # the classes the compiled C++ around the statements adds to on the device: the interpreter's share is most of each
+    for mine, theirs in ((issued + counts["valu_other"], "SQ_INSTS_VALU"), (counts["lds"], "SQ_INSTS_LDS"),
+                         (counts["salu"] + counts["branch"], "SQ_INSTS_SALU"), (counts["smem"], "SQ_INSTS_SMEM")):
+        assert 0.9 * full[theirs] < 64 * mine <= full[theirs], (theirs, 64 * mine, full[theirs])
+    # profiles/executed.json (bench.py's roofline.executed) quotes the same count
+    row = [r for r in json.load(open(os.path.join(ROOT, "profiles", "executed.json"))) if r["kernel"] == "walk_pipe_kernel"][0]
+    assert abs(row["matrix_instructions_per_tree"] - issued / 100) < 1e-9
