@@ -31,7 +31,7 @@ assert np.all(np.isfinite(out["log_likelihood"]))
 
 
 def emulated_counts(trees, whole_tree_units=True):
-    env = dict(os.environ, BITO_AMD_LIB=EMU, HIP_EMU_ASM_COUNT="1")
+    env = dict(os.environ, BITO_AMD_LIB=EMU, HIP_EMU_ASM_COUNT="1", HIP_EMU_ASM_HAZARDS="abort")
     if whole_tree_units:
         env.update(BITO_AMD_PIPE_WHOLE_TREES=str(trees), BITO_AMD_LDS_TILE_RUN="5")
     done = subprocess.run([sys.executable, "-c", BODY.format(root=ROOT, trees=trees)], capture_output=True, text=True, env=env)

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -69,6 +70,7 @@ struct Inst {
   int idx_mode = 0;      // gpr_idx(...) bits: SRC0 1, SRC1 2, SRC2 4, DST 8
   int target = -1;       // branch target (instruction index)
   int cls = 0;           // InstClass: what the hardware's SQ_INSTS_* counters would file it under
+  int wait_lgkm = -1, wait_vm = -1;  // s_waitcnt: the counts it waits for (-1: not named)
 };
 
 // Executed wave-level instructions by class, over the process (HIP_EMU_ASM_COUNT=1 prints them at exit as one JSON line on
@@ -89,6 +91,32 @@ struct InstCounts {
                  n[kClassBranch], n[kClassWait]);
   }
 };
+// Hazards: what the interpreter's one-instruction-at-a-time execution would otherwise hide.  (1) s_waitcnt: a register
+// read (or overwritten) while a load that names it may still be in flight, an LDS range read while a global_load_lds may
+// still be filling it.  "May": by the ISA's guarantees alone -- lgkmcnt(N) with N > 0 retires the oldest LDS operations
+// only as far as the count allows when every scalar load in flight is assumed to have returned first (scalar loads
+// return out of order), and never a scalar load.  (2) a scalar write of M0 needs one wait state before s_movrels or
+// global_load_lds reads it.  Every hazard is printed (the first sixteen) and counted; HIP_EMU_ASM_HAZARDS=abort makes
+// the first one fatal, =0 switches the check off.  The count is printed at exit with HIP_EMU_ASM_COUNT=1.
+struct HazardLog {
+  long long count = 0, checked_reads = 0, waits = 0;
+  int mode = 1;  // 0 off, 1 report, 2 abort
+  HazardLog() {
+    if (const char* m = std::getenv("HIP_EMU_ASM_HAZARDS")) mode = std::strcmp(m, "abort") == 0 ? 2 : std::atoi(m);
+  }
+  ~HazardLog() {
+    if (std::getenv("HIP_EMU_ASM_COUNT"))
+      std::fprintf(stderr, "{\"asm_hazards\": %lld, \"register_reads_checked\": %lld, \"s_waitcnt_executed\": %lld}\n", count, checked_reads, waits);
+  }
+  void Report(const char* what, const char* inst, const char* producer) {
+    if (count++ < 16) std::fprintf(stderr, "gfx950_asm: HAZARD: %s: %s   (in flight: %s)\n", what, inst, producer);
+    if (mode == 2) std::abort();
+  }
+};
+inline HazardLog& Hazards() {
+  static HazardLog h;
+  return h;
+}
 inline InstCounts& Counts() {
   static InstCounts c;
   return c;
@@ -206,6 +234,13 @@ inline Program ParseProgram(const char* text) {
         rest.erase(g);
       }
     }
+    if (in.op == "s_waitcnt") {
+      const size_t l = rest.find("lgkmcnt("), m = rest.find("vmcnt(");
+      if (l != std::string::npos) in.wait_lgkm = std::atoi(rest.c_str() + l + 8);
+      if (m != std::string::npos) in.wait_vm = std::atoi(rest.c_str() + m + 6);
+      if (rest.find("expcnt(") != std::string::npos) { std::fprintf(stderr, "gfx950_asm: expcnt is not modelled: %s\n", ln.c_str()); std::abort(); }
+    }
+    if (in.op == "s_nop") in.offset = std::atoi(rest.c_str());
     if (in.op == "s_waitcnt" || in.op == "s_nop" || in.op == "s_barrier" || in.op == "s_set_gpr_idx_off") rest.clear();
     // operands
     size_t at = 0;
@@ -236,7 +271,25 @@ struct WaveMachine {
   uint64_t exec = ~0ull, vcc = 0;
   bool scc = false, idx_on = false;
   int idx_bits = 0;
-  WaveMachine() : v((size_t)384 * 64, 0), a((size_t)256 * 64, 0) { std::memset(s, 0, sizeof(s)); }
+  // Memory operations in flight, as s_waitcnt sees them (the VALUES are delivered at once -- this is bookkeeping for the
+  // hazard check below).  lgkm: LDS operations (complete in order among themselves) and scalar loads (complete in any
+  // order); vm: global_load_lds (in order).  A register is "pending" from the load that names it to the s_waitcnt that
+  // guarantees its arrival; so is the LDS range a global_load_lds fills.
+  struct InFlight {
+    bool scalar = false;            // s_load*
+    std::vector<int> regs;          // destination registers: file << 16 | index (file 0 v, 1 a, 2 s)
+    uint32_t lds_lo = 0, lds_hi = 0;  // LDS bytes a global_load_lds writes
+    const char* text = "";
+  };
+  std::deque<InFlight> lgkm, vm;
+  std::vector<uint16_t> pending[3];  // per register of each file: loads in flight that will write it
+  long m0_age = 1000;                // wait states since a scalar instruction wrote M0
+  WaveMachine() : v((size_t)384 * 64, 0), a((size_t)256 * 64, 0) {
+    std::memset(s, 0, sizeof(s));
+    pending[0].assign(384, 0);
+    pending[1].assign(256, 0);
+    pending[2].assign(128, 0);
+  }
   uint32_t& V(int r, int lane) {
     if (r < 0 || r >= 384) { std::fprintf(stderr, "gfx950_asm: VGPR v%d does not exist\n", r); std::abort(); }
     return v[(size_t)r * 64 + lane];
@@ -295,12 +348,35 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
     }
     return idx;
   };
+  HazardLog& hazards = Hazards();
+  const Inst* current = nullptr;
+  int check_lane = 0;  // the first lane of EXEC: register checks are made once per instruction, not per lane
+  auto touch = [&](int file, int index, const char* what) {  // a register about to be read or overwritten
+    hazards.checked_reads++;
+    if (!M.pending[file][(size_t)index]) return;
+    const char* producer = "";
+    for (const auto* q : {&M.lgkm, &M.vm})
+      for (const WaveMachine::InFlight& f : *q)
+        for (int reg : f.regs)
+          if (reg == (file << 16 | index)) producer = f.text;
+    hazards.Report(what, current ? current->text.c_str() : "", producer);
+  };
   auto read32 = [&](const Reg& r0, int position, int lane, int word = 0) -> uint32_t {
     const Reg r = resolve(r0);
     switch (r.kind) {
-      case RK::V: return M.V(vindex(r, position) + word, lane);
-      case RK::A: return M.A(vindex(r, position) + word, lane);
-      case RK::S: return M.s[r.index + word];
+      case RK::V: {
+        const int idx = vindex(r, position) + word;
+        if (hazards.mode && (lane == 0 || lane == check_lane)) touch(0, idx, "reads a VGPR before the s_waitcnt that delivers it");
+        return M.V(idx, lane);
+      }
+      case RK::A: {
+        const int idx = vindex(r, position) + word;
+        if (hazards.mode && (lane == 0 || lane == check_lane)) touch(1, idx, "reads an AGPR before the s_waitcnt that delivers it");
+        return M.A(idx, lane);
+      }
+      case RK::S:
+        if (hazards.mode) touch(2, r.index + word, "reads an SGPR before the s_waitcnt that delivers it");
+        return M.s[r.index + word];
       case RK::M0: return M.m0;
       case RK::Exec: return (uint32_t)(M.exec >> (32 * word));
       case RK::Vcc: return (uint32_t)(M.vcc >> (32 * word));
@@ -324,10 +400,22 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
   auto write32 = [&](const Reg& r0, int lane, uint32_t value, int word = 0) {
     const Reg r = resolve(r0);
     switch (r.kind) {
-      case RK::V: M.V(vindex(r, 0) + word, lane) = value; break;
-      case RK::A: M.A(vindex(r, 0) + word, lane) = value; break;
-      case RK::S: M.s[r.index + word] = value; break;
-      case RK::M0: M.m0 = value; break;
+      case RK::V:
+        if (hazards.mode && (lane == 0 || lane == check_lane)) touch(0, vindex(r, 0) + word, "overwrites a VGPR a load in flight will write");
+        M.V(vindex(r, 0) + word, lane) = value;
+        break;
+      case RK::A:
+        if (hazards.mode && (lane == 0 || lane == check_lane)) touch(1, vindex(r, 0) + word, "overwrites an AGPR a load in flight will write");
+        M.A(vindex(r, 0) + word, lane) = value;
+        break;
+      case RK::S:
+        if (hazards.mode) touch(2, r.index + word, "overwrites an SGPR a load in flight will write");
+        M.s[r.index + word] = value;
+        break;
+      case RK::M0:
+        M.m0 = value;
+        M.m0_age = -1;  // (the instruction's own wait state is added at the end of the loop body)
+        break;
       case RK::Exec: M.exec = word ? ((M.exec & 0xffffffffull) | ((uint64_t)value << 32)) : ((M.exec & ~0xffffffffull) | value); break;
       default: break;
     }
@@ -337,7 +425,6 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
     if (r.kind == RK::V) M.V(r.index + word, lane) = value;
     else if (r.kind == RK::A) M.A(r.index + word, lane) = value;
   };
-  const Inst* current = nullptr;
   static const bool report_nonfinite = std::getenv("HIP_EMU_ASM_NONFINITE") != nullptr;
   static int nonfinite_reports = 0;
   auto writef64 = [&](const Reg& r, int lane, double d) {
@@ -366,6 +453,44 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
     }
     return ctx.lds + addr;
   };
+  auto issue = [&](std::deque<WaveMachine::InFlight>& queue, bool scalar_load, const Reg* dst, int words, const Inst& in) -> WaveMachine::InFlight& {
+    queue.emplace_back();
+    WaveMachine::InFlight& f = queue.back();
+    f.scalar = scalar_load;
+    f.text = in.text.c_str();
+    if (dst) {
+      const Reg r = resolve(*dst);
+      const int file = r.kind == RK::V ? 0 : r.kind == RK::A ? 1 : 2;
+      for (int w = 0; w < words; w++) {
+        f.regs.push_back(file << 16 | (r.index + w));
+        M.pending[file][(size_t)(r.index + w)]++;
+      }
+    }
+    return f;
+  };
+  auto retire = [&](std::deque<WaveMachine::InFlight>& queue, size_t position) {
+    for (int reg : queue[position].regs) M.pending[reg >> 16][(size_t)(reg & 0xffff)]--;
+    queue.erase(queue.begin() + (long)position);
+  };
+  // s_waitcnt lgkmcnt(n) / vmcnt(n): what the ISA guarantees has arrived (see HazardLog)
+  auto wait_for = [&](int lgkm, int vm) {
+    hazards.waits++;
+    if (lgkm == 0) {
+      while (!M.lgkm.empty()) retire(M.lgkm, 0);
+    } else if (lgkm > 0) {
+      size_t scalar_loads = 0;
+      for (const auto& f : M.lgkm) scalar_loads += f.scalar;
+      const long completions = (long)M.lgkm.size() - lgkm;       // at least this many have returned ...
+      long lds_done = completions - (long)scalar_loads;           // ... the scalar loads first, for all we know
+      for (size_t k = 0; k < M.lgkm.size() && lds_done > 0;) {
+        if (M.lgkm[k].scalar) { k++; continue; }
+        retire(M.lgkm, k);
+        lds_done--;
+      }
+    }
+    if (vm >= 0)
+      while ((long)M.vm.size() > vm) retire(M.vm, 0);
+  };
   size_t pc = 0;
   long executed = 0;
   Counts().statements++;
@@ -374,13 +499,17 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
     current = &in;
     const std::string& op = in.op;
     size_t next = pc + 1;
+    check_lane = M.exec ? __builtin_ctzll(M.exec) : 0;
     if (++executed > 50000000) AsmFail(in, "no end in sight");
     Counts().n[in.cls]++;
     static const long trace_until = std::getenv("HIP_EMU_ASM_TRACE") ? std::atol(std::getenv("HIP_EMU_ASM_TRACE")) : 0;
     if (executed <= trace_until && (op[0] == 's' && op != "s_nop" && op != "s_waitcnt"))
       std::fprintf(stderr, "  [%ld] pc %zu  %s   (m0 %u scc %d s32 %08x s48 %08x s92 %u)\n", executed, pc, in.text.c_str(), M.m0, (int)M.scc,
                    M.s[32], M.s[48], M.s[92]);
-    if (op == "s_nop" || op == "s_waitcnt") {
+    if (op == "s_nop") {
+      M.m0_age += in.offset;  // (s_nop n: n + 1 wait states, the one every instruction adds below included)
+    } else if (op == "s_waitcnt") {
+      if (hazards.mode) wait_for(in.wait_lgkm, in.wait_vm);
     } else if (op == "s_barrier") {
       ctx.barrier();
     } else if (op == "s_mov_b32") {
@@ -444,6 +573,7 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
       if (addr % 8 || addr / 8 > P.code.size()) AsmFail(in, "a jump outside the statement");
       next = (size_t)(addr / 8);
     } else if (op == "s_movrels_b32") {
+      if (hazards.mode && M.m0_age < 1) hazards.Report("s_movrels reads M0 without a wait state behind the scalar write", in.text.c_str(), "m0");
       const Reg src = resolve(in.r[1]);
       write32(in.r[0], 0, M.s[(src.index + (int)M.m0) & 127]);
     } else if (op == "s_set_gpr_idx_on") {
@@ -460,7 +590,10 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
       const uint64_t base = sreg64(in.r[1]);
       const uint64_t off = in.nr > 2 ? (resolve(in.r[2]).kind == RK::Imm ? in.r[2].imm : read32(in.r[2], 2, 0)) : 0;
       const Reg d = resolve(in.r[0]);
+      // (a load over a load in flight is not flagged: the loader warms the scalar cache with loads into one scratch
+      // register, and LDS reads return in order)
       std::memcpy(&M.s[d.index], reinterpret_cast<const void*>(base + off), (size_t)words * 4);
+      if (hazards.mode) issue(M.lgkm, true, &in.r[0], words, in);
     } else if (op == "v_mov_b32") {
       for (int l = 0; l < 64; l++)
         if (active(l)) write32(in.r[0], l, read32(in.r[1], 1, l));
@@ -525,6 +658,10 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
       for (int l = 0; l < 64; l++)
         if (active(l)) {
           const uint32_t addr = read32(in.r[1], 9, l) + (uint32_t)in.offset;
+          if (hazards.mode)
+            for (const WaveMachine::InFlight& f : M.vm)
+              if (addr < f.lds_hi && addr + (uint32_t)words * 4 > f.lds_lo)
+                hazards.Report("reads LDS bytes a global_load_lds may still be filling (no vmcnt wait)", in.text.c_str(), f.text);
           uint32_t tmp[4];
           // (a read past the launch's allocation returns zeros, as the hardware's out-of-range LDS reads do: the image
           // loader's last rows over-read into registers nothing uses; a WRITE out of range stays an error)
@@ -532,7 +669,9 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
           else std::memcpy(tmp, lds_at(addr, (size_t)words * 4), (size_t)words * 4);
           for (int w = 0; w < words; w++) write_raw(in.r[0], l, tmp[w], w);
         }
+      if (hazards.mode) issue(M.lgkm, false, &in.r[0], words, in);
     } else if (op == "ds_write_b64" || op == "ds_write_b128") {
+      if (hazards.mode) issue(M.lgkm, false, nullptr, 0, in);
       const int words = op == "ds_write_b64" ? 2 : 4;
       for (int l = 0; l < 64; l++)
         if (active(l)) {
@@ -542,6 +681,7 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
           std::memcpy(lds_at(addr, (size_t)words * 4), tmp, (size_t)words * 4);
         }
     } else if (op == "ds_add_f64") {
+      if (hazards.mode) issue(M.lgkm, false, nullptr, 0, in);
       for (int l = 0; l < 64; l++)
         if (active(l)) {
           const uint32_t addr = read32(in.r[0], 9, l) + (uint32_t)in.offset;
@@ -553,6 +693,12 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
     } else if (op == "global_load_lds_dwordx4") {
       // every lane: 16 bytes from (scalar base + its vector offset + offset) to LDS at M0 + offset + 16 * lane
       const uint64_t base = sreg64(in.r[1]);
+      if (hazards.mode) {
+        if (M.m0_age < 1) hazards.Report("global_load_lds reads M0 without a wait state behind the scalar write", in.text.c_str(), "m0");
+        WaveMachine::InFlight& f = issue(M.vm, false, nullptr, 0, in);
+        f.lds_lo = (M.m0 & 0x3ffff) + (uint32_t)in.offset;
+        f.lds_hi = f.lds_lo + 1024;
+      }
       for (int l = 0; l < 64; l++)
         if (active(l)) {
           const uint64_t from = base + read32(in.r[0], 9, l) + (uint64_t)in.offset;
@@ -561,6 +707,7 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
     } else {
       AsmFail(in, "opcode not implemented");
     }
+    M.m0_age++;
     pc = next;
   }
   for (size_t k = 0; k < operands.size(); k++) {

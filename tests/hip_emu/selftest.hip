@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "wave_sums.hpp"
@@ -49,8 +50,71 @@ __global__ void counter_kernel(unsigned long long* counter, int* order) {
   order[at] = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// The assembly interpreter (gfx950_asm.hpp) against the builtin it stands beside, and its hazard check against small
+// programs that keep and break the rules: variant 0 the 4x4x4 matrix instruction, 1 an LDS read behind its s_waitcnt,
+// 2 the same read used without the wait, 3 s_movrels straight behind a write of M0, 4 the same with its wait state,
+// 5 lgkmcnt(1) with a scalar load in flight (which may return first: the LDS read is NOT guaranteed).
+__global__ void __launch_bounds__(64) asm_kernel(const double* a, const double* b, double* out, int variant) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  double x = a[lane], y = b[lane], r = -1.0;
+  unsigned addr = (unsigned)lane * 8u;
+  const double* table = a;
+  lds[lane] = x;
+  __syncthreads();
+  using hip_emu::Op;
+  if (variant == 0)
+    hip_emu::RunAsm("v_mfma_f64_4x4x4_4b_f64 %[r], %[x], %[y], 0\n", {Op("r", "=v", r)}, {Op("x", "v", x), Op("y", "v", y)});
+  if (variant == 1)
+    hip_emu::RunAsm("ds_read_b64 v[2:3], %[addr]\ns_waitcnt lgkmcnt(0)\nv_add_f64 %[r], v[2:3], %[y]\n", {Op("r", "=v", r)},
+                    {Op("addr", "v", addr), Op("y", "v", y)});
+  if (variant == 2)
+    hip_emu::RunAsm("ds_read_b64 v[2:3], %[addr]\nv_add_f64 %[r], v[2:3], %[y]\ns_waitcnt lgkmcnt(0)\n", {Op("r", "=v", r)},
+                    {Op("addr", "v", addr), Op("y", "v", y)});
+  if (variant == 3)
+    hip_emu::RunAsm("s_mov_b32 s21, 7\ns_mov_b32 m0, 1\ns_movrels_b32 s10, s20\nv_mov_b32 %[r], s10\n", {Op("r", "=v", r)}, {});
+  if (variant == 4)
+    hip_emu::RunAsm("s_mov_b32 s21, 7\ns_mov_b32 m0, 1\ns_nop 0\ns_movrels_b32 s10, s20\nv_mov_b32 %[r], s10\n", {Op("r", "=v", r)}, {});
+  if (variant == 5)
+    hip_emu::RunAsm("s_load_dwordx2 s[30:31], %[table], 0x0\nds_read_b64 v[2:3], %[addr]\ns_waitcnt lgkmcnt(1)\n"
+                    "v_add_f64 %[r], v[2:3], %[y]\ns_waitcnt lgkmcnt(0)\n",
+                    {Op("r", "=v", r)}, {Op("addr", "v", addr), Op("y", "v", y), Op("table", "s", table)});
+  out[lane] = variant == 0 ? r - __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, 0.0, 0, 0, 0) : r;
+}
+
 int main() {
   int bad = 0;
+  {
+    std::vector<double> a(64), b(64);
+    for (int l = 0; l < 64; l++) {
+      a[l] = 0.3 + l * 0.37;
+      b[l] = 1.0 / (1 + l);
+    }
+    double *d_a, *d_b, *d_out;
+    hipMalloc(&d_a, 64 * 8);
+    hipMalloc(&d_b, 64 * 8);
+    hipMalloc(&d_out, 64 * 8);
+    hipMemcpy(d_a, a.data(), 64 * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d_b, b.data(), 64 * 8, hipMemcpyHostToDevice);
+    bool ok = true;
+    // (variant, hazards it must raise, the value every lane must hold -- NaN: lane-dependent, checked below)
+    const struct { int variant; long long hazards; } cases[] = {{0, 0}, {1, 0}, {2, 1}, {3, 1}, {4, 0}, {5, 1}};
+    for (const auto& c : cases) {
+      const long long before = hip_emu::Hazards().count;
+      hipLaunchKernelGGL(asm_kernel, dim3(1), dim3(64), 64 * sizeof(double), 0, d_a, d_b, d_out, c.variant);
+      const long long raised = hip_emu::Hazards().count - before;
+      bool fine = (raised > 0) == (c.hazards > 0);
+      for (int l = 0; l < 64 && fine; l++) {
+        if (c.variant == 0) fine = d_out[l] == 0.0;
+        else if (c.variant == 3 || c.variant == 4) { unsigned bits; float f = 0; (void)f; std::memcpy(&bits, &d_out[l], 4); fine = bits == 7u; }
+        else fine = d_out[l] == a[l] + b[l];
+      }
+      if (!fine) std::printf("  asm variant %d: %lld hazards raised (expected %s), out[5] %g\n", c.variant, raised, c.hazards ? "some" : "none", d_out[5]);
+      ok = ok && fine;
+    }
+    std::printf("asm_interpreter %s\n", ok ? "ok" : "BAD");
+    bad += !ok;
+  }
   {
     const int n = 1000, blocks = 3;
     std::vector<double> in(n);

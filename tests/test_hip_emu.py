@@ -22,7 +22,10 @@ def test_emulator_semantics():
     _build()
     done = subprocess.run([os.path.join(EMU, "_build", "selftest")], capture_output=True, text=True, timeout=120)
     assert done.returncode == 0, done.stdout + done.stderr
-    assert done.stdout.split() == ["block_sum", "ok", "wave_ops", "ok", "counter", "ok"]
+    # (asm_interpreter: the gfx950 interpreter's matrix instruction bit for bit the builtin's, and its hazard check on six
+    # small programs -- an LDS read used behind / before its s_waitcnt, s_movrels with / without the wait state behind a
+    # write of M0, lgkmcnt(1) with a scalar load in flight -- raising hazards exactly where the ISA's rules are broken)
+    assert done.stdout.split() == ["asm_interpreter", "ok", "block_sum", "ok", "wave_ops", "ok", "counter", "ok"]
 
 
 def test_emulated_mfma_is_what_the_device_measured():

@@ -7,14 +7,24 @@ checker at the bars of tests/test_gpu_parity.py.  Every layout the launch planne
 pattern groups per wave, the "many" form (33-36 taxa beside four groups), exact and reversible images (38 / 39 taxa),
 the wide form (49-64 taxa), the two-wave form and the two-class launch, tile runs and whole-tree units, the site-model
 gradient's second traversal.  What this holds in a round without GPU access: the text of the generated assembly and the
-C++ around it compute the reference's numbers; what it cannot show: timing, hazards the hardware's pipelines would expose
-(the interpreter completes every instruction before the next starts).  Each test runs in a process of its own.  Test
+C++ around it compute the reference's numbers, and its s_waitcnt discipline holds by the ISA's guarantees alone (every
+register read is checked against the loads in flight: 0 hazards over every layout); what it cannot show: timing, and
+the wait states between vector and matrix instructions that the hardware interlocks or the author counted by hand.  Each test runs in a process of its own.  Test
 infrastructure: the product has no CPU path."""
 import os
 
 import pytest
 
-from test_engine_emulated import AS_PRODUCT, EMU, HERE, ROOT, emulated, run, run_gpu_tests_emulated  # noqa: F401
+from test_engine_emulated import AS_PRODUCT, EMU, HERE, ROOT, emulated, run_gpu_tests_emulated  # noqa: F401
+from test_engine_emulated import run as run_emulated
+
+
+def run(body, timeout=600, **env):
+    """... with the interpreter's hazard check fatal: a register read before the s_waitcnt that delivers it, an LDS range
+    read while a global_load_lds may still be filling it, M0 used without its wait state (gfx950_asm.hpp: HazardLog) --
+    what one-instruction-at-a-time execution would otherwise hide -- aborts the run."""
+    env.setdefault("HIP_EMU_ASM_HAZARDS", "abort")
+    return run_emulated(body, timeout, **env)
 
 CASE = '''
 def check(n, P, T, site="weibull+4", kernel=_capi.KERNEL_LDS_PIPE, rooted=False, want="walk_pipe_kernel", form=None, seed=5):
