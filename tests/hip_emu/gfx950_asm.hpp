@@ -96,7 +96,12 @@ struct InstCounts {
 // still be filling it.  "May": by the ISA's guarantees alone -- lgkmcnt(N) with N > 0 retires the oldest LDS operations
 // only as far as the count allows when every scalar load in flight is assumed to have returned first (scalar loads
 // return out of order), and never a scalar load.  (2) a scalar write of M0 needs one wait state before s_movrels or
-// global_load_lds reads it.  Every hazard is printed (the first sixteen) and counted; HIP_EMU_ASM_HAZARDS=abort makes
+// global_load_lds reads it.  (3) the wait states around v_mfma_f64_4x4x4 that the generator pads by hand inside the
+// asm strings -- matrix result -> vector read or overwrite 6, -> matrix A/B operand 6, -> matrix C operand 4, -> address or
+// data of an LDS / memory instruction 9; vector result -> matrix operand 2 (scripts/gen_walk_pipe.py's table, measured
+// from hipcc's own output for gfx950); every instruction is one state, s_nop n is n + 1, a taken jump counts four more
+// (measured there: 21 cycles).  The generator pads statically per body and drains at labels; this check follows the
+// path actually executed, across bodies.  Every hazard is printed (the first sixteen) and counted; HIP_EMU_ASM_HAZARDS=abort makes
 // the first one fatal, =0 switches the check off.  The count is printed at exit with HIP_EMU_ASM_COUNT=1.
 struct HazardLog {
   long long count = 0, checked_reads = 0, waits = 0;
@@ -284,11 +289,20 @@ struct WaveMachine {
   std::deque<InFlight> lgkm, vm;
   std::vector<uint16_t> pending[3];  // per register of each file: loads in flight that will write it
   long m0_age = 1000;                // wait states since a scalar instruction wrote M0
+  // wait states between a producer and a dependent instruction (the table scripts/gen_walk_pipe.py works from, measured
+  // from what hipcc inserts for gfx950 around v_mfma_f64_4x4x4): where each VGPR / AGPR was last written, and by what
+  long issue_pos = 0;                        // wait states issued so far in this statement
+  std::vector<long> written_at[2];           // per VGPR / AGPR: issue_pos of its last write (very negative: long ago)
+  std::vector<uint8_t> written_by[2];        // 1 a matrix instruction, 2 another vector instruction, 0 anything else
   WaveMachine() : v((size_t)384 * 64, 0), a((size_t)256 * 64, 0) {
     std::memset(s, 0, sizeof(s));
     pending[0].assign(384, 0);
     pending[1].assign(256, 0);
     pending[2].assign(128, 0);
+    written_at[0].assign(384, -1000);
+    written_at[1].assign(256, -1000);
+    written_by[0].assign(384, 0);
+    written_by[1].assign(256, 0);
   }
   uint32_t& V(int r, int lane) {
     if (r < 0 || r >= 384) { std::fprintf(stderr, "gfx950_asm: VGPR v%d does not exist\n", r); std::abort(); }
@@ -351,6 +365,21 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
   HazardLog& hazards = Hazards();
   const Inst* current = nullptr;
   int check_lane = 0;  // the first lane of EXEC: register checks are made once per instruction, not per lane
+  int inst_kind = 0;  // of the instruction being executed: 1 matrix, 2 other vector, 3 LDS / memory, 0 scalar
+  auto spacing = [&](int file, int index, int position) {  // wait states behind the register's producer (files 0, 1)
+    const int by = M.written_by[file][(size_t)index];
+    if (!by || !inst_kind) return;
+    int need = 0;
+    if (by == 1) need = inst_kind == 1 ? (position == 3 ? 4 : position == 0 ? 0 : 6) : inst_kind == 2 ? 6 : 9;
+    else if (by == 2 && inst_kind == 1 && position != 0) need = 2;
+    const long have = M.issue_pos - M.written_at[file][(size_t)index] - 1;
+    if (have < need) {
+      char what[160];
+      std::snprintf(what, sizeof(what), "%ld wait states behind a %s result where %d are needed (%s%d as operand %d)", have,
+                    by == 1 ? "matrix" : "vector", need, file ? "a" : "v", index, position);
+      hazards.Report(what, current ? current->text.c_str() : "", "");
+    }
+  };
   auto touch = [&](int file, int index, const char* what) {  // a register about to be read or overwritten
     hazards.checked_reads++;
     if (!M.pending[file][(size_t)index]) return;
@@ -366,12 +395,18 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
     switch (r.kind) {
       case RK::V: {
         const int idx = vindex(r, position) + word;
-        if (hazards.mode && (lane == 0 || lane == check_lane)) touch(0, idx, "reads a VGPR before the s_waitcnt that delivers it");
+        if (hazards.mode && (lane == 0 || lane == check_lane)) {
+          touch(0, idx, "reads a VGPR before the s_waitcnt that delivers it");
+          spacing(0, idx, position);
+        }
         return M.V(idx, lane);
       }
       case RK::A: {
         const int idx = vindex(r, position) + word;
-        if (hazards.mode && (lane == 0 || lane == check_lane)) touch(1, idx, "reads an AGPR before the s_waitcnt that delivers it");
+        if (hazards.mode && (lane == 0 || lane == check_lane)) {
+          touch(1, idx, "reads an AGPR before the s_waitcnt that delivers it");
+          spacing(1, idx, position);
+        }
         return M.A(idx, lane);
       }
       case RK::S:
@@ -401,11 +436,21 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
     const Reg r = resolve(r0);
     switch (r.kind) {
       case RK::V:
-        if (hazards.mode && (lane == 0 || lane == check_lane)) touch(0, vindex(r, 0) + word, "overwrites a VGPR a load in flight will write");
+        if (hazards.mode && (lane == 0 || lane == check_lane)) {
+          touch(0, vindex(r, 0) + word, "overwrites a VGPR a load in flight will write");
+          if (inst_kind == 2) spacing(0, vindex(r, 0) + word, 9);  // (a vector instruction over a matrix result: as a read)
+          M.written_at[0][(size_t)(vindex(r, 0) + word)] = M.issue_pos;
+          M.written_by[0][(size_t)(vindex(r, 0) + word)] = (uint8_t)(inst_kind <= 2 ? inst_kind : 0);
+        }
         M.V(vindex(r, 0) + word, lane) = value;
         break;
       case RK::A:
-        if (hazards.mode && (lane == 0 || lane == check_lane)) touch(1, vindex(r, 0) + word, "overwrites an AGPR a load in flight will write");
+        if (hazards.mode && (lane == 0 || lane == check_lane)) {
+          touch(1, vindex(r, 0) + word, "overwrites an AGPR a load in flight will write");
+          if (inst_kind == 2) spacing(1, vindex(r, 0) + word, 9);
+          M.written_at[1][(size_t)(vindex(r, 0) + word)] = M.issue_pos;
+          M.written_by[1][(size_t)(vindex(r, 0) + word)] = (uint8_t)(inst_kind <= 2 ? inst_kind : 0);
+        }
         M.A(vindex(r, 0) + word, lane) = value;
         break;
       case RK::S:
@@ -422,8 +467,13 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
   };
   auto write_raw = [&](const Reg& r0, int lane, uint32_t value, int word) {  // a memory instruction's destination
     const Reg r = resolve(r0);
-    if (r.kind == RK::V) M.V(r.index + word, lane) = value;
-    else if (r.kind == RK::A) M.A(r.index + word, lane) = value;
+    if (r.kind == RK::V) {
+      M.V(r.index + word, lane) = value;
+      M.written_by[0][(size_t)(r.index + word)] = 0;
+    } else if (r.kind == RK::A) {
+      M.A(r.index + word, lane) = value;
+      M.written_by[1][(size_t)(r.index + word)] = 0;
+    }
   };
   static const bool report_nonfinite = std::getenv("HIP_EMU_ASM_NONFINITE") != nullptr;
   static int nonfinite_reports = 0;
@@ -494,12 +544,14 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
   size_t pc = 0;
   long executed = 0;
   Counts().statements++;
+  M.issue_pos += 1000;  // (compiled code stands between two statements: their producers are long ago)
   while (pc < P.code.size()) {
     const Inst& in = P.code[pc];
     current = &in;
     const std::string& op = in.op;
     size_t next = pc + 1;
     check_lane = M.exec ? __builtin_ctzll(M.exec) : 0;
+    inst_kind = in.cls == kClassMfma ? 1 : in.cls == kClassValu ? 2 : (in.cls == kClassLds || in.cls == kClassVmemRd) ? 3 : 0;
     if (++executed > 50000000) AsmFail(in, "no end in sight");
     Counts().n[in.cls]++;
     static const long trace_until = std::getenv("HIP_EMU_ASM_TRACE") ? std::atol(std::getenv("HIP_EMU_ASM_TRACE")) : 0;
@@ -708,6 +760,7 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
       AsmFail(in, "opcode not implemented");
     }
     M.m0_age++;
+    M.issue_pos += 1 + (op == "s_nop" ? in.offset : 0) + (next != pc + 1 ? 4 : 0);  // (a taken jump: four more states)
     pc = next;
   }
   for (size_t k = 0; k < operands.size(); k++) {

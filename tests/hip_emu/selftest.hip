@@ -53,7 +53,7 @@ __global__ void counter_kernel(unsigned long long* counter, int* order) {
 // The assembly interpreter (gfx950_asm.hpp) against the builtin it stands beside, and its hazard check against small
 // programs that keep and break the rules: variant 0 the 4x4x4 matrix instruction, 1 an LDS read behind its s_waitcnt,
 // 2 the same read used without the wait, 3 s_movrels straight behind a write of M0, 4 the same with its wait state,
-// 5 lgkmcnt(1) with a scalar load in flight (which may return first: the LDS read is NOT guaranteed).
+// 5 lgkmcnt(1) with a scalar load in flight (which may return first: the LDS read is NOT guaranteed), 6-9 below.
 __global__ void __launch_bounds__(64) asm_kernel(const double* a, const double* b, double* out, int variant) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
@@ -79,7 +79,19 @@ __global__ void __launch_bounds__(64) asm_kernel(const double* a, const double* 
     hip_emu::RunAsm("s_load_dwordx2 s[30:31], %[table], 0x0\nds_read_b64 v[2:3], %[addr]\ns_waitcnt lgkmcnt(1)\n"
                     "v_add_f64 %[r], v[2:3], %[y]\ns_waitcnt lgkmcnt(0)\n",
                     {Op("r", "=v", r)}, {Op("addr", "v", addr), Op("y", "v", y), Op("table", "s", table)});
-  out[lane] = variant == 0 ? r - __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, 0.0, 0, 0, 0) : r;
+  // wait states around the matrix instruction: 6 a vector read straight behind it, 7 the same behind s_nop 5, 8 a vector
+  // result as a matrix operand one state later, 9 the same two states later
+  if (variant == 6)
+    hip_emu::RunAsm("v_mfma_f64_4x4x4_4b_f64 v[4:5], %[x], %[y], 0\nv_add_f64 %[r], v[4:5], 0\n", {Op("r", "=v", r)}, {Op("x", "v", x), Op("y", "v", y)});
+  if (variant == 7)
+    hip_emu::RunAsm("v_mfma_f64_4x4x4_4b_f64 v[4:5], %[x], %[y], 0\ns_nop 5\nv_add_f64 %[r], v[4:5], 0\n", {Op("r", "=v", r)}, {Op("x", "v", x), Op("y", "v", y)});
+  if (variant == 8)
+    hip_emu::RunAsm("v_add_f64 v[6:7], %[x], 0\ns_nop 0\nv_mfma_f64_4x4x4_4b_f64 v[4:5], v[6:7], %[y], 0\ns_nop 5\nv_add_f64 %[r], v[4:5], 0\n",
+                    {Op("r", "=v", r)}, {Op("x", "v", x), Op("y", "v", y)});
+  if (variant == 9)
+    hip_emu::RunAsm("v_add_f64 v[6:7], %[x], 0\ns_nop 1\nv_mfma_f64_4x4x4_4b_f64 v[4:5], v[6:7], %[y], 0\ns_nop 5\nv_add_f64 %[r], v[4:5], 0\n",
+                    {Op("r", "=v", r)}, {Op("x", "v", x), Op("y", "v", y)});
+  out[lane] = (variant == 0 || variant >= 6) ? r - __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, 0.0, 0, 0, 0) : r;
 }
 
 int main() {
@@ -98,14 +110,14 @@ int main() {
     hipMemcpy(d_b, b.data(), 64 * 8, hipMemcpyHostToDevice);
     bool ok = true;
     // (variant, hazards it must raise, the value every lane must hold -- NaN: lane-dependent, checked below)
-    const struct { int variant; long long hazards; } cases[] = {{0, 0}, {1, 0}, {2, 1}, {3, 1}, {4, 0}, {5, 1}};
+    const struct { int variant; long long hazards; } cases[] = {{0, 0}, {1, 0}, {2, 1}, {3, 1}, {4, 0}, {5, 1}, {6, 1}, {7, 0}, {8, 1}, {9, 0}};
     for (const auto& c : cases) {
       const long long before = hip_emu::Hazards().count;
       hipLaunchKernelGGL(asm_kernel, dim3(1), dim3(64), 64 * sizeof(double), 0, d_a, d_b, d_out, c.variant);
       const long long raised = hip_emu::Hazards().count - before;
       bool fine = (raised > 0) == (c.hazards > 0);
       for (int l = 0; l < 64 && fine; l++) {
-        if (c.variant == 0) fine = d_out[l] == 0.0;
+        if (c.variant == 0 || c.variant >= 6) fine = d_out[l] == 0.0;
         else if (c.variant == 3 || c.variant == 4) { unsigned bits; float f = 0; (void)f; std::memcpy(&bits, &d_out[l], 4); fine = bits == 7u; }
         else fine = d_out[l] == a[l] + b[l];
       }

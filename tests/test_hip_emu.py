@@ -20,11 +20,12 @@ def _build():
 
 def test_emulator_semantics():
     _build()
-    done = subprocess.run([os.path.join(EMU, "_build", "selftest")], capture_output=True, text=True, timeout=120)
+    done = subprocess.run([os.path.join(EMU, "_build", "selftest")], capture_output=True, text=True, timeout=120,
+                          env=dict(os.environ, HIP_EMU_ASM_HAZARDS="1"))  # (hazards reported and counted, not fatal)
     assert done.returncode == 0, done.stdout + done.stderr
-    # (asm_interpreter: the gfx950 interpreter's matrix instruction bit for bit the builtin's, and its hazard check on six
+    # (asm_interpreter: the gfx950 interpreter's matrix instruction bit for bit the builtin's, and its hazard check on ten
     # small programs -- an LDS read used behind / before its s_waitcnt, s_movrels with / without the wait state behind a
-    # write of M0, lgkmcnt(1) with a scalar load in flight -- raising hazards exactly where the ISA's rules are broken)
+    # write of M0, lgkmcnt(1) with a scalar load in flight, vector reads and matrix operands with and without their wait states -- raising hazards exactly where the ISA's rules are broken)
     assert done.stdout.split() == ["asm_interpreter", "ok", "block_sum", "ok", "wave_ops", "ok", "counter", "ok"]
 
 
