@@ -27,6 +27,14 @@
 #include "../../include/bito_amd_gp.h"
 #include "gp_schedule.hpp"
 
+// No FMA contraction anywhere in this file (round 5).  An operation's arithmetic is inlined into several kernels -- the
+// stream interpreter, the levelled interpreter, the optimiser's evaluations -- and the executor promises that a scheduled
+// sweep is bit for bit the sequential one (gp_schedule.hpp; tests/test_gp.py holds it on the device): with contraction
+// left to the backend, where a multiply meets an add could differ from one inlining context to the next.  The CPU
+// checker (oracle/gp_oracle.c, -ffp-contract=off) rounds the same way.  These kernels are bound by dependent launches
+// and latency, not by the vector ALU: the unfused multiply-adds cost nothing that can be measured.
+#pragma clang fp contract(off)
+
 // a stream the executor has scheduled before (gp_schedule.hpp), found again by content
 struct GpCachedSchedule {
   uint64_t hash = 0;
