@@ -12,7 +12,5 @@ ln -sf ../libbito_amd_emu.so tests/hip_emu/_build/as_product/libbito_amd.so
 LOG=${1:-profiles/r5_emulated/gpu_suite_emulated.log}
 BITO_AMD_LIB=$PWD/tests/hip_emu/_build/libbito_amd_emu.so HIP_EMU_ASM_HAZARDS=abort \
 LD_LIBRARY_PATH=$PWD/tests/hip_emu/_build/as_product:$LD_LIBRARY_PATH \
-python -m pytest tests -m gpu -q -p no:cacheprovider -n 4 --timeout 300 -rfE --durations=15 \
-  -k "not (model0-2 or model0-3 or model1-2 or model1-3 or model2-2 or model2-3 or in_flight_with_updates_between_them and 2) and not test_tile_runs_of_the_lds_walk" \
-  > "$LOG" 2>&1
+python -m pytest tests -m gpu -q -p no:cacheprovider -n 4 --timeout 300 -rfE --durations=15 > "$LOG" 2>&1
 tail -5 "$LOG"

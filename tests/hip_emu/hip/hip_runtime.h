@@ -8,7 +8,8 @@
 // (a wrong index, a missed dependency, a race that a barrier was meant to close in program order) show up in the CPU
 // suite.  What it does not show: timing, the hardware's rounding under FMA contraction, memory-model effects between
 // workgroups.  gfx950 assembly: walk_pipe.hip's three asm statements are INTERPRETED (gfx950_asm.hpp, RunAsm below);
-// walk_lds.hip / walk_tree.hip (pinned-only kernels with inline assembly of their own) stay outside.  Lanes of a wave do
+// walk_lds.hip's asm statements (scalar descriptor loads and the waits for them) become copies: every kernel of the product
+// is in the emulated build.  Lanes of a wave do
 // not run in lockstep here: code that relies on that without a wave operation in between (one place, pipe_prepare's
 // exponentials handed round through LDS) gets a wave barrier in the prepared copy (prepare.py).
 //
@@ -395,6 +396,12 @@ inline T __shfl(T v, int src) {
 template <typename T>
 inline T __shfl_xor(T v, int mask) { return __shfl(v, hip_emu::Lane() ^ mask); }
 #define __builtin_amdgcn_readfirstlane(x) hip_emu::ReadFirstLane(x)
+// v_readlane_b32: the value of lane `lane` (wave-uniform index); ds_bpermute_b32: of lane (byte index / 4) & 63, per lane
+inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)hip_emu::Publish((uint64_t)(uint32_t)v)[lane & 63]; }
+inline int __builtin_amdgcn_ds_bpermute(int byte_index, int v) {
+  return (int)(uint32_t)hip_emu::Publish((uint64_t)(uint32_t)v)[(byte_index >> 2) & 63];
+}
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_ldexp(x, e) std::ldexp((double)(x), (int)(e))
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
@@ -431,25 +438,27 @@ inline double __hiloint2double(int hi, int lo) {
   return x;
 }
 
-// v_permlane32_swap / v_permlane16_swap (wave_sums.hpp): {new vdst, new vsrc}
-struct hip_emu_pair { int v[2]; int operator[](int i) const { return v[i]; } };
-inline hip_emu_pair __builtin_amdgcn_permlane32_swap(int vdst, int vsrc, bool, bool) {
-  const uint64_t* all = hip_emu::Publish(((uint64_t)(uint32_t)vdst << 32) | (uint32_t)vsrc);
+// v_permlane32_swap / v_permlane16_swap (wave_sums.hpp, walk_lds.hip, walk_tree.hip): {new vdst, new vsrc} -- a pair
+// of UNSIGNED dwords, as the device builtin's result (callers OR them into 64-bit patterns)
+struct hip_emu_pair { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+inline hip_emu_pair __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned vsrc, bool, bool) {
+  const uint64_t* all = hip_emu::Publish(((uint64_t)vdst << 32) | vsrc);
   const int lane = hip_emu::Lane();
   hip_emu_pair r;
-  r.v[0] = lane < 32 ? vdst : (int)(uint32_t)all[lane - 32];           // upper half of vdst <- lower half of vsrc
-  r.v[1] = lane < 32 ? (int)(uint32_t)(all[lane + 32] >> 32) : vsrc;   // lower half of vsrc <- upper half of vdst
+  r.v[0] = lane < 32 ? vdst : (uint32_t)all[lane - 32];           // upper half of vdst <- lower half of vsrc
+  r.v[1] = lane < 32 ? (uint32_t)(all[lane + 32] >> 32) : vsrc;   // lower half of vsrc <- upper half of vdst
   return r;
 }
-inline hip_emu_pair __builtin_amdgcn_permlane16_swap(int vdst, int vsrc, bool, bool) {
-  const uint64_t* all = hip_emu::Publish(((uint64_t)(uint32_t)vdst << 32) | (uint32_t)vsrc);
+inline hip_emu_pair __builtin_amdgcn_permlane16_swap(unsigned vdst, unsigned vsrc, bool, bool) {
+  const uint64_t* all = hip_emu::Publish(((uint64_t)vdst << 32) | vsrc);
   const int lane = hip_emu::Lane(), row = lane >> 4;
   hip_emu_pair r;
-  r.v[0] = (row & 1) ? (int)(uint32_t)all[lane - 16] : vdst;           // odd rows of vdst <- even rows of vsrc
-  r.v[1] = (row & 1) ? vsrc : (int)(uint32_t)(all[lane + 16] >> 32);   // even rows of vsrc <- odd rows of vdst
+  r.v[0] = (row & 1) ? (uint32_t)all[lane - 16] : vdst;           // odd rows of vdst <- even rows of vsrc
+  r.v[1] = (row & 1) ? vsrc : (uint32_t)(all[lane + 16] >> 32);   // even rows of vsrc <- odd rows of vdst
   return r;
 }
-// v_mov_b32 with DPP: row_shr:n (0x111-0x11f) and row_bcast:15 (0x142), the controls wave_sums.hpp uses; bank mask 0xf
+// v_mov_b32 with DPP: row_shr:n (0x111-0x11f), row_bcast:15 (0x142) -- the controls wave_sums.hpp uses -- and row_ror:n
+// (0x121-0x12f: walk_tree.hip); bank mask 0xf
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int, bool bound_ctrl) {
   const uint64_t* all = hip_emu::Publish((uint32_t)src);
   const int lane = hip_emu::Lane(), row = lane >> 4, in_row = lane & 15;
@@ -460,6 +469,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     return bound_ctrl ? 0 : old;
   }
   if (ctrl == 0x142) return row > 0 ? (int)(uint32_t)all[row * 16 - 1] : old;
+  if (ctrl >= 0x121 && ctrl <= 0x12f) return (int)(uint32_t)all[row * 16 + ((in_row - (ctrl - 0x120)) & 15)];  // row_ror:n
   std::fprintf(stderr, "hip_emu: DPP control 0x%x is not emulated\n", ctrl);
   std::abort();
 }

@@ -62,6 +62,21 @@ def interpreted_asm(text):
     return "".join(out)
 
 
+def lds_walk_asm(text):
+    """walk_lds.hip: its asm statements are scalar loads of a step descriptor into an SGPR tuple and the waits for them
+    (hidden from the compiler's own wait counting on purpose): a copy and nothing."""
+    pairs = (('asm volatile("s_load_dwordx16 %0, %1, 0x0" : "+s"(w) : "s"(p));', "std::memcpy(&w, p, 64);"),
+             ('asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w)::"memory");', ";"),
+             ('asm volatile("s_load_dwordx8 %0, %1, 0x0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(p) : "memory");', "std::memcpy(&w, p, 32);"),
+             ('asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(w) : "s"(p));', "std::memcpy(&w, p, 32);"),
+             ('asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");', ";"))
+    for old, new in pairs:
+        assert old in text, old
+        text = text.replace(old, new)
+    assert "asm volatile" not in text
+    return text
+
+
 def main():
     out = sys.argv[1]
     os.makedirs(out, exist_ok=True)
@@ -74,6 +89,8 @@ def main():
         # (gs_kernels.hip keeps its assembly behind GS_ASM_FETCH, which the emulated build sets to 0: the builtin form)
         if os.path.basename(path) == "walk_pipe.hip":
             text = interpreted_asm(text)
+        if os.path.basename(path) == "walk_lds.hip":
+            text = lds_walk_asm(text)
         if ("asm volatile" in text or "__asm__" in text) and "GS_ASM_FETCH" not in text:
             raise SystemExit(f"{path}: holds assembly the emulation cannot run")
         target = os.path.join(out, os.path.basename(path))

@@ -3,7 +3,8 @@ walk_hbm_kernel, final sums; walk_hbm_cat.hip; time_tree.hip as plain HIP C++; w
 interpreted instruction by instruction, tests/hip_emu/gfx950_asm.hpp) -- executed on the CPU through the stand-in HIP
 runtime of tests/hip_emu, against the CPU checker.  AUTO routes as in the product: walk_pipe_kernel for up to 64 taxa
 and four rate categories without rescaling (its own tests: tests/test_pipe_emulated.py), the HBM-arena walks for
-rescaling, five to eight rate categories and larger trees; only the pinned-only LDS walks are outside the emulated build.
+rescaling, five to eight rate categories and larger trees; the pinned-only LDS walks (walk_lds.hip, walk_tree.hip) are in
+the build as well -- every kernel of the product is.
 What this holds in a round without GPU access: the host side of a blocking call (chunks, device slots each on its own
 thread, the shared helper threads that pack large chunks, the site-model gradient's second pass from every slot's thread
 -- round 5's changes), and the logic of the kernels.  Small synthetic shapes: a tree costs a third of a second as fibers.
@@ -236,4 +237,43 @@ for site in ("weibull+4", "weibull+6"):
         assert np.array_equal(out["log_likelihood"], whole["log_likelihood"])
         assert np.array_equal(out["branch_lengths"], whole["branch_lengths"])
         print(site, rescaling, eng.kernel_name(), "ok")
+''')
+
+
+def test_emulated_pinned_lds_walks_against_the_checker(emulated):
+    """walk_lds_kernel (KERNEL_LDS: the first LDS-resident walk, compiled C++ with scalar descriptor prefetches) and
+    walk_tree_kernel (KERNEL_LDS_TREE: whole-tree workgroups, cross-lane sums by DPP / permlane swaps / ds_bpermute) --
+    kernels AUTO never picks, kept as pinned alternatives -- on the CPU: one, two and four rate categories, rooted and
+    unrooted, log-likelihood only and with the gradient; walk_lds_kernel also with the site-model gradient fused into its
+    pre-order pass.  With these every kernel of the product runs in the emulated build."""
+    run('''
+from test_gpu_parity import _random_rooted_parent_ids
+for kernel, name in ((_capi.KERNEL_LDS, "walk_lds_kernel"), (_capi.KERNEL_LDS_TREE, "walk_tree_kernel")):
+    for n, P, T, site, rooted in ((5, 16, 2, "weibull+4", False), (9, 70, 3, "weibull+4", True), (12, 40, 2, "weibull+2", False),
+                                  (23, 65, 2, "constant", True), (27, 130, 1, "weibull+4", False)):
+        w = small(n, P, T, site)
+        if rooted:
+            rng = np.random.default_rng(n)
+            w.parent_ids = np.stack([_random_rooted_parent_ids(n, rng) for _ in range(T)]).astype(np.int32)
+            w.branch_lengths = rng.uniform(0.01, 0.4, (T, 2 * n - 1))
+            w.branch_lengths[:, -1] = 0.0
+        gpu = bito_amd.Engine(spec(w), w.patterns, w.weights)
+        gpu.set_kernel(kernel)
+        cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 4)
+        ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+        ll = gpu.log_likelihoods(w.parent_ids, w.branch_lengths, w.params)
+        assert gpu.kernel_name() == name, gpu.kernel_name()
+        assert close(ll, ref["log_likelihood"], LL_ATOL, LL_RTOL), (name, n, site)
+        out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+        assert close(out["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL), (name, n, site)
+        assert close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL), (name, n, site)
+        print(name, n, P, site)
+w = small(9, 70, 3)
+gpu = bito_amd.Engine(spec(w), w.patterns, w.weights)
+gpu.set_kernel(_capi.KERNEL_LDS)
+cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 4)
+out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, flags=_capi.GRAD_SITE_MODEL)
+ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, flags=_capi.GRAD_SITE_MODEL)
+assert gpu.kernel_name() == "walk_lds_kernel"
+assert close(out["site_model"], ref["site_model"], 1e-6, 1e-8) and close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
 ''')
