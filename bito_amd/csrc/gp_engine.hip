@@ -30,8 +30,8 @@
 // No FMA contraction anywhere in this file (round 5).  An operation's arithmetic is inlined into several kernels -- the
 // stream interpreter, the levelled interpreter, the optimiser's evaluations -- and the executor promises that a scheduled
 // sweep is bit for bit the sequential one (gp_schedule.hpp; tests/test_gp.py holds it on the device): with contraction
-// left to the backend, where a multiply meets an add could differ from one inlining context to the next.  The CPU
-// checker (oracle/gp_oracle.c, -ffp-contract=off) rounds the same way.  These kernels are bound by dependent launches
+// left to the backend, where a multiply meets an add could differ from one inlining context to the next.  (The tests'
+// CPU restatement is compiled the same way: one rounding per operation.)  These kernels are bound by dependent launches
 // and latency, not by the vector ALU: the unfused multiply-adds cost nothing that can be measured.
 #pragma clang fp contract(off)
 
