@@ -241,15 +241,31 @@ int UnstoredNodes(int n, int M, int rooted, const int32_t* par, bool fold, std::
 
 // Trees [t0, t1) of a block whose shape ValidateTreeShape has accepted; writes the range's rows of cherries_of, the
 // range's fewest cherries and, on failure, *msg -- nothing else (see ValidateParamsRange).
+// does walk_pipe_kernel fold pitchforks for this engine's shape, and would a tree with `fewest` unstored nodes NOT fit beside
+// the most pattern groups a wave can carry at this size?  (Then the pitchforks are worth counting.)
+static bool FoldingApplies(const Worker* e) {
+  const int C = e->spec.category_count;
+  return e->pipe_fold != 0 && e->spec.state_count == 4 && e->n <= 64 && (C == 1 || C == 2 || C == 4);
+}
+static bool CherriesAloneDoNotFit(const Worker* e, int fewest) {
+  BatchDims probe{};
+  probe.taxon_count = e->n;
+  probe.node_count = 2 * e->n - 1;
+  probe.category_count = e->spec.category_count;
+  const int room = PipeMaxSlots(probe, e->n <= kPipeExactTaxa ? 4 : 2);  // (four groups per wave up to 38 taxa, two beyond)
+  return PipeSlotsOfTree(probe, fewest) > room;
+}
+
 int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_count, const int32_t* parent_ids,
-                       int* fewest_out, int32_t* cherries_of, std::string* msg, int* fewest_unstored_out = nullptr) {
+                       int* fewest_out, int32_t* cherries_of, std::string* msg, int* fewest_unstored_out = nullptr,
+                       bool* pitchforks_counted = nullptr) {
   const int n = e->n, M = node_count;
   std::vector<int> count(M), tip_children(M);
   std::vector<int> kids;  // (the detrifurcated tree, for the pitchfork count)
   int fewest = M, fewest_unstored = M;
   // (pitchforks are folded by walk_pipe_kernel alone: up to 64 taxa, four states, 1 / 2 / 4 rate categories)
-  const int C = e->spec.category_count;
-  const bool fold_counts = e->pipe_fold != 0 && e->spec.state_count == 4 && n <= 64 && (C == 1 || C == 2 || C == 4);
+  const bool fold_counts = FoldingApplies(e);
+  if (pitchforks_counted) *pitchforks_counted = false;
   for (int t = t0; t < t1; t++) {
     const int32_t* par = parent_ids + (size_t)t * (M - 1);
     std::fill(count.begin(), count.end(), 0);
@@ -290,20 +306,17 @@ int ValidateTreesRange(const Worker* e, int t0, int t1, int rooted, int node_cou
   // cherries, would NOT all fit beside the most pattern groups a wave can carry at this size (config 3 fits by its
   // cherries: its calls, the 100-tree ones included, pay nothing for the folding).
   fewest_unstored = fewest;
-  if (fold_counts && (cherries_of || fewest_unstored_out)) {
-    BatchDims probe{};
-    probe.taxon_count = n;
-    probe.node_count = 2 * n - 1;
-    probe.category_count = C;
-    const int room = PipeMaxSlots(probe, n <= kPipeExactTaxa ? 4 : 2);  // (four groups per wave up to 38 taxa, two beyond)
-    if (PipeSlotsOfTree(probe, fewest) > room) {
-      fewest_unstored = M;
-      for (int t = t0; t < t1; t++) {
-        const int unstored = UnstoredNodes(n, M, rooted, parent_ids + (size_t)t * (M - 1), true, &kids);
-        fewest_unstored = std::min(fewest_unstored, unstored);
-        if (cherries_of) cherries_of[t] = unstored;
-      }
+  // (A range of a blocking call decides by its own trees here; WorkerStageEnd, which sees the whole batch, counts the
+  // pitchforks of the ranges that did not when another range's trees make the batch need them: the plan does not depend
+  // on how the call was cut into ranges.)
+  if (fold_counts && (cherries_of || fewest_unstored_out) && CherriesAloneDoNotFit(e, fewest)) {
+    fewest_unstored = M;
+    for (int t = t0; t < t1; t++) {
+      const int unstored = UnstoredNodes(n, M, rooted, parent_ids + (size_t)t * (M - 1), true, &kids);
+      fewest_unstored = std::min(fewest_unstored, unstored);
+      if (cherries_of) cherries_of[t] = unstored;
     }
+    if (pitchforks_counted) *pitchforks_counted = true;
   }
   if (fewest_out) *fewest_out = fewest;
   if (fewest_unstored_out) *fewest_unstored_out = fewest_unstored;
@@ -900,7 +913,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     if (use_pipe) {
       auto form = [](const LdsPlan& p, int trees) {
         return std::to_string(trees) + " trees " + (p.layout == kPipePlanTwoWaves ? "two waves" : "one wave") + " per SIMD x " +
-               std::to_string(p.groups) + " pattern groups";
+               std::to_string(p.groups) + " pattern groups, " + std::to_string(p.slots) + " vectors per wave";
       };
       e->kernel_form = two_classes ? form(split.plan_a, split.count_a) + " + " + form(split.plan_b, split.count_b) : form(plan, T);
     } else {
@@ -1208,8 +1221,9 @@ void WorkerStageFill(Worker* e, int32_t t0, int32_t t1, StagePart* out) {
   const size_t a = (size_t)t0, count = (size_t)(t1 - t0);
   *out = StagePart{};
   out->first_tree = t0;
+  out->end_tree = t1;
   out->code = ValidateTreesRange(e, t0, t1, st.rooted, st.node_count, st.parent_ids, &out->min_cherries,
-                                 e->tree_cherries.data(), &out->message, &out->min_unstored);
+                                 e->tree_cherries.data(), &out->message, &out->min_unstored, &out->pitchforks_counted);
   if (!out->code && st.params) out->code = ValidateParamsRange(e, t0, t1, st.params, &out->message);
   if (out->code) return;
   double* stage = static_cast<double*>(e->pin_in.ptr);
@@ -1243,6 +1257,24 @@ int WorkerStageEnd(Worker* e, const StagePart* parts, int part_count) {
     min_unstored = std::min(min_unstored, parts[i].min_unstored);
     min_branch = std::min(min_branch, parts[i].min_branch);
     min_rate = std::min(min_rate, parts[i].min_rate);
+  }
+  // Pitchforks: a range counts them when ITS trees, by their cherries, do not fit beside the most pattern groups; the batch
+  // needs them when ANY range does.  The ranges that did not count are counted here (0.1 us per tree, in the mixed case
+  // alone), so that the per-tree counts, the class split and the plan are those of a call checked in one range.
+  if (FoldingApplies(e) && part_count > 1 && CherriesAloneDoNotFit(e, min_cherries)) {
+    std::vector<int> kids;
+    min_unstored = st.node_count;  // (from scratch: an uncounted range's minimum above is its cherries')
+    for (int i = 0; i < part_count; i++) {
+      if (parts[i].pitchforks_counted) {
+        min_unstored = std::min(min_unstored, parts[i].min_unstored);
+        continue;
+      }
+      for (int t = parts[i].first_tree; t < parts[i].end_tree; t++) {
+        const int unstored = UnstoredNodes(e->n, st.node_count, st.rooted, st.parent_ids + (size_t)t * (st.node_count - 1), true, &kids);
+        e->tree_cherries[(size_t)t] = unstored;
+        min_unstored = std::min(min_unstored, unstored);
+      }
+    }
   }
   const int tree_count = st.tree_count, rooted = st.rooted, wait = st.wait;
   const int n = e->n, N = 2 * n - 1, M = st.node_count, C = e->spec.category_count;

@@ -256,8 +256,9 @@ int WorkerStage(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_coun
 struct StagePart {
   int code = 0;          // BITO_AMD_OK or the error the range's first bad tree gives
   std::string message;
-  int first_tree = 0;
+  int first_tree = 0, end_tree = 0;
   int min_cherries = 1 << 30, min_unstored = 1 << 30;
+  bool pitchforks_counted = false;  // tree_cherries of [first_tree, end_tree) hold cherries + folded pitchforks, not cherries alone
   double min_branch = std::numeric_limits<double>::infinity(), min_rate = std::numeric_limits<double>::infinity();
 };
 int WorkerStageBegin(Worker* e, int32_t tree_count, int32_t rooted, int32_t node_count, const int32_t* parent_ids,

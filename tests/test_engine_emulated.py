@@ -277,3 +277,63 @@ ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, flags=_capi.GRAD_S
 assert gpu.kernel_name() == "walk_lds_kernel"
 assert close(out["site_model"], ref["site_model"], 1e-6, 1e-8) and close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
 ''')
+
+
+def test_emulated_pitchfork_counts_do_not_depend_on_the_ranges_of_a_call(emulated):
+    """A blocking call checks its trees in ranges (one per helper thread); a range counts the pitchforks walk_pipe_kernel
+    folds only when its own trees, by their cherries, would not fit beside four pattern groups.  27 taxa, where seven
+    unstored nodes fit: 47 trees with seven cherries and two foldable pitchforks, one tree with six cherries and three
+    (nine unstored nodes each way).  Cut into ranges, only that tree's range counts pitchforks on its own;
+    WorkerStageEnd counts the rest, so that the plan -- four groups for the whole batch and LDS vectors for nine unstored
+    nodes, not for seven -- and the results are those of the call checked in one range."""
+    run('''
+from bito_amd import treeio
+rng = np.random.default_rng(11)
+n, P, T = 27, 40, 48
+w = small(n, P, T)
+cherries = lambda pid: sum(1 for v in range(n, 2 * n - 2) if sum(1 for c in range(n) if pid[c] == v) == 2)
+def ladder_tree(pitchforks, plain, names):
+    # a node over two cherries (stored), then `pitchforks` groups ((a,b),c) and `plain` groups (a,b) joined to the growing
+    # ladder one at a time (a pitchfork folds when its sibling is a tip or a stored node), then the remaining tips one by
+    # one up to a trifurcating root
+    names = list(names)
+    text = "((%s,%s),(%s,%s))" % (names.pop(), names.pop(), names.pop(), names.pop())
+    for _ in range(pitchforks):
+        text = "(%s,((%s,%s),%s))" % (text, names.pop(), names.pop(), names.pop())
+    for _ in range(plain):
+        text = "(%s,(%s,%s))" % (text, names.pop(), names.pop())
+    last = names.pop()
+    for name in names:
+        text = "(%s,%s)" % (text, name)
+    return "(%s,%s);" % (text[1:-1], last)
+names = ["t%02d" % i for i in range(n)]
+newicks = [ladder_tree(2, 3, rng.permutation(names)) for _ in range(T)]
+newicks[31] = ladder_tree(3, 1, rng.permutation(names))
+tc = treeio.parse_newick_strings(newicks)
+w.parent_ids = np.ascontiguousarray(tc.parent_id_matrix(), dtype=np.int32)
+assert w.parent_ids.shape == (T, 2 * n - 3)
+import ctypes as C
+counts = {}
+for fold in (0, 1):
+    counts[fold] = np.zeros(T, dtype=np.int32)
+    _capi.lib().bito_amd_count_unstored_nodes(n, T, 0, 2 * n - 2, w.parent_ids.ctypes.data_as(C.POINTER(C.c_int32)), fold,
+                                              counts[fold].ctypes.data_as(C.POINTER(C.c_int32)))
+assert counts[0].tolist() == [7] * 31 + [6] + [7] * 16 and counts[1].tolist() == [9] * T, (counts[0], counts[1])
+order = [tc.taxon_names.index(name) for name in names]  # (rows of the alignment in the collection's taxon order)
+w.patterns = np.ascontiguousarray(w.patterns[np.argsort(order)])
+cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 4)
+ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params)
+forms, outs = [], []
+for threads in (1, 4, 6):
+    eng = bito_amd.Engine(spec(w), w.patterns, w.weights, host_threads=threads)
+    out = eng.gradients(w.parent_ids, w.branch_lengths, w.params)
+    assert eng.kernel_name() == "walk_pipe_kernel"
+    assert close(out["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL)
+    assert close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
+    forms.append(eng.kernel_form())
+    outs.append(out)
+assert forms[0] == forms[1] == forms[2] and "4 pattern groups, 16 vectors per wave" in forms[0], forms
+for o in outs[1:]:
+    assert np.array_equal(o["log_likelihood"], outs[0]["log_likelihood"]) and np.array_equal(o["branch_lengths"], outs[0]["branch_lengths"])
+print(forms[0])
+''', BITO_AMD_HOST_MIN_TREES=8)
