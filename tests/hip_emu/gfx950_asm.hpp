@@ -114,7 +114,7 @@ struct HazardLog {
       std::fprintf(stderr, "{\"asm_hazards\": %lld, \"register_reads_checked\": %lld, \"s_waitcnt_executed\": %lld}\n", count, checked_reads, waits);
   }
   void Report(const char* what, const char* inst, const char* producer) {
-    if (count++ < 16) std::fprintf(stderr, "gfx950_asm: HAZARD: %s: %s   (in flight: %s)\n", what, inst, producer);
+    if (__atomic_fetch_add(&count, 1, __ATOMIC_RELAXED) < 16) std::fprintf(stderr, "gfx950_asm: HAZARD: %s: %s   (in flight: %s)\n", what, inst, producer);
     if (mode == 2) std::abort();
   }
 };
@@ -381,7 +381,7 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
     }
   };
   auto touch = [&](int file, int index, const char* what) {  // a register about to be read or overwritten
-    hazards.checked_reads++;
+    __atomic_fetch_add(&hazards.checked_reads, 1, __ATOMIC_RELAXED);
     if (!M.pending[file][(size_t)index]) return;
     const char* producer = "";
     for (const auto* q : {&M.lgkm, &M.vm})
@@ -524,7 +524,7 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
   };
   // s_waitcnt lgkmcnt(n) / vmcnt(n): what the ISA guarantees has arrived (see HazardLog)
   auto wait_for = [&](int lgkm, int vm) {
-    hazards.waits++;
+    __atomic_fetch_add(&hazards.waits, 1, __ATOMIC_RELAXED);
     if (lgkm == 0) {
       while (!M.lgkm.empty()) retire(M.lgkm, 0);
     } else if (lgkm > 0) {
@@ -543,7 +543,7 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
   };
   size_t pc = 0;
   long executed = 0;
-  Counts().statements++;
+  __atomic_fetch_add(&Counts().statements, 1, __ATOMIC_RELAXED);
   M.issue_pos += 1000;  // (compiled code stands between two statements: their producers are long ago)
   while (pc < P.code.size()) {
     const Inst& in = P.code[pc];
@@ -553,7 +553,7 @@ inline void Execute(const Program& P, WaveMachine& M, std::vector<std::vector<ui
     check_lane = M.exec ? __builtin_ctzll(M.exec) : 0;
     inst_kind = in.cls == kClassMfma ? 1 : in.cls == kClassValu ? 2 : (in.cls == kClassLds || in.cls == kClassVmemRd) ? 3 : 0;
     if (++executed > 50000000) AsmFail(in, "no end in sight");
-    Counts().n[in.cls]++;
+    __atomic_fetch_add(&Counts().n[in.cls], 1, __ATOMIC_RELAXED);
     static const long trace_until = std::getenv("HIP_EMU_ASM_TRACE") ? std::atol(std::getenv("HIP_EMU_ASM_TRACE")) : 0;
     if (executed <= trace_until && (op[0] == 's' && op != "s_nop" && op != "s_waitcnt"))
       std::fprintf(stderr, "  [%ld] pc %zu  %s   (m0 %u scc %d s32 %08x s48 %08x s92 %u)\n", executed, pc, in.text.c_str(), M.m0, (int)M.scc,

@@ -136,10 +136,63 @@ struct dim3 {
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
+// ThreadSanitizer build (make race: -fsanitize=thread): every GPU thread is a TSan fiber, __syncthreads() and the wave
+// operations are its only happens-before edges inside a workgroup, so an LDS or global access that two threads of a
+// workgroup make without a barrier between them -- which the serial fibers above would never expose -- is REPORTED as a
+// data race.  (Within a wave the hardware's lockstep orders what TSan cannot know about: such reports name two lanes of
+// one wave and are read as "relies on lockstep".)  Workgroups and launches are ordered through the launching thread.
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define HIP_EMU_TSAN 1
+#endif
+#endif
+#ifndef HIP_EMU_TSAN
+#define HIP_EMU_TSAN 0
+#endif
+#if HIP_EMU_TSAN
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void* fiber);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+void __tsan_acquire(void* addr);
+void __tsan_release(void* addr);
+}
+#define HIP_EMU_NO_TSAN __attribute__((no_sanitize("thread")))
+#else
+#define HIP_EMU_NO_TSAN
+#endif
+
 namespace hip_emu {
 
+inline void TsanSwitch(void* fiber) {
+#if HIP_EMU_TSAN
+  __tsan_switch_to_fiber(fiber, 1u);  // (1: no happens-before edge between the fibers)
+#else
+  (void)fiber;
+#endif
+}
+inline void TsanRelease(void* token) {
+#if HIP_EMU_TSAN
+  __tsan_release(token);
+#else
+  (void)token;
+#endif
+}
+inline void TsanAcquire(void* token) {
+#if HIP_EMU_TSAN
+  __tsan_acquire(token);
+#else
+  (void)token;
+#endif
+}
+
 constexpr int kWave = 64;
+#if HIP_EMU_TSAN
+constexpr size_t kStack = 1024 << 10;  // (instrumented frames are larger)
+#else
 constexpr size_t kStack = 256 << 10;
+#endif
 
 // saves the callee-saved registers of the System V ABI on the current stack, parks the stack pointer in *from, takes
 // the one in *to and returns on that stack (a new fiber's stack is laid out as if it had called this from Trampoline)
@@ -154,6 +207,7 @@ __attribute__((naked, noinline)) static void SwitchStacks(void** /*from: rdi*/, 
 
 struct Fiber {
   void* sp = nullptr;
+  void* tsan = nullptr;  // (ThreadSanitizer build: this thread's fiber)
   char* stack = nullptr;
   bool done = false;
   unsigned tx = 0, ty = 0, tz = 0;
@@ -168,6 +222,8 @@ inline std::vector<char*>& StackPool() {
 struct Block {
   std::vector<Fiber> fibers;
   void* scheduler = nullptr;
+  void* scheduler_tsan = nullptr;
+  char start_token = 0, done_token = 0, barrier_token = 0;  // (ThreadSanitizer build: what the happens-before edges hang on)
   const std::function<void()>* body = nullptr;
   int current = -1, live = 0;
   // the workgroup barrier
@@ -179,6 +235,7 @@ struct Block {
   // per wave: exchange slots of the shuffles and a barrier of the wave's live lanes
   struct Wave {
     uint64_t bits[kWave];
+    char token = 0;                               // (ThreadSanitizer build: the wave operations' happens-before edges)
     void* machine = nullptr;                      // gfx950_asm.hpp: the wave's registers, kept from one asm statement to the next
     std::vector<std::vector<uint64_t>>* staged = nullptr;  // ... and the operands of the statement being run
     void (*release)(Wave&) = nullptr;                       // frees the two at the end of the workgroup
@@ -215,38 +272,47 @@ inline thread_local dim3 blockDim, gridDim;
 
 namespace hip_emu {
 
-inline void Yield() {
+HIP_EMU_NO_TSAN inline void Yield() {
   Block* b = Current();
   Fiber& f = b->fibers[(size_t)b->current];
+  TsanSwitch(b->scheduler_tsan);
   SwitchStacks(&f.sp, &b->scheduler);
   threadIdx = {f.tx, f.ty, f.tz};  // (another fiber ran meanwhile)
 }
 inline int Linear() { return (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)); }
 
-inline void BlockBarrier() {
+HIP_EMU_NO_TSAN inline void BlockBarrier() {
   Block* b = Current();
   const unsigned mine = b->generation;
+  TsanRelease(&b->barrier_token);  // (everything this thread did so far happens before what any thread does behind the barrier)
   if (++b->arrived == b->live) {
     b->arrived = 0;
     b->generation++;
+    TsanAcquire(&b->barrier_token);
     return;
   }
   while (b->generation == mine) Yield();
+  TsanAcquire(&b->barrier_token);
 }
-inline void WaveBarrier() {
+HIP_EMU_NO_TSAN inline void WaveBarrier() {
   Block* b = Current();
   Block::Wave& w = b->waves[(size_t)Linear() / kWave];
   const unsigned mine = w.generation;
+  TsanRelease(&w.token);
   if (++w.arrived == w.live) {
     w.arrived = 0;
     w.generation++;
+    TsanAcquire(&w.token);
     return;
   }
   while (w.generation == mine) Yield();
+  TsanAcquire(&w.token);
 }
 // a thread that returns leaves its block's and its wave's barriers (as a wave that has ended does on the hardware)
-inline void Retire() {
+HIP_EMU_NO_TSAN inline void Retire() {
   Block* b = Current();
+  TsanRelease(&b->barrier_token);
+  TsanRelease(&b->waves[(size_t)Linear() / kWave].token);
   b->live--;
   if (b->live > 0 && b->arrived == b->live) {
     b->arrived = 0;
@@ -260,18 +326,21 @@ inline void Retire() {
   }
 }
 
-inline void Trampoline() {
+HIP_EMU_NO_TSAN inline void Trampoline() {
   Block* b = Current();
+  TsanAcquire(&b->start_token);  // (first: the workgroup's record itself was written by the launching thread)
   Fiber& f = b->fibers[(size_t)b->current];
   threadIdx = {f.tx, f.ty, f.tz};
   (*b->body)();
   Retire();
   f.done = true;
+  TsanRelease(&b->done_token);  // (the launching thread acquires it behind the workgroup: last thing this fiber does)
+  TsanSwitch(b->scheduler_tsan);
   SwitchStacks(&f.sp, &b->scheduler);
   std::abort();  // (a finished fiber is never resumed)
 }
 
-inline void RunBlock(const std::function<void()>& body, dim3 block) {
+HIP_EMU_NO_TSAN inline void RunBlock(const std::function<void()>& body, dim3 block) {
   const int count = (int)(block.x * block.y * block.z);
   Block b;
   b.body = &body;
@@ -283,6 +352,14 @@ inline void RunBlock(const std::function<void()>& body, dim3 block) {
     b.waves[(size_t)t / kWave].lanes++;
   }
   Current() = &b;
+#if HIP_EMU_TSAN
+  // (fibers are kept from workgroup to workgroup, like the stacks: this runtime gives out about a thousand per process)
+  static thread_local std::vector<void*> tsan_fibers;  // (a fiber stays with the OS thread that made it)
+  b.scheduler_tsan = __tsan_get_current_fiber();
+  while ((int)tsan_fibers.size() < count) tsan_fibers.push_back(__tsan_create_fiber(0));
+  for (int t = 0; t < count; t++) b.fibers[(size_t)t].tsan = tsan_fibers[(size_t)t];
+#endif
+  TsanRelease(&b.start_token);  // (what the launching thread did -- and the workgroups before this one -- happens before this workgroup)
   std::vector<char*>& pool = StackPool();
   while ((int)pool.size() < count) pool.push_back(static_cast<char*>(std::malloc(kStack)));
   for (int t = 0; t < count; t++) {
@@ -309,6 +386,7 @@ inline void RunBlock(const std::function<void()>& body, dim3 block) {
       Fiber& f = b.fibers[(size_t)t];
       if (f.done) continue;
       b.current = t;
+      TsanSwitch(f.tsan);
       SwitchStacks(&b.scheduler, &f.sp);
       if (f.done) remaining--;
     }
@@ -321,12 +399,15 @@ inline void RunBlock(const std::function<void()>& body, dim3 block) {
   }
   for (Block::Wave& w : b.waves)
     if (w.release) w.release(w);
+  TsanAcquire(&b.done_token);
   Current() = nullptr;
 }
 
 template <typename F>
-inline void Launch(F&& body_of_thread, dim3 grid, dim3 block, size_t shared_bytes) {
+inline void Launch(const char* name, F&& body_of_thread, dim3 grid, dim3 block, size_t shared_bytes) {
   std::lock_guard<std::mutex> lock(LaunchMutex());
+  static const bool trace = std::getenv("HIP_EMU_TRACE_LAUNCH") != nullptr;  // (one line per launch: which kernel, what shape)
+  if (trace) std::fprintf(stderr, "hip_emu: launch %s grid (%u, %u, %u) block (%u, %u, %u) lds %zu\n", name, grid.x, grid.y, grid.z, block.x, block.y, block.z, shared_bytes);
   const std::function<void()> body = body_of_thread;
   DynamicStore().assign(shared_bytes / sizeof(double) + 2, 0.0);
   gridDim = grid;
@@ -342,7 +423,7 @@ inline void Launch(F&& body_of_thread, dim3 grid, dim3 block, size_t shared_byte
 }  // namespace hip_emu
 
 #define hipLaunchKernelGGL(kernel, grid, block, shared_bytes, stream, ...) \
-  hip_emu::Launch([=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (size_t)(shared_bytes))
+  hip_emu::Launch(#kernel, [=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (size_t)(shared_bytes))
 
 inline void __syncthreads() { hip_emu::BlockBarrier(); }
 inline void __threadfence() {}
@@ -355,7 +436,7 @@ template <typename T>
 inline T __shfl_xor(T v, int mask);
 // every lane of the wave publishes a 64-bit value; returns the wave's array (valid until the lane's next wave operation)
 namespace hip_emu {
-inline const uint64_t* Publish(uint64_t mine) {
+HIP_EMU_NO_TSAN inline const uint64_t* Publish(uint64_t mine) {
   Block* b = Current();
   const int lin = Linear(), lane = lin % kWave;
   Block::Wave& w = b->waves[(size_t)lin / kWave];
@@ -367,7 +448,7 @@ inline const uint64_t* Publish(uint64_t mine) {
   return w.bits;
 }
 // did lane l take part in the exchange the caller has just returned from?
-inline bool Active(int l) {
+HIP_EMU_NO_TSAN inline bool Active(int l) {
   Block* b = Current();
   const Block::Wave& w = b->waves[(size_t)Linear() / kWave];
   return l < w.lanes && w.stamp[l] == w.stamp[Linear() % kWave];
@@ -401,7 +482,6 @@ inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)hi
 inline int __builtin_amdgcn_ds_bpermute(int byte_index, int v) {
   return (int)(uint32_t)hip_emu::Publish((uint64_t)(uint32_t)v)[(byte_index >> 2) & 63];
 }
-#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_ldexp(x, e) std::ldexp((double)(x), (int)(e))
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
@@ -527,7 +607,7 @@ inline V4 hip_emu_mfma_f64_16x16x4(double a, double b, V4 c) {
   std::memcpy(A, hip_emu::Publish(ra), sizeof(A));
   std::memcpy(B, hip_emu::Publish(rb), sizeof(B));
   const int lane = hip_emu::Lane(), q = lane >> 4, j = lane & 15;
-  if (lane == 0) hip_emu::Builtins().mfma_16x16x4++;
+  if (lane == 0) __atomic_fetch_add(&hip_emu::Builtins().mfma_16x16x4, 1, __ATOMIC_RELAXED);
   V4 d = c;
   for (int r = 0; r < 4; r++) {
     const int i = 4 * r + q;
@@ -558,7 +638,7 @@ inline double hip_emu_mfma_f64_4x4x4(double a, double b, double c) {
   std::memcpy(A, hip_emu::Publish(ra), sizeof(A));
   std::memcpy(B, hip_emu::Publish(rb), sizeof(B));
   const int lane = hip_emu::Lane(), i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
-  if (lane == 0) hip_emu::Builtins().mfma_4x4x4++;
+  if (lane == 0) __atomic_fetch_add(&hip_emu::Builtins().mfma_4x4x4, 1, __ATOMIC_RELAXED);
   double acc = c;
   for (int k = 0; k < 4; k++) {
     double x, y;
@@ -598,11 +678,28 @@ inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
 template <typename T>
 inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
-inline double atomicAdd(double* p, double v) { const double old = *p; *p = old + v; return old; }
+inline double atomicAdd(double* p, double v) {
+  uint64_t seen = __atomic_load_n(reinterpret_cast<uint64_t*>(p), __ATOMIC_RELAXED), want;
+  double old;
+  do {
+    std::memcpy(&old, &seen, 8);
+    const double sum = old + v;
+    std::memcpy(&want, &sum, 8);
+  } while (!__atomic_compare_exchange_n(reinterpret_cast<uint64_t*>(p), &seen, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  return old;
+}
 template <typename T>
-inline T atomicMin(T* p, T v) { const T old = *p; if (v < old) *p = v; return old; }
+inline T atomicMin(T* p, T v) {
+  T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
 template <typename T>
-inline T atomicMax(T* p, T v) { const T old = *p; if (v > old) *p = v; return old; }
+inline T atomicMax(T* p, T v) {
+  T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v > old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
 
 // math of the device library that <cmath> spells the same way is used as is; min / max come as overloads in HIP
 inline int min(int a, int b) { return a < b ? a : b; }

@@ -8,6 +8,8 @@ import json
 import os
 import subprocess
 
+import pytest
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 EMU = os.path.join(HERE, "hip_emu")
@@ -38,3 +40,29 @@ def test_emulated_mfma_is_what_the_device_measured():
         device = json.load(fh)
     for key in ("matched", "of", "column_is_lane_mod_16", "bit_equal_to_sequential_fma_chain", "row_of[lane/16][register]"):
         assert got[key] == device[key], key
+
+
+def test_thread_sanitizer_sees_a_missing_barrier():
+    """The ThreadSanitizer build of the stand-in runtime (every GPU thread a TSan fiber; __syncthreads() and the wave
+    operations the only happens-before edges inside a workgroup): a kernel that reads LDS another wave wrote with no
+    barrier between is reported as a data race with both source lines -- whatever order the serial fibers happened to
+    run it in --; the same kernel with its __syncthreads() is clean.  scripts/emu_race_check.py runs the product's kernels this
+    way (GP executor, codon kernels, walk_pipe_kernel's C++) and under AddressSanitizer."""
+    built = subprocess.run(["make", "-s", "-C", EMU, "_build/racetest"], capture_output=True, text=True)
+    assert built.returncode == 0, built.stdout + built.stderr
+    env = dict(os.environ, TSAN_OPTIONS="report_signal_unsafe=0 exitcode=0")
+
+    def attempt(arg):
+        # (this image's TSan runtime dies at start-up now and then -- a SEGV inside the runtime before the kernel runs,
+        # dependent on the process's address-space layout: such a run says nothing and is repeated)
+        for _ in range(12):
+            done = subprocess.run([os.path.join(EMU, "_build", "racetest"), arg], capture_output=True, text=True, timeout=120, env=env)
+            if "DEADLYSIGNAL" not in done.stderr:
+                return done
+        pytest.skip("ThreadSanitizer's runtime does not start in this environment")
+
+    racy, clean = attempt("0"), attempt("1")
+    assert "out[0] 128" in clean.stdout
+    assert "WARNING: ThreadSanitizer: data race" in racy.stderr and "exchange_kernel<false>" in racy.stderr
+    assert "racetest.hip:14" in racy.stderr and "racetest.hip:16" in racy.stderr  # (the LDS write and the read)
+    assert "ThreadSanitizer" not in clean.stderr, clean.stderr[-2000:]
