@@ -9,7 +9,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU = os.path.join(ROOT, "tests", "hip_emu", "_build", "libbito_amd_emu.so")
+# (BENCH_DRY_RUN_LIB: another build of the emulated library, e.g. tests/hip_emu/_build/memcheck/libbito_amd_asan.so with
+# the AddressSanitizer runtime preloaded)
+EMU = os.environ.get("BENCH_DRY_RUN_LIB", os.path.join(ROOT, "tests", "hip_emu", "_build", "libbito_amd_emu.so"))
 
 BODY = r'''
 import os, runpy, sys
