@@ -32,6 +32,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <string>
 #include <functional>
 #include <mutex>
 #include <vector>
@@ -403,9 +405,11 @@ HIP_EMU_NO_TSAN inline void RunBlock(const std::function<void()>& body, dim3 blo
   Current() = nullptr;
 }
 
+void NoteLaunch(const char* name);  // (the matrix builtins' counts are kept per kernel: below, beside the builtins)
 template <typename F>
 inline void Launch(const char* name, F&& body_of_thread, dim3 grid, dim3 block, size_t shared_bytes) {
   std::lock_guard<std::mutex> lock(LaunchMutex());
+  NoteLaunch(name);
   static const bool trace = std::getenv("HIP_EMU_TRACE_LAUNCH") != nullptr;  // (one line per launch: which kernel, what shape)
   if (trace) std::fprintf(stderr, "hip_emu: launch %s grid (%u, %u, %u) block (%u, %u, %u) lds %zu\n", name, grid.x, grid.y, grid.z, block.x, block.y, block.z, shared_bytes);
   const std::function<void()> body = body_of_thread;
@@ -585,15 +589,27 @@ inline void hip_emu_buffer_store(T v, hip_emu_rsrc r, unsigned voffset, unsigned
 namespace hip_emu {
 struct BuiltinCounts {
   long long mfma_16x16x4 = 0, mfma_4x4x4 = 0;
+  std::map<std::string, long long> per_kernel;  // matrix builtins by the kernel that issued them (the name at the launch)
+  long long scratch = 0;
+  long long* current = &scratch;
   ~BuiltinCounts() {
-    if (std::getenv("HIP_EMU_ASM_COUNT"))
-      std::fprintf(stderr, "{\"builtin_mfma_f64_16x16x4\": %lld, \"builtin_mfma_f64_4x4x4\": %lld}\n", mfma_16x16x4, mfma_4x4x4);
+    if (!std::getenv("HIP_EMU_ASM_COUNT")) return;
+    std::fprintf(stderr, "{\"builtin_mfma_f64_16x16x4\": %lld, \"builtin_mfma_f64_4x4x4\": %lld}\n", mfma_16x16x4, mfma_4x4x4);
+    std::string line = "{\"builtin_mfma_by_kernel\": {";
+    bool first = true;
+    for (const auto& [name, count] : per_kernel) {
+      if (!count) continue;
+      line += std::string(first ? "" : ", ") + "\"" + name + "\": " + std::to_string(count);
+      first = false;
+    }
+    std::fprintf(stderr, "%s}}\n", line.c_str());
   }
 };
 inline BuiltinCounts& Builtins() {
   static BuiltinCounts c;
   return c;
 }
+inline void NoteLaunch(const char* name) { Builtins().current = &Builtins().per_kernel[name]; }
 }  // namespace hip_emu
 
 // v_mfma_f64_16x16x4: A lane = 16 k + i, B lane = 16 k + j; register r of lane 16 q + j holds D[4 r + q][j]; one
@@ -607,7 +623,10 @@ inline V4 hip_emu_mfma_f64_16x16x4(double a, double b, V4 c) {
   std::memcpy(A, hip_emu::Publish(ra), sizeof(A));
   std::memcpy(B, hip_emu::Publish(rb), sizeof(B));
   const int lane = hip_emu::Lane(), q = lane >> 4, j = lane & 15;
-  if (lane == 0) __atomic_fetch_add(&hip_emu::Builtins().mfma_16x16x4, 1, __ATOMIC_RELAXED);
+  if (lane == 0) {
+    __atomic_fetch_add(&hip_emu::Builtins().mfma_16x16x4, 1, __ATOMIC_RELAXED);
+    __atomic_fetch_add(hip_emu::Builtins().current, 1, __ATOMIC_RELAXED);
+  }
   V4 d = c;
   for (int r = 0; r < 4; r++) {
     const int i = 4 * r + q;
@@ -638,7 +657,10 @@ inline double hip_emu_mfma_f64_4x4x4(double a, double b, double c) {
   std::memcpy(A, hip_emu::Publish(ra), sizeof(A));
   std::memcpy(B, hip_emu::Publish(rb), sizeof(B));
   const int lane = hip_emu::Lane(), i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
-  if (lane == 0) __atomic_fetch_add(&hip_emu::Builtins().mfma_4x4x4, 1, __ATOMIC_RELAXED);
+  if (lane == 0) {
+    __atomic_fetch_add(&hip_emu::Builtins().mfma_4x4x4, 1, __ATOMIC_RELAXED);
+    __atomic_fetch_add(hip_emu::Builtins().current, 1, __ATOMIC_RELAXED);
+  }
   double acc = c;
   for (int k = 0; k < 4; k++) {
     double x, y;

@@ -337,3 +337,35 @@ for o in outs[1:]:
     assert np.array_equal(o["log_likelihood"], outs[0]["log_likelihood"]) and np.array_equal(o["branch_lengths"], outs[0]["branch_lengths"])
 print(forms[0])
 ''', BITO_AMD_HOST_MIN_TREES=8)
+
+
+def test_emulated_codon_walk_issues_the_matrix_instructions_the_device_counted(emulated):
+    """Config 5's executed-instruction count, held the way walk_pipe_kernel's is (tests/test_pipe_emulated.py): an MI355X
+    counted SQ_INSTS_MFMA = 843 055 104 v_mfma_f64_16x16x4 per launch of gs_walk_kernel over 4096 fluA codon trees
+    (profiles/r3_v9_codon_issue_pmc.json; every tree the same topology) = 205 824 per tree, the number
+    profiles/executed.json gives bench.py.  The emulated kernel, one tree, issues exactly that many through the matrix
+    builtin (counted per kernel by the stand-in runtime: the image kernel's 34 816 = 136 branches x 256 are not the
+    walk's)."""
+    import json
+
+    device = json.load(open(os.path.join(ROOT, "profiles", "r3_v9_codon_issue_pmc.json")))
+    assert device["SQ_INSTS_MFMA"] == 843055104.0
+    body = PRELUDE.format(root=ROOT, here=HERE) + '''
+w = workloads.flua_codon(1)
+eng = bito_amd.Engine(spec(w), w.patterns, w.weights)
+out = eng.gradients(w.parent_ids, w.branch_lengths, w.params)
+assert eng.kernel_name() == "gs_walk_kernel" and np.isfinite(out["log_likelihood"]).all()
+'''
+    done = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, timeout=600,
+                          env=dict(os.environ, BITO_AMD_LIB=EMU, HIP_EMU_ASM_COUNT="1"))
+    assert done.returncode == 0, done.stderr[-2000:]
+    counts = {}
+    for line in done.stderr.splitlines():
+        if line.startswith("{"):
+            counts.update(json.loads(line))
+    per_kernel = counts["builtin_mfma_by_kernel"]
+    walk = sum(v for k, v in per_kernel.items() if k != "gs_matrices_kernel")  # (the walk is launched through a pointer named `kern`)
+    assert per_kernel["gs_matrices_kernel"] == 136 * 256
+    assert walk * 4096 == int(device["SQ_INSTS_MFMA"]), (per_kernel, device["SQ_INSTS_MFMA"])
+    row = [r for r in json.load(open(os.path.join(ROOT, "profiles", "executed.json"))) if r["kernel"] == "gs_walk_kernel"][0]
+    assert row["matrix_instructions_per_tree"] == walk
