@@ -6,8 +6,8 @@ the two compiled C++ clients of the C ABI (tests/cabi_client.cpp, tests/gp_bindi
 objects of tests/hip_emu/_build/race (ThreadSanitizer) and _build/memcheck (AddressSanitizer: out-of-bounds and
 use-after-free accesses of kernels and host code -- the sanitizers this project can run, on the CPU build only), on case
 files written here:
-  gp       ds1-reduced-5's multi-tree DAG: populate, likelihoods, one scheduled optimisation sweep (concurrent workgroups of
-           gp_optimize_kernel, gp_levels_kernel), marginal
+  gp       ds1-reduced-5's multi-tree DAG and the DS1 ten-tree DAG (bench.py's Path B workload): populate, likelihoods, one
+           scheduled optimisation sweep (concurrent workgroups of gp_optimize_kernel, gp_levels_kernel), marginal
   codon    two 9-taxon trees under GY94 (61 states): gs_eigen_kernel (round 5: two barriers per Jacobi round instead of
            four), gs_matrices_kernel, gs_schedule / gs_walk kernels
   hbm      weibull+6 (walk_hbm_kernel) and 70 taxa with weibull+4 (walk_hbm_cat_kernel) on small alignments
@@ -66,6 +66,14 @@ def cases(which, tmp):
         sp, dag, bl, q, streams = t._instance(os.path.join(ROOT, "tests", "golden", "data"))
         t._case(os.path.join(tmp, "gp.txt"), sp, dag, bl, q, streams)
         out.append(("gp_binding_client", os.path.join(tmp, "gp.txt")))
+        # ... and Path B's bench workload: the DS1 ten-tree DAG (84 nodes, 119 edges, 934 patterns), 118 optimisations in 56
+        # launches of concurrent workgroups, the 1082-operation passes through gp_levels_kernel
+        dag, sp = workloads.ds1_subsplit_dag(10)
+        bl = np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)
+        streams = [dag.populate_plvs(), dag.compute_likelihoods(), dag.branch_length_optimization(), dag.populate_plvs(),
+                   dag.compute_likelihoods(), dag.marginal_likelihood()]
+        t._case(os.path.join(tmp, "gp_ds1.txt"), sp, dag, bl, dag.uniform_on_topological_support_prior(), streams)
+        out.append(("gp_binding_client", os.path.join(tmp, "gp_ds1.txt")))
     if which == "codon":
         w = workloads.flua_codon(2)
         keep = 9  # (the first nine taxa of fluA as a tree of their own: small enough for TSan, the same kernels)
