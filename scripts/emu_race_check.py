@@ -12,11 +12,13 @@ files written here:
            four), gs_matrices_kernel, gs_schedule / gs_walk kernels
   hbm      weibull+6 (walk_hbm_kernel) and 70 taxa with weibull+4 (walk_hbm_cat_kernel) on small alignments
   pipe     DS1-shaped trees through walk_pipe_kernel (the C++ around the interpreted assembly; the interpreter's own LDS
-           accesses are made on a wave's first lane)
+           accesses are made on a wave's first lane, its s_barrier is a happens-before edge like __syncthreads())
+  slots    150 trees in one blocking call over three device slots: the engine's own threads (an issuing thread per slot, the
+           shared helper threads that pack the chunks' ranges: round 5) -- real OS threads, real races if there were any
 Reports whose two stacks lie inside the stand-in runtime itself are listed separately; a report that names kernel code
 fails the run.  Within a wave the hardware's lockstep orders accesses TSan cannot know about: a report naming two lanes of
 one wave reads "relies on lockstep" (none in the kernels; pipe_prepare's hand-over is sealed by prepare.py).
-usage: python scripts/emu_race_check.py [gp codon hbm pipe]   (CPU only; needs /root/reference for the gp client)"""
+usage: python scripts/emu_race_check.py [gp codon hbm pipe slots]   (CPU only; needs /root/reference for the gp client)"""
 import glob
 import os
 import re
@@ -99,7 +101,16 @@ def cases(which, tmp):
         a = workloads.synthetic_gtr_weibull4(12, 70, tree_count=3)
         engine_case(os.path.join(tmp, "pipe.txt"), a)
         out.append(("cabi_client", os.path.join(tmp, "pipe.txt")))
+    if which == "slots":
+        a = workloads.synthetic_gtr_weibull4(6, 24, tree_count=150)
+        engine_case(os.path.join(tmp, "slots.txt"), a)
+        out.append(("cabi_client", os.path.join(tmp, "slots.txt")))
     return out
+
+
+# `slots`: the engine's own threads -- one blocking call of 150 trees over THREE device slots (an issuing thread each), cut
+# into chunks, the chunks' ranges packed by the shared helper threads (round 5): real OS threads, real races if any
+EXTRA = {"slots.txt": (["3"], {"BITO_AMD_CHUNK_FIRST": "8", "BITO_AMD_CHUNK_GROWTH": "2", "BITO_AMD_CHUNK_CAP": "40", "BITO_AMD_HOST_MIN_TREES": "8"})}
 
 
 RUNTIME = ("hip_emu::RunAsm", "hip_emu::Execute", "hip_emu::WaveMachine", "hip_emu::ProgramOf", "hip_emu::Block", "hip_emu::ParseProgram",
@@ -110,11 +121,12 @@ def run(program, case, tmp, tag):
     """one case under ThreadSanitizer (this image's TSan runtime dies at start-up now and then -- a SEGV inside the runtime
     before the first kernel, dependent on the address-space layout: such a run is repeated) and under AddressSanitizer"""
     log = os.path.join(tmp, "tsan_" + tag)
-    env = dict(os.environ, TSAN_OPTIONS=f"report_signal_unsafe=0 exitcode=0 history_size=4 log_path={log}")
+    args, more = EXTRA.get(os.path.basename(case), ([], {}))
+    env = dict(os.environ, TSAN_OPTIONS=f"report_signal_unsafe=0 exitcode=0 history_size=4 log_path={log}", **more)
     for attempt in range(12):
         for f in glob.glob(log + ".*"):
             os.remove(f)
-        done = subprocess.run([os.path.join(EMU, "_build", "race", program), case], capture_output=True, text=True, env=env, timeout=3000)
+        done = subprocess.run([os.path.join(EMU, "_build", "race", program), case] + args, capture_output=True, text=True, env=env, timeout=3000)
         if done.stdout.strip():
             break
     else:
@@ -129,12 +141,17 @@ def run(program, case, tmp, tag):
             frames = re.findall(r"#\d+ (.+?) /", stack)
             frames = [f for f in frames if not f.startswith(("std::", "__tsan", "operator", "malloc", "void std::", "__gnu_cxx::", "void __gnu_cxx::",
                                                              "memcmp", "memcpy", "memset", "free"))]
+            frames = [f for f in frames if "std::" not in f.split("(")[0] and "__gnu_cxx::" not in f.split("(")[0]]
             if frames and re.match(r"\s*(Read|Write|Previous read|Previous write|Atomic|Previous atomic)\b.* of size", stack):
                 tops.append(frames[0])
-        inside_runtime = tops and all(t.startswith(RUNTIME) or "RunAsm" in t or "WaveMachine" in t for t in tops)
+        # (everything in namespace hip_emu is the stand-in runtime and the interpreter; the device builtins' stand-ins are
+        # hip_emu_* free functions and count as kernel code)
+        if not tops:  # (both stacks inside the C++ library: the summary line names the function they were called from)
+            tops = re.findall(r"SUMMARY: ThreadSanitizer: data race \S+ in (.+)", r)
+        inside_runtime = tops and all("hip_emu::" in t.split("(")[0] or t.startswith(RUNTIME) for t in tops)
         (runtime if inside_runtime else kernel).append(r)
-    mem_env = dict(os.environ, ASAN_OPTIONS="detect_stack_use_after_return=0 detect_leaks=0 exitcode=23")
-    mem = subprocess.run([os.path.join(EMU, "_build", "memcheck", program), case], capture_output=True, text=True, env=mem_env, timeout=3000)
+    mem_env = dict(os.environ, ASAN_OPTIONS="detect_stack_use_after_return=0 detect_leaks=0 exitcode=23", **more)
+    mem = subprocess.run([os.path.join(EMU, "_build", "memcheck", program), case] + args, capture_output=True, text=True, env=mem_env, timeout=3000)
     memory_errors = mem.stderr.count("ERROR: AddressSanitizer")
     if mem.returncode not in (0, 23) and not memory_errors:
         raise SystemExit(f"{program} {case} (AddressSanitizer build): exit code {mem.returncode}\n{mem.stderr[-2000:]}")
@@ -144,7 +161,7 @@ def run(program, case, tmp, tag):
 
 
 def main():
-    wanted = [a for a in sys.argv[1:] if not a.startswith("-")] or ["gp", "codon", "hbm", "pipe"]
+    wanted = [a for a in sys.argv[1:] if not a.startswith("-")] or ["gp", "codon", "hbm", "pipe", "slots"]
     build()
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:

@@ -782,12 +782,14 @@ inline void RunAsm(const char* text, std::initializer_list<AsmOperand> outs, std
     ctx.barrier = [b] {
       const int waves = (int)b->waves.size();
       const unsigned mine = b->asm_generation;
+      TsanRelease(&b->barrier_token);  // (s_barrier is a workgroup barrier like __syncthreads(): the same happens-before edges)
       if (++b->asm_arrived == waves) {
         b->asm_arrived = 0;
         b->asm_generation++;
       } else {
         while (b->asm_generation == mine) Yield();
       }
+      TsanAcquire(&b->barrier_token);
     };
     static const bool digest = std::getenv("HIP_EMU_ASM_DIGEST") != nullptr;
     auto fnv = [](const void* data, size_t bytes, uint64_t h = 1469598103934665603ull) {
