@@ -431,6 +431,9 @@ def main():
                     help="codon workload: how many different (kappa, omega) rows the trees of a batch carry (tree t has row "
                          "t %% K; the reference hands every tree its own row, src/fat_beagle.hpp:173-181).  `value` is measured "
                          "with this K; the line also carries K = 1, 64 and one row per tree (`distinct_models`)")
+    ap.add_argument("--large-batch", type=int, default=16,
+                    help="ds1 workload: beside `value`, one blocking call of this many times its trees (16 x 6400 = 102 400 "
+                         "trees, 60 ms and more per call) reported as `large_batch`; 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="the timed region only: skip the small-collection calls and the second timed region (resident batch)")
@@ -677,6 +680,51 @@ def main():
                     eng.gradients_into(pid_s, bl_s[k & 1], par_s[0 if fixed else k & 1], ll_s, grad_s)
                 into[str(count)] = (time.perf_counter() - s0) / reps * 1e3
 
+    # the headline call at a device-filling size (calls of 50 ms and more): 16 x the trees of `value` in ONE
+    # blocking call, so that a driver's clock around the loop measures more than a 0.08 s region
+    large = None
+    if args.workload == "ds1" and world == 1 and not args.no_resident and not args.resident_only and not slots and args.large_batch > 0:
+        big = workloads.ds1_gtr_weibull4(args.replicas * args.large_batch)
+        Tb = big.tree_count
+        pid_b = np.ascontiguousarray(big.parent_ids, dtype=np.int32)
+        par_b = np.ascontiguousarray(big.params, dtype=np.float64)
+        par_sets_b = [par_b, workloads.other_bits(par_b, rate_column)]
+        bl_sets_b = [np.ascontiguousarray(big.branch_lengths, dtype=np.float64),
+                     np.ascontiguousarray(big.branch_lengths * 1.03125, dtype=np.float64)]
+        ll_b, grad_b = np.zeros(Tb), np.zeros((Tb, N))
+        for k in range(2):
+            eng.gradients_into(pid_b, bl_sets_b[k & 1], par_sets_b[k & 1], ll_b, grad_b)
+        eng.sync()
+        reps = max(2, min(args.steps, 5))
+        eng.kernel_timing(True)
+        b0 = time.perf_counter()
+        for k in range(reps):
+            eng.gradients_into(pid_b, bl_sets_b[k & 1], par_sets_b[k & 1], ll_b, grad_b)
+        eng.sync()
+        b_elapsed = time.perf_counter() - b0
+        b_kernel_ms, b_launches = eng.kernel_elapsed()
+        eng.kernel_timing(False)
+        if not os.environ.get("BENCH_ABLATION") and not (np.all(np.isfinite(ll_b)) and np.all(np.isfinite(grad_b))):
+            raise SystemExit("non-finite results in the large batch")
+        # the first trees of the large collection are the trees of the timed batch: same inputs, same call
+        # (a tree's results depend on its batch only through the order of the pattern-tile sums: DESIGN.md section 3)
+        same = min(T, Tb)
+        ref_ll = np.zeros(same)
+        ref_grad = np.zeros((same, N))
+        eng.gradients_into(np.ascontiguousarray(pid_b[:same]), np.ascontiguousarray(bl_sets_b[(reps - 1) & 1][:same]),
+                           np.ascontiguousarray(par_sets_b[(reps - 1) & 1][:same]), ref_ll, ref_grad)
+        large = {"trees": Tb, "calls": reps, "ms_per_call": b_elapsed / reps * 1e3, "trees_per_s": Tb * reps / b_elapsed,
+                 "launches_per_step": b_launches / reps, "kernel_ms_per_call": b_kernel_ms / reps,
+                 "max_dll_against_the_same_trees_in_a_call_of_their_own": float(np.max(np.abs(ll_b[:same] - ref_ll) / (1.0 + 2e-4 * np.abs(ref_ll)))),
+                 "max_dgrad_against_the_same_trees_in_a_call_of_their_own": float(np.max(np.abs(grad_b[:same] - ref_grad))),
+                 "note": f"{args.large_batch} x the trees of `value` in one blocking call (parameter rows change every call), "
+                         "mean of the calls; `value` stays the call BASELINE's metric is quoted on"}
+        if not os.environ.get("BENCH_ABLATION") and (large["max_dll_against_the_same_trees_in_a_call_of_their_own"] > 1e-11 or
+                                                     large["max_dgrad_against_the_same_trees_in_a_call_of_their_own"] > 1e-7):
+            raise SystemExit(f"the large batch's trees differ from the same trees in a call of their own: {large}")
+        # (leave the engine as the timed loop left it)
+        eng.gradients_into(pid, w.last_branch_lengths, w.last_params, out_ll, out_grad, rescaling=w.rescaling)
+
     # second timed region: the same passes over a batch that stays in HBM (no host arrays cross PCIe)
     resident = None
     if not args.no_resident:
@@ -788,6 +836,8 @@ def main():
                                        "note": "the same gradients call on 1 / 100 / 400 / 1600 of the trees, mean of 40 calls; "
                                                "parameter rows that change with every call (trees_per_call) and rows that never "
                                                "change (the last call's model is found standing)"}
+        if large is not None:
+            out["large_batch"] = large
         if cache_hit is not None:
             out["model_cache_hit"] = cache_hit
         if distinct is not None:

@@ -83,8 +83,11 @@ def main():
             "data", "config", "roofline", "cpu_baseline", "parity", "model_cache_hit", "resident"]
     if which.startswith("gp"):
         keys = [k for k in keys if k not in ("model_cache_hit", "resident")]
+    if which == "ds1" and not force_dist:
+        keys.append("large_batch")
     missing = [k for k in keys if k not in line]
     print(f"bench.py {which}: one JSON line, {len(line)} keys; missing {missing}; parity {line.get('parity')}")
+    print("   large_batch", line.get("large_batch"))
     print("   model_cache_hit", line.get("model_cache_hit"), "\n   blocking_call_ms", line.get("blocking_call_ms"),
           "\n   distinct_models", line.get("distinct_models"), "\n   config", {k: v for k, v in line["config"].items() if k != "workload"})
     if missing:
