@@ -135,7 +135,11 @@ HostPool* Pool(bito_amd_engine* e) {
 }
 
 SharedPool* Shared(bito_amd_engine* e) {
-  if (!e->shared_pool) e->shared_pool = std::make_unique<SharedPool>(std::max(0, e->host_threads - 1));
+  // (helpers poll beside one issuing thread per device slot: together they must not outnumber the CPUs this process
+  // may use, or the helpers take the time slices of the very threads they are there to relieve)
+  if (!e->shared_pool)
+    e->shared_pool = std::make_unique<SharedPool>(
+        std::max(0, std::min(e->host_threads - 1, UsableCpus() - (int)e->devices.size())));
   return e->shared_pool.get();
 }
 
@@ -311,9 +315,10 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
            (size_t)s.count * (want_gradient && out_grad ? N + 1 : 1) * sizeof(double) >= e->par_min_bytes;
   };
   auto big_copy = [&](const Shard& s) { return !threaded && big_block(s); };
+  int par_min_trees = e->par_min_trees;  // (this call's threshold: lowered below while the one-slot helpers still poll)
   // several issuing threads: ranges of half the threshold (512 trees), claimed by the thread itself and the shared helpers
   auto shared_parts = [&](int count) {
-    return std::max(1, std::min(Shared(e)->helpers() + 1, count / std::max(1, e->par_min_trees / 2)));
+    return std::max(1, std::min(Shared(e)->helpers() + 1, count / std::max(1, par_min_trees / 2)));
   };
   auto drain = [&](size_t k) -> int {
     const Shard& s = e->shards[k];
@@ -341,12 +346,13 @@ int Evaluate(bito_amd_engine* e, int32_t tree_count, int32_t rooted, int32_t nod
   // a call that will hand ranges to the helper threads wakes them now: they are up by the time the first chunk is staged.
   // (In a loop of calls they still poll from the call before: then smaller chunks -- the first one of a large call --
   // are worth cutting up as well.)
-  int par_min_trees = e->par_min_trees;
   if (!threaded && e->host_threads != 1 && tree_count >= e->par_min_trees) {
     if (Pool(e)->Hot()) par_min_trees = std::min(par_min_trees, 256);
     Pool(e)->Arm();
   }
-  if (threaded && e->host_threads != 1) Shared(e)->Arm();
+  // (several issuing threads: a shorter poll -- the staging of a call's large chunks is over within 2 ms, and every
+  // published range re-arms the helpers for kLingerNs)
+  if (threaded && e->host_threads != 1) Shared(e)->Arm(std::chrono::microseconds(2000));
   // what one issuing thread does with its chunks, in order; returns the first failure (the failing worker holds the message)
   struct Outcome {
     int rc = BITO_AMD_OK;

@@ -31,7 +31,10 @@
 // stream interpreter, the levelled interpreter, the optimiser's evaluations -- and the executor promises that a scheduled
 // sweep is bit for bit the sequential one (gp_schedule.hpp; tests/test_gp.py holds it on the device): with contraction
 // left to the backend, where a multiply meets an add could differ from one inlining context to the next.  (The tests'
-// CPU restatement is compiled the same way: one rounding per operation.)  These kernels are bound by dependent launches
+// CPU restatement is compiled the same way: one rounding per operation.)  ONE fused multiply-add is written out, and
+// therefore the same in every context: the per-pattern likelihood A + B e of EdgeFunction (fma(B, e, A), the form the
+// device ran in rounds 3-4; the restatement rounds the product first -- half an ulp of a value whose logarithm is held
+// to 1e-10).  These kernels are bound by dependent launches
 // and latency, not by the vector ALU: the unfused multiply-adds cost nothing that can be measured.
 #pragma clang fp contract(off)
 
@@ -50,6 +53,7 @@ struct GpCachedSchedule {
   int64_t* d_levels = nullptr;
   uint64_t* d_side = nullptr;
   bool on_device = false;
+  size_t device_bytes = 0;
   ~GpCachedSchedule() {
     if (d_ops || d_levels || d_side) (void)hipSetDevice(device);
     if (d_ops) (void)hipFree(d_ops);
@@ -57,6 +61,8 @@ struct GpCachedSchedule {
     if (d_side) (void)hipFree(d_side);
   }
 };
+
+constexpr size_t kScheduleCacheBytes = 64u << 20;  // device memory the cached schedules of one engine may hold
 
 struct bito_amd_gp_engine {
   int device = 0, n = 0, P = 0, Ppad = 0, nodes = 0, gpcsps = 0, plvs = 0;
@@ -812,7 +818,8 @@ static int ValidateOps(bito_amd_gp_engine* e, const bito_amd_gp_op* ops, int64_t
       case BITO_AMD_GP_RESET_MARGINAL_LIKELIHOOD: ok = !batched; break;
       case BITO_AMD_GP_INCREMENT_MARGINAL_LIKELIHOOD: ok = !batched && plv_ok(op.a) && gp_ok(op.b) && plv_ok(op.c); break;
       case BITO_AMD_GP_PREP_FOR_MARGINALIZATION:
-        ok = plv_ok(op.a) && op.count > 0 && side && op.b + op.count <= (uint64_t)side_count;
+        ok = plv_ok(op.a) && op.count > 0 && side && side_count > 0 && op.b <= (uint64_t)side_count &&
+             (uint64_t)op.count <= (uint64_t)side_count - op.b;  // (no sum: b near 2^64 must not wrap)
         for (uint32_t k = 0; ok && k < op.count; k++) ok = plv_ok(side[op.b + k]);
         break;
       case BITO_AMD_GP_OPTIMIZE_BRANCH_LENGTH: ok = plv_ok(op.a) && plv_ok(op.b) && gp_ok(op.c); break;
@@ -911,9 +918,14 @@ int bito_amd_gp_schedule_operations(const bito_amd_gp_op* ops, int64_t op_count,
                                     int32_t reorder, bito_amd_gp_op* out_ops, int32_t* out_launch, int32_t* out_level,
                                     int32_t* out_launch_kinds, int64_t* out_launch_count) {
   if (op_count < 0 || (op_count > 0 && (!ops || !out_ops)) || !out_launch_count) return BITO_AMD_ERR_BAD_ARG;
-  for (int64_t o = 0; o < op_count; o++)
-    if (ops[o].opcode == BITO_AMD_GP_PREP_FOR_MARGINALIZATION && (!side || ops[o].b + ops[o].count > (uint64_t)side_count))
+  for (int64_t o = 0; o < op_count; o++) {
+    // (needs no engine, so ids cannot be held to a DAG here; what the read / write sets index by must still be sane:
+    // a known opcode, and a side range that lies inside the side array -- compared without a sum that could wrap)
+    if (ops[o].opcode > BITO_AMD_GP_PREP_FOR_MARGINALIZATION) return BITO_AMD_ERR_BAD_ARG;
+    if (ops[o].opcode == BITO_AMD_GP_PREP_FOR_MARGINALIZATION &&
+        (!side || side_count <= 0 || ops[o].b > (uint64_t)side_count || (uint64_t)ops[o].count > (uint64_t)side_count - ops[o].b))
       return BITO_AMD_ERR_BAD_ARG;
+  }
   bito_amd_gp_schedule::Schedule S;
   bito_amd_gp_schedule::ScheduleStream(ops, op_count, side, reorder != 0, &S);
   if ((int64_t)S.image.size() != op_count) return BITO_AMD_ERR_STATE;
@@ -944,19 +956,48 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
   const std::shared_ptr<GpCachedSchedule> cached = ScheduleOf(e, ops, op_count, side, side_used, reorder);
   const bito_amd_gp_schedule::Schedule& S = cached->schedule;
   if (!cached->on_device) {
+    // (allocated into locals and handed to the cache entry only when all three stand: a failure half way leaves nothing
+    // behind for the next call to overwrite)
+    bito_amd_gp_op* up_ops = nullptr;
+    int64_t* up_levels = nullptr;
+    uint64_t* up_side = nullptr;
+    auto upload = [&]() -> hipError_t {
+      hipError_t st = hipSuccess;
+      if (op_count > 0) {
+        if ((st = hipMalloc((void**)&up_ops, (size_t)op_count * sizeof(bito_amd_gp_op))) != hipSuccess) return st;
+        if ((st = hipMemcpy(up_ops, S.image.data(), (size_t)op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice)) != hipSuccess) return st;
+      }
+      if (!S.level_offsets.empty()) {
+        if ((st = hipMalloc((void**)&up_levels, S.level_offsets.size() * sizeof(int64_t))) != hipSuccess) return st;
+        if ((st = hipMemcpy(up_levels, S.level_offsets.data(), S.level_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice)) != hipSuccess) return st;
+      }
+      // (never a null pointer in a kernel's argument list: a stream without PrepForMarginalization gets one entry)
+      if ((st = hipMalloc((void**)&up_side, (size_t)std::max<int64_t>(side_used, 1) * sizeof(uint64_t))) != hipSuccess) return st;
+      if (side_used > 0) st = hipMemcpy(up_side, side, (size_t)side_used * sizeof(uint64_t), hipMemcpyHostToDevice);
+      return st;
+    };
+    const hipError_t st = upload();
+    if (st != hipSuccess) {
+      if (up_ops) (void)hipFree(up_ops);
+      if (up_levels) (void)hipFree(up_levels);
+      if (up_side) (void)hipFree(up_side);
+      GP_TRY(e, st);
+    }
     cached->device = e->device;
-    if (op_count > 0) {
-      GP_TRY(e, hipMalloc((void**)&cached->d_ops, (size_t)op_count * sizeof(bito_amd_gp_op)));
-      GP_TRY(e, hipMemcpy(cached->d_ops, S.image.data(), (size_t)op_count * sizeof(bito_amd_gp_op), hipMemcpyHostToDevice));
-    }
-    if (!S.level_offsets.empty()) {
-      GP_TRY(e, hipMalloc((void**)&cached->d_levels, S.level_offsets.size() * sizeof(int64_t)));
-      GP_TRY(e, hipMemcpy(cached->d_levels, S.level_offsets.data(), S.level_offsets.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    }
-    // (never a null pointer in a kernel's argument list: a stream without PrepForMarginalization gets one entry)
-    GP_TRY(e, hipMalloc((void**)&cached->d_side, (size_t)std::max<int64_t>(side_used, 1) * sizeof(uint64_t)));
-    if (side_used > 0) GP_TRY(e, hipMemcpy(cached->d_side, side, (size_t)side_used * sizeof(uint64_t), hipMemcpyHostToDevice));
+    cached->d_ops = up_ops;
+    cached->d_levels = up_levels;
+    cached->d_side = up_side;
+    cached->device_bytes = (size_t)op_count * sizeof(bito_amd_gp_op) + S.level_offsets.size() * sizeof(int64_t) +
+                           (size_t)std::max<int64_t>(side_used, 1) * sizeof(uint64_t);
     cached->on_device = true;
+    // the cache is bounded by what it holds on the device as well as by its sixteen entries: the oldest schedules leave
+    // until the resident images fit kScheduleCacheBytes (the one in use always stays)
+    size_t held = 0;
+    for (const auto& c : e->schedules) held += c->device_bytes;
+    while (held > kScheduleCacheBytes && e->schedules.size() > 1 && e->schedules.back() != cached) {
+      held -= e->schedules.back()->device_bytes;
+      e->schedules.pop_back();
+    }
   }
   bito_amd_gp_op* const d_ops = cached->d_ops;
   const uint64_t* const d_side = cached->d_side;

@@ -226,16 +226,21 @@ class SharedPool {
   }
   void Loop() {
     unsigned seen = epoch_.load(std::memory_order_acquire);
+    unsigned spins = 0;
     for (;;) {
       // (polling helpers look at a counter, not at the list: the mutex stays free for the issuing threads)
       if (open_jobs_.load(std::memory_order_acquire) > 0) {
         if (std::shared_ptr<Job> job = Pick()) {
           Work(*job);
+          spins = 0;
           continue;
         }
       }
       if (Now() <= armed_until_.load(std::memory_order_relaxed)) {  // armed: poll
         if (stopping_.load(std::memory_order_acquire)) return;
+        // (every 64th look gives the CPU away if another thread wants it -- an issuing thread on a box with fewer CPUs
+        // than threads; with a CPU to itself the call returns at once)
+        if ((++spins & 63u) == 0) std::this_thread::yield();
         CpuPause();
         continue;
       }

@@ -25,8 +25,9 @@ def data_dir():
 # Run order of the GPU suite.  The driver runs `pytest tests -x -q -m gpu`: it stops at the first failure, so what ran
 # green under the driver before goes first and the tests of code whose device side changed in a round that had no GPU
 # access to check it (round 5: the GP executor's scheduled launches, gp_engine.hip; the multi-slot engine's shared helper
-# threads and per-slot second pass, engine.cpp; one barrier fewer per round in gs_eigen_kernel -- all green under
-# tests/hip_emu, none yet on hardware) go last -- a
+# threads and per-slot second pass, engine.cpp; one barrier fewer per round in gs_eigen_kernel -- none yet on hardware;
+# under tests/hip_emu their small-shape variants are green (tests/test_gp_emulated.py, tests/test_engine_emulated.py),
+# while the full-size forms of four of them exceed the emulated run's time limit, profiles/r5_emulated/) go last -- a
 # failure there must not hide the results of everything else.  Within a group the order is pytest's own.
 RUN_LAST = ("test_codon_fixtures.py", "test_gpu_general.py", "test_round5_host.py", "test_gp.py", "test_gp_binding_client.py", "test_nni.py", "test_tp.py")
 

@@ -795,3 +795,14 @@ def test_schedule_entry_point_rejects_streams_it_cannot_index():
     rc = L.bito_amd_gp_schedule_operations(ops.ctypes.data, 2, side.ctypes.data, 2, 1, out.ctypes.data, None, None, None, C.byref(count))
     assert rc == 0 and count.value == 1  # (the ZeroPLV of PLV 5 must follow the Prep that writes its count: two levels, one launch)
     assert [int(o["opcode"]) for o in out] == [gp.PREP_FOR_MARGINALIZATION, gp.ZERO_PLV]
+    # a start near 2^64 must not wrap around into the side array (the range is compared without a sum) ...
+    big = np.zeros(2, dtype=gp.OP_DTYPE)
+    big[0]["opcode"], big[0]["count"], big[0]["a"], big[0]["b"] = gp.PREP_FOR_MARGINALIZATION, 2, 5, 2 ** 64 - 1
+    big[1] = ops[1]
+    rc = L.bito_amd_gp_schedule_operations(big.ctypes.data, 2, side.ctypes.data, 2, 1, out.ctypes.data, None, None, None, C.byref(count))
+    assert rc == _capi.ERR_BAD_ARG
+    # ... and an opcode the read / write sets do not know is refused
+    big[0] = ops[1]
+    big[1]["opcode"] = 77
+    rc = L.bito_amd_gp_schedule_operations(big.ctypes.data, 2, side.ctypes.data, 2, 1, out.ctypes.data, None, None, None, C.byref(count))
+    assert rc == _capi.ERR_BAD_ARG
