@@ -32,6 +32,9 @@
 #ifndef GS_SPARSE_DP
 #define GS_SPARSE_DP 1
 #endif
+#ifndef GS_DP_COLUMN
+#define GS_DP_COLUMN 1  // 1: the sparse dP terms with a column's list in registers (round 6); 0: round 3's loop, lists in LDS
+#endif
 #ifndef GS_SIBLING_EARLY
 #define GS_SIBLING_EARLY 0
 #endif
@@ -419,7 +422,7 @@ constexpr int kPld = 66;  // LDS row stride of P (even: 16-byte aligned pairs)
 // for line of device code, the one the round's last full GPU run checked.
 constexpr int kGsMatJobs = 8;
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)  // (two waves per SIMD, as the 72 KB of LDS allow: 256 registers)
 gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ branch,
                    const int32_t* __restrict__ model_index, const double* __restrict__ gs_model,
                    double* __restrict__ imgs, int want_gradient, int deriv_mode) {
@@ -427,10 +430,12 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
   extern __shared__ double mat_lds[];
   double* const Pl = mat_lds;                                   // [64][kPld]  P, row-major
   v2d* const Bl = reinterpret_cast<v2d*>(Pl + 64 * kPld);       // [16 k-steps][2][64 lanes] pairs of V^-1 entries
-  double* const e = reinterpret_cast<double*>(Bl + 16 * 2 * 64);  // [64] exp(lambda t r_c)
-  double* const nz_val = e + 64;                                // [64][kGsQnzMax] nonzero entries of Q's columns
+  double* const e_all = reinterpret_cast<double*>(Bl + 16 * 2 * 64);  // [kGsMatJobs][64] exp(lambda t r_c) of the workgroup's jobs
+#if !GS_DP_COLUMN
+  double* const nz_val = e_all + kGsMatJobs * 64;               // [64][kGsQnzMax] nonzero entries of Q's columns
   uint8_t* const nz_idx = reinterpret_cast<uint8_t*>(nz_val + 64 * kGsQnzMax);
   uint8_t* const nz_cnt = nz_idx + 64 * kGsQnzMax;
+#endif
   const int C = d.category_count, NB = d.node_count - 1, n = d.taxon_count;
   const int jobs = NB * C;
   const int job0 = blockIdx.x * kGsMatJobs, job1 = min(job0 + kGsMatJobs, jobs);
@@ -447,6 +452,24 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
     Bl[i] = v2d{src[0], src[16]};
   }
   const bool sparse_dp = GS_SPARSE_DP && want_gradient && m[kGsQnzFlag] != 0.0;
+#if GS_DP_COLUMN
+  // Round 6: four threads per column of dP^T keep that column's list of Q -- row offsets into P and values -- in
+  // REGISTERS for all the jobs of the workgroup (round 3 staged the lists in LDS and read index and value again for
+  // every term of every pair of outputs: four LDS reads per term and pair, now two).  Lists shorter than kGsQnzMax are
+  // padded with (offset 0, value 0): a term P x (+-0) leaves the sum as it is, bit for bit, and the loop below has no
+  // trip count -- every register index is static.
+  const int dp_col = tid >> 2, dp_q = tid & 3;
+  int nz_off[kGsQnzMax];
+  double nz_v[kGsQnzMax];
+  if (sparse_dp) {
+    const int cnt = dp_col < S ? (int)m[kGsQnzCount + dp_col] : 0;
+#pragma unroll
+    for (int t = 0; t < kGsQnzMax; t++) {
+      nz_off[t] = t < cnt ? (int)m[kGsQnzIdx + dp_col * kGsQnzMax + t] : 0;
+      nz_v[t] = t < cnt ? m[kGsQnzVal + dp_col * kGsQnzMax + t] : 0.0;
+    }
+  }
+#else
   if (sparse_dp) {
     for (int i = tid; i < 64 * kGsQnzMax; i += 256) {
       nz_val[i] = m[kGsQnzVal + i];
@@ -454,6 +477,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
     }
     if (tid < 64) nz_cnt[tid] = (uint8_t)m[kGsQnzCount + tid];
   }
+#endif
   // result registers -> row-major LDS: register r of lane 16 q + j holds row 4 r + q, column j
   auto to_lds = [&](const v4d acc[4]) {
 #pragma unroll
@@ -462,13 +486,18 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
       for (int r = 0; r < 4; r++) Pl[(16 * w + 4 * r + kq) * kPld + 16 * nb + ii] = acc[nb][r];
   };
 
+  // the exponentials of ALL the workgroup's jobs at once, two per thread (round 6; one job's 64 at a time before, by
+  // one wave with the other three waiting at a barrier of their own per job: seven barriers fewer per workgroup)
+  for (int i = tid; i < (job1 - job0) * 64; i += 256) {
+    const int job = job0 + (i >> 6), br = job / C, c = job % C;
+    const double time = branch[(size_t)tree * d.node_count + br] * m[kGsCatRate + c];
+    e_all[i] = DetExp(m[kGsLambda + (i & 63)] * time);
+  }
   for (int job = job0; job < job1; job++) {
     const int br = job / C, c = job % C;
     const double rate = m[kGsCatRate + c];
-    const double time = branch[(size_t)tree * d.node_count + br] * rate;
-    __syncthreads();  // (the previous job's readers of Pl and e are done; the first job: Bl and the lists are in place)
-    if (tid < 64) e[tid] = DetExp(m[kGsLambda + tid] * time);
-    __syncthreads();
+    const double* const e = e_all + (job - job0) * 64;
+    __syncthreads();  // (the previous job's readers of Pl are done; the first job: Bl, the exponentials and the lists are in place)
     double* __restrict__ rec = imgs + (((size_t)blockIdx.y * NB + br) * C + c) * (3 * 4096);
     // rows 16 w .. 16 w + 15 of (V diag e) V^-1
     v4d acc[4];
@@ -524,6 +553,27 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
       // the matrix pipe gives (its other terms are exact zeros), at a tenth of the arithmetic and none of it on the pipe
       // this kernel and the traversal wait for
       v2d* __restrict__ out = reinterpret_cast<v2d*>(rec + 4096);
+#if GS_DP_COLUMN
+      double qv[kGsQnzMax];
+#pragma unroll
+      for (int t = 0; t < kGsQnzMax; t++) qv[t] = nz_v[t] * drate;
+#pragma unroll 2
+      for (int j = 0; j < 8; j++) {
+        // positions at, at + 1 of row dp_col: states 16 mm + 4 r + q and the one four further (r + 1); a quartet of
+        // threads writes 64 contiguous bytes per store
+        const int at = 2 * (dp_q + 4 * j);
+        const int mm = at >> 4, q = (at >> 2) & 3, r = at & 3;
+        const double* __restrict__ p0 = Pl + (16 * mm + 4 * r + q) * kPld;
+        const double* __restrict__ p1 = p0 + 4 * kPld;
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < kGsQnzMax; t++) {
+          d0 = __builtin_fma(p0[nz_off[t]], qv[t], d0);
+          d1 = __builtin_fma(p1[nz_off[t]], qv[t], d1);
+        }
+        out[dp_col * 32 + dp_q + 4 * j] = v2d{d0, d1};
+      }
+#else
 #pragma unroll 2
       for (int i = 0; i < 8; i++) {
         const int pos = i * 256 + tid;
@@ -544,6 +594,7 @@ gs_matrices_kernel(BatchDims d, int S, int tree0, const double* __restrict__ bra
         }
         out[pos] = v2d{d0, d1};
       }
+#endif
       continue;
     }
     // (a model whose Q is not that sparse: the second product on the matrix pipe, B = r_c Q from the model record)
@@ -570,8 +621,12 @@ void LaunchGsMatrices(const BatchDims& d, int S, int tree0, int chunk, const dou
                       int deriv_mode, hipStream_t stream) {
   const int jobs = (d.node_count - 1) * d.category_count;
   const dim3 grid((jobs + kGsMatJobs - 1) / kGsMatJobs, chunk);
-  const size_t lds = (64 * kPld + 16 * 2 * 64 * 2 + 64 + 64 * kGsQnzMax) * sizeof(double) + 64 * kGsQnzMax + 64;
-  // (72 KB of LDS: two workgroups per CU; the attribute is per device, and a process may drive several)
+#if GS_DP_COLUMN
+  const size_t lds = (64 * kPld + 16 * 2 * 64 * 2 + kGsMatJobs * 64) * sizeof(double);
+#else
+  const size_t lds = (64 * kPld + 16 * 2 * 64 * 2 + kGsMatJobs * 64 + 64 * kGsQnzMax) * sizeof(double) + 64 * kGsQnzMax + 64;
+#endif
+  // (69.5 KB of LDS: two workgroups per CU; the attribute is per device, and a process may drive several)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gs_matrices_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   hipLaunchKernelGGL(gs_matrices_kernel, grid, dim3(256), lds, stream, d, S, tree0, branch, model_index, gs_model,
                      imgs, want_gradient, deriv_mode);

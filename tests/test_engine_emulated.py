@@ -369,3 +369,47 @@ assert eng.kernel_name() == "gs_walk_kernel" and np.isfinite(out["log_likelihood
     assert walk * 4096 == int(device["SQ_INSTS_MFMA"]), (per_kernel, device["SQ_INSTS_MFMA"])
     row = [r for r in json.load(open(os.path.join(ROOT, "profiles", "executed.json"))) if r["kernel"] == "gs_walk_kernel"][0]
     assert row["matrix_instructions_per_tree"] == walk
+
+
+def test_emulated_codon_image_kernel_forms_give_the_same_bits(emulated, tmp_path):
+    """gs_matrices_kernel's sparse dP terms (round 6: four threads per column of dP^T with the column's list of Q in
+    registers, lists padded with zero terms; the exponentials of a workgroup's eight jobs taken at once) against round 3's
+    loop (lists in LDS, read per term; -DGS_DP_COLUMN=0): the same terms in the same order, so the SAME BITS in every
+    log-likelihood, branch gradient and site-model gradient -- two fluA codon trees, constant rates and weibull+3 with the
+    site-model gradient (whose second pass multiplies the lists by a negative d rate / d shape: the padding's -0)."""
+    emu_dir = os.path.join(HERE, "hip_emu")
+    flags = [f for f in subprocess.run(["make", "-s", "-C", emu_dir, "print-flags"], capture_output=True, text=True).stdout.split()]
+    assert flags, "tests/hip_emu/Makefile: print-flags"
+    obj, lib = str(tmp_path / "gs_kernels_round3.o"), str(tmp_path / "libbito_amd_emu_round3.so")
+    subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-DGS_DP_COLUMN=0", *flags, "-Wno-psabi", "-c", "_build/src/gs_kernels.hip", "-o", obj],
+                   check=True, cwd=emu_dir, capture_output=True)
+    others = [os.path.join(emu_dir, "_build", f) for f in os.listdir(os.path.join(emu_dir, "_build"))
+              if f.endswith(".o") and not f.startswith("gs_kernels")]
+    subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-shared", "-pthread", "-o", lib, obj, *others], check=True)
+    body = '''
+site = {site!r}
+w = workloads.flua_codon(2, site)
+if site == "constant":
+    w.params = workloads.codon_rows(2, 2)
+gpu = bito_amd.Engine(spec(w), w.patterns, w.weights)
+out = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, flags=_capi.GRAD_SITE_MODEL if site != "constant" else 0)
+assert gpu.kernel_name() == "gs_walk_kernel"
+np.save({path!r}, np.concatenate([np.ravel(out[k]) for k in ("log_likelihood", "branch_lengths", "site_model") if k in out and out[k] is not None]))
+'''
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+
+    jobs = []
+    for site in ("constant", "weibull+3"):
+        for tag, library in (("now", EMU), ("round3", lib)):
+            path = str(tmp_path / f"{site}_{tag}.npy")
+            code = PRELUDE.format(root=ROOT, here=HERE) + body.format(site=site, path=path)
+            jobs.append((site, tag, path, [sys.executable, "-c", code], dict(os.environ, BITO_AMD_LIB=library)))
+    with ThreadPoolExecutor(4) as pool:
+        done = list(pool.map(lambda j: subprocess.run(j[3], env=j[4], capture_output=True, text=True, timeout=1500), jobs))
+    for j, d in zip(jobs, done):
+        assert d.returncode == 0, d.stdout[-2000:] + d.stderr[-2000:]
+    for site in ("constant", "weibull+3"):
+        now, old = (np.load(str(tmp_path / f"{site}_{tag}.npy")) for tag in ("now", "round3"))
+        assert now.shape == old.shape and now.size >= 270 and np.all(np.isfinite(now))
+        assert np.array_equal(now, old), (site, float(np.abs(now - old).max()))
