@@ -271,10 +271,19 @@ gs_model_kernel(BatchDims d, ModelSpec spec, DeviceBatch b, const int32_t* __res
 // the row updates, which set the annihilated pairs to exactly zero: two barriers per round.  Wave g owns pairs 8 g .. 8 g + 7 of a round;
 // their LDS traffic is issued as eight independent streams.
 __device__ __forceinline__ void GsPair(int r, int k, int& p, int& q) {
-  const int a = k == 0 ? 63 : (r + k) % 63;
-  const int bb = k == 0 ? r : (r - k + 63) % 63;
+  // ((r + k) % 63 and (r - k + 63) % 63 for r < 63, k < 32: one conditional subtraction each)
+  const int x = r + k, y = r - k + 63;
+  const int a = k == 0 ? 63 : (x >= 63 ? x - 63 : x);
+  const int bb = k == 0 ? r : (y >= 63 ? y - 63 : y);
   p = a < bb ? a : bb;
   q = a < bb ? bb : a;
+}
+
+__device__ __forceinline__ double GsReadLane(double v, int lane) {
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 __global__ void __launch_bounds__(256)
@@ -283,7 +292,10 @@ gs_eigen_kernel(const int32_t* __restrict__ model_index, double* __restrict__ gs
   __shared__ double A[64 * kLd];
   __shared__ double U[64 * kLd];
   __shared__ double wmax[4];
-  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  // (g is the same in every lane of a wave: said so, the pairs of a round are scalar arithmetic and every LDS address
+  // below is one vector add -- round 6; the compiler had kept the pair arithmetic, a modulo by 63 per pair, on the
+  // vector ALU: 200 of the 550 instructions of a round)
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, g = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (model_index[t] != t) return;
   double* __restrict__ out = gs_model + (size_t)t * kGsModelStride;
   for (int idx = tid; idx < 4096; idx += 256) {
@@ -308,8 +320,8 @@ gs_eigen_kernel(const int32_t* __restrict__ model_index, double* __restrict__ gs
       // next barrier -- so no barrier stands between the angles and the column updates (round 5: wave 0 took all 32
       // angles and passed them through LDS behind a barrier of the workgroup; the same formulas, the same bits).
       double c_mine = 1.0, s_mine = 0.0;
+      int pp = 0, qq = 0;
       if (lane < 8) {
-        int pp, qq;
         GsPair(r, g * 8 + lane, pp, qq);
         const double apq = A[pp * kLd + qq];
         if (apq != 0.0) {
@@ -324,8 +336,8 @@ gs_eigen_kernel(const int32_t* __restrict__ model_index, double* __restrict__ gs
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         GsPair(r, g * 8 + k, p[k], q[k]);
-        c[k] = __shfl(c_mine, k);
-        s[k] = __shfl(s_mine, k);
+        c[k] = GsReadLane(c_mine, k);  // (a fixed lane: v_readlane into scalar registers, no LDS crossbar -- round 6)
+        s[k] = GsReadLane(s_mine, k);
       }
       {  // column updates: lane = row
         double ap[8], aq[8], up[8], uq[8];
@@ -352,12 +364,19 @@ gs_eigen_kernel(const int32_t* __restrict__ model_index, double* __restrict__ gs
           ap[k] = A[p[k] * kLd + lane];
           aq[k] = A[q[k] * kLd + lane];
         }
-        // (the annihilated pair is set to exactly zero where the row update writes it -- round 5: it was a step of its
-        // own behind a fourth barrier per round; the same values in LDS before anything reads them)
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          A[p[k] * kLd + lane] = lane == q[k] ? 0.0 : c[k] * ap[k] - s[k] * aq[k];
-          A[q[k] * kLd + lane] = lane == p[k] ? 0.0 : s[k] * ap[k] + c[k] * aq[k];
+          A[p[k] * kLd + lane] = c[k] * ap[k] - s[k] * aq[k];
+          A[q[k] * kLd + lane] = s[k] * ap[k] + c[k] * aq[k];
+        }
+        // The annihilated pairs are set to exactly zero by the lanes that took their angles, BEHIND the row update's
+        // writes of the same entries: one wave's LDS writes land in program order, and both come from this wave (round
+        // 5 selected the zero inside the row update: two compares and four selects per pair in all 64 lanes; round 4
+        // had a step of its own behind a barrier).  The same values in LDS before anything reads them.
+        __builtin_amdgcn_wave_barrier();  // (no instruction: the order of the two statements, for the compiler and the CPU emulation's fibers)
+        if (lane < 8) {
+          A[pp * kLd + qq] = 0.0;
+          A[qq * kLd + pp] = 0.0;
         }
       }
       __syncthreads();

@@ -11,7 +11,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "bito_amd", "csrc")
-FLAGS = {"gs_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "walk_lds.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+FLAGS = {"gs_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "_gs_round5.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+         "walk_lds.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def main():

@@ -481,6 +481,7 @@ inline T __shfl(T v, int src) {
 template <typename T>
 inline T __shfl_xor(T v, int mask) { return __shfl(v, hip_emu::Lane() ^ mask); }
 #define __builtin_amdgcn_readfirstlane(x) hip_emu::ReadFirstLane(x)
+#define __builtin_amdgcn_wave_barrier() hip_emu::WaveBarrier()  // (the lanes of a wave meet: one instruction stream on the device)
 // v_readlane_b32: the value of lane `lane` (wave-uniform index); ds_bpermute_b32: of lane (byte index / 4) & 63, per lane
 inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)hip_emu::Publish((uint64_t)(uint32_t)v)[lane & 63]; }
 inline int __builtin_amdgcn_ds_bpermute(int byte_index, int v) {

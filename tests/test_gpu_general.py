@@ -56,23 +56,33 @@ def test_general_kernels_match_oracle_on_headline_model():
     assert grad_close(out["branch_lengths"], ref["branch_lengths"])
 
 
-def test_codon_model_setup_is_bitwise_the_oracles():
+@pytest.mark.parametrize("distinct", [1, 16, 64])
+def test_codon_model_setup_is_bitwise_the_oracles(distinct):
     """Rate matrix, Jacobi eigensystem and F1x4 frequencies of the set-up kernel equal the oracle's bit
-    for bit (same operation order, no FMA contraction) -- errors there are coherent across patterns."""
-    w = workloads.flua_codon(2)
+    for bit (same operation order, no FMA contraction) -- errors there are coherent across patterns.  With one row for
+    all trees, and with 64 trees that carry 64 different (kappa, omega) rows: 64 eigensystems side by side in one launch
+    of gs_eigen_kernel (the reference hands every tree its own row, src/fat_beagle.hpp:173-181), every one the
+    checker's to the last bit (the alignment's first 16 patterns: the models do not depend on it)."""
+    T = 2 if distinct == 1 else distinct
+    w = workloads.flua_codon(T)
+    if distinct > 1:
+        w.params = workloads.codon_rows(T, distinct)
+        w.patterns, w.weights = np.ascontiguousarray(w.patterns[:, :16]), np.ascontiguousarray(w.weights[:16])
+        assert len(np.unique(w.params, axis=0)) == distinct
     eng = bito_amd.Engine(spec(w.substitution, w.site), w.patterns, w.weights)
     assert eng.state_count == 61 and eng.param_count == 6
     eng.log_likelihoods(w.parent_ids, w.branch_lengths, w.params)
-    got = eng.read_general_model(1)
     Q, V, Vi = (np.zeros(64 * 64) for _ in range(3))
     lam, pi = np.zeros(64), np.zeros(64)
-    assert gs.lib().gs_substitution_model(b"GY94", gs._dp(np.ascontiguousarray(w.params[1])), gs._dp(Q), gs._dp(V),
-                                          gs._dp(Vi), gs._dp(lam), gs._dp(pi)) == 0
-    assert np.array_equal(got["pi"], pi)
-    assert np.array_equal(got["Q"], Q.reshape(64, 64))
-    assert np.array_equal(got["lambda"], lam)
-    assert np.array_equal(got["V"], V.reshape(64, 64))
-    assert np.array_equal(got["Vinv"], Vi.reshape(64, 64))
+    for t in range(1 if distinct == 1 else 0, T):
+        got = eng.read_general_model(t)
+        assert gs.lib().gs_substitution_model(b"GY94", gs._dp(np.ascontiguousarray(w.params[t])), gs._dp(Q), gs._dp(V),
+                                              gs._dp(Vi), gs._dp(lam), gs._dp(pi)) == 0
+        assert np.array_equal(got["pi"], pi), t
+        assert np.array_equal(got["Q"], Q.reshape(64, 64)), t
+        assert np.array_equal(got["lambda"], lam), t
+        assert np.array_equal(got["V"], V.reshape(64, 64)), t
+        assert np.array_equal(got["Vinv"], Vi.reshape(64, 64)), t
 
 
 @pytest.mark.parametrize("site", ["constant", "weibull+3"])
