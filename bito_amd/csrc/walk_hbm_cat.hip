@@ -3,7 +3,9 @@
 // kernels.hip (walk_hbm_kernel) re-dealt over threads.  FP64, no atomics, fixed summation order.
 #include "kernels.hpp"
 #include "wave_sums.hpp"
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 // model.hpp switches fused multiply-add contraction off for the set-up arithmetic (errors in P(t) are coherent across
 // the site patterns; its operation order is part of the numerical contract).  The walk's own sums are per pattern,
@@ -100,7 +102,7 @@ inline int HbmCatTiles(int pattern_count) { return (pattern_count + kCatTile - 1
 // not read by the walk at all).  One workgroup per tree, the tree's tables in LDS
 // (25 bytes per internal node), one lane labels them, all write the records; trees too large for that are walked in
 // id order.
-constexpr int kStepInts = 12;
+constexpr int kStepInts = 16;
 // Unstored nodes: cherries, and with `fold` PITCHFORKS -- a tip and a cherry under one node (a sixth of a random tree's
 // internal nodes) --, rebuilt from their tips' matrix rows where they are used, like cherries: no step, no cell traffic.
 __device__ __forceinline__ bool IsCherry(const int32_t* __restrict__ c, int n, int root, int v) {
@@ -111,32 +113,87 @@ __device__ __forceinline__ bool IsFork(const int32_t* __restrict__ c, int n, int
   const int a = c[2 * (v - n)], b = c[2 * (v - n) + 1];
   return (a < n && IsCherry(c, n, root, b)) || (b < n && IsCherry(c, n, root, a));
 }
-// what a step knows about child cc: {its children (a pitchfork: its tip, then its cherry), the cherry's tips of a pitchfork}
-__device__ __forceinline__ void ChildInfo(const int32_t* __restrict__ c, int n, int root, int fold, int cc, int& a, int& b, int& hb, int& hc) {
-  a = b = hb = hc = -1;
+// Round 6, fold level 2: the two shapes of a FOUR-tip subtree are rebuilt where they are used as well -- a CATERPILLAR
+// (a tip and a pitchfork under one node: 69 of a random 1000-taxon tree's 999 internal nodes) and TWIN cherries (two
+// cherries under one node: 32) -- stored vectors per tree 498 -> 397, vector transfers 1104 -> 879
+// (scripts/sim_hbm_traffic.py).  A caterpillar is a pitchfork with one more tip on top: its pre-order part is one more
+// level (two edge sums, one transposed product) in front of the pitchfork's, with no more vectors live at a time.
+__device__ __forceinline__ bool IsCaterpillar(const int32_t* __restrict__ c, int n, int root, int v) {
+  if (v < n || v == root) return false;
+  const int a = c[2 * (v - n)], b = c[2 * (v - n) + 1];
+  return (a < n && IsFork(c, n, root, b)) || (b < n && IsFork(c, n, root, a));
+}
+__device__ __forceinline__ bool IsTwin(const int32_t* __restrict__ c, int n, int root, int v) {
+  if (v < n || v == root) return false;
+  return IsCherry(c, n, root, c[2 * (v - n)]) && IsCherry(c, n, root, c[2 * (v - n) + 1]);
+}
+__device__ __forceinline__ bool IsFourTips(const int32_t* __restrict__ c, int n, int root, int v) {
+  return IsCaterpillar(c, n, root, v) || IsTwin(c, n, root, v);
+}
+// ... folded into its parent's step unless its sibling is a four-tip subtree with a lower id: a step carries ONE of them,
+// in its first slot (five of a random 1000-taxon tree's 101 have such a sibling); par: the parents by node id
+__device__ __forceinline__ bool IsFoldedFour(const int32_t* __restrict__ c, const int32_t* __restrict__ par, int n, int root, int v) {
+  if (par == nullptr || !IsFourTips(c, n, root, v)) return false;
+  const int p = par[v];
+  const int sib = c[2 * (p - n)] == v ? c[2 * (p - n) + 1] : c[2 * (p - n)];
+  return !(sib < v && IsFourTips(c, n, root, sib));
+}
+// a node without a step and without a cell (fold 0: cherries; 1: and pitchforks; 2: and four-tip subtrees)
+__device__ __forceinline__ bool IsUnstored(const int32_t* __restrict__ c, const int32_t* __restrict__ par, int n, int root, int fold, int v) {
+  return IsCherry(c, n, root, v) || (fold >= 1 && IsFork(c, n, root, v)) || (fold >= 2 && IsFoldedFour(c, par, n, root, v));
+}
+// what a step knows about child cc -- six ids:
+//   stored node / cherry: {its children}            pitchfork: {its tip, its cherry | the cherry's tips}
+//   caterpillar: {its tip, its pitchfork F | F's tip, F's cherry H | H's tips}
+//   twin cherries: {cherry H1, cherry H2 | H1's tips | H2's tips}
+__device__ __forceinline__ void ChildInfo(const int32_t* __restrict__ c, const int32_t* __restrict__ par, int n, int root, int fold, int cc,
+                                          int& a, int& b, int& hb, int& hc, int& x, int& y) {
+  a = b = hb = hc = x = y = -1;
   if (cc < n) return;
   a = c[2 * (cc - n)];
   b = c[2 * (cc - n) + 1];
-  if (fold && IsFork(c, n, root, cc)) {
-    if (a >= n) {
-      const int t = a;
-      a = b;
-      b = t;
+  const bool four = fold >= 2 && IsFoldedFour(c, par, n, root, cc);
+  const bool fork = fold >= 1 && IsFork(c, n, root, cc), cat = four && IsCaterpillar(c, n, root, cc);
+  if (fork || cat) {
+    const int tip = a < n ? a : b, rest = a < n ? b : a;  // (the tip first)
+    a = tip;
+    b = rest;
+    const int u = c[2 * (rest - n)], v = c[2 * (rest - n) + 1];
+    hb = (fork || u < n) ? u : v;
+    hc = (fork || u < n) ? v : u;
+    if (cat) {
+      x = c[2 * (hc - n)];
+      y = c[2 * (hc - n) + 1];
     }
-    hb = c[2 * (b - n)];
-    hc = c[2 * (b - n) + 1];
+  } else if (four) {  // twin cherries
+    hb = c[2 * (a - n)];
+    hc = c[2 * (a - n) + 1];
+    x = c[2 * (b - n)];
+    y = c[2 * (b - n) + 1];
   }
 }
 __device__ __forceinline__ void WriteStep(int32_t* __restrict__ out, int k, int n, int root, int fold, int node, int next, int c0, int c1,
-                                          const int32_t* __restrict__ c) {
-  int4 lo, mid, hi;
+                                          const int32_t* __restrict__ c, const int32_t* __restrict__ par) {
+  // (a folded four-tip child goes into the first slot -- there is at most one: the walk has its code there alone, and its
+  // pre-order part parks a vector in the hand-over column, which a stored child that is processed next writes after it)
+  if (fold >= 2 && IsFoldedFour(c, par, n, root, c1)) {
+    const int t = c0;
+    c0 = c1;
+    c1 = t;
+  }
+  int4 lo, mid, hi, ex;
   lo.x = node; lo.y = c0; lo.z = c1; lo.w = next;
-  ChildInfo(c, n, root, fold, c0, mid.x, mid.y, hi.x, hi.y);
-  ChildInfo(c, n, root, fold, c1, mid.z, mid.w, hi.z, hi.w);
+  ChildInfo(c, par, n, root, fold, c0, mid.x, mid.y, hi.x, hi.y, ex.x, ex.y);
+  ChildInfo(c, par, n, root, fold, c1, mid.z, mid.w, hi.z, hi.w, ex.z, ex.w);
   int4* rec = reinterpret_cast<int4*>(out + (size_t)(1 + k) * kStepInts);
+  // (a four-tip child is told by its third id, written as -2 - id: the walk reads the record's last quarter only in
+  // the steps that have one)
+  if (ex.x >= 0) hi.x = -2 - hi.x;
+  if (ex.z >= 0) hi.z = -2 - hi.z;
   rec[0] = lo;
   rec[1] = mid;
   rec[2] = hi;
+  rec[3] = ex;
 }
 
 __global__ void __launch_bounds__(64)
@@ -147,10 +204,12 @@ hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __r
   int32_t* __restrict__ out = order + (size_t)blockIdx.x * (NI + 1) * kStepInts;
   if (!in_lds) {
     if (lane == 0) {
+      // (a tree too large for the tables: id order, and no four-tip folding -- that rule asks for a node's parent)
+      const int f = min(fold, 1);
       int k = 0, prev = -1;
       for (int v = 0; v < NI; v++) {
-        if (IsCherry(ch, n, root, n + v) || (fold && IsFork(ch, n, root, n + v))) continue;
-        WriteStep(out, k++, n, root, fold, n + v, prev, ch[2 * v], ch[2 * v + 1], ch);
+        if (IsUnstored(ch, nullptr, n, root, f, n + v)) continue;
+        WriteStep(out, k++, n, root, f, n + v, prev, ch[2 * v], ch[2 * v + 1], ch, nullptr);
         prev = n + v;
       }
       out[0] = k;
@@ -162,8 +221,12 @@ hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __r
   int32_t* need = size + NI;     // pending vectors the subtree's walk needs at once
   int32_t* start = need + NI;    // position of the subtree's first step
   int32_t* at = start + NI;      // node of step k
-  int8_t* flip = reinterpret_cast<int8_t*>(at + NI);  // child 1's subtree is visited first
+  int32_t* par = at + NI;        // [n + NI] parent by node id
+  int8_t* flip = reinterpret_cast<int8_t*>(par + n + NI);  // child 1's subtree is visited first
   for (int i = lane; i < 2 * NI; i += 64) c[i] = ch[i];
+  __syncthreads();
+  for (int i = lane; i < 2 * NI; i += 64) par[c[i]] = n + (i >> 1);
+  if (lane == 0) par[root] = -1;
   __syncthreads();
   if (lane == 0) {
     for (int v = 0; v < NI; v++) {  // ids ascend from the tips to the root
@@ -171,7 +234,7 @@ hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __r
       const int s0 = c0 >= n ? size[c0 - n] : 0, s1 = c1 >= n ? size[c1 - n] : 0;
       const int a = s0 ? need[c0 - n] : 0, b = s1 ? need[c1 - n] : 0;
       flip[v] = b > a;  // the heavier subtree first (ties: id order)
-      if (IsCherry(c, n, root, n + v) || (fold && IsFork(c, n, root, n + v))) {
+      if (IsUnstored(c, par, n, root, fold, n + v)) {
         size[v] = 0;
         need[v] = 0;
       } else {
@@ -197,16 +260,19 @@ hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __r
   const int steps = size[NI - 1];
   for (int k = lane; k < steps; k += 64) {
     const int node = at[k];
-    WriteStep(out, k, n, root, fold, node, k > 0 ? at[k - 1] : -1, c[2 * (node - n)], c[2 * (node - n) + 1], c);
+    WriteStep(out, k, n, root, fold, node, k > 0 ? at[k - 1] : -1, c[2 * (node - n)], c[2 * (node - n) + 1], c, par);
   }
 }
 
-inline size_t HbmOrderLdsBytes(const BatchDims& d) { return (size_t)(d.taxon_count - 1) * (6 * sizeof(int32_t) + 1) + 16; }
+inline size_t HbmOrderLdsBytes(const BatchDims& d) {
+  return (size_t)(d.taxon_count - 1) * (6 * sizeof(int32_t) + 1) + (size_t)(2 * d.taxon_count - 1) * sizeof(int32_t) + 16;
+}
 size_t HbmOrderInts(const BatchDims& d) { return (size_t)d.tree_count * d.taxon_count * kStepInts; }
 
-// BITO_AMD_HBM_FOLD=0: a step and a cell for every pitchfork
+// BITO_AMD_HBM_FOLD: 0 a step and a cell for every pitchfork; 1 pitchforks rebuilt where they are used (round 4); 2 (the
+// default since round 6) four-tip subtrees as well
 static int HbmFolds() {
-  static const int v = [] { const char* e = getenv("BITO_AMD_HBM_FOLD"); return e ? atoi(e) != 0 : 1; }();
+  static const int v = [] { const char* e = getenv("BITO_AMD_HBM_FOLD"); return e ? std::max(0, std::min(2, atoi(e))) : 2; }();
   return v;
 }
 
@@ -358,30 +424,41 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   const unsigned node_bytes = (unsigned)C * 4 * kCatTile * 8, mat_bytes = (unsigned)C * kMatHot * 8;
   const unsigned ulane = lane;
   struct Child {
-    int kind;  // 0 tip, 1 stored internal node, 2 cherry, 3 pitchfork
-    int a, b;  // its children (a pitchfork: its tip, then its cherry)
-    int hb, hc;  // a pitchfork's cherry's tips
-    int s, sb, sc;  // states: the tip's own | a cherry's two tips' | a pitchfork's tip's and its cherry's two
+    int kind;  // 0 tip, 1 stored internal node, 2 cherry, 3 pitchfork, 4 caterpillar, 5 twin cherries
+    int a, b;  // its children (a pitchfork, a caterpillar: its tip, then the rest)
+    int hb, hc;  // a pitchfork's cherry's tips | a caterpillar's pitchfork's tip and cherry | the first twin's tips
+    int st;  // states, a byte each: the tip's own | a cherry's two tips' | a pitchfork's tip's and its cherry's two
   };
-  // (a, b, hb, hc: out of the step's record)
+  auto tip_state = [&](int tip) { return (int)__builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)tip * Ppad, 0); };
+  // (a, b, hb, hc: out of the step's record; a four-tip subtree has hb < -1, and its last two ids and its states are
+  // fetched where its rows are -- one child in ten is one, and whatever every step carried for them would cost the walk
+  // registers it does not have at seven waves per SIMD)
   auto classify = [&](int cc, int a, int b, int hb, int hc) {
-    Child ci{0, a, b, hb, hc, 0, 0, 0};
+    Child ci{0, a, b, hb, hc, 0};
     if (cc < n) {
-      ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)cc * Ppad, 0);
+      ci.st = tip_state(cc);
+    } else if (hb < -1) {
+      ci.kind = a < n ? 4 : 5;
+      ci.hb = -2 - hb;
     } else if (hb >= 0) {
       ci.kind = 3;
-      ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)a * Ppad, 0);
-      ci.sb = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)hb * Ppad, 0);
-      ci.sc = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)hc * Ppad, 0);
+      ci.st = tip_state(a) | (tip_state(hb) << 8) | (tip_state(hc) << 16);
     } else if (a < n && b < n) {
       ci.kind = 2;
-      ci.s = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)a * Ppad, 0);
-      ci.sb = __builtin_amdgcn_raw_buffer_load_b8(tips, ulane, (unsigned)b * Ppad, 0);
+      ci.st = tip_state(a) | (tip_state(b) << 8);
     } else {
       ci.kind = 1;
     }
     return ci;
   };
+  int step_k = 0;  // the step at hand (its record's last quarter: a four-tip child's last two ids)
+  auto last_ids = [&](int& x, int& y) {  // (of the first slot's child: the only one that can be a four-tip subtree)
+    const int4 four = ord[7 + 4 * step_k];
+    x = __builtin_amdgcn_readfirstlane(four.x);
+    y = __builtin_amdgcn_readfirstlane(four.y);
+  };
+  const std::true_type kFirst{};
+  const std::false_type kSecond{};
   // Two thread-private LDS columns of four doubles.  Pre-order: `fwd` hands a vector to the step that follows
   // immediately (the partial of the child that is processed next) and `pend` keeps ONE vector that is needed later -- the
   // partial of the child that is NOT processed next -- until its reader comes, unless a younger such vector takes the
@@ -390,8 +467,17 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   // vectors that are needed later: the partial of a node whose parent is not the next step (also stored in the arena:
   // the pre-order pass reads it there), the oldest giving way.  Hits save the arena round trip of most of those vectors
   // (hbm_order_kernel's order is chosen for it).
-  double* __restrict__ fwd = lds + 4 * tid;
-  double* __restrict__ pend = lds + 4 * threads + 4 * tid;
+  // (the columns' addresses are formed where a column is touched, from the thread's id through an empty asm the compiler
+  // cannot look through: held in two registers from the kernel's start to its end they were the first values it
+  // spilled to scratch once the four-tip steps were in the loop -- round 6)
+  // (the thread's id is put together again from the wave's number and the lane: no register holds it through the loops)
+  auto Tid = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return (c << 6) + l;
+  };
+  auto Fwd = [&]() -> double* { return lds + 4 * Tid(); };
+  auto Pend = [&]() -> double* { return lds + 4 * threads + 4 * Tid(); };
   int pend_owner = -1;  // node whose vector `pend` holds (wave-uniform)
   int fwd_owner = -1;   // post-order only: node whose vector `fwd` holds
   bool fwd_younger = false;  // post-order, both columns taken: `fwd` holds the younger vector
@@ -402,30 +488,68 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     asm volatile("" : "+v"(state));
     BufLoadRow(matrows, (unsigned)(kMatPT * 8) + (unsigned)state * 32, (unsigned)node * mat_bytes, out);
   };
-  auto fetch = [&](const Child& ci, int cc, double x[4]) {
+  auto fetch = [&](const Child& ci, int cc, auto first, double x[4]) {
     if (ci.kind == 2) {
       double ra[4], rb[4];
-      tip_row(ci.a, ci.s, ra);
-      tip_row(ci.b, ci.sb, rb);
+      tip_row(ci.a, ci.st & 255, ra);
+      tip_row(ci.b, (ci.st >> 8) & 255, rb);
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = ra[i] * rb[i];
     } else if (ci.kind == 3) {  // a pitchfork's partial: a_tip . P_H (a_b . a_c)
       double ra[4], rb[4];
-      tip_row(ci.hb, ci.sb, ra);
-      tip_row(ci.hc, ci.sc, rb);
+      tip_row(ci.hb, (ci.st >> 8) & 255, ra);
+      tip_row(ci.hc, ci.st >> 16, rb);
 #pragma unroll
       for (int i = 0; i < 4; i++) ra[i] *= rb[i];
       MatVec(mats + ci.b * node_mat + kMatP, ra, rb);
-      tip_row(ci.a, ci.s, ra);
+      tip_row(ci.a, ci.st & 255, ra);
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = ra[i] * rb[i];
-    } else if (cc == pend_owner) {
+    } else if (decltype(first)::value && ci.kind == 4) {  // a caterpillar's partial: a_tip . P_F (a_b . P_H (a_c . a_d))
+      double ra[4], rb[4];
+      int tx, ty;
+      last_ids(tx, ty);
+      tip_row(tx, tip_state(tx), ra);
+      tip_row(ty, tip_state(ty), rb);
 #pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = pend[i];
+      for (int i = 0; i < 4; i++) ra[i] *= rb[i];
+      MatVec(mats + ci.hc * node_mat + kMatP, ra, rb);
+      tip_row(ci.hb, tip_state(ci.hb), ra);
+#pragma unroll
+      for (int i = 0; i < 4; i++) ra[i] *= rb[i];
+      MatVec(mats + ci.b * node_mat + kMatP, ra, rb);
+      tip_row(ci.a, tip_state(ci.a), ra);
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = ra[i] * rb[i];
+    } else if (decltype(first)::value && ci.kind == 5) {  // twin cherries: P_H1 (a_a . a_b) . P_H2 (a_c . a_d)
+      double ra[4], rb[4], m[4];
+      tip_row(ci.hb, tip_state(ci.hb), ra);
+      tip_row(ci.hc, tip_state(ci.hc), rb);
+#pragma unroll
+      for (int i = 0; i < 4; i++) ra[i] *= rb[i];
+      MatVec(mats + ci.a * node_mat + kMatP, ra, m);
+      int tx, ty;
+      last_ids(tx, ty);
+      tip_row(tx, tip_state(tx), ra);
+      tip_row(ty, tip_state(ty), rb);
+#pragma unroll
+      for (int i = 0; i < 4; i++) ra[i] *= rb[i];
+      MatVec(mats + ci.b * node_mat + kMatP, ra, rb);
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = m[i] * rb[i];
+    } else if (cc == pend_owner) {
+      {
+        double* const pend = Pend();
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = pend[i];
+      }
       pend_owner = -1;
     } else if (cc == fwd_owner) {
+      {
+        double* const fwd = Fwd();
 #pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = fwd[i];
+        for (int i = 0; i < 4; i++) x[i] = fwd[i];
+      }
       fwd_owner = -1;
     } else {
       ArenaLoad(arena, ulane, (unsigned)(cc - n) * node_bytes, x);
@@ -441,21 +565,33 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     if (into_fwd) {
       if (!GRAD && old >= 0) {
         double o[4];
+        {
+          double* const fwd = Fwd();
 #pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = fwd[i];
+          for (int i = 0; i < 4; i++) o[i] = fwd[i];
+        }
         ArenaStore(arena, ulane, (unsigned)(old - n) * node_bytes, o);
       }
+      {
+        double* const fwd = Fwd();
 #pragma unroll
-      for (int i = 0; i < 4; i++) fwd[i] = v[i];
+        for (int i = 0; i < 4; i++) fwd[i] = v[i];
+      }
     } else {
       if (!GRAD && old >= 0) {
         double o[4];
+        {
+          double* const pend = Pend();
 #pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = pend[i];
+          for (int i = 0; i < 4; i++) o[i] = pend[i];
+        }
         ArenaStore(arena, ulane, (unsigned)(old - n) * node_bytes, o);
       }
+      {
+        double* const pend = Pend();
 #pragma unroll
-      for (int i = 0; i < 4; i++) pend[i] = v[i];
+        for (int i = 0; i < 4; i++) pend[i] = v[i];
+      }
     }
     fwd_owner = into_fwd ? owner : fwd_owner;
     pend_owner = into_fwd ? pend_owner : owner;
@@ -468,7 +604,8 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
   double dd[4];
   int last = -1;
   for (int k = 0; k < steps; ++k) {
-    const int4 rec = ord[3 + 3 * k], sub = ord[4 + 3 * k], fork = ord[5 + 3 * k];
+    const int4 rec = ord[4 + 4 * k], sub = ord[5 + 4 * k], fork = ord[6 + 4 * k];
+    step_k = k;
     const int node = __builtin_amdgcn_readfirstlane(rec.x);
     const int c0 = __builtin_amdgcn_readfirstlane(rec.y), c1 = __builtin_amdgcn_readfirstlane(rec.z);
     const Child k0 = classify(c0, __builtin_amdgcn_readfirstlane(sub.x), __builtin_amdgcn_readfirstlane(sub.y),
@@ -482,26 +619,26 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     const double* m0 = mats + c0 * node_mat;
     const double* m1 = mats + c1 * node_mat;
     if (k0.kind == 0) {
-      tip_row(c0, k0.s, A);
+      tip_row(c0, k0.st, A);
     } else {
       double x[4];
       if (c0 == last) {
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] = dd[i];
       } else {
-        fetch(k0, c0, x);
+        fetch(k0, c0, kFirst, x);
       }
       MatVec(m0 + kMatP, x, A);
     }
     if (k1.kind == 0) {
-      tip_row(c1, k1.s, B);
+      tip_row(c1, k1.st, B);
     } else {
       double x[4];
       if (c1 == last) {
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] = dd[i];
       } else {
-        fetch(k1, c1, x);
+        fetch(k1, c1, kSecond, x);
       }
       MatVec(m1 + kMatP, x, B);
     }
@@ -550,6 +687,10 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     const int shift = RESCALE ? 0 : min(-__builtin_amdgcn_frexp_exp(total), 1000);
     const double gw = RESCALE ? weight * (mine / total) * rate
                               : weight * (tm->cat_weight[c] / __builtin_amdgcn_ldexp(total, shift)) * rate;
+    // (gw waits in the thread's slot of `terms`, free since the categories met: read once per step, it is two registers
+    // the walk does not carry through its longest stretches)
+    __syncthreads();  // (every wave has read the categories' terms)
+    terms[Tid()] = gw;
     double* __restrict__ my_row = part_grad + (((size_t)tree * tile_count + tile_id) * C + c) * N;
     const double* __restrict__ Q = tm->Q;
     bool u_forwarded = false;
@@ -557,24 +698,28 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     // frequencies -- waits for the first step in the column like any pending vector
     fwd_owner = -1;
     pend_owner = N - 1;
+    {
+      double* const pend = Pend();
 #pragma unroll
-    for (int i = 0; i < 4; i++) pend[i] = __builtin_amdgcn_ldexp(tm->pi[i], shift);
+      for (int i = 0; i < 4; i++) pend[i] = __builtin_amdgcn_ldexp(tm->pi[i], shift);
+    }
     // message of a child: tip -> its row of P^T; stored -> P x; cherry -> P (a_a . a_b)
-    auto message = [&](const Child& ci, int cc, double A[4]) {
+    auto message = [&](const Child& ci, int cc, auto first, double A[4]) {
       const double* m = mats + cc * node_mat;
       if (ci.kind == 0) {
-        tip_row(cc, ci.s, A);
+        tip_row(cc, ci.st, A);
       } else {
         double x[4];
-        fetch(ci, cc, x);
+        fetch(ci, cc, first, x);
         MatVec(m + kMatP, x, A);
       }
     };
     // the two tip edges of a cherry child whose pre-order partial is q
-    auto cherry_edges = [&](int ta, int state_a, int tb, int state_b, const double q[4], double rden) {
+    // (states travel packed, a byte each, and are taken apart where a row is asked for: one register, not one per tip)
+    auto cherry_edges = [&](int ta, int tb, int states, const double q[4], double rden) {
       double aa[4], ab[4], qa[4];
-      tip_row(ta, state_a, aa);
-      tip_row(tb, state_b, ab);
+      tip_row(ta, states & 255, aa);
+      tip_row(tb, (states >> 8) & 255, ab);
       MatVec(Q, aa, qa);
       double sa = 0.0, sb = 0.0;
 #pragma unroll
@@ -591,64 +736,169 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       MatVec(Q, A, qa);
       return (UAs[0] * qa[0] + UAs[1] * qa[1] + UAs[2] * qa[2] + UAs[3] * qa[3]) * rden;
     };
+    // a pitchfork whose pre-order partial is q: tip ta and cherry H (tips tb, tc) under it.  With a_a the tip's row and
+    // m = P_H (a_b . a_c):
+    //   edge of a:  sum_i (q . m)_i (Q a_a)_i      edge of H:  sum_i (q . a_a)_i (Q m)_i      partial of H:  P_H^T (q . a_a)
+    auto fork_edges = [&](int ta, int H, int tb, int tc, int states, const double q[4], double rden) {
+      double ra[4], m[4], t[4];
+      {
+        double rb[4];
+        tip_row(tb, (states >> 8) & 255, t);
+        tip_row(tc, states >> 16, rb);
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] *= rb[i];
+      }
+      MatVec(mats + H * node_mat + kMatP, t, m);
+      tip_row(ta, states & 255, ra);
+      MatVec(Q, ra, t);
+      double ea = 0.0, eh = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) ea += (q[i] * m[i]) * t[i];
+      MatVec(Q, m, t);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        ra[i] *= q[i];  // q . a_a
+        eh += ra[i] * t[i];
+      }
+      const double g = PairSum(ea * rden, eh * rden);
+      if ((lane & 31) == 31) my_row[lane < 32 ? ta : H] = g;
+      MatVecT(mats + H * node_mat + kMatP, ra, t);
+      cherry_edges(tb, tc, states >> 8, t, rden);
+    };
     // an internal child's pre-order partial P^T (u . a_sibling): stored in place (the child's cell held its
     // post-order partial, read for this step's message), handed to the next step through the thread's LDS
     // column when the child is processed next, or consumed here by a cherry's two tip edges
-    auto pre_part = [&](const Child& ci, int cc, const double UAs[4], double rden, bool forward) {
+    auto pre_part = [&](const Child& ci, int cc, auto first, const double UAs[4], double rden, bool forward) {
       if (ci.kind == 0) return;
       double q[4];
       MatVecT(mats + cc * node_mat + kMatP, UAs, q);
       if (ci.kind == 2) {
-        cherry_edges(ci.a, ci.s, ci.b, ci.sb, q, rden);
+        cherry_edges(ci.a, ci.b, ci.st, q, rden);
         return;
       }
       if (ci.kind == 3) {
-        // pitchfork: tip a and cherry H = ci.b (tips hb, hc) under cc.  With a_a the tip's row and m = P_H (a_b . a_c):
-        //   edge of a:  sum_i (q . m)_i (Q a_a)_i      edge of H:  sum_i (q . a_a)_i (Q m)_i      partial of H:  P_H^T (q . a_a)
+        fork_edges(ci.a, ci.b, ci.hb, ci.hc, ci.st, q, rden);
+        return;
+      }
+      if (decltype(first)::value && ci.kind == 4) {
+        // caterpillar: tip a and pitchfork F = ci.b (tip ci.hb, cherry H = ci.hc with tips x, y) under cc.  With a_a the
+        // tip's row and m = P_F (a_b . P_H (a_c . a_d)):
+        //   edge of a:  sum_i (q . m)_i (Q a_a)_i      edge of F:  sum_i (q . a_a)_i (Q m)_i      partial of F:  P_F^T (q . a_a)
+        // and below F the pitchfork's own part (which rebuilds H's message: nothing is kept across the two levels)
         double ra[4], m[4], t[4];
+        int tx, ty;
+        last_ids(tx, ty);
         {
           double rb[4];
-          tip_row(ci.hb, ci.sb, t);
-          tip_row(ci.hc, ci.sc, rb);
+          tip_row(tx, tip_state(tx), t);
+          tip_row(ty, tip_state(ty), rb);
+#pragma unroll
+          for (int i = 0; i < 4; i++) t[i] *= rb[i];
+          MatVec(mats + ci.hc * node_mat + kMatP, t, rb);
+          tip_row(ci.hb, tip_state(ci.hb), t);
 #pragma unroll
           for (int i = 0; i < 4; i++) t[i] *= rb[i];
         }
         MatVec(mats + ci.b * node_mat + kMatP, t, m);
-        tip_row(ci.a, ci.s, ra);
+        tip_row(ci.a, tip_state(ci.a), ra);
         MatVec(Q, ra, t);
-        double ea = 0.0, eh = 0.0;
+        double ea = 0.0, ef = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; i++) ea += (q[i] * m[i]) * t[i];
         MatVec(Q, m, t);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           ra[i] *= q[i];  // q . a_a
-          eh += ra[i] * t[i];
+          ef += ra[i] * t[i];
         }
-        const double g = PairSum(ea * rden, eh * rden);
+        const double g = PairSum(ea * rden, ef * rden);
         if ((lane & 31) == 31) my_row[lane < 32 ? ci.a : ci.b] = g;
         MatVecT(mats + ci.b * node_mat + kMatP, ra, t);
-        cherry_edges(ci.hb, ci.sb, ci.hc, ci.sc, t, rden);
+        __builtin_amdgcn_sched_barrier(0);
+        fork_edges(ci.hb, ci.hc, tx, ty, tip_state(ci.hb) | (tip_state(tx) << 8) | (tip_state(ty) << 16), t, rden);
+        return;
+      }
+      if (decltype(first)::value && ci.kind == 5) {
+        // twin cherries H1 = ci.a (tips hb, hc) and H2 = ci.b (tips x, y) under cc.  With m_k = P_Hk (the cherry's rows):
+        //   edge of H1:  sum_i (q . m2)_i (Q m1)_i      edge of H2:  sum_i (q . m1)_i (Q m2)_i
+        //   partial of H1:  P_H1^T (q . m2)             partial of H2:  P_H2^T (q . m1)
+        double m1[4], m2[4], t[4];
+        int tx, ty;
+        last_ids(tx, ty);
+        {
+          double rb[4];
+          tip_row(ci.hb, tip_state(ci.hb), t);
+          tip_row(ci.hc, tip_state(ci.hc), rb);
+#pragma unroll
+          for (int i = 0; i < 4; i++) t[i] *= rb[i];
+          MatVec(mats + ci.a * node_mat + kMatP, t, m1);
+          tip_row(tx, tip_state(tx), t);
+          tip_row(ty, tip_state(ty), rb);
+#pragma unroll
+          for (int i = 0; i < 4; i++) t[i] *= rb[i];
+          MatVec(mats + ci.b * node_mat + kMatP, t, m2);
+        }
+        MatVec(Q, m1, t);
+        double e1 = 0.0, e2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) e1 += (q[i] * m2[i]) * t[i];
+        MatVec(Q, m2, t);
+#pragma unroll
+        for (int i = 0; i < 4; i++) e2 += (q[i] * m1[i]) * t[i];
+        const double g = PairSum(e1 * rden, e2 * rden);
+        if ((lane & 31) == 31) my_row[lane < 32 ? ci.a : ci.b] = g;
+        // (q . m1, what H2's partial is made from, waits in the hand-over column while H1's tips take their edges: the
+        // column is free here -- hbm_order_kernel puts a four-tip child in front of a stored one -- and with it the
+        // step has no more vectors live at a time than a cherry child's)
+        {
+          double* const fwd = Fwd();
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            fwd[i] = q[i] * m1[i];
+            m2[i] *= q[i];  // q . m2: what H1's partial is made from
+          }
+        }
+        MatVecT(mats + ci.a * node_mat + kMatP, m2, t);
+        __builtin_amdgcn_sched_barrier(0);
+        cherry_edges(ci.hb, ci.hc, tip_state(ci.hb) | (tip_state(ci.hc) << 8), t, rden);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          double* const fwd = Fwd();
+#pragma unroll
+          for (int i = 0; i < 4; i++) m2[i] = fwd[i];
+        }
+        MatVecT(mats + ci.b * node_mat + kMatP, m2, t);
+        cherry_edges(tx, ty, tip_state(tx) | (tip_state(ty) << 8), t, rden);
         return;
       }
       if (RESCALE) { int unused = 0; ScalePow2(q, unused); }
       if (forward) {
+        {
+          double* const fwd = Fwd();
 #pragma unroll
-        for (int i = 0; i < 4; i++) fwd[i] = q[i];
+          for (int i = 0; i < 4; i++) fwd[i] = q[i];
+        }
         return;
       }
       if (pend_owner >= 0) {  // an older vector waits in the column: it moves to its cell in the arena
         double o[4];
+        {
+          double* const pend = Pend();
 #pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = pend[i];
+          for (int i = 0; i < 4; i++) o[i] = pend[i];
+        }
         ArenaStore(arena, ulane, (unsigned)(pend_owner - n) * node_bytes, o);
       }
+      {
+        double* const pend = Pend();
 #pragma unroll
-      for (int i = 0; i < 4; i++) pend[i] = q[i];
+        for (int i = 0; i < 4; i++) pend[i] = q[i];
+      }
       pend_owner = cc;
     };
     for (int k = steps - 1; k >= 0; --k) {
-      const int4 rec = ord[3 + 3 * k], sub = ord[4 + 3 * k], fork = ord[5 + 3 * k];
+      const int4 rec = ord[4 + 4 * k], sub = ord[5 + 4 * k], fork = ord[6 + 4 * k];
+      step_k = k;
       const int node = __builtin_amdgcn_readfirstlane(rec.x);
       const int c0 = __builtin_amdgcn_readfirstlane(rec.y), c1 = __builtin_amdgcn_readfirstlane(rec.z);
       const int next = __builtin_amdgcn_readfirstlane(rec.w);  // the step that follows
@@ -658,17 +908,23 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
                                 __builtin_amdgcn_readfirstlane(fork.z), __builtin_amdgcn_readfirstlane(fork.w));
       double U[4], A0[4], A1[4];
       if (u_forwarded) {
+        {
+          double* const fwd = Fwd();
 #pragma unroll
-        for (int i = 0; i < 4; i++) U[i] = fwd[i];
+          for (int i = 0; i < 4; i++) U[i] = fwd[i];
+        }
       } else if (node == pend_owner) {
+        {
+          double* const pend = Pend();
 #pragma unroll
-        for (int i = 0; i < 4; i++) U[i] = pend[i];
+          for (int i = 0; i < 4; i++) U[i] = pend[i];
+        }
         pend_owner = -1;
       } else {
         ArenaLoad(arena, ulane, (unsigned)(node - n) * node_bytes, U);
       }
-      message(k0, c0, A0);
-      message(k1, c1, A1);
+      message(k0, c0, kFirst, A0);
+      message(k1, c1, kSecond, A1);
       const bool fwd0 = k0.kind == 1 && c0 == next;
       const bool fwd1 = k1.kind == 1 && c1 == next;
       double UA1[4], UA0[4];
@@ -681,13 +937,13 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       // has underflowed (large tree, short branches: the slow categories go first) contributes its zero instead
       // of 0/0, while a pattern whose likelihood is zero still turns the tree's derivatives non-finite as the
       // reference's do.
-      double rden = gw;
+      double rden = terms[Tid()];  // = gw (parked above the loop)
       if (RESCALE) {
         const double den = UA1[0] * A0[0] + UA1[1] * A0[1] + UA1[2] * A0[2] + UA1[3] * A0[3];
         double r = __builtin_amdgcn_rcp(den);
         r = fma(fma(-den, r, 1.0), r, r);
         r = fma(fma(-den, r, 1.0), r, r);
-        rden = gw * r;
+        rden = rden * r;
       }
       // both edge sums first: after them only u . a1 and u . a0 are live
       const double e0 = edge_term(A0, UA1, rden);
@@ -697,9 +953,9 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       const double g = PairSum(e0, e1);
       if ((lane & 31) == 31) my_row[lane < 32 ? c0 : c1] = g;
       __builtin_amdgcn_sched_barrier(0);
-      pre_part(k0, c0, UA1, rden, fwd0);
+      pre_part(k0, c0, kFirst, UA1, rden, fwd0);
       __builtin_amdgcn_sched_barrier(0);
-      pre_part(k1, c1, UA0, rden, fwd1);
+      pre_part(k1, c1, kSecond, UA0, rden, fwd1);
       __builtin_amdgcn_sched_barrier(0);
       u_forwarded = fwd0 || fwd1;
     }

@@ -35,17 +35,41 @@ def children_of(parent_ids, n):
     return ch
 
 
-def unstored_nodes(ch, n, fold):
-    """cherries, and with fold the pitchforks (a tip and a cherry under one node): rebuilt where they are used"""
+def shapes(ch, n):
+    """(cherries, pitchforks, caterpillars, twins) as walk_hbm_cat.hip tells them: a pitchfork is a tip and a cherry
+    under one node, a caterpillar a tip and a pitchfork, twins two cherries; the root is none of them"""
     N = n + len(ch)
     root = N - 1
     cherry = {v for v in range(n, N) if ch[v - n, 0] < n and ch[v - n, 1] < n and v != root}
+    fork, cat, twin = set(), set(), set()
+    for v in range(n, N - 1):
+        c0, c1 = ch[v - n]
+        if (c0 < n and c1 in cherry) or (c1 < n and c0 in cherry):
+            fork.add(v)
+    for v in range(n, N - 1):
+        c0, c1 = ch[v - n]
+        if (c0 < n and c1 in fork) or (c1 < n and c0 in fork):
+            cat.add(v)
+        if c0 in cherry and c1 in cherry:
+            twin.add(v)
+    return cherry, fork, cat, twin
+
+
+def unstored_nodes(ch, n, fold):
+    """nodes without a step and a cell, rebuilt where they are used: cherries; fold >= 1 (True): pitchforks as well
+    (round 4); fold 2: and the two shapes of a four-tip subtree, caterpillars and twin cherries (round 6)"""
+    cherry, fork, cat, twin = shapes(ch, n)
     out = set(cherry)
     if fold:
-        for v in range(n, N - 1):
-            c0, c1 = ch[v - n]
-            if (c0 < n and c1 in cherry) or (c1 < n and c0 in cherry):
-                out.add(v)
+        out |= fork
+    if int(fold) >= 2:
+        # ... unless its sibling is a four-tip subtree with a lower id: a step carries ONE of them, in its first slot
+        four = cat | twin
+        for v in range(n, n + len(ch)):
+            a, b = ch[v - n]
+            if a in four and b in four:
+                four = four - {max(a, b)}
+        out |= four
     return out
 
 
@@ -166,7 +190,10 @@ def main():
             row[f"heavy d{depth}"] = kernel_traffic(ch, n, order, depth)
         row["heavy d2/1"] = kernel_traffic(ch, n, order, 2, 1)
         forder, _ = heavy_first_order(ch, n, fold=True)
-        row["fold d2/1"] = kernel_traffic(ch, n, forder, 2, 1, fold=True)  # the kernel since round 4
+        row["fold d2/1"] = kernel_traffic(ch, n, forder, 2, 1, fold=True)  # the kernel of rounds 4 and 5
+        f2order, _ = heavy_first_order(ch, n, fold=2)
+        row["fold2 d2/1"] = kernel_traffic(ch, n, f2order, 2, 1, fold=2)  # the kernel since round 6: four-tip subtrees too
+        row["stored, fold 2"] = N - n - len(unstored_nodes(ch, n, 2)) - 1
         row["fold d2"] = kernel_traffic(ch, n, forder, 2, fold=True)
         row["fold d4"] = kernel_traffic(ch, n, forder, 4, fold=True)
         row["stored, folded"] = N - n - len(unstored_nodes(ch, n, True)) - 1
@@ -174,9 +201,10 @@ def main():
         row["ids d2"] = kernel_traffic(ch, n, None, 2)
         row["ids d4"] = kernel_traffic(ch, n, None, 4)
         rows.append(row)
-    keys = [k for k in rows[0] if k not in ("stored", "max need", "stored, folded")]
+    keys = [k for k in rows[0] if k not in ("stored", "max need", "stored, folded", "stored, fold 2")]
     print(f"{n} taxa, {T} trees: stored vectors {np.mean([r['stored'] for r in rows]):.0f} "
-          f"(pitchforks folded: {np.mean([r['stored, folded'] for r in rows]):.0f}), "
+          f"(pitchforks folded: {np.mean([r['stored, folded'] for r in rows]):.0f}, four-tip subtrees too: "
+          f"{np.mean([r['stored, fold 2'] for r in rows]):.0f}), "
           f"Sethi-Ullman need max {max(r['max need'] for r in rows)}")
     for k in keys:
         a = np.array([r[k] for r in rows], dtype=float).mean(axis=0)

@@ -415,3 +415,69 @@ np.save({path!r}, np.concatenate([np.ravel(out[k]) for k in ("log_likelihood", "
         now, old = (np.load(str(tmp_path / f"{site}_{tag}.npy")) for tag in ("now", "round3"))
         assert now.shape == old.shape and now.size >= 270 and np.all(np.isfinite(now))
         assert np.array_equal(now, old), (site, float(np.abs(now - old).max()))
+
+
+@pytest.mark.parametrize("fold", [2, 1, 0])
+def test_emulated_four_tip_subtrees_rebuilt_where_they_are_used(emulated, fold):
+    """walk_hbm_cat_kernel with BITO_AMD_HBM_FOLD = 2 (round 6: caterpillars -- a tip and a pitchfork under one node -- and
+    twin cherries have no step and no cell: their partials are rebuilt from their four tips' matrix rows in the parent's
+    step, their six edges take their derivatives there), 1 (round 4: pitchforks only) and 0, on seeded random trees of 9
+    to 41 taxa that hold every case -- a four-tip child beside a tip, a cherry, a pitchfork, a stored node, another
+    four-tip child, and right under the root -- against the CPU checker: log-likelihood and gradient, with and without
+    rescaling, one and four rate categories; and the three levels agree with one another."""
+    out = run('''
+import sys
+sys.path.insert(0, os.path.join({root!r}, "scripts"))
+import sim_hbm_traffic as sim
+seen = {{"cat": 0, "twin": 0, "both four-tip": 0, "four-tip under the root": 0, "beside": set()}}
+for n, P, T, site in ((9, 70, 6, "weibull+4"), (17, 64, 6, "weibull+4"), (41, 70, 4, "weibull+4"), (24, 40, 5, "constant")):
+    w = small(n, P, T, site)
+    for t in range(T):
+        ch = sim.children_of(np.asarray(w.parent_ids[t]), n)
+        cherry, fork, cat, twin = sim.shapes(ch, n)
+        seen["cat"] += len(cat)
+        seen["twin"] += len(twin)
+        four = cat | twin
+        for v in range(n, n + len(ch)):
+            a, b = ch[v - n]
+            if a in four and b in four:
+                seen["both four-tip"] += 1
+            for x, y in ((a, b), (b, a)):
+                if x in four:
+                    seen["beside"].add("tip" if y < n else "cherry" if y in cherry else "fork" if y in fork else "four" if y in four else "stored")
+                    if v == n + len(ch) - 1:
+                        seen["four-tip under the root"] += 1
+    gpu = bito_amd.Engine(spec(w), w.patterns, w.weights)
+    gpu.set_kernel(1)  # the HBM-arena walk, whatever AUTO would take
+    cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 4)
+    for rescaling in (False, True):
+        res = gpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+        ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+        assert gpu.kernel_name().startswith("walk_hbm_cat"), gpu.kernel_name()
+        assert close(res["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL), (n, site, rescaling)
+        assert close(res["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL), (n, site, rescaling)
+        ll = gpu.log_likelihoods(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+        assert close(ll, ref["log_likelihood"], LL_ATOL, LL_RTOL)
+        np.save(os.path.join({tmp!r}, "fold%d_%d_%s_%d.npy" % ({fold}, n, site, rescaling)),
+                np.concatenate([res["log_likelihood"].ravel(), res["branch_lengths"].ravel()]))
+assert seen["cat"] >= 10 and seen["twin"] >= 5 and seen["both four-tip"] >= 1 and seen["four-tip under the root"] >= 1, seen
+assert {{"tip", "cherry", "fork", "stored", "four"}} <= seen["beside"], seen
+print("shapes", seen)
+'''.format(root=ROOT, tmp=FOLD_DIR, fold=fold), timeout=1500, BITO_AMD_HBM_FOLD=fold)
+    assert "shapes" in out
+    # the levels agree with one another (a tenth of the bars: the same arithmetic in another grouping of the steps)
+    import glob
+
+    import numpy as np
+
+    mine = sorted(glob.glob(os.path.join(FOLD_DIR, f"fold{fold}_*.npy")))
+    assert len(mine) == 8
+    for path in mine:
+        other = path.replace(f"fold{fold}_", "fold2_")
+        if fold != 2 and os.path.exists(other):
+            a, b = np.load(path), np.load(other)
+            assert np.all(np.abs(a - b) <= 1e-7 + 1e-10 * np.abs(b)), (path, float(np.abs(a - b).max()))
+
+
+FOLD_DIR = os.path.join(HERE, "hip_emu", "_build", "fold_levels")
+os.makedirs(FOLD_DIR, exist_ok=True)
