@@ -1,0 +1,41 @@
+#!/bin/bash
+# usage: scripts/gpu_round6.sh [tag]      (on the GPU box through gpurun; about 45 minutes)
+# Everything rounds 5 and 6 owe an MI355X in ONE lease, every step under its own timeout, every output kept under
+# gpurun_out/<tag>/ (a step that fails does not stop the next).  First what round 5 scripted (scripts/gpu_round5.sh: the
+# evidence run -- full -m gpu suite, smoke, the driver's bench command --, device Brent against the checker's iterates,
+# Path B scheduled and sequential, the headline's rocprofv3 profile, codon and config-4 bench lines, the eight-slot time
+# line), then round 6's changes one against the other, each a change whose purpose is speed and whose parity is held on
+# the CPU (emulated) already:
+#   * gs_matrices_kernel with a column's list of Q in registers       against  -DGS_DP_COLUMN=0 (round 3's loop)
+#   * gs_eigen_kernel (scalar pair arithmetic, v_readlane, masked zeroing): 4096 trees with a (kappa, omega) row each,
+#     kernel stats -- round 4 measured 0.94 ms per distinct model
+#   * walk_hbm_cat_kernel with four-tip subtrees rebuilt in the step  against  BITO_AMD_HBM_FOLD=1 (round 4's walk):
+#     config 4 and the 64 / 100 / 128-taxon sizes, with the FETCH_SIZE / WRITE_SIZE passes of both
+cd $GRAFT_REPO_ROOT
+T=${1:-r6}
+O=gpurun_out/$T
+mkdir -p $O
+step() { echo "=== $1 ($(date +%T))"; }
+bash scripts/gpu_round5.sh $T 2>&1 | tail -60
+step "codon: image kernel forms"
+bash scripts/build_gs_variants.sh dp_round3 "-DGS_DP_COLUMN=0" > $O/build_dp_round3.log 2>&1
+for lib in bito_amd/libbito_amd.so bito_amd/variants/dp_round3.so; do
+  name=codon_$( [ "$lib" = bito_amd/libbito_amd.so ] && echo column_lists || echo round3_loop )
+  BITO_AMD_LIB=$GRAFT_REPO_ROOT/$lib timeout 600 python3 bench.py --workload codon --steps 10 --warmup 2 --no-cpu-baseline --no-resident > $O/${name}_bench.json 2> $O/${name}_bench.err
+  tail -c 400 $O/${name}_bench.json; echo
+done
+step "codon: kernel stats, one row for all trees and a row per tree"
+cd /tmp && export TMPDIR=/tmp
+for K in 1 0; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/codon_models_${K}_stats -o s -- python3 $GRAFT_REPO_ROOT/bench.py --workload codon --distinct-models $K --steps 6 --warmup 2 --no-cpu-baseline --no-resident > $GRAFT_REPO_ROOT/$O/codon_models_${K}_stats.log 2>&1
+  grep -E "gs_eigen_kernel|gs_matrices_kernel|gs_walk_kernel|gs_model_kernel" $GRAFT_REPO_ROOT/$O/codon_models_${K}_stats/s_kernel_stats.csv | cut -c1-200
+done
+cd $GRAFT_REPO_ROOT
+step "config 4 and mid sizes: four-tip subtrees folded (default) against pitchforks only"
+for fold in 2 1; do
+  BITO_AMD_HBM_FOLD=$fold timeout 900 python3 bench.py --workload config4 --steps 6 --warmup 2 --no-cpu-baseline > $O/config4_fold${fold}_bench.json 2> $O/config4_fold${fold}_bench.err
+  tail -c 500 $O/config4_fold${fold}_bench.json; echo
+  BITO_AMD_HBM_FOLD=$fold timeout 600 python3 scripts/gpu_hbm_sizes.py 41 64 100 128 > $O/hbm_sizes_fold${fold}.log 2>&1; tail -6 $O/hbm_sizes_fold${fold}.log
+  BITO_AMD_HBM_FOLD=$fold bash scripts/profile_config4.sh $T/config4_fold${fold} > $O/profile_config4_fold${fold}.log 2>&1; tail -4 $O/profile_config4_fold${fold}.log | cut -c1-400
+done
+step "done"
