@@ -237,6 +237,12 @@ void LaunchPipeMasks(const BatchDims& d, const DeviceBatch& b, const LdsPlan& pl
 void LaunchPipePrepare(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream,
                        bool beside_traversal, int split_slots, int split_groups = 4, int split_layout = kPipePlanAuto,
                        const uint8_t* class_a = nullptr);
+// tree set-up + step tables + matrix images of a small batch in one launch (walk_pipe.hip, pipe_small_prepare_kernel):
+// LaunchSetup and LaunchPipePrepare in one, the same bits
+bool PipeSmallPrepareApplies(const BatchDims& d, const ModelSpec& spec);
+void LaunchPipeSmallPrepare(const BatchDims& d, const ModelSpec& spec, const DeviceBatch& b, const LdsPlan& plan, hipStream_t stream,
+                            int split_slots, int split_groups = 4, int split_layout = kPipePlanAuto,
+                            const uint8_t* class_a = nullptr);
 // deriv_mode 1: the edge derivatives use d r_c / d shape in place of r_c (site-model pass)
 void LaunchWalkPipe(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient, int want_site,
                     int deriv_mode, hipStream_t stream, const PipeClass& cls);

@@ -271,9 +271,10 @@ size_t HbmOrderInts(const BatchDims& d) { return (size_t)d.tree_count * d.taxon_
 
 // BITO_AMD_HBM_FOLD: 0 a step and a cell for every pitchfork; 1 pitchforks rebuilt where they are used (round 4); 2 (the
 // default since round 6) four-tip subtrees as well
+// (read at every launch of the order kernel: a process may compare the levels)
 static int HbmFolds() {
-  static const int v = [] { const char* e = getenv("BITO_AMD_HBM_FOLD"); return e ? std::max(0, std::min(2, atoi(e))) : 2; }();
-  return v;
+  const char* e = getenv("BITO_AMD_HBM_FOLD");
+  return e ? std::max(0, std::min(2, atoi(e))) : 2;
 }
 
 void LaunchHbmOrder(const BatchDims& d, const DeviceBatch& b, hipStream_t stream) {

@@ -855,7 +855,15 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
       // when the engine is idle, as it is for a caller that waits for every pass)
       const bool busy = e->one_shot ? e->one_shot == 2
                                     : (!e->serial_setup && e->last_pass_done != nullptr && hipEventQuery(e->last_pass_done) == hipErrorNotReady);
-      LaunchSetup(d, e->spec, b, want_gradient, prep, /*beside_traversal=*/busy);
+      // a small batch on an idle engine: set-up, step tables and images as ONE launch (round 6; walk_pipe.hip,
+      // pipe_small_prepare_kernel -- the same functions, the same bits; BITO_AMD_SMALL_PREPARE=0: three launches)
+      const bool fused_prepare = use_pipe && !busy && e->small_prepare && T <= 2048 && SetupReadsHostInputs(d, e->spec) &&
+                                 PipeSmallPrepareApplies(d, e->spec);
+      if (fused_prepare)
+        LaunchPipeSmallPrepare(d, e->spec, b, plan, prep, two_classes ? split.slots_a : 0, two_classes ? split.groups_a : 4,
+                               two_classes ? split.layout_a : kPipePlanAuto, class_flags);
+      else
+        LaunchSetup(d, e->spec, b, want_gradient, prep, /*beside_traversal=*/busy);
       NoteModelCache(e, b);
       // (that kernel made the device copies of the inputs: later passes wait for it.  The event is recorded behind the
       // kernels that follow on the same stream, not between the set-up and the image kernel: there the marker costs the
@@ -867,8 +875,9 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
         e->inputs_on_host = false;
       }
       if (use_pipe) {
-        LaunchPipePrepare(d, b, plan, prep, busy, two_classes ? split.slots_a : 0, two_classes ? split.groups_a : 4,
-                          two_classes ? split.layout_a : kPipePlanAuto, class_flags);
+        if (!fused_prepare)
+          LaunchPipePrepare(d, b, plan, prep, busy, two_classes ? split.slots_a : 0, two_classes ? split.groups_a : 4,
+                            two_classes ? split.layout_a : kPipePlanAuto, class_flags);
         if (build_masks) LaunchPipeMasks(d, b, plan, reinterpret_cast<uint32_t*>(e->pipe_masks.ptr), prep);
         if (build_masks_a) LaunchPipeMasks(d, b, split.plan_a, reinterpret_cast<uint32_t*>(e->pipe_masks_a.ptr), prep);
       } else {
@@ -1067,6 +1076,7 @@ int WorkerCreate(int32_t device_id, uint64_t arena_bytes, const char* substituti
   }
   if (const char* serial = std::getenv("BITO_AMD_SERIAL_SETUP")) e->serial_setup = std::atoi(serial);
   if (const char* direct = std::getenv("BITO_AMD_PIPE_DIRECT")) e->pipe_direct = std::atoi(direct) != 0;
+  if (const char* fused = std::getenv("BITO_AMD_SMALL_PREPARE")) e->small_prepare = std::atoi(fused) != 0;
   if (const char* two = std::getenv("BITO_AMD_PIPE_TWO")) e->pipe_two = std::atoi(two);
   if (const char* fold = std::getenv("BITO_AMD_PIPE_FOLD")) e->pipe_fold = std::atoi(fold);
   for (int i = 0; i < Worker::kSets; i++) {

@@ -481,3 +481,11 @@ print("shapes", seen)
 
 FOLD_DIR = os.path.join(HERE, "hip_emu", "_build", "fold_levels")
 os.makedirs(FOLD_DIR, exist_ok=True)
+
+
+def test_emulated_round6_gpu_tests_as_they_are(emulated):
+    """tests/test_round6.py -m gpu, unchanged, under emulation: small calls whose set-up, step tables and images are one
+    launch give the three-launch route's bits; the HBM-arena walk with four-tip subtrees folded against the checker at
+    41, 65 and 100 taxa."""
+    out = run_gpu_tests_emulated(["tests/test_round6.py"], timeout=2400)
+    assert "5 passed" in out, out[-600:]

@@ -1,0 +1,83 @@
+"""Round 6's changes that a device must confirm (they were built without GPU access, their parity held under tests/hip_emu:
+tests/test_engine_emulated.py runs these very functions on the emulated library).
+* small calls: tree set-up, step tables and matrix images as ONE launch (walk_pipe.hip, pipe_small_prepare_kernel) -- the
+  same functions in the same order as the three-launch route: the same bits in every result;
+* walk_hbm_cat_kernel with four-tip subtrees rebuilt where they are used (BITO_AMD_HBM_FOLD=2, the default): against the CPU
+  checker on trees that hold every neighbour case is tests/test_engine_emulated.py's (an environment variable read once per
+  process); here the default level on mid-size trees against the checker."""
+import numpy as np
+import pytest
+
+import bito_amd
+from bito_amd import workloads
+from test_engine_chunks import GRAD_ATOL, GRAD_RTOL, LL_ATOL, LL_RTOL, _close, _Env, _spec
+
+
+def small_call_results():
+    """results of small blocking calls (1 to 100 trees of 6 to 45 taxa; the same rows twice, then other rows: the model
+    of the call before copied, then set up afresh) by the fused launch and by the three-launch route"""
+    out = {}
+    for n, P, T in ((6, 24, 1), (9, 70, 7), (12, 40, 8), (27, 60, 9), (33, 50, 17), (45, 40, 5), (27, 130, 100)):
+        w = workloads.synthetic_gtr_weibull4(n, P, tree_count=T)
+        w.rescaling = False
+        for fused in (1, 0):
+            with _Env(BITO_AMD_SMALL_PREPARE=fused):
+                eng = bito_amd.Engine(_spec(w), w.patterns, w.weights)
+            for rep in range(3):
+                params = w.params if rep < 2 else workloads.other_bits(w.params, 4)
+                r = eng.gradients(w.parent_ids, w.branch_lengths, params)
+                assert eng.kernel_name() == "walk_pipe_kernel", eng.kernel_name()
+                out[(n, T, rep, fused)] = np.concatenate([r["log_likelihood"].ravel(), r["branch_lengths"].ravel()])
+            out[(n, T, "ll", fused)] = eng.log_likelihoods(w.parent_ids, w.branch_lengths, w.params)
+    return out
+
+
+@pytest.mark.gpu
+def test_small_calls_in_one_set_up_launch_give_the_three_launch_routes_bits():
+    out = small_call_results()
+    for key, value in out.items():
+        if key[3] == 1:
+            other = out[key[:3] + (0,)]
+            assert np.all(np.isfinite(value)) and np.array_equal(value, other), (key, float(np.abs(value - other).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [41, 65, 100])
+def test_hbm_walk_with_four_tip_subtrees_folded_against_the_checker(n):
+    """the HBM-arena walk at its default fold level (four-tip subtrees rebuilt in their parents' steps), 20 trees x 300
+    patterns, with and without rescaling, against the CPU checker"""
+    from oracle import oracle
+
+    w = workloads.synthetic_gtr_weibull4(n, 300, tree_count=20)
+    eng = bito_amd.Engine(_spec(w), w.patterns, w.weights)
+    eng.set_kernel(1)
+    cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
+    for rescaling in (True, False):
+        out = eng.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+        ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+        assert eng.kernel_name().startswith("walk_hbm_cat")
+        assert _close(out["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL)
+        assert _close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
+
+
+@pytest.mark.gpu
+def test_hbm_walk_fold_levels_agree():
+    """BITO_AMD_HBM_FOLD = 2 (four-tip subtrees rebuilt in the step), 1 (pitchforks only, round 4) and 0 on the same 24
+    trees of 64 taxa: the same arithmetic in another grouping of the steps -- without rescaling the same bits, with it
+    (a folded node's power-of-two rescaling is skipped) a tenth of the bars"""
+    w = workloads.synthetic_gtr_weibull4(64, 200, tree_count=24)
+    res = {}
+    for fold in (2, 1, 0):
+        with _Env(BITO_AMD_HBM_FOLD=fold):
+            eng = bito_amd.Engine(_spec(w), w.patterns, w.weights)
+            eng.set_kernel(1)
+            for rescaling in (False, True):
+                out = eng.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+                assert eng.kernel_name().startswith("walk_hbm_cat")
+                res[(fold, rescaling)] = (out["log_likelihood"].copy(), out["branch_lengths"].copy())
+    for fold in (1, 0):
+        assert np.array_equal(res[(2, False)][0], res[(fold, False)][0]) and np.array_equal(res[(2, False)][1], res[(fold, False)][1])
+        assert _close(res[(2, True)][0], res[(fold, True)][0], 0.1 * LL_ATOL, 0.1 * LL_RTOL)
+        assert _close(res[(2, True)][1], res[(fold, True)][1], 0.1 * GRAD_ATOL, 0.1 * GRAD_RTOL)
+    # (the levels really differ in what they fold: the rescaled gradients carry another rounding)
+    assert not np.array_equal(res[(2, True)][1], res[(1, True)][1]) and not np.array_equal(res[(1, True)][1], res[(0, True)][1])
