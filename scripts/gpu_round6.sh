@@ -11,6 +11,7 @@
 #     kernel stats -- round 4 measured 0.94 ms per distinct model
 #   * walk_hbm_cat_kernel with four-tip subtrees rebuilt in the step  against  BITO_AMD_HBM_FOLD=1 (round 4's walk):
 #     config 4 and the 64 / 100 / 128-taxon sizes, with the FETCH_SIZE / WRITE_SIZE passes of both
+#   * small calls with set-up, step tables and images as one launch     against  BITO_AMD_SMALL_PREPARE=0 (three launches)
 cd $GRAFT_REPO_ROOT
 T=${1:-r6}
 O=gpurun_out/$T
@@ -37,5 +38,17 @@ for fold in 2 1; do
   tail -c 500 $O/config4_fold${fold}_bench.json; echo
   BITO_AMD_HBM_FOLD=$fold timeout 600 python3 scripts/gpu_hbm_sizes.py 41 64 100 128 > $O/hbm_sizes_fold${fold}.log 2>&1; tail -6 $O/hbm_sizes_fold${fold}.log
   BITO_AMD_HBM_FOLD=$fold bash scripts/profile_config4.sh $T/config4_fold${fold} > $O/profile_config4_fold${fold}.log 2>&1; tail -4 $O/profile_config4_fold${fold}.log | cut -c1-400
+done
+step "small calls: one set-up launch (default) against three"
+for fused in 1 0; do
+  BITO_AMD_SMALL_PREPARE=$fused timeout 600 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --large-batch 0 > $O/small_calls_prepare${fused}_bench.json 2> $O/small_calls_prepare${fused}_bench.err
+  python3 - <<PY
+import json
+try:
+    j = json.loads(open("$O/small_calls_prepare${fused}_bench.json").read().strip().splitlines()[-1])
+    print("BITO_AMD_SMALL_PREPARE=$fused", "value %.0f trees/s" % j["value"], "blocking_call_ms", j["blocking_call_ms"]["trees_per_call"], "cache hit", j["blocking_call_ms"]["trees_per_call_model_cache_hit"])
+except Exception as err:
+    print("no line:", err)
+PY
 done
 step "done"
