@@ -72,6 +72,7 @@ struct bito_amd_gp_engine {
   double* scratch = nullptr;
   double *diff = nullptr, *coef = nullptr;  // DAGBranchHandler differences_; per-pattern optimiser coefficients
   int method = 0, significant_digits = 10, optimization_count = 0;
+  int opt_waves = 4;  // waves per optimiser workgroup of the scheduled launches (BITO_AMD_GP_OPT_WAVES: 4 or 16)
   int* counts = nullptr;
   bito_amd_gp_op* d_ops = nullptr;
   uint64_t* d_side = nullptr;
@@ -347,13 +348,18 @@ constexpr int kOptMaxIter = 1000;
 // cross-wave sum as much as the arithmetic.  Measured on the DS1 ten-tree DAG (bench.py --workload gp, 118 optimised edges
 // of 934 patterns per sweep): four waves 4.98 ms per sweep (42 us per edge), sixteen waves -- one pattern per thread --
 // 7.22 ms.
-constexpr int kOptWaves = 4, kOptThreads = 64 * kOptWaves;
+// Round 6: the number of waves is the LAUNCH's (blockDim.x / 64; scratch sized for sixteen).  Four is the default and the
+// only form a device has timed.  Sixteen -- a pattern per thread at DS1's size -- lost in round 4, when an evaluation was
+// two barriers and three cross-wave sums; since round 5 Brent's trial points are one barrier and one sum, and what that
+// changes only a device can say: BITO_AMD_GP_OPT_WAVES=16 (read when the engine is created) for scripts/gpu_round6.sh.
+// (The wave count is part of the summation order: other counts give other last bits, each held to the checker's bars.)
+constexpr int kOptWaves = 4, kOptThreads = 64 * kOptWaves, kOptMaxWaves = 16;
 
 struct EdgeFunction {
   const double* A;
   const double* B;
   const double* weights;
-  double* sh;  // [2][3][kOptWaves] block-reduction scratch in LDS, the two halves used by alternate evaluations
+  double* sh;  // [2][3][kOptMaxWaves] block-reduction scratch in LDS, the two halves used by alternate evaluations
   double resc;
   int P;
   // diagnostics: the optimiser's evaluations are recorded when a trace buffer is set
@@ -379,15 +385,16 @@ struct EdgeFunction {
       a2 += w * ((dd * l - d * d) / (l * l));
     }
     double v[3] = {a0, a1, a2};
-    double* const buf = sh + (phase++ & 1) * 3 * kOptWaves;
+    const int waves = (int)(blockDim.x >> 6);
+    double* const buf = sh + (phase++ & 1) * 3 * kOptMaxWaves;
     for (int k = 0; k < 3; k++) {
       for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
-      if ((threadIdx.x & 63) == 0) buf[k * kOptWaves + (threadIdx.x >> 6)] = v[k];
+      if ((threadIdx.x & 63) == 0) buf[k * kOptMaxWaves + (threadIdx.x >> 6)] = v[k];
     }
     __syncthreads();
     double total[3] = {0, 0, 0};
     for (int k = 0; k < 3; k++)
-      for (int w = 0; w < kOptWaves; w++) total[k] += buf[k * kOptWaves + w];  // (fixed order: every thread the same bits)
+      for (int w = 0; w < waves; w++) total[k] += buf[k * kOptMaxWaves + w];  // (fixed order: every thread the same bits)
     out[0] = total[0] + resc;
     out[1] = total[1];
     out[2] = total[2];
@@ -399,12 +406,13 @@ struct EdgeFunction {
     const double e = exp(kLam * t);
     double a0 = 0;
     for (int p = threadIdx.x; p < P; p += blockDim.x) a0 += weights[p] * log(fma(B[p], e, A[p]));
-    double* const buf = sh + (phase++ & 1) * 3 * kOptWaves;
+    const int waves = (int)(blockDim.x >> 6);
+    double* const buf = sh + (phase++ & 1) * 3 * kOptMaxWaves;
     for (int o = 32; o > 0; o >>= 1) a0 += __shfl_xor(a0, o);
     if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = a0;
     __syncthreads();
     double total = 0;
-    for (int w = 0; w < kOptWaves; w++) total += buf[w];
+    for (int w = 0; w < waves; w++) total += buf[w];
     return total + resc;
   }
   // brent_nongrad_func: x is the LOG branch length.  kind (trace only): 0 the handler's evaluation of the current
@@ -501,7 +509,7 @@ __device__ void BrentMinimize(EdgeFunction& f, bool with_gradients, double guess
   *fx_out = fx;
 }
 
-// The whole optimisation of one edge by one workgroup of kOptThreads threads; sh[2][3 kOptWaves] and sh_resc[kOptWaves] are LDS scratch,
+// The whole optimisation of one edge by one workgroup (four waves, or what the launch has); sh[2][3 kOptMaxWaves] and sh_resc[kOptMaxWaves] are LDS scratch,
 // coef holds 2 * Ppad doubles private to the workgroup.
 __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict__ plv, const int* __restrict__ counts,
                              const double* __restrict__ weights, double* __restrict__ bl, double* __restrict__ diff,
@@ -533,7 +541,7 @@ __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict_
   if ((threadIdx.x & 63) == 0) sh_resc[threadIdx.x >> 6] = resc;
   __syncthreads();
   double resc_total = 0;
-  for (int w = 0; w < kOptWaves; w++) resc_total += sh_resc[w];
+  for (int w = 0; w < (int)(blockDim.x >> 6); w++) resc_total += sh_resc[w];
   EdgeFunction f{coef, coef + Ppad, weights, sh, resc_total, P, cfg.trace_rows, cfg.trace_cursor, cfg.trace_capacity, (double)edge, 0};
   const double current = bl[edge];
   double result = current;
@@ -603,13 +611,14 @@ __device__ void OptimizeEdge(const bito_amd_gp_op& op, const double* __restrict_
 // One workgroup per optimisation of the launch.  The optimisations of a launch are independent of one another
 // (gp_schedule.hpp: equal optimiser depth, so no PLV or branch length one writes is read or written by another); each has
 // its own coefficient block.
-__global__ void __launch_bounds__(kOptThreads)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
 gp_optimize_kernel(const bito_amd_gp_op* __restrict__ ops, const double* __restrict__ plv,
                    const int* __restrict__ counts, const double* __restrict__ weights, double* __restrict__ bl,
                    double* __restrict__ diff, double* __restrict__ coef, int P, int Ppad, double log_threshold,
                    OptSettings cfg) {
-  __shared__ double sh[2 * 3 * kOptWaves];
-  __shared__ double sh_resc[kOptWaves];
+  __shared__ double sh[2 * 3 * kOptMaxWaves];
+  __shared__ double sh_resc[kOptMaxWaves];
   OptimizeEdge(ops[blockIdx.x], plv, counts, weights, bl, diff, coef + (size_t)blockIdx.x * 2 * Ppad, sh, sh_resc, P, Ppad,
                log_threshold, cfg);
 }
@@ -625,8 +634,8 @@ gp_block_stream_kernel(const bito_amd_gp_op* __restrict__ ops, const int64_t* __
                        double* __restrict__ ll, double* __restrict__ marginal, double* __restrict__ diff,
                        double* __restrict__ coef, int P, int Ppad, double threshold, double log_threshold,
                        OptSettings cfg) {
-  __shared__ double sh[2 * 3 * kOptWaves];
-  __shared__ double sh_resc[kOptWaves];
+  __shared__ double sh[2 * 3 * kOptMaxWaves];
+  __shared__ double sh_resc[kOptMaxWaves];
   const int64_t first = offsets[blockIdx.x], last = offsets[blockIdx.x + 1];
   double* my_coef = coef + (size_t)blockIdx.x * 2 * Ppad;
   for (int64_t o = first; o < last; o++) {
@@ -677,6 +686,7 @@ int bito_amd_gp_create(int32_t device_id, int32_t taxon_count, int32_t pattern_c
   e->device = device_id; e->n = taxon_count; e->P = pattern_count; e->Ppad = (pattern_count + 63) / 64 * 64;
   e->nodes = node_count; e->gpcsps = gpcsp_count; e->plvs = 6 * node_count;
   e->threshold = rescaling_threshold; e->log_threshold = std::log(rescaling_threshold);
+  if (const char* w = std::getenv("BITO_AMD_GP_OPT_WAVES")) e->opt_waves = std::atoi(w) == kOptMaxWaves ? kOptMaxWaves : kOptWaves;
   (void)hipSetDevice(device_id);
   const size_t plv_bytes = (size_t)e->plvs * 4 * e->Ppad * sizeof(double);
   bool ok = hipMalloc((void**)&e->plv, plv_bytes) == hipSuccess &&
@@ -1025,8 +1035,12 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
         break;
       case bito_amd_gp_schedule::kOptimisers:
         // DAGBranchHandler::OptimizeBranchLength for every edge of the launch, a workgroup each
-        hipLaunchKernelGGL(gp_optimize_kernel, dim3((unsigned)L.count), dim3(kOptThreads), 0, 0, d_ops + L.first, e->plv,
-                           e->counts, e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, Settings(e));
+        if (e->opt_waves == kOptMaxWaves)
+          hipLaunchKernelGGL(gp_optimize_kernel<64 * kOptMaxWaves>, dim3((unsigned)L.count), dim3(64 * kOptMaxWaves), 0, 0, d_ops + L.first,
+                             e->plv, e->counts, e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, Settings(e));
+        else
+          hipLaunchKernelGGL(gp_optimize_kernel<kOptThreads>, dim3((unsigned)L.count), dim3(kOptThreads), 0, 0, d_ops + L.first, e->plv,
+                             e->counts, e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, Settings(e));
         GP_TRY(e, hipGetLastError());
         break;
       default: {

@@ -12,6 +12,7 @@
 #   * walk_hbm_cat_kernel with four-tip subtrees rebuilt in the step  against  BITO_AMD_HBM_FOLD=1 (round 4's walk):
 #     config 4 and the 64 / 100 / 128-taxon sizes, with the FETCH_SIZE / WRITE_SIZE passes of both
 #   * small calls with set-up, step tables and images as one launch     against  BITO_AMD_SMALL_PREPARE=0 (three launches)
+#   * Path B with sixteen waves per optimiser workgroup (BITO_AMD_GP_OPT_WAVES=16)  against  four (the default)
 cd $GRAFT_REPO_ROOT
 T=${1:-r6}
 O=gpurun_out/$T
@@ -38,6 +39,19 @@ for fold in 2 1; do
   tail -c 500 $O/config4_fold${fold}_bench.json; echo
   BITO_AMD_HBM_FOLD=$fold timeout 600 python3 scripts/gpu_hbm_sizes.py 41 64 100 128 > $O/hbm_sizes_fold${fold}.log 2>&1; tail -6 $O/hbm_sizes_fold${fold}.log
   BITO_AMD_HBM_FOLD=$fold bash scripts/profile_config4.sh $T/config4_fold${fold} > $O/profile_config4_fold${fold}.log 2>&1; tail -4 $O/profile_config4_fold${fold}.log | cut -c1-400
+done
+step "Path B: sixteen waves per optimiser workgroup against four (the default)"
+for dag in ds1 seeded; do
+  BITO_AMD_GP_OPT_WAVES=16 timeout 400 python3 bench.py --workload gp --gp-dag $dag --steps 20 --warmup 3 --cpu-seconds 5 > $O/gp_${dag}_waves16_bench.json 2> $O/gp_${dag}_waves16_bench.err
+  python3 - <<PY
+import json
+for name in ("gp_${dag}_bench", "gp_${dag}_waves16_bench"):
+    try:
+        j = json.loads(open("$O/" + name + ".json").read().strip().splitlines()[-1])
+        print(name, "ms/step %.3f" % j["ms_per_step"], j["config"]["ms_by_schedule"], j.get("parity", {}).get("after_one_sweep", {}).get("max_d_branch_length"))
+    except Exception as err:
+        print(name, "no line:", err)
+PY
 done
 step "small calls: one set-up launch (default) against three"
 for fused in 1 0; do

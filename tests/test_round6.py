@@ -17,7 +17,10 @@ def small_call_results():
     """results of small blocking calls (1 to 100 trees of 6 to 45 taxa; the same rows twice, then other rows: the model
     of the call before copied, then set up afresh) by the fused launch and by the three-launch route"""
     out = {}
-    for n, P, T in ((6, 24, 1), (9, 70, 7), (12, 40, 8), (27, 60, 9), (33, 50, 17), (45, 40, 5), (27, 130, 100)):
+    shapes = [(6, 24, 1), (9, 70, 7), (12, 40, 8), (27, 60, 9), (33, 50, 17), (45, 40, 5)]
+    if "cpu-emulation" not in bito_amd.version():  # (a hundred trees as fibers take a minute: the device's case)
+        shapes.append((27, 130, 100))
+    for n, P, T in shapes:
         w = workloads.synthetic_gtr_weibull4(n, P, tree_count=T)
         w.rescaling = False
         for fused in (1, 0):
@@ -81,3 +84,38 @@ def test_hbm_walk_fold_levels_agree():
         assert _close(res[(2, True)][1], res[(fold, True)][1], 0.1 * GRAD_ATOL, 0.1 * GRAD_RTOL)
     # (the levels really differ in what they fold: the rescaled gradients carry another rounding)
     assert not np.array_equal(res[(2, True)][1], res[(1, True)][1]) and not np.array_equal(res[(1, True)][1], res[(0, True)][1])
+
+
+@pytest.mark.gpu
+def test_sixteen_waves_per_optimiser_workgroup(data_dir):
+    """BITO_AMD_GP_OPT_WAVES=16: gp_optimize_kernel with a pattern per thread at DS1's size (1024 threads; four waves is the
+    default) -- another summation order, the same bars: Brent visits the checker's points on fluA and on the DS1 ten-tree DAG
+    (tests/gp_trace.py) and ends at its lengths to 1e-8, Newton too; and a scheduled sweep is still bit for bit the sequential
+    one (both run the same kernel)."""
+    import gp_trace
+    import test_gp
+    from bito_amd import gp
+
+    sp, tree, flu = test_gp._flu(data_dir)
+    cases = [("fluA", sp, flu, flu.branch_lengths(np.full(tree.node_count, 0.01)))]
+    dag, sp2 = workloads.ds1_subsplit_dag(10)
+    cases.append(("DS1 DAG", sp2, dag, np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)))
+    with _Env(BITO_AMD_GP_OPT_WAVES=16):
+        for name, sp_, dag_, bl0 in cases:
+            cpu, bl_cpu = test_gp._traced_sweep(test_gp._oracle_factory, sp_, dag_, bl0, gp.BRENT)
+            gpu, bl_gpu = test_gp._traced_sweep(test_gp._gpu_factory, sp_, dag_, bl0, gp.BRENT)
+            problems, stats = gp_trace.compare(cpu, gpu)
+            assert not problems, (name, problems[:3], stats)
+            assert stats["ties"] == 0 and stats["compared"] == len(cpu) == len(gpu), (name, stats)
+            assert np.abs(bl_gpu - bl_cpu).max() < 1e-8, name
+            results = []
+            for factory in (test_gp._gpu_factory, test_gp._oracle_factory):
+                eng = factory(sp_, dag_)
+                eng.set_branch_lengths(bl0)
+                eng.set_optimization_method(gp.NEWTON)
+                eng.reset_optimization_count()
+                eng.process_operations(dag_.populate_plvs())
+                eng.process_operations(dag_.branch_length_optimization())
+                results.append(eng.get_branch_lengths())
+            assert np.abs(results[0] - results[1]).max() < 1e-8 * max(1.0, np.abs(results[1]).max()), name
+        test_gp._scheduled_and_sequential_sweeps_agree([(workloads.ds1_subsplit_dag(10), 1e-40)], (gp.BRENT, gp.NEWTON))
