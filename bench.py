@@ -410,6 +410,60 @@ def gp_workload(args):
     print(json.dumps(out), flush=True)
 
 
+def large_batch_child(args):
+    """`large_batch` of the ds1 line, in a process of its own (bench.py --large-batch-child): one engine, --large-batch x the
+    trees of `value` in ONE blocking gradients call, parameter rows changing every call; the first trees (those of `value`'s
+    batch) again in a call of their own.  Prints one JSON object."""
+    import bito_amd
+    from bito_amd import workloads
+
+    big = workloads.ds1_gtr_weibull4(args.replicas * args.large_batch)
+    T = 100 * args.replicas
+    Tb = big.tree_count
+    N = 2 * big.patterns.shape[0] - 1
+    eng = bito_amd.Engine(bito_amd.PhyloModelSpecification(big.substitution, big.site, big.clock), big.patterns, big.weights,
+                          device_id=int(os.environ.get("BENCH_CHILD_DEVICE", "0")),
+                          host_threads=int(os.environ.get("BENCH_CHILD_HOST_THREADS", "0")))
+    eng.set_kernel(args.kernel)
+    pid_b = np.ascontiguousarray(big.parent_ids, dtype=np.int32)
+    par_b = np.ascontiguousarray(big.params, dtype=np.float64)
+    par_sets_b = [par_b, workloads.other_bits(par_b, 4)]
+    bl_sets_b = [np.ascontiguousarray(big.branch_lengths, dtype=np.float64),
+                 np.ascontiguousarray(big.branch_lengths * 1.03125, dtype=np.float64)]
+    ll_b, grad_b = np.zeros(Tb), np.zeros((Tb, N))
+    for k in range(2):
+        eng.gradients_into(pid_b, bl_sets_b[k & 1], par_sets_b[k & 1], ll_b, grad_b)
+    eng.sync()
+    reps = max(2, min(args.steps, 5))
+    eng.kernel_timing(True)
+    b0 = time.perf_counter()
+    for k in range(reps):
+        eng.gradients_into(pid_b, bl_sets_b[k & 1], par_sets_b[k & 1], ll_b, grad_b)
+    eng.sync()
+    b_elapsed = time.perf_counter() - b0
+    b_kernel_ms, b_launches = eng.kernel_elapsed()
+    eng.kernel_timing(False)
+    ablation = bool(os.environ.get("BENCH_ABLATION"))
+    if not ablation and not (np.all(np.isfinite(ll_b)) and np.all(np.isfinite(grad_b))):
+        raise SystemExit("non-finite results in the large batch")
+    # (a tree's results depend on its batch only through the order of the pattern-tile sums: DESIGN.md section 3)
+    same = min(T, Tb)
+    ref_ll, ref_grad = np.zeros(same), np.zeros((same, N))
+    eng.gradients_into(np.ascontiguousarray(pid_b[:same]), np.ascontiguousarray(bl_sets_b[(reps - 1) & 1][:same]),
+                       np.ascontiguousarray(par_sets_b[(reps - 1) & 1][:same]), ref_ll, ref_grad)
+    large = {"trees": Tb, "calls": reps, "ms_per_call": b_elapsed / reps * 1e3, "trees_per_s": Tb * reps / b_elapsed,
+             "launches_per_step": b_launches / reps, "kernel_ms_per_call": b_kernel_ms / reps, "kernel": eng.kernel_name(),
+             "max_dll_against_the_same_trees_in_a_call_of_their_own": float(np.max(np.abs(ll_b[:same] - ref_ll) / (1.0 + 2e-4 * np.abs(ref_ll)))),
+             "max_dgrad_against_the_same_trees_in_a_call_of_their_own": float(np.max(np.abs(grad_b[:same] - ref_grad))),
+             "note": f"{args.large_batch} x the trees of `value` in one blocking call (parameter rows change every call), mean of "
+                     "the calls, in a process of its own; `value` stays the call BASELINE's metric is quoted on"}
+    if not ablation and (large["max_dll_against_the_same_trees_in_a_call_of_their_own"] > 1e-11 or
+                         large["max_dgrad_against_the_same_trees_in_a_call_of_their_own"] > 1e-7):
+        raise SystemExit(f"the large batch's trees differ from the same trees in a call of their own: {large}")
+    sys.stdout.flush()
+    print(json.dumps(large), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -434,6 +488,7 @@ def main():
     ap.add_argument("--large-batch", type=int, default=16,
                     help="ds1 workload: beside `value`, one blocking call of this many times its trees (16 x 6400 = 102 400 "
                          "trees, 60 ms and more per call) reported as `large_batch`; 0 = skip")
+    ap.add_argument("--large-batch-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="the timed region only: skip the small-collection calls and the second timed region (resident batch)")
@@ -454,6 +509,8 @@ def main():
 
     if args.workload == "gp":
         return gp_workload(args)
+    if args.large_batch_child:
+        return large_batch_child(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -681,49 +738,25 @@ def main():
                 into[str(count)] = (time.perf_counter() - s0) / reps * 1e3
 
     # the headline call at a device-filling size (calls of 50 ms and more): 16 x the trees of `value` in ONE
-    # blocking call, so that a driver's clock around the loop measures more than a 0.08 s region
+    # blocking call, so that a driver's clock around the loop measures more than a 0.08 s region.  In a process of its
+    # own: a batch sixteen times the largest the engine has run on a device must not be able to take this line with it
+    # (the sample is reported with whatever went wrong instead)
     large = None
     if args.workload == "ds1" and world == 1 and not args.no_resident and not args.resident_only and not slots and args.large_batch > 0:
-        big = workloads.ds1_gtr_weibull4(args.replicas * args.large_batch)
-        Tb = big.tree_count
-        pid_b = np.ascontiguousarray(big.parent_ids, dtype=np.int32)
-        par_b = np.ascontiguousarray(big.params, dtype=np.float64)
-        par_sets_b = [par_b, workloads.other_bits(par_b, rate_column)]
-        bl_sets_b = [np.ascontiguousarray(big.branch_lengths, dtype=np.float64),
-                     np.ascontiguousarray(big.branch_lengths * 1.03125, dtype=np.float64)]
-        ll_b, grad_b = np.zeros(Tb), np.zeros((Tb, N))
-        for k in range(2):
-            eng.gradients_into(pid_b, bl_sets_b[k & 1], par_sets_b[k & 1], ll_b, grad_b)
-        eng.sync()
-        reps = max(2, min(args.steps, 5))
-        eng.kernel_timing(True)
-        b0 = time.perf_counter()
-        for k in range(reps):
-            eng.gradients_into(pid_b, bl_sets_b[k & 1], par_sets_b[k & 1], ll_b, grad_b)
-        eng.sync()
-        b_elapsed = time.perf_counter() - b0
-        b_kernel_ms, b_launches = eng.kernel_elapsed()
-        eng.kernel_timing(False)
-        if not os.environ.get("BENCH_ABLATION") and not (np.all(np.isfinite(ll_b)) and np.all(np.isfinite(grad_b))):
-            raise SystemExit("non-finite results in the large batch")
-        # the first trees of the large collection are the trees of the timed batch: same inputs, same call
-        # (a tree's results depend on its batch only through the order of the pattern-tile sums: DESIGN.md section 3)
-        same = min(T, Tb)
-        ref_ll = np.zeros(same)
-        ref_grad = np.zeros((same, N))
-        eng.gradients_into(np.ascontiguousarray(pid_b[:same]), np.ascontiguousarray(bl_sets_b[(reps - 1) & 1][:same]),
-                           np.ascontiguousarray(par_sets_b[(reps - 1) & 1][:same]), ref_ll, ref_grad)
-        large = {"trees": Tb, "calls": reps, "ms_per_call": b_elapsed / reps * 1e3, "trees_per_s": Tb * reps / b_elapsed,
-                 "launches_per_step": b_launches / reps, "kernel_ms_per_call": b_kernel_ms / reps,
-                 "max_dll_against_the_same_trees_in_a_call_of_their_own": float(np.max(np.abs(ll_b[:same] - ref_ll) / (1.0 + 2e-4 * np.abs(ref_ll)))),
-                 "max_dgrad_against_the_same_trees_in_a_call_of_their_own": float(np.max(np.abs(grad_b[:same] - ref_grad))),
-                 "note": f"{args.large_batch} x the trees of `value` in one blocking call (parameter rows change every call), "
-                         "mean of the calls; `value` stays the call BASELINE's metric is quoted on"}
-        if not os.environ.get("BENCH_ABLATION") and (large["max_dll_against_the_same_trees_in_a_call_of_their_own"] > 1e-11 or
-                                                     large["max_dgrad_against_the_same_trees_in_a_call_of_their_own"] > 1e-7):
-            raise SystemExit(f"the large batch's trees differ from the same trees in a call of their own: {large}")
-        # (leave the engine as the timed loop left it)
-        eng.gradients_into(pid, w.last_branch_lengths, w.last_params, out_ll, out_grad, rescaling=w.rescaling)
+        import subprocess
+
+        # (BENCH_CHILD_CMD: scripts/bench_dry_run.py's interpreter line, whose child must see the same tiny workloads)
+        head = json.loads(os.environ["BENCH_CHILD_CMD"]) if os.environ.get("BENCH_CHILD_CMD") else [sys.executable, os.path.abspath(__file__)]
+        cmd = head + ["--large-batch-child", "--large-batch", str(args.large_batch),
+                      "--replicas", str(args.replicas), "--steps", str(args.steps), "--kernel", str(args.kernel)]
+        env = dict(os.environ, BENCH_CHILD_DEVICE=str(local_rank), BENCH_CHILD_HOST_THREADS=str(host_threads))
+        try:
+            done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            lines = [ln for ln in done.stdout.strip().splitlines() if ln.startswith("{")]
+            large = json.loads(lines[-1]) if done.returncode == 0 and lines else {
+                "error": f"exit code {done.returncode}: " + (done.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+        except (subprocess.TimeoutExpired, OSError, ValueError) as err:
+            large = {"error": repr(err)[:300]}
 
     # second timed region: the same passes over a batch that stays in HBM (no host arrays cross PCIe)
     resident = None

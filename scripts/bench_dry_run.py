@@ -56,7 +56,7 @@ real_codon = workloads.flua_codon
 workloads.flua_codon = lambda T=64, site="constant", seed=20240605: real_codon(min(T, 2), site, seed)
 real_synth = workloads.synthetic_gtr_weibull4
 workloads.synthetic_gtr_weibull4 = lambda n=1000, P=10000, tree_count=125, first_tree=0: real_synth(40, 130, min(tree_count, 3), first_tree)
-sys.argv = ["bench.py"] + {argv!r}
+sys.argv = ["bench.py"] + (sys.argv[1:] if len(sys.argv) > 1 else {argv!r})  # (arguments given: bench.py's own child)
 runpy.run_path(os.path.join({root!r}, "bench.py"), run_name="__main__")
 '''
 
@@ -74,7 +74,9 @@ def main():
     env = dict(os.environ, BITO_AMD_LIB=EMU)
     if force_dist:
         env["BENCH_FORCE_DIST"] = "1"
-    done = subprocess.run([sys.executable, "-c", BODY.format(root=ROOT, argv=argv)], capture_output=True, text=True, env=env)
+    body = BODY.format(root=ROOT, argv=argv)
+    env["BENCH_CHILD_CMD"] = json.dumps([sys.executable, "-c", body])  # (bench.py's large-batch child: the same tiny workloads)
+    done = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, env=env)
     if done.returncode != 0:
         sys.stderr.write(done.stdout[-2000:] + done.stderr[-4000:])
         raise SystemExit(f"bench.py {which}: exit code {done.returncode}")
