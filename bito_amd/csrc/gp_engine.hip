@@ -72,7 +72,7 @@ struct bito_amd_gp_engine {
   double* scratch = nullptr;
   double *diff = nullptr, *coef = nullptr;  // DAGBranchHandler differences_; per-pattern optimiser coefficients
   int method = 0, significant_digits = 10, optimization_count = 0;
-  int opt_waves = 4;  // waves per optimiser workgroup of the scheduled launches (BITO_AMD_GP_OPT_WAVES: 4 or 16)
+  int opt_waves = 4;  // waves per optimiser workgroup of the scheduled launches (BITO_AMD_GP_OPT_WAVES: 1, 2, 4, 8 or 16)
   int* counts = nullptr;
   bito_amd_gp_op* d_ops = nullptr;
   uint64_t* d_side = nullptr;
@@ -351,7 +351,8 @@ constexpr int kOptMaxIter = 1000;
 // Round 6: the number of waves is the LAUNCH's (blockDim.x / 64; scratch sized for sixteen).  Four is the default and the
 // only form a device has timed.  Sixteen -- a pattern per thread at DS1's size -- lost in round 4, when an evaluation was
 // two barriers and three cross-wave sums; since round 5 Brent's trial points are one barrier and one sum, and what that
-// changes only a device can say: BITO_AMD_GP_OPT_WAVES=16 (read when the engine is created) for scripts/gpu_round6.sh.
+// changes only a device can say: BITO_AMD_GP_OPT_WAVES = 1, 2, 8 or 16 (read when the engine is created; one wave: no
+// cross-wave sum at all) for scripts/gpu_round6.sh.
 // (The wave count is part of the summation order: other counts give other last bits, each held to the checker's bars.)
 constexpr int kOptWaves = 4, kOptThreads = 64 * kOptWaves, kOptMaxWaves = 16;
 
@@ -686,7 +687,10 @@ int bito_amd_gp_create(int32_t device_id, int32_t taxon_count, int32_t pattern_c
   e->device = device_id; e->n = taxon_count; e->P = pattern_count; e->Ppad = (pattern_count + 63) / 64 * 64;
   e->nodes = node_count; e->gpcsps = gpcsp_count; e->plvs = 6 * node_count;
   e->threshold = rescaling_threshold; e->log_threshold = std::log(rescaling_threshold);
-  if (const char* w = std::getenv("BITO_AMD_GP_OPT_WAVES")) e->opt_waves = std::atoi(w) == kOptMaxWaves ? kOptMaxWaves : kOptWaves;
+  if (const char* w = std::getenv("BITO_AMD_GP_OPT_WAVES")) {
+    const int v = std::atoi(w);
+    e->opt_waves = (v == 1 || v == 2 || v == 8 || v == 16) ? v : kOptWaves;
+  }
   (void)hipSetDevice(device_id);
   const size_t plv_bytes = (size_t)e->plvs * 4 * e->Ppad * sizeof(double);
   bool ok = hipMalloc((void**)&e->plv, plv_bytes) == hipSuccess &&
@@ -1035,12 +1039,17 @@ int bito_amd_gp_process_operations(bito_amd_gp_engine* e, const bito_amd_gp_op* 
         break;
       case bito_amd_gp_schedule::kOptimisers:
         // DAGBranchHandler::OptimizeBranchLength for every edge of the launch, a workgroup each
-        if (e->opt_waves == kOptMaxWaves)
-          hipLaunchKernelGGL(gp_optimize_kernel<64 * kOptMaxWaves>, dim3((unsigned)L.count), dim3(64 * kOptMaxWaves), 0, 0, d_ops + L.first,
-                             e->plv, e->counts, e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, Settings(e));
-        else
-          hipLaunchKernelGGL(gp_optimize_kernel<kOptThreads>, dim3((unsigned)L.count), dim3(kOptThreads), 0, 0, d_ops + L.first, e->plv,
-                             e->counts, e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, Settings(e));
+#define BITO_GP_OPT(THREADS)                                                                                              \
+  hipLaunchKernelGGL(gp_optimize_kernel<THREADS>, dim3((unsigned)L.count), dim3(THREADS), 0, 0, d_ops + L.first, e->plv, \
+                     e->counts, e->weights, e->bl, e->diff, e->coef, e->P, e->Ppad, e->log_threshold, Settings(e))
+        switch (e->opt_waves) {
+          case 1: BITO_GP_OPT(64); break;
+          case 2: BITO_GP_OPT(128); break;
+          case 8: BITO_GP_OPT(512); break;
+          case 16: BITO_GP_OPT(1024); break;
+          default: BITO_GP_OPT(kOptThreads); break;
+        }
+#undef BITO_GP_OPT
         GP_TRY(e, hipGetLastError());
         break;
       default: {

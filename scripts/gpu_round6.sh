@@ -40,12 +40,14 @@ for fold in 2 1; do
   BITO_AMD_HBM_FOLD=$fold timeout 600 python3 scripts/gpu_hbm_sizes.py 41 64 100 128 > $O/hbm_sizes_fold${fold}.log 2>&1; tail -6 $O/hbm_sizes_fold${fold}.log
   BITO_AMD_HBM_FOLD=$fold bash scripts/profile_config4.sh $T/config4_fold${fold} > $O/profile_config4_fold${fold}.log 2>&1; tail -4 $O/profile_config4_fold${fold}.log | cut -c1-400
 done
-step "Path B: sixteen waves per optimiser workgroup against four (the default)"
+step "Path B: one, two, eight and sixteen waves per optimiser workgroup against four (the default)"
 for dag in ds1 seeded; do
-  BITO_AMD_GP_OPT_WAVES=16 timeout 400 python3 bench.py --workload gp --gp-dag $dag --steps 20 --warmup 3 --cpu-seconds 5 > $O/gp_${dag}_waves16_bench.json 2> $O/gp_${dag}_waves16_bench.err
+  for waves in 1 2 8 16; do
+    BITO_AMD_GP_OPT_WAVES=$waves timeout 400 python3 bench.py --workload gp --gp-dag $dag --steps 20 --warmup 3 --cpu-seconds 3 > $O/gp_${dag}_waves${waves}_bench.json 2> $O/gp_${dag}_waves${waves}_bench.err
+  done
   python3 - <<PY
 import json
-for name in ("gp_${dag}_bench", "gp_${dag}_waves16_bench"):
+for name in ("gp_${dag}_bench", "gp_${dag}_waves1_bench", "gp_${dag}_waves2_bench", "gp_${dag}_waves8_bench", "gp_${dag}_waves16_bench"):
     try:
         j = json.loads(open("$O/" + name + ".json").read().strip().splitlines()[-1])
         print(name, "ms/step %.3f" % j["ms_per_step"], j["config"]["ms_by_schedule"], j.get("parity", {}).get("after_one_sweep", {}).get("max_d_branch_length"))

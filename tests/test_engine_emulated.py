@@ -486,4 +486,4 @@ def test_emulated_round6_gpu_tests_as_they_are(emulated):
     launch give the three-launch route's bits; the HBM-arena walk with four-tip subtrees folded against the checker at
     41, 65 and 100 taxa."""
     out = run_gpu_tests_emulated(["tests/test_round6.py"], timeout=2400)
-    assert "6 passed" in out, out[-600:]
+    assert "7 passed" in out, out[-600:]

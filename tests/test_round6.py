@@ -87,9 +87,10 @@ def test_hbm_walk_fold_levels_agree():
 
 
 @pytest.mark.gpu
-def test_sixteen_waves_per_optimiser_workgroup(data_dir):
-    """BITO_AMD_GP_OPT_WAVES=16: gp_optimize_kernel with a pattern per thread at DS1's size (1024 threads; four waves is the
-    default) -- another summation order, the same bars: Brent visits the checker's points on fluA and on the DS1 ten-tree DAG
+@pytest.mark.parametrize("waves", [16, 1])
+def test_other_wave_counts_of_the_optimiser_workgroup(data_dir, waves):
+    """BITO_AMD_GP_OPT_WAVES = 16 (gp_optimize_kernel with a pattern per thread at DS1's size) and 1 (no cross-wave sum at
+    all); four waves is the default -- another summation order, the same bars: Brent visits the checker's points on fluA and on the DS1 ten-tree DAG
     (tests/gp_trace.py) and ends at its lengths to 1e-8, Newton too; and a scheduled sweep is still bit for bit the sequential
     one (both run the same kernel)."""
     import gp_trace
@@ -100,7 +101,7 @@ def test_sixteen_waves_per_optimiser_workgroup(data_dir):
     cases = [("fluA", sp, flu, flu.branch_lengths(np.full(tree.node_count, 0.01)))]
     dag, sp2 = workloads.ds1_subsplit_dag(10)
     cases.append(("DS1 DAG", sp2, dag, np.random.default_rng(1).uniform(0.01, 0.2, dag.gpcsp_count)))
-    with _Env(BITO_AMD_GP_OPT_WAVES=16):
+    with _Env(BITO_AMD_GP_OPT_WAVES=waves):
         for name, sp_, dag_, bl0 in cases:
             cpu, bl_cpu = test_gp._traced_sweep(test_gp._oracle_factory, sp_, dag_, bl0, gp.BRENT)
             gpu, bl_gpu = test_gp._traced_sweep(test_gp._gpu_factory, sp_, dag_, bl0, gp.BRENT)
