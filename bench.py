@@ -519,6 +519,31 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
 
+    # The headline call at a device-filling size (calls of 50 ms and more): 16 x the trees of `value` in ONE
+    # blocking call, so that a driver's clock around the loop measures more than a 0.08 s region.  In a process of its
+    # own -- a batch sixteen times the largest the engine has run on a device must not be able to take this line with it
+    # (the sample is reported with whatever went wrong instead) -- and FIRST, before this process has touched the GPU:
+    # the child is over by the time anything here is timed, and no program is started from a process that holds a device.
+    large = None
+    if (args.workload == "ds1" and world == 1 and not args.no_resident and not args.resident_only and not args.engine_devices
+            and args.large_batch > 0):
+        import subprocess
+
+        from bito_amd.dist import host_threads_for_rank as _threads
+
+        # (BENCH_CHILD_CMD: scripts/bench_dry_run.py's interpreter line, whose child must see the same tiny workloads)
+        head = json.loads(os.environ["BENCH_CHILD_CMD"]) if os.environ.get("BENCH_CHILD_CMD") else [sys.executable, os.path.abspath(__file__)]
+        cmd = head + ["--large-batch-child", "--large-batch", str(args.large_batch),
+                      "--replicas", str(args.replicas), "--steps", str(args.steps), "--kernel", str(args.kernel)]
+        env = dict(os.environ, BENCH_CHILD_DEVICE=str(local_rank), BENCH_CHILD_HOST_THREADS=str(_threads()))
+        try:
+            done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            lines = [ln for ln in done.stdout.strip().splitlines() if ln.startswith("{")]
+            large = json.loads(lines[-1]) if done.returncode == 0 and lines else {
+                "error": f"exit code {done.returncode}: " + (done.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+        except (subprocess.TimeoutExpired, OSError, ValueError) as err:
+            large = {"error": repr(err)[:300]}
+
     import torch
 
     import bito_amd
@@ -736,27 +761,6 @@ def main():
                 for k in range(reps):
                     eng.gradients_into(pid_s, bl_s[k & 1], par_s[0 if fixed else k & 1], ll_s, grad_s)
                 into[str(count)] = (time.perf_counter() - s0) / reps * 1e3
-
-    # the headline call at a device-filling size (calls of 50 ms and more): 16 x the trees of `value` in ONE
-    # blocking call, so that a driver's clock around the loop measures more than a 0.08 s region.  In a process of its
-    # own: a batch sixteen times the largest the engine has run on a device must not be able to take this line with it
-    # (the sample is reported with whatever went wrong instead)
-    large = None
-    if args.workload == "ds1" and world == 1 and not args.no_resident and not args.resident_only and not slots and args.large_batch > 0:
-        import subprocess
-
-        # (BENCH_CHILD_CMD: scripts/bench_dry_run.py's interpreter line, whose child must see the same tiny workloads)
-        head = json.loads(os.environ["BENCH_CHILD_CMD"]) if os.environ.get("BENCH_CHILD_CMD") else [sys.executable, os.path.abspath(__file__)]
-        cmd = head + ["--large-batch-child", "--large-batch", str(args.large_batch),
-                      "--replicas", str(args.replicas), "--steps", str(args.steps), "--kernel", str(args.kernel)]
-        env = dict(os.environ, BENCH_CHILD_DEVICE=str(local_rank), BENCH_CHILD_HOST_THREADS=str(host_threads))
-        try:
-            done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-            lines = [ln for ln in done.stdout.strip().splitlines() if ln.startswith("{")]
-            large = json.loads(lines[-1]) if done.returncode == 0 and lines else {
-                "error": f"exit code {done.returncode}: " + (done.stderr.strip().splitlines() or ["no output"])[-1][:300]}
-        except (subprocess.TimeoutExpired, OSError, ValueError) as err:
-            large = {"error": repr(err)[:300]}
 
     # second timed region: the same passes over a batch that stays in HBM (no host arrays cross PCIe)
     resident = None
