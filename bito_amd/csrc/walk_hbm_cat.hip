@@ -95,13 +95,13 @@ inline int HbmCatTiles(int pattern_count) { return (pattern_count + kCatTile - 1
 // moves 1672 vectors per tree and pass, in this order 1478 (scripts/sim_hbm_traffic.py; the least possible, one store
 // and one load of every stored vector, is 1329).  Cherries are no steps of their own (rebuilt where they are used) and
 // do not appear in the order.
-// order[tree] = NI + 1 records of twelve int32: record 0 = {steps}, record 1 + k = step k = {node, child 0, child 1, node
+// order[tree] = NI + 1 records of sixteen int32: record 0 = {steps}, record 1 + k = step k = {node, child 0, child 1, node
 // of step k - 1 (the step that follows in the pre-order pass) | children of child 0, children of child 1 (-1, -1 under a
-// tip; a pitchfork: its tip, then its cherry) | the tips of a pitchfork child's cherry (else -1, -1)} -- everything a
-// step must know about the topology in scalar loads whose address does not depend on an earlier load (the child lists are
-// not read by the walk at all).  One workgroup per tree, the tree's tables in LDS
-// (25 bytes per internal node), one lane labels them, all write the records; trees too large for that are walked in
-// id order.
+// tip; a pitchfork: its tip, then its cherry) | the tips of a pitchfork child's cherry (else -1, -1) | the last two ids of a
+// four-tip child (ChildInfo below; round 6)} -- everything a step must know about the topology in scalar loads whose
+// address does not depend on an earlier load (the child lists are not read by the walk at all; the last quarter only by
+// the steps that have a four-tip child).  One workgroup per tree, the tree's tables in LDS (33 bytes per internal
+// node), one lane labels them, all write the records; trees too large for that are walked in id order.
 constexpr int kStepInts = 16;
 // Unstored nodes: cherries, and with `fold` PITCHFORKS -- a tip and a cherry under one node (a sixth of a random tree's
 // internal nodes) --, rebuilt from their tips' matrix rows where they are used, like cherries: no step, no cell traffic.
@@ -115,7 +115,7 @@ __device__ __forceinline__ bool IsFork(const int32_t* __restrict__ c, int n, int
 }
 // Round 6, fold level 2: the two shapes of a FOUR-tip subtree are rebuilt where they are used as well -- a CATERPILLAR
 // (a tip and a pitchfork under one node: 69 of a random 1000-taxon tree's 999 internal nodes) and TWIN cherries (two
-// cherries under one node: 32) -- stored vectors per tree 498 -> 397, vector transfers 1104 -> 879
+// cherries under one node: 32), one per step -- stored vectors per tree 498 -> 402, vector transfers 1104 -> 888
 // (scripts/sim_hbm_traffic.py).  A caterpillar is a pitchfork with one more tip on top: its pre-order part is one more
 // level (two edge sums, one transposed product) in front of the pitchfork's, with no more vectors live at a time.
 __device__ __forceinline__ bool IsCaterpillar(const int32_t* __restrict__ c, int n, int root, int v) {
