@@ -269,12 +269,13 @@ inline size_t HbmOrderLdsBytes(const BatchDims& d) {
 }
 size_t HbmOrderInts(const BatchDims& d) { return (size_t)d.tree_count * d.taxon_count * kStepInts; }
 
-// BITO_AMD_HBM_FOLD: 0 a step and a cell for every pitchfork; 1 pitchforks rebuilt where they are used (round 4); 2 (the
-// default since round 6) four-tip subtrees as well
+// BITO_AMD_HBM_FOLD: 0 a step and a cell for every pitchfork; 1 (the default) pitchforks rebuilt where they are used (round
+// 4); 2 four-tip subtrees as well (round 6: built and held to the checker without GPU access -- it becomes the default
+// when a device has run and timed it, scripts/gpu_round6.sh)
 // (read at every launch of the order kernel: a process may compare the levels)
 static int HbmFolds() {
   const char* e = getenv("BITO_AMD_HBM_FOLD");
-  return e ? std::max(0, std::min(2, atoi(e))) : 2;
+  return e ? std::max(0, std::min(2, atoi(e))) : 1;
 }
 
 void LaunchHbmOrder(const BatchDims& d, const DeviceBatch& b, hipStream_t stream) {

@@ -856,7 +856,8 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
       const bool busy = e->one_shot ? e->one_shot == 2
                                     : (!e->serial_setup && e->last_pass_done != nullptr && hipEventQuery(e->last_pass_done) == hipErrorNotReady);
       // a small batch on an idle engine: set-up, step tables and images as ONE launch (round 6; walk_pipe.hip,
-      // pipe_small_prepare_kernel -- the same functions, the same bits; BITO_AMD_SMALL_PREPARE=0: three launches)
+      // pipe_small_prepare_kernel -- the same functions, the same bits; BITO_AMD_SMALL_PREPARE=1, off by default until
+      // a device has run it)
       const bool fused_prepare = use_pipe && !busy && e->small_prepare && T <= 2048 && SetupReadsHostInputs(d, e->spec) &&
                                  PipeSmallPrepareApplies(d, e->spec);
       if (fused_prepare)

@@ -150,7 +150,7 @@ struct Worker {
   DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
   DeviceBuffer<uint8_t> pipe_done;   // per tree: its whole-tree unit wrote the final results itself (kernels.hpp: DeviceBatch::pipe_done)
   bool pipe_direct = true;           // (BITO_AMD_PIPE_DIRECT=0 when the worker is created: everything through the final-sums kernel)
-  bool small_prepare = true;  // a small batch on an idle engine: set-up + step tables + images as one launch
+  bool small_prepare = false;  // BITO_AMD_SMALL_PREPARE=1: a small batch on an idle engine gets set-up + step tables + images as ONE launch (round 6; off until a device has run it)
   // walk_pipe_kernel in two launches: the trees of the resident batch that keep few enough vectors for four
   // pattern groups per wave (class A), and the others (class B) -- one tree with few cherries would otherwise
   // halve the groups of the whole batch

@@ -9,9 +9,9 @@
 #   * gs_matrices_kernel with a column's list of Q in registers       against  -DGS_DP_COLUMN=0 (round 3's loop)
 #   * gs_eigen_kernel (scalar pair arithmetic, v_readlane, masked zeroing): 4096 trees with a (kappa, omega) row each,
 #     kernel stats -- round 4 measured 0.94 ms per distinct model
-#   * walk_hbm_cat_kernel with four-tip subtrees rebuilt in the step  against  BITO_AMD_HBM_FOLD=1 (round 4's walk):
+#   * walk_hbm_cat_kernel with four-tip subtrees rebuilt in the step (BITO_AMD_HBM_FOLD=2)  against  round 4's walk (the default):
 #     config 4 and the 64 / 100 / 128-taxon sizes, with the FETCH_SIZE / WRITE_SIZE passes of both
-#   * small calls with set-up, step tables and images as one launch     against  BITO_AMD_SMALL_PREPARE=0 (three launches)
+#   * small calls with set-up, step tables and images as one launch (BITO_AMD_SMALL_PREPARE=1)  against  three launches (the default)
 #   * Path B with sixteen waves per optimiser workgroup (BITO_AMD_GP_OPT_WAVES=16)  against  four (the default)
 cd $GRAFT_REPO_ROOT
 T=${1:-r6}
@@ -33,7 +33,7 @@ for K in 1 0; do
   grep -E "gs_eigen_kernel|gs_matrices_kernel|gs_walk_kernel|gs_model_kernel" $GRAFT_REPO_ROOT/$O/codon_models_${K}_stats/s_kernel_stats.csv | cut -c1-200
 done
 cd $GRAFT_REPO_ROOT
-step "config 4 and mid sizes: four-tip subtrees folded (default) against pitchforks only"
+step "config 4 and mid sizes: four-tip subtrees folded (BITO_AMD_HBM_FOLD=2) against pitchforks only (the default)"
 for fold in 2 1; do
   BITO_AMD_HBM_FOLD=$fold timeout 900 python3 bench.py --workload config4 --steps 6 --warmup 2 --no-cpu-baseline > $O/config4_fold${fold}_bench.json 2> $O/config4_fold${fold}_bench.err
   tail -c 500 $O/config4_fold${fold}_bench.json; echo
@@ -55,7 +55,7 @@ for name in ("gp_${dag}_bench", "gp_${dag}_waves1_bench", "gp_${dag}_waves2_benc
         print(name, "no line:", err)
 PY
 done
-step "small calls: one set-up launch (default) against three"
+step "small calls: one set-up launch (BITO_AMD_SMALL_PREPARE=1) against three (the default)"
 for fused in 1 0; do
   BITO_AMD_SMALL_PREPARE=$fused timeout 600 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --large-batch 0 > $O/small_calls_prepare${fused}_bench.json 2> $O/small_calls_prepare${fused}_bench.err
   python3 - <<PY

@@ -29,8 +29,9 @@ def data_dir():
 # under tests/hip_emu their small-shape variants are green (tests/test_gp_emulated.py, tests/test_engine_emulated.py),
 # while the full-size forms of four of them exceed the emulated run's time limit, profiles/r5_emulated/) go last -- a
 # failure there must not hide the results of everything else.  Round 6 (no GPU access either) adds tests/test_round6.py
-# and the kernels it changed: gs_eigen_kernel / gs_matrices_kernel (test_codon_fixtures.py, test_gpu_general.py), the
-# HBM-arena walk's four-tip steps.  Within a group the order is pytest's own.
+# -- the forms it built behind switches that are off by default (the HBM-arena walk's four-tip steps, the one-launch
+# set-up of small calls, other wave counts of the GP optimiser) -- and the codon kernels it changed in place:
+# gs_eigen_kernel / gs_matrices_kernel (test_codon_fixtures.py, test_gpu_general.py).  Within a group the order is pytest's own.
 RUN_LAST = ("test_round6.py", "test_codon_fixtures.py", "test_gpu_general.py", "test_round5_host.py", "test_gp.py", "test_gp_binding_client.py", "test_nni.py", "test_tp.py")
 
 
@@ -39,14 +40,3 @@ def pytest_collection_modifyitems(config, items):
     last = [it for it in items if os.path.basename(str(it.fspath)) in RUN_LAST]
     items[:] = first + last
 
-
-# What the device has run and what it has not.  Rounds 5 and 6 had no GPU access; round 6's two changes that sit under
-# nearly every test -- walk_hbm_cat_kernel's four-tip steps (BITO_AMD_HBM_FOLD=2, the default) and the one-launch set-up of
-# small calls (BITO_AMD_SMALL_PREPARE=1, the default) -- are switched back to the forms round 4's GPU runs checked for the
-# tests that come first, and run as the product ships them in the modules of RUN_LAST (tests/test_round6.py holds them to
-# the other forms and to the checker): a fault in them cannot hide, under the driver's -x, what was green before.
-@pytest.fixture(autouse=True)
-def _forms_the_device_has_run(request, monkeypatch):
-    if os.path.basename(str(request.node.fspath)) not in RUN_LAST and request.node.get_closest_marker("gpu") is not None:
-        monkeypatch.setenv("BITO_AMD_HBM_FOLD", "1")
-        monkeypatch.setenv("BITO_AMD_SMALL_PREPARE", "0")

@@ -2,9 +2,11 @@
 tests/test_engine_emulated.py runs these very functions on the emulated library).
 * small calls: tree set-up, step tables and matrix images as ONE launch (walk_pipe.hip, pipe_small_prepare_kernel) -- the
   same functions in the same order as the three-launch route: the same bits in every result;
-* walk_hbm_cat_kernel with four-tip subtrees rebuilt where they are used (BITO_AMD_HBM_FOLD=2, the default): against the CPU
-  checker on trees that hold every neighbour case is tests/test_engine_emulated.py's (an environment variable read once per
-  process); here the default level on mid-size trees against the checker."""
+* walk_hbm_cat_kernel with four-tip subtrees rebuilt where they are used (BITO_AMD_HBM_FOLD=2): against the CPU checker on
+  trees that hold every neighbour case is tests/test_engine_emulated.py's; here on mid-size trees against the checker, and
+  the three levels against one another;
+* other wave counts of the GP optimiser's workgroups (BITO_AMD_GP_OPT_WAVES).
+All three are switches that are OFF by default until a device has run them (scripts/gpu_round6.sh times them)."""
 import numpy as np
 import pytest
 
@@ -47,20 +49,21 @@ def test_small_calls_in_one_set_up_launch_give_the_three_launch_routes_bits():
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [41, 65, 100])
 def test_hbm_walk_with_four_tip_subtrees_folded_against_the_checker(n):
-    """the HBM-arena walk at its default fold level (four-tip subtrees rebuilt in their parents' steps), 20 trees x 300
-    patterns, with and without rescaling, against the CPU checker"""
+    """the HBM-arena walk at fold level 2 (four-tip subtrees rebuilt in their parents' steps), 20 trees x 300 patterns,
+    with and without rescaling, against the CPU checker"""
     from oracle import oracle
 
     w = workloads.synthetic_gtr_weibull4(n, 300, tree_count=20)
     eng = bito_amd.Engine(_spec(w), w.patterns, w.weights)
     eng.set_kernel(1)
     cpu = oracle.OracleEngine(w.substitution, w.site, w.clock, w.patterns, w.weights, 8)
-    for rescaling in (True, False):
-        out = eng.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
-        ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
-        assert eng.kernel_name().startswith("walk_hbm_cat")
-        assert _close(out["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL)
-        assert _close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
+    with _Env(BITO_AMD_HBM_FOLD=2):  # (read at every launch)
+        for rescaling in (True, False):
+            out = eng.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+            ref = cpu.gradients(w.parent_ids, w.branch_lengths, w.params, rescaling=rescaling)
+            assert eng.kernel_name().startswith("walk_hbm_cat")
+            assert _close(out["log_likelihood"], ref["log_likelihood"], LL_ATOL, LL_RTOL)
+            assert _close(out["branch_lengths"], ref["branch_lengths"], GRAD_ATOL, GRAD_RTOL)
 
 
 @pytest.mark.gpu
