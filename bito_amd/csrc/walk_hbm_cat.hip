@@ -100,7 +100,7 @@ inline int HbmCatTiles(int pattern_count) { return (pattern_count + kCatTile - 1
 // tip; a pitchfork: its tip, then its cherry) | the tips of a pitchfork child's cherry (else -1, -1) | the last two ids of a
 // four-tip child (ChildInfo below; round 6)} -- everything a step must know about the topology in scalar loads whose
 // address does not depend on an earlier load (the child lists are not read by the walk at all; the last quarter only by
-// the steps that have a four-tip child).  One workgroup per tree, the tree's tables in LDS (33 bytes per internal
+// the steps that have a four-tip child).  One workgroup per tree, the tree's tables in LDS (34 bytes per internal
 // node), one lane labels them, all write the records; trees too large for that are walked in id order.
 constexpr int kStepInts = 16;
 // Unstored nodes: cherries, and with `fold` PITCHFORKS -- a tip and a cherry under one node (a sixth of a random tree's
@@ -223,10 +223,13 @@ hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __r
   int32_t* at = start + NI;      // node of step k
   int32_t* par = at + NI;        // [n + NI] parent by node id
   int8_t* flip = reinterpret_cast<int8_t*>(par + n + NI);  // child 1's subtree is visited first
+  int8_t* unstored = flip + NI;  // the node has no step (told by all lanes at once: the labelling below is one lane's)
   for (int i = lane; i < 2 * NI; i += 64) c[i] = ch[i];
   __syncthreads();
   for (int i = lane; i < 2 * NI; i += 64) par[c[i]] = n + (i >> 1);
   if (lane == 0) par[root] = -1;
+  __syncthreads();
+  for (int v = lane; v < NI; v += 64) unstored[v] = IsUnstored(c, par, n, root, fold, n + v);
   __syncthreads();
   if (lane == 0) {
     for (int v = 0; v < NI; v++) {  // ids ascend from the tips to the root
@@ -234,7 +237,7 @@ hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __r
       const int s0 = c0 >= n ? size[c0 - n] : 0, s1 = c1 >= n ? size[c1 - n] : 0;
       const int a = s0 ? need[c0 - n] : 0, b = s1 ? need[c1 - n] : 0;
       flip[v] = b > a;  // the heavier subtree first (ties: id order)
-      if (IsUnstored(c, par, n, root, fold, n + v)) {
+      if (unstored[v]) {
         size[v] = 0;
         need[v] = 0;
       } else {
@@ -265,7 +268,7 @@ hbm_order_kernel(BatchDims d, const int32_t* __restrict__ children, int32_t* __r
 }
 
 inline size_t HbmOrderLdsBytes(const BatchDims& d) {
-  return (size_t)(d.taxon_count - 1) * (6 * sizeof(int32_t) + 1) + (size_t)(2 * d.taxon_count - 1) * sizeof(int32_t) + 16;
+  return (size_t)(d.taxon_count - 1) * (6 * sizeof(int32_t) + 2) + (size_t)(2 * d.taxon_count - 1) * sizeof(int32_t) + 16;
 }
 size_t HbmOrderInts(const BatchDims& d) { return (size_t)d.tree_count * d.taxon_count * kStepInts; }
 
