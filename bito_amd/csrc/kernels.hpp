@@ -206,6 +206,12 @@ void LaunchLdsSchedule(const BatchDims& d, const DeviceBatch& b, const LdsPlan& 
 void LaunchWalkLds(const BatchDims& d, const DeviceBatch& b, const LdsPlan& plan, int want_gradient, int want_site,
                    hipStream_t stream);
 
+// completion flag of a blocking call's chunk (pinned host memory), stored by the last workgroup that counts itself
+struct ReduceDone {
+  unsigned long long* flag = nullptr;
+  unsigned long long ticket = 0;
+  int* counter = nullptr;
+};
 // LDS-resident traversal with hand-scheduled loops (walk_pipe.hip): the mapping of walk_lds_kernel,
 // stored child MESSAGES instead of partials, both tree loops software-pipelined gfx950 assembly.
 // Images: [T][N-1][128] doubles ((P, P^T) per lane); step tables: [T][2][n+1][8] dwords in b.sched; the
@@ -227,6 +233,11 @@ struct PipeClass {
   int row_stride;          // partial rows per tree the reduction adds up
   int reserve_cus = 0;     // CUs this launch leaves free: a blocking call's next chunk has its set-up kernels to run
                            // while this traversal holds every other CU (engine.cpp)
+  // round 6 (BITO_AMD_PIPE_LAST_UNIT=1): a tree's LAST run-of-tiles unit forms its final sums, so that no final-sums
+  // launch follows the traversal -- a counter per tree (zero before the launch; the unit that finds it at runs - 1
+  // resets it), and the chunk's completion flag stored by the workgroup that finishes the launch's last tree
+  int* tree_units = nullptr;
+  ReduceDone done{};
 };
 size_t PipeScheduleInts(const BatchDims& d);
 size_t PipeMaskInts(const BatchDims& d, const LdsPlan& plan);
@@ -298,11 +309,6 @@ void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int c
 // done: when the sums are the last kernel of a blocking call's chunk and go straight to pinned host memory, the
 // workgroup that finishes last stores `ticket` to `flag` (pinned, polled by the host) behind everybody's results;
 // `counter` is a zeroed int in device memory that the kernel leaves zeroed.
-struct ReduceDone {
-  unsigned long long* flag = nullptr;
-  unsigned long long ticket = 0;
-  int* counter = nullptr;
-};
 void LaunchReduce(const BatchDims& d, const DeviceBatch& b, int tiles, int want_gradient,
                   hipStream_t stream, int grad_rows = 0, ReduceDone done = ReduceDone{}, const uint8_t* skip = nullptr,
                   int first_tree = 0);

@@ -900,6 +900,7 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
       ev1 = NextEvent(e);
       HIP_TRY(e, hipEventRecord(ev0, walk));
     }
+    bool last_unit = false;
     if (use_tree) LaunchWalkTree(d, b, tplan, want_gradient, walk);
     else if (use_pipe) {
       const int site = want_site && want_gradient && deriv_mode == 0;
@@ -908,13 +909,25 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
         HIP_TRY(e, e->pipe_done.Reserve((size_t)T));
         b.pipe_done = e->pipe_done.ptr;
       }
+      // (BITO_AMD_PIPE_LAST_UNIT=1: a one-class launch finishes every tree itself -- whole-tree units as ever, the others by
+      // the last of their runs of tiles -- and stores the chunk's completion flag: no final-sums launch behind it)
+      last_unit = e->pipe_last_unit && e->pipe_direct && !site && !two_classes;
+      PipeClass whole{T, nullptr, b.pipe_masks, grad_rows, e->reserve_cus};
+      if (last_unit) {
+        const size_t had = e->pipe_tree_units.capacity;
+        HIP_TRY(e, e->pipe_tree_units.Reserve((size_t)T));
+        if (e->pipe_tree_units.capacity != had)  // (the counters are zero between launches: each tree's last unit resets its own)
+          HIP_TRY(e, hipMemsetAsync(e->pipe_tree_units.ptr, 0, e->pipe_tree_units.capacity * sizeof(int32_t), walk));
+        whole.tree_units = e->pipe_tree_units.ptr;
+        whole.done = DoneByReduce(e);
+      }
       if (two_classes) {
         LaunchWalkPipe(d, b, split.plan_a, want_gradient, site, deriv_mode, walk,
                        PipeClass{split.count_a, e->pipe_order.ptr, reinterpret_cast<const uint32_t*>(e->pipe_masks_a.ptr), grad_rows, e->reserve_cus});
         LaunchWalkPipe(d, b, split.plan_b, want_gradient, site, deriv_mode, walk,
                        PipeClass{split.count_b, e->pipe_order.ptr + split.count_a, b.pipe_masks, grad_rows, e->reserve_cus});
       } else {
-        LaunchWalkPipe(d, b, plan, want_gradient, site, deriv_mode, walk, PipeClass{T, nullptr, b.pipe_masks, grad_rows, e->reserve_cus});
+        LaunchWalkPipe(d, b, plan, want_gradient, site, deriv_mode, walk, whole);
       }
     }
     else LaunchWalkLds(d, b, plan, want_gradient, want_site && want_gradient && deriv_mode == 0, walk);
@@ -933,8 +946,9 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
     // (walk_pipe_kernel's partial log-likelihoods are per run of tiles as well)
     // (one-class launches: the whole-tree units are trees 0 .. whole_trees-1, all written by the traversal)
     const int reduce_from = (use_pipe && b.pipe_done != nullptr && !two_classes) ? plan.whole_trees : 0;
-    LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, walk, grad_rows, DoneByReduce(e),
-                 use_pipe ? b.pipe_done : nullptr, reduce_from);
+    if (!last_unit)
+      LaunchReduce(d, b, use_pipe ? grad_rows : tiles, want_gradient, walk, grad_rows, DoneByReduce(e),
+                   use_pipe ? b.pipe_done : nullptr, reduce_from);
     if (inputs_event_due) HIP_TRY(e, hipEventRecord(e->ev_inputs, walk));  // (in line: the set-up ran on this stream)
     if (!bare) HIP_TRY(e, hipEventRecord(e->ev_walk_done[set], walk));
     e->last_pass_done = bare ? nullptr : e->ev_walk_done[set];
@@ -1078,6 +1092,7 @@ int WorkerCreate(int32_t device_id, uint64_t arena_bytes, const char* substituti
   if (const char* serial = std::getenv("BITO_AMD_SERIAL_SETUP")) e->serial_setup = std::atoi(serial);
   if (const char* direct = std::getenv("BITO_AMD_PIPE_DIRECT")) e->pipe_direct = std::atoi(direct) != 0;
   if (const char* fused = std::getenv("BITO_AMD_SMALL_PREPARE")) e->small_prepare = std::atoi(fused) != 0;
+  if (const char* last = std::getenv("BITO_AMD_PIPE_LAST_UNIT")) e->pipe_last_unit = std::atoi(last) != 0;
   if (const char* two = std::getenv("BITO_AMD_PIPE_TWO")) e->pipe_two = std::atoi(two);
   if (const char* fold = std::getenv("BITO_AMD_PIPE_FOLD")) e->pipe_fold = std::atoi(fold);
   for (int i = 0; i < Worker::kSets; i++) {

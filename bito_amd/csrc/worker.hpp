@@ -149,6 +149,8 @@ struct Worker {
   long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
   DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
   DeviceBuffer<uint8_t> pipe_done;   // per tree: its whole-tree unit wrote the final results itself (kernels.hpp: DeviceBatch::pipe_done)
+  DeviceBuffer<int32_t> pipe_tree_units;  // per tree: run-of-tiles units that have counted themselves (BITO_AMD_PIPE_LAST_UNIT=1; zero between launches)
+  bool pipe_last_unit = false;       // BITO_AMD_PIPE_LAST_UNIT=1: a tree's last unit forms its final sums, no final-sums launch (round 6; off until a device has run it)
   bool pipe_direct = true;           // (BITO_AMD_PIPE_DIRECT=0 when the worker is created: everything through the final-sums kernel)
   bool small_prepare = false;  // BITO_AMD_SMALL_PREPARE=1: a small batch on an idle engine gets set-up + step tables + images as ONE launch (round 6; off until a device has run it)
   // walk_pipe_kernel in two launches: the trees of the resident batch that keep few enough vectors for four
@@ -227,7 +229,7 @@ struct Worker {
     for (auto& r : out_ll_ring) r.Free(); model.Free(); gs_model.Free(); gs_model_index.Free(); sched.Free();
     tt_parents.Free(); tt_heights.Free(); tt_bounds.Free(); tt_ratios.Free(); tt_in.Free(); tt_work.Free();
     tt_out.Free(); tt_aux.Free();
-    children2.Free(); sched2.Free(); pipe_masks.Free(); pipe_queue.Free(); pipe_done.Free(); pipe_order.Free(); pipe_masks_a.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
+    children2.Free(); sched2.Free(); pipe_masks.Free(); pipe_queue.Free(); pipe_done.Free(); pipe_tree_units.Free(); pipe_order.Free(); pipe_masks_a.Free(); branch2.Free(); images2.Free(); model2.Free(); out_site.Free();
     children3.Free(); sched3.Free(); branch3.Free(); images3.Free(); model3.Free();
     for (int i = 0; i < kSets; i++) {
       if (ev_prep_done[i]) (void)hipEventDestroy(ev_prep_done[i]);

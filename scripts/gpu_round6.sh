@@ -11,7 +11,8 @@
 #     kernel stats -- round 4 measured 0.94 ms per distinct model
 #   * walk_hbm_cat_kernel with four-tip subtrees rebuilt in the step (BITO_AMD_HBM_FOLD=2)  against  round 4's walk (the default):
 #     config 4 and the 64 / 100 / 128-taxon sizes, with the FETCH_SIZE / WRITE_SIZE passes of both
-#   * small calls with set-up, step tables and images as one launch (BITO_AMD_SMALL_PREPARE=1)  against  three launches (the default)
+#   * small calls with set-up, step tables and images as one launch (BITO_AMD_SMALL_PREPARE=1) and a tree's final sums by its
+#     last run of tiles (BITO_AMD_PIPE_LAST_UNIT=1: two launches per small call in all)  against  the default's four
 #   * Path B with sixteen waves per optimiser workgroup (BITO_AMD_GP_OPT_WAVES=16)  against  four (the default)
 cd $GRAFT_REPO_ROOT
 T=${1:-r6}
@@ -55,14 +56,14 @@ for name in ("gp_${dag}_bench", "gp_${dag}_waves1_bench", "gp_${dag}_waves2_benc
         print(name, "no line:", err)
 PY
 done
-step "small calls: one set-up launch (BITO_AMD_SMALL_PREPARE=1) against three (the default)"
-for fused in 1 0; do
-  BITO_AMD_SMALL_PREPARE=$fused timeout 600 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --large-batch 0 > $O/small_calls_prepare${fused}_bench.json 2> $O/small_calls_prepare${fused}_bench.err
+step "small calls: one set-up launch (BITO_AMD_SMALL_PREPARE=1), no final-sums launch (BITO_AMD_PIPE_LAST_UNIT=1), both, neither (the default: four launches)"
+for fused in 11 10 01 00; do  # (set-up as one launch, final sums by a tree's last unit)
+  BITO_AMD_SMALL_PREPARE=${fused:0:1} BITO_AMD_PIPE_LAST_UNIT=${fused:1:1} timeout 600 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --large-batch 0 > $O/small_calls_prepare${fused}_bench.json 2> $O/small_calls_prepare${fused}_bench.err
   python3 - <<PY
 import json
 try:
     j = json.loads(open("$O/small_calls_prepare${fused}_bench.json").read().strip().splitlines()[-1])
-    print("BITO_AMD_SMALL_PREPARE=$fused", "value %.0f trees/s" % j["value"], "blocking_call_ms", j["blocking_call_ms"]["trees_per_call"], "cache hit", j["blocking_call_ms"]["trees_per_call_model_cache_hit"])
+    print("BITO_AMD_SMALL_PREPARE, BITO_AMD_PIPE_LAST_UNIT = $fused", "value %.0f trees/s" % j["value"], "blocking_call_ms", j["blocking_call_ms"]["trees_per_call"], "cache hit", j["blocking_call_ms"]["trees_per_call_model_cache_hit"])
 except Exception as err:
     print("no line:", err)
 PY

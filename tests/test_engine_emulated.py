@@ -483,9 +483,10 @@ os.makedirs(FOLD_DIR, exist_ok=True)
 
 def test_emulated_round6_gpu_tests_as_they_are(emulated):
     """tests/test_round6.py -m gpu, unchanged, under emulation: small calls whose set-up, step tables and images are one
-    launch give the three-launch route's bits; the HBM-arena walk with four-tip subtrees folded against the checker (41
+    launch give the three-launch route's bits, and a tree's last run of tiles forms its final sums as the final-sums kernel
+    would; the HBM-arena walk with four-tip subtrees folded against the checker (41
     taxa here) and its three fold levels against one another; sixteen waves per optimiser workgroup on the checker's
     iterates."""
-    out = run_gpu_tests_emulated(["tests/test_round6.py", "-k", "small_calls or fold_levels or (against_the_checker and 41) or (wave_counts and 16)"],
+    out = run_gpu_tests_emulated(["tests/test_round6.py", "-k", "small_calls or last_unit or fold_levels or (against_the_checker and 41) or (wave_counts and 16)"],
                                  timeout=2400)
-    assert "4 passed" in out, out[-600:]  # (the 65- and 100-taxon cases and one wave per optimiser: profiles/r6_cpu/)
+    assert "5 passed" in out, out[-600:]  # (the 65- and 100-taxon cases and one wave per optimiser: profiles/r6_cpu/)

@@ -5,8 +5,9 @@ tests/test_engine_emulated.py runs these very functions on the emulated library)
 * walk_hbm_cat_kernel with four-tip subtrees rebuilt where they are used (BITO_AMD_HBM_FOLD=2): against the CPU checker on
   trees that hold every neighbour case is tests/test_engine_emulated.py's; here on mid-size trees against the checker, and
   the three levels against one another;
-* other wave counts of the GP optimiser's workgroups (BITO_AMD_GP_OPT_WAVES).
-All three are switches that are OFF by default until a device has run them (scripts/gpu_round6.sh times them)."""
+* other wave counts of the GP optimiser's workgroups (BITO_AMD_GP_OPT_WAVES);
+* the final sums of a tree by the last of its runs of tiles (BITO_AMD_PIPE_LAST_UNIT=1): no final-sums launch.
+All of them are switches that are OFF by default until a device has run them (scripts/gpu_round6.sh times them)."""
 import numpy as np
 import pytest
 
@@ -123,3 +124,43 @@ def test_other_wave_counts_of_the_optimiser_workgroup(data_dir, waves):
                 results.append(eng.get_branch_lengths())
             assert np.abs(results[0] - results[1]).max() < 1e-8 * max(1.0, np.abs(results[1]).max()), name
         test_gp._scheduled_and_sequential_sweeps_agree([(workloads.ds1_subsplit_dag(10), 1e-40)], (gp.BRENT, gp.NEWTON))
+
+
+@pytest.mark.gpu
+def test_last_unit_of_a_tree_forms_its_final_sums():
+    """BITO_AMD_PIPE_LAST_UNIT=1: walk_pipe_kernel's run-of-tiles units count themselves per tree, and the one that counts last
+    forms the tree's final sums as reduce_tiles_kernel would (the same rows in the same order: the same bits) and, for a
+    blocking call, the workgroup that finishes the launch's last tree stores the completion flag -- no final-sums launch
+    behind the traversal.  Blocking calls and passes over a resident batch, batches that are all whole-tree units, all runs of
+    tiles, and both (BITO_AMD_PIPE_WHOLE_TREES), against the two-launch route bit for bit; a 2800-tree call in chunks."""
+    import os
+
+    res = {}
+    for last in (1, 0):
+        for n, P, T, whole in ((9, 70, 7, None), (12, 200, 8, 3), (27, 130, 9, 0), (33, 300, 5, 2), (45, 64, 6, None)):
+            w = workloads.synthetic_gtr_weibull4(n, P, tree_count=T)
+            w.rescaling = False
+            env = {"BITO_AMD_PIPE_LAST_UNIT": last}
+            if whole is not None:
+                env["BITO_AMD_PIPE_WHOLE_TREES"] = whole
+            with _Env(**env):
+                eng = bito_amd.Engine(_spec(w), w.patterns, w.weights)
+                for rep in range(2):
+                    r = eng.gradients(w.parent_ids, w.branch_lengths * (1 + 0.01 * rep), w.params)
+                    assert eng.kernel_name() == "walk_pipe_kernel"
+                    res[(n, rep, last)] = np.concatenate([r["log_likelihood"].ravel(), r["branch_lengths"].ravel()])
+                res[(n, "ll", last)] = eng.log_likelihoods(w.parent_ids, w.branch_lengths, w.params)
+                eng.upload(w.parent_ids, w.branch_lengths, w.params)
+                for _ in range(2):
+                    eng.run(True, False)
+                res[(n, "resident", last)] = np.concatenate([np.ravel(x) for x in eng.download() if x is not None])
+        if "cpu-emulation" not in bito_amd.version():  # (chunks on two workers, each with its own counters and flag)
+            big = workloads.ds1_gtr_weibull4(28)
+            with _Env(BITO_AMD_PIPE_LAST_UNIT=last):
+                eng = bito_amd.Engine(_spec(big), big.patterns, big.weights)
+                r = eng.gradients(big.parent_ids, big.branch_lengths, big.params)
+            res[("chunks", 0, last)] = np.concatenate([r["log_likelihood"].ravel(), r["branch_lengths"].ravel()])
+    for key, value in res.items():
+        if key[2] == 1:
+            other = res[key[:2] + (0,)]
+            assert np.all(np.isfinite(value)) and np.array_equal(value, other), (key, float(np.abs(value - other).max()))
