@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts/gpu_round6.sh [tag]      (on the GPU box through gpurun; about 45 minutes)
+# usage: scripts/gpu_round6.sh [tag] [all | r5 | r6]      (on the GPU box through gpurun; about 45 minutes a part)
 # Everything rounds 5 and 6 owe an MI355X in ONE lease, every step under its own timeout, every output kept under
 # gpurun_out/<tag>/ (a step that fails does not stop the next).  First what round 5 scripted (scripts/gpu_round5.sh: the
 # evidence run -- full -m gpu suite, smoke, the driver's bench command --, device Brent against the checker's iterates,
@@ -14,12 +14,16 @@
 #   * small calls with set-up, step tables and images as one launch (BITO_AMD_SMALL_PREPARE=1) and a tree's final sums by its
 #     last run of tiles (BITO_AMD_PIPE_LAST_UNIT=1: two launches per small call in all)  against  the default's four
 #   * Path B with sixteen waves per optimiser workgroup (BITO_AMD_GP_OPT_WAVES=16)  against  four (the default)
+# usage: scripts/gpu_round6.sh [tag] [all | r5 | r6]   -- two leases of about 45 minutes: `r5` (round 5's list: the evidence run
+# first) and `r6` (round 6's forms against what they replace); `all` runs one behind the other in one call
 cd $GRAFT_REPO_ROOT
 T=${1:-r6}
+PART=${2:-all}
 O=gpurun_out/$T
 mkdir -p $O
 step() { echo "=== $1 ($(date +%T))"; }
-bash scripts/gpu_round5.sh $T 2>&1 | tail -60
+if [ "$PART" != r6 ]; then bash scripts/gpu_round5.sh $T 2>&1 | tail -60; fi
+if [ "$PART" = r5 ]; then exit 0; fi
 step "codon: image kernel forms"
 bash scripts/build_gs_variants.sh dp_round3 "-DGS_DP_COLUMN=0" > $O/build_dp_round3.log 2>&1
 for lib in bito_amd/libbito_amd.so bito_amd/variants/dp_round3.so; do
