@@ -1,8 +1,9 @@
 """bench.py's control flow, end to end, WITHOUT a GPU: the emulated library (tests/hip_emu) in place of libbito_amd.so, the
 three torch.cuda calls bench.py makes turned into no-ops, and the workloads shrunk to a handful of tiny trees -- so that a
 slip in the bench script (a misspelt key, a wrong shape) is found on the CPU and not by the one GPU run a round may get.
-The numbers it prints mean nothing.  usage: python scripts/bench_dry_run.py [ds1 | ds1-dist | codon | config4 | gp | gp-seeded]   (ds1-dist: the summed-log-likelihood
-all-reduce of a multi-rank run, on a one-rank gloo group)"""
+The numbers it prints mean nothing.  usage: python scripts/bench_dry_run.py [ds1 | ds1-dist | ds1-2ranks | codon | config4 | gp | gp-seeded]   (ds1-dist: the
+summed-log-likelihood all-reduce of a multi-rank run, on a one-rank gloo group; ds1-2ranks: two processes under
+torch.distributed.run as the driver launches --gpus 2, gloo in RCCL's place)"""
 import json
 import os
 import subprocess
@@ -21,6 +22,8 @@ import torch
 torch.cuda.is_available = lambda: True
 torch.cuda.set_device = lambda d: None
 torch.cuda.synchronize = lambda *a: None
+if os.environ.get("BENCH_DRY_RUN_RANKS"):  # (two ranks under torch.distributed.run: the emulated runtime has one device)
+    os.environ["LOCAL_RANK"] = "0"
 if os.environ.get("BENCH_FORCE_DIST") == "1":
     # the multi-rank code path on one rank: a gloo group in place of RCCL, "cuda" tensors that stay on the host
     import torch.distributed as dist
@@ -63,8 +66,10 @@ runpy.run_path(os.path.join({root!r}, "bench.py"), run_name="__main__")
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "ds1"
-    force_dist = which.endswith("-dist")  # ds1-dist: BENCH_FORCE_DIST=1, the reduce path of a multi-rank run on one rank
-    which = which.replace("-dist", "")
+    # ds1-2ranks: bench.py as the driver launches it for --gpus 2 (torch.distributed.run, two processes), gloo in RCCL's place
+    two_ranks = which.endswith("-2ranks")
+    force_dist = which.endswith("-dist") or two_ranks  # ds1-dist: BENCH_FORCE_DIST=1, the reduce path of a multi-rank run on one rank
+    which = which.replace("-dist", "").replace("-2ranks", "")
     argv = {"ds1": ["--steps", "2", "--warmup", "1", "--replicas", "1", "--cpu-seconds", "2"],
             "codon": ["--workload", "codon", "--trees", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
             "config4": ["--workload", "config4", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
@@ -74,19 +79,38 @@ def main():
     env = dict(os.environ, BITO_AMD_LIB=EMU)
     if force_dist:
         env["BENCH_FORCE_DIST"] = "1"
+    if two_ranks:
+        argv = ["--gpus", "2"] + argv
     body = BODY.format(root=ROOT, argv=argv)
     env["BENCH_CHILD_CMD"] = json.dumps([sys.executable, "-c", body])  # (bench.py's large-batch child: the same tiny workloads)
-    done = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, env=env)
+    if two_ranks:
+        import tempfile
+
+        env["BENCH_DRY_RUN_RANKS"] = "2"
+        with tempfile.NamedTemporaryFile("w", suffix="_bench_dry_run.py", delete=False) as fh:
+            fh.write(body)
+        try:
+            done = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                   "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29553"), fh.name],
+                                  capture_output=True, text=True, env=env)
+        finally:
+            os.unlink(fh.name)
+    else:
+        done = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, env=env)
     if done.returncode != 0:
         sys.stderr.write(done.stdout[-2000:] + done.stderr[-4000:])
         raise SystemExit(f"bench.py {which}: exit code {done.returncode}")
-    line = json.loads(done.stdout.strip().splitlines()[-1])
+    line = json.loads([ln for ln in done.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    if two_ranks:
+        assert line["n_gpus"] == 2 and "summed_log_likelihood" in line["config"], line["config"]
     keys = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
             "data", "config", "roofline", "cpu_baseline", "parity", "model_cache_hit", "resident"]
     if which.startswith("gp"):
         keys = [k for k in keys if k not in ("model_cache_hit", "resident")]
     if which == "ds1" and not force_dist:
         keys.append("large_batch")
+    if two_ranks:  # (the CPU baseline is rank 0's at N = 1 only)
+        keys.remove("cpu_baseline")
     missing = [k for k in keys if k not in line]
     print(f"bench.py {which}: one JSON line, {len(line)} keys; missing {missing}; parity {line.get('parity')}")
     print("   large_batch", line.get("large_batch"))
