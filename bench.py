@@ -337,7 +337,9 @@ def gp_workload(args):
         "config": {"workload": f"Path B: subsplit DAG of {'the ten DS1 golden trees' if args.gp_dag == 'ds1' else '20 seeded random topologies over the DS1 taxa'}"
                                f" ({dag.node_count} nodes, {dag.gpcsp_count} edges, 27 taxa, {P} patterns, JC69), branch lengths U(0.01, 0.2) set every step",
                    "operations_per_step": op_total, "operations_by_kind": kinds, "ms_by_schedule": parts,
-                   "multi_gpu": "one DAG is one shared structure: replicas only (SURVEY.md 8e)"},
+                   "multi_gpu": "one DAG is one shared structure: replicas only (SURVEY.md 8e)",
+                   **({"switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("BITO_AMD_") and k != "BITO_AMD_LIB"}}
+                      if any(k.startswith("BITO_AMD_") and k != "BITO_AMD_LIB" for k in os.environ) else {})},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "numerator": "op-by-op bytes of the step's operations (PLVs read + written, 4 x P doubles + P counts each)",
@@ -881,6 +883,9 @@ def main():
             out["distinct_models"] = distinct
         if codon:
             out["config"]["distinct_models_in_value"] = int(len(np.unique(params, axis=0)))
+        switches = {k: v for k, v in sorted(os.environ.items()) if k.startswith("BITO_AMD_") and k != "BITO_AMD_LIB"}
+        if switches:  # (an A/B line says which of the library's switches it ran with: scripts/README.md lists them)
+            out["config"]["switches"] = switches
         out["config"]["parameter_rows"] = "two sets take turns step by step (they differ in the last bit of one rate): no step finds the models of the step before"
         if resident is not None:
             out["resident"] = resident
