@@ -76,6 +76,8 @@ struct DeviceBatch {
   int32_t* pipe_queue;        // [2] next unit of work, workgroups that have left (walk_pipe_kernel; zero between launches)
   uint8_t* pipe_done;         // [T] or null: walk_pipe_kernel's whole-tree units write their tree's final results themselves
                               //     (out_ll, out_grad) and set the tree's flag; the final-sums kernel leaves those trees alone
+  int hbm_fold;               // what walk_hbm_cat_kernel rebuilds where it is used (HbmFoldLevel() when the pass's step records
+                              // were written: the walk that reads them must be the one they were written for)
   // traversal scratch + outputs
   double* arena;              // [chunk][n-1][C][4][Ppad]
   double* scale_arena;        // [chunk][n-1][Ppad]  post-order 1/scale factors (rescaled gradients)
@@ -302,6 +304,8 @@ void LaunchSiteFromCategoryRows(const BatchDims& d, const DeviceBatch& b, int ro
 // the order in which walk_hbm_cat_kernel takes a tree's internal nodes, as step records in b.sched (HbmOrderInts int32)
 size_t HbmOrderInts(const BatchDims& d);
 void LaunchHbmOrder(const BatchDims& d, const DeviceBatch& b, hipStream_t stream);
+// BITO_AMD_HBM_FOLD, read now: 0 cherries only, 1 (default) pitchforks as well, 2 four-tip subtrees too (walk_hbm_cat.hip)
+int HbmFoldLevel();
 void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int chunk_trees, int want_gradient,
                       int rescaling, int deriv_mode, hipStream_t stream);
 

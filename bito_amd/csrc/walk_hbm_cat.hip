@@ -275,8 +275,9 @@ size_t HbmOrderInts(const BatchDims& d) { return (size_t)d.tree_count * d.taxon_
 // BITO_AMD_HBM_FOLD: 0 a step and a cell for every pitchfork; 1 (the default) pitchforks rebuilt where they are used (round
 // 4); 2 four-tip subtrees as well (round 6: built and held to the checker without GPU access -- it becomes the default
 // when a device has run and timed it, scripts/gpu_round6.sh)
-// (read at every launch of the order kernel: a process may compare the levels)
-static int HbmFolds() {
+// (read once per pass by the worker, which hands the level to the order kernel's launch and to the walk's through
+// DeviceBatch::hbm_fold: a process may compare the levels, and the walk is always the one its records were written for)
+int HbmFoldLevel() {
   const char* e = getenv("BITO_AMD_HBM_FOLD");
   return e ? std::max(0, std::min(2, atoi(e))) : 1;
 }
@@ -286,7 +287,7 @@ void LaunchHbmOrder(const BatchDims& d, const DeviceBatch& b, hipStream_t stream
   const bool in_lds = lds <= 150 * 1024;
   if (in_lds && lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hbm_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(hbm_order_kernel, dim3(d.tree_count), dim3(64), in_lds ? lds : 0, stream, d, b.children, b.sched, in_lds ? 1 : 0, HbmFolds());
+  hipLaunchKernelGGL(hbm_order_kernel, dim3(d.tree_count), dim3(64), in_lds ? lds : 0, stream, d, b.children, b.sched, in_lds ? 1 : 0, b.hbm_fold);
 }
 
 #ifndef HBM_CAT_WAVES
@@ -384,7 +385,10 @@ __device__ __forceinline__ void ScalePow2(double v[4], int& exponent_sum) {
   exponent_sum += ex;
 }
 
-template <bool GRAD, bool RESCALE>
+// FOUR: the walk for step records of fold level 2 (four-tip children: the code of the two shapes in a step's first slot,
+// and with it the column addresses formed at their uses and gw parked in LDS -- what it takes to stay at 72 registers).
+// FOUR = false is the walk of levels 0 and 1 as round 4's device runs had it: none of that in its step.
+template <bool GRAD, bool RESCALE, bool FOUR>
 __global__ void __launch_bounds__(256, HBM_CAT_WAVES)
 walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children, const int32_t* __restrict__ order,
                     const double* __restrict__ all_mats, const TreeModel* __restrict__ models,
@@ -442,7 +446,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     Child ci{0, a, b, hb, hc, 0};
     if (cc < n) {
       ci.st = tip_state(cc);
-    } else if (hb < -1) {
+    } else if (FOUR && hb < -1) {
       ci.kind = a < n ? 4 : 5;
       ci.hb = -2 - hb;
     } else if (hb >= 0) {
@@ -481,8 +485,16 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
     asm volatile("" : "+v"(l));
     return (c << 6) + l;
   };
-  auto Fwd = [&]() -> double* { return lds + 4 * Tid(); };
-  auto Pend = [&]() -> double* { return lds + 4 * threads + 4 * Tid(); };
+  double* const fwd_held = lds + 4 * tid;  // (FOUR = false: the two addresses held in registers, as rounds 3 to 5 had them)
+  double* const pend_held = lds + 4 * threads + 4 * tid;
+  auto Fwd = [&]() -> double* {
+    if constexpr (FOUR) return lds + 4 * Tid();
+    else return fwd_held;
+  };
+  auto Pend = [&]() -> double* {
+    if constexpr (FOUR) return lds + 4 * threads + 4 * Tid();
+    else return pend_held;
+  };
   int pend_owner = -1;  // node whose vector `pend` holds (wave-uniform)
   int fwd_owner = -1;   // post-order only: node whose vector `fwd` holds
   bool fwd_younger = false;  // post-order, both columns taken: `fwd` holds the younger vector
@@ -510,7 +522,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       tip_row(ci.a, ci.st & 255, ra);
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = ra[i] * rb[i];
-    } else if (decltype(first)::value && ci.kind == 4) {  // a caterpillar's partial: a_tip . P_F (a_b . P_H (a_c . a_d))
+    } else if (FOUR && decltype(first)::value && ci.kind == 4) {  // a caterpillar's partial: a_tip . P_F (a_b . P_H (a_c . a_d))
       double ra[4], rb[4];
       int tx, ty;
       last_ids(tx, ty);
@@ -526,7 +538,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       tip_row(ci.a, tip_state(ci.a), ra);
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = ra[i] * rb[i];
-    } else if (decltype(first)::value && ci.kind == 5) {  // twin cherries: P_H1 (a_a . a_b) . P_H2 (a_c . a_d)
+    } else if (FOUR && decltype(first)::value && ci.kind == 5) {  // twin cherries: P_H1 (a_a . a_b) . P_H2 (a_c . a_d)
       double ra[4], rb[4], m[4];
       tip_row(ci.hb, tip_state(ci.hb), ra);
       tip_row(ci.hc, tip_state(ci.hc), rb);
@@ -694,8 +706,10 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
                               : weight * (tm->cat_weight[c] / __builtin_amdgcn_ldexp(total, shift)) * rate;
     // (gw waits in the thread's slot of `terms`, free since the categories met: read once per step, it is two registers
     // the walk does not carry through its longest stretches)
-    __syncthreads();  // (every wave has read the categories' terms)
-    terms[Tid()] = gw;
+    if constexpr (FOUR) {
+      __syncthreads();  // (every wave has read the categories' terms)
+      terms[Tid()] = gw;
+    }
     double* __restrict__ my_row = part_grad + (((size_t)tree * tile_count + tile_id) * C + c) * N;
     const double* __restrict__ Q = tm->Q;
     bool u_forwarded = false;
@@ -785,7 +799,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
         fork_edges(ci.a, ci.b, ci.hb, ci.hc, ci.st, q, rden);
         return;
       }
-      if (decltype(first)::value && ci.kind == 4) {
+      if (FOUR && decltype(first)::value && ci.kind == 4) {
         // caterpillar: tip a and pitchfork F = ci.b (tip ci.hb, cherry H = ci.hc with tips x, y) under cc.  With a_a the
         // tip's row and m = P_F (a_b . P_H (a_c . a_d)):
         //   edge of a:  sum_i (q . m)_i (Q a_a)_i      edge of F:  sum_i (q . a_a)_i (Q m)_i      partial of F:  P_F^T (q . a_a)
@@ -823,7 +837,7 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
         fork_edges(ci.hb, ci.hc, tx, ty, tip_state(ci.hb) | (tip_state(tx) << 8) | (tip_state(ty) << 16), t, rden);
         return;
       }
-      if (decltype(first)::value && ci.kind == 5) {
+      if (FOUR && decltype(first)::value && ci.kind == 5) {
         // twin cherries H1 = ci.a (tips hb, hc) and H2 = ci.b (tips x, y) under cc.  With m_k = P_Hk (the cherry's rows):
         //   edge of H1:  sum_i (q . m2)_i (Q m1)_i      edge of H2:  sum_i (q . m1)_i (Q m2)_i
         //   partial of H1:  P_H1^T (q . m2)             partial of H2:  P_H2^T (q . m1)
@@ -942,7 +956,8 @@ walk_hbm_cat_kernel(BatchDims d, int tree0, const int32_t* __restrict__ children
       // has underflowed (large tree, short branches: the slow categories go first) contributes its zero instead
       // of 0/0, while a pattern whose likelihood is zero still turns the tree's derivatives non-finite as the
       // reference's do.
-      double rden = terms[Tid()];  // = gw (parked above the loop)
+      double rden = gw;
+      if constexpr (FOUR) rden = terms[Tid()];  // (= gw, parked above the loop)
       if (RESCALE) {
         const double den = UA1[0] * A0[0] + UA1[1] * A0[1] + UA1[2] * A0[2] + UA1[3] * A0[3];
         double r = __builtin_amdgcn_rcp(den);
@@ -1016,10 +1031,15 @@ void LaunchWalkHbmCat(const BatchDims& d, const DeviceBatch& b, int tree0, int c
   const dim3 grid((unsigned)tiles * (unsigned)chunk), block(threads);
   const size_t lds = (size_t)threads * (8 * sizeof(double) + sizeof(double) + sizeof(int));
   static const int by_xcd = [] { const char* v = getenv("BITO_AMD_HBM_BY_XCD"); return v ? atoi(v) : 1; }();
-#define BITO_CAT(G, R) hipLaunchKernelGGL((walk_hbm_cat_kernel<G, R>), grid, block, lds, stream, d, tree0, b.children, b.sched, b.mats, b.model, \
-                                          b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad, deriv_mode, tiles, chunk, by_xcd)
-  if (want_gradient) { if (rescaling) BITO_CAT(true, true); else BITO_CAT(true, false); }
-  else { if (rescaling) BITO_CAT(false, true); else BITO_CAT(false, false); }
+#define BITO_CAT(G, R, F) hipLaunchKernelGGL((walk_hbm_cat_kernel<G, R, F>), grid, block, lds, stream, d, tree0, b.children, b.sched, b.mats, b.model, \
+                                             b.tip_states, b.weights, b.arena, b.part_ll, b.part_grad, deriv_mode, tiles, chunk, by_xcd)
+  if (b.hbm_fold >= 2) {  // (the step records hold four-tip children)
+    if (want_gradient) { if (rescaling) BITO_CAT(true, true, true); else BITO_CAT(true, false, true); }
+    else { if (rescaling) BITO_CAT(false, true, true); else BITO_CAT(false, false, true); }
+  } else {
+    if (want_gradient) { if (rescaling) BITO_CAT(true, true, false); else BITO_CAT(true, false, false); }
+    else { if (rescaling) BITO_CAT(false, true, false); else BITO_CAT(false, false, false); }
+  }
 #undef BITO_CAT
 }
 

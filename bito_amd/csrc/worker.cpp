@@ -489,6 +489,7 @@ void NoteModelCache(Worker* e, const DeviceBatch& b) {
 
 DeviceBatch MakeBatch(Worker* e, int set = 0) {
   DeviceBatch b{};
+  b.hbm_fold = e->hbm_fold_of_set[set];
   b.parent_ids = e->parent_ids.ptr;
   b.branch_in = e->branch_in.ptr;
   b.rates = e->has_rates ? e->rates.ptr : nullptr;
@@ -970,6 +971,9 @@ int RunResident(Worker* e, int want_gradient, int rescaling, int deriv_mode = 0,
   HIP_TRY(e, e->arena.Reserve(chunk * per_tree / sizeof(double)));
   if (want_gradient && rescaling)
     HIP_TRY(e, e->scale_arena.Reserve(chunk * (size_t)(d.taxon_count - 1) * d.pattern_stride));
+  // (the fold level of walk_hbm_cat_kernel is this pass's: its step records are written for it below, unless the pass
+  // re-uses the set's records -- serial_setup 2 -- and with them the level they were written for)
+  if (!(e->serial_setup == 2 && e->run_counter > (unsigned)Worker::kSets)) e->hbm_fold_of_set[set] = HbmFoldLevel();
   const DeviceBatch b = MakeBatch(e, set);
   const hipStream_t walk = WalkStream(e);
   e->last_walk = walk;

@@ -147,6 +147,7 @@ struct Worker {
   DeviceBuffer<int32_t> children, sched, children2, sched2, children3, sched3;
   DeviceBuffer<int32_t> pipe_masks;  // packed tip masks per pattern tile (walk_pipe_kernel): a function of the alignment and the plan
   long long pipe_masks_key = -1;     // groups | tiles << 8 the masks were built for
+  int hbm_fold_of_set[3] = {1, 1, 1};  // HbmFoldLevel() when a buffer set's step records were last written (walk_hbm_cat_kernel)
   DeviceBuffer<int32_t> pipe_queue;  // walk_pipe_kernel's unit queue (the kernel leaves it zeroed)
   DeviceBuffer<uint8_t> pipe_done;   // per tree: its whole-tree unit wrote the final results itself (kernels.hpp: DeviceBatch::pipe_done)
   DeviceBuffer<int32_t> pipe_tree_units;  // per tree: run-of-tiles units that have counted themselves (BITO_AMD_PIPE_LAST_UNIT=1; zero between launches)
