@@ -164,3 +164,17 @@ def test_last_unit_of_a_tree_forms_its_final_sums():
         if key[2] == 1:
             other = res[key[:2] + (0,)]
             assert np.all(np.isfinite(value)) and np.array_equal(value, other), (key, float(np.abs(value - other).max()))
+
+
+@pytest.mark.gpu
+def test_seeded_sweeps_with_round_6s_switches_on():
+    """scripts/gpu_fuzz.py (random shapes, models, rooted and unrooted, rescaling on and off, against the CPU checker) with
+    the forms round 6 built behind switches: the HBM-arena walk pinned with four-tip subtrees folded and trees of up to 333 taxa;
+    walk_pipe_kernel pinned with small calls set up in one launch and a tree's final sums formed by its last unit.  (The same
+    sweeps ran on the emulated library: profiles/r6_cpu/fuzz_*.log.)"""
+    from test_gpu_fuzz import _sweep
+
+    done, declined = _sweep("gpu_fuzz.py", 100, 6106, 1, env={"FUZZ_LARGE_TREES": "1", "BITO_AMD_HBM_FOLD": "2"})
+    assert done == 100 and declined == 0
+    done, declined = _sweep("gpu_fuzz.py", 100, 6107, 5, env={"BITO_AMD_SMALL_PREPARE": "1", "BITO_AMD_PIPE_LAST_UNIT": "1"})
+    assert done == 100 and declined < 100
